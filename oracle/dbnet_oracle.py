@@ -1,0 +1,396 @@
+"""CPU oracle for the DBNet hot path (TEST INFRASTRUCTURE — never on the product path).
+
+A from-scratch functional restatement, in plain CPU PyTorch fp32 ops, of the
+reference's model forward, loss stack and per-step update:
+
+  * model assembly / forward ........ /root/reference/src/models.py:34-48
+  * ResNet-18 stem + BasicBlock ..... /root/reference/src/modules/resnet.py:70-91,231-242
+  * ConvBnRelu ...................... /root/reference/src/modules/basic.py:32-36
+  * FPN neck ........................ /root/reference/src/modules/segmentation_body.py:64-87
+  * DBHead + step function .......... /root/reference/src/modules/segmentation_head.py:35-45,106-108
+  * OHEM-BCE / Dice / L1 / DBLoss ... /root/reference/src/losses.py:18-40,48-66,75-82,105-139
+  * step order + Adam ............... /root/reference/src/train.py:110-117,160-172
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this file, and only as the checker / reported baseline.  The product
+package `db_text_minimal_amd` must never import it.
+
+Pinning: the reference has no tests and no golden vectors, so the
+oracle is pinned against outputs of the reference itself, imported in the build
+container by `tests/golden/make_golden.py` (fixtures in `tests/golden/*.npz`,
+checked by `tests/test_oracle_golden.py`).
+
+The state is a flat dict keyed exactly like the reference's `state_dict()`
+(211 entries).  Nothing here reads /root/reference.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+K_STEP = 50.0  # segmentation_head.py:21
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# ----------------------------------------------------------------------------
+# state layout
+# ----------------------------------------------------------------------------
+
+
+def _bn_entries(prefix, c):
+    return [
+        (prefix + '.weight', (c, ), 'bn_w'),
+        (prefix + '.bias', (c, ), 'bn_b'),
+        (prefix + '.running_mean', (c, ), 'bn_rm'),
+        (prefix + '.running_var', (c, ), 'bn_rv'),
+        (prefix + '.num_batches_tracked', (), 'bn_nbt'),
+    ]
+
+
+def state_spec():
+    """[(key, shape, kind)] in the reference's state_dict order."""
+    s = []
+    s.append(('backbone.conv1.weight', (64, 3, 7, 7), 'conv_w'))
+    s += _bn_entries('backbone.bn1', 64)
+    inpl = 64
+    for li, planes in enumerate([64, 128, 256, 512], start=1):
+        for bi in range(2):
+            p = 'backbone.layer%d.%d' % (li, bi)
+            cin = inpl if bi == 0 else planes
+            s.append((p + '.conv1.weight', (planes, cin, 3, 3), 'conv_w'))
+            s += _bn_entries(p + '.bn1', planes)
+            s.append((p + '.conv2.weight', (planes, planes, 3, 3), 'conv_w'))
+            s += _bn_entries(p + '.bn2', planes)
+            if bi == 0 and li > 1:
+                s.append((p + '.downsample.0.weight', (planes, cin, 1, 1), 'conv_w'))
+                s += _bn_entries(p + '.downsample.1', planes)
+        inpl = planes
+    # dead parameters the reference constructs but never uses (resnet.py:192-195)
+    s.append(('backbone.fc.weight', (1000, 512), 'dead'))
+    s.append(('backbone.fc.bias', (1000, ), 'dead'))
+    s.append(('backbone.smooth.weight', (256, 2048, 1, 1), 'dead'))
+    s.append(('backbone.smooth.bias', (256, ), 'dead'))
+    b = 'segmentation_body.'
+    for name, cin in (('reduce_conv_c2', 64), ('reduce_conv_c3', 128), ('reduce_conv_c4', 256), ('reduce_conv_c5', 512)):
+        s.append((b + name + '.conv.weight', (64, cin, 1, 1), 'conv_w'))
+        s.append((b + name + '.conv.bias', (64, ), 'conv_b'))
+        s += _bn_entries(b + name + '.bn', 64)
+    for name in ('smooth_p4', 'smooth_p3', 'smooth_p2'):
+        s.append((b + name + '.conv.weight', (64, 64, 3, 3), 'conv_w'))
+        s.append((b + name + '.conv.bias', (64, ), 'conv_b'))
+        s += _bn_entries(b + name + '.bn', 64)
+    s.append((b + 'conv.0.weight', (256, 256, 3, 3), 'conv_w'))
+    s.append((b + 'conv.0.bias', (256, ), 'conv_b'))
+    s += _bn_entries(b + 'conv.1', 256)
+    h = 'segmentation_head.'
+    s.append((h + 'binarize.0.weight', (64, 256, 3, 3), 'conv_w'))
+    s.append((h + 'binarize.0.bias', (64, ), 'conv_b'))
+    s += _bn_entries(h + 'binarize.1', 64)
+    s.append((h + 'binarize.3.weight', (64, 64, 2, 2), 'convT_w'))
+    s.append((h + 'binarize.3.bias', (64, ), 'conv_b'))
+    s += _bn_entries(h + 'binarize.4', 64)
+    s.append((h + 'binarize.6.weight', (64, 1, 2, 2), 'convT_w'))
+    s.append((h + 'binarize.6.bias', (1, ), 'conv_b'))
+    s.append((h + 'thresh.0.weight', (64, 256, 3, 3), 'conv_w'))  # bias=False (segmentation_head.py:64-68)
+    s += _bn_entries(h + 'thresh.1', 64)
+    s.append((h + 'thresh.3.weight', (64, 64, 2, 2), 'convT_w'))
+    s.append((h + 'thresh.3.bias', (64, ), 'conv_b'))
+    s += _bn_entries(h + 'thresh.4', 64)
+    s.append((h + 'thresh.6.weight', (64, 1, 2, 2), 'convT_w'))
+    s.append((h + 'thresh.6.bias', (1, ), 'conv_b'))
+    return s
+
+
+def _key_seed(key, seed):
+    hsh = 1469598103934665603
+    for ch in key.encode():
+        hsh = ((hsh ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return (hsh ^ (seed * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF
+
+
+def procedural_fill(state, seed=0):
+    """Deterministic, per-key seeded fill (in place) of any dict keyed like the
+    reference state_dict.  Applied identically to the imported reference model
+    (when making goldens), to the oracle and to the HIP model, so no weights
+    have to be shipped.  Values have trained-net-like scales."""
+    kinds = {k: kind for k, _, kind in state_spec()}
+    for key, t in state.items():
+        kind = kinds[key]
+        g = torch.Generator().manual_seed(_key_seed(key, seed))
+        if kind == 'bn_nbt':
+            t.fill_(0)
+            continue
+        shape = tuple(t.shape)
+        if kind in ('conv_w', 'convT_w', 'dead'):
+            if len(shape) == 4:
+                fan = shape[1] * shape[2] * shape[3] if kind != 'convT_w' else shape[0] * shape[2] * shape[3] // 4
+            else:
+                fan = shape[-1]
+            v = torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan, 1))
+        elif kind == 'conv_b':
+            v = torch.randn(shape, generator=g) * 0.05
+        elif kind == 'bn_w':
+            v = 0.5 + torch.rand(shape, generator=g)
+        elif kind == 'bn_b':
+            v = torch.randn(shape, generator=g) * 0.1
+        elif kind == 'bn_rm':
+            v = torch.randn(shape, generator=g) * 0.1
+        elif kind == 'bn_rv':
+            v = 0.5 + torch.rand(shape, generator=g)
+        else:
+            raise KeyError(kind)
+        with torch.no_grad():
+            t.copy_(v.to(t.dtype))
+    return state
+
+
+def new_state(seed=0):
+    sd = OrderedDict()
+    for key, shape, kind in state_spec():
+        sd[key] = torch.zeros(shape, dtype=torch.int64 if kind == 'bn_nbt' else torch.float32)
+    return procedural_fill(sd, seed)
+
+
+def trainable_keys(include_dead=False):
+    out = []
+    for key, _, kind in state_spec():
+        if kind in ('bn_rm', 'bn_rv', 'bn_nbt'):
+            continue
+        if kind == 'dead' and not include_dead:
+            continue
+        out.append(key)
+    return out
+
+
+def synthetic_batch(n, size, seed=0, img_scale=1.0):
+    """Inputs of SURVEY.md §8c(2): img ~ N(0,1)·scale; binary masks like the real
+    loader (data_loaders.py:158-165); gts stacked in train.py:163-166 order."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(n, 3, size, size, generator=g) * img_scale
+    u = torch.rand(4, n, size, size, generator=g)
+    prob_gt = (u[0] > 0.9).float()
+    sup_mask = (u[1] > 0.05).float()
+    thresh_gt = 0.3 + 0.4 * u[2]
+    text_area = (u[3] > 0.8).float()
+    return img, torch.stack([prob_gt, sup_mask, thresh_gt, text_area])
+
+
+# ----------------------------------------------------------------------------
+# forward
+# ----------------------------------------------------------------------------
+
+
+def _bn(sd, prefix, x, training, update_stats):
+    w, b = sd[prefix + '.weight'], sd[prefix + '.bias']
+    rm, rv = sd[prefix + '.running_mean'], sd[prefix + '.running_var']
+    if not training:
+        return F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+    if update_stats:
+        y = F.batch_norm(x, rm, rv, w, b, True, BN_MOMENTUM, BN_EPS)
+        sd[prefix + '.num_batches_tracked'] += 1
+        return y
+    return F.batch_norm(x, None, None, w, b, True, BN_MOMENTUM, BN_EPS)
+
+
+def _basic_block(sd, p, x, stride, has_down, training, upd):
+    # resnet.py:70-91
+    out = F.conv2d(x, sd[p + '.conv1.weight'], None, stride, 1)
+    out = F.relu(_bn(sd, p + '.bn1', out, training, upd))
+    out = F.conv2d(out, sd[p + '.conv2.weight'], None, 1, 1)
+    out = _bn(sd, p + '.bn2', out, training, upd)
+    if has_down:
+        res = F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride, 0)
+        res = _bn(sd, p + '.downsample.1', res, training, upd)
+    else:
+        res = x
+    return F.relu(out + res)
+
+
+def _cbr(sd, p, x, pad, training, upd):
+    # basic.py:32-36
+    y = F.conv2d(x, sd[p + '.conv.weight'], sd[p + '.conv.bias'], 1, pad)
+    return F.relu(_bn(sd, p + '.bn', y, training, upd))
+
+
+def _nearest(x, size):
+    return F.interpolate(x, size=size)  # default mode='nearest' (segmentation_body.py:79-87)
+
+
+def _head_branch(sd, p, x, training, upd, has_bias0):
+    # segmentation_head.py:24-29 / 64-79
+    y = F.conv2d(x, sd[p + '.0.weight'], sd[p + '.0.bias'] if has_bias0 else None, 1, 1)
+    y = F.relu(_bn(sd, p + '.1', y, training, upd))
+    y = F.conv_transpose2d(y, sd[p + '.3.weight'], sd[p + '.3.bias'], 2)
+    y = F.relu(_bn(sd, p + '.4', y, training, upd))
+    y = F.conv_transpose2d(y, sd[p + '.6.weight'], sd[p + '.6.bias'], 2)
+    return torch.sigmoid(y)
+
+
+def forward(sd, x, training=True, update_stats=True, taps=None):
+    """DBTextModel.forward (models.py:34-48).  `taps`, if a dict, receives the
+    intermediate feature maps (NCHW) by name."""
+    H, W = x.shape[2], x.shape[3]
+    upd = update_stats
+    t = taps if taps is not None else {}
+    # stem (resnet.py:231-235)
+    y = F.conv2d(x, sd['backbone.conv1.weight'], None, 2, 3)
+    y = F.relu(_bn(sd, 'backbone.bn1', y, training, upd))
+    y = F.max_pool2d(y, 3, 2, 1)
+    t['pool'] = y
+    feats = []
+    for li in range(1, 5):
+        y = _basic_block(sd, 'backbone.layer%d.0' % li, y, 1 if li == 1 else 2, li > 1, training, upd)
+        y = _basic_block(sd, 'backbone.layer%d.1' % li, y, 1, False, training, upd)
+        feats.append(y)
+        t['c%d' % (li + 1)] = y
+    c2, c3, c4, c5 = feats
+    b = 'segmentation_body.'
+    # FPN (segmentation_body.py:64-77)
+    p5 = _cbr(sd, b + 'reduce_conv_c5', c5, 0, training, upd)
+    p4 = _nearest(p5, c4.shape[2:]) + _cbr(sd, b + 'reduce_conv_c4', c4, 0, training, upd)
+    p4 = _cbr(sd, b + 'smooth_p4', p4, 1, training, upd)
+    p3 = _nearest(p4, c3.shape[2:]) + _cbr(sd, b + 'reduce_conv_c3', c3, 0, training, upd)
+    p3 = _cbr(sd, b + 'smooth_p3', p3, 1, training, upd)
+    p2 = _nearest(p3, c2.shape[2:]) + _cbr(sd, b + 'reduce_conv_c2', c2, 0, training, upd)
+    p2 = _cbr(sd, b + 'smooth_p2', p2, 1, training, upd)
+    hw = p2.shape[2:]
+    cat = torch.cat([p2, _nearest(p3, hw), _nearest(p4, hw), _nearest(p5, hw)], dim=1)
+    f = F.conv2d(cat, sd[b + 'conv.0.weight'], sd[b + 'conv.0.bias'], 1, 1)
+    f = F.relu(_bn(sd, b + 'conv.1', f, training, upd))
+    t['p5'], t['p4'], t['p3'], t['p2'], t['fpn'] = p5, p4, p3, p2, f
+    # DB head (segmentation_head.py:35-45)
+    P = _head_branch(sd, 'segmentation_head.binarize', f, training, upd, True)
+    T = _head_branch(sd, 'segmentation_head.thresh', f, training, upd, False)
+    if training:
+        B = torch.reciprocal(1 + torch.exp(-K_STEP * (P - T)))  # :106-108
+        y = torch.cat((P, T, B), dim=1)
+    else:
+        y = torch.cat((P, T), dim=1)
+    # models.py:43-46 — identity when H, W are multiples of 32
+    return F.interpolate(y, size=(H, W), mode='bilinear', align_corners=True)
+
+
+# ----------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------
+
+
+def ohem_bce(pred, gt, mask, negative_ratio=3, eps=1e-6, reduction='mean'):
+    """losses.py:18-40, statement by statement (including the scalar-BCE quirk
+    under reduction='mean')."""
+    positive = gt * mask
+    negative = (1 - gt) * mask
+    n_pos = int(positive.sum())
+    n_neg = min(int(n_pos * negative_ratio), int(negative.sum()))
+    loss = F.binary_cross_entropy(pred, gt, reduction=reduction)
+    pos_loss = loss * positive
+    neg_loss = loss * negative
+    neg_loss, _ = torch.topk(neg_loss.reshape(-1), n_neg)
+    return (pos_loss.sum() + neg_loss.sum()) / (n_pos + n_neg + eps)
+
+
+def dice(pred, gt, mask, eps=1e-6):
+    # losses.py:62-64
+    inter = (pred * gt * mask).sum()
+    union = (pred * mask).sum() + (gt * mask).sum() + eps
+    return 1 - 2.0 * inter / union
+
+
+def masked_l1(pred, gt, mask, eps=1e-6):
+    # losses.py:77-78
+    return (torch.abs(pred - gt) * mask).sum() / (mask.sum() + eps)
+
+
+def db_loss(preds, gts, alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3, eps=1e-6):
+    """DBLoss.forward (losses.py:105-139).  Returns the 5-tuple for 3-channel
+    preds, the single prob+beta*thresh value for 2-channel preds."""
+    assert preds.dim() == 4 and gts.dim() == 4
+    P, T = preds[:, 0], preds[:, 1]
+    G, M, Tg, A = gts[0], gts[1], gts[2], gts[3]
+    prob = ohem_bce(P, G, M, negative_ratio, eps, reduction)
+    thr = masked_l1(T, Tg, A, eps)
+    pt = prob + beta * thr
+    if preds.size(1) == 3:
+        binl = dice(preds[:, 2], G, M, eps)
+        return prob, thr, binl, pt, alpha * binl + pt
+    return pt
+
+
+def db_loss_closed_form(preds, gts, alpha=1.0, beta=10.0, negative_ratio=3, eps=1e-6):
+    """What the HIP loss kernel evaluates for reduction='mean' with binary
+    gt/mask: bce_mean * (sum_pos + n_neg) / (n_pos+n_neg+eps).
+    Float64 sums; used to cross-check the literal restatement above."""
+    P, T = preds[:, 0].double(), preds[:, 1].double()
+    G, M, Tg, A = (g.double() for g in gts)
+    s_pos = (G * M).sum()
+    s_neg = ((1 - G) * M).sum()
+    n_pos = int(s_pos)
+    n_neg = min(int(n_pos * negative_ratio), int(s_neg))
+    bce = -(G * torch.clamp(torch.log(P), min=-100) + (1 - G) * torch.clamp(torch.log1p(-P), min=-100)).mean()
+    prob = bce * (s_pos + n_neg) / (n_pos + n_neg + eps)
+    thr = ((T - Tg).abs() * A).sum() / (A.sum() + eps)
+    out = [prob, thr]
+    if preds.size(1) == 3:
+        B = preds[:, 2].double()
+        binl = 1 - 2.0 * (B * G * M).sum() / ((B * M).sum() + s_pos + eps)
+        out += [binl, prob + beta * thr, alpha * binl + prob + beta * thr]
+    else:
+        out += [prob + beta * thr]
+    return [float(v) for v in out]
+
+
+# ----------------------------------------------------------------------------
+# per-step loop (train.py:160-172) with an explicit Adam restatement
+# ----------------------------------------------------------------------------
+
+
+class AdamState:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0,
+    amsgrad=False) restated (train.py:114-117)."""
+
+    def __init__(self, lr=0.005, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def step(self, sd, grads):
+        self.t += 1
+        bc1 = 1 - self.b1**self.t
+        bc2 = 1 - self.b2**self.t
+        for k, g in grads.items():
+            if g is None:
+                continue
+            if k not in self.m:
+                self.m[k] = torch.zeros_like(g)
+                self.v[k] = torch.zeros_like(g)
+            m, v = self.m[k], self.v[k]
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+            sd[k].addcdiv_(m, denom, value=-self.lr / bc1)
+
+
+def loss_and_grads(sd, img, gts, update_stats=True, world_scale=1.0, **loss_kw):
+    """forward + DBLoss + backward; returns (preds, losses(5 floats), grads dict)."""
+    keys = trainable_keys()
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = OrderedDict(sd)
+    work.update(leaves)
+    preds = forward(work, img, training=True, update_stats=update_stats)
+    for k in sd:  # carry running-stat updates back
+        if k not in leaves:
+            sd[k] = work[k]
+    losses = db_loss(preds, gts, **loss_kw)
+    total = losses[4]
+    grads = torch.autograd.grad(total, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: (g * world_scale if g is not None else None) for k, g in zip(keys, grads)}
+    return preds.detach(), [float(v.detach()) for v in losses], grads
+
+
+def train_step(sd, opt, img, gts, **loss_kw):
+    """One iteration of train.py:160-172 on the flat state dict."""
+    preds, losses, grads = loss_and_grads(sd, img, gts, **loss_kw)
+    with torch.no_grad():
+        opt.step(sd, grads)
+    return preds, losses

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference; nothing in the test
+suite or on the GPU box does):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's DBTextModel / DBLoss (models.py, losses.py) with
+`model_zoo.load_url` stubbed to `{}` (no network; models.py:17 hard-codes
+pretrained=True), fills the model with `oracle.dbnet_oracle.procedural_fill`
+(a build-owned per-key seeded fill, so weights need not be committed), drives
+it with a 10-line restatement of train.py:160-172 and stores inputs'
+seeds + expected outputs as small .npz files.  The fixtures are data only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference/src')
+sys.dont_write_bytecode = True
+
+import torch.utils.model_zoo as mz  # noqa: E402
+
+mz.load_url = lambda *a, **k: {}
+
+from models import DBTextModel  # noqa: E402  (reference)
+from losses import DBLoss  # noqa: E402  (reference)
+from oracle import dbnet_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+SAMPLE = 256
+
+
+def sample_idx(numel, k=SAMPLE):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * (numel // k)) + (numel // (2 * k))
+
+
+def summarize(prefix, t, out, full_below=8192):
+    a = t.detach().double().reshape(-1).numpy()
+    out[prefix + '/stats'] = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum()), a.min(), a.max()])
+    if a.size <= full_below:
+        out[prefix + '/full'] = t.detach().float().numpy()
+    else:
+        out[prefix + '/sample'] = a[sample_idx(a.size)].astype(np.float32)
+
+
+def make_ref(seed):
+    m = DBTextModel()
+    O.procedural_fill(m.state_dict(), seed)
+    return m
+
+
+def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1):
+    print('==', name)
+    torch.manual_seed(0)
+    m = make_ref(seed).train()
+    crit = DBLoss(alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3)
+    opt = torch.optim.Adam(m.parameters(), lr=0.005, weight_decay=0, amsgrad=False)
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=img_scale)
+    out = {'meta': np.array([n, size, seed, steps]), 'img_scale': np.array(img_scale)}
+    step_losses = []
+    for it in range(steps):
+        preds = m(img)
+        assert preds.size(1) == 3
+        losses = crit(preds, gts)
+        opt.zero_grad()
+        losses[4].backward()
+        if it == 0:
+            if full_maps:
+                out['preds'] = preds.detach().numpy()
+            else:
+                for c, nm in enumerate('PTB'):
+                    summarize('preds_' + nm, preds[:, c], out, full_below=0)
+            for k, p in m.named_parameters():
+                if p.grad is not None:
+                    summarize('grad/' + k, p.grad, out)
+            out['dead_grad_none'] = np.array(
+                [int(p.grad is None) for k, p in m.named_parameters() if k.startswith(('backbone.fc', 'backbone.smooth'))])
+        opt.step()
+        step_losses.append([float(v) for v in losses])
+        print('  step', it, step_losses[-1])
+    out['losses'] = np.array(step_losses)
+    sd = m.state_dict()
+    # post-step state: running stats always, params as summaries
+    for k, v in sd.items():
+        if 'running' in k:
+            summarize('post/' + k, v, out, full_below=600)
+        elif 'num_batches' not in k and not k.startswith(('backbone.fc', 'backbone.smooth')):
+            summarize('post/' + k, v, out, full_below=0)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    return m
+
+
+def case_eval(name, n, size, seed):
+    print('==', name)
+    m = make_ref(seed).eval()
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    with torch.no_grad():
+        preds = m(img)
+        assert preds.size(1) == 2
+        val = DBLoss()(preds, gts)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), meta=np.array([n, size, seed, 0]), preds=preds.numpy(),
+                        loss=np.array(float(val)))
+
+
+def case_loss_kats():
+    print('== loss_kats')
+    out = {}
+    crit = DBLoss()
+    g = torch.Generator().manual_seed(7)
+
+    def run(tag, preds, gts, crit_=crit):
+        preds = preds.clone().requires_grad_(True)
+        res = crit_(preds, gts)
+        res5 = res if isinstance(res, tuple) else (res, )
+        tot = res5[-1]
+        (dp, ) = torch.autograd.grad(tot, preds)
+        out[tag + '/preds'] = preds.detach().numpy()
+        out[tag + '/gts'] = gts.numpy()
+        out[tag + '/losses'] = np.array([float(v) for v in res5])
+        out[tag + '/dpreds'] = dp.numpy()
+        print('  ', tag, out[tag + '/losses'])
+
+    n, s = 2, 64
+    P = torch.rand(n, 1, s, s, generator=g) * 0.98 + 0.01
+    T = torch.rand(n, 1, s, s, generator=g) * 0.98 + 0.01
+    B = torch.reciprocal(1 + torch.exp(-50 * (P - T)))
+    preds3 = torch.cat([P, T, B], 1)
+    _, gts = O.synthetic_batch(n, s, seed=11)
+    run('default', preds3, gts)
+    run('eval2ch', preds3[:, :2].contiguous(), gts)
+    g0 = gts.clone()
+    g0[0].zero_()  # no positives -> prob_loss 0.0 (topk k=0)
+    run('no_positive', preds3, g0)
+    g1 = gts.clone()
+    g1[1].zero_()  # everything masked out
+    g1[3].zero_()
+    run('all_masked', preds3, g1)
+    # few positives so that n_neg = 3*n_pos side of the min() is taken, and the other side
+    g2 = gts.clone()
+    g2[0] = (torch.rand(n, s, s, generator=g) > 0.5).float()
+    run('neg_limited', preds3, g2)
+    # saturated probabilities: log clamp at -100
+    Ps = (torch.rand(n, 1, s, s, generator=g) > 0.5).float()
+    run('saturated', torch.cat([Ps, T, torch.reciprocal(1 + torch.exp(-50 * (Ps - T)))], 1), gts)
+    run('alpha_beta', preds3, gts, DBLoss(alpha=5.0, beta=2.0, negative_ratio=1))
+    # contrast: reduction='none' (true per-pixel OHEM) — recorded so a future top-k kernel can be pinned
+    run('reduction_none', preds3, gts, DBLoss(reduction='none'))
+    np.savez_compressed(os.path.join(HERE, 'loss_kats.npz'), **out)
+
+
+def case_dp(name, size, seed):
+    """gradient after all-reduce == mean of per-shard grads."""
+    print('==', name)
+    img, gts = O.synthetic_batch(2, size, seed=seed + 100)
+    acc = None
+    out = {'meta': np.array([2, size, seed, 1])}
+    for r in range(2):
+        m = make_ref(seed).train()
+        crit = DBLoss()
+        preds = m(img[r:r + 1])
+        tot = crit(preds, gts[:, r:r + 1])[4]
+        tot.backward()
+        out['loss_rank%d' % r] = np.array(float(tot))
+        gr = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        acc = gr if acc is None else {k: acc[k] + gr[k] for k in acc}
+    for k, v in acc.items():
+        summarize('grad/' + k, v / 2, out)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
+def check_oracle():
+    """Pin the oracle against the imported reference right here."""
+    print('== oracle vs reference')
+    m = make_ref(3).train()
+    sd = O.new_state(3)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    img, gts = O.synthetic_batch(2, 96, seed=5)
+    preds = m(img)
+    losses = DBLoss()(preds, gts)
+    losses[4].backward()
+    p2, l2, g2 = O.loss_and_grads(sd, img, gts)
+    print('  preds maxdiff', float((preds - p2).abs().max()))
+    print('  losses', [float(v) for v in losses], l2)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert k not in g2 or g2[k] is None
+            continue
+        d = float((p.grad - g2[k]).abs().max() / (p.grad.abs().max() + 1e-12))
+        worst = max(worst, d)
+    print('  worst rel grad diff', worst)
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            assert torch.allclose(v, sd[k], atol=1e-6), k
+    assert float((preds - p2).abs().max()) < 1e-5 and worst < 1e-4
+
+
+if __name__ == '__main__':
+    check_oracle()
+    case_loss_kats()
+    case_train('train_1x64', 1, 64, seed=1, steps=3)
+    case_train('train_2x128', 2, 128, seed=2, steps=3)
+    case_train('train_2x96_scaled', 2, 96, seed=4, img_scale=60.0, steps=1)
+    case_eval('eval_2x128', 2, 128, seed=2)
+    case_dp('dp_2x1x128', 128, seed=6)
+    if '--no-640' not in sys.argv:
+        case_train('cfg1_2x640', 2, 640, seed=0, full_maps=False, steps=3)
+    print('done')
