@@ -1,0 +1,86 @@
+"""ctypes binding of libdbnet_hip.so (the C ABI declared in include/dbnet_hip.h).
+
+The product path has no CPU or PyTorch-op fallback: if the HIP library is
+missing or fails to load, importing a compute entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdbnet_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argument kinds (p = device/host pointer, i = int, l = long, f = float); all return int
+SIGNATURES = {
+    'dbn_pack_weights': 'piiiiipp',
+    'dbn_igemm_packed_floats': 'ii',
+    'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
+    'dbn_wgrad_splitk': 'iiiiiii',
+    'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
+    'dbn_reduce_ws_floats': 'i',
+    'dbn_bn_train_stats': 'piippffppppppp' + 'p',
+    'dbn_bn_eval_coef': 'ippppfppp',
+    'dbn_bn_apply': 'pppppppliip',
+    'dbn_bn_backward': 'pppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
+    'dbn_col_sum': 'piipfpp',
+    'dbn_bnrelu_maxpool_fwd': 'ppppiiiip',
+    'dbn_bnrelu_maxpool_bwd': 'ppppppiiiip',
+    'dbn_nearest_up_fwd': 'ppp' + 'i' * 8 + 'p',
+    'dbn_nearest_up_bwd': 'pp' + 'i' * 9 + 'p',
+    'dbn_nchw3_to_nhwc4': 'ppiiip',
+    'dbn_add_inplace': 'pplp',
+    'dbn_head_tail_fwd': 'ppppppp' + 'iiii' + 'f' + 'p',
+    'dbn_head_tail_bwd_ws_floats': '',
+    'dbn_head_tail_bwd': 'p' * 12 + 'iiii' + 'ff' + 'pp',
+    'dbn_db_loss_ws_bytes': '',
+    'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
+    'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
+    'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
+}
+_KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libdbnet_hip.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise HipLibraryError('building libdbnet_hip.so failed (see output above)')
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError('%s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                  '(there is no CPU fallback for the DBNet hot path)' % LIB_PATH)
+        try:
+            l = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise HipLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, sig in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is missing
+            fn.argtypes = [_KIND[k] for k in sig]
+            fn.restype = _I
+        _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        if rc == 1:
+            raise RuntimeError('libdbnet_hip: invalid argument in %s' % what)
+        raise RuntimeError('libdbnet_hip: %s failed with hipError %d' % (what, rc - 1000))

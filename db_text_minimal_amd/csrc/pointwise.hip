@@ -1,0 +1,523 @@
+// HBM-bound NHWC kernels around the convolutions: train-mode BatchNorm (statistics,
+// affine+ReLU(+residual) apply, backward), stem max-pool fused with BN+ReLU, nearest
+// upsample/concat of the FPN, layout packing, column sums (bias gradients) and the
+// flat fused Adam step.
+//
+// Replaces, on the reference's hot path: nn.BatchNorm2d / nn.ReLU (resnet.py:73-91,
+// basic.py:32-36), nn.MaxPool2d (resnet.py:185,235), F.interpolate(nearest) + add/cat
+// (segmentation_body.py:79-87), torch.optim.Adam.step (train.py:114-117,172).
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PART = 1024;  // max partial blocks for per-channel reductions
+
+// ----------------------------------------------------------------------------------
+// per-channel reductions over [M][C] (C % 4 == 0, C <= 1024): each block reduces a
+// contiguous row range into part[block][NV][C]; a second kernel folds the partials in
+// double precision.  Thread t owns channel quad t % (C/4) and walks rows t / (C/4).
+// ----------------------------------------------------------------------------------
+template <int NV, class F>
+__device__ __forceinline__ void channel_reduce(int M, int C, float* __restrict__ part, F&& body) {
+    const int c4n = C >> 2;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const int nrl = blockDim.x / c4n;
+    const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+    f32x4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rl < nrl)
+        for (int r = r0 + rl; r < r1; r += nrl) body(r, c4, acc);
+    extern __shared__ float red[];  // [nrl][NV][C]
+    if (rl < nrl) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(red + ((long)rl * NV + v) * C + 4 * c4) = acc[v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nrl; ++k) s += red[(long)k * NV * C + i];
+        part[(long)blockIdx.x * NV * C + i] = s;
+    }
+}
+
+__global__ void bn_stats_kernel(const float* __restrict__ y, int M, int C, float* __restrict__ part) {
+    // shifted sums around the first row (pivot) to avoid E[x^2]-E[x]^2 cancellation
+    channel_reduce<2>(M, C, part, [&](int r, int c4, f32x4* acc) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(y + 4 * c4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + (long)r * C + 4 * c4) - pv;
+        acc[0] += v;
+        acc[1] += v * v;
+    });
+}
+
+// out: scale = gamma*rstd, shift = beta - mean*scale, saved mean / rstd; running stats
+// updated in place like F.batch_norm(training=True, momentum) does (unbiased var).
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const float* __restrict__ y, int M, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s1 += (double)part[(long)b * 2 * C + c];
+        s2 += (double)part[(long)b * 2 * C + C + c];
+    }
+    const double pv = (double)y[c];
+    const double dm = s1 / M;
+    const double mean = pv + dm;
+    double var = s2 / M - dm * dm;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-meanf, sc, beta[c]);
+    mean_out[c] = meanf;
+    rstd_out[c] = rstd;
+    if (run_mean) {
+        const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * meanf;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ run_mean, const float* __restrict__ run_var, float eps,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(run_var[c] + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-run_mean[c], sc, beta[c]);
+}
+
+// out = act(y*sc+sh [+ res*rsc+rsh | + res])
+__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                float* __restrict__ out, long total4, int C, int relu) {
+    const int c4n = C >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = dbn_affine(v[e], s[e], h[e]);
+        if (res) {
+            const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+            if (rsc) {
+                const f32x4 s2 = *reinterpret_cast<const f32x4*>(rsc + c);
+                const f32x4 h2 = *reinterpret_cast<const f32x4*>(rsh + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += dbn_affine(r[e], s2[e], h2[e]);
+            } else {
+                o += r;
+            }
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+// backward reductions: g = dout * (zmask > 0);  sums of g and g*xhat
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ dout,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, int M, int C,
+                                     float* __restrict__ part) {
+    channel_reduce<2>(M, C, part, [&](int r, int c4, f32x4* acc) {
+        const long off = (long)r * C + 4 * c4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + off);
+        if (zmask) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + 4 * c4);
+        acc[0] += g;
+        acc[1] += g * ((v - mu) * rs);
+    });
+}
+
+// dgamma, dbeta, and the two per-channel means used by the apply pass
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, int M, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float gscale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s1 += (double)part[(long)b * 2 * C + c];
+        s2 += (double)part[(long)b * 2 * C + C + c];
+    }
+    dbeta[c] = (float)(s1 * gscale);
+    dgamma[c] = (float)(s2 * gscale);
+    c1[c] = (float)(s1 / M);
+    c2[c] = (float)(s2 / M);
+}
+
+// dy = gamma*rstd*(g - c1 - xhat*c2); optionally also emits g (the ReLU-masked dout)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ dout,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
+                                    float* __restrict__ dy, float* __restrict__ gout, int gout_acc, long total4, int C) {
+    const int c4n = C >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        if (zmask) {
+            const f32x4 z = reinterpret_cast<const f32x4*>(zmask)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
+        const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
+        const f32x4 xh = (v - mu) * rs;
+        reinterpret_cast<f32x4*>(dy)[i] = ga * rs * (g - k1 - xh * k2);
+        if (gout) {
+            if (gout_acc) g += reinterpret_cast<const f32x4*>(gout)[i];
+            reinterpret_cast<f32x4*>(gout)[i] = g;
+        }
+    }
+}
+
+// generic column sum [M][C] -> part (NV=1)
+__global__ void col_sum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ part) {
+    channel_reduce<1>(M, C, part, [&](int r, int c4, f32x4* acc) { acc[0] += *reinterpret_cast<const f32x4*>(x + (long)r * C + 4 * c4); });
+}
+
+__global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)part[(long)b * n + i];
+    out[i] = (float)(s * scale);
+}
+
+// ----------------------------------------------------------------------------------
+// stem: relu(bn(y)) -> maxpool 3x3 s2 p1, forward and backward
+// ----------------------------------------------------------------------------------
+__global__ void bnrelu_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          float* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const long total = (long)N * Ho * Wo * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long t = i / c4n;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};  // relu output >= 0, so 0 is a neutral start (padding never wins)
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - 1 + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int q = 0; q < 3; ++q) {
+                const int iw = ow * 2 - 1 + q;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + (((long)n * H + ih) * W + iw) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], dbn_affine_relu(v[e], s[e], h[e]));
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = m;
+    }
+}
+
+// dz[n,ih,iw,c] = [z>0] * sum over windows containing (ih,iw) whose max equals z of dpool
+__global__ void bnrelu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          const float* __restrict__ pooled, const float* __restrict__ dpool,
+                                          float* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const long total = (long)N * H * W * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long t = i / c4n;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = dbn_affine_relu(v[e], s[e], h[e]);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows oh with oh*2-1 <= ih <= oh*2+1
+        const int oh_lo = max(0, (ih) / 2), oh_hi = min(Ho - 1, (ih + 1) / 2);
+        const int ow_lo = max(0, (iw) / 2), ow_hi = min(Wo - 1, (iw + 1) / 2);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
+                const f32x4 pm = *reinterpret_cast<const f32x4*>(pooled + o);
+                const f32x4 dp = *reinterpret_cast<const f32x4*>(dpool + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (z[e] > 0.f && z[e] == pm[e]) g[e] += dp[e];
+            }
+        reinterpret_cast<f32x4*>(dz)[i] = g;
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// nearest upsample (F.interpolate(size=...) semantics: src = min(floor(dst*in/out), in-1))
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_src(int d, int in, int out) {
+    const float scale = (float)in / (float)out;
+    const int s = (int)floorf((float)d * scale);
+    return s < in - 1 ? s : in - 1;
+}
+
+// dst[n,h,w,coff+c] = src[n,nh,nw,c] (+ addend[n,h,w,c])
+__global__ void nearest_up_fwd_kernel(const float* __restrict__ src, const float* __restrict__ addend, float* __restrict__ dst,
+                                      int N, int Hs, int Ws, int C, int H, int W, int Cdst, int coff) {
+    const int c4n = C >> 2;
+    const long total = (long)N * H * W * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long t = i / c4n;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        const int sh_ = nearest_src(h, Hs, H), sw_ = nearest_src(w, Ws, W);
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + (((long)n * Hs + sh_) * Ws + sw_) * C + c);
+        if (addend) v += *reinterpret_cast<const f32x4*>(addend + (((long)n * H + h) * W + w) * C + c);
+        *reinterpret_cast<f32x4*>(dst + (((long)n * H + h) * W + w) * Cdst + coff + c) = v;
+    }
+}
+
+// dsrc[n,hs,ws,c] (+)= sum over (h,w) mapping to (hs,ws) of dbig[n,h,w,coff+c]
+__global__ void nearest_up_bwd_kernel(const float* __restrict__ dbig, float* __restrict__ dsrc, int N, int Hs, int Ws, int C,
+                                      int H, int W, int Cbig, int coff, int accumulate) {
+    const int c4n = C >> 2;
+    const long total = (long)N * Hs * Ws * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long t = i / c4n;
+        const int ws = (int)(t % Ws);
+        t /= Ws;
+        const int hs = (int)(t % Hs);
+        const int n = (int)(t / Hs);
+        // candidate destination range (generous by one on both sides, then filtered exactly)
+        int h0 = (int)((long)hs * H / Hs) - 1, h1 = (int)(((long)hs + 1) * H / Hs) + 1;
+        int w0 = (int)((long)ws * W / Ws) - 1, w1 = (int)(((long)ws + 1) * W / Ws) + 1;
+        h0 = max(h0, 0); h1 = min(h1, H - 1);
+        w0 = max(w0, 0); w1 = min(w1, W - 1);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int h = h0; h <= h1; ++h) {
+            if (nearest_src(h, Hs, H) != hs) continue;
+            for (int w = w0; w <= w1; ++w) {
+                if (nearest_src(w, Ws, W) != ws) continue;
+                g += *reinterpret_cast<const f32x4*>(dbig + (((long)n * H + h) * W + w) * Cbig + coff + c);
+            }
+        }
+        f32x4* d = reinterpret_cast<f32x4*>(dsrc) + i;
+        if (accumulate) g += *d;
+        *d = g;
+    }
+}
+
+// [N,3,H,W] -> [N,H,W,4] (4th channel zero)
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ out, int N, long HW) {
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i - n * HW;
+        const float* b = x + n * 3 * HW + p;
+        reinterpret_cast<f32x4*>(out)[i] = f32x4{b[0], b[HW], b[2 * HW], 0.f};
+    }
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long total4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(x)[i];
+}
+
+// ----------------------------------------------------------------------------------
+// Adam over one flat fp32 buffer (torch.optim.Adam semantics, amsgrad=False, wd=0)
+// ----------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr_over_bc1, float b1, float b2, float eps, float inv_sqrt_bc2, float gscale) {
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
+            vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+            pp[e] -= lr_over_bc1 * (mm[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    // tail
+    const long t = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gg = g[t] * gscale;
+        const float mm = b1 * m[t] + (1.f - b1) * gg;
+        const float vv = b2 * v[t] + (1.f - b2) * gg * gg;
+        m[t] = mm;
+        v[t] = vv;
+        p[t] -= lr_over_bc1 * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    }
+}
+
+inline int part_blocks(int M, int C) {
+    // rows per block >= 64 so partials stay small; <= MAX_PART blocks
+    int nb = (M + 63) / 64;
+    if (nb > MAX_PART) nb = MAX_PART;
+    if (nb < 1) nb = 1;
+    (void)C;
+    return nb;
+}
+inline size_t red_smem(int C, int nv) {
+    const int nrl = 256 / (C / 4);
+    return (size_t)(nrl > 0 ? nrl : 1) * nv * C * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of scratch needed by the per-channel reduction entry points below
+int dbn_reduce_ws_floats(int C) { return MAX_PART * 2 * C; }
+
+int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                       float* ws, void* stream) {
+    DBN_REQUIRE(y && gamma && beta && scale && shift && save_mean && save_rstd && ws);
+    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = part_blocks(M, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), red_smem(C, 2), st, y, M, C, ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nb, y, M, C, gamma, beta, eps,
+                       momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
+}
+
+int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
+                     float* scale, float* shift, void* stream) {
+    DBN_REQUIRE(gamma && beta && run_mean && run_var && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                       run_mean, run_var, eps, scale, shift);
+    return dbn_status();
+}
+
+int dbn_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                 const float* res_shift, float* out, long M, int C, int relu, void* stream) {
+    DBN_REQUIRE(y && scale && shift && out && M > 0 && C % 4 == 0);
+    DBN_REQUIRE((res_scale == nullptr) == (res_shift == nullptr));
+    const long total4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
+                       res_scale, res_shift, out, total4, C, relu);
+    return dbn_status();
+}
+
+int dbn_bn_backward(const float* y, const float* zmask, const float* dout, const float* save_mean, const float* save_rstd,
+                    const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
+                    float grad_scale, float* ws, void* stream) {
+    DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
+    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = part_blocks(M, C);
+    float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
+    float* c2 = c1 + C;
+    const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nbu), dim3(256), red_smem(C, 2), st, y, zmask, dout, save_mean, save_rstd, M,
+                       C, ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
+                       grad_scale);
+    const long total4 = (long)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, dout, save_mean, save_rstd,
+                       gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
+    return dbn_status();
+}
+
+int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {
+    DBN_REQUIRE(x && out && ws && M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = part_blocks(M, C);
+    hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), red_smem(C, 1), st, x, M, C, ws);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, out, scale);
+    return dbn_status();
+}
+
+int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
+                           void* stream) {
+    DBN_REQUIRE(y && scale && shift && out && C % 4 == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(dbn_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo);
+    return dbn_status();
+}
+
+int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
+                           float* dz, int N, int H, int W, int C, void* stream) {
+    DBN_REQUIRE(y && scale && shift && pooled && dpool && dz && C % 4 == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo);
+    return dbn_status();
+}
+
+int dbn_nearest_up_fwd(const float* src, const float* addend, float* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
+                       int coff, void* stream) {
+    DBN_REQUIRE(src && dst && C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0 && coff + C <= Cdst);
+    DBN_REQUIRE(addend == nullptr || (Cdst == C && coff == 0));
+    hipLaunchKernelGGL(nearest_up_fwd_kernel, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, src,
+                       addend, dst, N, Hs, Ws, C, H, W, Cdst, coff);
+    return dbn_status();
+}
+
+int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
+                       int accumulate, void* stream) {
+    DBN_REQUIRE(dbig && dsrc && C % 4 == 0 && Cbig % 4 == 0 && coff % 4 == 0 && coff + C <= Cbig);
+    hipLaunchKernelGGL(nearest_up_bwd_kernel, dim3(dbn_grid((long)N * Hs * Ws * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       dbig, dsrc, N, Hs, Ws, C, H, W, Cbig, coff, accumulate);
+    return dbn_status();
+}
+
+int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) {
+    DBN_REQUIRE(x && out && N > 0);
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N,
+                       (long)H * W);
+    return dbn_status();
+}
+
+int dbn_add_inplace(const float* x, float* y, long n, void* stream) {
+    DBN_REQUIRE(x && y && n % 4 == 0);
+    hipLaunchKernelGGL(axpy_kernel, dim3(dbn_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4);
+    return dbn_status();
+}
+
+int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
+                  float grad_scale, void* stream) {
+    DBN_REQUIRE(p && g && m && v && n > 0 && step >= 1);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(dbn_grid(n / 4 + 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+    return dbn_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+"""Host-side executor of the DBNet forward/backward on MI355X.
+
+Walks the module tree of `models.DBTextModel` (same topology as the reference:
+/root/reference/src/models.py:34-48, modules/resnet.py:70-91,231-242,
+modules/segmentation_body.py:64-87, modules/segmentation_head.py:35-45) and
+issues the kernels of libdbnet_hip.so on the current HIP stream.  PyTorch is
+used for device memory and streams only — there is no ATen arithmetic here.
+
+Data layout in HBM
+  * activations: NHWC fp32, kept in a persistent arena (one buffer per named
+    tensor, reused every step -> no allocator traffic, graph-capturable);
+  * parameters: one flat fp32 buffer in the reference's OIHW layouts (the
+    nn.Parameters are views into it), one flat gradient buffer of the same
+    shape -> a single Adam launch and a single all-reduce per step;
+  * GEMM weight panels ([K/4][Cout][4]) are re-packed from the flat buffer
+    whenever the parameters change.
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+DEAD_PREFIXES = ('backbone.fc.', 'backbone.smooth.')
+K_STEP_DEFAULT = 50.0
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.L = _lib.lib()
+        self.bufs = {}
+        self.packs = {}
+        self.param_epoch = 0
+        self.generation = 0
+        self.saved_generation = -1
+        self.flat = None
+        self.flat_grad = None
+        self.offsets = None
+        self.views = {}
+        self.grad_views = {}
+        self.grad_scale = 1.0
+        self._live = None
+        self.nbt_pending = {}
+
+    # ------------------------------------------------------------------ memory
+    @property
+    def live_params(self):
+        if self._live is None:
+            self._live = [(n, p) for n, p in self.model.named_parameters() if not n.startswith(DEAD_PREFIXES)]
+        return self._live
+
+    def ensure_flat(self):
+        params = self.live_params
+        dev = params[0][1].device
+        if dev.type != 'cuda':
+            raise RuntimeError('DBTextModel parameters must live on a HIP device (model.to("cuda")); '
+                               'there is no CPU path')
+        if self.flat is not None and self.flat.device == dev:
+            base = self.flat.data_ptr()
+            if all(p.data_ptr() == base + 4 * off for (_, p), off in zip(params, self.offsets)):
+                return
+        offs, total = [], 0
+        for _, p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.views, self.grad_views = {}, {}
+        for (n, p), off in zip(params, offs):
+            if p.dtype != torch.float32:
+                raise RuntimeError('fp32 parameters expected, got %s for %s' % (p.dtype, n))
+            v = flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.views[n] = v
+            self.grad_views[n] = grad[off:off + p.numel()].view(p.shape)
+        self.flat, self.flat_grad, self.offsets = flat, grad, offs
+        self.bufs, self.packs = {}, {}
+        self.param_epoch += 1
+
+    def flush_counters(self):
+        """BatchNorm `num_batches_tracked` is bookkeeping only (momentum is fixed); it is
+        counted on the host and written to the buffers when the state is read."""
+        if not self.nbt_pending:
+            return
+        mods = dict(self.model.named_modules())
+        for name, cnt in self.nbt_pending.items():
+            mods[name].num_batches_tracked += cnt
+        self.nbt_pending = {}
+
+    def mark_params_dirty(self):
+        self.param_epoch += 1
+
+    def buf(self, name, *shape):
+        t = self.bufs.get(name)
+        dev = self.flat.device
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+            t = torch.empty(shape, device=dev, dtype=torch.float32)
+            self.bufs[name] = t
+        return t
+
+    def scratch(self, name, numel):
+        t = self.bufs.get(name)
+        if t is None or t.numel() < numel or t.device != self.flat.device:
+            t = torch.empty(int(numel), device=self.flat.device, dtype=torch.float32)
+            self.bufs[name] = t
+        return t
+
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.flat.device).cuda_stream
+
+    def reduce_ws(self):
+        return self.scratch('_reduce_ws', self.L.dbn_reduce_ws_floats(512))
+
+    # ------------------------------------------------------------ weight panels
+    def pack(self, name, w, mode, O=None, I=None):
+        key = (name, mode)
+        ent = self.packs.get(key)
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        if ent is not None and ent[1] == stamp:
+            return ent[0]
+        O = w.shape[0] if O is None else O
+        I = w.shape[1] if I is None else I
+        R, S = w.shape[2], w.shape[3]
+        Cs = (I + 3) // 4 * 4 if mode == 0 else O
+        Cd = O if mode == 0 else I
+        n = self.L.dbn_igemm_packed_floats(R * S * Cs, Cd)
+        out = ent[0] if ent is not None else torch.empty(n, device=w.device, dtype=torch.float32)
+        check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, out.data_ptr(), self.stream), 'pack_weights')
+        self.packs[key] = (out, stamp)
+        return out
+
+    # ------------------------------------------------------------------ kernels
+    def conv_fwd(self, name, x, conv, out_name):
+        N, H, W, C = x.shape
+        k, s, p = conv.k, conv.stride, conv.padding
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
+        wpk = self.pack(name, conv.weight, 0)
+        y = self.buf(out_name, N, Ho, Wo, conv.cout)
+        check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
+                                   k, s, p, 0, 0, 0, self.stream), 'igemm fwd ' + name)
+        return y
+
+    def conv_dgrad(self, name, dy, conv, dx, accumulate):
+        N, Ho, Wo, O = dy.shape
+        _, H, W, I = dx.shape
+        wpk = self.pack(name, conv.weight, 1)
+        check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
+                                   conv.stride, conv.padding, 1, int(accumulate), 0, self.stream), 'igemm dgrad ' + name)
+
+    def wgrad(self, name, sm, big, O, I, k, stride, pad, gview):
+        N, Ho, Wo, _ = sm.shape
+        _, H, W, Cb = big.shape
+        sk = self.L.dbn_wgrad_splitk(N, Ho, Wo, O, Cb, k, k)
+        slab = self.scratch('_wgrad_slab', sk * O * k * k * Cb)
+        check(self.L.dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k,
+                                   k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
+
+    def conv_wgrad(self, name, dy, x, conv):
+        self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
+        if conv.bias is not None:
+            self.col_sum(dy, self.grad_views[name + '.bias'])
+
+    def convT_fwd(self, name, x, ct, out_name):
+        N, H, W, C = x.shape
+        wpk = self.pack(name, ct.weight, 1)
+        y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
+        check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
+                                   2, 2, 0, 1, 0, 0, self.stream), 'igemm convT fwd ' + name)
+        return y
+
+    def convT_bwd(self, name, dy, x, ct, dx):
+        N, H2, W2, Co = dy.shape
+        _, H, W, Ci = x.shape
+        wpk = self.pack(name, ct.weight, 0)
+        check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2, 2, 0, 0, 0,
+                                   0, self.stream), 'igemm convT dgrad ' + name)
+        self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
+        if ct.bias is not None:
+            self.col_sum(dy, self.grad_views[name + '.bias'])
+
+    def col_sum(self, x, out):
+        C = x.shape[-1]
+        M = x.numel() // C
+        check(self.L.dbn_col_sum(x.data_ptr(), M, C, out.data_ptr(), self.grad_scale, self.reduce_ws().data_ptr(), self.stream),
+              'col_sum')
+
+    def bn_coef(self, name, bn, y, train):
+        C = y.shape[-1]
+        M = y.numel() // C
+        sc, sh = self.buf(name + '/scale', C), self.buf(name + '/shift', C)
+        if train:
+            mu, rs = self.buf(name + '/mean', C), self.buf(name + '/rstd', C)
+            check(self.L.dbn_bn_train_stats(y.data_ptr(), M, C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+                                            bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                            mu.data_ptr(), rs.data_ptr(), self.reduce_ws().data_ptr(), self.stream),
+                  'bn stats ' + name)
+            self.nbt_pending[name] = self.nbt_pending.get(name, 0) + 1  # folded into the buffer by flush_counters()
+        else:
+            check(self.L.dbn_bn_eval_coef(C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                          bn.running_var.data_ptr(), bn.eps, sc.data_ptr(), sh.data_ptr(), self.stream),
+                  'bn eval ' + name)
+        return sc, sh
+
+    def bn_apply(self, y, sc, sh, out_name, relu=True, res=None, rsc=None, rsh=None):
+        C = y.shape[-1]
+        out = self.buf(out_name, *y.shape)
+        check(self.L.dbn_bn_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), _p(res), _p(rsc), _p(rsh), out.data_ptr(),
+                                  y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
+        return out
+
+    def bn_backward(self, name, y, zmask, dout, dy_name, gout=None, gout_acc=False):
+        C = y.shape[-1]
+        M = y.numel() // C
+        dy = self.buf(dy_name, *y.shape)
+        check(self.L.dbn_bn_backward(y.data_ptr(), _p(zmask), dout.data_ptr(), self.bufs[name + '/mean'].data_ptr(),
+                                     self.bufs[name + '/rstd'].data_ptr(), self.views[name + '.weight'].data_ptr(), dy.data_ptr(),
+                                     _p(gout), int(gout_acc), self.grad_views[name + '.weight'].data_ptr(),
+                                     self.grad_views[name + '.bias'].data_ptr(), M, C, self.grad_scale,
+                                     self.reduce_ws().data_ptr(), self.stream), 'bn backward ' + name)
+        return dy
+
+    def up_fwd(self, src, addend, dst, coff=0):
+        N, Hs, Ws, C = src.shape
+        _, H, W, Cd = dst.shape
+        check(self.L.dbn_nearest_up_fwd(src.data_ptr(), _p(addend), dst.data_ptr(), N, Hs, Ws, C, H, W, Cd, coff, self.stream),
+              'nearest_up_fwd')
+
+    def up_bwd(self, dbig, dsrc, coff, accumulate):
+        N, Hs, Ws, C = dsrc.shape
+        _, H, W, Cb = dbig.shape
+        check(self.L.dbn_nearest_up_bwd(dbig.data_ptr(), dsrc.data_ptr(), N, Hs, Ws, C, H, W, Cb, coff, int(accumulate),
+                                        self.stream), 'nearest_up_bwd')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train):
+        m = self.model
+        if x.dim() != 4 or x.size(1) != 3:
+            raise AssertionError('expected input [N,3,H,W]')
+        if not x.is_cuda:
+            raise RuntimeError('DBTextModel runs on MI355X only: input must be a HIP tensor')
+        N, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise NotImplementedError('H and W must be multiples of 32 (the final bilinear resample of models.py:43-46 is then '
+                                      'the identity and is elided); got %dx%d' % (H, W))
+        self.ensure_flat()
+        x = x.contiguous().float()
+        L, st = self.L, self.stream
+        self.generation += 1
+        bb = m.backbone
+        x4 = self.buf('x4', N, H, W, 4)
+        check(L.dbn_nchw3_to_nhwc4(x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
+        y0 = self.conv_fwd('backbone.conv1', x4, bb.conv1, 'stem/y')
+        sc, sh = self.bn_coef('backbone.bn1', bb.bn1, y0, train)
+        pool = self.buf('stem/pool', N, H // 4, W // 4, 64)
+        check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H // 2, W // 2, 64, st),
+              'maxpool fwd')
+        feats = []
+        cur = pool
+        for li in range(1, 5):
+            layer = getattr(bb, 'layer%d' % li)
+            for bi, blk in enumerate(layer):
+                cur = self._block_fwd('backbone.layer%d.%d' % (li, bi), blk, cur, train)
+            feats.append(cur)
+        c2, c3, c4, c5 = feats
+        fpn = m.segmentation_body
+        pre = 'segmentation_body.'
+
+        def cbr(name, mod, xin):
+            y = self.conv_fwd(pre + name + '.conv', xin, mod.conv, name + '/y')
+            s_, h_ = self.bn_coef(pre + name + '.bn', mod.bn, y, train)
+            return self.bn_apply(y, s_, h_, name + '/z')
+
+        p5 = cbr('reduce_conv_c5', fpn.reduce_conv_c5, c5)
+        r4 = cbr('reduce_conv_c4', fpn.reduce_conv_c4, c4)
+        p4pre = self.buf('p4pre', *r4.shape)
+        self.up_fwd(p5, r4, p4pre)
+        p4 = cbr('smooth_p4', fpn.smooth_p4, p4pre)
+        r3 = cbr('reduce_conv_c3', fpn.reduce_conv_c3, c3)
+        p3pre = self.buf('p3pre', *r3.shape)
+        self.up_fwd(p4, r3, p3pre)
+        p3 = cbr('smooth_p3', fpn.smooth_p3, p3pre)
+        r2 = cbr('reduce_conv_c2', fpn.reduce_conv_c2, c2)
+        p2pre = self.buf('p2pre', *r2.shape)
+        self.up_fwd(p3, r2, p2pre)
+        p2 = cbr('smooth_p2', fpn.smooth_p2, p2pre)
+        Hq, Wq = p2.shape[1], p2.shape[2]
+        cat = self.buf('cat', N, Hq, Wq, 256)
+        for i, t in enumerate((p2, p3, p4, p5)):
+            self.up_fwd(t, None, cat, coff=64 * i)
+        fy = self.conv_fwd(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y')
+        s_, h_ = self.bn_coef(pre + 'conv.1', fpn.conv[1], fy, train)
+        f = self.bn_apply(fy, s_, h_, 'fpn/z')
+        head = m.segmentation_head
+        z1 = {}
+        for br in ('binarize', 'thresh'):
+            seq = getattr(head, br)
+            hp = 'segmentation_head.%s.' % br
+            ya = self.conv_fwd(hp + '0', f, seq[0], br + '/y0')
+            s_, h_ = self.bn_coef(hp + '1', seq[1], ya, train)
+            za = self.bn_apply(ya, s_, h_, br + '/z0')
+            yb = self.convT_fwd(hp + '3', za, seq[3], br + '/y1')
+            s_, h_ = self.bn_coef(hp + '4', seq[4], yb, train)
+            z1[br] = self.bn_apply(yb, s_, h_, br + '/z1')
+        ch = 3 if train else 2
+        out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
+        b6, t6 = head.binarize[6], head.thresh[6]
+        check(L.dbn_head_tail_fwd(z1['binarize'].data_ptr(), z1['thresh'].data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(),
+                                  b6.bias.data_ptr(), t6.bias.data_ptr(), out.data_ptr(), N, H // 2, W // 2, ch, float(head.k), st),
+              'head_tail_fwd')
+        if train:
+            self.saved_generation = self.generation
+            self.saved_out = out
+            self.saved_shape = (N, H, W)
+        return out
+
+    def _block_fwd(self, name, blk, x, train):
+        y1 = self.conv_fwd(name + '.conv1', x, blk.conv1, name + '/y1')
+        s1, h1 = self.bn_coef(name + '.bn1', blk.bn1, y1, train)
+        z1 = self.bn_apply(y1, s1, h1, name + '/z1')
+        y2 = self.conv_fwd(name + '.conv2', z1, blk.conv2, name + '/y2')
+        s2, h2 = self.bn_coef(name + '.bn2', blk.bn2, y2, train)
+        if blk.downsample is not None:
+            yd = self.conv_fwd(name + '.downsample.0', x, blk.downsample[0], name + '/yd')
+            sd, hd = self.bn_coef(name + '.downsample.1', blk.downsample[1], yd, train)
+            out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=yd, rsc=sd, rsh=hd)
+        else:
+            out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=x)
+        self.bufs[name + '/in'] = x
+        return out
+
+    # ----------------------------------------------------------------- backward
+    def backward(self, dpreds):
+        """Consumes d(loss)/d(preds) [N,3,H,W]; fills the flat gradient buffer."""
+        if self.saved_generation != self.generation:
+            raise RuntimeError('backward() without a matching train-mode forward (activations were overwritten)')
+        m, L, st = self.model, self.L, self.stream
+        N, H, W = self.saved_shape
+        B = self.bufs
+        out = self.saved_out
+        dpreds = dpreds.contiguous()
+        assert dpreds.shape == out.shape
+        head = m.segmentation_head
+        b6, t6 = head.binarize[6], head.thresh[6]
+        dz1b = self.buf('binarize/dz1', N, H // 2, W // 2, 64)
+        dz1t = self.buf('thresh/dz1', N, H // 2, W // 2, 64)
+        ws = self.scratch('_head_ws', L.dbn_head_tail_bwd_ws_floats())
+        G = self.grad_views
+        check(L.dbn_head_tail_bwd(B['binarize/z1'].data_ptr(), B['thresh/z1'].data_ptr(), b6.weight.data_ptr(),
+                                  t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), dz1b.data_ptr(), dz1t.data_ptr(),
+                                  G['segmentation_head.binarize.6.weight'].data_ptr(),
+                                  G['segmentation_head.binarize.6.bias'].data_ptr(),
+                                  G['segmentation_head.thresh.6.weight'].data_ptr(),
+                                  G['segmentation_head.thresh.6.bias'].data_ptr(), N, H // 2, W // 2, 3, float(head.k),
+                                  self.grad_scale, ws.data_ptr(), st), 'head_tail_bwd')
+        f = B['fpn/z']
+        df = self.buf('fpn/dz', *f.shape)
+        for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
+            seq = getattr(head, br)
+            hp = 'segmentation_head.%s.' % br
+            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], B[br + '/z1'], dz1, br + '/dy1')
+            dz0 = self.buf(br + '/dz0', *B[br + '/z0'].shape)
+            self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0)
+            dy0 = self.bn_backward(hp + '1', B[br + '/y0'], B[br + '/z0'], dz0, br + '/dy0')
+            self.conv_wgrad(hp + '0', dy0, f, seq[0])
+            self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0))
+        fpn = m.segmentation_body
+        pre = 'segmentation_body.'
+        dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], f, df, 'fpn/dy')
+        cat = B['cat']
+        self.conv_wgrad(pre + 'conv.0', dfy, cat, fpn.conv[0])
+        dcat = self.buf('dcat', *cat.shape)
+        self.conv_dgrad(pre + 'conv.0', dfy, fpn.conv[0], dcat, False)
+        dP = {}
+        for i, nm in enumerate(('smooth_p2', 'smooth_p3', 'smooth_p4', 'reduce_conv_c5')):
+            z = B[nm + '/z']
+            d = self.buf(nm + '/dz', *z.shape)
+            self.up_bwd(dcat, d, 64 * i, False)
+            dP[nm] = d
+
+        def cbr_bwd(name, mod, xin, dz, dx, dx_acc):
+            dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], B[name + '/z'], dz, name + '/dy')
+            self.conv_wgrad(pre + name + '.conv', dy, xin, mod.conv)
+            self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc)
+
+        # gradient slots of the backbone features (written first by the FPN reduce convs)
+        dC = {k: self.buf('d' + k, *B[k].shape) for k in ('backbone.layer1.1/out', 'backbone.layer2.1/out',
+                                                           'backbone.layer3.1/out', 'backbone.layer4.1/out')}
+        c2, c3, c4, c5 = (B['backbone.layer%d.1/out' % i] for i in (1, 2, 3, 4))
+        dc2, dc3, dc4, dc5 = (dC['backbone.layer%d.1/out' % i] for i in (1, 2, 3, 4))
+        # p2 = smooth_p2(p2pre), p2pre = up(p3) + r2
+        dp2pre = self.buf('dp2pre', *B['p2pre'].shape)
+        cbr_bwd('smooth_p2', fpn.smooth_p2, B['p2pre'], dP['smooth_p2'], dp2pre, False)
+        self.up_bwd(dp2pre, dP['smooth_p3'], 0, True)
+        cbr_bwd('reduce_conv_c2', fpn.reduce_conv_c2, c2, dp2pre, dc2, False)
+        dp3pre = self.buf('dp3pre', *B['p3pre'].shape)
+        cbr_bwd('smooth_p3', fpn.smooth_p3, B['p3pre'], dP['smooth_p3'], dp3pre, False)
+        self.up_bwd(dp3pre, dP['smooth_p4'], 0, True)
+        cbr_bwd('reduce_conv_c3', fpn.reduce_conv_c3, c3, dp3pre, dc3, False)
+        dp4pre = self.buf('dp4pre', *B['p4pre'].shape)
+        cbr_bwd('smooth_p4', fpn.smooth_p4, B['p4pre'], dP['smooth_p4'], dp4pre, False)
+        self.up_bwd(dp4pre, dP['reduce_conv_c5'], 0, True)
+        cbr_bwd('reduce_conv_c4', fpn.reduce_conv_c4, c4, dp4pre, dc4, False)
+        cbr_bwd('reduce_conv_c5', fpn.reduce_conv_c5, c5, dP['reduce_conv_c5'], dc5, False)
+        # backbone, deepest stage first; dC[...] already holds the FPN contribution
+        bb = m.backbone
+        dpool = self.buf('stem/dpool', *B['stem/pool'].shape)
+        for li in (4, 3, 2, 1):
+            layer = getattr(bb, 'layer%d' % li)
+            for bi in (1, 0):
+                name = 'backbone.layer%d.%d' % (li, bi)
+                dout = self.bufs['d' + name + '/out']
+                xin = B[name + '/in']
+                if bi == 1:
+                    dx, acc = self.buf('d' + 'backbone.layer%d.0/out' % li, *xin.shape), False
+                elif li > 1:
+                    dx, acc = dC['backbone.layer%d.1/out' % (li - 1)], True
+                else:
+                    dx, acc = dpool, False
+                self._block_bwd(name, layer[bi], xin, dout, dx, acc)
+        y0 = B['stem/y']
+        dz = self.buf('stem/dz', *y0.shape)
+        check(L.dbn_bnrelu_maxpool_bwd(y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
+                                       B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, H // 2, W // 2, 64, st),
+              'maxpool bwd')
+        dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy')
+        self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)
+        self.saved_generation = -1
+
+    def _block_bwd(self, name, blk, xin, dout, dx, dx_acc):
+        B = self.bufs
+        out = B[name + '/out']
+        has_down = blk.downsample is not None
+        if has_down:
+            dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], out, dout, name + '/dy2')
+        else:
+            # identity shortcut: the ReLU-masked gradient goes straight to the block input
+            dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], out, dout, name + '/dy2', gout=dx, gout_acc=dx_acc)
+            dx_acc = True
+        z1 = B[name + '/z1']
+        self.conv_wgrad(name + '.conv2', dy2, z1, blk.conv2)
+        dz1 = self.buf(name + '/dz1', *z1.shape)
+        self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False)
+        dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], z1, dz1, name + '/dy1')
+        self.conv_wgrad(name + '.conv1', dy1, xin, blk.conv1)
+        self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc)
+        if has_down:
+            dyd = self.bn_backward(name + '.downsample.1', B[name + '/yd'], out, dout, name + '/dyd')
+            self.conv_wgrad(name + '.downsample.0', dyd, xin, blk.downsample[0])
+            self.conv_dgrad(name + '.downsample.0', dyd, blk.downsample[0], dx, True)

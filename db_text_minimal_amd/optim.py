@@ -1,0 +1,55 @@
+"""Fused flat Adam — the optimizer of /root/reference/src/train.py:114-117
+(`torch.optim.Adam(lr=.005, betas=(.9,.999), eps=1e-8, weight_decay=0,
+amsgrad=False)`) as ONE HIP launch over the model's flat parameter buffer
+(dbn_adam_step: reads p,g,m,v, writes p,m,v = 28 B/param).
+"""
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class FusedAdam:
+    def __init__(self, model, lr=0.005, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError('weight_decay=0, amsgrad=False only (the reference configuration, example_config.yaml:68-77)')
+        self.model = model
+        self.engine = model.engine
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
+        self.param_groups = [dict(self.defaults, params=[p for _, p in self.engine.live_params])]
+        self.step_count = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    def zero_grad(self, set_to_none=True):
+        # every step overwrites the flat gradient buffer completely; nothing to clear
+        return None
+
+    def _ensure_state(self):
+        eng = self.engine
+        eng.ensure_flat()
+        if self.exp_avg is None or self.exp_avg.shape != eng.flat.shape or self.exp_avg.device != eng.flat.device:
+            self.exp_avg = torch.zeros_like(eng.flat)
+            self.exp_avg_sq = torch.zeros_like(eng.flat)
+
+    def step(self, grad_scale=1.0):
+        self._ensure_state()
+        eng = self.engine
+        g = self.param_groups[0]
+        self.step_count += 1
+        check(_lib.lib().dbn_adam_step(eng.flat.data_ptr(), eng.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), eng.flat.numel(), float(g['lr']), float(g['betas'][0]),
+                                       float(g['betas'][1]), float(g['eps']), self.step_count, float(grad_scale), eng.stream),
+              'adam_step')
+        eng.mark_params_dirty()
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
+
+    def load_state_dict(self, sd):
+        self._ensure_state()
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.param_groups[0].update(sd['param_groups'][0])

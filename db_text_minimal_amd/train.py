@@ -1,0 +1,90 @@
+"""The per-step training loop of /root/reference/src/train.py:155-172, MI355X-native.
+
+    preds = dbnet(batch['img'])                      # train.py:160
+    _batch = stack(prob_map, supervision_mask, thresh_map, text_area_map)   # :163-166
+    losses = criterion(preds, _batch)                # :167-168
+    optimizer.zero_grad(); total.backward(); optimizer.step()               # :169-172
+
+`DBTrainer.step` issues exactly that sequence as HIP kernels on one stream, with
+no autograd graph, no host synchronisation and (for world_size > 1) ONE
+all-reduce of the flat gradient buffer over RCCL/xGMI per step; the 1/world
+average is folded into the Adam kernel.  BatchNorm statistics and the loss
+normalisers stay per GPU (standard data-parallel semantics).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check
+from .optim import FusedAdam
+
+GT_KEYS = ('prob_map', 'supervision_mask', 'thresh_map', 'text_area_map')  # train.py:163-166 order
+
+
+def stack_gts(batch):
+    return torch.stack([batch[k] for k in GT_KEYS])
+
+
+class DBTrainer:
+    def __init__(self, model, criterion, optimizer=None, process_group=None, lr=0.005):
+        self.model = model
+        self.criterion = criterion
+        self.optimizer = optimizer if optimizer is not None else FusedAdam(model, lr=lr)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._gone = None
+        self.comm_stream = None
+
+    def _loss(self, preds, gts):
+        """dbn_db_loss_fwd + _bwd with d(total)=1; returns (losses[5], dpreds)."""
+        L = _lib.lib()
+        c = self.criterion
+        N, C, H, W = preds.shape
+        dev = preds.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if self._gone is None or self._gone.device != dev:
+            self._gone = torch.tensor([0., 0., 0., 0., 1.], device=dev)
+            self._coef = torch.empty(8, device=dev)
+            self._ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=dev)
+        losses = torch.empty(5, device=dev)
+        check(L.dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps,
+                                losses.data_ptr(), self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
+        dpreds = self.model.engine.buf('dpreds', N, C, H, W)
+        check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(), c.alpha, c.beta,
+                                N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')
+        return losses, dpreds
+
+    def step(self, img, gts):
+        """One training iteration.  img [N,3,H,W], gts [4,N,H,W] (or the reference's batch dict
+        as `img`, with gts=None).  Returns (preds, losses[5]) as device tensors; no host sync."""
+        if isinstance(img, dict):
+            batch = img
+            img, gts = batch['img'], stack_gts(batch)
+        model, eng = self.model, self.model.engine
+        if not model.training:
+            raise RuntimeError('DBTrainer.step requires model.train()')
+        preds = eng.forward(img, train=True)
+        assert preds.size(1) == 3  # train.py:161
+        gts = gts.contiguous().float()
+        losses, dpreds = self._loss(preds, gts)
+        self.optimizer.zero_grad()
+        eng.backward(dpreds)
+        scale = 1.0
+        if self.world > 1:
+            dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)  # the one collective per step
+            scale = 1.0 / self.world
+        self.optimizer.step(grad_scale=scale)
+        return preds, losses
+
+
+def init_distributed():
+    """One process per GPU, launched by torch.distributed.run; backend nccl == RCCL on ROCm."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    return rank, local, world

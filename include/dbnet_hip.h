@@ -1,0 +1,101 @@
+/* C ABI of libdbnet_hip.so — the MI355X (gfx950) DBNet hot path.
+ *
+ * The reference (huyhoang17/DB_text_minimal) is pure Python/PyTorch and has no FFI
+ * layer; its accelerator boundary is the nn.Module call surface of
+ *   DBTextModel.forward   /root/reference/src/models.py:34-48
+ *   DBLoss.forward        /root/reference/src/losses.py:105-139
+ *   the optimizer step    /root/reference/src/train.py:169-172
+ * The entry points below are what a binding for that surface calls (see
+ * INTEGRATION.md for the ctypes stub).  Conventions:
+ *   - all pointers are DEVICE pointers to fp32 unless stated otherwise; the library
+ *     never allocates, frees or retains them;
+ *   - activations are NHWC ([N,H,W,C], C % 4 == 0); the model input and the three
+ *     output maps are NCHW exactly like the reference's tensors;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it;
+ *   - return value 0 = ok, 1 = invalid argument, 1000+e = hipError_t e at launch.
+ */
+#ifndef DBNET_HIP_H
+#define DBNET_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolutions (replaces nn.Conv2d / nn.ConvTranspose2d fwd+bwd:
+ *      modules/resnet.py:27-34,70-91,167-172; modules/basic.py:17-25;
+ *      modules/segmentation_body.py:22-61; modules/segmentation_head.py:24-29,64-79) */
+
+/* OIHW weights -> GEMM panels [ceil(K/16)*4][Cd][4].  mode 0: forward conv panels
+ * (Cs = I rounded up to 4, Cd = O); mode 1: data-gradient / ConvTranspose panels
+ * (Cs = O, Cd = I).  `out` holds dbn_igemm_packed_floats(R*S*Cs, Cd) floats. */
+int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, float* out, void* stream);
+int dbn_igemm_packed_floats(int K, int Cd);
+
+/* dst[N,Hd,Wd,Cd] (+)= gather(src[N,Hs,Ws,Cs]) x panels + bias.
+ * mode 0: hs = hd*stride - pad + r (Conv2d forward; ConvTranspose2d data gradient)
+ * mode 1: hs = (hd + pad - r)/stride when divisible (Conv2d data gradient;
+ *         ConvTranspose2d forward).  bias may be NULL.  tile_hint 0 = auto. */
+int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                  int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream);
+
+/* grad_oihw[O][I][R][S] = scale * sum_p sm[p][o] * big[pixel(p)+tap][i];
+ * sm = [N,Ho,Wo,O] (output-side tensor), big = [N,H,W,Cb] (input-side, Cb >= I).
+ * slab: dbn_wgrad_splitk(...) * O * R*S*Cb floats of scratch. */
+int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S);
+int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                  int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
+
+/* ---- BatchNorm / ReLU / residual (nn.BatchNorm2d + nn.ReLU: resnet.py:73-91, basic.py:32-36) */
+int dbn_reduce_ws_floats(int C);
+int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                       float* ws, void* stream);
+int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
+                     float* scale, float* shift, void* stream);
+/* out = act(y*scale+shift [+ res*res_scale+res_shift | + res]) */
+int dbn_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                 const float* res_shift, float* out, long M, int C, int relu, void* stream);
+/* g = dout * (zmask > 0) (zmask NULL: g = dout); dy = BN backward of g; optional gout (+)= g */
+int dbn_bn_backward(const float* y, const float* zmask, const float* dout, const float* save_mean, const float* save_rstd,
+                    const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
+                    float grad_scale, float* ws, void* stream);
+int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream);
+
+/* ---- stem pooling (nn.MaxPool2d(3,2,1) over relu(bn1(.)): resnet.py:233-235) */
+int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
+                           void* stream);
+int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
+                           float* dz, int N, int H, int W, int C, void* stream);
+
+/* ---- FPN nearest upsample + add / concat (segmentation_body.py:79-87) */
+int dbn_nearest_up_fwd(const float* src, const float* addend, float* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
+                       int coff, void* stream);
+int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
+                       int accumulate, void* stream);
+
+/* ---- layout / misc */
+int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
+int dbn_add_inplace(const float* x, float* y, long n, void* stream);
+
+/* ---- DB head tail (segmentation_head.py:28-29,35-45,77-79,106-108) */
+int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,
+                      const float* bias_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
+int dbn_head_tail_bwd_ws_floats(void);
+int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
+                      const float* dpreds, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
+                      int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
+
+/* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W] */
+int dbn_db_loss_ws_bytes(void);
+int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                    float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
+int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, float alpha, float beta,
+                    int N, int H, int W, int channels, float* dpreds, void* stream);
+
+/* ---- optimizer (torch.optim.Adam, train.py:114-117,172) over one flat buffer */
+int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""-m gpu: DBLoss HIP kernels vs the reference's own outputs (golden KATs generated
+by tests/golden/make_golden.py from /root/reference/src/losses.py) and vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, report
+from db_text_minimal_amd import DBLoss
+from oracle import dbnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta']
+
+
+@pytest.mark.parametrize('tag', KATS)
+def test_loss_known_answers(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
+    preds = torch.from_numpy(z[tag + '/preds']).to(DEV).requires_grad_(True)
+    gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
+    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss()
+    res = crit(preds, gts)
+    res5 = res if isinstance(res, tuple) else (res, )
+    got = torch.stack([r.detach() for r in res5]).cpu()
+    report('losses ' + tag, got, torch.from_numpy(z[tag + '/losses']).float(), 1e-5, 1e-5)
+    res5[-1].backward()
+    ref = torch.from_numpy(z[tag + '/dpreds'])
+    scale = float(ref.abs().max())
+    report('dpreds ' + tag, preds.grad.cpu(), ref, 1e-6 * max(scale, 1e-3), 1e-4)
+
+
+def test_loss_individual_outputs_backward():
+    """backward through prob_loss / threshold_loss / binary_loss individually (the 5-tuple is differentiable)."""
+    img, gts = O.synthetic_batch(2, 32, seed=3)
+    g = torch.Generator().manual_seed(1)
+    P = torch.rand(2, 1, 32, 32, generator=g) * 0.9 + 0.05
+    T = torch.rand(2, 1, 32, 32, generator=g) * 0.9 + 0.05
+    preds = torch.cat([P, T, torch.sigmoid(50 * (P - T))], 1)
+    for idx in range(5):
+        pc = preds.clone().requires_grad_(True)
+        O.db_loss(pc, gts)[idx].backward()
+        pd = preds.to(DEV).requires_grad_(True)
+        DBLoss()(pd, gts.to(DEV))[idx].backward()
+        report('dpreds via output %d' % idx, pd.grad.cpu(), pc.grad, 1e-9, 1e-4)
+
+
+def test_loss_full_size_properties():
+    """BASELINE full size (16x640x640): closed-form properties instead of a slow CPU run."""
+    N, S = 16, 640
+    g = torch.Generator(device=DEV).manual_seed(0)
+    P = torch.rand(N, 1, S, S, device=DEV, generator=g) * 0.98 + 0.01
+    T = torch.rand(N, 1, S, S, device=DEV, generator=g) * 0.98 + 0.01
+    B = torch.sigmoid(50 * (P - T))
+    preds = torch.cat([P, T, B], 1).requires_grad_(True)
+    u = torch.rand(4, N, S, S, device=DEV, generator=g)
+    gts = torch.stack([(u[0] > 0.9).float(), (u[1] > 0.05).float(), 0.3 + 0.4 * u[2], (u[3] > 0.8).float()])
+    crit = DBLoss()
+    prob, thr, binl, pt, total = crit(preds, gts)
+    vals = [float(v) for v in (prob, thr, binl, pt, total)]
+    assert all(np.isfinite(vals))
+    assert abs(vals[3] - (vals[0] + 10 * vals[1])) < 1e-5 and abs(vals[4] - (vals[2] + vals[3])) < 1e-5
+    assert 0 <= vals[2] <= 1  # the reference's `assert loss <= 1` (losses.py:65)
+    # linearity of the gradient in the upstream grad; dice term independent of P
+    total.backward()
+    g1 = preds.grad.clone()
+    preds.grad = None
+    (3 * crit(preds, gts)[4]).backward()
+    assert torch.allclose(preds.grad, 3 * g1, rtol=1e-5, atol=1e-12)
+    # masked pixels: no L1 gradient where text_area == 0
+    assert float((g1[:, 1] * (1 - gts[3])).abs().max()) == 0
+    # fp64 closed form on device data (oracle function is dtype-agnostic)
+    ref = O.db_loss_closed_form(preds.detach().cpu(), gts.cpu())
+    for a, b in zip(vals, ref):
+        assert abs(a - b) <= 1e-5 + 1e-5 * abs(b), (vals, ref)

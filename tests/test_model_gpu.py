@@ -1,0 +1,163 @@
+"""-m gpu: DBTextModel / DBLoss / per-step loop on MI355X vs (a) golden vectors produced by the
+reference itself and (b) the CPU oracle run side by side.  north_star tolerance on the three
+output maps: 1e-3 abs / 1e-2 rel (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, report, report_robust
+from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
+from oracle import dbnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MAP_ATOL, MAP_RTOL = 1e-3, 1e-2  # BASELINE.json north_star
+
+
+def make_model(seed):
+    m = DBTextModel()
+    m.load_state_dict(O.new_state(seed))
+    return m.to(DEV)
+
+
+def sample_idx(numel, k=256):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * (numel // k)) + (numel // (2 * k))
+
+
+def check_summary(z, prefix, t, atol_scale=2e-4, rtol=2e-3):
+    """Compare a tensor with the stats/full/sample summary stored by make_golden.summarize."""
+    a = t.detach().double().cpu().reshape(-1)
+    st = z[prefix + '/stats']
+    scale = max(float(st[4]), -float(st[3]), 1e-12)  # max |ref|
+    n = a.numel()
+    if prefix + '/full' in z.files:
+        ref = torch.from_numpy(z[prefix + '/full']).double().reshape(-1)
+        report(prefix, a, ref, atol_scale * scale, rtol)
+    else:
+        ref = torch.from_numpy(z[prefix + '/sample']).double()
+        report(prefix + ' (sample)', a[torch.from_numpy(sample_idx(n))], ref, atol_scale * scale, rtol)
+    l2 = float(a.pow(2).sum().sqrt())
+    assert abs(l2 - st[2]) <= 1e-3 * st[2] + atol_scale * scale, (prefix, 'L2', l2, st[2])
+
+
+@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled'])
+def test_train_steps_vs_reference_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    n, size, seed, steps = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=float(z['img_scale']))
+    model = make_model(seed).train()
+    trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    img, gts = img.to(DEV), gts.to(DEV)
+    for it in range(steps):
+        preds, losses = trainer.step(img, gts)
+        if it == 0:
+            report(name + ' preds', preds.cpu(), torch.from_numpy(z['preds']), MAP_ATOL, MAP_RTOL)
+            report(name + ' preds (tight)', preds.cpu(), torch.from_numpy(z['preds']), 1e-4, 1e-3)
+            for k in [f[len('grad/'):-len('/stats')] for f in z.files if f.startswith('grad/') and f.endswith('/stats')]:
+                if k.endswith('.bias') and ('conv.bias' in k or k.endswith(('.0.bias', '.3.bias'))):
+                    continue  # conv bias ahead of train-mode BN: analytically zero, reference value is round-off noise
+                check_summary(z, 'grad/' + k, model.engine.grad_views[k])
+        report('%s losses step %d' % (name, it), losses.cpu().double(), torch.from_numpy(z['losses'][it]), 2e-4, 2e-3)
+    sd = model.state_dict()
+    for f in z.files:
+        if f.startswith('post/') and f.endswith('/stats'):
+            k = f[len('post/'):-len('/stats')]
+            if 'running' in k:
+                check_summary(z, 'post/' + k, sd[k], 1e-4, 1e-3)
+    assert int(sd['backbone.bn1.num_batches_tracked']) == steps
+
+
+def test_eval_mode_vs_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'eval_2x128.npz'))
+    n, size, seed, _ = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    model = make_model(seed).eval()
+    with torch.no_grad():
+        preds = model(img.to(DEV))
+        val = DBLoss()(preds, gts.to(DEV))
+    assert preds.shape == (n, 2, size, size)
+    report('eval preds', preds.cpu(), torch.from_numpy(z['preds']), MAP_ATOL, MAP_RTOL)
+    report('eval loss', val.cpu().double().view(1), torch.from_numpy(z['loss']).view(1), 1e-4, 1e-3)
+
+
+def test_autograd_surface_matches_trainer_and_oracle():
+    """The reference call surface (train.py:160-172) with torch.optim.Adam == the fused trainer == oracle."""
+    seed, n, size = 9, 2, 64
+    img, gts = O.synthetic_batch(n, size, seed=seed)
+    sd = O.new_state(seed)
+    opt_o = O.AdamState(lr=0.005)
+    m1 = make_model(seed).train()
+    crit = DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean').to(DEV)
+    opt1 = torch.optim.Adam(m1.parameters(), lr=0.005, weight_decay=0, amsgrad=False)
+    m2 = make_model(seed).train()
+    tr2 = DBTrainer(m2, DBLoss(), FusedAdam(m2, lr=0.005))
+    imgd, gtsd = img.to(DEV), gts.to(DEV)
+    for it in range(2):
+        preds_o, losses_o = O.train_step(sd, opt_o, img, gts)
+        preds1 = m1(imgd)
+        assert preds1.size(1) == 3
+        l1 = crit(preds1, gtsd)
+        opt1.zero_grad()
+        l1[4].backward()
+        opt1.step()
+        preds2, l2 = tr2.step(imgd, gtsd)
+        report('step %d preds autograd-vs-oracle' % it, preds1.detach().cpu(), preds_o, MAP_ATOL, MAP_RTOL)
+        report('step %d preds trainer-vs-autograd' % it, preds2.cpu(), preds1.detach().cpu(), 1e-6, 1e-6)
+        report('step %d losses' % it, torch.stack([v.detach() for v in l1]).cpu().double(), torch.tensor(losses_o).double(), 2e-4,
+               2e-3)
+        report('step %d losses trainer' % it, l2.cpu().double(), torch.tensor(losses_o).double(), 2e-4, 2e-3)
+    for k in ('backbone.fc.weight', 'backbone.smooth.weight'):
+        assert dict(m1.named_parameters())[k].grad is None  # dead params
+    for k in ('backbone.conv1.weight', 'segmentation_body.conv.0.weight', 'segmentation_head.thresh.6.weight',
+              'backbone.layer3.0.bn2.weight'):
+        report_robust('post-step param ' + k, m1.state_dict()[k].cpu(), sd[k], 2e-3, 1e-2, 0.995)
+        report_robust('post-step param (trainer) ' + k, m2.state_dict()[k].cpu(), m1.state_dict()[k].cpu(), 1e-4, 1e-3, 0.995)
+
+
+def test_cfg1_2x640_vs_reference_golden(golden_dir):
+    """BASELINE configs[0]: 2x3x640x640 forward + DBLoss (+ 3 Adam steps) vs the reference's numbers."""
+    z = np.load(os.path.join(golden_dir, 'cfg1_2x640.npz'))
+    n, size, seed, steps = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    model = make_model(seed).train()
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    img, gts = img.to(DEV), gts.to(DEV)
+    for it in range(steps):
+        preds, losses = tr.step(img, gts)
+        if it == 0:
+            for c, nm in enumerate('PTB'):
+                check_summary(z, 'preds_' + nm, preds[:, c], 1e-3, 1e-2)
+            for k in ('backbone.conv1.weight', 'backbone.layer2.0.conv1.weight', 'segmentation_body.conv.0.weight',
+                      'segmentation_head.binarize.0.weight', 'segmentation_head.thresh.3.weight',
+                      'segmentation_head.binarize.6.weight'):
+                check_summary(z, 'grad/' + k, model.engine.grad_views[k], 5e-4, 5e-3)
+        report('cfg1 losses step %d' % it, losses.cpu().double(), torch.from_numpy(z['losses'][it]), 5e-4, 5e-3)
+
+
+def test_full_size_bs16_properties():
+    """BASELINE configs[1] size (16x3x640x640): size-independent properties of the output maps."""
+    seed = 0
+    img, gts = O.synthetic_batch(16, 640, seed=seed + 100)
+    model = make_model(seed).train()
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    img, gts = img.to(DEV), gts.to(DEV)
+    preds, losses = tr.step(img, gts)
+    assert preds.shape == (16, 3, 640, 640) and torch.isfinite(preds).all() and torch.isfinite(losses).all()
+    assert float(preds.min()) >= 0 and float(preds.max()) <= 1
+    P, T, B = preds[:, 0], preds[:, 1], preds[:, 2]
+    assert torch.allclose(B, torch.sigmoid(50 * (P - T)), atol=1e-5)
+    # images are independent except through BN batch statistics: first two images of the batch
+    # must equal the 2-image run only if BN saw the same batch -> instead check determinism:
+    model2 = make_model(seed).train()
+    preds2 = model2.engine.forward(img, train=True)
+    assert torch.equal(preds, preds2), 'forward is not run-to-run deterministic'
+    g = model.engine.flat_grad
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    l0 = float(losses[4])
+    for _ in range(3):
+        _, losses = tr.step(img, gts)
+    assert float(losses[4]) < l0, 'loss did not decrease over 4 Adam steps on a fixed batch'

@@ -1,0 +1,273 @@
+"""-m gpu: every kernel of libdbnet_hip.so, called through the C ABI, against the
+plain fp32 CPU PyTorch op it replaces (same seeded inputs).  Tolerances: the
+igemm kernels use exact-f32 MFMA (k-ordered fmaf chains), so they agree with
+the CPU result to fp32 round-off (1e-4 abs / 1e-4 rel on O(1..10) values)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, L, igemm, nchw, nhwc, pack, reduce_ws, report, rnd, stream, wgrad
+from db_text_minimal_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def pad_c(x, c):
+    if x.shape[1] == c:
+        return x
+    return torch.cat([x, torch.zeros(x.shape[0], c - x.shape[1], *x.shape[2:])], 1)
+
+
+CONV_CASES = [
+    # N, Cin, Cout, k, s, p, H, W
+    (2, 64, 64, 3, 1, 1, 16, 12),
+    (1, 64, 128, 3, 2, 1, 18, 14),
+    (2, 64, 128, 1, 2, 0, 16, 16),
+    (2, 3, 64, 7, 2, 3, 32, 40),
+    (1, 256, 256, 3, 1, 1, 12, 12),
+    (3, 128, 64, 1, 1, 0, 9, 7),
+    (1, 512, 512, 3, 1, 1, 2, 2),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+def test_conv_forward(case, tile):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    b = rnd(Co, seed=3)
+    ref = F.conv2d(x, w, b, s, p)
+    Ho, Wo = ref.shape[2:]
+    xs = nhwc(pad_c(x, (Ci + 3) // 4 * 4))
+    y = torch.full((N, Ho, Wo, Co), float('nan'), device=DEV)
+    igemm(xs, pack(w, 0), b.to(DEV), y, k, s, p, 0, 0, tile)
+    report('conv fwd %s tile %d' % (case, tile), nchw(y), ref, 1e-4, 1e-4)
+    # accumulate flag, no bias
+    y2 = torch.ones((N, Ho, Wo, Co), device=DEV)
+    igemm(xs, pack(w, 0), None, y2, k, s, p, 0, 1, tile)
+    report('conv fwd acc %s' % (case, ), nchw(y2), F.conv2d(x, w, None, s, p) + 1, 1e-4, 1e-4)
+
+
+DGRAD_CASES = [(2, 64, 64, 3, 1, 1, 16, 12), (1, 64, 128, 3, 2, 1, 18, 14), (2, 64, 128, 1, 2, 0, 16, 16),
+               (1, 256, 256, 3, 1, 1, 12, 12), (1, 128, 256, 3, 2, 1, 8, 8), (1, 256, 512, 1, 2, 0, 4, 4)]
+
+
+@pytest.mark.parametrize('case', DGRAD_CASES)
+@pytest.mark.parametrize('tile', [0, 4])
+def test_conv_dgrad(case, tile):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=4)
+    (dx_ref, ) = torch.autograd.grad(y, x, dy)
+    dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)
+    igemm(nhwc(dy), pack(w, 1), None, dx, k, s, p, 1, 0, tile)
+    report('conv dgrad %s tile %d' % (case, tile), nchw(dx), dx_ref, 1e-4, 1e-4)
+
+
+WGRAD_CASES = DGRAD_CASES + [(2, 3, 64, 7, 2, 3, 32, 40), (4, 64, 64, 3, 1, 1, 40, 40), (1, 512, 512, 3, 1, 1, 2, 2)]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv_wgrad(case):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=4)
+    (dw_ref, ) = torch.autograd.grad(y, w, dy)
+    g = wgrad(nhwc(dy), nhwc(pad_c(x, (Ci + 3) // 4 * 4)), Co, Ci, k, s, p)
+    scale = float(dw_ref.abs().max())
+    report('conv wgrad %s' % (case, ), g.cpu(), dw_ref, 2e-5 * scale + 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64, 8, 6), (1, 64, 64, 16, 16)])
+def test_conv_transpose(shape):
+    N, Ci, Co, H, W = shape
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Ci, Co, 2, 2, seed=2, scale=0.1).requires_grad_(True)
+    b = rnd(Co, seed=3)
+    ref = F.conv_transpose2d(x, w, b, 2)
+    dy = rnd(*ref.shape, seed=5)
+    dx_ref, dw_ref = torch.autograd.grad(ref, (x, w), dy)
+    xs = nhwc(x.detach())
+    y = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
+    igemm(xs, pack(w.detach(), 1), b.to(DEV), y, 2, 2, 0, 1)
+    report('convT fwd', nchw(y), ref, 1e-4, 1e-4)
+    dys = nhwc(dy)
+    dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)
+    igemm(dys, pack(w.detach(), 0), None, dx, 2, 2, 0, 0)
+    report('convT dgrad', nchw(dx), dx_ref, 1e-4, 1e-4)
+    g = wgrad(xs, dys, Ci, Co, 2, 2, 0)
+    report('convT wgrad', g.cpu(), dw_ref, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 10), (128, 1, 7, 5), (256, 2, 6, 6), (512, 3, 2, 2), (64, 4, 48, 48)])
+def test_batchnorm_train(C, N, H, W):
+    x = (rnd(N, C, H, W, seed=1) * 2 + 3).requires_grad_(True)
+    gamma = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True)
+    beta = rnd(C, seed=3).requires_grad_(True)
+    rm, rv = rnd(C, seed=4), rnd(C, seed=5).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    res = rnd(N, C, H, W, seed=6)
+    ybn = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    out_ref = F.relu(ybn + res)
+    dout = rnd(N, C, H, W, seed=7)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(out_ref, (x, gamma, beta), dout)
+    M = N * H * W
+    xs = nhwc(x.detach())
+    dv = lambda t: t.detach().clone().to(DEV)
+    g_, b_, rm_, rv_ = dv(gamma), dv(beta), dv(rm), dv(rv)
+    sc, sh, mu, rs = (torch.empty(C, device=DEV) for _ in range(4))
+    ws = reduce_ws()
+    _lib.check(L().dbn_bn_train_stats(xs.data_ptr(), M, C, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(),
+                                      rv_.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(),
+                                      stream()), 'bn stats')
+    report('bn running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
+    report('bn running_var', rv_.cpu(), rv_ref, 1e-5, 1e-5)
+    ress = nhwc(res)
+    out = torch.empty_like(xs)
+    _lib.check(L().dbn_bn_apply(xs.data_ptr(), sc.data_ptr(), sh.data_ptr(), ress.data_ptr(), None, None, out.data_ptr(), M, C, 1,
+                                stream()), 'bn apply')
+    report('bn apply+res+relu', nchw(out), out_ref, 1e-5, 1e-5)
+    douts = nhwc(dout)
+    dy = torch.empty_like(xs)
+    gout = torch.ones_like(xs)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.check(L().dbn_bn_backward(xs.data_ptr(), out.data_ptr(), douts.data_ptr(), mu.data_ptr(), rs.data_ptr(), g_.data_ptr(),
+                                   dy.data_ptr(), gout.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), M, C, 1.0, ws.data_ptr(),
+                                   stream()), 'bn bwd')
+    report('bn bwd dx', nchw(dy), dx_ref, 2e-5, 1e-4)
+    report('bn bwd dgamma', dg.cpu(), dg_ref, 1e-4, 1e-4)
+    report('bn bwd dbeta', db.cpu(), db_ref, 1e-4, 1e-4)
+    report('bn bwd masked grad (acc)', nchw(gout), dout * (out_ref > 0) + 1, 1e-6, 1e-6)
+    # second-BN residual (downsample form) and eval coefficients
+    sc2, sh2 = rnd(C, seed=8).to(DEV), rnd(C, seed=9).to(DEV)
+    _lib.check(L().dbn_bn_apply(xs.data_ptr(), sc.data_ptr(), sh.data_ptr(), ress.data_ptr(), sc2.data_ptr(), sh2.data_ptr(),
+                                out.data_ptr(), M, C, 0, stream()), 'bn apply2')
+    ref2 = ybn + res * sc2.cpu().view(1, C, 1, 1) + sh2.cpu().view(1, C, 1, 1)
+    report('bn apply + bn(res)', nchw(out), ref2, 1e-5, 1e-5)
+    _lib.check(L().dbn_bn_eval_coef(C, g_.data_ptr(), b_.data_ptr(), rm_.data_ptr(), rv_.data_ptr(), 1e-5, sc.data_ptr(),
+                                    sh.data_ptr(), stream()), 'bn eval')
+    _lib.check(L().dbn_bn_apply(xs.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, None, None, out.data_ptr(), M, C, 0, stream()),
+               'bn apply3')
+    report('bn eval', nchw(out), F.batch_norm(x, rm_ref, rv_ref, gamma, beta, False, 0.1, 1e-5), 1e-5, 1e-5)
+    cs = torch.empty(C, device=DEV)
+    _lib.check(L().dbn_col_sum(xs.data_ptr(), M, C, cs.data_ptr(), 1.0, ws.data_ptr(), stream()), 'col_sum')
+    report('col_sum', cs.cpu(), x.detach().sum((0, 2, 3)), 1e-5 * M, 1e-5)
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 16, 12), (1, 7, 9), (1, 32, 32)])
+def test_bnrelu_maxpool(N, H, W):
+    C = 64
+    y = rnd(N, C, H, W, seed=1).requires_grad_(True)
+    sc, sh = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.3
+    z = F.relu(y * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1))
+    pool_ref = F.max_pool2d(z, 3, 2, 1)
+    dp = rnd(*pool_ref.shape, seed=4)
+    (dz_ref, ) = torch.autograd.grad(pool_ref, z, dp)
+    dz_ref = dz_ref * (z > 0)
+    ys, scd, shd = nhwc(y.detach()), sc.to(DEV), sh.to(DEV)
+    Ho, Wo = pool_ref.shape[2:]
+    pool = torch.empty(N, Ho, Wo, C, device=DEV)
+    _lib.check(L().dbn_bnrelu_maxpool_fwd(ys.data_ptr(), scd.data_ptr(), shd.data_ptr(), pool.data_ptr(), N, H, W, C, stream()),
+               'pool')
+    report('maxpool fwd', nchw(pool), pool_ref, 1e-6, 1e-6)
+    dz = torch.empty(N, H, W, C, device=DEV)
+    dps = nhwc(dp)
+    _lib.check(L().dbn_bnrelu_maxpool_bwd(ys.data_ptr(), scd.data_ptr(), shd.data_ptr(), pool.data_ptr(), dps.data_ptr(),
+                                          dz.data_ptr(), N, H, W, C, stream()), 'pool bwd')
+    report('maxpool bwd', nchw(dz), dz_ref, 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize('hs,ws,h,w', [(4, 4, 8, 8), (2, 3, 8, 12), (1, 1, 8, 8), (3, 5, 7, 9), (8, 8, 8, 8)])
+def test_nearest_upsample(hs, ws, h, w):
+    N, C = 2, 64
+    a = rnd(N, C, hs, ws, seed=1).requires_grad_(True)
+    b = rnd(N, C, h, w, seed=2)
+    ref = F.interpolate(a, size=(h, w)) + b
+    dout = rnd(N, C, h, w, seed=3)
+    (da_ref, ) = torch.autograd.grad(ref, a, dout)
+    as_, bs = nhwc(a.detach()), nhwc(b)
+    out = torch.empty(N, h, w, C, device=DEV)
+    _lib.check(L().dbn_nearest_up_fwd(as_.data_ptr(), bs.data_ptr(), out.data_ptr(), N, hs, ws, C, h, w, C, 0, stream()), 'up')
+    report('upsample_add fwd', nchw(out), ref, 1e-6, 1e-6)
+    cat = torch.zeros(N, h, w, 256, device=DEV)
+    _lib.check(L().dbn_nearest_up_fwd(as_.data_ptr(), None, cat.data_ptr(), N, hs, ws, C, h, w, 256, 128, stream()), 'upcat')
+    report('upsample_cat fwd', nchw(cat)[:, 128:192], F.interpolate(a.detach(), size=(h, w)), 1e-6, 1e-6)
+    assert float(cat[..., :128].abs().max()) == 0 and float(cat[..., 192:].abs().max()) == 0
+    dbig = torch.zeros(N, h, w, 256, device=DEV)
+    dbig[..., 64:128] = nhwc(dout)
+    da = torch.ones(N, hs, ws, C, device=DEV)
+    _lib.check(L().dbn_nearest_up_bwd(dbig.data_ptr(), da.data_ptr(), N, hs, ws, C, h, w, 256, 64, 1, stream()), 'up bwd')
+    report('upsample bwd (acc)', nchw(da), da_ref + 1, 1e-5, 1e-5)
+
+
+def test_input_pack():
+    x = rnd(2, 3, 10, 12, seed=1)
+    out = torch.empty(2, 10, 12, 4, device=DEV)
+    xd = x.to(DEV)
+    _lib.check(L().dbn_nchw3_to_nhwc4(xd.data_ptr(), out.data_ptr(), 2, 10, 12, stream()), 'pack input')
+    ref = torch.cat([x, torch.zeros(2, 1, 10, 12)], 1)
+    report('nchw3->nhwc4', nchw(out), ref, 0, 0)
+
+
+@pytest.mark.parametrize('N,Hq,Wq,ch', [(2, 8, 6, 3), (1, 5, 7, 2), (3, 16, 16, 3)])
+def test_head_tail(N, Hq, Wq, ch):
+    xb = rnd(N, 64, Hq, Wq, seed=1).abs().requires_grad_(True)
+    xt = rnd(N, 64, Hq, Wq, seed=2).abs().requires_grad_(True)
+    wb = rnd(64, 1, 2, 2, seed=3, scale=0.2).requires_grad_(True)
+    wt = rnd(64, 1, 2, 2, seed=4, scale=0.2).requires_grad_(True)
+    bb, bt = torch.tensor([0.1], requires_grad=True), torch.tensor([-0.2], requires_grad=True)
+    P = torch.sigmoid(F.conv_transpose2d(xb, wb, bb, 2))
+    T = torch.sigmoid(F.conv_transpose2d(xt, wt, bt, 2))
+    if ch == 3:
+        ref = torch.cat([P, T, torch.reciprocal(1 + torch.exp(-50 * (P - T)))], 1)
+    else:
+        ref = torch.cat([P, T], 1)
+    dpred = rnd(*ref.shape, seed=5)
+    grads = torch.autograd.grad(ref, (xb, xt, wb, bb, wt, bt), dpred)
+    d = lambda t: t.detach().contiguous().to(DEV)
+    xbs, xts = nhwc(xb.detach()), nhwc(xt.detach())
+    wbd, wtd, bbd, btd = d(wb), d(wt), d(bb), d(bt)
+    out = torch.full(ref.shape, float('nan'), device=DEV)
+    _lib.check(L().dbn_head_tail_fwd(xbs.data_ptr(), xts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), bbd.data_ptr(),
+                                     btd.data_ptr(), out.data_ptr(), N, Hq, Wq, ch, 50.0, stream()), 'head fwd')
+    report('head tail fwd', out.cpu(), ref, 2e-6, 1e-5)
+    if ch != 3:
+        return
+    dxb, dxt = torch.empty_like(xbs), torch.empty_like(xts)
+    dwb, dwt = torch.empty(256, device=DEV), torch.empty(256, device=DEV)
+    dbb, dbt = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    ws = torch.empty(L().dbn_head_tail_bwd_ws_floats(), device=DEV)
+    dpd = d(dpred)
+    _lib.check(L().dbn_head_tail_bwd(xbs.data_ptr(), xts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), out.data_ptr(),
+                                     dpd.data_ptr(), dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
+                                     dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, ch, 50.0, 1.0, ws.data_ptr(), stream()),
+               'head bwd')
+    sc = 1e-4
+    report('head bwd dxb', nchw(dxb), grads[0], sc, 1e-3)
+    report('head bwd dxt', nchw(dxt), grads[1], sc, 1e-3)
+    report('head bwd dwb', dwb.cpu().view(64, 1, 2, 2), grads[2], sc * 10, 1e-3)
+    report('head bwd dbias_b', dbb.cpu(), grads[3], sc * 10, 1e-3)
+    report('head bwd dwt', dwt.cpu().view(64, 1, 2, 2), grads[4], sc * 10, 1e-3)
+    report('head bwd dbias_t', dbt.cpu(), grads[5], sc * 10, 1e-3)
+
+
+def test_adam():
+    from oracle import dbnet_oracle as O
+    n = 1003 * 4
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2) * 1e-3, rnd(n, seed=3) * 1e-2
+    sd = {'w': p0.clone()}
+    opt = O.AdamState(lr=0.005)
+    opt.step(sd, {'w': g1})
+    opt.step(sd, {'w': g2})
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate((g1, g2)):
+        gd = (g * 4).to(DEV)  # grad_scale 0.25 undoes the x4 (the 1/world path)
+        _lib.check(L().dbn_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.005, 0.9, 0.999, 1e-8, i + 1,
+                                     0.25, stream()), 'adam')
+    report('adam params', p.cpu(), sd['w'], 1e-6, 1e-5)
+    report('adam exp_avg', m.cpu(), opt.m['w'], 1e-8, 1e-5)

@@ -1,0 +1,118 @@
+"""CPU: pin the oracle (oracle/dbnet_oracle.py) against golden vectors produced by the REFERENCE
+itself (tests/golden/make_golden.py imported /root/reference/src/{models,losses}.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dbnet_oracle as O
+
+
+def sample_idx(numel, k=256):
+    if numel <= k:
+        return np.arange(numel)
+    return (np.arange(k, dtype=np.int64) * (numel // k)) + (numel // (2 * k))
+
+
+def test_state_spec_matches_reference_layout():
+    spec = O.state_spec()
+    assert len(spec) == 211
+    n_params = sum(int(np.prod(s)) for k, s, kind in spec if kind not in ('bn_rm', 'bn_rv', 'bn_nbt'))
+    assert n_params == 13306922
+    live = sum(int(np.prod(s)) for k, s, kind in spec if kind not in ('bn_rm', 'bn_rv', 'bn_nbt', 'dead'))
+    assert live == 12269378
+
+
+@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled'])
+def test_oracle_train_steps_match_reference(golden_dir, name):
+    torch.set_num_threads(8)
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    n, size, seed, steps = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=float(z['img_scale']))
+    sd = O.new_state(seed)
+    opt = O.AdamState(lr=0.005)
+    for it in range(steps):
+        if it == 0:
+            preds, losses, grads = O.loss_and_grads(sd, img, gts)
+            assert np.abs(preds.numpy() - z['preds']).max() < 1e-6
+            for f in z.files:
+                if f.startswith('grad/') and f.endswith('/stats'):
+                    k = f[5:-6]
+                    a = grads[k].double().reshape(-1).numpy()
+                    st = z[f]
+                    assert abs(np.sqrt((a * a).sum()) - st[2]) <= 1e-5 * st[2] + 1e-12, k
+                    key = 'grad/' + k + ('/full' if 'grad/' + k + '/full' in z.files else '/sample')
+                    ref = z[key].reshape(-1)
+                    got = a if key.endswith('full') else a[sample_idx(a.size)]
+                    assert np.abs(got - ref).max() <= 1e-5 * max(abs(st[3]), abs(st[4])) + 1e-12, k
+            with torch.no_grad():
+                opt.step(sd, grads)
+        else:
+            preds, losses = O.train_step(sd, opt, img, gts)
+        assert np.allclose(losses, z['losses'][it], rtol=2e-4, atol=1e-6), (it, losses, z['losses'][it])
+
+
+def test_oracle_eval_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'eval_2x128.npz'))
+    n, size, seed, _ = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    with torch.no_grad():
+        preds = O.forward(O.new_state(seed), img, training=False)
+        val = O.db_loss(preds, gts)
+    assert preds.shape[1] == 2 and np.abs(preds.numpy() - z['preds']).max() < 1e-6
+    assert abs(float(val) - float(z['loss'])) < 1e-6
+
+
+@pytest.mark.parametrize('tag', ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta',
+                                 'reduction_none'])
+def test_oracle_loss_known_answers(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
+    preds = torch.from_numpy(z[tag + '/preds']).requires_grad_(True)
+    gts = torch.from_numpy(z[tag + '/gts'])
+    kw = {}
+    if tag == 'alpha_beta':
+        kw = dict(alpha=5.0, beta=2.0, negative_ratio=1)
+    if tag == 'reduction_none':
+        kw = dict(reduction='none')
+    res = O.db_loss(preds, gts, **kw)
+    res5 = res if isinstance(res, tuple) else (res, )
+    assert np.allclose([float(v) for v in res5], z[tag + '/losses'], rtol=1e-6, atol=1e-7)
+    res5[-1].backward()
+    assert np.allclose(preds.grad.numpy(), z[tag + '/dpreds'], rtol=1e-5, atol=1e-9)
+    if tag not in ('reduction_none', ):
+        # closed form evaluated by the HIP kernel == the literal reference formula (binary maps)
+        cf = O.db_loss_closed_form(preds.detach(), gts, **{k: v for k, v in kw.items() if k != 'reduction'})
+        ref = z[tag + '/losses']
+        cf = cf if len(ref) == 5 else cf[-1:]
+        assert np.allclose(cf, ref, rtol=2e-5, atol=1e-6), (cf, ref)
+
+
+def test_oracle_adam_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(1000, generator=g)
+    q = torch.nn.Parameter(p.clone())
+    topt = torch.optim.Adam([q], lr=0.005, weight_decay=0, amsgrad=False)
+    sd, opt = {'w': p.clone()}, O.AdamState(lr=0.005)
+    for i in range(3):
+        gr = torch.randn(1000, generator=g) * 10**(-i)
+        q.grad = gr.clone()
+        topt.step()
+        opt.step(sd, {'w': gr})
+    assert torch.allclose(sd['w'], q.data, rtol=1e-6, atol=1e-7)
+
+
+def test_dp_golden_is_mean_of_shard_grads(golden_dir):
+    """SURVEY.md §8e pin, oracle side: averaging per-shard oracle grads reproduces the reference's."""
+    z = np.load(os.path.join(golden_dir, 'dp_2x1x128.npz'))
+    _, size, seed, _ = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(2, size, seed=seed + 100)
+    acc = None
+    for r in range(2):
+        _, losses, gr = O.loss_and_grads(O.new_state(seed), img[r:r + 1], gts[:, r:r + 1])
+        assert abs(losses[4] - float(z['loss_rank%d' % r])) < 1e-5
+        acc = gr if acc is None else {k: acc[k] + gr[k] for k in gr}
+    for k in ('backbone.conv1.weight', 'segmentation_head.thresh.6.weight', 'backbone.layer4.1.bn2.weight'):
+        a = (acc[k] / 2).double().reshape(-1).numpy()
+        st = z['grad/' + k + '/stats']
+        assert abs(np.sqrt((a * a).sum()) - st[2]) <= 1e-5 * st[2]
