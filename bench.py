@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DBNet (ResNet18-FPN-DBHead) training images/s at 640x640, bs 16 per GPU,
+fp32, synthetic data (BASELINE.json `metric`, configs[1]; the path of SURVEY.md §8).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one iteration of the reference's loop (train.py:160-172): forward, DBLoss,
+backward, [one RCCL all-reduce of the flat gradients when N > 1], Adam — all HIP kernels of
+libdbnet_hip.so.  Inputs are resident in HBM before the timed region.  One process per GPU
+(launched by torch.distributed.run for N > 1); rank 0 prints ONE JSON line.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic FLOP/s from
+                HIP-event brackets around its launches inside the timed region, vs 157.3 TFLOP/s
+  kernels       the same figure for every igemm tile variant, the weight-gradient kernel and the
+                HBM-bound DB-head kernel (instrumented extra step after the timed region)
+  cpu_baseline  the CPU oracle (oracle/dbnet_oracle.py, plain PyTorch fp32) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem dgrad
+
+
+def synthetic(n, size, seed, dev):
+    """SURVEY.md §8d inputs, generated on the device (seed 42 + rank)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    img = torch.randn(n, 3, size, size, device=dev, generator=g)
+    u = torch.rand(4, n, size, size, device=dev, generator=g)
+    gts = torch.stack([(u[0] > 0.9).float(), (u[1] > 0.05).float(), 0.3 + 0.4 * u[2], (u[3] > 0.8).float()])
+    return img, gts
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle train step (fwd + DBLoss + backward + Adam) on the host cores, BASELINE configs[0]
+    shape (2x3x640x640).  Bounded sample: 1 warm-up + up to 3 timed steps."""
+    from oracle import dbnet_oracle as O
+    threads = torch.get_num_threads()
+    n, size = 2, 640
+    img, gts = O.synthetic_batch(n, size, seed=42)
+    sd = O.new_state(0)
+    opt = O.AdamState(lr=0.005)
+    O.train_step(sd, opt, img, gts)
+    times = []
+    t_all = time.time()
+    for _ in range(3):
+        t0 = time.time()
+        O.train_step(sd, opt, img, gts)
+        times.append(time.time() - t0)
+        if time.time() - t_all > max_seconds:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': round(n / med, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d train steps (fwd+DBLoss+bwd+Adam) of the CPU oracle at 2x3x640x640 fp32, median; '
+                      'torch CPU threads=%d' % (len(times), threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE: 16)')
+    ap.add_argument('--size', type=int, default=640)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
+    from db_text_minimal_amd.engine import KernelTimer
+    from db_text_minimal_amd.train import init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(42)  # utils.setup_determinism(42): same initial weights on every rank
+    model = DBTextModel().to(dev).train()
+    trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
+    img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
+    eng = model.engine
+
+    for _ in range(args.warmup):
+        trainer.step(img, gts)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer = KernelTimer(labels=('igemm_f32_kernel', ))
+    eng.prof = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds, losses = trainer.step(img, gts)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.prof = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(losses[4])
+    if not (final_loss == final_loss):
+        raise SystemExit('non-finite loss')
+
+    # dominant kernel, measured inside the timed region
+    summ = timer.summary()
+    dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
+    dname, d = dom
+    achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+    roofline = {'bound': 'mfma', 'kernel': dname, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': d['launches'] // args.steps, 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+                'share_of_step_time': round(d['ms'] / (dt * 1e3), 4)}
+
+    # every kernel family once more, outside the timed region
+    kernels = []
+    if rank == 0:
+        timer2 = KernelTimer()
+        eng.prof = timer2
+        trainer.step(img, gts)
+        torch.cuda.synchronize()
+        eng.prof = None
+        for name, v in sorted(timer2.summary().items(), key=lambda kv: -kv[1]['ms']):
+            ent = {'kernel': name, 'launches': v['launches'], 'ms_per_step': round(v['ms'], 3)}
+            if v['flops'] > 0:
+                a = v['flops'] / (v['ms'] * 1e-3) / 1e12
+                ent.update(bound='mfma', achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                           frac=round(a / PEAK_F32_MFMA_TFLOPS, 4))
+            elif v['bytes'] > 0:
+                a = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+                ent.update(bound='hbm', achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
+            kernels.append(ent)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        line = {
+            'metric': 'train images/sec @640x640 bs=16/GPU', 'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ResNet18-FPN-DBHead DBNet train step (fwd+DBLoss+bwd+Adam), %dx%d, bs %d/GPU, fp32, '
+                                   'random-init weights (BASELINE configs[1])' % (args.size, args.size, args.batch),
+                       'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
+                       'grad_allreduce': 'one RCCL all-reduce of the flat 49 MB fp32 gradient buffer per step' if world > 1 else None},
+            'roofline': roofline,
+            'step_tflops': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / ms, 2),
+            'kernels': kernels,
+            'final_total_loss': round(final_loss, 5),
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,6 +18,7 @@ SIGNATURES = {
     'dbn_pack_weights': 'piiiiipp',
     'dbn_igemm_packed_floats': 'ii',
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
+    'dbn_igemm_tile_config': 'ii',
     'dbn_wgrad_splitk': 'iiiiiii',
     'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
     'dbn_reduce_ws_floats': 'i',

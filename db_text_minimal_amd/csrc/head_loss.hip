@@ -169,11 +169,11 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
 }
 
 __global__ void fold_partials_d_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
     if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)part[(long)b * n + i];
-    out[i] = (float)(s * scale);
+    const double s = dbn_team32_fold(part, nb, n, i, l32);
+    if (l32 == 0) out[i] = (float)(s * scale);
 }
 
 // ----------------------------------------------------------------------------------
@@ -247,11 +247,21 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
 //   2: dice U   3: dice I   4: has_pos flag (n_pos + n_neg > 0 ... always 1; kept for clarity)
 __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb, long px, int CH, float alpha, float beta,
                                         float negative_ratio, float eps, float* __restrict__ losses, float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one 256-thread block: 32 lanes fold each of the NSUM (<= 8) partial columns, thread 0 finishes
+    __shared__ double sums[8];
+    {
+        const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        double t = 0.0;
+        if (k < NSUM)
+            for (int b = l32; b < nb; b += 32) t += part[(long)b * NSUM + k];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (l32 == 0) sums[k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double s[NSUM];
-    for (int k = 0; k < NSUM; ++k) s[k] = 0.0;
-    for (int b = 0; b < nb; ++b)
-        for (int k = 0; k < NSUM; ++k) s[k] += part[(long)b * NSUM + k];
+    for (int k = 0; k < NSUM; ++k) s[k] = sums[k];
     // losses.py:25-28 — int() truncations
     const long n_pos = (long)(float)s[S_POS];
     const long n_neg_expect = (long)((double)n_pos * (double)negative_ratio);
@@ -356,14 +366,14 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
     DBN_REQUIRE(channels == 2 || channels == 3);
     hipStream_t st = (hipStream_t)stream;
     const long npx = (long)N * Hq * Wq;
-    const int nb = dbn_grid(npx * 16, 256, 2048);
+    const int nb = dbn_grid(npx * 16, 256, 2047);
     hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, dxb, dxt, ws, N, Hq, Wq,
                        channels, kstep);
     // fold partials: layout [dwb 256][dbias_b][dwt 256][dbias_t] -> staged in the tail of ws, then scattered by 4 tiny copies
     float* folded = ws + (long)2048 * 2 * 257 - 2 * 257;
     // nb <= 2047 partial rows may be used without touching the tail
     if (nb >= 2048) return DBN_ERR_ARG;
-    hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(2 * 257, 64)), dim3(64), 0, st, ws, nb, 2 * 257, folded,
+    hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(2 * 257, 8)), dim3(256), 0, st, ws, nb, 2 * 257, folded,
                        grad_scale);
     (void)hipMemcpyAsync(dw_b, folded, 256 * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dbias_b, folded + 256, sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -383,7 +393,7 @@ int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, i
     hipStream_t st = (hipStream_t)stream;
     const int nb = dbn_grid((long)N * HW / 4, 256, 1024);
     hipLaunchKernelGGL(db_loss_fwd_kernel, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
-    hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
+    hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
                        beta, negative_ratio, eps, losses, coef);
     return dbn_status();
 }

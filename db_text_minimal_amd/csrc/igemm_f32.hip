@@ -387,6 +387,19 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
 
 extern "C" {
 
+// Tile configuration dbn_igemm_f32 picks for an M x Cd output (tile_hint 0):
+// 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64 — the largest tile that still yields
+// >= ~2 workgroups per CU on 256 CUs.
+int dbn_igemm_tile_config(int M, int Cd) {
+    const long b128 = (long)dbn_ceil_div(M, 128) * (Cd / 128);
+    const long b256 = (long)dbn_ceil_div(M, 256) * (Cd / 64);
+    const long b12864 = (long)dbn_ceil_div(M, 128) * (Cd / 64);
+    if (Cd % 128 == 0 && b128 >= 512) return 1;
+    if (b256 >= 512) return 2;
+    if (b12864 >= 512) return 3;
+    return 4;
+}
+
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
     DBN_REQUIRE(src && wpk && dst);
@@ -401,17 +414,7 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
     p.K = R * S * Cs;
     p.KT = (p.K + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
-    int cfg = tile_hint;
-    if (cfg <= 0) {
-        // choose the largest tile that still yields >= ~2 workgroups per CU
-        const long b128 = (long)dbn_ceil_div(p.M, 128) * (Cd / 128);
-        const long b256 = (long)dbn_ceil_div(p.M, 256) * (Cd / 64);
-        const long b12864 = (long)dbn_ceil_div(p.M, 128) * (Cd / 64);
-        if (Cd % 128 == 0 && b128 >= 512) cfg = 1;
-        else if (b256 >= 512) cfg = 2;
-        else if (b12864 >= 512) cfg = 3;
-        else cfg = 4;
-    }
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.M, Cd);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
     switch (cfg) {
         case 1: return launch_igemm<128, 128, 2, 2>(p, st);

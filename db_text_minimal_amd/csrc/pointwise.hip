@@ -58,13 +58,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // 8 channels per 256-thread block; 32 lanes fold the partials of one channel
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        s1 += (double)part[(long)b * 2 * C + c];
-        s2 += (double)part[(long)b * 2 * C + C + c];
-    }
+    const double s1 = dbn_team32_fold(part, nb, 2L * C, c, l32);
+    const double s2 = dbn_team32_fold(part, nb, 2L * C, (long)C + c, l32);
+    if (l32 != 0) return;
     const double pv = (double)y[c];
     const double dm = s1 / M;
     const double mean = pv + dm;
@@ -151,13 +151,13 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* _
 // dgamma, dbeta, and the two per-channel means used by the apply pass
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, int M, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2, float gscale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // 8 channels per 256-thread block; 32 lanes fold the partials of one channel
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        s1 += (double)part[(long)b * 2 * C + c];
-        s2 += (double)part[(long)b * 2 * C + C + c];
-    }
+    const double s1 = dbn_team32_fold(part, nb, 2L * C, c, l32);
+    const double s2 = dbn_team32_fold(part, nb, 2L * C, (long)C + c, l32);
+    if (l32 != 0) return;
     dbeta[c] = (float)(s1 * gscale);
     dgamma[c] = (float)(s2 * gscale);
     c1[c] = (float)(s1 / M);
@@ -199,11 +199,11 @@ __global__ void col_sum_kernel(const float* __restrict__ x, int M, int C, float*
 }
 
 __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
     if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)part[(long)b * n + i];
-    out[i] = (float)(s * scale);
+    const double s = dbn_team32_fold(part, nb, n, i, l32);
+    if (l32 == 0) out[i] = (float)(s * scale);
 }
 
 // ----------------------------------------------------------------------------------
@@ -410,7 +410,7 @@ int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const f
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), red_smem(C, 2), st, y, M, C, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nb, y, M, C, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, y, M, C, gamma, beta, eps,
                        momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
 }
@@ -445,7 +445,7 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* dout, const
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nbu), dim3(256), red_smem(C, 2), st, y, zmask, dout, save_mean, save_rstd, M,
                        C, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
                        grad_scale);
     const long total4 = (long)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, dout, save_mean, save_rstd,
@@ -458,7 +458,7 @@ int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
     hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), red_smem(C, 1), st, x, M, C, ws);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 64)), dim3(64), 0, st, ws, nb, C, out, scale);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, C, out, scale);
     return dbn_status();
 }
 

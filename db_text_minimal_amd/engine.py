@@ -28,6 +28,54 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def flat_layout(numels):
+    """Offsets (in floats, 16-byte aligned) of tensors packed into one flat buffer, and its size."""
+    offs, total = [], 0
+    for n in numels:
+        offs.append(total)
+        total += (n + 3) // 4 * 4
+    return offs, total
+
+
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2>', 2: 'igemm_f32_kernel<256,64,4,1>',
+                    3: 'igemm_f32_kernel<128,64,2,2>', 4: 'igemm_f32_kernel<64,64,2,2>'}
+
+
+class KernelTimer:
+    """HIP-event bracket around selected launches (events are recorded on the stream the
+    kernels are launched on).  `labels`: None = time everything, else a tuple of label prefixes."""
+
+    def __init__(self, labels=None):
+        self.labels = labels
+        self.records = []
+        self._open = None
+
+    def begin(self, label, flops=0.0, nbytes=0.0):
+        if self.labels is not None and not label.startswith(self.labels):
+            return
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._open = (label, flops, nbytes, e0, e1)
+
+    def end(self):
+        if self._open is not None:
+            self._open[4].record()
+            self.records.append(self._open)
+            self._open = None
+
+    def summary(self):
+        """label -> dict(launches, ms, flops, bytes); call after a device synchronize."""
+        out = {}
+        for label, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+            d['bytes'] += nbytes
+        return out
+
+
 class Engine:
     def __init__(self, model):
         self.model = model
@@ -45,6 +93,7 @@ class Engine:
         self.grad_scale = 1.0
         self._live = None
         self.nbt_pending = {}
+        self.prof = None  # optional KernelTimer
 
     # ------------------------------------------------------------------ memory
     @property
@@ -63,10 +112,7 @@ class Engine:
             base = self.flat.data_ptr()
             if all(p.data_ptr() == base + 4 * off for (_, p), off in zip(params, self.offsets)):
                 return
-        offs, total = [], 0
-        for _, p in params:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
+        offs, total = flat_layout([p.numel() for _, p in params])
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         grad = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views, self.grad_views = {}, {}
@@ -143,24 +189,39 @@ class Engine:
         assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
         wpk = self.pack(name, conv.weight, 0)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
+        if self.prof:
+            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k)
         check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
                                    k, s, p, 0, 0, 0, self.stream), 'igemm fwd ' + name)
+        if self.prof:
+            self.prof.end()
         return y
+
+    def _prof_igemm(self, M, Cd, flops):
+        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)], flops)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate):
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
         wpk = self.pack(name, conv.weight, 1)
+        if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
+            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k)
         check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
                                    conv.stride, conv.padding, 1, int(accumulate), 0, self.stream), 'igemm dgrad ' + name)
+        if self.prof:
+            self.prof.end()
 
     def wgrad(self, name, sm, big, O, I, k, stride, pad, gview):
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
         sk = self.L.dbn_wgrad_splitk(N, Ho, Wo, O, Cb, k, k)
         slab = self.scratch('_wgrad_slab', sk * O * k * k * Cb)
+        if self.prof:
+            self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k)
         check(self.L.dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k,
                                    k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
+        if self.prof:
+            self.prof.end()
 
     def conv_wgrad(self, name, dy, x, conv):
         self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
@@ -171,16 +232,24 @@ class Engine:
         N, H, W, C = x.shape
         wpk = self.pack(name, ct.weight, 1)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
+        if self.prof:
+            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4)
         check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
                                    2, 2, 0, 1, 0, 0, self.stream), 'igemm convT fwd ' + name)
+        if self.prof:
+            self.prof.end()
         return y
 
     def convT_bwd(self, name, dy, x, ct, dx):
         N, H2, W2, Co = dy.shape
         _, H, W, Ci = x.shape
         wpk = self.pack(name, ct.weight, 0)
+        if self.prof:
+            self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4)
         check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2, 2, 0, 0, 0,
                                    0, self.stream), 'igemm convT dgrad ' + name)
+        if self.prof:
+            self.prof.end()
         self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
         if ct.bias is not None:
             self.col_sum(dy, self.grad_views[name + '.bias'])
@@ -311,9 +380,13 @@ class Engine:
         ch = 3 if train else 2
         out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
         b6, t6 = head.binarize[6], head.thresh[6]
+        if self.prof:  # reads 2 x 64ch at (H/2, W/2), writes `ch` full-resolution maps
+            self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * (H // 2) * (W // 2) * 128 + 4.0 * N * H * W * ch)
         check(L.dbn_head_tail_fwd(z1['binarize'].data_ptr(), z1['thresh'].data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(),
                                   b6.bias.data_ptr(), t6.bias.data_ptr(), out.data_ptr(), N, H // 2, W // 2, ch, float(head.k), st),
               'head_tail_fwd')
+        if self.prof:
+            self.prof.end()
         if train:
             self.saved_generation = self.generation
             self.saved_out = out

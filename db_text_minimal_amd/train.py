@@ -27,6 +27,16 @@ def stack_gts(batch):
     return torch.stack([batch[k] for k in GT_KEYS])
 
 
+def allreduce_flat_grads(flat_grad, world, group=None):
+    """THE collective of a data-parallel step: one sum all-reduce over the flat fp32 gradient
+    buffer (12 269 378 elements = 49 MB for ResNet18-FPN-DBHead).  Returns the factor the
+    optimizer applies to turn the sum into the mean (folded into the Adam kernel)."""
+    if world <= 1:
+        return 1.0
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
 class DBTrainer:
     def __init__(self, model, criterion, optimizer=None, process_group=None, lr=0.005):
         self.model = model
@@ -71,10 +81,7 @@ class DBTrainer:
         losses, dpreds = self._loss(preds, gts)
         self.optimizer.zero_grad()
         eng.backward(dpreds)
-        scale = 1.0
-        if self.world > 1:
-            dist.all_reduce(eng.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)  # the one collective per step
-            scale = 1.0 / self.world
+        scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
         self.optimizer.step(grad_scale=scale)
         return preds, losses
 

@@ -37,6 +37,9 @@ int dbn_igemm_packed_floats(int K, int Cd);
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream);
 
+/* tile configuration chosen for tile_hint 0: 1=128x128, 2=256x64, 3=128x64, 4=64x64 */
+int dbn_igemm_tile_config(int M, int Cd);
+
 /* grad_oihw[O][I][R][S] = scale * sum_p sm[p][o] * big[pixel(p)+tap][i];
  * sm = [N,Ho,Wo,O] (output-side tensor), big = [N,H,W,Cb] (input-side, Cb >= I).
  * slab: dbn_wgrad_splitk(...) * O * R*S*Cb floats of scratch. */

@@ -217,14 +217,16 @@ def _nearest(x, size):
     return F.interpolate(x, size=size)  # default mode='nearest' (segmentation_body.py:79-87)
 
 
-def _head_branch(sd, p, x, training, upd, has_bias0):
+def _head_branch(sd, p, x, training, upd, has_bias0, taps=None, tag=''):
     # segmentation_head.py:24-29 / 64-79
-    y = F.conv2d(x, sd[p + '.0.weight'], sd[p + '.0.bias'] if has_bias0 else None, 1, 1)
-    y = F.relu(_bn(sd, p + '.1', y, training, upd))
-    y = F.conv_transpose2d(y, sd[p + '.3.weight'], sd[p + '.3.bias'], 2)
-    y = F.relu(_bn(sd, p + '.4', y, training, upd))
-    y = F.conv_transpose2d(y, sd[p + '.6.weight'], sd[p + '.6.bias'], 2)
-    return torch.sigmoid(y)
+    t = taps if taps is not None else {}
+    y0 = F.conv2d(x, sd[p + '.0.weight'], sd[p + '.0.bias'] if has_bias0 else None, 1, 1)
+    z0 = F.relu(_bn(sd, p + '.1', y0, training, upd))
+    y1 = F.conv_transpose2d(z0, sd[p + '.3.weight'], sd[p + '.3.bias'], 2)
+    z1 = F.relu(_bn(sd, p + '.4', y1, training, upd))
+    y2 = F.conv_transpose2d(z1, sd[p + '.6.weight'], sd[p + '.6.bias'], 2)
+    t[tag + '/y0'], t[tag + '/z0'], t[tag + '/y1'], t[tag + '/z1'] = y0, z0, y1, z1
+    return torch.sigmoid(y2)
 
 
 def forward(sd, x, training=True, update_stats=True, taps=None):
@@ -260,8 +262,8 @@ def forward(sd, x, training=True, update_stats=True, taps=None):
     f = F.relu(_bn(sd, b + 'conv.1', f, training, upd))
     t['p5'], t['p4'], t['p3'], t['p2'], t['fpn'] = p5, p4, p3, p2, f
     # DB head (segmentation_head.py:35-45)
-    P = _head_branch(sd, 'segmentation_head.binarize', f, training, upd, True)
-    T = _head_branch(sd, 'segmentation_head.thresh', f, training, upd, False)
+    P = _head_branch(sd, 'segmentation_head.binarize', f, training, upd, True, t, 'binarize')
+    T = _head_branch(sd, 'segmentation_head.thresh', f, training, upd, False, t, 'thresh')
     if training:
         B = torch.reciprocal(1 + torch.exp(-K_STEP * (P - T)))  # :106-108
         y = torch.cat((P, T, B), dim=1)

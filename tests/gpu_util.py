@@ -30,7 +30,9 @@ def report(tag, got, ref, atol, rtol):
     assert torch.isfinite(got).all(), tag + ': non-finite values'
     err = (got - ref).abs()
     tol = atol + rtol * ref.abs()
-    worst = float((err / tol).max()) if err.numel() else 0.0
+    worst = float((err / tol.clamp_min(1e-300)).max()) if err.numel() else 0.0
+    if float(err.max() if err.numel() else 0) == 0.0:
+        worst = 0.0
     msg = '%s: max abs err %.3e (ref max %.3e), worst err/tol %.3f' % (tag, float(err.max()) if err.numel() else 0,
                                                                       float(ref.abs().max()) if ref.numel() else 0, worst)
     print(msg)

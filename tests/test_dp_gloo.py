@@ -1,0 +1,70 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange of the per-step loop.  Each rank
+computes the gradients of ITS shard with the CPU oracle, lays them out with the product's flat
+layout and runs the product's one-collective-per-step function; the result must be the mean of
+the per-shard gradients, pinned against the reference-generated golden."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from db_text_minimal_amd.engine import DEAD_PREFIXES, flat_layout
+from db_text_minimal_amd.train import allreduce_flat_grads
+from oracle import dbnet_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, size, seed, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(4)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        img, gts = O.synthetic_batch(world, size, seed=seed + 100)
+        _, losses, grads = O.loss_and_grads(O.new_state(seed), img[rank:rank + 1], gts[:, rank:rank + 1])
+        keys = [k for k in O.trainable_keys() if not k.startswith(DEAD_PREFIXES)]
+        offs, total = flat_layout([grads[k].numel() for k in keys])
+        flat = torch.zeros(total)
+        for k, off in zip(keys, offs):
+            flat[off:off + grads[k].numel()] = grads[k].reshape(-1)
+        scale = allreduce_flat_grads(flat, world)  # one all_reduce call
+        flat *= scale
+        if rank == 0:
+            np.savez(out_path, flat=flat.numpy(), offs=np.array(offs), keys=np.array(keys), loss=losses[4])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_allreduce_matches_reference_golden(tmp_path, golden_dir):
+    z = np.load(os.path.join(golden_dir, 'dp_2x1x128.npz'))
+    _, size, seed, _ = (int(v) for v in z['meta'])
+    out = str(tmp_path / 'dp.npz')
+    mp.spawn(_worker, args=(2, _free_port(), size, seed, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert abs(float(r['loss']) - float(z['loss_rank0'])) < 1e-5
+    flat, offs, keys = r['flat'], r['offs'], list(r['keys'])
+    assert len(keys) == 111 and flat.size >= 12269378  # live parameter tensors / elements
+    for k in ('backbone.conv1.weight', 'backbone.layer4.1.conv2.weight', 'segmentation_body.conv.0.weight',
+              'segmentation_head.thresh.6.weight', 'backbone.layer2.0.downsample.1.bias'):
+        st = z['grad/' + k + '/stats']
+        i = keys.index(k)
+        n = int(np.prod([s for s in O.new_state(seed)[k].shape])) if k in O.new_state(0) else 0
+        a = flat[offs[i]:offs[i] + n].astype(np.float64)
+        assert abs(np.sqrt((a * a).sum()) - st[2]) <= 1e-5 * st[2], k
+        assert abs(a.sum() - st[0]) <= 1e-4 * st[1] + 1e-12, k
+
+
+def test_single_rank_is_a_noop():
+    g = torch.arange(8.)
+    assert allreduce_flat_grads(g, 1) == 1.0 and torch.equal(g, torch.arange(8.))

@@ -1,0 +1,117 @@
+"""CPU (-m "not gpu"): host-side logic of the drop-in surface and the C-ABI library itself
+(loads, exports every symbol include/dbnet_hip.h declares; no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from db_text_minimal_amd import DBLoss, DBTextModel, FusedAdam, _lib
+from oracle import dbnet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_decls():
+    hdr = open(os.path.join(ROOT, 'include', 'dbnet_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return re.findall(r'int\s+(dbn_\w+)\s*\(([^)]*)\)\s*;', hdr)
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    path = _lib.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    decls = header_decls()
+    assert len(decls) >= 24
+    for name, _ in decls:
+        assert hasattr(lib, name), 'libdbnet_hip.so does not export ' + name
+    assert set(n for n, _ in decls) == set(_lib.SIGNATURES), 'ctypes table and header disagree'
+
+
+def test_ctypes_signatures_match_header():
+    for name, args in header_decls():
+        kinds = ''
+        args = args.strip()
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                kinds += 'p' if '*' in a else 'l' if a.startswith('long') else 'f' if a.startswith('float') else 'i'
+        assert _lib.SIGNATURES[name] == kinds, name
+
+
+def test_size_queries_without_gpu():
+    L = _lib.lib()
+    assert L.dbn_igemm_packed_floats(7 * 7 * 4, 64) == 208 * 64  # K=196 padded to 208
+    assert L.dbn_reduce_ws_floats(512) == 1024 * 2 * 512
+    # bs16 640x640 shapes: FPN conv / head convs use the 128x128 tile, Cout=64 layers 256x64
+    assert L.dbn_igemm_tile_config(409600, 256) == 1
+    assert L.dbn_igemm_tile_config(409600, 64) == 2
+    assert L.dbn_igemm_tile_config(6400, 512) == 4
+    sk = L.dbn_wgrad_splitk(16, 160, 160, 64, 64, 3, 3)
+    assert 1 <= sk <= 409600 // 256
+
+
+def test_state_dict_keys_shapes_match_reference_layout():
+    m = DBTextModel()
+    sd = m.state_dict()
+    spec = O.state_spec()
+    assert list(sd.keys()) == [k for k, _, _ in spec]  # 211 keys, reference order
+    for k, shape, kind in spec:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sum(p.numel() for p in m.parameters()) == 13306922
+    assert m.name == 'resnet18_FPN_DBHead'  # models.py:31-32
+    m2 = DBTextModel()
+    m2.load_state_dict(O.new_state(3))
+    for k, v in O.new_state(3).items():
+        assert torch.equal(m2.state_dict()[k], v), k
+
+
+def test_reference_init_statistics():
+    """Init follows the reference: resnet.py:197-203 (conv N(0, sqrt(2/(k*k*Cout))), BN 1/0),
+    segmentation_head.py:47-53 (kaiming_normal_, BN w=1 b=1e-4)."""
+    torch.manual_seed(0)
+    m = DBTextModel()
+    w = m.backbone.layer2[0].conv1.weight
+    assert abs(float(w.std()) - (2.0 / (9 * 128))**0.5) < 2e-3
+    assert float(m.backbone.bn1.weight.min()) == 1 and float(m.backbone.bn1.bias.abs().max()) == 0
+    hw = m.segmentation_head.binarize[0].weight
+    assert abs(float(hw.std()) - (2.0 / (256 * 9))**0.5) < 1e-3
+    ct = m.segmentation_head.thresh[3].weight  # ConvTranspose2d: fan_in = Cout*k*k
+    assert abs(float(ct.std()) - (2.0 / (64 * 4))**0.5) < 5e-3
+    assert abs(float(m.segmentation_head.binarize[4].bias[0]) - 1e-4) < 1e-9
+    assert m.segmentation_head.thresh[0].bias is None and m.segmentation_head.binarize[0].bias is not None
+
+
+def test_no_cpu_fallback_and_error_surface():
+    m = DBTextModel()
+    with pytest.raises(RuntimeError, match='HIP device'):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match='only holds parameters'):
+        m.backbone.conv1(torch.zeros(1, 3, 8, 8))
+    crit = DBLoss()
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        crit(torch.rand(1, 3, 8, 8), torch.rand(4, 1, 8, 8))
+    with pytest.raises(AssertionError):
+        crit(torch.rand(3, 8, 8), torch.rand(4, 1, 8, 8))  # losses.py:113-114
+    with pytest.raises(NotImplementedError):
+        DBLoss(reduction='none')
+    with pytest.raises(NotImplementedError):
+        FusedAdam(m, weight_decay=0.1)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'db_text_minimal_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('the CPU oracle', ''), os.path.join(dirpath, f)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.lib()
