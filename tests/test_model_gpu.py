@@ -47,7 +47,7 @@ def check_grad_summary(z, prefix, t, l2_rtol=2e-2, sample_tol=5e-2):
     ref = torch.from_numpy(z[key]).double().reshape(-1)
     got = a if key.endswith('full') else a[torch.from_numpy(sample_idx(a.numel()))]
     err = float((got - ref).abs().max())
-    cos = float((got @ ref) / (got.norm() * ref.norm() + 1e-300))
+    cos = float((got @ ref) / (got.norm() * ref.norm())) if float(ref.norm()) > 0 and float(got.norm()) > 0 else 1.0
     l2 = float(a.pow(2).sum().sqrt())
     print('%s: |g|max %.3e  sample err/scale %.3e  cos %.6f  L2 %.5e vs %.5e' % (prefix, scale, err / scale, cos, l2, st[2]))
     assert torch.isfinite(a).all(), prefix
