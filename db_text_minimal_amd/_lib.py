@@ -20,6 +20,7 @@ SIGNATURES = {
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
     'dbn_wgrad_splitk': 'iiiiiii',
+    'dbn_wgrad_slab_floats': 'iiiiiii',
     'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
     'dbn_reduce_ws_floats': 'i',
     'dbn_bn_train_stats': 'piippffppppppp' + 'p',
@@ -41,6 +42,7 @@ SIGNATURES = {
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
+LONG_RETURN = {'dbn_wgrad_slab_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 
@@ -75,7 +77,7 @@ def lib():
         for name, sig in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the symbol is missing
             fn.argtypes = [_KIND[k] for k in sig]
-            fn.restype = _I
+            fn.restype = _L if name in LONG_RETURN else _I
         _lib = l
     return _lib
 

@@ -27,11 +27,23 @@ struct IgemmParams {
     const float* wpk;   // [KT*4][Cd][4]
     const float* bias;  // [Cd] or null
     float* dst;         // [N,Hd,Wd,Cd]
-    int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate;
+    int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, accumulate;
     int M, K, KT;
+    unsigned src_bytes;
 };
 
-template <int BM, int BN, int WM, int WN>
+constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
+
+__device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// MODE 0: hs = hd*stride - pad + r (forward conv);  MODE 1: hs = (hd + pad - r)/stride (data gradient /
+// transposed conv), stride in {1,2}.  The gather is branch-free: an invalid tap (padding, stride hole,
+// M or K tail) gets an out-of-range buffer offset, for which the hardware returns zeros.
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -53,28 +65,29 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- per-thread gather state -------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const int smask = p.stride - 1, sshift = p.stride >> 1;  // stride 1 or 2
+
+    // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
     const int a_chunk = tid & 3;
-    int a_hb[A_LD], a_wb[A_LD];
-    long a_base[A_LD];
-    bool a_ok[A_LD];
+    int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
     const int HWd = p.Hd * p.Wd;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         const int row = (tid >> 2) + j * (NT / 4);
         const int m = m0 + row;
-        a_ok[j] = m < p.M;
-        const int mm = a_ok[j] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / HWd;
         const int rem = mm - n * HWd;
         const int hd = rem / p.Wd;
         const int wd = rem - hd * p.Wd;
-        a_base[j] = (long)n * p.Hs * p.Ws * p.Cs;
-        if (p.mode == 0) {
-            a_hb[j] = hd * p.stride - p.pad;
+        a_nb[j] = n * p.Hs * p.Ws * p.Cs;
+        if (MODE == 0) {
+            a_hb[j] = ok ? hd * p.stride - p.pad : -(1 << 20);  // a far-away row can never be in range
             a_wb[j] = wd * p.stride - p.pad;
         } else {
-            a_hb[j] = hd + p.pad;
+            a_hb[j] = ok ? hd + p.pad : -(1 << 20);
             a_wb[j] = wd + p.pad;
         }
     }
@@ -85,44 +98,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     int k_r = k_tap / p.S;
     int k_s = k_tap - k_r * p.S;
 
-    f32x4 ra[A_LD], rb[B_LD];
-
-    auto gather = [&](int kt) {
+    unsigned aoff[A_LD];
+    auto next_offsets = [&]() {  // offsets of the current k position, then advance by one tile (16 k)
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            bool v = a_ok[j] && (kidx < p.K);
             int hs, ws;
-            if (p.mode == 0) {
+            bool v = kidx < p.K;
+            if (MODE == 0) {
                 hs = a_hb[j] + k_r;
                 ws = a_wb[j] + k_s;
             } else {
                 const int th = a_hb[j] - k_r, tw = a_wb[j] - k_s;
-                v = v && th >= 0 && tw >= 0;
-                if (p.stride == 1) {
-                    hs = th;
-                    ws = tw;
-                } else if (p.stride == 2) {
-                    v = v && (((th | tw) & 1) == 0);
-                    hs = th >> 1;
-                    ws = tw >> 1;
-                } else {
-                    hs = th / p.stride;
-                    ws = tw / p.stride;
-                    v = v && (hs * p.stride == th) && (ws * p.stride == tw);
-                }
+                v = v && ((th | tw) >= 0) && (((th | tw) & smask) == 0);
+                hs = th >> sshift;
+                ws = tw >> sshift;
             }
             v = v && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v) val = *reinterpret_cast<const f32x4*>(p.src + a_base[j] + ((long)hs * p.Ws + ws) * p.Cs + k_ci);
-            ra[j] = val;
+            const unsigned off = (unsigned)(a_nb[j] + (hs * p.Ws + ws) * p.Cs + k_ci) * 4u;
+            aoff[j] = v ? off : OOB_OFFSET;
         }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int idx = tid + j * NT;
-            const int c = idx / BN, n = idx - c * BN;
-            rb[j] = *reinterpret_cast<const f32x4*>(p.wpk + ((long)(kt * 4 + c) * p.Cd + n0 + n) * 4);
-        }
-        // advance the k-walk by one tile (16 k)
         kidx += 16;
         k_ci += 16;
         while (k_ci >= p.Cs) {
@@ -133,17 +127,34 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             }
         }
     };
+    const f32x4* bptr[B_LD];
+    int b_lds[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int idx = tid + j * NT;
+        const int c = idx / BN, n = idx - c * BN;
+        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk) + (long)c * p.Cd + n0 + n;
+        b_lds[j] = c * BS + n;
+    }
+    const long b_step = 4L * p.Cd;  // float4 per k-tile
+
+    f32x4 ra[A_LD], rb[B_LD];
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) ra[j] = buffer_load_f32x4(rsrc, aoff[j]);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            rb[j] = *bptr[j];
+            bptr[j] += b_step;
+        }
+    };
     auto stage = [&](int buf) {
         f32x4* As = smem + buf * STAGE;
         f32x4* Bs = As + 4 * AS;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int idx = tid + j * NT;
-            const int c = idx / BN, n = idx - c * BN;
-            Bs[c * BS + n] = rb[j];
-        }
+        for (int j = 0; j < B_LD; ++j) Bs[b_lds[j]] = rb[j];
     };
 
     f32x16 acc[MI][NI];
@@ -154,30 +165,37 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    gather(0);
+    next_offsets();
+    issue_loads();
+    next_offsets();  // offsets of tile 1
     stage(0);
     __syncthreads();
 
     for (int kt = 0; kt < p.KT; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < p.KT;
-        if (more) gather(kt + 1);
+        if (more) issue_loads();  // tile kt+1 in flight under the MFMAs of tile kt
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + 4 * AS;
+        // all fragment reads of the k-tile up front: the second half's LDS latency hides under the first half's MFMAs
+        f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            f32x4 af[MI], bf[NI];
 #pragma unroll
-            for (int a = 0; a < MI; ++a) af[a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+            for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bf[b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+            for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int a = 0; a < MI; ++a)
 #pragma unroll
                     for (int b = 0; b < NI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
+            if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
         }
         if (more) stage(buf ^ 1);
         __syncthreads();
@@ -205,9 +223,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_igemm(const IgemmParams& p, hipStream_t st) {
+int launch_igemm(const IgemmParams& p, int mode, hipStream_t st) {
     const int grid = dbn_ceil_div(p.M, BM) * (p.Cd / BN);
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    if (mode == 0)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     return dbn_status();
 }
 
@@ -220,17 +241,38 @@ struct WgradParams {
     float* slab;       // [splitk][O][J]
     int N, Ho, Wo, O, H, W, Cb, R, S, stride, pad;
     int P, J, pchunk;
+    float rcp_HWo, rcp_Wo;
+    unsigned sm_bytes, big_bytes;
 };
+
+// q = p / d, r = p % d for 0 <= p < 2^24 using a float reciprocal (exact after one correction step)
+__device__ __forceinline__ void divmod24(int p, int d, float rd, int& q, int& r) {
+    q = (int)((float)p * rd);
+    r = p - q * d;
+    if (r < 0) {
+        r += d;
+        --q;
+    } else if (r >= d) {
+        r -= d;
+        ++q;
+    }
+}
+
+// Position <-> index permutation of a tile edge of length B (B % 4 == 0): the staging threads
+// transpose 4x4 blocks (4 pixels x 4 channels) in registers and write channel 4c+e to LDS position
+// e*(B/4)+c, which keeps both the ds_write_b128 of the staging pass and the ds_read_b128 of the MFMA
+// fragments conflict-free.  The accumulators (and the slabs) therefore live in "position space".
+__host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { return 4 * (pos % (B / 4)) + pos / (B / 4); }
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int A_LD = 4 * BM / NT, B_LD = 4 * BN / NT;
-    constexpr int STAGE = 16 * (BM + BN);
-    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small");
-    __shared__ float smem[2 * STAGE];
+    constexpr int AS = BM + 2, BS = BN + 2;  // chunk strides in float4 units
+    constexpr int STAGE = 4 * AS + 4 * BS;
+    static_assert(BM + BN <= NT && BM % 64 == 0 && BN % 64 == 0, "staging roles must fit the workgroup in whole waves");
+    __shared__ f32x4 smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -244,54 +286,62 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int pend = min(p.P, pbeg + p.pchunk);
     const int KT = (pend - pbeg + 15) / 16;
 
-    // A slots: row = pixel within the k-tile, c4 = channel quad
-    constexpr int A_C4 = BM / 4, B_C4 = BN / 4;
-    const int a_c4 = tid % A_C4, a_row0 = tid / A_C4;
-    const int b_c4 = tid % B_C4, b_row0 = tid / B_C4;
-    constexpr int A_RSTEP = NT / A_C4, B_RSTEP = NT / B_C4;
-    // this thread's B column quad -> (tap, ci)
-    const int jj = j0 + 4 * b_c4;
-    const bool j_ok = jj < p.J;
+    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sm), 0, p.sm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.big), 0, p.big_bytes, 0x00020000);
+
+    // staging roles (wave-uniform): threads [0,BM) transpose the A panel (sm: 16 pixels x BM channels),
+    // threads [NT-BN,NT) the B panel (gathered big: 16 pixels x BN (tap,channel) columns).
+    const bool is_a = tid < BM;
+    const bool is_b = tid >= NT - BN;
+    const int slot = is_a ? tid : tid - (NT - BN);
+    const int qn = is_a ? BM / 4 : BN / 4;
+    const int s_c = slot % qn, s_g = slot / qn;  // column quad, pixel group (rows 4g..4g+3)
+    // B column quad -> (tap, ci)
+    const int jj = j0 + 4 * s_c;
+    const bool j_ok = is_b && jj < p.J;
     const int tap = j_ok ? jj / p.Cb : 0;
     const int ci = j_ok ? jj - tap * p.Cb : 0;
-    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int tr = tap / p.S - p.pad, ts = tap % p.S - p.pad;
     const int HWo = p.Ho * p.Wo;
+    const int lds_base = (is_a ? 0 : 4 * AS) + s_g * (is_a ? AS : BS) + s_c;
 
-    f32x4 ra[A_LD], rb[B_LD];
+    f32x4 rr[4];
     auto gather = [&](int kt) {
-        const int pk = pbeg + kt * 16;
+        const int pp0 = pbeg + kt * 16 + 4 * s_g;
+        if (is_a) {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const int pp = pk + a_row0 + j * A_RSTEP;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pp < pend) v = *reinterpret_cast<const f32x4*>(p.sm + (long)pp * p.O + o0 + 4 * a_c4);
-            ra[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int pp = pk + b_row0 + j * B_RSTEP;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pp < pend && j_ok) {
-                const int n = pp / HWo;
-                const int rem = pp - n * HWo;
-                const int oh = rem / p.Wo;
-                const int ow = rem - oh * p.Wo;
-                const int ih = oh * p.stride - p.pad + tr, iw = ow * p.stride - p.pad + ts;
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.big + (((long)n * p.H + ih) * p.W + iw) * p.Cb + ci);
+            for (int i = 0; i < 4; ++i) {
+                const int pp = pp0 + i;
+                const unsigned off = (unsigned)(pp * p.O + o0 + 4 * s_c) * 4u;
+                rr[i] = buffer_load_f32x4(rs_sm, pp < pend ? off : OOB_OFFSET);
             }
-            rb[j] = v;
+        } else if (is_b) {
+            int n, rem, oh, ow;
+            divmod24(pp0, HWo, p.rcp_HWo, n, rem);
+            divmod24(rem, p.Wo, p.rcp_Wo, oh, ow);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ih = oh * p.stride + tr, iw = ow * p.stride + ts;
+                const bool v = j_ok && (pp0 + i) < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const unsigned off = (unsigned)(((n * p.H + ih) * p.W + iw) * p.Cb + ci) * 4u;
+                rr[i] = buffer_load_f32x4(rs_big, v ? off : OOB_OFFSET);
+                // next pixel (row-major over n, oh, ow), branch-free carry
+                ++ow;
+                const bool cw = ow == p.Wo;
+                ow = cw ? 0 : ow;
+                oh += cw ? 1 : 0;
+                const bool ch = oh == p.Ho;
+                oh = ch ? 0 : oh;
+                n += ch ? 1 : 0;
+            }
         }
     };
     auto stage = [&](int buf) {
-        float* As = smem + buf * STAGE;
-        float* Bs = As + 16 * BM;
+        if (is_a || is_b) {
+            f32x4* dst = smem + buf * STAGE + lds_base;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j)
-            *reinterpret_cast<f32x4*>(As + (a_row0 + j * A_RSTEP) * BM + 4 * a_c4) = ra[j];
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            *reinterpret_cast<f32x4*>(Bs + (b_row0 + j * B_RSTEP) * BN + 4 * b_c4) = rb[j];
+            for (int e = 0; e < 4; ++e) dst[e * qn] = f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]};
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -311,47 +361,54 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         const int buf = kt & 1;
         const bool more = kt + 1 < KT;
         if (more) gather(kt + 1);
-        const float* As = smem + buf * STAGE;
-        const float* Bs = As + 16 * BM;
+        const f32x4* As = smem + buf * STAGE;
+        const f32x4* Bs = As + 4 * AS;
+        f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float af[MI], bf[NI];
+        for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int a = 0; a < MI; ++a) af[a] = As[(2 * kk + lh) * BM + wm * TM + a * 32 + li];
+            for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bf[b] = Bs[(2 * kk + lh) * BN + wn * TN + b * 32 + li];
-#pragma unroll
-            for (int a = 0; a < MI; ++a)
-#pragma unroll
-                for (int b = 0; b < NI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < MI; ++a)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
 
-    float* out = p.slab + (long)blockIdx.y * p.O * p.J;
+    // slab in position space: [split][O (tile-major positions)][Jp = njt*BN]
+    const int Jp = njt * BN;
+    float* out = p.slab + (long)blockIdx.y * p.O * Jp;
 #pragma unroll
     for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b) {
             const int col = j0 + wn * TN + b * 32 + li;
-            if (col < p.J) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = o0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    out[(long)row * p.J + col] = acc[a][b][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = o0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(long)row * Jp + col] = acc[a][b][r];
             }
         }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Cb, int I, int R, int S,
-                                    float* __restrict__ grad, float scale) {
-    const long total = (long)O * J;
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
+                                    int R, int S, float* __restrict__ grad, float scale) {
+    const long total = (long)O * Jp;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(idx / J);
-        const int j = (int)(idx - (long)o * J);
+        const int prow = (int)(idx / Jp);
+        const int pcol = (int)(idx - (long)prow * Jp);
+        const int o = (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
+        const int j = (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
+        if (j >= J) continue;
         const int tap = j / Cb, i = j - tap * Cb;
         if (i >= I) continue;
         double s = 0.0;
@@ -391,13 +448,25 @@ extern "C" {
 // 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64 — the largest tile that still yields
 // >= ~2 workgroups per CU on 256 CUs.
 int dbn_igemm_tile_config(int M, int Cd) {
-    const long b128 = (long)dbn_ceil_div(M, 128) * (Cd / 128);
-    const long b256 = (long)dbn_ceil_div(M, 256) * (Cd / 64);
-    const long b12864 = (long)dbn_ceil_div(M, 128) * (Cd / 64);
-    if (Cd % 128 == 0 && b128 >= 512) return 1;
-    if (b256 >= 512) return 2;
-    if (b12864 >= 512) return 3;
-    return 4;
+    // Workgroups are handed to the 256 CUs as they free up, so a launch lasts about
+    // ceil(blocks/256) tiles per CU; pick the tile that minimises tiles-per-CU x tile area / efficiency
+    // (efficiency = measured steady-state MFMA utilisation of each variant).
+    const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 64, 64};
+    const double eff[4] = {0.89, 0.83, 0.80, 0.72};
+    int best = 4;
+    double best_t = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        if (Cd % bn[c]) continue;
+        const long blocks = (long)dbn_ceil_div(M, bm[c]) * (Cd / bn[c]);
+        const long per_cu = (blocks + 255) / 256;
+        double t = (double)per_cu * bm[c] * bn[c] / eff[c];
+        if (blocks < 512) t *= 1.0 + 0.25 * (512 - blocks) / 512.0;  // too few workgroups to hide latency
+        if (t < best_t) {
+            best_t = t;
+            best = c + 1;
+        }
+    }
+    return best;
 }
 
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -405,22 +474,24 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
     DBN_REQUIRE(src && wpk && dst);
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
-    DBN_REQUIRE((long)N * Hd * Wd < (1L << 31) && (long)N * Hs * Ws * Cs < (1L << 40));
+    DBN_REQUIRE((long)N * Hd * Wd < (1L << 31) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
+    DBN_REQUIRE(stride == 1 || stride == 2);
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
-    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.mode = mode; p.accumulate = accumulate;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.M = N * Hd * Wd;
     p.K = R * S * Cs;
     p.KT = (p.K + 15) / 16;
+    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
     hipStream_t st = (hipStream_t)stream;
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.M, Cd);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
     switch (cfg) {
-        case 1: return launch_igemm<128, 128, 2, 2>(p, st);
-        case 2: return launch_igemm<256, 64, 4, 1>(p, st);
-        case 3: return launch_igemm<128, 64, 2, 2>(p, st);
-        default: return launch_igemm<64, 64, 2, 2>(p, st);
+        case 1: return launch_igemm<128, 128, 2, 2>(p, mode, st);
+        case 2: return launch_igemm<256, 64, 4, 1>(p, mode, st);
+        case 3: return launch_igemm<128, 64, 2, 2>(p, mode, st);
+        default: return launch_igemm<64, 64, 2, 2>(p, mode, st);
     }
 }
 
@@ -438,20 +509,46 @@ int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, 
     return dbn_status();
 }
 
-// Number of pixel splits dbn_wgrad_f32 will use (the caller sizes the slab workspace
-// as splitk * O * R*S*Cb floats).
+static void wgrad_tiles(int O, int J, int& bm, int& bn) {
+    bm = (O % 128 == 0 && J >= 128) ? 128 : 64;
+    bn = (J >= 128) ? 128 : 64;
+}
+
+// Number of pixel splits dbn_wgrad_f32 will use.
 int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     const long P = (long)N * Ho * Wo;
     const int J = R * S * Cb;
-    const int bm = (O % 128 == 0 && J >= 128) ? 128 : 64;
-    const int bn = (J >= 128) ? 128 : 64;
+    int bm, bn;
+    wgrad_tiles(O, J, bm, bn);
     const long tiles = (long)(O / bm) * ((J + bn - 1) / bn);
-    long sk = (1024 + tiles - 1) / tiles;
-    long maxsk = (P + 255) / 256;  // at least 256 pixels per split
-    if (sk > maxsk) sk = maxsk;
-    if (sk < 1) sk = 1;
+    // splits such that tiles*splits fills whole rounds of the 256 CUs (k workgroups per CU, k = 4..2)
+    long maxsk = (P + 511) / 512;  // at least 512 pixels per split
+    if (maxsk < 1) maxsk = 1;
+    long sk = 1;
+    double best = -1.0;
+    for (int k = 4; k >= 2; --k) {
+        long cand = (256L * k) / tiles;
+        if (cand < 1) cand = 1;
+        if (cand > maxsk) cand = maxsk;
+        const long blocks = tiles * cand;
+        const double util = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+        const double score = util + 0.02 * k;  // prefer more resident workgroups at equal utilisation
+        if (score > best) {
+            best = score;
+            sk = cand;
+        }
+    }
     long pchunk = ((P + sk - 1) / sk + 15) / 16 * 16;
     return (int)((P + pchunk - 1) / pchunk);
+}
+
+// Floats of slab scratch dbn_wgrad_f32 needs: splitk * O * (R*S*Cb rounded up to the tile width).
+long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
+    const int J = R * S * Cb;
+    int bm, bn;
+    wgrad_tiles(O, J, bm, bn);
+    const long Jp = (long)((J + bn - 1) / bn) * bn;
+    return (long)dbn_wgrad_splitk(N, Ho, Wo, O, Cb, R, S) * O * Jp;
 }
 
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
@@ -463,12 +560,19 @@ int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oi
     p.N = N; p.Ho = Ho; p.Wo = Wo; p.O = O; p.H = H; p.W = W; p.Cb = Cb; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.P = N * Ho * Wo;
     p.J = R * S * Cb;
+    DBN_REQUIRE((long)N * Ho * Wo < (1L << 24) - 64);
+    DBN_REQUIRE((long)N * Ho * Wo * O * 4 < 0xF0000000L && (long)N * H * W * Cb * 4 < 0xF0000000L);
+    p.rcp_HWo = 1.0f / (float)(Ho * Wo);
+    p.rcp_Wo = 1.0f / (float)Wo;
+    p.sm_bytes = (unsigned)((long)N * Ho * Wo * O * 4);
+    p.big_bytes = (unsigned)((long)N * H * W * Cb * 4);
     const int splitk = dbn_wgrad_splitk(N, Ho, Wo, O, Cb, R, S);
     p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
     hipStream_t st = (hipStream_t)stream;
-    const int bm = (O % 128 == 0 && p.J >= 128) ? 128 : 64;
-    const int bn = (p.J >= 128) ? 128 : 64;
-    dim3 grid((O / bm) * ((p.J + bn - 1) / bn), splitk);
+    int bm, bn;
+    wgrad_tiles(O, p.J, bm, bn);
+    const int njt = (p.J + bn - 1) / bn;
+    dim3 grid((O / bm) * njt, splitk);
     if (bm == 128 && bn == 128)
         hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
     else if (bn == 128)
@@ -477,8 +581,9 @@ int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oi
         hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
     int rc = dbn_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * p.J)), dim3(256), 0, st, slab, splitk, O, p.J, Cb, I, R, S,
-                       grad_oihw, scale);
+    const int Jp = njt * bn;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp)), dim3(256), 0, st, slab, splitk, O, p.J, Jp, bm, bn, Cb, I, R,
+                       S, grad_oihw, scale);
     return dbn_status();
 }
 

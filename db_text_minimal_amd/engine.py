@@ -15,6 +15,8 @@ Data layout in HBM
   * GEMM weight panels ([K/4][Cout][4]) are re-packed from the flat buffer
     whenever the parameters change.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -37,8 +39,8 @@ def flat_layout(numels):
     return offs, total
 
 
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2>', 2: 'igemm_f32_kernel<256,64,4,1>',
-                    3: 'igemm_f32_kernel<128,64,2,2>', 4: 'igemm_f32_kernel<64,64,2,2>'}
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d>'}  # rocprof names
 
 
 class KernelTimer:
@@ -50,13 +52,13 @@ class KernelTimer:
         self.records = []
         self._open = None
 
-    def begin(self, label, flops=0.0, nbytes=0.0):
+    def begin(self, label, flops=0.0, nbytes=0.0, tag=''):
         if self.labels is not None and not label.startswith(self.labels):
             return
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._open = (label, flops, nbytes, e0, e1)
+        self._open = (label, flops, nbytes, e0, e1, tag)
 
     def end(self):
         if self._open is not None:
@@ -67,7 +69,7 @@ class KernelTimer:
     def summary(self):
         """label -> dict(launches, ms, flops, bytes); call after a device synchronize."""
         out = {}
-        for label, flops, nbytes, e0, e1 in self.records:
+        for label, flops, nbytes, e0, e1, _ in self.records:
             d = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
@@ -94,6 +96,9 @@ class Engine:
         self._live = None
         self.nbt_pending = {}
         self.prof = None  # optional KernelTimer
+        self.overlap_wgrad = False  # optional: weight gradients on a second HIP stream (measured +1.3 %, off by default)
+        self._side = None
+        self._side_used = False
 
     # ------------------------------------------------------------------ memory
     @property
@@ -161,7 +166,36 @@ class Engine:
         return torch.cuda.current_stream(self.flat.device).cuda_stream
 
     def reduce_ws(self):
-        return self.scratch('_reduce_ws', self.L.dbn_reduce_ws_floats(512))
+        # one scratch per stream: the side (weight-gradient) stream reduces bias gradients concurrently
+        name = '_reduce_ws_side' if self._in_side else '_reduce_ws'
+        return self.scratch(name, self.L.dbn_reduce_ws_floats(512))
+
+    _in_side = False
+
+    @contextlib.contextmanager
+    def side_stream(self):
+        """Run the enclosed launches on the side stream, ordered after everything enqueued so far on
+        the current stream (the producer of dy).  Weight gradients only feed the optimizer, so they
+        overlap the HBM-bound BatchNorm-backward / dgrad chain; `join_side()` re-joins the streams."""
+        if not self.overlap_wgrad or (self.prof is not None and self.prof.labels is None):  # full profiling serialises
+            yield
+            return
+        if self._side is None or self._side.device != self.flat.device:
+            self._side = torch.cuda.Stream(device=self.flat.device)
+        main = torch.cuda.current_stream(self.flat.device)
+        self._side.wait_stream(main)
+        self._side_used = True
+        self._in_side = True
+        try:
+            with torch.cuda.stream(self._side):
+                yield
+        finally:
+            self._in_side = False
+
+    def join_side(self):
+        if self._side_used:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            self._side_used = False
 
     # ------------------------------------------------------------ weight panels
     def pack(self, name, w, mode, O=None, I=None):
@@ -190,22 +224,22 @@ class Engine:
         wpk = self.pack(name, conv.weight, 0)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
-            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k)
+            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
         check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
                                    k, s, p, 0, 0, 0, self.stream), 'igemm fwd ' + name)
         if self.prof:
             self.prof.end()
         return y
 
-    def _prof_igemm(self, M, Cd, flops):
-        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)], flops)
+    def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
+        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % mode, flops, 0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate):
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
         wpk = self.pack(name, conv.weight, 1)
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
-            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k)
+            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 1)
         check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
                                    conv.stride, conv.padding, 1, int(accumulate), 0, self.stream), 'igemm dgrad ' + name)
         if self.prof:
@@ -214,26 +248,26 @@ class Engine:
     def wgrad(self, name, sm, big, O, I, k, stride, pad, gview):
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
-        sk = self.L.dbn_wgrad_splitk(N, Ho, Wo, O, Cb, k, k)
-        slab = self.scratch('_wgrad_slab', sk * O * k * k * Cb)
+        slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k))
         if self.prof:
-            self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k)
+            self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
         check(self.L.dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k,
                                    k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
         if self.prof:
             self.prof.end()
 
     def conv_wgrad(self, name, dy, x, conv):
-        self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
-        if conv.bias is not None:
-            self.col_sum(dy, self.grad_views[name + '.bias'])
+        with self.side_stream():
+            self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
+            if conv.bias is not None:
+                self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def convT_fwd(self, name, x, ct, out_name):
         N, H, W, C = x.shape
         wpk = self.pack(name, ct.weight, 1)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
-            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4)
+            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 1)
         check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
                                    2, 2, 0, 1, 0, 0, self.stream), 'igemm convT fwd ' + name)
         if self.prof:
@@ -245,14 +279,15 @@ class Engine:
         _, H, W, Ci = x.shape
         wpk = self.pack(name, ct.weight, 0)
         if self.prof:
-            self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4)
+            self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4, 'convT dgrad ' + name, 0)
         check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2, 2, 0, 0, 0,
                                    0, self.stream), 'igemm convT dgrad ' + name)
         if self.prof:
             self.prof.end()
-        self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
-        if ct.bias is not None:
-            self.col_sum(dy, self.grad_views[name + '.bias'])
+        with self.side_stream():
+            self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
+            if ct.bias is not None:
+                self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def col_sum(self, x, out):
         C = x.shape[-1]
@@ -504,6 +539,7 @@ class Engine:
               'maxpool bwd')
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy')
         self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)
+        self.join_side()
         self.saved_generation = -1
 
     def _block_bwd(self, name, blk, xin, dout, dx, dx_acc):

@@ -42,8 +42,9 @@ int dbn_igemm_tile_config(int M, int Cd);
 
 /* grad_oihw[O][I][R][S] = scale * sum_p sm[p][o] * big[pixel(p)+tap][i];
  * sm = [N,Ho,Wo,O] (output-side tensor), big = [N,H,W,Cb] (input-side, Cb >= I).
- * slab: dbn_wgrad_splitk(...) * O * R*S*Cb floats of scratch. */
+ * slab: dbn_wgrad_slab_floats(...) floats of scratch (split-K partial sums, reduced deterministically). */
 int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S);
+long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S);
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                   int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
 

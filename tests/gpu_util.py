@@ -61,8 +61,7 @@ def igemm(src, wpk, bias, dst, R, stride, pad, mode, accumulate=0, tile=0):
 def wgrad(sm, big, O, I, k, stride, pad, scale=1.0):
     N, Ho, Wo, _ = sm.shape
     _, H, W, Cb = big.shape
-    sk = L().dbn_wgrad_splitk(N, Ho, Wo, O, Cb, k, k)
-    slab = torch.empty(sk * O * k * k * Cb, device=DEV)
+    slab = torch.empty(L().dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k), device=DEV)
     g = torch.full((O, I, k, k), float('nan'), device=DEV)
     _lib.check(L().dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k,
                                  stride, pad, scale, stream()), 'wgrad')
