@@ -97,7 +97,7 @@ def main():
         trainer.step(img, gts)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -110,7 +110,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.prof = None
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -128,6 +128,15 @@ def main():
                 'launches_per_step': d['launches'] // args.steps, 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                 'share_of_step_time': round(d['ms'] / (dt * 1e3), 4)}
+
+    # HBM traffic of that kernel from the committed PMC passes (profiles/, tools/pmc_traffic.py), per launch
+    try:
+        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(dname)
+        if tr:
+            roofline['traffic'] = tr['hbm_bytes_per_launch']
+            roofline['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_pmc_traffic.json)'
+    except (OSError, ValueError, KeyError):
+        pass
 
     # every kernel family once more, outside the timed region
     kernels = []
@@ -167,7 +176,7 @@ def main():
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,7 +15,8 @@ _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 # name -> argument kinds (p = device/host pointer, i = int, l = long, f = float); all return int
 SIGNATURES = {
-    'dbn_pack_weights': 'piiiiipp',
+    'dbn_pack_weights': 'piiiiiipp',
+    'dbn_igemm_panel_floats': 'iiiiii',
     'dbn_igemm_packed_floats': 'ii',
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
@@ -42,7 +43,7 @@ SIGNATURES = {
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
-LONG_RETURN = {'dbn_wgrad_slab_floats'}
+LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

@@ -19,17 +19,32 @@
 // double-buffered LDS image laid out [k/4][row][4] so that every lane fetches its four
 // k-values for four consecutive MFMAs with one conflict-free ds_read_b128.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
+// One GEMM problem of a launch.  A stride-2 data gradient / ConvTranspose forward is split into
+// up to four output-parity classes (each a dense stride-1 transposed conv over a quarter of the
+// output pixels with only the taps that hit it), so no zero taps are multiplied.
+struct IgemmClass {
+    int Hd, Wd;        // output sub-grid of this problem
+    int M, K, KT;      // rows, reduction length, k-tiles
+    int R, S;          // taps of this problem
+    int pad_h, pad_w;  // MODE 0: conv padding; MODE 1/2: hs = hd + pad_h - r
+    int oh0, ow0;      // MODE 2: dst pixel = (2*hd + oh0, 2*wd + ow0)
+    int tiles;         // workgroups of this problem
+    long wpk_off;      // float offset of its weight panels
+};
+
 struct IgemmParams {
     const float* src;   // [N,Hs,Ws,Cs]
-    const float* wpk;   // [KT*4][Cd][4]
+    const float* wpk;   // per problem: [KT*4][Cd][4]
     const float* bias;  // [Cd] or null
-    float* dst;         // [N,Hd,Wd,Cd]
-    int N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, accumulate;
-    int M, K, KT;
+    float* dst;         // [N,Hdf,Wdf,Cd]
+    int N, Hs, Ws, Cs, Cd, Hdf, Wdf, stride, accumulate, ncls;
+    int flags;  // experiment switches (DBN_IGEMM_FLAGS): 1 = s_setprio around the MFMA cluster
     unsigned src_bytes;
+    IgemmClass cls[4];
 };
 
 constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
@@ -40,9 +55,25 @@ __device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t rsrc, 
     return __builtin_bit_cast(f32x4, v);
 }
 
-// MODE 0: hs = hd*stride - pad + r (forward conv);  MODE 1: hs = (hd + pad - r)/stride (data gradient /
-// transposed conv), stride in {1,2}.  The gather is branch-free: an invalid tap (padding, stride hole,
-// M or K tail) gets an out-of-range buffer offset, for which the hardware returns zeros.
+// q = p / d, r = p % d for 0 <= p < 2^24 using a float reciprocal (exact after one correction step)
+__device__ __forceinline__ void divmod24(int p, int d, float rd, int& q, int& r) {
+    q = (int)((float)p * rd);
+    r = p - q * d;
+    if (r < 0) {
+        r += d;
+        --q;
+    } else if (r >= d) {
+        r -= d;
+        ++q;
+    }
+}
+
+// MODE 0: hs = hd*stride - pad + r (forward conv, stride 1 or 2)
+// MODE 1: hs = hd + pad - r        (stride-1 data gradient)
+// MODE 2: like MODE 1 per output-parity class, dst pixel = (2*hd+oh0, 2*wd+ow0) (stride-2 data
+//         gradient / ConvTranspose2d(k2,s2) forward)
+// The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
+// offset, for which the hardware returns zeros.
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParams p) {
     constexpr int NT = WM * WN * 64;
@@ -60,60 +91,59 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    int ci_ = 0;
+    if (MODE == 2) {
+        while (ci_ + 1 < p.ncls && tile >= p.cls[ci_].tiles) {
+            tile -= p.cls[ci_].tiles;
+            ++ci_;
+        }
+    }
+    const IgemmClass& q = p.cls[ci_];
     const int ntn = p.Cd / BN;
-    const int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
+    const int qM = q.M, qK = q.K, qKT = q.KT, qS = q.S, qHd = q.Hd, qWd = q.Wd;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
-    const int smask = p.stride - 1, sshift = p.stride >> 1;  // stride 1 or 2
 
     // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
     const int a_chunk = tid & 3;
     int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
-    const int HWd = p.Hd * p.Wd;
+    const int HWd = qHd * qWd;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         const int row = (tid >> 2) + j * (NT / 4);
         const int m = m0 + row;
-        const bool ok = m < p.M;
+        const bool ok = m < qM;
         const int mm = ok ? m : 0;
         const int n = mm / HWd;
         const int rem = mm - n * HWd;
-        const int hd = rem / p.Wd;
-        const int wd = rem - hd * p.Wd;
+        const int hd = rem / qWd;
+        const int wd = rem - hd * qWd;
         a_nb[j] = n * p.Hs * p.Ws * p.Cs;
         if (MODE == 0) {
-            a_hb[j] = ok ? hd * p.stride - p.pad : -(1 << 20);  // a far-away row can never be in range
-            a_wb[j] = wd * p.stride - p.pad;
+            a_hb[j] = ok ? hd * p.stride - q.pad_h : -(1 << 20);  // a far-away row can never be in range
+            a_wb[j] = wd * p.stride - q.pad_w;
         } else {
-            a_hb[j] = ok ? hd + p.pad : -(1 << 20);
-            a_wb[j] = wd + p.pad;
+            a_hb[j] = ok ? hd + q.pad_h : -(1 << 20);
+            a_wb[j] = wd + q.pad_w;
         }
     }
     // k-walk of this thread's chunk: k = kt*16 + 4*a_chunk = (r*S + s)*Cs + ci
     int kidx = 4 * a_chunk;
     int k_tap = kidx / p.Cs;
     int k_ci = kidx - k_tap * p.Cs;
-    int k_r = k_tap / p.S;
-    int k_s = k_tap - k_r * p.S;
+    int k_r = k_tap / qS;
+    int k_s = k_tap - k_r * qS;
 
     unsigned aoff[A_LD];
     auto next_offsets = [&]() {  // offsets of the current k position, then advance by one tile (16 k)
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            int hs, ws;
-            bool v = kidx < p.K;
-            if (MODE == 0) {
-                hs = a_hb[j] + k_r;
-                ws = a_wb[j] + k_s;
-            } else {
-                const int th = a_hb[j] - k_r, tw = a_wb[j] - k_s;
-                v = v && ((th | tw) >= 0) && (((th | tw) & smask) == 0);
-                hs = th >> sshift;
-                ws = tw >> sshift;
-            }
-            v = v && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+            const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
+            const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
+            const bool v = kidx < qK && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
             const unsigned off = (unsigned)(a_nb[j] + (hs * p.Ws + ws) * p.Cs + k_ci) * 4u;
             aoff[j] = v ? off : OOB_OFFSET;
         }
@@ -121,7 +151,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         k_ci += 16;
         while (k_ci >= p.Cs) {
             k_ci -= p.Cs;
-            if (++k_s == p.S) {
+            if (++k_s == qS) {
                 k_s = 0;
                 ++k_r;
             }
@@ -133,7 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     for (int j = 0; j < B_LD; ++j) {
         const int idx = tid + j * NT;
         const int c = idx / BN, n = idx - c * BN;
-        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk) + (long)c * p.Cd + n0 + n;
+        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk + q.wpk_off) + (long)c * p.Cd + n0 + n;
         b_lds[j] = c * BS + n;
     }
     const long b_step = 4L * p.Cd;  // float4 per k-tile
@@ -171,9 +201,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     stage(0);
     __syncthreads();
 
-    for (int kt = 0; kt < p.KT; ++kt) {
+    for (int kt = 0; kt < qKT; ++kt) {
         const int buf = kt & 1;
-        const bool more = kt + 1 < p.KT;
+        const bool more = kt + 1 < qKT;
         if (more) issue_loads();  // tile kt+1 in flight under the MFMAs of tile kt
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + 4 * AS;
@@ -186,6 +216,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 #pragma unroll
             for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
         }
+        if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -197,23 +228,33 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
             if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
         }
+        if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
 #pragma unroll
     for (int a = 0; a < MI; ++a) {
 #pragma unroll
-        for (int b = 0; b < NI; ++b) {
-            const int col = n0 + wn * TN + b * 32 + li;
-            const float bv = p.bias ? p.bias[col] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < qM) {
+                long doff;
+                if (MODE == 2) {  // scatter to the parity class's pixels of the full-resolution output
+                    int n, rem, hd, wd;
+                    divmod24(row, HWd, rcp_hw, n, rem);
+                    divmod24(rem, qWd, rcp_w, hd, wd);
+                    doff = (((long)n * p.Hdf + 2 * hd + q.oh0) * p.Wdf + 2 * wd + q.ow0) * p.Cd;
+                } else {
+                    doff = (long)row * p.Cd;
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < p.M) {
-                    float* d = p.dst + (long)row * p.Cd + col;
-                    float v = acc[a][b][r] + bv;
+                for (int b = 0; b < NI; ++b) {
+                    const int col = n0 + wn * TN + b * 32 + li;
+                    float* d = p.dst + doff + col;
+                    float v = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
                     if (p.accumulate) v += *d;
                     *d = v;
                 }
@@ -223,12 +264,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 }
 
 template <int BM, int BN, int WM, int WN>
-int launch_igemm(const IgemmParams& p, int mode, hipStream_t st) {
-    const int grid = dbn_ceil_div(p.M, BM) * (p.Cd / BN);
+int launch_igemm(IgemmParams& p, int mode, hipStream_t st) {
+    int grid = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+        p.cls[c].tiles = dbn_ceil_div(p.cls[c].M, BM) * (p.Cd / BN);
+        grid += p.cls[c].tiles;
+    }
     if (mode == 0)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     return dbn_status();
 }
 
@@ -244,19 +291,6 @@ struct WgradParams {
     float rcp_HWo, rcp_Wo;
     unsigned sm_bytes, big_bytes;
 };
-
-// q = p / d, r = p % d for 0 <= p < 2^24 using a float reciprocal (exact after one correction step)
-__device__ __forceinline__ void divmod24(int p, int d, float rd, int& q, int& r) {
-    q = (int)((float)p * rd);
-    r = p - q * d;
-    if (r < 0) {
-        r += d;
-        --q;
-    } else if (r >= d) {
-        r -= d;
-        ++q;
-    }
-}
 
 // Position <-> index permutation of a tile edge of length B (B % 4 == 0): the staging threads
 // transpose 4x4 blocks (4 pixels x 4 channels) in registers and write channel 4c+e to LDS position
@@ -417,28 +451,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
     }
 }
 
+// OIHW -> [Kpad/4][Cd][4] panels.  mode 0: k = (r*S+s)*Cs + cs -> w[cd][cs][r][s] (cs < I);
+// mode 1: data-gradient panels, taps r = r0 + rstep*r', s = s0 + rstep*s' (R', S' of them):
+//         k = (r'*S'+s')*Cs + cs -> w[cs][cd][r][s].
 __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int K,
-                                    int Kpad, float* __restrict__ out) {
+                                    int Kpad, int Rp, int Sp, int r0, int s0, int rstep, float* __restrict__ out) {
     const long total = (long)Kpad * Cd;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 3);
-        const long q = idx >> 2;
-        const int cd = (int)(q % Cd);
-        const int kc = (int)(q / Cd);
+        const long qd = idx >> 2;
+        const int cd = (int)(qd % Cd);
+        const int kc = (int)(qd / Cd);
         const int k = 4 * kc + e;
         float v = 0.f;
         if (k < K) {
             const int tap = k / Cs, cs = k - tap * Cs;
-            const int r = tap / S, s = tap - r * S;
+            const int rp = tap / Sp, sp = tap - rp * Sp;
+            const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
             if (mode == 0) {
-                if (cs < I) v = w[(((long)cd * I + cs) * R + r) * S + s];
+                if (cs < I) v = w[(((long)cd * I + cs) * R + r) * S + sx];
             } else {
-                v = w[(((long)cs * I + cd) * R + r) * S + s];
+                v = w[(((long)cs * I + cd) * R + r) * S + sx];
             }
         }
         out[idx] = v;
     }
 }
+
+inline int taps_of_parity(int R, int ph) { return (R - ph + 1) / 2; }
 
 }  // namespace
 
@@ -469,44 +509,123 @@ int dbn_igemm_tile_config(int M, int Cd) {
     return best;
 }
 
+static int igemm_dispatch(IgemmParams& p, int kmode, int tile_hint, hipStream_t st) {
+    long Mmax = 0;
+    for (int c = 0; c < p.ncls; ++c) Mmax = p.cls[c].M > Mmax ? p.cls[c].M : Mmax;
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config((int)Mmax * (p.ncls > 1 ? p.ncls : 1), p.Cd);
+    if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
+    switch (cfg) {
+        case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, st);
+        case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, st);
+        case 3: return launch_igemm<128, 64, 2, 2>(p, kmode, st);
+        default: return launch_igemm<64, 64, 2, 2>(p, kmode, st);
+    }
+}
+
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
     DBN_REQUIRE(src && wpk && dst);
-    DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
-    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
-    DBN_REQUIRE((long)N * Hd * Wd < (1L << 31) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
-    DBN_REQUIRE(stride == 1 || stride == 2);
+    DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
+    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
+    DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
+    hipStream_t st = (hipStream_t)stream;
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
-    p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Hd = Hd; p.Wd = Wd; p.Cd = Cd;
-    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
-    p.M = N * Hd * Wd;
-    p.K = R * S * Cs;
-    p.KT = (p.K + 15) / 16;
-    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
-    hipStream_t st = (hipStream_t)stream;
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.M, Cd);
-    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
-    switch (cfg) {
-        case 1: return launch_igemm<128, 128, 2, 2>(p, mode, st);
-        case 2: return launch_igemm<256, 64, 4, 1>(p, mode, st);
-        case 3: return launch_igemm<128, 64, 2, 2>(p, mode, st);
-        default: return launch_igemm<64, 64, 2, 2>(p, mode, st);
+    p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
+    p.stride = stride; p.accumulate = accumulate;
+    {
+        static int flags = -1;
+        if (flags < 0) {
+            const char* e = getenv("DBN_IGEMM_FLAGS");
+            flags = e ? atoi(e) : 0;
+        }
+        p.flags = flags;
     }
+    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
+    if (!(mode == 1 && stride == 2)) {
+        p.ncls = 1;
+        IgemmClass& q = p.cls[0];
+        q.Hd = Hd; q.Wd = Wd; q.M = N * Hd * Wd; q.R = R; q.S = S;
+        q.K = R * S * Cs; q.KT = (q.K + 15) / 16;
+        q.pad_h = q.pad_w = pad; q.oh0 = q.ow0 = 0; q.wpk_off = 0; q.tiles = 0;
+        return igemm_dispatch(p, mode, tile_hint, st);
+    }
+    // stride-2 data gradient / ConvTranspose forward: one problem per output parity class, heaviest first
+    p.ncls = 0;
+    long off = 0;
+    int covered = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int Rc = taps_of_parity(R, ph), Sc = taps_of_parity(S, pw);
+            const int oh0 = (((ph - pad) % 2) + 2) % 2, ow0 = (((pw - pad) % 2) + 2) % 2;
+            const int Hc = (Hd - oh0 + 1) / 2, Wc = (Wd - ow0 + 1) / 2;
+            const int K = Rc * Sc * Cs, Kpad = ((K + 15) / 16) * 16;
+            if (Rc > 0 && Sc > 0 && Hc > 0 && Wc > 0) {
+                IgemmClass& q = p.cls[p.ncls++];
+                q.Hd = Hc; q.Wd = Wc; q.M = N * Hc * Wc; q.R = Rc; q.S = Sc; q.K = K; q.KT = Kpad / 16;
+                q.pad_h = (oh0 + pad - ph) / 2; q.pad_w = (ow0 + pad - pw) / 2;
+                q.oh0 = oh0; q.ow0 = ow0; q.wpk_off = off; q.tiles = 0;
+                ++covered;
+            }
+            off += (long)Kpad * Cd;
+        }
+    if (covered < 4 && !accumulate) {  // some output pixels receive no tap: they are zero
+        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * sizeof(float), st) != hipSuccess) return dbn_status();
+        p.accumulate = 1;
+    }
+    if (p.ncls == 0) return DBN_OK;
+    // heaviest class first (longest workgroups start earliest)
+    for (int a = 0; a < p.ncls; ++a)
+        for (int b = a + 1; b < p.ncls; ++b)
+            if (p.cls[b].K > p.cls[a].K) {
+                IgemmClass t = p.cls[a];
+                p.cls[a] = p.cls[b];
+                p.cls[b] = t;
+            }
+    return igemm_dispatch(p, 2, tile_hint, st);
 }
 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
-int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, float* out, void* stream) {
-    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1));
+// Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
+// mode 1/stride 2 -> four parity-class panels back to back.
+long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride) {
+    if (mode == 0) return dbn_igemm_packed_floats(R * S * ((I + 3) / 4 * 4), O);
+    if (stride == 1) return dbn_igemm_packed_floats(R * S * O, I);
+    long tot = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) tot += dbn_igemm_packed_floats(taps_of_parity(R, ph) * taps_of_parity(S, pw) * O, I);
+    return tot;
+}
+
+static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp, int Sp, int r0, int s0, int rstep, float* out,
+                    hipStream_t st) {
+    const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
+    const int Cd = (mode == 0) ? O : I;
+    const int K = Rp * Sp * Cs, Kpad = ((K + 15) / 16) * 16;
+    const long total = (long)Kpad * Cd;
+    if (total == 0) return DBN_OK;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad, Rp, Sp,
+                       r0, s0, rstep, out);
+    return dbn_status();
+}
+
+int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, float* out, void* stream) {
+    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
     const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);
-    const int K = R * S * Cs, Kpad = ((K + 15) / 16) * 16;
-    const long total = (long)Kpad * Cd;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(dbn_grid(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I, R, S, mode,
-                       Cs, Cd, K, Kpad, out);
-    return dbn_status();
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0 || stride == 1) return pack_one(w_oihw, O, I, R, S, mode, R, S, 0, 0, 1, out, st);
+    long off = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int Rc = taps_of_parity(R, ph), Sc = taps_of_parity(S, pw);
+            const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, 2, out + off, st);
+            if (rc) return rc;
+            off += dbn_igemm_packed_floats(Rc * Sc * O, I);
+        }
+    return DBN_OK;
 }
 
 static void wgrad_tiles(int O, int J, int& bm, int& bn) {

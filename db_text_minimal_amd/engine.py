@@ -198,20 +198,16 @@ class Engine:
             self._side_used = False
 
     # ------------------------------------------------------------ weight panels
-    def pack(self, name, w, mode, O=None, I=None):
-        key = (name, mode)
+    def pack(self, name, w, mode, stride=1):
+        key = (name, mode, stride)
         ent = self.packs.get(key)
         stamp = (w._version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
-        O = w.shape[0] if O is None else O
-        I = w.shape[1] if I is None else I
-        R, S = w.shape[2], w.shape[3]
-        Cs = (I + 3) // 4 * 4 if mode == 0 else O
-        Cd = O if mode == 0 else I
-        n = self.L.dbn_igemm_packed_floats(R * S * Cs, Cd)
+        O, I, R, S = w.shape
+        n = self.L.dbn_igemm_panel_floats(O, I, R, S, mode, stride)
         out = ent[0] if ent is not None else torch.empty(n, device=w.device, dtype=torch.float32)
-        check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, out.data_ptr(), self.stream), 'pack_weights')
+        check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), self.stream), 'pack_weights')
         self.packs[key] = (out, stamp)
         return out
 
@@ -237,9 +233,9 @@ class Engine:
     def conv_dgrad(self, name, dy, conv, dx, accumulate):
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
-        wpk = self.pack(name, conv.weight, 1)
+        wpk = self.pack(name, conv.weight, 1, conv.stride)
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
-            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 1)
+            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1)
         check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
                                    conv.stride, conv.padding, 1, int(accumulate), 0, self.stream), 'igemm dgrad ' + name)
         if self.prof:
@@ -264,10 +260,10 @@ class Engine:
 
     def convT_fwd(self, name, x, ct, out_name):
         N, H, W, C = x.shape
-        wpk = self.pack(name, ct.weight, 1)
+        wpk = self.pack(name, ct.weight, 1, 2)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
-            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 1)
+            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 2)
         check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
                                    2, 2, 0, 1, 0, 0, self.stream), 'igemm convT fwd ' + name)
         if self.prof:

@@ -31,7 +31,7 @@ def allreduce_flat_grads(flat_grad, world, group=None):
     """THE collective of a data-parallel step: one sum all-reduce over the flat fp32 gradient
     buffer (12 269 378 elements = 49 MB for ResNet18-FPN-DBHead).  Returns the factor the
     optimizer applies to turn the sum into the mean (folded into the Adam kernel)."""
-    if world <= 1:
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
@@ -91,7 +91,10 @@ def init_distributed():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('DBN_FORCE_DIST', '0') == '1'  # exercise the RCCL path even with one rank
+    if (world > 1 or force) and not dist.is_initialized():
         torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     return rank, local, world

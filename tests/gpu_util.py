@@ -39,15 +39,12 @@ def report(tag, got, ref, atol, rtol):
     assert worst <= 1.0, msg
 
 
-def pack(w, mode):
+def pack(w, mode, stride=1):
     """w: CPU OIHW tensor -> device panels."""
     O, I, R, S = w.shape
-    Cs = (I + 3) // 4 * 4 if mode == 0 else O
-    Cd = O if mode == 0 else I
-    n = L().dbn_igemm_packed_floats(R * S * Cs, Cd)
-    out = torch.empty(n, device=DEV)
+    out = torch.empty(L().dbn_igemm_panel_floats(O, I, R, S, mode, stride), device=DEV)
     wd = w.contiguous().to(DEV)
-    _lib.check(L().dbn_pack_weights(wd.data_ptr(), O, I, R, S, mode, out.data_ptr(), stream()), 'pack')
+    _lib.check(L().dbn_pack_weights(wd.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), stream()), 'pack')
     return out
 
 

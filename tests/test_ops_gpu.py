@@ -49,7 +49,7 @@ def test_conv_forward(case, tile):
     report('conv fwd acc %s' % (case, ), nchw(y2), F.conv2d(x, w, None, s, p) + 1, 1e-4, 1e-4)
 
 
-DGRAD_CASES = [(2, 64, 64, 3, 1, 1, 16, 12), (1, 64, 128, 3, 2, 1, 18, 14), (2, 64, 128, 1, 2, 0, 16, 16),
+DGRAD_CASES = [(2, 64, 64, 3, 1, 1, 16, 12), (1, 64, 128, 3, 2, 1, 18, 14), (2, 64, 128, 1, 2, 0, 16, 16), (1, 64, 64, 3, 2, 1, 17, 13),
                (1, 256, 256, 3, 1, 1, 12, 12), (1, 128, 256, 3, 2, 1, 8, 8), (1, 256, 512, 1, 2, 0, 4, 4)]
 
 
@@ -63,8 +63,11 @@ def test_conv_dgrad(case, tile):
     dy = rnd(*y.shape, seed=4)
     (dx_ref, ) = torch.autograd.grad(y, x, dy)
     dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)
-    igemm(nhwc(dy), pack(w, 1), None, dx, k, s, p, 1, 0, tile)
+    igemm(nhwc(dy), pack(w, 1, s), None, dx, k, s, p, 1, 0, tile)
     report('conv dgrad %s tile %d' % (case, tile), nchw(dx), dx_ref, 1e-4, 1e-4)
+    dx2 = torch.ones((N, H, W, Ci), device=DEV)  # accumulate form
+    igemm(nhwc(dy), pack(w, 1, s), None, dx2, k, s, p, 1, 1, tile)
+    report('conv dgrad acc %s' % (case, ), nchw(dx2), dx_ref + 1, 1e-4, 1e-4)
 
 
 WGRAD_CASES = DGRAD_CASES + [(2, 3, 64, 7, 2, 3, 32, 40), (4, 64, 64, 3, 1, 1, 40, 40), (1, 512, 512, 3, 1, 1, 2, 2)]
@@ -94,7 +97,7 @@ def test_conv_transpose(shape):
     dx_ref, dw_ref = torch.autograd.grad(ref, (x, w), dy)
     xs = nhwc(x.detach())
     y = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
-    igemm(xs, pack(w.detach(), 1), b.to(DEV), y, 2, 2, 0, 1)
+    igemm(xs, pack(w.detach(), 1, 2), b.to(DEV), y, 2, 2, 0, 1)
     report('convT fwd', nchw(y), ref, 1e-4, 1e-4)
     dys = nhwc(dy)
     dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)

@@ -22,7 +22,7 @@ def run():
         igemm(y, wp, None, x, k, s, p, 1, 0, tile)
     else:
         wgrad(y, x, Co, Ci, k, s, p)
-wp = pack(w, 0 if mode == 'fwd' else 1)
+wp = pack(w, 0 if mode == 'fwd' else 1, s)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
