@@ -27,7 +27,7 @@ SIGNATURES = {
     'dbn_bn_train_stats': 'piippffppppppp' + 'p',
     'dbn_bn_eval_coef': 'ippppfppp',
     'dbn_bn_apply': 'pppppppliip',
-    'dbn_bn_backward': 'pppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
+    'dbn_bn_backward': 'pppppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
     'dbn_col_sum': 'piipfpp',
     'dbn_bnrelu_maxpool_fwd': 'ppppiiiip',
     'dbn_bnrelu_maxpool_bwd': 'ppppppiiiip',

@@ -50,11 +50,13 @@ __device__ __forceinline__ double dbn_wave_sum_d(double v) {
     return v;
 }
 
-// Sum part[b*stride + idx] over b = 0..nb-1 in double with a 32-lane team: call with all 32
-// lanes of an aligned half-wave (lane32 = threadIdx.x & 31); every lane returns the total.
-__device__ __forceinline__ double dbn_team32_fold(const float* __restrict__ part, int nb, long stride, long idx, int lane32) {
+// Partial sums are stored transposed, part[idx*nb + b] (b = producing block), so that the 32 lanes
+// folding one output read one contiguous 128-byte line per step.  Call with all 32 lanes of an
+// aligned half-wave (lane32 = threadIdx.x & 31); every lane returns the total (fp64 fold).
+__device__ __forceinline__ double dbn_team32_fold(const float* __restrict__ part, int nb, long idx, int lane32) {
     double s = 0.0;
-    for (int b = lane32; b < nb; b += 32) s += (double)part[(long)b * stride + idx];
+    const float* row = part + idx * nb;
+    for (int b = lane32; b < nb; b += 32) s += (double)row[b];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     return s;

@@ -164,7 +164,7 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
     for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) {
         float s = 0.f;
         for (int g = 0; g < 16; ++g) s += red[g][i];
-        part[(long)blockIdx.x * (2 * 257) + i] = s;
+        part[(long)i * gridDim.x + blockIdx.x] = s;  // transposed: [514][blocks]
     }
 }
 
@@ -172,7 +172,7 @@ __global__ void fold_partials_d_kernel(const float* __restrict__ part, int nb, i
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (i >= n) return;
-    const double s = dbn_team32_fold(part, nb, n, i, l32);
+    const double s = dbn_team32_fold(part, nb, i, l32);
     if (l32 == 0) out[i] = (float)(s * scale);
 }
 

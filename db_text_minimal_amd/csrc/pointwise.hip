@@ -14,7 +14,7 @@ constexpr int MAX_PART = 1024;  // max partial blocks for per-channel reductions
 
 // ----------------------------------------------------------------------------------
 // per-channel reductions over [M][C] (C % 4 == 0, C <= 1024): each block reduces a
-// contiguous row range into part[block][NV][C]; a second kernel folds the partials in
+// contiguous row range into part[NV*C][block]; a second kernel folds the partials in
 // double precision.  Thread t owns channel quad t % (C/4) and walks rows t / (C/4).
 // ----------------------------------------------------------------------------------
 template <int NV, class F>
@@ -38,7 +38,7 @@ __device__ __forceinline__ void channel_reduce(int M, int C, float* __restrict__
     for (int i = threadIdx.x; i < NV * C; i += blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nrl; ++k) s += red[(long)k * NV * C + i];
-        part[(long)blockIdx.x * NV * C + i] = s;
+        part[(long)i * gridDim.x + blockIdx.x] = s;  // transposed: [NV*C][blocks]
     }
 }
 
@@ -62,8 +62,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (c >= C) return;
-    const double s1 = dbn_team32_fold(part, nb, 2L * C, c, l32);
-    const double s2 = dbn_team32_fold(part, nb, 2L * C, (long)C + c, l32);
+    const double s1 = dbn_team32_fold(part, nb, c, l32);
+    const double s2 = dbn_team32_fold(part, nb, (long)C + c, l32);
     if (l32 != 0) return;
     const double pv = (double)y[c];
     const double dm = s1 / M;
@@ -129,18 +129,26 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
 }
 
 // backward reductions: g = dout * (zmask > 0);  sums of g and g*xhat
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ dout,
+// ReLU mask of g: from a saved activation (zmask), or recomputed from y with the forward's own
+// scale/shift (msc/msh; bit-identical to the forward because both use dbn_affine), or none.
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ msc,
+                                     const float* __restrict__ msh, const float* __restrict__ dout,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, int M, int C,
                                      float* __restrict__ part) {
     channel_reduce<2>(M, C, part, [&](int r, int c4, f32x4* acc) {
         const long off = (long)r * C + 4 * c4;
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + off);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
         if (zmask) {
             const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        } else if (msc) {
+            const f32x4 s_ = *reinterpret_cast<const f32x4*>(msc + 4 * c4);
+            const f32x4 h_ = *reinterpret_cast<const f32x4*>(msh + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = dbn_affine(v[e], s_[e], h_[e]) > 0.f ? g[e] : 0.f;
         }
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
         const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + 4 * c4);
         acc[0] += g;
@@ -155,8 +163,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, i
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (c >= C) return;
-    const double s1 = dbn_team32_fold(part, nb, 2L * C, c, l32);
-    const double s2 = dbn_team32_fold(part, nb, 2L * C, (long)C + c, l32);
+    const double s1 = dbn_team32_fold(part, nb, c, l32);
+    const double s2 = dbn_team32_fold(part, nb, (long)C + c, l32);
     if (l32 != 0) return;
     dbeta[c] = (float)(s1 * gscale);
     dgamma[c] = (float)(s2 * gscale);
@@ -165,7 +173,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, i
 }
 
 // dy = gamma*rstd*(g - c1 - xhat*c2); optionally also emits g (the ReLU-masked dout)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ dout,
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ msc,
+                                    const float* __restrict__ msh, const float* __restrict__ dout,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
                                     float* __restrict__ dy, float* __restrict__ gout, int gout_acc, long total4, int C) {
@@ -173,12 +182,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
         if (zmask) {
             const f32x4 z = reinterpret_cast<const f32x4*>(zmask)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+        } else if (msc) {
+            const f32x4 s_ = *reinterpret_cast<const f32x4*>(msc + c);
+            const f32x4 h_ = *reinterpret_cast<const f32x4*>(msh + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = dbn_affine(v[e], s_[e], h_[e]) > 0.f ? g[e] : 0.f;
         }
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
         const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -202,7 +216,7 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int l32 = threadIdx.x & 31;
     if (i >= n) return;
-    const double s = dbn_team32_fold(part, nb, n, i, l32);
+    const double s = dbn_team32_fold(part, nb, i, l32);
     if (l32 == 0) out[i] = (float)(s * scale);
 }
 
@@ -433,23 +447,25 @@ int dbn_bn_apply(const float* y, const float* scale, const float* shift, const f
     return dbn_status();
 }
 
-int dbn_bn_backward(const float* y, const float* zmask, const float* dout, const float* save_mean, const float* save_rstd,
+int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
+                    const float* save_mean, const float* save_rstd,
                     const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
                     float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
     DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    DBN_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(zmask && mask_scale));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
     float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
     float* c2 = c1 + C;
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nbu), dim3(256), red_smem(C, 2), st, y, zmask, dout, save_mean, save_rstd, M,
-                       C, ws);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nbu), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout, save_mean,
+                       save_rstd, M, C, ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
                        grad_scale);
     const long total4 = (long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, dout, save_mean, save_rstd,
-                       gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout,
+                       save_mean, save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
     return dbn_status();
 }
 

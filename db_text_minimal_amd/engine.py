@@ -315,15 +315,22 @@ class Engine:
                                   y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
         return out
 
-    def bn_backward(self, name, y, zmask, dout, dy_name, gout=None, gout_acc=False):
+    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False):
+        """mask: None (no ReLU), 'self' (ReLU directly on this BN's output: recomputed from y with the
+        forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates)."""
         C = y.shape[-1]
         M = y.numel() // C
         dy = self.buf(dy_name, *y.shape)
-        check(self.L.dbn_bn_backward(y.data_ptr(), _p(zmask), dout.data_ptr(), self.bufs[name + '/mean'].data_ptr(),
-                                     self.bufs[name + '/rstd'].data_ptr(), self.views[name + '.weight'].data_ptr(), dy.data_ptr(),
-                                     _p(gout), int(gout_acc), self.grad_views[name + '.weight'].data_ptr(),
-                                     self.grad_views[name + '.bias'].data_ptr(), M, C, self.grad_scale,
-                                     self.reduce_ws().data_ptr(), self.stream), 'bn backward ' + name)
+        zmask = msc = msh = None
+        if isinstance(mask, str):
+            msc, msh = self.bufs[name + '/scale'], self.bufs[name + '/shift']
+        elif mask is not None:
+            zmask = mask
+        check(self.L.dbn_bn_backward(y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
+                                     self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
+                                     self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
+                                     self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(), M, C,
+                                     self.grad_scale, self.reduce_ws().data_ptr(), self.stream), 'bn backward ' + name)
         return dy
 
     def up_fwd(self, src, addend, dst, coff=0):
@@ -468,15 +475,15 @@ class Engine:
         for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], B[br + '/z1'], dz1, br + '/dy1')
+            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1')
             dz0 = self.buf(br + '/dz0', *B[br + '/z0'].shape)
             self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0)
-            dy0 = self.bn_backward(hp + '1', B[br + '/y0'], B[br + '/z0'], dz0, br + '/dy0')
+            dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0')
             self.conv_wgrad(hp + '0', dy0, f, seq[0])
             self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0))
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
-        dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], f, df, 'fpn/dy')
+        dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], 'self', df, 'fpn/dy')
         cat = B['cat']
         self.conv_wgrad(pre + 'conv.0', dfy, cat, fpn.conv[0])
         dcat = self.buf('dcat', *cat.shape)
@@ -489,7 +496,7 @@ class Engine:
             dP[nm] = d
 
         def cbr_bwd(name, mod, xin, dz, dx, dx_acc):
-            dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], B[name + '/z'], dz, name + '/dy')
+            dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], 'self', dz, name + '/dy')
             self.conv_wgrad(pre + name + '.conv', dy, xin, mod.conv)
             self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc)
 
@@ -552,7 +559,7 @@ class Engine:
         self.conv_wgrad(name + '.conv2', dy2, z1, blk.conv2)
         dz1 = self.buf(name + '/dz1', *z1.shape)
         self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False)
-        dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], z1, dz1, name + '/dy1')
+        dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], 'self', dz1, name + '/dy1')
         self.conv_wgrad(name + '.conv1', dy1, xin, blk.conv1)
         self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc)
         if has_down:

@@ -62,8 +62,11 @@ int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* 
 /* out = act(y*scale+shift [+ res*res_scale+res_shift | + res]) */
 int dbn_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
                  const float* res_shift, float* out, long M, int C, int relu, void* stream);
-/* g = dout * (zmask > 0) (zmask NULL: g = dout); dy = BN backward of g; optional gout (+)= g */
-int dbn_bn_backward(const float* y, const float* zmask, const float* dout, const float* save_mean, const float* save_rstd,
+/* g = dout * relu_mask; the mask is (zmask > 0) from a saved activation, or recomputed as
+ * (y*mask_scale+mask_shift > 0) from the forward's own BN coefficients, or absent (all NULL).
+ * dy = BN backward of g; optional gout (+)= g */
+int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
+                    const float* save_mean, const float* save_rstd,
                     const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
                     float grad_scale, float* ws, void* stream);
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream);

@@ -118,7 +118,7 @@ def test_batchnorm_train(C, N, H, W):
     ybn = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
     out_ref = F.relu(ybn + res)
     dout = rnd(N, C, H, W, seed=7)
-    dx_ref, dg_ref, db_ref = torch.autograd.grad(out_ref, (x, gamma, beta), dout)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(out_ref, (x, gamma, beta), dout, retain_graph=True)
     M = N * H * W
     xs = nhwc(x.detach())
     dv = lambda t: t.detach().clone().to(DEV)
@@ -139,13 +139,25 @@ def test_batchnorm_train(C, N, H, W):
     dy = torch.empty_like(xs)
     gout = torch.ones_like(xs)
     dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    _lib.check(L().dbn_bn_backward(xs.data_ptr(), out.data_ptr(), douts.data_ptr(), mu.data_ptr(), rs.data_ptr(), g_.data_ptr(),
-                                   dy.data_ptr(), gout.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), M, C, 1.0, ws.data_ptr(),
-                                   stream()), 'bn bwd')
+    _lib.check(L().dbn_bn_backward(xs.data_ptr(), out.data_ptr(), None, None, douts.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                                   g_.data_ptr(), dy.data_ptr(), gout.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), M, C, 1.0,
+                                   ws.data_ptr(), stream()), 'bn bwd')
     report('bn bwd dx', nchw(dy), dx_ref, 2e-5, 1e-4)
     report('bn bwd dgamma', dg.cpu(), dg_ref, 1e-4, 1e-4)
     report('bn bwd dbeta', db.cpu(), db_ref, 1e-4, 1e-4)
     report('bn bwd masked grad (acc)', nchw(gout), dout * (out_ref > 0) + 1, 1e-6, 1e-6)
+    # plain BN+ReLU (no residual): mask recomputed from y with the forward's scale/shift == mask from the saved activation
+    zr_ref = F.relu(ybn)
+    dxr_ref, dgr_ref, dbr_ref = torch.autograd.grad(zr_ref, (x, gamma, beta), dout, retain_graph=True)
+    for use_saved in (True, False):
+        zs = nhwc(zr_ref.detach())
+        _lib.check(L().dbn_bn_backward(xs.data_ptr(), zs.data_ptr() if use_saved else None, None if use_saved else sc.data_ptr(),
+                                       None if use_saved else sh.data_ptr(), douts.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                                       g_.data_ptr(), dy.data_ptr(), None, 0, dg.data_ptr(), db.data_ptr(), M, C, 1.0, ws.data_ptr(),
+                                       stream()), 'bn bwd relu')
+        report('bn+relu bwd dx (saved mask=%s)' % use_saved, nchw(dy), dxr_ref, 2e-5, 1e-4)
+        report('bn+relu bwd dgamma', dg.cpu(), dgr_ref, 1e-4, 1e-4)
+        report('bn+relu bwd dbeta', db.cpu(), dbr_ref, 1e-4, 1e-4)
     # second-BN residual (downsample form) and eval coefficients
     sc2, sh2 = rnd(C, seed=8).to(DEV), rnd(C, seed=9).to(DEV)
     _lib.check(L().dbn_bn_apply(xs.data_ptr(), sc.data_ptr(), sh.data_ptr(), ress.data_ptr(), sc2.data_ptr(), sh2.data_ptr(),
