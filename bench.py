@@ -75,6 +75,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE: 16)')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16'],
+                    help="conv math: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; bf16 = bf16 operands")
+    ap.add_argument('--alt-modes', action='store_true', help='also time the other conv-math modes (reported under alt_modes)')
     args = ap.parse_args()
 
     from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
@@ -89,6 +92,7 @@ def main():
 
     torch.manual_seed(42)  # utils.setup_determinism(42): same initial weights on every rank
     model = DBTextModel().to(dev).train()
+    model.engine.set_conv_math(args.math)
     trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
     img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
     eng = model.engine
@@ -157,6 +161,24 @@ def main():
                 ent.update(bound='hbm', achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
             kernels.append(ent)
 
+    alt = {}
+    if args.alt_modes:
+        for mode in ('f32', 'bf16x3', 'bf16'):
+            if mode == args.math:
+                continue
+            eng.set_conv_math(mode)
+            for _ in range(2):
+                trainer.step(img, gts)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                trainer.step(img, gts)
+            barrier()
+            alt[mode] = {'images_per_s': round(world * args.batch * args.steps / (time.perf_counter() - t1), 2),
+                         'note': {'bf16x3': 'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (fp32-accurate)',
+                                  'bf16': 'conv operands rounded to bf16, fp32 accumulate/storage (BASELINE configs[2] compute mode)',
+                                  'f32': 'exact-fp32 MFMA'}[mode]}
+        eng.set_conv_math(args.math)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
@@ -171,6 +193,8 @@ def main():
             'roofline': roofline,
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / ms, 2),
             'kernels': kernels,
+            'conv_math': args.math,
+            'alt_modes': alt,
             'final_total_loss': round(final_loss, 5),
         }
         if not args.no_cpu_baseline:

@@ -20,6 +20,10 @@ SIGNATURES = {
     'dbn_igemm_packed_floats': 'ii',
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
+    'dbn_pack_weights_bf16s': 'piiiiiiipp',
+    'dbn_igemm_bf16s_panel_floats': 'iiiiiii',
+    'dbn_igemm_bf16s': 'pppp' + 'i' * 15 + 'p',
+    'dbn_wgrad_bf16s': 'pppp' + 'i' * 12 + 'fip',
     'dbn_wgrad_splitk': 'iiiiiii',
     'dbn_wgrad_slab_floats': 'iiiiiii',
     'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
@@ -43,7 +47,7 @@ SIGNATURES = {
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
-LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats'}
+LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

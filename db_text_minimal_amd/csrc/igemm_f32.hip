@@ -42,7 +42,6 @@ struct IgemmParams {
     const float* bias;  // [Cd] or null
     float* dst;         // [N,Hdf,Wdf,Cd]
     int N, Hs, Ws, Cs, Cd, Hdf, Wdf, stride, accumulate, ncls;
-    int flags;  // experiment switches (DBN_IGEMM_FLAGS): 1 = s_setprio around the MFMA cluster
     unsigned src_bytes;
     IgemmClass cls[4];
 };
@@ -68,21 +67,82 @@ __device__ __forceinline__ void divmod24(int p, int d, float rd, int& q, int& r)
     }
 }
 
+
+// ---- split-bf16 matrix math (NS > 0) ------------------------------------------------------------
+// NS = 1: operands rounded to bf16 (bf16 MFMA, fp32 accumulate).
+// NS = 3: every fp32 operand is split exactly into three bf16 terms (a = a0 + a1 + a2, 24 mantissa
+//         bits) and the product is evaluated as a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 on the bf16
+//         matrix pipe with fp32 accumulation: fp32-accurate (mean rel. error 1.3e-7 at K=2304, lower than
+//         a plain fp32 fmaf chain) at 6/16 of the fp32-MFMA cost.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {  // round-to-nearest-even fp32 -> bf16 bit pattern
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+
+// four fp32 values -> NS x (four bf16 packed in 8 bytes).  The casts compile to v_cvt_pk_bf16_f32
+// (round-to-nearest-even); the residual a - bf16(a) is exact in fp32.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[NS > 0 ? NS : 1]) {
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16x2 lo = {(__bf16)r[0], (__bf16)r[1]};
+        const bf16x2 hi = {(__bf16)r[2], (__bf16)r[3]};
+        const unsigned ulo = __builtin_bit_cast(unsigned, lo), uhi = __builtin_bit_cast(unsigned, hi);
+        out[s] = u32x2{ulo, uhi};
+        if (s + 1 < NS) {
+            r[0] -= __builtin_bit_cast(float, ulo << 16);
+            r[1] -= __builtin_bit_cast(float, ulo & 0xFFFF0000u);
+            r[2] -= __builtin_bit_cast(float, uhi << 16);
+            r[3] -= __builtin_bit_cast(float, uhi & 0xFFFF0000u);
+        }
+    }
+}
+
+template <int NS, int MI, int NI>
+__device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][MI], const bf16x8 (&bf)[NS > 0 ? NS : 1][NI],
+                                           f32x16 (&acc)[MI][NI]) {
+    // smallest terms first
+    constexpr int NPROD = NS == 3 ? 6 : 1;
+    constexpr int pi[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int pj[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < NPROD; ++t) {
+        const int i = NS == 3 ? pi[t] : 0, j = NS == 3 ? pj[t] : 0;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][a], bf[j][b], acc[a][b], 0, 0, 0);
+    }
+}
+
 // MODE 0: hs = hd*stride - pad + r (forward conv, stride 1 or 2)
 // MODE 1: hs = hd + pad - r        (stride-1 data gradient)
 // MODE 2: like MODE 1 per output-parity class, dst pixel = (2*hd+oh0, 2*wd+ow0) (stride-2 data
 //         gradient / ConvTranspose2d(k2,s2) forward)
 // The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
 // offset, for which the hardware returns zeros.
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int NS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
     constexpr int A_LD = BM * 4 / NT;  // float4 gathers per thread per k-tile
-    constexpr int B_LD = BN * 4 / NT;
-    constexpr int AS = BM + 2, BS = BN + 2;  // chunk strides (float4 units); +2 keeps ds_write_b128 conflict-free
-    constexpr int STAGE = 4 * AS + 4 * BS;
+    // LDS image in 16-byte units.  NS == 0: [k/4][row][4 f32], chunk stride +2 keeps ds_write_b128 conflict-free.
+    // NS > 0: per split [k/8][row][8 bf16], row stride +4 (== 64 B mod 128) keeps the ds_write_b64 conflict-free.
+    constexpr int AS = NS == 0 ? BM + 2 : BM + 4, BS = NS == 0 ? BN + 2 : BN + 4;
+    constexpr int A_IMG = NS == 0 ? 4 * AS : NS * 2 * AS, B_IMG = NS == 0 ? 4 * BS : NS * 2 * BS;
+    constexpr int B_PIECES = NS == 0 ? 4 * BN : NS * 2 * BN;  // 16-byte pieces of the weight panel per k-tile
+    constexpr int B_LD = (B_PIECES + NT - 1) / NT;
+    constexpr bool B_FULL = B_PIECES % NT == 0;  // every thread owns B_LD pieces
+    constexpr int STAGE = A_IMG + B_IMG;
+    constexpr int NSX = NS > 0 ? NS : 1;
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
     __shared__ f32x4 smem[2 * STAGE];
 
@@ -149,24 +209,35 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         }
         kidx += 16;
         k_ci += 16;
-        while (k_ci >= p.Cs) {
-            k_ci -= p.Cs;
-            if (++k_s == qS) {
-                k_s = 0;
-                ++k_r;
+        if (p.Cs >= 16) {  // at most one tap boundary per step: branch-free selects
+            const bool wrap = k_ci >= p.Cs;
+            k_ci -= wrap ? p.Cs : 0;
+            k_s += wrap ? 1 : 0;
+            const bool wrap_s = k_s == qS;
+            k_s = wrap_s ? 0 : k_s;
+            k_r += wrap_s ? 1 : 0;
+        } else {
+            while (k_ci >= p.Cs) {  // stem (Cs = 4): several taps per step
+                k_ci -= p.Cs;
+                if (++k_s == qS) {
+                    k_s = 0;
+                    ++k_r;
+                }
             }
         }
     };
     const f32x4* bptr[B_LD];
     int b_lds[B_LD];
+    bool b_on[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
         const int idx = tid + j * NT;
-        const int c = idx / BN, n = idx - c * BN;
+        b_on[j] = B_FULL || idx < B_PIECES;
+        const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
         bptr[j] = reinterpret_cast<const f32x4*>(p.wpk + q.wpk_off) + (long)c * p.Cd + n0 + n;
         b_lds[j] = c * BS + n;
     }
-    const long b_step = 4L * p.Cd;  // float4 per k-tile
+    const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
 
     f32x4 ra[A_LD], rb[B_LD];
     auto issue_loads = [&]() {
@@ -174,17 +245,31 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         for (int j = 0; j < A_LD; ++j) ra[j] = buffer_load_f32x4(rsrc, aoff[j]);
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            rb[j] = *bptr[j];
+            if (B_FULL || b_on[j]) rb[j] = *bptr[j];
             bptr[j] += b_step;
         }
     };
     auto stage = [&](int buf) {
         f32x4* As = smem + buf * STAGE;
-        f32x4* Bs = As + 4 * AS;
+        f32x4* Bs = As + A_IMG;
+        if constexpr (NS == 0) {
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
+            for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
+        } else {
+            // chunk c holds k = 4c..4c+3 of the k-tile: bf16 image slot [c>>1][row], 8-byte half (c&1)
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) Bs[b_lds[j]] = rb[j];
+            for (int j = 0; j < A_LD; ++j) {
+                u32x2 sp[NSX];
+                split4<NS>(ra[j], sp);
+                const int row = (tid >> 2) + j * (NT / 4);
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    reinterpret_cast<u32x2*>(As + (t * 2 + (a_chunk >> 1)) * AS + row)[a_chunk & 1] = sp[t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            if (B_FULL || b_on[j]) Bs[b_lds[j]] = rb[j];
     };
 
     f32x16 acc[MI][NI];
@@ -206,29 +291,41 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         const bool more = kt + 1 < qKT;
         if (more) issue_loads();  // tile kt+1 in flight under the MFMAs of tile kt
         const f32x4* As = smem + buf * STAGE;
-        const f32x4* Bs = As + 4 * AS;
-        // all fragment reads of the k-tile up front: the second half's LDS latency hides under the first half's MFMAs
-        f32x4 af[2][MI], bf[2][NI];
+        const f32x4* Bs = As + A_IMG;
+        if constexpr (NS == 0) {
+            // all fragment reads of the k-tile up front: the second half's LDS latency hides under the first half's MFMAs
+            f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+                for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+                for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
+                if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
+            }
+        } else {
+            // one 32x32x16 bf16 MFMA k-step per k-tile: lane half lh owns k = 8*lh .. 8*lh+7
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * 2 + lh) * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NS, MI, NI>(af, bf, acc);
+            next_offsets();
         }
-        if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int a = 0; a < MI; ++a)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
-            if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
-        }
-        if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
@@ -263,20 +360,27 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_igemm(IgemmParams& p, int mode, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     int grid = 0;
     for (int c = 0; c < p.ncls; ++c) {
         p.cls[c].tiles = dbn_ceil_div(p.cls[c].M, BM) * (p.Cd / BN);
         grid += p.cls[c].tiles;
     }
     if (mode == 0)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     return dbn_status();
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st) {
+    if (ns == 0) return launch_igemm_ns<BM, BN, WM, WN, 0>(p, mode, st);
+    if (ns == 1) return launch_igemm_ns<BM, BN, WM, WN, 1>(p, mode, st);
+    return launch_igemm_ns<BM, BN, WM, WN, 3>(p, mode, st);
 }
 
 // --------------------------------------------------------------------------------
@@ -298,13 +402,15 @@ struct WgradParams {
 // fragments conflict-free.  The accumulators (and the slabs) therefore live in "position space".
 __host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { return 4 * (pos % (B / 4)) + pos / (B / 4); }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int AS = BM + 2, BS = BN + 2;  // chunk strides in float4 units
-    constexpr int STAGE = 4 * AS + 4 * BS;
+    constexpr int AS = NS == 0 ? BM + 2 : BM + 4, BS = NS == 0 ? BN + 2 : BN + 4;  // strides in 16-byte units
+    constexpr int A_IMG = NS == 0 ? 4 * AS : NS * 2 * AS, B_IMG = NS == 0 ? 4 * BS : NS * 2 * BS;
+    constexpr int STAGE = A_IMG + B_IMG;
+    constexpr int NSX = NS > 0 ? NS : 1;
     static_assert(BM + BN <= NT && BM % 64 == 0 && BN % 64 == 0, "staging roles must fit the workgroup in whole waves");
     __shared__ f32x4 smem[2 * STAGE];
 
@@ -337,7 +443,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int ci = j_ok ? jj - tap * p.Cb : 0;
     const int tr = tap / p.S - p.pad, ts = tap % p.S - p.pad;
     const int HWo = p.Ho * p.Wo;
-    const int lds_base = (is_a ? 0 : 4 * AS) + s_g * (is_a ? AS : BS) + s_c;
+    const int ld = is_a ? AS : BS;
+    const int lds_base = (is_a ? 0 : A_IMG) + s_c;
 
     f32x4 rr[4];
     auto gather = [&](int kt) {
@@ -373,8 +480,20 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     auto stage = [&](int buf) {
         if (is_a || is_b) {
             f32x4* dst = smem + buf * STAGE + lds_base;
+            if constexpr (NS == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e * qn] = f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]};
+                for (int e = 0; e < 4; ++e) dst[s_g * ld + e * qn] = f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]};
+            } else {
+                // pixel group g = k 4g..4g+3 of the k-tile: bf16 image slot [g>>1][pos], 8-byte half (g&1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x2 sp[NSX];
+                    split4<NS>(f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]}, sp);
+#pragma unroll
+                    for (int t = 0; t < NS; ++t)
+                        reinterpret_cast<u32x2*>(dst + (t * 2 + (s_g >> 1)) * ld + e * qn)[s_g & 1] = sp[t];
+                }
+            }
         }
     };
 
@@ -396,24 +515,36 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         const bool more = kt + 1 < KT;
         if (more) gather(kt + 1);
         const f32x4* As = smem + buf * STAGE;
-        const f32x4* Bs = As + 4 * AS;
-        f32x4 af[2][MI], bf[2][NI];
+        const f32x4* Bs = As + A_IMG;
+        if constexpr (NS == 0) {
+            f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+                for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+                for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
+        } else {
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * 2 + lh) * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NS, MI, NI>(af, bf, acc);
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int a = 0; a < MI; ++a)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
@@ -478,6 +609,38 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
     }
 }
 
+// Split-bf16 weight panels for the NS > 0 kernels: [KT][NS][2][Cd][8 bf16]; element (k, cd, split t)
+// at ((kt*NS + t)*2 + k8)*Cd*8 + cd*8 + e with k = 16*kt + 8*k8 + e.  Same (mode, tap subset) semantics as above.
+__global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int K,
+                                          int Kpad, int Rp, int Sp, int r0, int s0, int rstep, int NS,
+                                          unsigned short* __restrict__ out) {
+    const long total = (long)Kpad * Cd;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7);
+        const long qd = idx >> 3;
+        const int cd = (int)(qd % Cd);
+        const int k8g = (int)(qd / Cd);  // global k/8
+        const int k = 8 * k8g + e;
+        float v = 0.f;
+        if (k < K) {
+            const int tap = k / Cs, cs = k - tap * Cs;
+            const int rp = tap / Sp, sp = tap - rp * Sp;
+            const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
+            if (mode == 0) {
+                if (cs < I) v = w[(((long)cd * I + cs) * R + r) * S + sx];
+            } else {
+                v = w[(((long)cs * I + cd) * R + r) * S + sx];
+            }
+        }
+        const int kt = k8g >> 1, k8 = k8g & 1;
+        for (int t = 0; t < NS; ++t) {
+            const unsigned bits = bf16_bits_rne(v);
+            out[((((long)kt * NS + t) * 2 + k8) * Cd + cd) * 8 + e] = (unsigned short)bits;
+            v -= bf16_bits_to_f32(bits);
+        }
+    }
+}
+
 inline int taps_of_parity(int R, int ph) { return (R - ph + 1) / 2; }
 
 }  // namespace
@@ -509,22 +672,29 @@ int dbn_igemm_tile_config(int M, int Cd) {
     return best;
 }
 
-static int igemm_dispatch(IgemmParams& p, int kmode, int tile_hint, hipStream_t st) {
+static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st) {
     long Mmax = 0;
     for (int c = 0; c < p.ncls; ++c) Mmax = p.cls[c].M > Mmax ? p.cls[c].M : Mmax;
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config((int)Mmax * (p.ncls > 1 ? p.ncls : 1), p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
     switch (cfg) {
-        case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, st);
-        case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, st);
-        case 3: return launch_igemm<128, 64, 2, 2>(p, kmode, st);
-        default: return launch_igemm<64, 64, 2, 2>(p, kmode, st);
+        case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st);
+        case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st);
+        case 3: return launch_igemm<128, 64, 2, 2>(p, kmode, ns, st);
+        default: return launch_igemm<64, 64, 2, 2>(p, kmode, ns, st);
     }
 }
 
-int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
-                  int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
-    DBN_REQUIRE(src && wpk && dst);
+// panel size in floats of one problem: fp32 panels Kpad*Cd; split-bf16 panels Kpad*Cd*ns/2
+static long panel_floats(int K, int Cd, int ns) {
+    const long kp = ((K + 15) / 16) * 16;
+    return ns == 0 ? kp * Cd : kp * Cd * ns / 2;
+}
+
+static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                     int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                     void* stream) {
+    DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
     DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
@@ -533,14 +703,6 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.stride = stride; p.accumulate = accumulate;
-    {
-        static int flags = -1;
-        if (flags < 0) {
-            const char* e = getenv("DBN_IGEMM_FLAGS");
-            flags = e ? atoi(e) : 0;
-        }
-        p.flags = flags;
-    }
     p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
     if (!(mode == 1 && stride == 2)) {
         p.ncls = 1;
@@ -548,7 +710,7 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
         q.Hd = Hd; q.Wd = Wd; q.M = N * Hd * Wd; q.R = R; q.S = S;
         q.K = R * S * Cs; q.KT = (q.K + 15) / 16;
         q.pad_h = q.pad_w = pad; q.oh0 = q.ow0 = 0; q.wpk_off = 0; q.tiles = 0;
-        return igemm_dispatch(p, mode, tile_hint, st);
+        return igemm_dispatch(p, mode, ns, tile_hint, st);
     }
     // stride-2 data gradient / ConvTranspose forward: one problem per output parity class, heaviest first
     p.ncls = 0;
@@ -567,7 +729,7 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
                 q.oh0 = oh0; q.ow0 = ow0; q.wpk_off = off; q.tiles = 0;
                 ++covered;
             }
-            off += (long)Kpad * Cd;
+            off += panel_floats(K, Cd, ns);
         }
     if (covered < 4 && !accumulate) {  // some output pixels receive no tap: they are zero
         if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * sizeof(float), st) != hipSuccess) return dbn_status();
@@ -582,50 +744,84 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
                 p.cls[a] = p.cls[b];
                 p.cls[b] = t;
             }
-    return igemm_dispatch(p, 2, tile_hint, st);
+    return igemm_dispatch(p, 2, ns, tile_hint, st);
+}
+
+int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                  int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, 0, stream);
+}
+
+// Same contract as dbn_igemm_f32 with the products evaluated on the bf16 matrix pipe: ns = 3 fp32-accurate
+// three-way operand split (6 bf16 MFMAs per product group), ns = 1 plain bf16 operands.  Panels from
+// dbn_pack_weights_bf16s with the same (mode, stride, ns).
+int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                    int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    void* stream) {
+    DBN_REQUIRE(ns == 1 || ns == 3);
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream);
 }
 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
 // Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
 // mode 1/stride 2 -> four parity-class panels back to back.
-long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride) {
-    if (mode == 0) return dbn_igemm_packed_floats(R * S * ((I + 3) / 4 * 4), O);
-    if (stride == 1) return dbn_igemm_packed_floats(R * S * O, I);
+static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, int ns) {
+    if (mode == 0) return panel_floats(R * S * ((I + 3) / 4 * 4), O, ns);
+    if (stride == 1) return panel_floats(R * S * O, I, ns);
     long tot = 0;
     for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) tot += dbn_igemm_packed_floats(taps_of_parity(R, ph) * taps_of_parity(S, pw) * O, I);
+        for (int pw = 0; pw < 2; ++pw) tot += panel_floats(taps_of_parity(R, ph) * taps_of_parity(S, pw) * O, I, ns);
     return tot;
 }
 
-static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp, int Sp, int r0, int s0, int rstep, float* out,
-                    hipStream_t st) {
+// Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
+// mode 1/stride 2 -> four parity-class panels back to back.
+long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride) { return panel_floats_all(O, I, R, S, mode, stride, 0); }
+long dbn_igemm_bf16s_panel_floats(int O, int I, int R, int S, int mode, int stride, int ns) {
+    return panel_floats_all(O, I, R, S, mode, stride, ns);
+}
+
+static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp, int Sp, int r0, int s0, int rstep, int ns,
+                    float* out, hipStream_t st) {
     const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
     const int Cd = (mode == 0) ? O : I;
     const int K = Rp * Sp * Cs, Kpad = ((K + 15) / 16) * 16;
     const long total = (long)Kpad * Cd;
     if (total == 0) return DBN_OK;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad, Rp, Sp,
-                       r0, s0, rstep, out);
+    if (ns == 0)
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad, Rp,
+                           Sp, r0, s0, rstep, out);
+    else
+        hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad,
+                           Rp, Sp, r0, s0, rstep, ns, reinterpret_cast<unsigned short*>(out));
     return dbn_status();
 }
 
-int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, float* out, void* stream) {
+static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
     const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0 || stride == 1) return pack_one(w_oihw, O, I, R, S, mode, R, S, 0, 0, 1, out, st);
+    if (mode == 0 || stride == 1) return pack_one(w_oihw, O, I, R, S, mode, R, S, 0, 0, 1, ns, out, st);
     long off = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             const int Rc = taps_of_parity(R, ph), Sc = taps_of_parity(S, pw);
-            const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, 2, out + off, st);
+            const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, 2, ns, out + off, st);
             if (rc) return rc;
-            off += dbn_igemm_packed_floats(Rc * Sc * O, I);
+            off += panel_floats(Rc * Sc * O, I, ns);
         }
     return DBN_OK;
+}
+
+int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, float* out, void* stream) {
+    return pack_run(w_oihw, O, I, R, S, mode, stride, 0, out, stream);
+}
+int dbn_pack_weights_bf16s(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
+    DBN_REQUIRE(ns == 1 || ns == 3);
+    return pack_run(w_oihw, O, I, R, S, mode, stride, ns, out, stream);
 }
 
 static void wgrad_tiles(int O, int J, int& bm, int& bn) {
@@ -670,9 +866,9 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return (long)dbn_wgrad_splitk(N, Ho, Wo, O, Cb, R, S) * O * Jp;
 }
 
-int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
-                  int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
-    DBN_REQUIRE(sm && big && slab && grad_oihw);
+static int wgrad_run(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream) {
+    DBN_REQUIRE(sm && big && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
     WgradParams p;
     p.sm = sm; p.big = big; p.slab = slab;
@@ -692,18 +888,37 @@ int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oi
     wgrad_tiles(O, p.J, bm, bn);
     const int njt = (p.J + bn - 1) / bn;
     dim3 grid((O / bm) * njt, splitk);
-    if (bm == 128 && bn == 128)
-        hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
-    else if (bn == 128)
-        hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+#define DBN_WGRAD_LAUNCH(NS_)                                                                             \
+    do {                                                                                                    \
+        if (bm == 128 && bn == 128)                                                                         \
+            hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);         \
+        else if (bn == 128)                                                                                 \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);          \
+        else                                                                                                \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_>), grid, dim3(256), 0, st, p);           \
+    } while (0)
+    if (ns == 0) DBN_WGRAD_LAUNCH(0);
+    else if (ns == 1) DBN_WGRAD_LAUNCH(1);
+    else DBN_WGRAD_LAUNCH(3);
+#undef DBN_WGRAD_LAUNCH
     int rc = dbn_status();
     if (rc) return rc;
     const int Jp = njt * bn;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp)), dim3(256), 0, st, slab, splitk, O, p.J, Jp, bm, bn, Cb, I, R,
                        S, grad_oihw, scale);
     return dbn_status();
+}
+
+int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                  int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
+    return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, 0, stream);
+}
+
+// dbn_wgrad_f32 on the bf16 matrix pipe (ns = 3: fp32-accurate operand split; ns = 1: bf16 operands)
+int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                    int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream) {
+    DBN_REQUIRE(ns == 1 || ns == 3);
+    return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, stream);
 }
 
 }  // extern "C"

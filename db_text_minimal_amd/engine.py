@@ -39,8 +39,8 @@ def flat_layout(numels):
     return offs, total
 
 
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d>',
-                    3: 'igemm_f32_kernel<128,64,2,2,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d>'}  # rocprof names
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d>'}  # rocprof names
 
 
 class KernelTimer:
@@ -96,6 +96,7 @@ class Engine:
         self._live = None
         self.nbt_pending = {}
         self.prof = None  # optional KernelTimer
+        self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = bf16 operands
         self.overlap_wgrad = False  # optional: weight gradients on a second HIP stream (measured +1.3 %, off by default)
         self._side = None
         self._side_used = False
@@ -142,6 +143,14 @@ class Engine:
         for name, cnt in self.nbt_pending.items():
             mods[name].num_batches_tracked += cnt
         self.nbt_pending = {}
+
+    MATH_MODES = {'f32': 0, 'bf16x3': 3, 'bf16': 1}
+
+    def set_conv_math(self, mode):
+        """'f32' (default): v_mfma_f32_32x32x2_f32, bit-exact fp32 products.  'bf16x3': fp32 operands split
+        into three bf16 terms, six bf16 MFMAs per product group, fp32 accumulate (fp32-accurate).
+        'bf16': operands rounded to bf16 (BASELINE configs[2] compute mode).  Tensors stay fp32 in HBM."""
+        self.ns = self.MATH_MODES[mode]
 
     def mark_params_dirty(self):
         self.param_epoch += 1
@@ -199,17 +208,32 @@ class Engine:
 
     # ------------------------------------------------------------ weight panels
     def pack(self, name, w, mode, stride=1):
-        key = (name, mode, stride)
+        ns = self.ns
+        key = (name, mode, stride, ns)
         ent = self.packs.get(key)
         stamp = (w._version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
         O, I, R, S = w.shape
-        n = self.L.dbn_igemm_panel_floats(O, I, R, S, mode, stride)
+        if ns == 0:
+            n = self.L.dbn_igemm_panel_floats(O, I, R, S, mode, stride)
+        else:
+            n = self.L.dbn_igemm_bf16s_panel_floats(O, I, R, S, mode, stride, ns)
         out = ent[0] if ent is not None else torch.empty(n, device=w.device, dtype=torch.float32)
-        check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), self.stream), 'pack_weights')
+        if ns == 0:
+            check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), self.stream), 'pack_weights')
+        else:
+            check(self.L.dbn_pack_weights_bf16s(w.data_ptr(), O, I, R, S, mode, stride, ns, out.data_ptr(), self.stream),
+                  'pack_weights_bf16s')
         self.packs[key] = (out, stamp)
         return out
+
+    def _igemm(self, what, *args):
+        """args = the dbn_igemm_f32 argument list without the trailing stream."""
+        if self.ns == 0:
+            check(self.L.dbn_igemm_f32(*args, self.stream), what)
+        else:
+            check(self.L.dbn_igemm_bf16s(*args, self.ns, self.stream), what)
 
     # ------------------------------------------------------------------ kernels
     def conv_fwd(self, name, x, conv, out_name):
@@ -221,14 +245,14 @@ class Engine:
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
             self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
-        check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
-                                   k, s, p, 0, 0, 0, self.stream), 'igemm fwd ' + name)
+        self._igemm('igemm fwd ' + name, x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
+                    k, s, p, 0, 0, 0)
         if self.prof:
             self.prof.end()
         return y
 
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
-        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % mode, flops, 0.0, tag)
+        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns), flops, 0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate):
         N, Ho, Wo, O = dy.shape
@@ -236,8 +260,8 @@ class Engine:
         wpk = self.pack(name, conv.weight, 1, conv.stride)
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
             self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1)
-        check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
-                                   conv.stride, conv.padding, 1, int(accumulate), 0, self.stream), 'igemm dgrad ' + name)
+        self._igemm('igemm dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
+                    conv.stride, conv.padding, 1, int(accumulate), 0)
         if self.prof:
             self.prof.end()
 
@@ -247,8 +271,12 @@ class Engine:
         slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k))
         if self.prof:
             self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
-        check(self.L.dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k,
-                                   k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
+        args = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride, pad,
+                self.grad_scale)
+        if self.ns == 0:
+            check(self.L.dbn_wgrad_f32(*args, self.stream), 'wgrad ' + name)
+        else:
+            check(self.L.dbn_wgrad_bf16s(*args, self.ns, self.stream), 'wgrad ' + name)
         if self.prof:
             self.prof.end()
 
@@ -264,8 +292,8 @@ class Engine:
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
             self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 2)
-        check(self.L.dbn_igemm_f32(x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
-                                   2, 2, 0, 1, 0, 0, self.stream), 'igemm convT fwd ' + name)
+        self._igemm('igemm convT fwd ' + name, x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W,
+                    ct.cout, 2, 2, 2, 0, 1, 0, 0)
         if self.prof:
             self.prof.end()
         return y
@@ -276,8 +304,8 @@ class Engine:
         wpk = self.pack(name, ct.weight, 0)
         if self.prof:
             self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4, 'convT dgrad ' + name, 0)
-        check(self.L.dbn_igemm_f32(dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2, 2, 0, 0, 0,
-                                   0, self.stream), 'igemm convT dgrad ' + name)
+        self._igemm('igemm convT dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2,
+                    2, 0, 0, 0, 0)
         if self.prof:
             self.prof.end()
         with self.side_stream():

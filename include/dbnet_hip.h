@@ -41,6 +41,19 @@ int dbn_igemm_packed_floats(int K, int Cd);
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream);
 
+/* The same three operations with the products evaluated on the bf16 matrix pipe (fp32 accumulate,
+ * fp32 tensors in and out).  ns = 3: every fp32 operand is split exactly into three bf16 terms and
+ * six partial products are accumulated -> fp32-accurate (measured error below a plain fp32 fmaf
+ * chain) at 6/16 of the fp32-MFMA cost.  ns = 1: operands rounded to bf16 (BASELINE configs[2]
+ * "bf16 compute").  Panels must come from dbn_pack_weights_bf16s with the same (mode, stride, ns). */
+int dbn_pack_weights_bf16s(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream);
+long dbn_igemm_bf16s_panel_floats(int O, int I, int R, int S, int mode, int stride, int ns);
+int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                    int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    void* stream);
+int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                    int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream);
+
 /* tile configuration chosen for tile_hint 0: 1=128x128, 2=256x64, 3=128x64, 4=64x64 */
 int dbn_igemm_tile_config(int M, int Cd);
 

@@ -39,29 +39,40 @@ def report(tag, got, ref, atol, rtol):
     assert worst <= 1.0, msg
 
 
-def pack(w, mode, stride=1):
-    """w: CPU OIHW tensor -> device panels."""
+def pack(w, mode, stride=1, ns=0):
+    """w: CPU OIHW tensor -> device panels (ns = 0 fp32 MFMA, 3 = bf16x3 split, 1 = bf16)."""
     O, I, R, S = w.shape
-    out = torch.empty(L().dbn_igemm_panel_floats(O, I, R, S, mode, stride), device=DEV)
     wd = w.contiguous().to(DEV)
-    _lib.check(L().dbn_pack_weights(wd.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), stream()), 'pack')
+    if ns == 0:
+        out = torch.empty(L().dbn_igemm_panel_floats(O, I, R, S, mode, stride), device=DEV)
+        _lib.check(L().dbn_pack_weights(wd.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), stream()), 'pack')
+    else:
+        out = torch.empty(L().dbn_igemm_bf16s_panel_floats(O, I, R, S, mode, stride, ns), device=DEV)
+        _lib.check(L().dbn_pack_weights_bf16s(wd.data_ptr(), O, I, R, S, mode, stride, ns, out.data_ptr(), stream()), 'pack')
     return out
 
 
-def igemm(src, wpk, bias, dst, R, stride, pad, mode, accumulate=0, tile=0):
+def igemm(src, wpk, bias, dst, R, stride, pad, mode, accumulate=0, tile=0, ns=0):
     N, Hs, Ws, Cs = src.shape
     _, Hd, Wd, Cd = dst.shape
-    _lib.check(L().dbn_igemm_f32(src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(), N, Hs,
-                                 Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, mode, accumulate, tile, stream()), 'igemm')
+    args = (src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(), N, Hs, Ws, Cs, Hd, Wd, Cd, R,
+            R, stride, pad, mode, accumulate, tile)
+    if ns == 0:
+        _lib.check(L().dbn_igemm_f32(*args, stream()), 'igemm')
+    else:
+        _lib.check(L().dbn_igemm_bf16s(*args, ns, stream()), 'igemm_bf16s')
 
 
-def wgrad(sm, big, O, I, k, stride, pad, scale=1.0):
+def wgrad(sm, big, O, I, k, stride, pad, scale=1.0, ns=0):
     N, Ho, Wo, _ = sm.shape
     _, H, W, Cb = big.shape
     slab = torch.empty(L().dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k), device=DEV)
     g = torch.full((O, I, k, k), float('nan'), device=DEV)
-    _lib.check(L().dbn_wgrad_f32(sm.data_ptr(), big.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k,
-                                 stride, pad, scale, stream()), 'wgrad')
+    args = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride, pad, scale)
+    if ns == 0:
+        _lib.check(L().dbn_wgrad_f32(*args, stream()), 'wgrad')
+    else:
+        _lib.check(L().dbn_wgrad_bf16s(*args, ns, stream()), 'wgrad_bf16s')
     return g
 
 

@@ -201,3 +201,31 @@ def test_full_size_bs16_properties():
     for _ in range(3):
         _, losses = tr.step(img, gts)
     assert float(losses[4]) < l0, 'loss did not decrease over 4 Adam steps on a fixed batch'
+
+
+@pytest.mark.parametrize('math,map_tol,loss_tol,cos_min', [('bf16x3', (1e-3, 1e-2), 1e-5, 0.999), ('bf16', (6e-2, 6e-2), 3e-2, 0.75)])
+def test_split_bf16_conv_math_modes(math, map_tol, loss_tol, cos_min):
+    """Conv math on the bf16 matrix pipe.  'bf16x3' (three-way exact operand split, fp32 accumulate) must meet the SAME
+    north_star tolerance as the native fp32 path; 'bf16' (BASELINE configs[2] compute mode: operands rounded to bf16,
+    fp32 accumulate / storage / BN / loss) gets the looser bound stated here: 5e-2 abs on P,T (B = sigmoid(50(P-T)) is
+    not compared per pixel), 3 % on the losses, gradient cosine >= 0.75 (measured 0.82-0.98: bf16 activation
+    noise flips many ReLU masks and the k=50 step function concentrates the gradient on few pixels)."""
+    seed, n, size = 11, 2, 128
+    img, gts = O.synthetic_batch(n, size, seed=seed)
+    sd = O.new_state(seed)
+    model = make_model(seed).train()
+    model.engine.set_conv_math(math)
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+    preds_o, losses_o, grads_o = O.loss_and_grads(sd, img, gts)
+    chans = 3 if math == 'bf16x3' else 2
+    report(math + ' maps', preds[:, :chans].cpu(), preds_o[:, :chans], *map_tol)
+    report(math + ' losses', losses.cpu().double(), torch.tensor(losses_o).double(), loss_tol, loss_tol if math == 'bf16' else 1e-5)
+    worst = 1.0
+    for k in ('backbone.conv1.weight', 'backbone.layer2.0.conv1.weight', 'segmentation_body.conv.0.weight',
+              'segmentation_head.binarize.3.weight', 'segmentation_head.thresh.0.weight', 'backbone.layer4.1.bn2.weight'):
+        a, b = model.engine.grad_views[k].cpu().double().flatten(), grads_o[k].double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm()))
+        print('%s grad %s: cos %.6f, |g| ratio %.5f' % (math, k, cos, float(a.norm() / b.norm())))
+        worst = min(worst, cos)
+    assert worst >= cos_min, worst

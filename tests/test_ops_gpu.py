@@ -286,3 +286,80 @@ def test_adam():
                                      0.25, stream()), 'adam')
     report('adam params', p.cpu(), sd['w'], 1e-6, 1e-5)
     report('adam exp_avg', m.cpu(), opt.m['w'], 1e-8, 1e-5)
+
+
+# ---- split-bf16 math modes (same kernels, products on the bf16 matrix pipe) ---------------------
+# ns=3 ("bf16x3"): fp32-accurate -> same tolerances as the native fp32 path.  ns=1: bf16 operands
+# (8-bit mantissa): relative error ~ 2^-9 * sqrt(K)/sqrt(K) per output -> 2e-2 of the output scale.
+SPLIT_TOL = {3: (1e-4, 1e-4), 1: (3e-2, 3e-2)}
+
+
+@pytest.mark.parametrize('ns', [3, 1])
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+def test_conv_forward_split(case, tile, ns):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    b = rnd(Co, seed=3)
+    ref = F.conv2d(x, w, b, s, p)
+    Ho, Wo = ref.shape[2:]
+    xs = nhwc(pad_c(x, (Ci + 3) // 4 * 4))
+    y = torch.full((N, Ho, Wo, Co), float('nan'), device=DEV)
+    igemm(xs, pack(w, 0, s, ns), b.to(DEV), y, k, s, p, 0, 0, tile, ns)
+    atol, rtol = SPLIT_TOL[ns]
+    report('conv fwd ns=%d %s tile %d' % (ns, case, tile), nchw(y), ref, atol * float(ref.abs().max()) if ns == 1 else atol, rtol)
+
+
+@pytest.mark.parametrize('ns', [3, 1])
+@pytest.mark.parametrize('case', DGRAD_CASES)
+def test_conv_dgrad_split(case, ns):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=4)
+    (dx_ref, ) = torch.autograd.grad(y, x, dy)
+    dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)
+    igemm(nhwc(dy), pack(w, 1, s, ns), None, dx, k, s, p, 1, 0, 0, ns)
+    atol, rtol = SPLIT_TOL[ns]
+    report('conv dgrad ns=%d %s' % (ns, case), nchw(dx), dx_ref, atol * float(dx_ref.abs().max()) if ns == 1 else atol, rtol)
+
+
+@pytest.mark.parametrize('ns', [3, 1])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv_wgrad_split(case, ns):
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = rnd(*y.shape, seed=4)
+    (dw_ref, ) = torch.autograd.grad(y, w, dy)
+    g = wgrad(nhwc(dy), nhwc(pad_c(x, (Ci + 3) // 4 * 4)), Co, Ci, k, s, p, 1.0, ns)
+    scale = float(dw_ref.abs().max())
+    if ns == 3:
+        report('conv wgrad ns=3 %s' % (case, ), g.cpu(), dw_ref, 2e-5 * scale + 1e-5, 1e-4)
+    else:
+        report('conv wgrad ns=1 %s' % (case, ), g.cpu(), dw_ref, 3e-2 * scale, 3e-2)
+
+
+@pytest.mark.parametrize('ns', [3, 1])
+def test_conv_transpose_split(ns):
+    N, Ci, Co, H, W = 2, 64, 64, 8, 6
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Ci, Co, 2, 2, seed=2, scale=0.1).requires_grad_(True)
+    b = rnd(Co, seed=3)
+    ref = F.conv_transpose2d(x, w, b, 2)
+    dy = rnd(*ref.shape, seed=5)
+    dx_ref, dw_ref = torch.autograd.grad(ref, (x, w), dy)
+    xs = nhwc(x.detach())
+    atol, rtol = SPLIT_TOL[ns]
+    y = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
+    igemm(xs, pack(w.detach(), 1, 2, ns), b.to(DEV), y, 2, 2, 0, 1, 0, 0, ns)
+    report('convT fwd ns=%d' % ns, nchw(y), ref, atol * float(ref.abs().max()), rtol)
+    dys = nhwc(dy)
+    dx = torch.full((N, H, W, Ci), float('nan'), device=DEV)
+    igemm(dys, pack(w.detach(), 0, 2, ns), None, dx, 2, 2, 0, 0, 0, 0, ns)
+    report('convT dgrad ns=%d' % ns, nchw(dx), dx_ref, atol * float(dx_ref.abs().max()), rtol)
+    g = wgrad(xs, dys, Ci, Co, 2, 2, 0, 1.0, ns)
+    report('convT wgrad ns=%d' % ns, g.cpu(), dw_ref, atol * float(dw_ref.abs().max()), rtol)
