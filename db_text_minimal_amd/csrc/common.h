@@ -54,9 +54,14 @@ __device__ __forceinline__ double dbn_wave_sum_d(double v) {
 // folding one output read one contiguous 128-byte line per step.  Call with all 32 lanes of an
 // aligned half-wave (lane32 = threadIdx.x & 31); every lane returns the total (fp64 fold).
 __device__ __forceinline__ double dbn_team32_fold(const float* __restrict__ part, int nb, long idx, int lane32) {
-    double s = 0.0;
     const float* row = part + idx * nb;
-    for (int b = lane32; b < nb; b += 32) s += (double)row[b];
+    double s = 0.0;
+    int b = lane32;
+    for (; b + 96 < nb; b += 128) {  // four independent loads in flight per lane
+        const float v0 = row[b], v1 = row[b + 32], v2 = row[b + 64], v3 = row[b + 96];
+        s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; b < nb; b += 32) s += (double)row[b];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     return s;

@@ -343,6 +343,39 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
     }
 }
 
+// 2x2 confusion matrix of the per-step pixel metric (text_metrics.py:14-24,63-82):
+// pred = (P*M > thresh), gt = int(G*M); hist[2*gt + pred] += 1 over ALL pixels.
+__global__ void pixel_confusion_kernel(const float* __restrict__ preds, long batch_stride, const float* __restrict__ gt,
+                                       const float* __restrict__ mask, int N, long HW, float thresh, double* __restrict__ hist) {
+    const long total = (long)N * HW;
+    unsigned c01 = 0, c10 = 0, c11 = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, o = i - n * HW;
+        const float m = mask[i];
+        const int p = preds[n * batch_stride + o] * m > thresh;
+        const int g = (int)(gt[i] * m) != 0;  // binary maps: int() truncation like .astype(np.int32)
+        c01 += (!g) & p;
+        c10 += g & (!p);
+        c11 += g & p;
+    }
+    __shared__ unsigned red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned v[3] = {c01, c10, c11};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+        if (lane == 0) red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
+        atomicAdd(&hist[1 + threadIdx.x], (double)t);  // integer-valued doubles: the sum is exact and order-independent
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 3) atomicAdd(&hist[4], (double)total);  // hist[0] = total - others, formed by the reader
+}
+
 }  // namespace
 
 extern "C" {
@@ -405,6 +438,17 @@ int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, con
     DBN_REQUIRE(HW % 4 == 0);
     hipLaunchKernelGGL(db_loss_bwd_kernel, dim3(dbn_grid((long)N * HW / 4)), dim3(256), 0, (hipStream_t)stream, preds, gts, coef,
                        grad_losses, alpha, beta, N, HW, channels, dpreds);
+    return dbn_status();
+}
+
+// hist: 5 doubles, ACCUMULATED into (running confusion matrix): [unused, n01, n10, n11, total]; n00 = total-n01-n10-n11.
+// preds points at the probability plane of image 0; batch_stride = floats between consecutive images (C*H*W).
+int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, const float* mask, int N, int H, int W, float thresh,
+                        double* hist, void* stream) {
+    DBN_REQUIRE(preds && gt && mask && hist && N > 0 && H > 0 && W > 0);
+    const long total = (long)N * H * W;
+    hipLaunchKernelGGL(pixel_confusion_kernel, dim3(dbn_grid(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, preds, batch_stride,
+                       gt, mask, N, (long)H * W, thresh, hist);
     return dbn_status();
 }
 

@@ -115,6 +115,12 @@ int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, i
 int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, float alpha, float beta,
                     int N, int H, int W, int channels, float* dpreds, void* stream);
 
+/* ---- per-step pixel metric (cal_text_score / RunningScore._fast_hist, text_metrics.py:14-24,63-82):
+ *      2x2 confusion matrix of (P*M > thresh) vs int(G*M), accumulated on device into 5 doubles
+ *      [unused, n01, n10, n11, total] (index = 2*gt + pred) — replaces 3 D2H copies + np.bincount per step */
+int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, const float* mask, int N, int H, int W, float thresh,
+                        double* hist, void* stream);
+
 /* ---- optimizer (torch.optim.Adam, train.py:114-117,172) over one flat buffer */
 int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);

@@ -396,3 +396,36 @@ def train_step(sd, opt, img, gts, **loss_kw):
     with torch.no_grad():
         opt.step(sd, grads)
     return preds, losses
+
+
+# ----------------------------------------------------------------------------
+# per-step pixel metric (text_metrics.py:9-82), numpy restatement
+# ----------------------------------------------------------------------------
+
+
+def pixel_confusion(texts, gt_texts, training_masks, thresh=0.5, n_classes=2):
+    """cal_text_score's thresholding (text_metrics.py:73-80) + RunningScore._fast_hist (:14-24),
+    summed over the batch.  Returns the n x n confusion matrix (rows: gt, cols: pred)."""
+    import numpy as np
+    masks = training_masks.detach().cpu().numpy()
+    pred = texts.detach().cpu().numpy() * masks
+    pred[pred <= thresh] = 0
+    pred[pred > thresh] = 1
+    pred = pred.astype(np.int32)
+    gt = (gt_texts.detach().cpu().numpy() * masks).astype(np.int32)
+    hist = np.zeros((n_classes, n_classes))
+    for lt, lp in zip(gt, pred):
+        lt, lp = lt.flatten(), lp.flatten()
+        m = (lt >= 0) & (lt < n_classes)
+        hist += np.bincount(n_classes * lt[m].astype(int) + lp[m], minlength=n_classes**2).reshape(n_classes, n_classes)
+    return hist
+
+
+def scores_from_confusion(hist):
+    """RunningScore.get_scores (text_metrics.py:36-58)."""
+    import numpy as np
+    acc = np.diag(hist).sum() / (hist.sum() + 0.0001)
+    acc_cls = np.nanmean(np.diag(hist) / (hist.sum(axis=1) + 0.0001))
+    iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist) + 0.0001)
+    freq = hist.sum(axis=1) / (hist.sum() + 0.0001)
+    return {'Overall Acc': acc, 'Mean Acc': acc_cls, 'FreqW Acc': (freq[freq > 0] * iu[freq > 0]).sum(), 'Mean IoU': np.nanmean(iu)}

@@ -177,6 +177,33 @@ def case_dp(name, size, seed):
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
+def case_pixel_metrics():
+    """cal_text_score / RunningScore of the reference (text_metrics.py); its imports `iou` (shapely) and
+    `utils` (cv2, ...) are not installed here and are unrelated to the pixel metric -> stubbed."""
+    print('== pixel_metrics')
+    import types
+    for name, attrs in (('iou', {'DetectionIoUEvaluator': object}), ('utils', {'to_list_tuples_coords': None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    from text_metrics import RunningScore, cal_text_score  # reference
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    rs = RunningScore(2)
+    for step in range(2):
+        P = torch.rand(2, 48, 40, generator=g)
+        G = (torch.rand(2, 48, 40, generator=g) > 0.7).float()
+        M = (torch.rand(2, 48, 40, generator=g) > 0.1).float()
+        score = cal_text_score(P, G, M, rs, thresh=0.25)
+        out['step%d/P' % step], out['step%d/G' % step], out['step%d/M' % step] = P.numpy(), G.numpy(), M.numpy()
+        out['step%d/hist' % step] = rs.confusion_matrix.copy()
+        out['step%d/scores' % step] = np.array([score[k] for k in ('Overall Acc', 'Mean Acc', 'FreqW Acc', 'Mean IoU')])
+        hist_o = O.pixel_confusion(P, G, M, 0.25)
+        print('  ', rs.confusion_matrix.tolist(), score)
+    np.savez_compressed(os.path.join(HERE, 'pixel_metrics.npz'), **out)
+
+
 def check_oracle():
     """Pin the oracle against the imported reference right here."""
     print('== oracle vs reference')
@@ -208,6 +235,9 @@ def check_oracle():
 
 if __name__ == '__main__':
     check_oracle()
+    case_pixel_metrics()
+    if '--only-metrics' in sys.argv:
+        sys.exit(0)
     case_loss_kats()
     case_train('train_1x64', 1, 64, seed=1, steps=3)
     case_train('train_2x128', 2, 128, seed=2, steps=3)

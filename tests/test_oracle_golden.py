@@ -116,3 +116,16 @@ def test_dp_golden_is_mean_of_shard_grads(golden_dir):
         a = (acc[k] / 2).double().reshape(-1).numpy()
         st = z['grad/' + k + '/stats']
         assert abs(np.sqrt((a * a).sum()) - st[2]) <= 1e-5 * st[2]
+
+
+def test_oracle_pixel_metrics_match_reference(golden_dir):
+    """text_metrics.cal_text_score / RunningScore restated in the oracle vs the reference's own output."""
+    z = np.load(os.path.join(golden_dir, 'pixel_metrics.npz'))
+    hist = np.zeros((2, 2))
+    for step in range(2):
+        P, G, M = (torch.from_numpy(z['step%d/%s' % (step, k)]) for k in 'PGM')
+        hist += O.pixel_confusion(P, G, M, 0.25)
+        assert np.array_equal(hist, z['step%d/hist' % step])
+        sc = O.scores_from_confusion(hist)
+        got = [sc[k] for k in ('Overall Acc', 'Mean Acc', 'FreqW Acc', 'Mean IoU')]
+        assert np.allclose(got, z['step%d/scores' % step], rtol=1e-12)
