@@ -45,10 +45,13 @@ SIGNATURES = {
     'dbn_db_loss_ws_bytes': '',
     'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
+    'dbn_db_loss_ohem_ws_bytes': 'iii',
+    'dbn_db_loss_ohem_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
+    'dbn_db_loss_ohem_bwd': 'ppppp' + 'ff' + 'iiii' + 'pp',
     'dbn_pixel_confusion': 'plppiiifpp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
-LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats'}
+LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

@@ -298,8 +298,8 @@ __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb,
 
 // gout[5]: upstream grads of the 5 returned losses (device); dpreds planes like preds.
 __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float* __restrict__ gts, const float* __restrict__ coef,
-                                   const float* __restrict__ gout, float alpha, float beta, int N, long HW, int CH,
-                                   float* __restrict__ dpreds) {
+                                   const float* __restrict__ gout, const float* __restrict__ ohem_v, float alpha, float beta, int N,
+                                   long HW, int CH, float* __restrict__ dpreds) {
     const long total4 = (long)N * HW / 4;
     const long NHW = (long)N * HW;
     // effective weights of the three base losses
@@ -314,6 +314,8 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
         w_bin = 0.f;
     }
     const float cb = coef[0] * w_prob;
+    const bool per_pixel = ohem_v != nullptr;
+    const float tau = per_pixel ? coef[4] : 0.f, tie_w = per_pixel ? coef[5] : 0.f;
     const float ca = coef[1] * w_thr;
     const float U = coef[2], I = coef[3];
     const float cd = -2.f * w_bin / (U * U);
@@ -332,7 +334,13 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             // ATen binary_cross_entropy backward: (x - t) / max((1-x)*x, 1e-12)
-            dP[e] = cb * (P[e] - G[e]) / fmaxf((1.f - P[e]) * P[e], 1e-12f);
+            float wsel = 1.f;  // 'mean': the scalar BCE weights every pixel alike
+            if (per_pixel) {     // 'none': positives + the selected (top n_neg) negatives
+                const float vv = ohem_v[p + e];
+                const float sel = vv > tau ? 1.f : (vv == tau ? tie_w : 0.f);
+                wsel = G[e] * M[e] + (1.f - G[e]) * M[e] * sel;
+            }
+            dP[e] = cb * wsel * (P[e] - G[e]) / fmaxf((1.f - P[e]) * P[e], 1e-12f);
             const float d = T[e] - Tg[e];
             dT[e] = ca * A[e] * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
             dB[e] = cd * M[e] * (G[e] * U - I);
@@ -341,6 +349,167 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
         *reinterpret_cast<f32x4*>(db + HW) = dT;
         if (CH == 3) *reinterpret_cast<f32x4*>(db + 2 * HW) = dB;
     }
+}
+
+// ----------------------------------------------------------------------------------
+// true per-pixel OHEM (DBLoss(reduction='none'), losses.py:30-39): device radix select of the
+// n_neg largest negative losses.  State (uint64 words): [0] k, [1] prefix bits, [2] count above the
+// prefix so far, [3] tau bits, [4] cnt_eq;  hist: 3 x 2048 uint32.
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_px(float P, float G) {
+    const float lp = fmaxf(logf(P), -100.f);
+    const float lq = fmaxf(log1pf(-P), -100.f);
+    return (G - 1.f) * lq - G * lp;
+}
+
+constexpr int OHEM_BINS = 2048;
+__device__ __forceinline__ unsigned ohem_digit(unsigned bits, int pass) {
+    return pass == 0 ? bits >> 21 : pass == 1 ? (bits >> 10) & 2047u : bits & 1023u;
+}
+__device__ __forceinline__ bool ohem_prefix_match(unsigned bits, unsigned prefix, int pass) {
+    return pass == 0 ? true : pass == 1 ? (bits >> 21) == (prefix >> 21) : (bits >> 10) == (prefix >> 10);
+}
+
+// k = n_neg from the folded sums; clears the select state.  One block.
+__global__ void ohem_prepare_kernel(const double* __restrict__ part, int nb, float negative_ratio, unsigned long long* __restrict__ st,
+                                    unsigned* __restrict__ hist) {
+    __shared__ double sums[2];
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        double t = 0.0;
+        for (int b = l32; b < nb; b += 32) t += part[(long)b * NSUM + (k == 0 ? S_POS : S_NEG)];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (l32 == 0) sums[k] = t;
+    }
+    for (int i = threadIdx.x; i < 3 * OHEM_BINS; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long n_pos = (long)(float)sums[0];
+        const long n_exp = (long)((double)n_pos * (double)negative_ratio);
+        const long n_cur = (long)(float)sums[1];
+        st[0] = (unsigned long long)(n_exp < n_cur ? n_exp : n_cur);
+        st[1] = 0;
+        st[2] = 0;
+        st[3] = 0xFFFFFFFFull;  // tau bits: "select nothing" until the scans say otherwise
+        st[4] = 0;
+    }
+}
+
+// v[i] = bce_i * negative_i; partial sums of bce_i * positive_i (double, [block])
+__global__ void ohem_values_kernel(const float* __restrict__ preds, const float* __restrict__ gts, int N, long HW, int CH,
+                                   float* __restrict__ v, double* __restrict__ part) {
+    const long total = (long)N * HW, NHW = total;
+    double acc = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, o = i - n * HW;
+        const float P = preds[n * CH * HW + o], G = gts[i], M = gts[NHW + i];
+        const float l = bce_px(P, G);
+        v[i] = fabsf(l * ((1.f - G) * M));  // +0 (never -0): the select orders values by their bit pattern
+        acc += (double)(l * (G * M));
+    }
+    __shared__ double red[4];
+    const double w = dbn_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+        part[blockIdx.x] = t;
+    }
+}
+
+__global__ void ohem_hist_kernel(const float* __restrict__ v, long total, const unsigned long long* __restrict__ st, int pass,
+                                 unsigned* __restrict__ hist) {
+    __shared__ unsigned lh[OHEM_BINS];
+    for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const unsigned prefix = (unsigned)st[1];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const unsigned bits = __builtin_bit_cast(unsigned, v[i]);  // v >= 0: the bit pattern orders like the value
+        if (ohem_prefix_match(bits, prefix, pass)) atomicAdd(&lh[ohem_digit(bits, pass)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < OHEM_BINS; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[pass * OHEM_BINS + i], lh[i]);
+}
+
+// walk the bins from the top until the k-th largest value's bin; extend the prefix.  One thread.
+__global__ void ohem_scan_kernel(unsigned long long* __restrict__ st, const unsigned* __restrict__ hist, int pass) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long k = st[0];
+    if (k == 0) return;
+    unsigned long long above = st[2];
+    const int nb = pass == 2 ? 1024 : OHEM_BINS;
+    int b = nb - 1;
+    for (; b > 0; --b) {
+        const unsigned c = hist[pass * OHEM_BINS + b];
+        if (above + c >= k) break;
+        above += c;
+    }
+    st[2] = above;
+    const unsigned long long shift = pass == 0 ? 21 : pass == 1 ? 10 : 0;
+    st[1] |= (unsigned long long)b << shift;
+    if (pass == 2) {
+        st[3] = st[1];                        // tau bits
+        st[4] = hist[2 * OHEM_BINS + b];      // elements equal to tau
+    }
+}
+
+// partial[block] = {sum of v > tau, count of v > tau}
+__global__ void ohem_sum_kernel(const float* __restrict__ v, long total, const unsigned long long* __restrict__ st,
+                                double* __restrict__ part) {
+    const unsigned tau = (unsigned)st[3];
+    double acc = 0.0, cnt = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float x = v[i];
+        if (__builtin_bit_cast(unsigned, x) > tau) {
+            acc += (double)x;
+            cnt += 1.0;
+        }
+    }
+    __shared__ double red[4][2];
+    const double w0 = dbn_wave_sum_d(acc), w1 = dbn_wave_sum_d(cnt);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6][0] = w0;
+        red[threadIdx.x >> 6][1] = w1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k][threadIdx.x];
+        part[2 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
+// prob_loss of the per-pixel OHEM; overwrites losses[0], [3], [4] and coef[0], coef[4..6] left by the 'mean' finalize.
+__global__ void ohem_finalize_kernel(const double* __restrict__ part_sums, int nb_sums, const double* __restrict__ part_pos, int nb_pos,
+                                     const double* __restrict__ part_sel, int nb_sel, const unsigned long long* __restrict__ st,
+                                     int CH, float alpha, float beta, float eps, float* __restrict__ losses, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s_pos = 0.0, pos_loss = 0.0, sel = 0.0, cnt_gt = 0.0;
+    for (int b = 0; b < nb_sums; ++b) s_pos += part_sums[(long)b * NSUM + S_POS];
+    for (int b = 0; b < nb_pos; ++b) pos_loss += part_pos[b];
+    for (int b = 0; b < nb_sel; ++b) {
+        sel += part_sel[2 * b];
+        cnt_gt += part_sel[2 * b + 1];
+    }
+    const double k = (double)st[0];
+    const float tau = k > 0 ? __builtin_bit_cast(float, (unsigned)st[3]) : 0.f;
+    const double n_tie = k - cnt_gt;  // taken from the elements equal to tau
+    const double cnt_eq = (double)st[4];
+    const long n_pos = (long)(float)s_pos;
+    const float denom = (float)((double)n_pos + k + (double)eps);
+    const float prob = (float)(pos_loss + sel + n_tie * (double)tau) / denom;
+    const float thr = losses[1];
+    const float pt = prob + beta * thr;
+    losses[0] = prob;
+    losses[3] = pt;
+    losses[4] = (CH == 3 ? alpha * losses[2] : 0.f) + pt;
+    coef[0] = 1.f / denom;
+    coef[4] = k > 0 ? tau : 3.0e38f;  // nothing is above FLT_MAX-ish -> no negatives selected
+    coef[5] = (k > 0 && cnt_eq > 0) ? (float)(n_tie / cnt_eq) : 0.f;
+    coef[6] = 1.f;  // per-pixel mode
 }
 
 // 2x2 confusion matrix of the per-step pixel metric (text_metrics.py:14-24,63-82):
@@ -417,28 +586,75 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
 
 int dbn_db_loss_ws_bytes() { return 1024 * NSUM * (int)sizeof(double); }
 
-// losses: [5] floats, coef: [8] floats (kept for the backward), ws: dbn_db_loss_ws_bytes()
-int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
-                    float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
+// workspace of the per-pixel OHEM path: sums partials | pos partials | select partials | state | hist | v[N*H*W]
+static const long OHEM_OFF_POS = 1024L * NSUM * 8, OHEM_OFF_SEL = OHEM_OFF_POS + 1024L * 8, OHEM_OFF_ST = OHEM_OFF_SEL + 2048L * 8,
+                  OHEM_OFF_HIST = OHEM_OFF_ST + 64, OHEM_OFF_V = OHEM_OFF_HIST + 3L * OHEM_BINS * 4;
+long dbn_db_loss_ohem_ws_bytes(int N, int H, int W) { return OHEM_OFF_V + (long)N * H * W * 4; }
+
+static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                           float negative_ratio, float eps, int per_pixel, float* losses, float* coef, void* ws, void* stream) {
     DBN_REQUIRE(preds && gts && losses && coef && ws && (channels == 2 || channels == 3));
     const long HW = (long)H * W;
     DBN_REQUIRE(HW % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     const int nb = dbn_grid((long)N * HW / 4, 256, 1024);
+    char* base = (char*)ws;
     hipLaunchKernelGGL(db_loss_fwd_kernel, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
     hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
                        beta, negative_ratio, eps, losses, coef);
+    if (!per_pixel) return dbn_status();
+    double* part_pos = (double*)(base + OHEM_OFF_POS);
+    double* part_sel = (double*)(base + OHEM_OFF_SEL);
+    unsigned long long* state = (unsigned long long*)(base + OHEM_OFF_ST);
+    unsigned* hist = (unsigned*)(base + OHEM_OFF_HIST);
+    float* v = (float*)(base + OHEM_OFF_V);
+    const long total = (long)N * HW;
+    const int nbv = dbn_grid(total, 256, 1024);
+    hipLaunchKernelGGL(ohem_prepare_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, negative_ratio, state, hist);
+    hipLaunchKernelGGL(ohem_values_kernel, dim3(nbv), dim3(256), 0, st, preds, gts, N, HW, channels, v, part_pos);
+    for (int pass = 0; pass < 3; ++pass) {
+        hipLaunchKernelGGL(ohem_hist_kernel, dim3(nbv), dim3(256), 0, st, v, total, state, pass, hist);
+        hipLaunchKernelGGL(ohem_scan_kernel, dim3(1), dim3(64), 0, st, state, hist, pass);
+    }
+    hipLaunchKernelGGL(ohem_sum_kernel, dim3(nbv), dim3(256), 0, st, v, total, state, part_sel);
+    hipLaunchKernelGGL(ohem_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, part_pos, nbv, part_sel, nbv, state,
+                       channels, alpha, beta, eps, losses, coef);
+    return dbn_status();
+}
+
+// losses: [5] floats, coef: [8] floats (kept for the backward), ws: dbn_db_loss_ws_bytes()
+int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                    float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
+    return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, 0, losses, coef, ws, stream);
+}
+
+// DBLoss(reduction='none'): true per-pixel OHEM (top n_neg negative losses, device radix select).
+// ws: dbn_db_loss_ohem_ws_bytes(N,H,W) bytes, must stay untouched until dbn_db_loss_ohem_bwd has run.
+int dbn_db_loss_ohem_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                         float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
+    return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, 1, losses, coef, ws, stream);
+}
+
+static int db_loss_bwd_run(const float* preds, const float* gts, const float* coef, const float* grad_losses, const float* ohem_v,
+                           float alpha, float beta, int N, int H, int W, int channels, float* dpreds, void* stream) {
+    DBN_REQUIRE(preds && gts && coef && grad_losses && dpreds && (channels == 2 || channels == 3));
+    const long HW = (long)H * W;
+    DBN_REQUIRE(HW % 4 == 0);
+    hipLaunchKernelGGL(db_loss_bwd_kernel, dim3(dbn_grid((long)N * HW / 4)), dim3(256), 0, (hipStream_t)stream, preds, gts, coef,
+                       grad_losses, ohem_v, alpha, beta, N, HW, channels, dpreds);
     return dbn_status();
 }
 
 int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, float alpha, float beta,
                     int N, int H, int W, int channels, float* dpreds, void* stream) {
-    DBN_REQUIRE(preds && gts && coef && grad_losses && dpreds && (channels == 2 || channels == 3));
-    const long HW = (long)H * W;
-    DBN_REQUIRE(HW % 4 == 0);
-    hipLaunchKernelGGL(db_loss_bwd_kernel, dim3(dbn_grid((long)N * HW / 4)), dim3(256), 0, (hipStream_t)stream, preds, gts, coef,
-                       grad_losses, alpha, beta, N, HW, channels, dpreds);
-    return dbn_status();
+    return db_loss_bwd_run(preds, gts, coef, grad_losses, nullptr, alpha, beta, N, H, W, channels, dpreds, stream);
+}
+
+int dbn_db_loss_ohem_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, const void* ws,
+                         float alpha, float beta, int N, int H, int W, int channels, float* dpreds, void* stream) {
+    DBN_REQUIRE(ws);
+    return db_loss_bwd_run(preds, gts, coef, grad_losses, (const float*)((const char*)ws + OHEM_OFF_V), alpha, beta, N, H, W, channels,
+                           dpreds, stream);
 }
 
 // hist: 5 doubles, ACCUMULATED into (running confusion matrix): [unused, n01, n10, n11, total]; n00 = total-n01-n10-n11.

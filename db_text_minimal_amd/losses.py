@@ -10,6 +10,9 @@ The reductions and the gradient are two HIP kernels (dbn_db_loss_fwd/_bwd).
 With the default `reduction='mean'` the reference's "OHEM" term is a scalar BCE
 re-weighted by counts; the kernel evaluates that closed form,
 which is exact for binary gt/mask maps (what the reference's loader produces).
+`reduction='none'` is the paper's per-pixel OHEM: the `n_neg` hardest negatives
+are selected on device by a 3-pass radix select (dbn_db_loss_ohem_fwd/_bwd)
+instead of `torch.topk` over 6.5 M elements.
 No host synchronisation happens here (the reference's `int(tensor)` / `assert`
 syncs, losses.py:25-27,65, are folded into the finalize kernel).
 """
@@ -22,25 +25,30 @@ from ._lib import check
 
 class _DBLossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, preds, gts, alpha, beta, negative_ratio, eps):
+    def forward(ctx, preds, gts, alpha, beta, negative_ratio, eps, per_pixel):
         L = _lib.lib()
         N, C, H, W = preds.shape
         st = torch.cuda.current_stream(preds.device).cuda_stream
         losses = torch.empty(5, device=preds.device, dtype=torch.float32)
-        coef = torch.empty(8, device=preds.device, dtype=torch.float32)
-        ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=preds.device, dtype=torch.float32)
-        check(L.dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
-                                losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_fwd')
-        ctx.save_for_backward(preds, gts, coef)
-        ctx.cfg = (alpha, beta)
+        coef = torch.zeros(8, device=preds.device, dtype=torch.float32)
+        if per_pixel:
+            ws = torch.empty(L.dbn_db_loss_ohem_ws_bytes(N, H, W) // 4 + 1, device=preds.device, dtype=torch.float32)
+            check(L.dbn_db_loss_ohem_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
+                                         losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_ohem_fwd')
+        else:
+            ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=preds.device, dtype=torch.float32)
+            check(L.dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
+                                    losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_fwd')
+        ctx.save_for_backward(preds, gts, coef, ws)
+        ctx.cfg = (alpha, beta, per_pixel)
         if C == 3:
             return tuple(losses[i] for i in range(5))
         return losses[4]
 
     @staticmethod
     def backward(ctx, *gouts):
-        preds, gts, coef = ctx.saved_tensors
-        alpha, beta = ctx.cfg
+        preds, gts, coef, ws = ctx.saved_tensors
+        alpha, beta, per_pixel = ctx.cfg
         L = _lib.lib()
         N, C, H, W = preds.shape
         st = torch.cuda.current_stream(preds.device).cuda_stream
@@ -52,17 +60,21 @@ class _DBLossFunction(torch.autograd.Function):
         else:
             g[4] = gouts[0]
         dpreds = torch.empty_like(preds)
-        check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), coef.data_ptr(), g.data_ptr(), alpha, beta, N, H, W, C,
-                                dpreds.data_ptr(), st), 'db_loss_bwd')
-        return dpreds, None, None, None, None, None
+        if per_pixel:
+            check(L.dbn_db_loss_ohem_bwd(preds.data_ptr(), gts.data_ptr(), coef.data_ptr(), g.data_ptr(), ws.data_ptr(), alpha, beta,
+                                         N, H, W, C, dpreds.data_ptr(), st), 'db_loss_ohem_bwd')
+        else:
+            check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), coef.data_ptr(), g.data_ptr(), alpha, beta, N, H, W, C,
+                                    dpreds.data_ptr(), st), 'db_loss_bwd')
+        return dpreds, None, None, None, None, None, None
 
 
 class DBLoss(nn.Module):
     def __init__(self, alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3, eps=1e-6):
         super().__init__()
-        if reduction != 'mean':
-            raise NotImplementedError("only reduction='mean' (the reference's configured default, example_config.yaml:73) "
-                                      "is implemented on device; per-pixel OHEM (reduction='none') needs a top-k kernel")
+        if reduction not in ('mean', 'none'):
+            raise NotImplementedError("reduction must be 'mean' (the reference's configured default, example_config.yaml:73) "
+                                      "or 'none' (true per-pixel OHEM)")
         self.alpha = float(alpha)
         self.beta = float(beta)
         self.reduction = reduction
@@ -77,4 +89,4 @@ class DBLoss(nn.Module):
         assert preds.size(1) in (2, 3) and gts.size(0) == 4 and gts.shape[1:] == (preds.size(0), preds.size(2), preds.size(3))
         preds = preds.contiguous().float()
         gts = gts.contiguous().float()
-        return _DBLossFunction.apply(preds, gts, self.alpha, self.beta, self.negative_ratio, self.eps)
+        return _DBLossFunction.apply(preds, gts, self.alpha, self.beta, self.negative_ratio, self.eps, self.reduction == 'none')

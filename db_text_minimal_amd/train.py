@@ -54,16 +54,25 @@ class DBTrainer:
         N, C, H, W = preds.shape
         dev = preds.device
         st = torch.cuda.current_stream(dev).cuda_stream
+        per_pixel = getattr(c, 'reduction', 'mean') == 'none'
         if self._gone is None or self._gone.device != dev:
             self._gone = torch.tensor([0., 0., 0., 0., 1.], device=dev)
-            self._coef = torch.empty(8, device=dev)
-            self._ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=dev)
+            self._coef = torch.zeros(8, device=dev)
+            self._ws = None
+        need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if per_pixel else L.dbn_db_loss_ws_bytes()) // 4 + 1
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=dev)
         losses = torch.empty(5, device=dev)
-        check(L.dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps,
-                                losses.data_ptr(), self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
+        fwd = L.dbn_db_loss_ohem_fwd if per_pixel else L.dbn_db_loss_fwd
+        check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
+                  self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
         dpreds = self.model.engine.buf('dpreds', N, C, H, W)
-        check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(), c.alpha, c.beta,
-                                N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')
+        if per_pixel:
+            check(L.dbn_db_loss_ohem_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(),
+                                         self._ws.data_ptr(), c.alpha, c.beta, N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')
+        else:
+            check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(), c.alpha, c.beta,
+                                    N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')
         return losses, dpreds
 
     def step(self, img, gts):

@@ -115,6 +115,15 @@ int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, i
 int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, float alpha, float beta,
                     int N, int H, int W, int channels, float* dpreds, void* stream);
 
+/* DBLoss(reduction='none') — true per-pixel OHEM (losses.py:30-39 with a per-pixel BCE): the n_neg largest
+ * negative losses are found by a 3-pass radix select on device (no sort, no host sync).  `ws` holds
+ * dbn_db_loss_ohem_ws_bytes(N,H,W) bytes and must stay untouched between _fwd and _bwd. */
+long dbn_db_loss_ohem_ws_bytes(int N, int H, int W);
+int dbn_db_loss_ohem_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                         float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
+int dbn_db_loss_ohem_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, const void* ws,
+                         float alpha, float beta, int N, int H, int W, int channels, float* dpreds, void* stream);
+
 /* ---- per-step pixel metric (cal_text_score / RunningScore._fast_hist, text_metrics.py:14-24,63-82):
  *      2x2 confusion matrix of (P*M > thresh) vs int(G*M), accumulated on device into 5 doubles
  *      [unused, n01, n10, n11, total] (index = 2*gt + pred) — replaces 3 D2H copies + np.bincount per step */

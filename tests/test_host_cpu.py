@@ -102,7 +102,7 @@ def test_no_cpu_fallback_and_error_surface():
     with pytest.raises(AssertionError):
         crit(torch.rand(3, 8, 8), torch.rand(4, 1, 8, 8))  # losses.py:113-114
     with pytest.raises(NotImplementedError):
-        DBLoss(reduction='none')
+        DBLoss(reduction='sum')
     with pytest.raises(NotImplementedError):
         FusedAdam(m, weight_decay=0.1)
 

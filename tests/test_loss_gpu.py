@@ -12,7 +12,7 @@ from oracle import dbnet_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta']
+KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_none']
 
 
 @pytest.mark.parametrize('tag', KATS)
@@ -20,7 +20,7 @@ def test_loss_known_answers(golden_dir, tag):
     z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
     preds = torch.from_numpy(z[tag + '/preds']).to(DEV).requires_grad_(True)
     gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
-    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss()
+    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss(reduction='none') if tag == 'reduction_none' else DBLoss()
     res = crit(preds, gts)
     res5 = res if isinstance(res, tuple) else (res, )
     got = torch.stack([r.detach() for r in res5]).cpu()
@@ -74,3 +74,54 @@ def test_loss_full_size_properties():
     ref = O.db_loss_closed_form(preds.detach().cpu(), gts.cpu())
     for a, b in zip(vals, ref):
         assert abs(a - b) <= 1e-5 + 1e-5 * abs(b), (vals, ref)
+
+
+@pytest.mark.parametrize('n,size,ratio', [(2, 128, 3), (1, 64, 1), (2, 96, 0.5)])
+def test_per_pixel_ohem_vs_oracle(n, size, ratio):
+    """DBLoss(reduction='none'): device radix select == torch.topk of the literal reference formula (oracle)."""
+    _, gts = O.synthetic_batch(n, size, seed=31)
+    g = torch.Generator().manual_seed(5)
+    P = torch.rand(n, 1, size, size, generator=g) * 0.98 + 0.01
+    T = torch.rand(n, 1, size, size, generator=g) * 0.98 + 0.01
+    preds = torch.cat([P, T, torch.sigmoid(50 * (P - T))], 1)
+    pc = preds.clone().requires_grad_(True)
+    ref = O.db_loss(pc, gts, reduction='none', negative_ratio=ratio)
+    ref[4].backward()
+    pd = preds.to(DEV).requires_grad_(True)
+    got = DBLoss(reduction='none', negative_ratio=ratio)(pd, gts.to(DEV))
+    got[4].backward()
+    report('ohem losses', torch.stack([v.detach() for v in got]).cpu().double(), torch.tensor([float(v) for v in ref]).double(), 1e-6, 1e-5)
+    report('ohem dpreds', pd.grad.cpu(), pc.grad, 1e-9, 1e-4)
+
+
+def test_per_pixel_ohem_edges_and_full_size():
+    # no positives -> k = 0 -> prob_loss 0 and no BCE gradient
+    _, gts = O.synthetic_batch(1, 64, seed=3)
+    gts[0].zero_()
+    P = torch.rand(1, 3, 64, 64) * 0.9 + 0.05
+    pd = P.to(DEV).requires_grad_(True)
+    res = DBLoss(reduction='none')(pd, gts.to(DEV))
+    res[0].backward()
+    assert float(res[0]) == 0.0 and float(pd.grad.abs().max()) == 0.0
+    # full size: selected count == n_neg, loss is finite and >= the 'mean' variant's denominator logic
+    N, S = 16, 640
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    Pm = torch.rand(N, 1, S, S, device=DEV, generator=gen) * 0.98 + 0.01
+    Tm = torch.rand(N, 1, S, S, device=DEV, generator=gen) * 0.98 + 0.01
+    preds = torch.cat([Pm, Tm, torch.sigmoid(50 * (Pm - Tm))], 1).requires_grad_(True)
+    u = torch.rand(4, N, S, S, device=DEV, generator=gen)
+    gts = torch.stack([(u[0] > 0.9).float(), (u[1] > 0.05).float(), 0.3 + 0.4 * u[2], (u[3] > 0.8).float()])
+    res = DBLoss(reduction='none')(preds, gts)
+    res[0].backward()
+    pos = gts[0] * gts[1]
+    neg = (1 - gts[0]) * gts[1]
+    n_pos = int(pos.sum())
+    n_neg = min(3 * n_pos, int(neg.sum()))
+    dP = preds.grad[:, 0]
+    sel_neg = int(((dP != 0) & (neg > 0)).sum())
+    assert abs(sel_neg - n_neg) <= 2, (sel_neg, n_neg)  # ties at the threshold share a fractional weight
+    assert int(((dP != 0) & (pos > 0)).sum()) == n_pos
+    # independent evaluation with torch.topk on the device data (checker only)
+    l = torch.nn.functional.binary_cross_entropy(preds[:, 0].detach(), gts[0], reduction='none')
+    ref = ((l * pos).sum() + torch.topk((l * neg).view(-1), n_neg)[0].sum()) / (n_pos + n_neg + 1e-6)
+    assert abs(float(res[0]) - float(ref)) <= 1e-5 * float(ref)
