@@ -77,7 +77,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help="conv math: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; bf16 = bf16 operands")
-    ap.add_argument('--alt-modes', action='store_true', help='also time the other conv-math modes (reported under alt_modes)')
+    ap.add_argument('--no-alt-modes', action='store_true',
+                    help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
     args = ap.parse_args()
 
     from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
@@ -162,7 +163,7 @@ def main():
             kernels.append(ent)
 
     alt = {}
-    if args.alt_modes:
+    if not args.no_alt_modes:
         for mode in ('f32', 'bf16x3', 'bf16'):
             if mode == args.math:
                 continue

@@ -1,23 +1,27 @@
-// fp32 implicit-GEMM convolution kernels for gfx950 (MI355X), built on the exact-f32
-// matrix instruction v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s chip peak).
+// Implicit-GEMM convolution kernels for gfx950 (MI355X).
 //
-//   dbn_igemm_f32      forward conv (gather mode 0) and data-gradient / transposed
-//                      conv (gather mode 1) over NHWC activations
-//   dbn_wgrad_f32      weight gradient: split-K over output pixels into fp32 slabs
-//   dbn_wgrad_reduce   deterministic slab reduction + scatter into OIHW gradients
-//   dbn_pack_weights   OIHW -> [K/4][Cd][4] panels read by dbn_igemm_f32
+//   dbn_igemm_f32 / dbn_igemm_bf16s   forward conv (gather mode 0) and data-gradient / transposed conv
+//                                     (gather mode 1; stride 2 as four output-parity problems) over NHWC
+//   dbn_wgrad_f32 / dbn_wgrad_bf16s   weight gradient: split-K over output pixels into fp32 slabs
+//                                     + deterministic slab reduction scattered into OIHW gradients
+//   dbn_pack_weights[_bf16s]          OIHW -> GEMM panels
 //
-// Replaces the ATen convolution calls under /root/reference/src/modules/resnet.py:70-91,
-// 231-242, modules/basic.py:32-36, modules/segmentation_body.py:64-77 and
-// modules/segmentation_head.py:24-29,64-79 (Conv2d / ConvTranspose2d forward and
-// their autograd backward).
+// Replaces the ATen convolution calls under /root/reference/src/modules/resnet.py:70-91,231-242,
+// modules/basic.py:32-36, modules/segmentation_body.py:64-77 and modules/segmentation_head.py:24-29,64-79
+// (Conv2d / ConvTranspose2d forward and their autograd backward).
 //
-// Tiling: a workgroup of 4 waves owns a BM x BN output tile,
-// each wave a (BM/WM) x (BN/WN) sub-tile held as 32x32 f32 accumulators.  K is walked
-// in steps of 16; the A panel (im2col gather, 16 B per lane = 4 consecutive input
-// channels of one tap) and the B panel (pre-packed weights) are staged through a
-// double-buffered LDS image laid out [k/4][row][4] so that every lane fetches its four
-// k-values for four consecutive MFMAs with one conflict-free ds_read_b128.
+// Matrix instruction (template parameter NS):
+//   NS = 0  v_mfma_f32_32x32x2_f32 — exact fp32 products, 64 FLOP/clk/SIMD, 157 TFLOP/s chip peak (default)
+//   NS = 3  v_mfma_f32_32x32x16_bf16 on an exact three-way bf16 split of every fp32 operand, six partial
+//           products, fp32 accumulate: fp32-accurate at 6/16 of the fp32-MFMA cost
+//   NS = 1  the same with operands rounded to bf16 (BASELINE configs[2] compute mode)
+//
+// Tiling: a workgroup of 4 waves owns a BM x BN output tile, each wave a (BM/WM) x (BN/WN)
+// sub-tile of 32x32 f32 accumulators.  K is walked in steps of 16; the A panel (im2col gather, 16 B per lane
+// = 4 consecutive input channels of one tap, branch-free buffer loads that return 0 out of range) and the B
+// panel (pre-packed weights) are staged through a double-buffered LDS image laid out [k/4][row][4 f32]
+// (NS = 0) or [split][k/8][row][8 bf16] (NS > 0) so that every lane fetches the k-values of its MFMAs with
+// conflict-free ds_read_b128.
 #include "common.h"
 #include <stdlib.h>
 
@@ -447,14 +451,16 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int lds_base = (is_a ? 0 : A_IMG) + s_c;
 
     f32x4 rr[4];
-    auto gather = [&](int kt) {
+    unsigned woff[4];
+    // byte offsets of this thread's 4 loads for k-tile kt (address math kept apart from the loads so that it
+    // can be issued in the shadow of the previous tile's MFMAs)
+    auto offsets = [&](int kt) {
         const int pp0 = pbeg + kt * 16 + 4 * s_g;
         if (is_a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pp = pp0 + i;
-                const unsigned off = (unsigned)(pp * p.O + o0 + 4 * s_c) * 4u;
-                rr[i] = buffer_load_f32x4(rs_sm, pp < pend ? off : OOB_OFFSET);
+                woff[i] = pp < pend ? (unsigned)(pp * p.O + o0 + 4 * s_c) * 4u : OOB_OFFSET;
             }
         } else if (is_b) {
             int n, rem, oh, ow;
@@ -464,8 +470,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             for (int i = 0; i < 4; ++i) {
                 const int ih = oh * p.stride + tr, iw = ow * p.stride + ts;
                 const bool v = j_ok && (pp0 + i) < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const unsigned off = (unsigned)(((n * p.H + ih) * p.W + iw) * p.Cb + ci) * 4u;
-                rr[i] = buffer_load_f32x4(rs_big, v ? off : OOB_OFFSET);
+                woff[i] = v ? (unsigned)(((n * p.H + ih) * p.W + iw) * p.Cb + ci) * 4u : OOB_OFFSET;
                 // next pixel (row-major over n, oh, ow), branch-free carry
                 ++ow;
                 const bool cw = ow == p.Wo;
@@ -475,6 +480,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                 oh = ch ? 0 : oh;
                 n += ch ? 1 : 0;
             }
+        }
+    };
+    auto issue_loads = [&]() {
+        if (is_a) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_sm, woff[i]);
+        } else if (is_b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_big, woff[i]);
         }
     };
     auto stage = [&](int buf) {
@@ -505,15 +519,23 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Address math placement (measured): with the long fp32 MFMAs (NS = 0) computing the offsets right before
+    // the loads is faster (fewer live registers across the MFMA block); with the short bf16 MFMAs (NS > 0) they
+    // are computed one tile ahead, in the shadow of the previous tile's MFMAs.
     if (KT > 0) {
-        gather(0);
+        offsets(0);
+        issue_loads();
+        if (NS > 0) offsets(1);
         stage(0);
     }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < KT;
-        if (more) gather(kt + 1);
+        if (more) {
+            if (NS == 0) offsets(kt + 1);
+            issue_loads();
+        }
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
         if constexpr (NS == 0) {
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             }
             mfma_split<NS, MI, NI>(af, bf, acc);
         }
+        if (NS > 0) offsets(kt + 2);  // independent of the MFMAs above: overlaps their execution
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
@@ -841,13 +864,18 @@ int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     if (maxsk < 1) maxsk = 1;
     long sk = 1;
     double best = -1.0;
+    static double prefer = -100.0;
+    if (prefer < -99.0) {
+        const char* e = getenv("DBN_WGRAD_PREFER");
+        prefer = e ? atof(e) : 0.02;
+    }
     for (int k = 4; k >= 2; --k) {
         long cand = (256L * k) / tiles;
         if (cand < 1) cand = 1;
         if (cand > maxsk) cand = maxsk;
         const long blocks = tiles * cand;
         const double util = (double)blocks / (double)(((blocks + 255) / 256) * 256);
-        const double score = util + 0.02 * k;  // prefer more resident workgroups at equal utilisation
+        const double score = util + prefer * k;  // tie-break between 2..4 workgroups per CU (DBN_WGRAD_PREFER)
         if (score > best) {
             best = score;
             sk = cand;
