@@ -194,12 +194,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             a_wb[j] = wd + q.pad_w;
         }
     }
-    // k-walk of this thread's chunk: k = kt*16 + 4*a_chunk = (r*S + s)*Cs + ci
+    // K order (must match the weight panels, pack_weights_kernel):
+    //   Cs % 16 == 0: k = ((cb*R + r)*S + s)*16 + cl with ci = 16*cb + cl — every k-tile is one tap of one
+    //                 16-channel block and the R*S taps of a block are consecutive k-tiles, so the 9 re-reads of
+    //                 an input pixel's 64-byte slice happen back to back (L1/L2 hits instead of a trip to the fabric);
+    //   otherwise (stem, Cs = 4): k = (r*S + s)*Cs + ci.
+    const bool blocked = (p.Cs & 15) == 0;
     int kidx = 4 * a_chunk;
-    int k_tap = kidx / p.Cs;
-    int k_ci = kidx - k_tap * p.Cs;
-    int k_r = k_tap / qS;
-    int k_s = k_tap - k_r * qS;
+    int k_ci, k_r, k_s;
+    if (blocked) {
+        k_ci = 4 * a_chunk;
+        k_r = 0;
+        k_s = 0;
+    } else {
+        const int k_tap = kidx / p.Cs;
+        k_ci = kidx - k_tap * p.Cs;
+        k_r = k_tap / qS;
+        k_s = k_tap - k_r * qS;
+    }
+    const int qR = q.R;
 
     unsigned aoff[A_LD];
     auto next_offsets = [&]() {  // offsets of the current k position, then advance by one tile (16 k)
@@ -212,15 +225,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             aoff[j] = v ? off : OOB_OFFSET;
         }
         kidx += 16;
-        k_ci += 16;
-        if (p.Cs >= 16) {  // at most one tap boundary per step: branch-free selects
-            const bool wrap = k_ci >= p.Cs;
-            k_ci -= wrap ? p.Cs : 0;
-            k_s += wrap ? 1 : 0;
-            const bool wrap_s = k_s == qS;
-            k_s = wrap_s ? 0 : k_s;
-            k_r += wrap_s ? 1 : 0;
+        if (blocked) {  // next tap of the same channel block; after the last tap, the next block (branch-free)
+            ++k_s;
+            const bool ws_ = k_s == qS;
+            k_s = ws_ ? 0 : k_s;
+            k_r += ws_ ? 1 : 0;
+            const bool wr_ = k_r == qR;
+            k_r = wr_ ? 0 : k_r;
+            k_ci += wr_ ? 16 : 0;
         } else {
+            k_ci += 16;
             while (k_ci >= p.Cs) {  // stem (Cs = 4): several taps per step
                 k_ci -= p.Cs;
                 if (++k_s == qS) {
@@ -423,10 +437,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    // 1-D grid of tiles x splits.  The XCD remap gives each XCD (private L2) a contiguous run of work items,
+    // ordered split-major, so all (o, j) tiles of one pixel range run on the same XCD and share dY / X in its L2.
     const int njt = (p.J + BN - 1) / BN;
-    const int ot = blockIdx.x / njt, jt = blockIdx.x - ot * njt;
+    const int ntiles = (p.O / BM) * njt;
+    const int work = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / ntiles, tile_ = work - split * ntiles;
+    const int ot = tile_ / njt, jt = tile_ - ot * njt;
     const int o0 = ot * BM, j0 = jt * BN;
-    const int pbeg = blockIdx.y * p.pchunk;
+    const int pbeg = split * p.pchunk;
     const int pend = min(p.P, pbeg + p.pchunk);
     const int KT = (pend - pbeg + 15) / 16;
 
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 
     // slab in position space: [split][O (tile-major positions)][Jp = njt*BN]
     const int Jp = njt * BN;
-    float* out = p.slab + (long)blockIdx.y * p.O * Jp;
+    float* out = p.slab + (long)split * p.O * Jp;
 #pragma unroll
     for (int a = 0; a < MI; ++a)
 #pragma unroll
@@ -619,7 +638,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
         const int k = 4 * kc + e;
         float v = 0.f;
         if (k < K) {
-            const int tap = k / Cs, cs = k - tap * Cs;
+            int tap, cs;
+            if ((Cs & 15) == 0) {  // channel-block-major K order (see igemm_f32_kernel)
+                const int blk = k >> 4;
+                tap = blk % (Rp * Sp);
+                cs = (blk / (Rp * Sp)) * 16 + (k & 15);
+            } else {
+                tap = k / Cs;
+                cs = k - tap * Cs;
+            }
             const int rp = tap / Sp, sp = tap - rp * Sp;
             const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
             if (mode == 0) {
@@ -646,7 +673,15 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, in
         const int k = 8 * k8g + e;
         float v = 0.f;
         if (k < K) {
-            const int tap = k / Cs, cs = k - tap * Cs;
+            int tap, cs;
+            if ((Cs & 15) == 0) {  // channel-block-major K order (see igemm_f32_kernel)
+                const int blk = k >> 4;
+                tap = blk % (Rp * Sp);
+                cs = (blk / (Rp * Sp)) * 16 + (k & 15);
+            } else {
+                tap = k / Cs;
+                cs = k - tap * Cs;
+            }
             const int rp = tap / Sp, sp = tap - rp * Sp;
             const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
             if (mode == 0) {
@@ -915,7 +950,7 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
     int bm, bn;
     wgrad_tiles(O, p.J, bm, bn);
     const int njt = (p.J + bn - 1) / bn;
-    dim3 grid((O / bm) * njt, splitk);
+    dim3 grid((O / bm) * njt * splitk);
 #define DBN_WGRAD_LAUNCH(NS_)                                                                             \
     do {                                                                                                    \
         if (bm == 128 && bn == 128)                                                                         \
