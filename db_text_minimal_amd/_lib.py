@@ -37,6 +37,8 @@ SIGNATURES = {
     'dbn_bnrelu_maxpool_bwd': 'ppppppiiiip',
     'dbn_nearest_up_fwd': 'ppp' + 'i' * 8 + 'p',
     'dbn_nearest_up_bwd': 'pp' + 'i' * 9 + 'p',
+    'dbn_bilinear_fwd': 'ppliiiip',
+    'dbn_bilinear_bwd': 'ppliiiip',
     'dbn_nchw3_to_nhwc4': 'ppiiip',
     'dbn_add_inplace': 'pplp',
     'dbn_head_tail_fwd': 'ppppppp' + 'iiii' + 'f' + 'p',

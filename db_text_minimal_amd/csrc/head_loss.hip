@@ -181,9 +181,24 @@ __global__ void fold_partials_d_kernel(const float* __restrict__ part, int nb, i
 // ----------------------------------------------------------------------------------
 enum { S_POS = 0, S_NEG, S_BCE, S_L1, S_A, S_BGM, S_BM, NSUM };
 
+// loads/stores of V consecutive floats (V = 4: one 16-byte access when H*W % 4 == 0; V = 1: any size)
+template <int V>
+__device__ __forceinline__ f32x4 ldv(const float* p) {
+    if constexpr (V == 4) return *reinterpret_cast<const f32x4*>(p);
+    return f32x4{p[0], 0.f, 0.f, 0.f};
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, f32x4 v) {
+    if constexpr (V == 4) *reinterpret_cast<f32x4*>(p) = v;
+    else p[0] = v[0];
+}
+
+
+
+template <int V>
 __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float* __restrict__ gts, int N, long HW, int CH,
                                    double* __restrict__ part) {
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / V;
     const long NHW = (long)N * HW;
     float s[NSUM];
 #pragma unroll
@@ -193,19 +208,19 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
     for (int k = 0; k < NSUM; ++k) ds[k] = 0.0;
     int cnt = 0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const long p = i * 4;
+        const long p = i * V;
         const long n = p / HW, o = p - n * HW;
         const float* pb = preds + n * CH * HW + o;
-        const f32x4 P = *reinterpret_cast<const f32x4*>(pb);
-        const f32x4 T = *reinterpret_cast<const f32x4*>(pb + HW);
+        const f32x4 P = ldv<V>(pb);
+        const f32x4 T = ldv<V>(pb + HW);
         f32x4 B = {0.f, 0.f, 0.f, 0.f};
-        if (CH == 3) B = *reinterpret_cast<const f32x4*>(pb + 2 * HW);
-        const f32x4 G = *reinterpret_cast<const f32x4*>(gts + p);
-        const f32x4 M = *reinterpret_cast<const f32x4*>(gts + NHW + p);
-        const f32x4 Tg = *reinterpret_cast<const f32x4*>(gts + 2 * NHW + p);
-        const f32x4 A = *reinterpret_cast<const f32x4*>(gts + 3 * NHW + p);
+        if (CH == 3) B = ldv<V>(pb + 2 * HW);
+        const f32x4 G = ldv<V>(gts + p);
+        const f32x4 M = ldv<V>(gts + NHW + p);
+        const f32x4 Tg = ldv<V>(gts + 2 * NHW + p);
+        const f32x4 A = ldv<V>(gts + 3 * NHW + p);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             s[S_POS] += G[e] * M[e];
             s[S_NEG] += (1.f - G[e]) * M[e];
             const float lp = fmaxf(logf(P[e]), -100.f);
@@ -297,10 +312,11 @@ __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb,
 }
 
 // gout[5]: upstream grads of the 5 returned losses (device); dpreds planes like preds.
+template <int V>
 __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float* __restrict__ gts, const float* __restrict__ coef,
                                    const float* __restrict__ gout, const float* __restrict__ ohem_v, float alpha, float beta, int N,
                                    long HW, int CH, float* __restrict__ dpreds) {
-    const long total4 = (long)N * HW / 4;
+    const long total4 = (long)N * HW / V;
     const long NHW = (long)N * HW;
     // effective weights of the three base losses
     float w_prob, w_thr, w_bin;
@@ -320,19 +336,19 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
     const float U = coef[2], I = coef[3];
     const float cd = -2.f * w_bin / (U * U);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const long p = i * 4;
+        const long p = i * V;
         const long n = p / HW, o = p - n * HW;
         const float* pb = preds + n * CH * HW + o;
         float* db = dpreds + n * CH * HW + o;
-        const f32x4 P = *reinterpret_cast<const f32x4*>(pb);
-        const f32x4 T = *reinterpret_cast<const f32x4*>(pb + HW);
-        const f32x4 G = *reinterpret_cast<const f32x4*>(gts + p);
-        const f32x4 M = *reinterpret_cast<const f32x4*>(gts + NHW + p);
-        const f32x4 Tg = *reinterpret_cast<const f32x4*>(gts + 2 * NHW + p);
-        const f32x4 A = *reinterpret_cast<const f32x4*>(gts + 3 * NHW + p);
-        f32x4 dP, dT, dB;
+        const f32x4 P = ldv<V>(pb);
+        const f32x4 T = ldv<V>(pb + HW);
+        const f32x4 G = ldv<V>(gts + p);
+        const f32x4 M = ldv<V>(gts + NHW + p);
+        const f32x4 Tg = ldv<V>(gts + 2 * NHW + p);
+        const f32x4 A = ldv<V>(gts + 3 * NHW + p);
+        f32x4 dP = {0.f, 0.f, 0.f, 0.f}, dT = dP, dB = dP;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             // ATen binary_cross_entropy backward: (x - t) / max((1-x)*x, 1e-12)
             float wsel = 1.f;  // 'mean': the scalar BCE weights every pixel alike
             if (per_pixel) {     // 'none': positives + the selected (top n_neg) negatives
@@ -345,9 +361,9 @@ __global__ void db_loss_bwd_kernel(const float* __restrict__ preds, const float*
             dT[e] = ca * A[e] * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
             dB[e] = cd * M[e] * (G[e] * U - I);
         }
-        *reinterpret_cast<f32x4*>(db) = dP;
-        *reinterpret_cast<f32x4*>(db + HW) = dT;
-        if (CH == 3) *reinterpret_cast<f32x4*>(db + 2 * HW) = dB;
+        stv<V>(db, dP);
+        stv<V>(db + HW, dT);
+        if (CH == 3) stv<V>(db + 2 * HW, dB);
     }
 }
 
@@ -595,11 +611,14 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
                            float negative_ratio, float eps, int per_pixel, float* losses, float* coef, void* ws, void* stream) {
     DBN_REQUIRE(preds && gts && losses && coef && ws && (channels == 2 || channels == 3));
     const long HW = (long)H * W;
-    DBN_REQUIRE(HW % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    const int nb = dbn_grid((long)N * HW / 4, 256, 1024);
+    const bool vec = HW % 4 == 0;
+    const int nb = dbn_grid((long)N * HW / (vec ? 4 : 1), 256, 1024);
     char* base = (char*)ws;
-    hipLaunchKernelGGL(db_loss_fwd_kernel, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
+    if (vec)
+        hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
+    else
+        hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
     hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
                        beta, negative_ratio, eps, losses, coef);
     if (!per_pixel) return dbn_status();
@@ -639,9 +658,12 @@ static int db_loss_bwd_run(const float* preds, const float* gts, const float* co
                            float alpha, float beta, int N, int H, int W, int channels, float* dpreds, void* stream) {
     DBN_REQUIRE(preds && gts && coef && grad_losses && dpreds && (channels == 2 || channels == 3));
     const long HW = (long)H * W;
-    DBN_REQUIRE(HW % 4 == 0);
-    hipLaunchKernelGGL(db_loss_bwd_kernel, dim3(dbn_grid((long)N * HW / 4)), dim3(256), 0, (hipStream_t)stream, preds, gts, coef,
-                       grad_losses, ohem_v, alpha, beta, N, HW, channels, dpreds);
+    if (HW % 4 == 0)
+        hipLaunchKernelGGL(db_loss_bwd_kernel<4>, dim3(dbn_grid((long)N * HW / 4)), dim3(256), 0, (hipStream_t)stream, preds, gts,
+                           coef, grad_losses, ohem_v, alpha, beta, N, HW, channels, dpreds);
+    else
+        hipLaunchKernelGGL(db_loss_bwd_kernel<1>, dim3(dbn_grid((long)N * HW)), dim3(256), 0, (hipStream_t)stream, preds, gts, coef,
+                           grad_losses, ohem_v, alpha, beta, N, HW, channels, dpreds);
     return dbn_status();
 }
 

@@ -347,6 +347,71 @@ __global__ void nearest_up_bwd_kernel(const float* __restrict__ dbig, float* __r
     }
 }
 
+// ----------------------------------------------------------------------------------
+// F.interpolate(mode='bilinear', align_corners=True) of NCHW planes (models.py:43-46): only a real
+// resample when H or W is not a multiple of 32 (e.g. 428 -> 427 rows in the inference CLIs).
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_src(int d, float scale, int in, int& i0, int& i1, float& w1) {
+    const float x = scale * (float)d;  // align_corners=True: scale = (in-1)/(out-1)
+    i0 = (int)x;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = x - (float)i0;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst, long planes, int Hs, int Ws, int H, int W,
+                                    float sh, float sw) {
+    const long total = planes * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        const long t = i / W;
+        const int h = (int)(t % H);
+        const long pl = t / H;
+        int h0, h1, w0, w1;
+        float lh, lw;
+        bilinear_src(h, sh, Hs, h0, h1, lh);
+        bilinear_src(w, sw, Ws, w0, w1, lw);
+        const float* s = src + pl * (long)Hs * Ws;
+        dst[i] = (1.f - lh) * ((1.f - lw) * s[(long)h0 * Ws + w0] + lw * s[(long)h0 * Ws + w1]) +
+                 lh * ((1.f - lw) * s[(long)h1 * Ws + w0] + lw * s[(long)h1 * Ws + w1]);
+    }
+}
+
+// adjoint, gather form (deterministic): dsrc[hs,ws] = sum over dst pixels whose footprint contains (hs,ws)
+__global__ void bilinear_bwd_kernel(const float* __restrict__ ddst, float* __restrict__ dsrc, long planes, int Hs, int Ws, int H, int W,
+                                    float sh, float sw) {
+    const long total = planes * Hs * Ws;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ws = (int)(i % Ws);
+        const long t = i / Ws;
+        const int hs = (int)(t % Hs);
+        const long pl = t / Hs;
+        // candidate destination rows/cols: x = scale*d in (hs-1, hs+1)
+        const float ih = sh > 0.f ? 1.f / sh : 0.f, iw = sw > 0.f ? 1.f / sw : 0.f;
+        int hlo = sh > 0.f ? (int)floorf((float)(hs - 1) * ih) - 1 : 0, hhi = sh > 0.f ? (int)ceilf((float)(hs + 1) * ih) + 1 : H - 1;
+        int wlo = sw > 0.f ? (int)floorf((float)(ws - 1) * iw) - 1 : 0, whi = sw > 0.f ? (int)ceilf((float)(ws + 1) * iw) + 1 : W - 1;
+        hlo = max(hlo, 0); hhi = min(hhi, H - 1);
+        wlo = max(wlo, 0); whi = min(whi, W - 1);
+        const float* d = ddst + pl * (long)H * W;
+        float acc = 0.f;
+        for (int h = hlo; h <= hhi; ++h) {
+            int h0, h1;
+            float lh;
+            bilinear_src(h, sh, Hs, h0, h1, lh);
+            const float wh = (h0 == hs ? 1.f - lh : 0.f) + (h1 == hs ? lh : 0.f);
+            if (wh == 0.f) continue;
+            for (int w = wlo; w <= whi; ++w) {
+                int w0, w1;
+                float lw;
+                bilinear_src(w, sw, Ws, w0, w1, lw);
+                const float ww = (w0 == ws ? 1.f - lw : 0.f) + (w1 == ws ? lw : 0.f);
+                if (ww != 0.f) acc += wh * ww * d[(long)h * W + w];
+            }
+        }
+        dsrc[i] = acc;
+    }
+}
+
 // [N,3,H,W] -> [N,H,W,4] (4th channel zero)
 __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ out, int N, long HW) {
     const long total = (long)N * HW;
@@ -517,6 +582,24 @@ int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* st
     DBN_REQUIRE(x && out && N > 0);
     hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N,
                        (long)H * W);
+    return dbn_status();
+}
+
+static float bilinear_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+// dst[planes,H,W] = bilinear(align_corners=True) of src[planes,Hs,Ws] (NCHW planes, planes = N*C)
+int dbn_bilinear_fwd(const float* src, float* dst, long planes, int Hs, int Ws, int H, int W, void* stream) {
+    DBN_REQUIRE(src && dst && planes > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(dbn_grid(planes * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, planes, Hs, Ws, H,
+                       W, bilinear_scale(Hs, H), bilinear_scale(Ws, W));
+    return dbn_status();
+}
+
+// dsrc[planes,Hs,Ws] = adjoint of the above applied to ddst[planes,H,W]
+int dbn_bilinear_bwd(const float* ddst, float* dsrc, long planes, int Hs, int Ws, int H, int W, void* stream) {
+    DBN_REQUIRE(ddst && dsrc && planes > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(dbn_grid(planes * Hs * Ws)), dim3(256), 0, (hipStream_t)stream, ddst, dsrc, planes, Hs,
+                       Ws, H, W, bilinear_scale(Hs, H), bilinear_scale(Ws, W));
     return dbn_status();
 }
 

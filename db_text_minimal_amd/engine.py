@@ -381,9 +381,8 @@ class Engine:
         if not x.is_cuda:
             raise RuntimeError('DBTextModel runs on MI355X only: input must be a HIP tensor')
         N, _, H, W = x.shape
-        if H % 32 or W % 32:
-            raise NotImplementedError('H and W must be multiples of 32 (the final bilinear resample of models.py:43-46 is then '
-                                      'the identity and is elided); got %dx%d' % (H, W))
+        if H < 32 or W < 32:
+            raise ValueError('input must be at least 32x32 (five stride-2 stages); got %dx%d' % (H, W))
         self.ensure_flat()
         x = x.contiguous().float()
         L, st = self.L, self.stream
@@ -393,8 +392,9 @@ class Engine:
         check(L.dbn_nchw3_to_nhwc4(x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
         y0 = self.conv_fwd('backbone.conv1', x4, bb.conv1, 'stem/y')
         sc, sh = self.bn_coef('backbone.bn1', bb.bn1, y0, train)
-        pool = self.buf('stem/pool', N, H // 4, W // 4, 64)
-        check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H // 2, W // 2, 64, st),
+        H0, W0 = y0.shape[1], y0.shape[2]
+        pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
+        check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
               'maxpool fwd')
         feats = []
         cur = pool
@@ -444,19 +444,24 @@ class Engine:
             s_, h_ = self.bn_coef(hp + '4', seq[4], yb, train)
             z1[br] = self.bn_apply(yb, s_, h_, br + '/z1')
         ch = 3 if train else 2
+        Hh, Wh = z1['binarize'].shape[1], z1['binarize'].shape[2]
+        resample = (2 * Hh, 2 * Wh) != (H, W)  # only when H or W is not a multiple of 32 (models.py:43-46)
         out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
+        head_out = self.buf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
         b6, t6 = head.binarize[6], head.thresh[6]
-        if self.prof:  # reads 2 x 64ch at (H/2, W/2), writes `ch` full-resolution maps
-            self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * (H // 2) * (W // 2) * 128 + 4.0 * N * H * W * ch)
+        if self.prof:  # reads 2 x 64ch at half resolution, writes `ch` full-resolution maps
+            self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * Hh * Wh * 128 + 4.0 * N * 4 * Hh * Wh * ch)
         check(L.dbn_head_tail_fwd(z1['binarize'].data_ptr(), z1['thresh'].data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(),
-                                  b6.bias.data_ptr(), t6.bias.data_ptr(), out.data_ptr(), N, H // 2, W // 2, ch, float(head.k), st),
+                                  b6.bias.data_ptr(), t6.bias.data_ptr(), head_out.data_ptr(), N, Hh, Wh, ch, float(head.k), st),
               'head_tail_fwd')
         if self.prof:
             self.prof.end()
+        if resample:
+            check(L.dbn_bilinear_fwd(head_out.data_ptr(), out.data_ptr(), N * ch, 2 * Hh, 2 * Wh, H, W, st), 'bilinear_fwd')
         if train:
             self.saved_generation = self.generation
-            self.saved_out = out
-            self.saved_shape = (N, H, W)
+            self.saved_out = head_out
+            self.saved_shape = (N, H, W, Hh, Wh, resample)
         return out
 
     def _block_fwd(self, name, blk, x, train):
@@ -480,15 +485,19 @@ class Engine:
         if self.saved_generation != self.generation:
             raise RuntimeError('backward() without a matching train-mode forward (activations were overwritten)')
         m, L, st = self.model, self.L, self.stream
-        N, H, W = self.saved_shape
+        N, H, W, Hh, Wh, resample = self.saved_shape
         B = self.bufs
-        out = self.saved_out
+        out = self.saved_out  # head output before the (optional) final resample
         dpreds = dpreds.contiguous()
-        assert dpreds.shape == out.shape
+        assert dpreds.shape == (N, 3, H, W)
+        if resample:
+            dhead = self.buf('head/dout', *out.shape)
+            check(L.dbn_bilinear_bwd(dpreds.data_ptr(), dhead.data_ptr(), N * 3, 2 * Hh, 2 * Wh, H, W, st), 'bilinear_bwd')
+            dpreds = dhead
         head = m.segmentation_head
         b6, t6 = head.binarize[6], head.thresh[6]
-        dz1b = self.buf('binarize/dz1', N, H // 2, W // 2, 64)
-        dz1t = self.buf('thresh/dz1', N, H // 2, W // 2, 64)
+        dz1b = self.buf('binarize/dz1', N, Hh, Wh, 64)
+        dz1t = self.buf('thresh/dz1', N, Hh, Wh, 64)
         ws = self.scratch('_head_ws', L.dbn_head_tail_bwd_ws_floats())
         G = self.grad_views
         check(L.dbn_head_tail_bwd(B['binarize/z1'].data_ptr(), B['thresh/z1'].data_ptr(), b6.weight.data_ptr(),
@@ -496,7 +505,7 @@ class Engine:
                                   G['segmentation_head.binarize.6.weight'].data_ptr(),
                                   G['segmentation_head.binarize.6.bias'].data_ptr(),
                                   G['segmentation_head.thresh.6.weight'].data_ptr(),
-                                  G['segmentation_head.thresh.6.bias'].data_ptr(), N, H // 2, W // 2, 3, float(head.k),
+                                  G['segmentation_head.thresh.6.bias'].data_ptr(), N, Hh, Wh, 3, float(head.k),
                                   self.grad_scale, ws.data_ptr(), st), 'head_tail_bwd')
         f = B['fpn/z']
         df = self.buf('fpn/dz', *f.shape)
@@ -566,7 +575,7 @@ class Engine:
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)
         check(L.dbn_bnrelu_maxpool_bwd(y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
-                                       B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, H // 2, W // 2, 64, st),
+                                       B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, y0.shape[1], y0.shape[2], 64, st),
               'maxpool bwd')
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy')
         self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)

@@ -2,6 +2,10 @@
 (`torch.optim.Adam(lr=.005, betas=(.9,.999), eps=1e-8, weight_decay=0,
 amsgrad=False)`) as ONE HIP launch over the model's flat parameter buffer
 (dbn_adam_step: reads p,g,m,v, writes p,m,v = 28 B/param).
+
+It subclasses `torch.optim.Optimizer` only for interface compatibility (so the
+reference's `ReduceLROnPlateau` / `WarmupPolyLR` schedulers, train.py:119-139, accept it and drive
+`param_groups[0]['lr']`); no torch optimizer arithmetic is used.
 """
 import torch
 
@@ -9,14 +13,14 @@ from . import _lib
 from ._lib import check
 
 
-class FusedAdam:
+class FusedAdam(torch.optim.Optimizer):
     def __init__(self, model, lr=0.005, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError('weight_decay=0, amsgrad=False only (the reference configuration, example_config.yaml:68-77)')
         self.model = model
         self.engine = model.engine
-        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
-        self.param_groups = [dict(self.defaults, params=[p for _, p in self.engine.live_params])]
+        params = [p for _, p in self.engine.live_params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self.step_count = 0
         self.exp_avg = None
         self.exp_avg_sq = None
@@ -32,7 +36,11 @@ class FusedAdam:
             self.exp_avg = torch.zeros_like(eng.flat)
             self.exp_avg_sq = torch.zeros_like(eng.flat)
 
-    def step(self, grad_scale=1.0):
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        """Consumes the engine's flat gradient buffer (filled by DBTrainer / engine.backward)."""
+        if closure is not None:
+            raise NotImplementedError('closures are not supported')
         self._ensure_state()
         eng = self.engine
         g = self.param_groups[0]

@@ -96,6 +96,11 @@ int dbn_nearest_up_fwd(const float* src, const float* addend, float* dst, int N,
 int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
                        int accumulate, void* stream);
 
+/* ---- final resample of the model (F.interpolate bilinear, align_corners=True: models.py:43-46); the identity
+ *      (and elided) when H, W are multiples of 32.  NCHW planes. */
+int dbn_bilinear_fwd(const float* src, float* dst, long planes, int Hs, int Ws, int H, int W, void* stream);
+int dbn_bilinear_bwd(const float* ddst, float* dsrc, long planes, int Hs, int Ws, int H, int W, void* stream);
+
 /* ---- layout / misc */
 int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
 int dbn_add_inplace(const float* x, float* y, long n, void* stream);

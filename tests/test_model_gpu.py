@@ -255,3 +255,62 @@ def test_cfg5_inference_1280_bs32_vs_oracle():
     err = (preds_bf16[31].cpu() - ref[1]).abs()
     print('cfg5 bf16 conv math: mean abs err %.3e, max %.3e' % (float(err.mean()), float(err.max())))
     assert torch.isfinite(preds_bf16).all() and float(err.mean()) < 2e-2
+
+
+def test_checkpoint_roundtrip_and_lr_schedulers(tmp_path):
+    """train.py:119-139,288-318: state_dict save/load with the reference key set, torch LR schedulers driving FusedAdam."""
+    seed = 2
+    img, gts = O.synthetic_batch(2, 64, seed=seed)
+    model = make_model(seed).train()
+    opt = FusedAdam(model, lr=0.005)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.5**it)  # any _LRScheduler (e.g. the reference's WarmupPolyLR)
+    plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(FusedAdam(make_model(seed)), mode='min', factor=0.1, patience=0)
+    tr = DBTrainer(model, DBLoss(), opt)
+    tr.step(img.to(DEV), gts.to(DEV))
+    sched.step()
+    assert abs(opt.param_groups[0]['lr'] - 0.0025) < 1e-12
+    plateau.step(1.0); plateau.step(2.0)
+    path = str(tmp_path / 'dbnet.pth')
+    torch.save(model.state_dict(), path)
+    assert os.path.getsize(path) < 80e6  # the flat buffer is stored once, not once per parameter view
+    sd = torch.load(path, map_location='cpu')
+    assert list(sd.keys()) == [k for k, _, _ in O.state_spec()]
+    m2 = DBTextModel()
+    m2.load_state_dict(sd)
+    m2 = m2.to(DEV).eval()
+    model.eval()
+    with torch.no_grad():
+        a, b = model(img.to(DEV)), m2(img.to(DEV))
+    assert torch.equal(a, b)
+    assert int(sd['backbone.bn1.num_batches_tracked']) == 1
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 96, 70), (2, 70, 90), (1, 33, 47)])
+def test_arbitrary_input_sizes(n, h, w):
+    """The inference CLIs resize without padding (utils.py:160-175), so H, W are not multiples of 32 there: the FPN's
+    size-based nearest upsampling and the final bilinear(align_corners=True) resample (models.py:43-46) become real
+    resamples.  Eval and train forward/backward vs the oracle."""
+    seed = 8
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(n, 3, h, w, generator=g)
+    u = torch.rand(4, n, h, w, generator=g)
+    gts = torch.stack([(u[0] > 0.9).float(), (u[1] > 0.05).float(), 0.3 + 0.4 * u[2], (u[3] > 0.8).float()])
+    model = make_model(seed).eval()
+    with torch.no_grad():
+        pe = model(img.to(DEV))
+        ref_e = O.forward(O.new_state(seed), img, training=False)
+    assert pe.shape == (n, 2, h, w)
+    report('odd-size eval maps', pe.cpu(), ref_e, MAP_ATOL, MAP_RTOL)
+    model.train()
+    sd = O.new_state(seed)
+    preds_o, losses_o, grads_o = O.loss_and_grads(sd, img, gts)
+    preds = model(img.to(DEV))
+    losses = DBLoss()(preds, gts.to(DEV))
+    losses[4].backward()
+    report('odd-size train maps (P,T)', preds[:, :2].detach().cpu(), preds_o[:, :2], MAP_ATOL, MAP_RTOL)
+    report('odd-size losses', torch.stack([v.detach() for v in losses]).cpu().double(), torch.tensor(losses_o).double(), 1e-4, 1e-3)
+    for k in ('backbone.conv1.weight', 'segmentation_body.conv.0.weight', 'segmentation_head.thresh.3.weight'):
+        a, b = dict(model.named_parameters())[k].grad.cpu().double().flatten(), grads_o[k].double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm()))
+        print('odd-size grad %s cos %.6f' % (k, cos))
+        assert cos > 0.995, (k, cos)

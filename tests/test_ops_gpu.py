@@ -363,3 +363,21 @@ def test_conv_transpose_split(ns):
     report('convT dgrad ns=%d' % ns, nchw(dx), dx_ref, atol * float(dx_ref.abs().max()), rtol)
     g = wgrad(xs, dys, Ci, Co, 2, 2, 0, 1.0, ns)
     report('convT wgrad ns=%d' % ns, g.cpu(), dw_ref, atol * float(dw_ref.abs().max()), rtol)
+
+
+@pytest.mark.parametrize('hs,ws,h,w', [(428, 640, 427, 640), (12, 20, 9, 17), (8, 8, 8, 8), (6, 5, 13, 11), (4, 4, 1, 1)])
+def test_bilinear_align_corners(hs, ws, h, w):
+    """models.py:43-46: F.interpolate(size=(H,W), mode='bilinear', align_corners=True) on NCHW planes, and its adjoint."""
+    N, C = 2, 3
+    a = rnd(N, C, hs, ws, seed=1).requires_grad_(True)
+    ref = F.interpolate(a, size=(h, w), mode='bilinear', align_corners=True)
+    dout = rnd(N, C, h, w, seed=2)
+    (da_ref, ) = torch.autograd.grad(ref, a, dout)
+    ad = a.detach().to(DEV)
+    out = torch.full((N, C, h, w), float('nan'), device=DEV)
+    _lib.check(L().dbn_bilinear_fwd(ad.data_ptr(), out.data_ptr(), N * C, hs, ws, h, w, stream()), 'bilinear fwd')
+    report('bilinear fwd', out.cpu(), ref, 1e-5, 1e-5)
+    dd = dout.to(DEV)
+    da = torch.full((N, C, hs, ws), float('nan'), device=DEV)
+    _lib.check(L().dbn_bilinear_bwd(dd.data_ptr(), da.data_ptr(), N * C, hs, ws, h, w, stream()), 'bilinear bwd')
+    report('bilinear bwd', da.cpu(), da_ref, 1e-5, 1e-5)
