@@ -883,6 +883,18 @@ int dbn_pack_weights_bf16s(const float* w_oihw, int O, int I, int R, int S, int 
 }
 
 static void wgrad_tiles(int O, int J, int& bm, int& bn) {
+    static int force192 = -1;
+    if (force192 < 0) {
+        const char* e = getenv("DBN_WGRAD_192");
+        force192 = e ? atoi(e) : 1;  // 0: never, 1: 64-output-channel layers, 2: every layer with J % 192 == 0
+    }
+    if (J % 192 == 0 && ((force192 == 1 && O == 64) || force192 == 2)) {
+        // 64 x 192: J = taps*Cin of every 3x3 layer is a multiple of 192 (no padded columns), and the 64 + 192
+        // staging threads are exactly the 4 waves of the workgroup
+        bm = 64;
+        bn = 192;
+        return;
+    }
     bm = (O % 128 == 0 && J >= 128) ? 128 : 64;
     bn = (J >= 128) ? 128 : 64;
 }
@@ -953,7 +965,9 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
     dim3 grid((O / bm) * njt * splitk);
 #define DBN_WGRAD_LAUNCH(NS_)                                                                             \
     do {                                                                                                    \
-        if (bm == 128 && bn == 128)                                                                         \
+        if (bn == 192)                                                                                      \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 192, 2, 2, NS_>), grid, dim3(256), 0, st, p);          \
+        else if (bm == 128 && bn == 128)                                                                    \
             hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);         \
         else if (bn == 128)                                                                                 \
             hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);          \
