@@ -37,6 +37,7 @@ struct IgemmClass {
     int pad_h, pad_w;  // MODE 0: conv padding; MODE 1/2: hs = hd + pad_h - r
     int oh0, ow0;      // MODE 2: dst pixel = (2*hd + oh0, 2*wd + ow0)
     int tiles;         // workgroups of this problem
+    int row_base;      // index of this problem's first M-tile among all M-tiles of the launch (BN statistics)
     long wpk_off;      // float offset of its weight panels
 };
 
@@ -46,6 +47,8 @@ struct IgemmParams {
     const float* bias;  // [Cd] or null
     float* dst;         // [N,Hdf,Wdf,Cd]
     int N, Hs, Ws, Cs, Cd, Hdf, Wdf, stride, accumulate, ncls;
+    int stat_rows;      // total M-tiles of the launch
+    float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
     unsigned src_bytes;
     IgemmClass cls[4];
 };
@@ -348,6 +351,60 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         __syncthreads();
     }
 
+    // ---- optional BatchNorm statistics of this tile (train-mode BN follows the conv): per output channel the
+    // pivot (first row of the tile), sum and sum of squares of (value - pivot) over the tile's valid rows.  A
+    // per-tile pivot keeps the fp32 sums free of cancellation; the finalize kernel merges tiles in fp64.
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(smem);  // the LDS panels are dead after the last barrier of the k-loop
+        float* piv = red;                             // [BN]
+        float* r1 = red + BN;                         // [WM][BN]
+        float* r2 = r1 + WM * BN;                     // [WM][BN]
+        if (wm == 0 && lh == 0) {
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                const int cl = wn * TN + b * 32 + li;
+                piv[cl] = acc[0][b][0] + (p.bias ? p.bias[n0 + cl] : 0.f);  // row m0 (< M always)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int cl = wn * TN + b * 32 + li;
+            const float pv = piv[cl], bv = p.bias ? p.bias[n0 + cl] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float d = (acc[a][b][r] + bv) - pv;
+                    s1 += row < qM ? d : 0.f;
+                    s2 += row < qM ? d * d : 0.f;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                r1[wm * BN + cl] = s1;
+                r2[wm * BN + cl] = s2;
+            }
+        }
+        __syncthreads();
+        const int trow = q.row_base + mt;
+        for (int cl = tid; cl < BN; cl += NT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += r1[w * BN + cl];
+                s2 += r2[w * BN + cl];
+            }
+            const long c = n0 + cl;
+            p.stats[(0L * p.Cd + c) * p.stat_rows + trow] = piv[cl];
+            p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
+            p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
+        }
+        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)min(BM, qM - m0);
+    }
+
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
 #pragma unroll
@@ -380,11 +437,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
-    int grid = 0;
+    int grid = 0, rows = 0;
     for (int c = 0; c < p.ncls; ++c) {
-        p.cls[c].tiles = dbn_ceil_div(p.cls[c].M, BM) * (p.Cd / BN);
+        const int mtiles = dbn_ceil_div(p.cls[c].M, BM);
+        p.cls[c].tiles = mtiles * (p.Cd / BN);
+        p.cls[c].row_base = rows;
+        rows += mtiles;
         grid += p.cls[c].tiles;
     }
+    p.stat_rows = rows;
     if (mode == 0)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
@@ -624,6 +685,63 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
     }
 }
 
+// Merge the per-tile BatchNorm partials written by the igemm epilogue (Chan et al. parallel variance, fp64)
+// into scale/shift, saved mean/rstd and the running statistics.  One 256-thread block per channel.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = dbn_wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+__global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int rows, int C, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                                         float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float* pv = stats + (0L * C + c) * rows;
+    const float* s1 = stats + (1L * C + c) * rows;
+    const float* s2 = stats + (2L * C + c) * rows;
+    const float* cn = stats + 3L * C * rows;
+    double n = 0.0, sum = 0.0;
+    for (int t = threadIdx.x; t < rows; t += blockDim.x) {
+        const double nt = (double)cn[t];
+        n += nt;
+        sum += nt * (double)pv[t] + (double)s1[t];
+    }
+    n = block_sum_d(n, red);
+    sum = block_sum_d(sum, red);
+    const double mean = sum / n;
+    double m2 = 0.0;
+    for (int t = threadIdx.x; t < rows; t += blockDim.x) {
+        const float ntf = cn[t];
+        const double nt = (double)ntf, inv = (double)(1.0f / ntf);  // counts are small integers: the fp32 reciprocal is ample
+        const double a1 = (double)s1[t];
+        const double dm = (double)pv[t] + a1 * inv - mean;
+        m2 += ((double)s2[t] - a1 * a1 * inv) + nt * dm * dm;
+    }
+    m2 = block_sum_d(m2, red);
+    if (threadIdx.x != 0) return;
+    double var = m2 / n;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-meanf, sc, beta[c]);
+    mean_out[c] = meanf;
+    rstd_out[c] = rstd;
+    if (run_mean) {
+        const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * meanf;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
 // OIHW -> [Kpad/4][Cd][4] panels.  mode 0: k = (r*S+s)*Cs + cs -> w[cd][cs][r][s] (cs < I);
 // mode 1: data-gradient panels, taps r = r0 + rstep*r', s = s0 + rstep*s' (R', S' of them):
 //         k = (r'*S'+s')*Cs + cs -> w[cs][cd][r][s].
@@ -751,7 +869,7 @@ static long panel_floats(int K, int Cd, int ns) {
 
 static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                     void* stream) {
+                     void* stream, float* stats = nullptr) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
@@ -761,6 +879,7 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.stride = stride; p.accumulate = accumulate;
+    p.stats = stats; p.stat_rows = 0;
     p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
     if (!(mode == 1 && stride == 2)) {
         p.ncls = 1;
@@ -808,6 +927,60 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, 0, stream);
+}
+
+// Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32)
+static int bn_tile_rows(int N, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint) {
+    const int bm_of[5] = {0, 128, 256, 128, 64};
+    if (!(mode == 1 && stride == 2)) {
+        const int M = N * Hd * Wd;
+        int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M, Cd);
+        if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+        return dbn_ceil_div(M, bm_of[cfg]);
+    }
+    long Mmax = 0;
+    int Mc[4], nc = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            // (k2,s2,p0 ConvTranspose forward is the only BN-followed stride-2 transposed conv: every class exists)
+            const int Hc = (Hd - ph + 1) / 2, Wc = (Wd - pw + 1) / 2;
+            if (Hc > 0 && Wc > 0) {
+                Mc[nc] = N * Hc * Wc;
+                Mmax = Mc[nc] > Mmax ? Mc[nc] : Mmax;
+                ++nc;
+            }
+        }
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config((int)Mmax * (nc > 1 ? nc : 1), Cd);
+    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    int rows = 0;
+    for (int i = 0; i < nc; ++i) rows += dbn_ceil_div(Mc[i], bm_of[cfg]);
+    return rows;
+}
+
+// floats of scratch for the fused conv + BatchNorm-statistics call
+long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) {
+    long worst = 0;
+    for (int t = 1; t <= 4; ++t) {
+        const long r = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, t);
+        worst = r > worst ? r : worst;
+    }
+    return (3L * Cd + 1) * worst;
+}
+
+// Convolution (dbn_igemm_f32 / _bf16s contract; ns = 0, 1, 3) whose epilogue also accumulates the train-mode
+// BatchNorm statistics of its output, followed by the finalize kernel: replaces conv -> separate statistics pass.
+// Outputs like dbn_bn_train_stats.  ws: dbn_conv_bn_ws_floats(...) floats.
+int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                    int Cd, int R, int S, int stride, int pad, int mode, int tile_hint, int ns, const float* gamma,
+                    const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* scale, float* shift,
+                    float* save_mean, float* save_rstd, float* ws, void* stream) {
+    DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
+    const int rows = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, tile_hint);
+    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, 0, tile_hint, ns, stream, ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
+                       beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
 }
 
 // Same contract as dbn_igemm_f32 with the products evaluated on the bf16 matrix pipe: ns = 3 fp32-accurate

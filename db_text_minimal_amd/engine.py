@@ -251,6 +251,59 @@ class Engine:
             self.prof.end()
         return y
 
+    fuse_bn_stats = True  # accumulate train-mode BN statistics in the conv epilogue (no separate statistics pass)
+
+    def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride):
+        """args: dbn_igemm_f32's arguments up to and including `mode` (without accumulate / tile_hint / stream)."""
+        C = y.shape[-1]
+        sc, sh = self.buf(bn_name + '/scale', C), self.buf(bn_name + '/shift', C)
+        mu, rs = self.buf(bn_name + '/mean', C), self.buf(bn_name + '/rstd', C)
+        N, Hd, Wd = y.shape[0], y.shape[1], y.shape[2]
+        ws = self.scratch('_conv_bn_ws', self.L.dbn_conv_bn_ws_floats(N, Hd, Wd, C, mode, stride))
+        check(self.L.dbn_conv_bn_f32(*args, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                     mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), what)
+        self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
+        return sc, sh
+
+    def conv_bn(self, name, x, conv, out_name, bn_name, bn, train):
+        """conv -> BatchNorm coefficients.  Train mode: one fused call (statistics in the conv epilogue)."""
+        if not (train and self.fuse_bn_stats):
+            y = self.conv_fwd(name, x, conv, out_name)
+            sc, sh = self.bn_coef(bn_name, bn, y, train)
+            return y, sc, sh
+        N, H, W, C = x.shape
+        k, s, p = conv.k, conv.stride, conv.padding
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
+        wpk = self.pack(name, conv.weight, 0)
+        y = self.buf(out_name, N, Ho, Wo, conv.cout)
+        if self.prof:
+            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
+        sc, sh = self._conv_bn_call('conv+bn ' + name, bn_name, bn, y,
+                                    (x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k, k,
+                                     s, p, 0), 0, s)
+        if self.prof:
+            self.prof.end()
+        return y, sc, sh
+
+    def convT_bn(self, name, x, ct, out_name, bn_name, bn, train):
+        if not (train and self.fuse_bn_stats):
+            y = self.convT_fwd(name, x, ct, out_name)
+            sc, sh = self.bn_coef(bn_name, bn, y, train)
+            return y, sc, sh
+        N, H, W, C = x.shape
+        wpk = self.pack(name, ct.weight, 1, 2)
+        y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
+        if self.prof:
+            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 2)
+        sc, sh = self._conv_bn_call('convT+bn ' + name, bn_name, bn, y,
+                                    (x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
+                                     2, 2, 0, 1), 1, 2)
+        if self.prof:
+            self.prof.end()
+        return y, sc, sh
+
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
         self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns), flops, 0.0, tag)
 
@@ -390,8 +443,7 @@ class Engine:
         bb = m.backbone
         x4 = self.buf('x4', N, H, W, 4)
         check(L.dbn_nchw3_to_nhwc4(x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
-        y0 = self.conv_fwd('backbone.conv1', x4, bb.conv1, 'stem/y')
-        sc, sh = self.bn_coef('backbone.bn1', bb.bn1, y0, train)
+        y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
         check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
@@ -408,8 +460,7 @@ class Engine:
         pre = 'segmentation_body.'
 
         def cbr(name, mod, xin):
-            y = self.conv_fwd(pre + name + '.conv', xin, mod.conv, name + '/y')
-            s_, h_ = self.bn_coef(pre + name + '.bn', mod.bn, y, train)
+            y, s_, h_ = self.conv_bn(pre + name + '.conv', xin, mod.conv, name + '/y', pre + name + '.bn', mod.bn, train)
             return self.bn_apply(y, s_, h_, name + '/z')
 
         p5 = cbr('reduce_conv_c5', fpn.reduce_conv_c5, c5)
@@ -429,19 +480,16 @@ class Engine:
         cat = self.buf('cat', N, Hq, Wq, 256)
         for i, t in enumerate((p2, p3, p4, p5)):
             self.up_fwd(t, None, cat, coff=64 * i)
-        fy = self.conv_fwd(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y')
-        s_, h_ = self.bn_coef(pre + 'conv.1', fpn.conv[1], fy, train)
+        fy, s_, h_ = self.conv_bn(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
         f = self.bn_apply(fy, s_, h_, 'fpn/z')
         head = m.segmentation_head
         z1 = {}
         for br in ('binarize', 'thresh'):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            ya = self.conv_fwd(hp + '0', f, seq[0], br + '/y0')
-            s_, h_ = self.bn_coef(hp + '1', seq[1], ya, train)
+            ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train)
             za = self.bn_apply(ya, s_, h_, br + '/z0')
-            yb = self.convT_fwd(hp + '3', za, seq[3], br + '/y1')
-            s_, h_ = self.bn_coef(hp + '4', seq[4], yb, train)
+            yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = self.bn_apply(yb, s_, h_, br + '/z1')
         ch = 3 if train else 2
         Hh, Wh = z1['binarize'].shape[1], z1['binarize'].shape[2]
@@ -465,14 +513,12 @@ class Engine:
         return out
 
     def _block_fwd(self, name, blk, x, train):
-        y1 = self.conv_fwd(name + '.conv1', x, blk.conv1, name + '/y1')
-        s1, h1 = self.bn_coef(name + '.bn1', blk.bn1, y1, train)
+        y1, s1, h1 = self.conv_bn(name + '.conv1', x, blk.conv1, name + '/y1', name + '.bn1', blk.bn1, train)
         z1 = self.bn_apply(y1, s1, h1, name + '/z1')
-        y2 = self.conv_fwd(name + '.conv2', z1, blk.conv2, name + '/y2')
-        s2, h2 = self.bn_coef(name + '.bn2', blk.bn2, y2, train)
+        y2, s2, h2 = self.conv_bn(name + '.conv2', z1, blk.conv2, name + '/y2', name + '.bn2', blk.bn2, train)
         if blk.downsample is not None:
-            yd = self.conv_fwd(name + '.downsample.0', x, blk.downsample[0], name + '/yd')
-            sd, hd = self.bn_coef(name + '.downsample.1', blk.downsample[1], yd, train)
+            yd, sd, hd = self.conv_bn(name + '.downsample.0', x, blk.downsample[0], name + '/yd', name + '.downsample.1',
+                                      blk.downsample[1], train)
             out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=yd, rsc=sd, rsh=hd)
         else:
             out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=x)

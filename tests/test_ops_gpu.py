@@ -381,3 +381,36 @@ def test_bilinear_align_corners(hs, ws, h, w):
     da = torch.full((N, C, hs, ws), float('nan'), device=DEV)
     _lib.check(L().dbn_bilinear_bwd(dd.data_ptr(), da.data_ptr(), N * C, hs, ws, h, w, stream()), 'bilinear bwd')
     report('bilinear bwd', da.cpu(), da_ref, 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 16, 12), (3, 128, 64, 1, 1, 0, 9, 7), (2, 3, 64, 7, 2, 3, 32, 40), (1, 256, 256, 3, 1, 1, 12, 12),
+                                  (4, 64, 64, 3, 1, 1, 40, 40)])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+@pytest.mark.parametrize('ns', [0, 3])
+def test_conv_with_fused_bn_statistics(case, tile, ns):
+    """dbn_conv_bn_f32: conv output + train-mode BN coefficients/running stats from the epilogue partials == F.conv2d + F.batch_norm."""
+    N, Ci, Co, k, s, p, H, W = case
+    x = rnd(N, Ci, H, W, seed=1) * 2 + 0.5
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    b = rnd(Co, seed=3) * 3  # large bias: mean >> std exercises the pivot
+    gamma, beta = rnd(Co, seed=4) * 0.3 + 1, rnd(Co, seed=5)
+    rm, rv = rnd(Co, seed=6), rnd(Co, seed=7).abs() + 0.5
+    y_ref = F.conv2d(x, w, b, s, p)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z_ref = F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    Ho, Wo = y_ref.shape[2:]
+    xs = nhwc(pad_c(x, (Ci + 3) // 4 * 4))
+    y = torch.full((N, Ho, Wo, Co), float('nan'), device=DEV)
+    d = lambda t: t.clone().to(DEV)
+    g_, b_, rm_, rv_, bias_ = d(gamma), d(beta), d(rm), d(rv), d(b)
+    sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+    ws = torch.empty(L().dbn_conv_bn_ws_floats(N, Ho, Wo, Co, 0, s), device=DEV)
+    wpk = pack(w, 0, s, ns)
+    _lib.check(L().dbn_conv_bn_f32(xs.data_ptr(), wpk.data_ptr(), bias_.data_ptr(), y.data_ptr(), N, H, W, xs.shape[3], Ho, Wo, Co, k, k,
+                                   s, p, 0, tile, ns, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                   sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
+    report('conv_bn y', nchw(y), y_ref, 1e-4, 1e-4)
+    report('conv_bn running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
+    report('conv_bn running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
+    z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
+    report('conv_bn normalised output', z, z_ref, 2e-5, 1e-4)
