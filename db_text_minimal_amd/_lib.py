@@ -41,6 +41,8 @@ SIGNATURES = {
     'dbn_nearest_up_bwd': 'pp' + 'i' * 9 + 'p',
     'dbn_bilinear_fwd': 'ppliiiip',
     'dbn_bilinear_bwd': 'ppliiiip',
+    'dbn_fpn_combine_weights': 'piiiipp',
+    'dbn_fpn_scatter_wgrad': 'ppppiipp',
     'dbn_nchw3_to_nhwc4': 'ppiiip',
     'dbn_add_inplace': 'pplp',
     'dbn_head_tail_fwd': 'ppppppp' + 'iiii' + 'f' + 'p',

@@ -872,7 +872,8 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
                      void* stream, float* stats = nullptr) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
-    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
+    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
+    DBN_REQUIRE(stride == 1 || stride == 2 || (mode == 0 && stride >= 1));  // forward conv: any stride; data gradient: 1 or 2
     DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
     hipStream_t st = (hipStream_t)stream;
     IgemmParams p;
@@ -1030,7 +1031,8 @@ static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp
 }
 
 static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
-    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1) && (stride == 1 || stride == 2));
+    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1));
+    DBN_REQUIRE(stride == 1 || stride == 2 || (mode == 0 && stride >= 1));
     const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);

@@ -111,6 +111,13 @@ int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, in
 int dbn_bilinear_fwd(const float* src, float* dst, long planes, int Hs, int Ws, int H, int W, void* stream);
 int dbn_bilinear_bwd(const float* ddst, float* dsrc, long planes, int Hs, int Ws, int H, int W, void* stream);
 
+/* ---- FPN output conv over [p2 | up2(p3) | up4(p4) | up8(p5)] (segmentation_body.py:55-61,82-87): its data and
+ *      weight gradients per upsample group g (factor f = 2^g) are those of a (f+2)x(f+2), stride-f, pad-1 conv with
+ *      COMBINED weights (sums of the 3x3 taps that read the same low-resolution pixel): 47 % of the MACs, no concat. */
+int dbn_fpn_combine_weights(const float* w, int Co, int Cin, int group, int Cg, float* wd, void* stream);
+int dbn_fpn_scatter_wgrad(const float* t0, const float* t1, const float* t2, const float* t3, int Co, int Cg, float* dw,
+                          void* stream);
+
 /* ---- layout / misc */
 int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
 int dbn_add_inplace(const float* x, float* y, long n, void* stream);

@@ -414,3 +414,30 @@ def test_conv_with_fused_bn_statistics(case, tile, ns):
     report('conv_bn running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
     z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
     report('conv_bn normalised output', z, z_ref, 2e-5, 1e-4)
+
+
+def test_fpn_structured_conv_gradients():
+    """Data/weight gradients of conv3x3 over [p2 | up2(p3) | up4(p4) | up8(p5)] via the combined (f+2)x(f+2) stride-f
+    convs == autograd of F.conv2d(torch.cat(nearest-upsampled)) (segmentation_body.py:75-76,82-87)."""
+    N, H, W, Cg, Co = 2, 16, 24, 64, 256
+    ps = [rnd(N, Cg, H >> g, W >> g, seed=10 + g).requires_grad_(True) for g in range(4)]
+    w = rnd(Co, 4 * Cg, 3, 3, seed=3, scale=0.03).requires_grad_(True)
+    cat = torch.cat([ps[0]] + [F.interpolate(ps[g], size=(H, W)) for g in range(1, 4)], 1)
+    y = F.conv2d(cat, w, None, 1, 1)
+    dy = rnd(*y.shape, seed=4)
+    grads = torch.autograd.grad(y, ps + [w], dy)
+    dys = nhwc(dy)
+    wd_ = w.detach().to(DEV)
+    ts = []
+    for g in range(4):
+        f, k = 1 << g, (1 << g) + 2
+        wdg = torch.empty(Cg, Co, k, k, device=DEV)
+        _lib.check(L().dbn_fpn_combine_weights(wd_.data_ptr(), Co, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+        d = torch.full((N, H >> g, W >> g, Cg), float('nan'), device=DEV)
+        igemm(dys, pack(wdg.cpu(), 0, f), None, d, k, f, 1, 0)
+        report('fpn level %d dgrad' % g, nchw(d), grads[g], 1e-4, 1e-4)
+        ts.append(wgrad(nhwc(ps[g].detach()), dys, Cg, Co, k, f, 1))
+    dw = torch.full((Co, 4 * Cg, 3, 3), float('nan'), device=DEV)
+    _lib.check(L().dbn_fpn_scatter_wgrad(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), Co, Cg, dw.data_ptr(),
+                                         stream()), 'scatter')
+    report('fpn structured wgrad', dw.cpu(), grads[4], 2e-5 * float(grads[4].abs().max()) + 1e-5, 1e-4)
