@@ -21,7 +21,7 @@ SIGNATURES = {
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
     'dbn_conv_bn_ws_floats': 'iiiiii',
-    'dbn_conv_bn_f32': 'pppp' + 'i' * 14 + 'pp' + 'ff' + 'ppppppp' + 'p',
+    'dbn_conv_bn_f32': 'pppp' + 'i' * 15 + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_pack_weights_bf16s': 'piiiiiiipp',
     'dbn_igemm_bf16s_panel_floats': 'iiiiiii',
     'dbn_igemm_bf16s': 'pppp' + 'i' * 15 + 'p',

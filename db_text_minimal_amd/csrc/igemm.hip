@@ -27,30 +27,51 @@
 
 namespace {
 
-// One GEMM problem of a launch.  A stride-2 data gradient / ConvTranspose forward is split into
-// up to four output-parity classes (each a dense stride-1 transposed conv over a quarter of the
-// output pixels with only the taps that hit it), so no zero taps are multiplied.
+// Geometry of one GEMM problem of a launch.  A stride-f data gradient / transposed conv (f = 2, 4, 8) is split into
+// f*f output-parity classes — each a dense stride-1 transposed conv over 1/f^2 of the output pixels with only the
+// taps that reach it — so no zero taps are multiplied.  Classes are derived from the class index by class_geom()
+// on both host and device; the launch carries only per-class tile ranges and weight-panel offsets.
 struct IgemmClass {
     int Hd, Wd;        // output sub-grid of this problem
     int M, K, KT;      // rows, reduction length, k-tiles
     int R, S;          // taps of this problem
     int pad_h, pad_w;  // MODE 0: conv padding; MODE 1/2: hs = hd + pad_h - r
-    int oh0, ow0;      // MODE 2: dst pixel = (2*hd + oh0, 2*wd + ow0)
-    int tiles;         // workgroups of this problem
-    int row_base;      // index of this problem's first M-tile among all M-tiles of the launch (BN statistics)
-    long wpk_off;      // float offset of its weight panels
+    int oh0, ow0;      // MODE 2: dst pixel = (f*hd + oh0, f*wd + ow0)
 };
+
+constexpr int MAX_CLASSES = 64;
+
+__host__ __device__ inline int taps_of_class(int R, int ph, int f) { return ph < R ? (R - ph + f - 1) / f : 0; }
+
+// class c = ph*f + pw of a transposed conv (R x S taps, stride f, padding pad) onto an Hdf x Wdf output
+__host__ __device__ inline IgemmClass class_geom(int c, int f, int R, int S, int pad, int N, int Hdf, int Wdf, int Cs) {
+    IgemmClass q;
+    const int ph = c / f, pw = c - ph * f;
+    q.R = taps_of_class(R, ph, f);
+    q.S = taps_of_class(S, pw, f);
+    q.oh0 = (((ph - pad) % f) + f) % f;
+    q.ow0 = (((pw - pad) % f) + f) % f;
+    q.Hd = q.oh0 < Hdf ? (Hdf - q.oh0 + f - 1) / f : 0;
+    q.Wd = q.ow0 < Wdf ? (Wdf - q.ow0 + f - 1) / f : 0;
+    q.pad_h = (q.oh0 + pad - ph) / f;  // exact: oh0 + pad - ph is a multiple of f
+    q.pad_w = (q.ow0 + pad - pw) / f;
+    q.M = N * q.Hd * q.Wd;
+    q.K = q.R * q.S * Cs;
+    q.KT = (q.K + 15) / 16;
+    return q;
+}
 
 struct IgemmParams {
     const float* src;   // [N,Hs,Ws,Cs]
     const float* wpk;   // per problem: [KT*4][Cd][4]
     const float* bias;  // [Cd] or null
     float* dst;         // [N,Hdf,Wdf,Cd]
-    int N, Hs, Ws, Cs, Cd, Hdf, Wdf, stride, accumulate, ncls;
+    int N, Hs, Ws, Cs, Cd, Hdf, Wdf, R, S, stride, pad, accumulate, ncls;
     int stat_rows;      // total M-tiles of the launch
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
     unsigned src_bytes;
-    IgemmClass cls[4];
+    // MODE 2 only: per class exclusive end of its workgroup range, first M-tile index, weight-panel offset (floats)
+    int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
 };
 
 constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
@@ -159,14 +180,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const int li = lane & 31, lh = lane >> 5;
 
     int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
-    int ci_ = 0;
+    IgemmClass q;
+    int q_row_base = 0, q_wpk_off = 0;
     if (MODE == 2) {
-        while (ci_ + 1 < p.ncls && tile >= p.cls[ci_].tiles) {
-            tile -= p.cls[ci_].tiles;
-            ++ci_;
-        }
+        int c = 0;
+        while (c + 1 < p.ncls && tile >= p.tile_end[c]) ++c;
+        tile -= c ? p.tile_end[c - 1] : 0;
+        q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
+        q_row_base = p.row_base[c];
+        q_wpk_off = p.wpk_off[c];
+    } else {
+        q.Hd = p.Hdf; q.Wd = p.Wdf; q.M = p.N * p.Hdf * p.Wdf; q.R = p.R; q.S = p.S;
+        q.K = p.R * p.S * p.Cs; q.KT = (q.K + 15) / 16;
+        q.pad_h = q.pad_w = p.pad; q.oh0 = q.ow0 = 0;
     }
-    const IgemmClass& q = p.cls[ci_];
     const int ntn = p.Cd / BN;
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         const int idx = tid + j * NT;
         b_on[j] = B_FULL || idx < B_PIECES;
         const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
-        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk + q.wpk_off) + (long)c * p.Cd + n0 + n;
+        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk + q_wpk_off) + (long)c * p.Cd + n0 + n;
         b_lds[j] = c * BS + n;
     }
     const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
@@ -351,6 +378,32 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         __syncthreads();
     }
 
+    // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
+    // statistics below and the store loop both see the final values
+    const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
+    auto dst_offset = [&](int row) -> long {
+        if (MODE == 2) {  // the parity class's pixels of the full-resolution output
+            int n, rem, hd, wd;
+            divmod24(row, HWd, rcp_hw, n, rem);
+            divmod24(rem, qWd, rcp_w, hd, wd);
+            return (((long)n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * p.Cd;
+        }
+        return (long)row * p.Cd;
+    };
+    if (p.accumulate) {
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < qM) {
+                    const long doff = dst_offset(row);
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) acc[a][b][r] += p.dst[doff + n0 + wn * TN + b * 32 + li];
+                }
+            }
+    }
+
     // ---- optional BatchNorm statistics of this tile (train-mode BN follows the conv): per output channel the
     // pivot (first row of the tile), sum and sum of squares of (value - pivot) over the tile's valid rows.  A
     // per-tile pivot keeps the fp32 sums free of cancellation; the finalize kernel merges tiles in fp64.
@@ -389,7 +442,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             }
         }
         __syncthreads();
-        const int trow = q.row_base + mt;
+        const int trow = q_row_base + mt;
         for (int cl = tid; cl < BN; cl += NT) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -406,29 +459,17 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
 #pragma unroll
     for (int a = 0; a < MI; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row < qM) {
-                long doff;
-                if (MODE == 2) {  // scatter to the parity class's pixels of the full-resolution output
-                    int n, rem, hd, wd;
-                    divmod24(row, HWd, rcp_hw, n, rem);
-                    divmod24(rem, qWd, rcp_w, hd, wd);
-                    doff = (((long)n * p.Hdf + 2 * hd + q.oh0) * p.Wdf + 2 * wd + q.ow0) * p.Cd;
-                } else {
-                    doff = (long)row * p.Cd;
-                }
+                const long doff = dst_offset(row);
 #pragma unroll
                 for (int b = 0; b < NI; ++b) {
                     const int col = n0 + wn * TN + b * 32 + li;
-                    float* d = p.dst + doff + col;
-                    float v = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
-                    if (p.accumulate) v += *d;
-                    *d = v;
+                    p.dst[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
                 }
             }
         }
@@ -438,14 +479,21 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     int grid = 0, rows = 0;
-    for (int c = 0; c < p.ncls; ++c) {
-        const int mtiles = dbn_ceil_div(p.cls[c].M, BM);
-        p.cls[c].tiles = mtiles * (p.Cd / BN);
-        p.cls[c].row_base = rows;
-        rows += mtiles;
-        grid += p.cls[c].tiles;
+    if (mode == 2) {
+        for (int c = 0; c < p.ncls; ++c) {
+            const IgemmClass q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
+            const int mtiles = (q.K > 0 && q.M > 0) ? dbn_ceil_div(q.M, BM) : 0;
+            p.row_base[c] = rows;
+            rows += mtiles;
+            grid += mtiles * (p.Cd / BN);
+            p.tile_end[c] = grid;
+        }
+    } else {
+        rows = dbn_ceil_div(p.N * p.Hdf * p.Wdf, BM);
+        grid = rows * (p.Cd / BN);
     }
     p.stat_rows = rows;
+    if (grid == 0) return DBN_OK;
     if (mode == 0)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
@@ -817,7 +865,6 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, in
     }
 }
 
-inline int taps_of_parity(int R, int ph) { return (R - ph + 1) / 2; }
 
 }  // namespace
 
@@ -849,9 +896,8 @@ int dbn_igemm_tile_config(int M, int Cd) {
 }
 
 static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st) {
-    long Mmax = 0;
-    for (int c = 0; c < p.ncls; ++c) Mmax = p.cls[c].M > Mmax ? p.cls[c].M : Mmax;
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config((int)Mmax * (p.ncls > 1 ? p.ncls : 1), p.Cd);
+    // tile choice from the total row count (for parity classes: all classes together)
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
     switch (cfg) {
         case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st);
@@ -873,55 +919,36 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
-    DBN_REQUIRE(stride == 1 || stride == 2 || (mode == 0 && stride >= 1));  // forward conv: any stride; data gradient: 1 or 2
+    DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
     DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
     hipStream_t st = (hipStream_t)stream;
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
-    p.stride = stride; p.accumulate = accumulate;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.stats = stats; p.stat_rows = 0;
     p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
-    if (!(mode == 1 && stride == 2)) {
+    if (!(mode == 1 && stride > 1)) {
         p.ncls = 1;
-        IgemmClass& q = p.cls[0];
-        q.Hd = Hd; q.Wd = Wd; q.M = N * Hd * Wd; q.R = R; q.S = S;
-        q.K = R * S * Cs; q.KT = (q.K + 15) / 16;
-        q.pad_h = q.pad_w = pad; q.oh0 = q.ow0 = 0; q.wpk_off = 0; q.tiles = 0;
         return igemm_dispatch(p, mode, ns, tile_hint, st);
     }
-    // stride-2 data gradient / ConvTranspose forward: one problem per output parity class, heaviest first
-    p.ncls = 0;
+    // stride-f data gradient / transposed conv: one problem per output parity class
+    p.ncls = stride * stride;
     long off = 0;
     int covered = 0;
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
-            const int Rc = taps_of_parity(R, ph), Sc = taps_of_parity(S, pw);
-            const int oh0 = (((ph - pad) % 2) + 2) % 2, ow0 = (((pw - pad) % 2) + 2) % 2;
-            const int Hc = (Hd - oh0 + 1) / 2, Wc = (Wd - ow0 + 1) / 2;
-            const int K = Rc * Sc * Cs, Kpad = ((K + 15) / 16) * 16;
-            if (Rc > 0 && Sc > 0 && Hc > 0 && Wc > 0) {
-                IgemmClass& q = p.cls[p.ncls++];
-                q.Hd = Hc; q.Wd = Wc; q.M = N * Hc * Wc; q.R = Rc; q.S = Sc; q.K = K; q.KT = Kpad / 16;
-                q.pad_h = (oh0 + pad - ph) / 2; q.pad_w = (ow0 + pad - pw) / 2;
-                q.oh0 = oh0; q.ow0 = ow0; q.wpk_off = off; q.tiles = 0;
-                ++covered;
-            }
-            off += panel_floats(K, Cd, ns);
-        }
-    if (covered < 4 && !accumulate) {  // some output pixels receive no tap: they are zero
+    for (int c = 0; c < p.ncls; ++c) {
+        const IgemmClass q = class_geom(c, stride, R, S, pad, N, Hd, Wd, Cs);
+        p.wpk_off[c] = (int)off;
+        if (q.K > 0 && q.M > 0) ++covered;
+        off += panel_floats(q.K, Cd, ns);
+    }
+    DBN_REQUIRE(off < (1L << 31));
+    DBN_REQUIRE(covered == p.ncls || !bias);  // a bias would have to reach the tap-less pixels too
+    if (covered < p.ncls && !accumulate) {  // some output pixels receive no tap: they are zero
         if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * sizeof(float), st) != hipSuccess) return dbn_status();
         p.accumulate = 1;
     }
-    if (p.ncls == 0) return DBN_OK;
-    // heaviest class first (longest workgroups start earliest)
-    for (int a = 0; a < p.ncls; ++a)
-        for (int b = a + 1; b < p.ncls; ++b)
-            if (p.cls[b].K > p.cls[a].K) {
-                IgemmClass t = p.cls[a];
-                p.cls[a] = p.cls[b];
-                p.cls[b] = t;
-            }
+    if (covered == 0) return DBN_OK;
     return igemm_dispatch(p, 2, ns, tile_hint, st);
 }
 
@@ -933,28 +960,20 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
 // Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32)
 static int bn_tile_rows(int N, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint) {
     const int bm_of[5] = {0, 128, 256, 128, 64};
-    if (!(mode == 1 && stride == 2)) {
+    if (!(mode == 1 && stride > 1)) {
         const int M = N * Hd * Wd;
         int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M, Cd);
         if (cfg == 1 && Cd % 128 != 0) cfg = 3;
         return dbn_ceil_div(M, bm_of[cfg]);
     }
-    long Mmax = 0;
-    int Mc[4], nc = 0;
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
-            // (k2,s2,p0 ConvTranspose forward is the only BN-followed stride-2 transposed conv: every class exists)
-            const int Hc = (Hd - ph + 1) / 2, Wc = (Wd - pw + 1) / 2;
-            if (Hc > 0 && Wc > 0) {
-                Mc[nc] = N * Hc * Wc;
-                Mmax = Mc[nc] > Mmax ? Mc[nc] : Mmax;
-                ++nc;
-            }
-        }
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config((int)Mmax * (nc > 1 ? nc : 1), Cd);
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(N * Hd * Wd, Cd);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
     int rows = 0;
-    for (int i = 0; i < nc; ++i) rows += dbn_ceil_div(Mc[i], bm_of[cfg]);
+    for (int c = 0; c < stride * stride; ++c) {  // BN follows only tap-complete transposed convs: every class has pixels
+        const int ph = c / stride, pw = c % stride;
+        const int Hc = ph < Hd ? (Hd - ph + stride - 1) / stride : 0, Wc = pw < Wd ? (Wd - pw + stride - 1) / stride : 0;
+        if (Hc > 0 && Wc > 0) rows += dbn_ceil_div(N * Hc * Wc, bm_of[cfg]);
+    }
     return rows;
 }
 
@@ -972,12 +991,12 @@ long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) 
 // BatchNorm statistics of its output, followed by the finalize kernel: replaces conv -> separate statistics pass.
 // Outputs like dbn_bn_train_stats.  ws: dbn_conv_bn_ws_floats(...) floats.
 int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
-                    int Cd, int R, int S, int stride, int pad, int mode, int tile_hint, int ns, const float* gamma,
-                    const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* scale, float* shift,
-                    float* save_mean, float* save_rstd, float* ws, void* stream) {
+                    int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                    float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
     const int rows = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, tile_hint);
-    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, 0, tile_hint, ns, stream, ws);
+    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
@@ -1002,8 +1021,8 @@ static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, i
     if (mode == 0) return panel_floats(R * S * ((I + 3) / 4 * 4), O, ns);
     if (stride == 1) return panel_floats(R * S * O, I, ns);
     long tot = 0;
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) tot += panel_floats(taps_of_parity(R, ph) * taps_of_parity(S, pw) * O, I, ns);
+    for (int c = 0; c < stride * stride; ++c)
+        tot += panel_floats(taps_of_class(R, c / stride, stride) * taps_of_class(S, c % stride, stride) * O, I, ns);
     return tot;
 }
 
@@ -1032,20 +1051,20 @@ static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp
 
 static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1));
-    DBN_REQUIRE(stride == 1 || stride == 2 || (mode == 0 && stride >= 1));
+    DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
     const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0 || stride == 1) return pack_one(w_oihw, O, I, R, S, mode, R, S, 0, 0, 1, ns, out, st);
     long off = 0;
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
-            const int Rc = taps_of_parity(R, ph), Sc = taps_of_parity(S, pw);
-            const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, 2, ns, out + off, st);
-            if (rc) return rc;
-            off += panel_floats(Rc * Sc * O, I, ns);
-        }
+    for (int c = 0; c < stride * stride; ++c) {  // same class order and offsets as igemm_run
+        const int ph = c / stride, pw = c % stride;
+        const int Rc = taps_of_class(R, ph, stride), Sc = taps_of_class(S, pw, stride);
+        const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, stride, ns, out + off, st);
+        if (rc) return rc;
+        off += panel_floats(Rc * Sc * O, I, ns);
+    }
     return DBN_OK;
 }
 

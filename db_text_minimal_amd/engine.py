@@ -207,11 +207,13 @@ class Engine:
             self._side_used = False
 
     # ------------------------------------------------------------ weight panels
-    def pack(self, name, w, mode, stride=1):
+    def pack(self, name, w, mode, stride=1, version=None):
+        """Weight panels of `w` for (mode, stride), cached until `w` changes.  `version` replaces w._version for tensors
+        that are rewritten through raw pointers (the FPN's combined weights)."""
         ns = self.ns
         key = (name, mode, stride, ns)
         ent = self.packs.get(key)
-        stamp = (w._version, self.param_epoch, w.data_ptr())
+        stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
         O, I, R, S = w.shape
@@ -253,14 +255,14 @@ class Engine:
 
     fuse_bn_stats = True  # accumulate train-mode BN statistics in the conv epilogue (no separate statistics pass)
 
-    def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride):
+    def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride, accumulate=0):
         """args: dbn_igemm_f32's arguments up to and including `mode` (without accumulate / tile_hint / stream)."""
         C = y.shape[-1]
         sc, sh = self.buf(bn_name + '/scale', C), self.buf(bn_name + '/shift', C)
         mu, rs = self.buf(bn_name + '/mean', C), self.buf(bn_name + '/rstd', C)
         N, Hd, Wd = y.shape[0], y.shape[1], y.shape[2]
         ws = self.scratch('_conv_bn_ws', self.L.dbn_conv_bn_ws_floats(N, Hd, Wd, C, mode, stride))
-        check(self.L.dbn_conv_bn_f32(*args, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+        check(self.L.dbn_conv_bn_f32(*args, accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), what)
         self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
@@ -477,10 +479,17 @@ class Engine:
         self.up_fwd(p3, r2, p2pre)
         p2 = cbr('smooth_p2', fpn.smooth_p2, p2pre)
         Hq, Wq = p2.shape[1], p2.shape[2]
-        cat = self.buf('cat', N, Hq, Wq, 256)
-        for i, t in enumerate((p2, p3, p4, p5)):
-            self.up_fwd(t, None, cat, coff=64 * i)
-        fy, s_, h_ = self.conv_bn(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
+        zs = (p2, p3, p4, p5)
+        self.fpn_exact = self.fpn_structured and all(Hq == zs[g].shape[1] << g and Wq == zs[g].shape[2] << g for g in range(4))
+        if self.fpn_exact:
+            # conv over [p2 | up2(p3) | up4(p4) | up8(p5)] without building the concat: per level a transposed conv
+            # (k = f+2, stride f, pad 1) with combined weights, accumulated into one output (47 % of the dense MACs)
+            fy, s_, h_ = self._fpn_conv_forward(pre + 'conv.0', fpn.conv[0], zs, 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
+        else:
+            cat = self.buf('cat', N, Hq, Wq, 256)
+            for i, t in enumerate(zs):
+                self.up_fwd(t, None, cat, coff=64 * i)
+            fy, s_, h_ = self.conv_bn(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
         f = self.bn_apply(fy, s_, h_, 'fpn/z')
         head = m.segmentation_head
         z1 = {}
@@ -567,16 +576,15 @@ class Engine:
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
         dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], 'self', df, 'fpn/dy')
-        cat = B['cat']
         dP = {}
         levels = ('smooth_p2', 'smooth_p3', 'smooth_p4', 'reduce_conv_c5')
         zs = [B[nm + '/z'] for nm in levels]
-        if self.fpn_structured and all(zs[0].shape[1] == zs[g].shape[1] << g and zs[0].shape[2] == zs[g].shape[2] << g
-                                       for g in range(4)):
+        if self.fpn_exact:
             # conv over [p2 | up2(p3) | up4(p4) | up8(p5)]: per level a (f+2)x(f+2) stride-f conv with combined weights
             # (47 % of the MACs of the dense 256->256 3x3 data/weight gradients, no concat-gradient tensor)
             self._fpn_conv_backward(pre + 'conv.0', fpn.conv[0], dfy, levels, zs, dP)
         else:
+            cat = B['cat']
             self.conv_wgrad(pre + 'conv.0', dfy, cat, fpn.conv[0])
             dcat = self.buf('dcat', *cat.shape)
             self.conv_dgrad(pre + 'conv.0', dfy, fpn.conv[0], dcat, False)
@@ -635,12 +643,13 @@ class Engine:
         self.join_side()
         self.saved_generation = -1
 
-    fpn_structured = True
+    fpn_structured = True  # FPN output conv per upsample level (forward and backward) instead of over the concat
+    fpn_exact = False  # set by forward(): the levels are exact 1, 1/2, 1/4, 1/8 sizes, so the structured path applies
 
-    def _fpn_conv_backward(self, name, conv, dy, levels, zs, dP):
-        N, H, W, Co = dy.shape
+    def _fpn_combined_weights(self, name, conv, Cg):
+        """Wd_g[ci][co][u][v] = sum of the 3x3 taps of W[co][64g+ci] that land on offset (u,v) of level g's (f+2)^2 footprint."""
         w = conv.weight
-        Cg = zs[0].shape[3]
+        Co = w.shape[0]
         stamp = (w._version, self.param_epoch, w.data_ptr())
         ent = self.packs.get((name, 'combined'))
         if ent is None or ent[1] != stamp:
@@ -649,14 +658,43 @@ class Engine:
                 check(self.L.dbn_fpn_combine_weights(w.data_ptr(), Co, w.shape[1], g, Cg, wds[g].data_ptr(), self.stream),
                       'fpn_combine_weights')
             self.packs[(name, 'combined')] = (wds, stamp)
-        wds = self.packs[(name, 'combined')][0]
+        return self.packs[(name, 'combined')][0], stamp[:2]
+
+    def _fpn_conv_forward(self, name, conv, zs, out_name, bn_name, bn, train):
+        N, H, W, Cg = zs[0].shape
+        Co = conv.cout
+        wds, wver = self._fpn_combined_weights(name, conv, Cg)
+        y = self.buf(out_name, N, H, W, Co)
+        fused = train and self.fuse_bn_stats
+        sc = sh = None
+        for g, z in enumerate(zs):
+            f, k = 1 << g, (1 << g) + 2
+            Hg, Wg = z.shape[1], z.shape[2]
+            wpk = self.pack('%s#f%d' % (name, g), wds[g], 1, f, version=wver)
+            if self.prof:
+                self._prof_igemm(N * H * W, Co, 2.0 * N * Hg * Wg * Cg * Co * k * k, 'fwd %s level %d' % (name, g), 2 if g else 1)
+            args = (z.data_ptr(), wpk.data_ptr(), _p(conv.bias) if g == 0 else None, y.data_ptr(), N, Hg, Wg, Cg, H, W, Co, k, k, f, 1, 1)
+            if g == 3 and fused:
+                sc, sh = self._conv_bn_call('fpn conv+bn level 3', bn_name, bn, y, args, 1, f, accumulate=1)
+            else:
+                self._igemm('igemm fpn fwd', *args, int(g > 0), 0)
+            if self.prof:
+                self.prof.end()
+        if not fused:
+            sc, sh = self.bn_coef(bn_name, bn, y, train)
+        return y, sc, sh
+
+    def _fpn_conv_backward(self, name, conv, dy, levels, zs, dP):
+        N, H, W, Co = dy.shape
+        Cg = zs[0].shape[3]
+        wds, wver = self._fpn_combined_weights(name, conv, Cg)
         ts = []
         for g, nm in enumerate(levels):
             f, k = 1 << g, (1 << g) + 2
             z = zs[g]
             Hg, Wg = z.shape[1], z.shape[2]
             d = self.buf(nm + '/dz', *z.shape)
-            wpk = self.pack('%s#g%d' % (name, g), wds[g], 0, f)
+            wpk = self.pack('%s#g%d' % (name, g), wds[g], 0, f, version=wver)
             flops = 2.0 * N * Hg * Wg * Cg * Co * k * k
             if self.prof:
                 self._prof_igemm(N * Hg * Wg, Cg, flops, 'dgrad %s level %d' % (name, g), 0)

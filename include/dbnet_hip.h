@@ -56,13 +56,13 @@ int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_
 
 /* Convolution whose epilogue also accumulates the train-mode BatchNorm statistics of its output (per-tile pivot,
  * sum, sum of squares; merged in fp64 by a finalize kernel): one call replaces conv + statistics pass.
- * Arguments: dbn_igemm_f32's (without `accumulate`), ns = 0 (fp32 MFMA) / 3 / 1 (split-bf16), then
- * dbn_bn_train_stats' BN arguments.  ws: dbn_conv_bn_ws_floats(N,Hd,Wd,Cd,mode,stride) floats. */
+ * Arguments: dbn_igemm_f32's, ns = 0 (fp32 MFMA) / 3 / 1 (split-bf16), then dbn_bn_train_stats' BN arguments.
+ * With accumulate = 1 the statistics are those of the final (previous dst + this conv) values.  ws: dbn_conv_bn_ws_floats(N,Hd,Wd,Cd,mode,stride) floats. */
 long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride);
 int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
-                    int Cd, int R, int S, int stride, int pad, int mode, int tile_hint, int ns, const float* gamma,
-                    const float* beta, float eps, float momentum, float* run_mean, float* run_var, float* scale, float* shift,
-                    float* save_mean, float* save_rstd, float* ws, void* stream);
+                    int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                    float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
 
 /* tile configuration chosen for tile_hint 0: 1=128x128, 2=256x64, 3=128x64, 4=64x64 */
 int dbn_igemm_tile_config(int M, int Cd);

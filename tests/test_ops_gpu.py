@@ -407,7 +407,7 @@ def test_conv_with_fused_bn_statistics(case, tile, ns):
     ws = torch.empty(L().dbn_conv_bn_ws_floats(N, Ho, Wo, Co, 0, s), device=DEV)
     wpk = pack(w, 0, s, ns)
     _lib.check(L().dbn_conv_bn_f32(xs.data_ptr(), wpk.data_ptr(), bias_.data_ptr(), y.data_ptr(), N, H, W, xs.shape[3], Ho, Wo, Co, k, k,
-                                   s, p, 0, tile, ns, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                   s, p, 0, 0, tile, ns, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
                                    sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
     report('conv_bn y', nchw(y), y_ref, 1e-4, 1e-4)
     report('conv_bn running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
@@ -441,3 +441,64 @@ def test_fpn_structured_conv_gradients():
     _lib.check(L().dbn_fpn_scatter_wgrad(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), Co, Cg, dw.data_ptr(),
                                          stream()), 'scatter')
     report('fpn structured wgrad', dw.cpu(), grads[4], 2e-5 * float(grads[4].abs().max()) + 1e-5, 1e-4)
+
+
+@pytest.mark.parametrize('f,k,pad', [(2, 4, 1), (4, 6, 1), (8, 10, 1), (4, 4, 0), (2, 3, 1), (4, 3, 1), (8, 2, 0)])
+@pytest.mark.parametrize('ns', [0, 3])
+def test_conv_transpose_general_stride(f, k, pad, ns):
+    """mode 1 with stride f in {2,4,8}: f*f output-parity classes in one launch == F.conv_transpose2d; classes without
+    taps (k < f) are zero-filled; accumulate=1 adds onto dst."""
+    N, Ci, Co, H, W = 2, 64, 128, 5, 7
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Ci, Co, k, k, seed=2, scale=0.1)
+    b = rnd(Co, seed=3) if k >= f else None  # kernels smaller than the stride leave pixels without taps: no bias there
+    ref = F.conv_transpose2d(x, w, b, f, pad)
+    xs = nhwc(x)
+    y = torch.full((N, ref.shape[2], ref.shape[3], Co), float('nan'), device=DEV)
+    wpk = pack(w, 1, f, ns)
+    igemm(xs, wpk, None if b is None else b.to(DEV), y, k, f, pad, 1, ns=ns)
+    report('convT s%d k%d' % (f, k), nchw(y), ref, 1e-4, 1e-4)
+    base = rnd(*ref.shape, seed=9)
+    y2 = nhwc(base)
+    igemm(xs, wpk, None, y2, k, f, pad, 1, accumulate=1, ns=ns)
+    report('convT s%d k%d accumulate' % (f, k), nchw(y2), base + F.conv_transpose2d(x, w, None, f, pad), 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('ns', [0, 3])
+def test_fpn_structured_conv_forward(ns):
+    """conv3x3 over [p2 | up2(p3) | up4(p4) | up8(p5)] == conv3x3(p2, W[:, :64]) + sum_g convT_{k=f+2, stride f, pad 1}(p_g, Wd_g),
+    with the train-mode BN statistics of the accumulated result from the last launch (segmentation_body.py:75-76,82-87)."""
+    N, H, W, Cg, Co = 2, 16, 24, 64, 256
+    ps = [rnd(N, Cg, H >> g, W >> g, seed=10 + g) for g in range(4)]
+    w = rnd(Co, 4 * Cg, 3, 3, seed=3, scale=0.03)
+    bias = rnd(Co, seed=5)
+    gamma, beta = rnd(Co, seed=6) * 0.3 + 1, rnd(Co, seed=7)
+    rm, rv = rnd(Co, seed=8), rnd(Co, seed=9).abs() + 0.5
+    cat = torch.cat([ps[0]] + [F.interpolate(ps[g], size=(H, W)) for g in range(1, 4)], 1)
+    y_ref = F.conv2d(cat, w, bias, 1, 1)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z_ref = F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    wd_ = w.to(DEV)
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV)
+    igemm(nhwc(ps[0]), pack(w[:, :Cg].contiguous(), 0, 1, ns), bias.to(DEV), y, 3, 1, 1, 0, ns=ns)
+    d = lambda t: t.clone().to(DEV)
+    g_, b_, rm_, rv_ = d(gamma), d(beta), d(rm), d(rv)
+    sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+    for g in range(1, 4):
+        f, k = 1 << g, (1 << g) + 2
+        wdg = torch.empty(Cg, Co, k, k, device=DEV)
+        _lib.check(L().dbn_fpn_combine_weights(wd_.data_ptr(), Co, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+        wpk = pack(wdg.cpu(), 1, f, ns)
+        xs = nhwc(ps[g])
+        if g < 3:
+            igemm(xs, wpk, None, y, k, f, 1, 1, accumulate=1, ns=ns)
+        else:
+            ws = torch.empty(L().dbn_conv_bn_ws_floats(N, H, W, Co, 1, f), device=DEV)
+            _lib.check(L().dbn_conv_bn_f32(xs.data_ptr(), wpk.data_ptr(), None, y.data_ptr(), N, H >> g, W >> g, Cg, H, W, Co, k, k, f, 1,
+                                           1, 1, 0, ns, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                           sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
+    report('fpn fwd y', nchw(y), y_ref, 1e-4, 1e-4)
+    report('fpn fwd running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
+    report('fpn fwd running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
+    z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
+    report('fpn fwd normalised output', z, z_ref, 2e-5, 1e-4)
