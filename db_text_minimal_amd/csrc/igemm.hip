@@ -718,18 +718,36 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
                                     int R, int S, float* __restrict__ grad, float scale) {
-    const long total = (long)O * Jp;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
+    const long total = (long)O * Jp, total4 = total >> 2;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
+        const long idx = q << 2;
+        const f32x4* src = reinterpret_cast<const f32x4*>(slab) + q;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        int z = 0;
+        for (; z + 4 <= splitk; z += 4) {
+            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + 1) * total4];
+            const f32x4 v2 = src[(long)(z + 2) * total4], v3 = src[(long)(z + 3) * total4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += ((double)v0[e] + (double)v1[e]) + ((double)v2[e] + (double)v3[e]);
+        }
+        for (; z < splitk; ++z) {
+            const f32x4 v = src[(long)z * total4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
+        }
         const int prow = (int)(idx / Jp);
-        const int pcol = (int)(idx - (long)prow * Jp);
+        const int pcol0 = (int)(idx - (long)prow * Jp);
         const int o = (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
-        const int j = (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
-        if (j >= J) continue;
-        const int tap = j / Cb, i = j - tap * Cb;
-        if (i >= I) continue;
-        double s = 0.0;
-        for (int z = 0; z < splitk; ++z) s += (double)slab[(long)z * total + idx];
-        grad[((long)o * I + i) * (R * S) + tap] = (float)(s * scale);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pcol = pcol0 + e;
+            const int j = (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
+            if (j >= J) continue;
+            const int tap = j / Cb, i = j - tap * Cb;
+            if (i >= I) continue;
+            grad[((long)o * I + i) * (R * S) + tap] = (float)(s[e] * scale);
+        }
     }
 }
 
@@ -749,30 +767,28 @@ __global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int ro
                                          const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
                                          float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int c = blockIdx.x;
     const float* pv = stats + (0L * C + c) * rows;
     const float* s1 = stats + (1L * C + c) * rows;
     const float* s2 = stats + (2L * C + c) * rows;
     const float* cn = stats + 3L * C * rows;
-    double n = 0.0, sum = 0.0;
+    // one pass: shift every tile's sums from its own pivot to the first tile's pivot P0 (exact algebra, fp64):
+    //   sum (x-P0) = s1 + n d,   sum (x-P0)^2 = s2 + 2 d s1 + n d^2,   d = pivot - P0
+    const double p0 = (double)pv[0];
+    double n = 0.0, a1 = 0.0, a2 = 0.0;
     for (int t = threadIdx.x; t < rows; t += blockDim.x) {
-        const double nt = (double)cn[t];
+        const double nt = (double)cn[t], d = (double)pv[t] - p0, t1 = (double)s1[t];
         n += nt;
-        sum += nt * (double)pv[t] + (double)s1[t];
+        a1 += t1 + nt * d;
+        a2 += (double)s2[t] + d * (2.0 * t1 + nt * d);
     }
     n = block_sum_d(n, red);
-    sum = block_sum_d(sum, red);
-    const double mean = sum / n;
-    double m2 = 0.0;
-    for (int t = threadIdx.x; t < rows; t += blockDim.x) {
-        const float ntf = cn[t];
-        const double nt = (double)ntf, inv = (double)(1.0f / ntf);  // counts are small integers: the fp32 reciprocal is ample
-        const double a1 = (double)s1[t];
-        const double dm = (double)pv[t] + a1 * inv - mean;
-        m2 += ((double)s2[t] - a1 * a1 * inv) + nt * dm * dm;
-    }
-    m2 = block_sum_d(m2, red);
+    a1 = block_sum_d(a1, red);
+    a2 = block_sum_d(a2, red);
+    const double m1 = a1 / n;
+    const double mean = p0 + m1;
+    const double m2 = a2 - a1 * m1;
     if (threadIdx.x != 0) return;
     double var = m2 / n;
     if (var < 0.0) var = 0.0;
@@ -998,7 +1014,7 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
     const int rows = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, tile_hint);
     const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
 }
@@ -1175,7 +1191,7 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
     int rc = dbn_status();
     if (rc) return rc;
     const int Jp = njt * bn;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp)), dim3(256), 0, st, slab, splitk, O, p.J, Jp, bm, bn, Cb, I, R,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splitk, O, p.J, Jp, bm, bn, Cb, I, R,
                        S, grad_oihw, scale);
     return dbn_status();
 }
