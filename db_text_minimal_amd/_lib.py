@@ -21,6 +21,8 @@ SIGNATURES = {
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
     'dbn_conv_bn_ws_floats': 'iiiiii',
+    'dbn_pyramid_conv_ws_floats': 'iiii',
+    'dbn_pyramid_conv_f32': 'p' * 10 + 'i' * 7 + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_conv_bn_f32': 'pppp' + 'i' * 15 + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_pack_weights_bf16s': 'piiiiiiipp',
     'dbn_igemm_bf16s_panel_floats': 'iiiiiii',
@@ -57,7 +59,7 @@ SIGNATURES = {
     'dbn_pixel_confusion': 'plppiiifpp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
-LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats'}
+LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

@@ -72,6 +72,10 @@ struct IgemmParams {
     unsigned src_bytes;
     // MODE 2 only: per class exclusive end of its workgroup range, first M-tile index, weight-panel offset (floats)
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
+    // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
+    const float* seg_src[4];
+    const float* seg_wpk[4];
+    unsigned seg_bytes[4];
 };
 
 constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
@@ -152,8 +156,12 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 
 // MODE 0: hs = hd*stride - pad + r (forward conv, stride 1 or 2)
 // MODE 1: hs = hd + pad - r        (stride-1 data gradient)
-// MODE 2: like MODE 1 per output-parity class, dst pixel = (2*hd+oh0, 2*wd+ow0) (stride-2 data
-//         gradient / ConvTranspose2d(k2,s2) forward)
+// MODE 2: like MODE 1 per output-parity class, dst pixel = (f*hd+oh0, f*wd+ow0) (stride-f data
+//         gradient / ConvTranspose2d forward, f = 2, 4, 8)
+// MODE 3: pyramid conv: dst = sum over levels g = 0..3 of the transposed conv (k = 2^g + 2, stride 2^g, pad 1) of
+//         seg_src[g] — a 3x3 conv over the concatenation of four nearest-upsampled maps without the
+//         concatenation.  One workgroup owns a tile of one pixel class mod 8 and walks the four levels' taps
+//         in one accumulator: K = Cs * (9 + 4 + {1,2,4} + {1,2,4}) instead of 36 * Cs.
 // The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
 // offset, for which the hardware returns zeros.
 template <int BM, int BN, int WM, int WN, int MODE, int NS>
@@ -182,7 +190,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
     IgemmClass q;
     int q_row_base = 0, q_wpk_off = 0;
-    if (MODE == 2) {
+    if (MODE == 3) {
+        q.Hd = p.Hdf >> 3; q.Wd = p.Wdf >> 3; q.M = p.N * q.Hd * q.Wd;
+        const int mtiles = (q.M + BM - 1) / BM, tpc = mtiles * (p.Cd / BN);
+        const int c = tile / tpc;
+        tile -= c * tpc;
+        q.oh0 = c >> 3; q.ow0 = c & 7;
+        q_row_base = c * mtiles;
+        q.R = q.S = q.K = q.KT = q.pad_h = q.pad_w = 0;  // per level, see level_setup
+    } else if (MODE == 2) {
         int c = 0;
         while (c + 1 < p.ncls && tile >= p.tile_end[c]) ++c;
         tile -= c ? p.tile_end[c - 1] : 0;
@@ -197,13 +213,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const int ntn = p.Cd / BN;
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int qM = q.M, qK = q.K, qKT = q.KT, qS = q.S, qHd = q.Hd, qWd = q.Wd;
+    const int qM = q.M, qHd = q.Hd, qWd = q.Wd;
+    int qK = q.K, qKT = q.KT, qS = q.S, qR = q.R;  // MODE 3 changes these (and the source) per level
+    int gHs = p.Hs, gWs = p.Ws;
 
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
 
     // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
     const int a_chunk = tid & 3;
     int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
+    int a_n[MODE == 3 ? A_LD : 1], a_hd[MODE == 3 ? A_LD : 1], a_wd[MODE == 3 ? A_LD : 1];
     const int HWd = qHd * qWd;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
@@ -216,7 +235,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         const int hd = rem / qWd;
         const int wd = rem - hd * qWd;
         a_nb[j] = n * p.Hs * p.Ws * p.Cs;
-        if (MODE == 0) {
+        if (MODE == 3) {
+            a_n[j] = n;
+            a_hd[j] = ok ? hd : -(1 << 20);
+            a_wd[j] = wd;
+        } else if (MODE == 0) {
             a_hb[j] = ok ? hd * p.stride - q.pad_h : -(1 << 20);  // a far-away row can never be in range
             a_wb[j] = wd * p.stride - q.pad_w;
         } else {
@@ -242,7 +265,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         k_r = k_tap / qS;
         k_s = k_tap - k_r * qS;
     }
-    const int qR = q.R;
 
     unsigned aoff[A_LD];
     auto next_offsets = [&]() {  // offsets of the current k position, then advance by one tile (16 k)
@@ -250,8 +272,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         for (int j = 0; j < A_LD; ++j) {
             const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
             const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
-            const bool v = kidx < qK && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-            const unsigned off = (unsigned)(a_nb[j] + (hs * p.Ws + ws) * p.Cs + k_ci) * 4u;
+            const bool v = kidx < qK && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * 4u;
             aoff[j] = v ? off : OOB_OFFSET;
         }
         kidx += 16;
@@ -277,14 +299,43 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const f32x4* bptr[B_LD];
     int b_lds[B_LD];
     bool b_on[B_LD];
+    auto panel_setup = [&](const float* panel) {
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-        const int idx = tid + j * NT;
-        b_on[j] = B_FULL || idx < B_PIECES;
-        const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
-        bptr[j] = reinterpret_cast<const f32x4*>(p.wpk + q_wpk_off) + (long)c * p.Cd + n0 + n;
-        b_lds[j] = c * BS + n;
-    }
+        for (int j = 0; j < B_LD; ++j) {
+            const int idx = tid + j * NT;
+            b_on[j] = B_FULL || idx < B_PIECES;
+            const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
+            bptr[j] = reinterpret_cast<const f32x4*>(panel) + (long)c * p.Cd + n0 + n;
+            b_lds[j] = c * BS + n;
+        }
+    };
+    if (MODE != 3) panel_setup(p.wpk + q_wpk_off);
+    // MODE 3: source, tap geometry and weight panel of pyramid level g for this tile's pixel class
+    auto level_setup = [&](int g) {
+        const int f = 1 << g, kk = f + 2;
+        const int oh0g = q.oh0 & (f - 1), ow0g = q.ow0 & (f - 1);
+        const int ph = (oh0g + 1) & (f - 1), pw = (ow0g + 1) & (f - 1);
+        qR = taps_of_class(kk, ph, f);
+        qS = taps_of_class(kk, pw, f);
+        const int padh = (oh0g + 1 - ph) >> g, padw = (ow0g + 1 - pw) >> g;
+        qK = qR * qS * p.Cs;
+        qKT = qK >> 4;
+        gHs = p.Hdf >> g;
+        gWs = p.Wdf >> g;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        long krows = 0;  // padded-K rows of the classes packed before (ph, pw)
+        for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
+        panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2));
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            a_nb[j] = a_n[MODE == 3 ? j : 0] * gHs * gWs * p.Cs;
+            a_hb[j] = a_hd[MODE == 3 ? j : 0] * (8 >> g) + (q.oh0 >> g) + padh;
+            a_wb[j] = a_wd[MODE == 3 ? j : 0] * (8 >> g) + (q.ow0 >> g) + padw;
+        }
+        kidx = 4 * a_chunk;
+        k_ci = 4 * a_chunk;
+        k_r = k_s = 0;
+    };
     const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
 
     f32x4 ra[A_LD], rb[B_LD];
@@ -328,6 +379,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
+    if (MODE == 3) level_setup(level);
     next_offsets();
     issue_loads();
     next_offsets();  // offsets of tile 1
@@ -377,12 +430,13 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
+    }
 
     // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
     // statistics below and the store loop both see the final values
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
     auto dst_offset = [&](int row) -> long {
-        if (MODE == 2) {  // the parity class's pixels of the full-resolution output
+        if (MODE >= 2) {  // the parity class's pixels of the full-resolution output
             int n, rem, hd, wd;
             divmod24(row, HWd, rcp_hw, n, rem);
             divmod24(rem, qWd, rcp_w, hd, wd);
@@ -479,7 +533,10 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     int grid = 0, rows = 0;
-    if (mode == 2) {
+    if (mode == 3) {
+        rows = 64 * dbn_ceil_div(p.N * (p.Hdf >> 3) * (p.Wdf >> 3), BM);
+        grid = rows * (p.Cd / BN);
+    } else if (mode == 2) {
         for (int c = 0; c < p.ncls; ++c) {
             const IgemmClass q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
             const int mtiles = (q.K > 0 && q.M > 0) ? dbn_ceil_div(q.M, BM) : 0;
@@ -498,8 +555,12 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
-    else
+    else if (mode == 2)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else if constexpr (BM == 128 && BN == 128)  // the pyramid conv is built for the 128x128 tile only
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 3, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else
+        return DBN_ERR_ARG;
     return dbn_status();
 }
 
@@ -809,9 +870,36 @@ __global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int ro
 // OIHW -> [Kpad/4][Cd][4] panels.  mode 0: k = (r*S+s)*Cs + cs -> w[cd][cs][r][s] (cs < I);
 // mode 1: data-gradient panels, taps r = r0 + rstep*r', s = s0 + rstep*s' (R', S' of them):
 //         k = (r'*S'+s')*Cs + cs -> w[cs][cd][r][s].
-__global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int K,
-                                    int Kpad, int Rp, int Sp, int r0, int s0, int rstep, float* __restrict__ out) {
-    const long total = (long)Kpad * Cd;
+// Problem of one block row of a pack launch: the whole kernel (f == 1), or parity class blockIdx.y of a stride-f
+// transposed conv — its taps r = ph + f*rp and the offset (in padded-K rows) of its panel behind the earlier classes.
+struct PackClass {
+    int Rp, Sp, r0, s0, rstep, K, Kpad;
+    long krow0;
+};
+__device__ inline PackClass pack_class(int f, int R, int S, int Cs) {
+    PackClass q;
+    q.krow0 = 0;
+    if (f <= 1) {
+        q.Rp = R; q.Sp = S; q.r0 = q.s0 = 0; q.rstep = 1;
+    } else {
+        const int c = blockIdx.y;
+        for (int d = 0; d < c; ++d)
+            q.krow0 += (taps_of_class(R, d / f, f) * taps_of_class(S, d % f, f) * Cs + 15) / 16 * 16;
+        q.r0 = c / f; q.s0 = c % f; q.rstep = f;
+        q.Rp = taps_of_class(R, q.r0, f);
+        q.Sp = taps_of_class(S, q.s0, f);
+    }
+    q.K = q.Rp * q.Sp * Cs;
+    q.Kpad = (q.K + 15) / 16 * 16;
+    return q;
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int f,
+                                    float* __restrict__ out) {
+    const PackClass q = pack_class(f, R, S, Cs);
+    const int K = q.K, Rp = q.Rp, Sp = q.Sp, r0 = q.r0, s0 = q.s0, rstep = q.rstep;
+    out += q.krow0 * Cd;
+    const long total = (long)q.Kpad * Cd;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 3);
         const long qd = idx >> 2;
@@ -843,10 +931,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
 
 // Split-bf16 weight panels for the NS > 0 kernels: [KT][NS][2][Cd][8 bf16]; element (k, cd, split t)
 // at ((kt*NS + t)*2 + k8)*Cd*8 + cd*8 + e with k = 16*kt + 8*k8 + e.  Same (mode, tap subset) semantics as above.
-__global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int K,
-                                          int Kpad, int Rp, int Sp, int r0, int s0, int rstep, int NS,
-                                          unsigned short* __restrict__ out) {
-    const long total = (long)Kpad * Cd;
+__global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int f,
+                                          int NS, unsigned short* __restrict__ out) {
+    const PackClass q = pack_class(f, R, S, Cs);
+    const int K = q.K, Rp = q.Rp, Sp = q.Sp, r0 = q.r0, s0 = q.s0, rstep = q.rstep;
+    out += q.krow0 * Cd * NS;
+    const long total = (long)q.Kpad * Cd;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7);
         const long qd = idx >> 3;
@@ -1031,8 +1121,45 @@ int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float
 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
+// ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
+static int pyramid_rows(int N, int H, int W) { return 64 * dbn_ceil_div((long)N * (H >> 3) * (W >> 3), 128); }
+
+long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * pyramid_rows(N, H, W); }
+
+int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
+                         const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                         int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                         float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
+    DBN_REQUIRE((long)N * H * W < (1L << 24) && (long)N * H * W * Cs * 4 < 0xF0000000L);
+    DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
+    const bool bn = gamma != nullptr;
+    DBN_REQUIRE(!bn || (beta && scale && shift && save_mean && save_rstd && ws));
+    IgemmParams p;
+    const float* srcs[4] = {s0, s1, s2, s3};
+    const float* wpks[4] = {w0, w1, w2, w3};
+    for (int g = 0; g < 4; ++g) {
+        p.seg_src[g] = srcs[g];
+        p.seg_wpk[g] = wpks[g];
+        p.seg_bytes[g] = (unsigned)((long)N * (H >> g) * (W >> g) * Cs * 4);
+    }
+    p.src = s0; p.wpk = w0; p.bias = bias; p.dst = dst;
+    p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
+    p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
+    p.stats = bn ? ws : nullptr;
+    p.stat_rows = 0;
+    p.src_bytes = p.seg_bytes[0];
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st);
+    if (rc || !bn) return rc;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(p.stat_rows >= 2048 ? 1024 : 256), 0, st, ws, p.stat_rows, Cd, gamma,
+                       beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
+}
+
 // Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
-// mode 1/stride 2 -> four parity-class panels back to back.
+// mode 1/stride f -> f*f parity-class panels back to back.
 static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, int ns) {
     if (mode == 0) return panel_floats(R * S * ((I + 3) / 4 * 4), O, ns);
     if (stride == 1) return panel_floats(R * S * O, I, ns);
@@ -1042,27 +1169,9 @@ static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, i
     return tot;
 }
 
-// Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
-// mode 1/stride 2 -> four parity-class panels back to back.
 long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride) { return panel_floats_all(O, I, R, S, mode, stride, 0); }
 long dbn_igemm_bf16s_panel_floats(int O, int I, int R, int S, int mode, int stride, int ns) {
     return panel_floats_all(O, I, R, S, mode, stride, ns);
-}
-
-static int pack_one(const float* w, int O, int I, int R, int S, int mode, int Rp, int Sp, int r0, int s0, int rstep, int ns,
-                    float* out, hipStream_t st) {
-    const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
-    const int Cd = (mode == 0) ? O : I;
-    const int K = Rp * Sp * Cs, Kpad = ((K + 15) / 16) * 16;
-    const long total = (long)Kpad * Cd;
-    if (total == 0) return DBN_OK;
-    if (ns == 0)
-        hipLaunchKernelGGL(pack_weights_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad, Rp,
-                           Sp, r0, s0, rstep, out);
-    else
-        hipLaunchKernelGGL(pack_weights_bf16s_kernel, dim3(dbn_grid(total)), dim3(256), 0, st, w, O, I, R, S, mode, Cs, Cd, K, Kpad,
-                           Rp, Sp, r0, s0, rstep, ns, reinterpret_cast<unsigned short*>(out));
-    return dbn_status();
 }
 
 static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
@@ -1072,16 +1181,17 @@ static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, i
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 0 || stride == 1) return pack_one(w_oihw, O, I, R, S, mode, R, S, 0, 0, 1, ns, out, st);
-    long off = 0;
-    for (int c = 0; c < stride * stride; ++c) {  // same class order and offsets as igemm_run
-        const int ph = c / stride, pw = c % stride;
-        const int Rc = taps_of_class(R, ph, stride), Sc = taps_of_class(S, pw, stride);
-        const int rc = pack_one(w_oihw, O, I, R, S, 1, Rc, Sc, ph, pw, stride, ns, out + off, st);
-        if (rc) return rc;
-        off += panel_floats(Rc * Sc * O, I, ns);
-    }
-    return DBN_OK;
+    // one launch; a strided transposed conv packs its stride^2 parity classes as block rows (class order and
+    // panel offsets as in igemm_run)
+    const int f = (mode == 1 && stride > 1) ? stride : 1;
+    const long total = (long)(((dbn_ceil_div(R, f) * dbn_ceil_div(S, f) * Cs + 15) / 16) * 16) * Cd;  // largest class
+    const dim3 grid(dbn_grid(total, 256, f > 2 ? 64 : 1024), f * f);
+    if (ns == 0)
+        hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, out);
+    else
+        hipLaunchKernelGGL(pack_weights_bf16s_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, ns,
+                           reinterpret_cast<unsigned short*>(out));
+    return dbn_status();
 }
 
 int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, float* out, void* stream) {

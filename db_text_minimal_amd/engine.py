@@ -644,6 +644,7 @@ class Engine:
         self.saved_generation = -1
 
     fpn_structured = True  # FPN output conv per upsample level (forward and backward) instead of over the concat
+    fpn_one_launch = True  # forward: the four levels in one launch (dbn_pyramid_conv_f32) instead of four accumulating ones
     fpn_exact = False  # set by forward(): the levels are exact 1, 1/2, 1/4, 1/8 sizes, so the structured path applies
 
     def _fpn_combined_weights(self, name, conv, Cg):
@@ -667,6 +668,29 @@ class Engine:
         y = self.buf(out_name, N, H, W, Co)
         fused = train and self.fuse_bn_stats
         sc = sh = None
+        if self.fpn_one_launch and Co % 128 == 0 and Cg % 16 == 0:
+            # all four levels in one launch: one accumulator per output tile, no read-modify-write of y
+            wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
+            flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
+            if self.prof:
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d>' % self.ns, flops, 0.0, 'fwd %s (pyramid)' % name)
+            if fused:
+                C = Co
+                sc, sh = self.buf(bn_name + '/scale', C), self.buf(bn_name + '/shift', C)
+                mu, rs = self.buf(bn_name + '/mean', C), self.buf(bn_name + '/rstd', C)
+                ws = self.scratch('_conv_bn_ws', self.L.dbn_pyramid_conv_ws_floats(N, H, W, Co))
+                bnargs = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr())
+                self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
+            else:
+                bnargs = (None, None, 0.0, 0.0) + (None, ) * 7
+            check(self.L.dbn_pyramid_conv_f32(*[z.data_ptr() for z in zs], *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
+                                              N, H, W, Cg, Co, 0, self.ns, *bnargs, self.stream), 'pyramid_conv')
+            if self.prof:
+                self.prof.end()
+            if not fused:
+                sc, sh = self.bn_coef(bn_name, bn, y, train)
+            return y, sc, sh
         for g, z in enumerate(zs):
             f, k = 1 << g, (1 << g) + 2
             Hg, Wg = z.shape[1], z.shape[2]

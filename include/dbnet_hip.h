@@ -64,6 +64,19 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
                     const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                     float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
 
+/* Pyramid conv — the FPN output conv of segmentation_body.py:75-76 over torch.cat([p2, up2(p3), up4(p4), up8(p5)])
+ * (segmentation_body.py:82-87) without building the concatenation:
+ *   dst[N,H,W,Cd] = bias + sum_{g=0..3} ConvTranspose2d(k = 2^g + 2, stride 2^g, padding 1)(s_g),  s_g: [N, H>>g, W>>g, Cs]
+ * with combined weights from dbn_fpn_combine_weights (level g: [Cs][Cd][k][k]) packed by dbn_pack_weights(mode 1,
+ * stride 2^g) into w_g.  One launch; H, W multiples of 8, Cs % 16 == 0, Cd % 128 == 0.  gamma != NULL additionally produces the
+ * train-mode BatchNorm coefficients of dst exactly like dbn_conv_bn_f32 (ws: dbn_pyramid_conv_ws_floats floats).
+ * tile_hint: 0 | 1 (128x128 is the only tile). */
+long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd);
+int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
+                         const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                         int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                         float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
+
 /* tile configuration chosen for tile_hint 0: 1=128x128, 2=256x64, 3=128x64, 4=64x64 */
 int dbn_igemm_tile_config(int M, int Cd);
 

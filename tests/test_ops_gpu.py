@@ -502,3 +502,44 @@ def test_fpn_structured_conv_forward(ns):
     report('fpn fwd running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
     z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
     report('fpn fwd normalised output', z, z_ref, 2e-5, 1e-4)
+
+
+@pytest.mark.parametrize('ns', [0, 3])
+@pytest.mark.parametrize('shape', [(2, 16, 24, 64, 256), (1, 8, 8, 64, 128), (3, 40, 8, 32, 128)])
+@pytest.mark.parametrize('bn', [False, True])
+def test_pyramid_conv(shape, ns, bn):
+    """dbn_pyramid_conv_f32 (one launch, no concat) == F.conv2d(torch.cat([p2, up2(p3), up4(p4), up8(p5)]), W, b, 1, 1)
+    (+ train-mode BatchNorm coefficients / running statistics) — segmentation_body.py:75-76,82-87."""
+    N, H, W, Cg, Co = shape
+    ps = [rnd(N, Cg, H >> g, W >> g, seed=10 + g) for g in range(4)]
+    w = rnd(Co, 4 * Cg, 3, 3, seed=3, scale=0.03)
+    bias = rnd(Co, seed=5)
+    gamma, beta = rnd(Co, seed=6) * 0.3 + 1, rnd(Co, seed=7)
+    rm, rv = rnd(Co, seed=8), rnd(Co, seed=9).abs() + 0.5
+    cat = torch.cat([ps[0]] + [F.interpolate(ps[g], size=(H, W)) for g in range(1, 4)], 1)
+    y_ref = F.conv2d(cat, w, bias, 1, 1)
+    wd_ = w.to(DEV)
+    wpk = []
+    for g in range(4):
+        k = (1 << g) + 2
+        wdg = torch.empty(Cg, Co, k, k, device=DEV)
+        _lib.check(L().dbn_fpn_combine_weights(wd_.data_ptr(), Co, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+        wpk.append(pack(wdg.cpu(), 1, 1 << g, ns))
+    xs = [nhwc(t) for t in ps]
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV)
+    d = lambda t: t.clone().to(DEV)
+    g_, b_, rm_, rv_, bias_ = d(gamma), d(beta), d(rm), d(rv), d(bias)
+    sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+    ws = torch.empty(L().dbn_pyramid_conv_ws_floats(N, H, W, Co), device=DEV)
+    bnargs = (g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+              rs.data_ptr(), ws.data_ptr()) if bn else (None, None, 0.0, 0.0) + (None, ) * 7
+    _lib.check(L().dbn_pyramid_conv_f32(*[t.data_ptr() for t in xs], *[t.data_ptr() for t in wpk], bias_.data_ptr(), y.data_ptr(), N, H,
+                                        W, Cg, Co, 0, ns, *bnargs, stream()), 'pyramid_conv')
+    report('pyramid conv y', nchw(y), y_ref, 1e-4, 1e-4)
+    if bn:
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        z_ref = F.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+        report('pyramid running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
+        report('pyramid running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
+        z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
+        report('pyramid normalised output', z, z_ref, 2e-5, 1e-4)
