@@ -72,6 +72,8 @@ struct IgemmParams {
     unsigned src_bytes;
     // MODE 2 only: per class exclusive end of its workgroup range, first M-tile index, weight-panel offset (floats)
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
+    // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
+    int ksplit, kt_per;
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
     const float* seg_src[4];
     const float* seg_wpk[4];
@@ -255,10 +257,17 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     const bool blocked = (p.Cs & 15) == 0;
     int kidx = 4 * a_chunk;
     int k_ci, k_r, k_s;
-    if (blocked) {
-        k_ci = 4 * a_chunk;
-        k_r = 0;
-        k_s = 0;
+    int kt_begin = 0, kt_end = qKT;
+    if (MODE < 2 && p.ksplit > 1) {
+        kt_begin = blockIdx.y * p.kt_per;
+        kt_end = min(qKT, kt_begin + p.kt_per);
+    }
+    if (blocked) {  // k-tile kt is tap (kt % RS) of channel block (kt / RS)
+        const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
+        kidx += 16 * kt_begin;
+        k_ci = 16 * cb + 4 * a_chunk;
+        k_r = tap / qS;
+        k_s = tap - k_r * qS;
     } else {
         const int k_tap = kidx / p.Cs;
         k_ci = kidx - k_tap * p.Cs;
@@ -309,7 +318,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             b_lds[j] = c * BS + n;
         }
     };
-    if (MODE != 3) panel_setup(p.wpk + q_wpk_off);
+    const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
+    if (MODE != 3) {
+        panel_setup(p.wpk + q_wpk_off);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) bptr[j] += kt_begin * b_step;
+    }
     // MODE 3: source, tap geometry and weight panel of pyramid level g for this tile's pixel class
     auto level_setup = [&](int g) {
         const int f = 1 << g, kk = f + 2;
@@ -336,7 +350,6 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         k_ci = 4 * a_chunk;
         k_r = k_s = 0;
     };
-    const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
 
     f32x4 ra[A_LD], rb[B_LD];
     auto issue_loads = [&]() {
@@ -380,16 +393,19 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
-    if (MODE == 3) level_setup(level);
+    if (MODE == 3) {
+        level_setup(level);
+        kt_end = qKT;
+    }
     next_offsets();
     issue_loads();
     next_offsets();  // offsets of tile 1
     stage(0);
     __syncthreads();
 
-    for (int kt = 0; kt < qKT; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < qKT;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
         if (more) issue_loads();  // tile kt+1 in flight under the MFMAs of tile kt
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
@@ -434,6 +450,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 
     // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
     // statistics below and the store loop both see the final values
+    float* const dstp = (MODE < 2 && p.ksplit > 1) ? p.dst + (long)blockIdx.y * qM * p.Cd : p.dst;
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
     auto dst_offset = [&](int row) -> long {
         if (MODE >= 2) {  // the parity class's pixels of the full-resolution output
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
                 if (row < qM) {
                     const long doff = dst_offset(row);
 #pragma unroll
-                    for (int b = 0; b < NI; ++b) acc[a][b][r] += p.dst[doff + n0 + wn * TN + b * 32 + li];
+                    for (int b = 0; b < NI; ++b) acc[a][b][r] += dstp[doff + n0 + wn * TN + b * 32 + li];
                 }
             }
     }
@@ -523,7 +540,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
 #pragma unroll
                 for (int b = 0; b < NI; ++b) {
                     const int col = n0 + wn * TN + b * 32 + li;
-                    p.dst[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
+                    dstp[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
                 }
             }
         }
@@ -551,10 +568,11 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     }
     p.stat_rows = rows;
     if (grid == 0) return DBN_OK;
+    const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
     if (mode == 0)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 2)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if constexpr (BM == 128 && BN == 128)  // the pyramid conv is built for the 128x128 tile only
@@ -870,6 +888,20 @@ __global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int ro
 // OIHW -> [Kpad/4][Cd][4] panels.  mode 0: k = (r*S+s)*Cs + cs -> w[cd][cs][r][s] (cs < I);
 // mode 1: data-gradient panels, taps r = r0 + rstep*r', s = s0 + rstep*s' (R', S' of them):
 //         k = (r'*S'+s')*Cs + cs -> w[cs][cd][r][s].
+// dst = [dst +] bias + sum over the split-K slabs, fixed order
+__global__ void splitk_sum_kernel(const float* __restrict__ slab, int splits, long total4, int Cd, const float* __restrict__ bias,
+                                  int accumulate, float* __restrict__ dst) {
+    const int c4n = Cd >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
+        f32x4 v = src[0];
+        for (int z = 1; z < splits; ++z) v += src[(long)z * total4];
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * (int)(i % c4n));
+        if (accumulate) v += reinterpret_cast<const f32x4*>(dst)[i];
+        reinterpret_cast<f32x4*>(dst)[i] = v;
+    }
+}
+
 // Problem of one block row of a pack launch: the whole kernel (f == 1), or parity class blockIdx.y of a stride-f
 // transposed conv — its taps r = ph + f*rp and the offset (in padded-K rows) of its panel behind the earlier classes.
 struct PackClass {
@@ -1021,7 +1053,7 @@ static long panel_floats(int K, int Cd, int ns) {
 
 static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                     void* stream, float* stats = nullptr) {
+                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
@@ -1033,11 +1065,25 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.stats = stats; p.stat_rows = 0;
+    p.ksplit = 1; p.kt_per = 0;
     p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
     if (!(mode == 1 && stride > 1)) {
         p.ncls = 1;
-        return igemm_dispatch(p, mode, ns, tile_hint, st);
+        if (ksplit <= 1) return igemm_dispatch(p, mode, ns, tile_hint, st);
+        // split-K: slabs of partial sums, then a fixed-order reduction that also applies bias / accumulate
+        const int KT = (R * S * Cs + 15) / 16;
+        DBN_REQUIRE(slab && !stats && Cs % 16 == 0 && ksplit <= KT && ksplit <= 64);
+        p.kt_per = dbn_ceil_div(KT, ksplit);
+        p.ksplit = dbn_ceil_div(KT, p.kt_per);
+        p.dst = slab; p.bias = nullptr; p.accumulate = 0;
+        const int rc = igemm_dispatch(p, mode, ns, tile_hint, st);
+        if (rc) return rc;
+        const long total4 = (long)N * Hd * Wd * Cd / 4;
+        hipLaunchKernelGGL(splitk_sum_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit, total4, Cd, bias, accumulate,
+                           dst);
+        return dbn_status();
     }
+    DBN_REQUIRE(ksplit <= 1);
     // stride-f data gradient / transposed conv: one problem per output parity class
     p.ncls = stride * stride;
     long off = 0;
@@ -1119,6 +1165,36 @@ int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream);
 }
 
+// Split-K plan for a conv whose output grid alone cannot fill the chip (few pixels x few channels, long reduction —
+// the coarse FPN levels' data gradients): number of K splits (1 = none) for M rows, Cd channels, K = R*S*Cs.
+int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) {
+    if (Cs % 16 != 0) return 1;
+    const int cfg0 = dbn_igemm_tile_config(M, Cd);
+    const int cfg = (cfg0 == 1 && Cd % 128 != 0) ? 3 : cfg0;
+    static const int bm_of[5] = {0, 128, 256, 128, 64}, bn_of[5] = {0, 128, 64, 64, 64};
+    const long tiles = (long)dbn_ceil_div(M, bm_of[cfg]) * (Cd / bn_of[cfg]);
+    const int KT = (K + 15) / 16;
+    static int max_tiles = -1;
+    if (max_tiles < 0) {
+        const char* e = getenv("DBN_SPLITK_MAX_TILES");
+        max_tiles = e ? atoi(e) : 256;
+    }
+    if (tiles > max_tiles) return 1;
+    long sk = 1024 / tiles;      // about four workgroups per CU
+    if (sk > KT / 32) sk = KT / 32;  // at least 32 k-tiles per split
+    if (sk > 64) sk = 64;
+    return sk < 2 ? 1 : (int)sk;
+}
+
+// dbn_igemm_f32 with the reduction split `ksplit` ways (mode 0, or mode 1 with stride 1; Cs % 16 == 0).
+// slab: ksplit * N*Hd*Wd*Cd floats of scratch.  Bit-reproducible (fixed summation order).
+int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                         int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                         int ksplit, float* slab, void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream,
+                     nullptr, ksplit, slab);
+}
+
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
 // ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
@@ -1149,6 +1225,7 @@ int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, cons
     p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
     p.stats = bn ? ws : nullptr;
     p.stat_rows = 0;
+    p.ksplit = 1; p.kt_per = 0;
     p.src_bytes = p.seg_bytes[0];
     hipStream_t st = (hipStream_t)stream;
     const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st);

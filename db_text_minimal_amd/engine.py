@@ -232,6 +232,13 @@ class Engine:
 
     def _igemm(self, what, *args):
         """args = the dbn_igemm_f32 argument list without the trailing stream."""
+        N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
+        if self.splitk and (mode == 0 or stride == 1):
+            ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
+            if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
+                slab = self.scratch('_splitk_slab', ks * N * Hd * Wd * Cd)
+                check(self.L.dbn_igemm_splitk_f32(*args, self.ns, ks, slab.data_ptr(), self.stream), what)
+                return
         if self.ns == 0:
             check(self.L.dbn_igemm_f32(*args, self.stream), what)
         else:
@@ -253,6 +260,7 @@ class Engine:
             self.prof.end()
         return y
 
+    splitk = True  # split the reduction of convs with few output tiles (dbn_igemm_splitk_plan)
     fuse_bn_stats = True  # accumulate train-mode BN statistics in the conv epilogue (no separate statistics pass)
 
     def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride, accumulate=0):
@@ -270,13 +278,14 @@ class Engine:
 
     def conv_bn(self, name, x, conv, out_name, bn_name, bn, train):
         """conv -> BatchNorm coefficients.  Train mode: one fused call (statistics in the conv epilogue)."""
-        if not (train and self.fuse_bn_stats):
-            y = self.conv_fwd(name, x, conv, out_name)
-            sc, sh = self.bn_coef(bn_name, bn, y, train)
-            return y, sc, sh
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        split = self.splitk and self.L.dbn_igemm_splitk_plan(N * Ho * Wo, conv.cout, k * k * C, C) > 1
+        if not (train and self.fuse_bn_stats) or split:  # split-K convs take their statistics in a (small) separate pass
+            y = self.conv_fwd(name, x, conv, out_name)
+            sc, sh = self.bn_coef(bn_name, bn, y, train)
+            return y, sc, sh
         assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
         wpk = self.pack(name, conv.weight, 0)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)

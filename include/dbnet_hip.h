@@ -64,6 +64,17 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
                     const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                     float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
 
+/* Split-K variant of dbn_igemm_f32 / dbn_igemm_bf16s (ns selects the math) for convs whose output grid cannot fill
+ * 256 CUs but whose reduction is long (the coarse FPN levels' data gradients: 6400 pixels x 64 channels, K = 25600):
+ * `ksplit` workgroup rows each reduce a contiguous range of k-tiles into their own slab, a second kernel sums the
+ * slabs in fixed order and applies bias / accumulate.  mode 0, or mode 1 with stride 1; Cs % 16 == 0.
+ * dbn_igemm_splitk_plan returns the split count the library would pick (1 = do not split);
+ * slab: ksplit * N*Hd*Wd*Cd floats. */
+int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs);
+int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                         int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                         int ksplit, float* slab, void* stream);
+
 /* Pyramid conv — the FPN output conv of segmentation_body.py:75-76 over torch.cat([p2, up2(p3), up4(p4), up8(p5)])
  * (segmentation_body.py:82-87) without building the concatenation:
  *   dst[N,H,W,Cd] = bias + sum_{g=0..3} ConvTranspose2d(k = 2^g + 2, stride 2^g, padding 1)(s_g),  s_g: [N, H>>g, W>>g, Cs]

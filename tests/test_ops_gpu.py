@@ -543,3 +543,39 @@ def test_pyramid_conv(shape, ns, bn):
         report('pyramid running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
         z = nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1)
         report('pyramid normalised output', z, z_ref, 2e-5, 1e-4)
+
+
+@pytest.mark.parametrize('case', [(2, 256, 64, 10, 8, 1, 40, 40, 0), (2, 256, 64, 6, 4, 1, 24, 40, 0), (1, 512, 512, 3, 1, 1, 10, 12, 0),
+                                  (2, 128, 64, 3, 1, 1, 9, 7, 1), (1, 64, 64, 3, 2, 1, 17, 15, 0)])
+@pytest.mark.parametrize('ksplit', [2, 5, 7])
+@pytest.mark.parametrize('ns', [0, 3])
+def test_conv_splitk(case, ksplit, ns):
+    """dbn_igemm_splitk_f32 (reduction split over workgroup rows + fixed-order slab sum, bias, accumulate) == F.conv2d /
+    its data gradient; equals the unsplit kernel to rounding."""
+    N, Ci, Co, k, s, p, H, W, mode = case
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(mode == 1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(1.0 / (Ci * k * k))**0.5)
+    b = rnd(Co, seed=3)
+    if mode == 0:
+        ref = F.conv2d(x, w, b, s, p)
+        src, wpk, bias, Cd = nhwc(x.detach()), pack(w, 0, s, ns), b.to(DEV), Co
+    else:
+        y = F.conv2d(x, w, None, s, p)
+        dy = rnd(*y.shape, seed=4)
+        (ref, ) = torch.autograd.grad(y, x, dy)
+        src, wpk, bias, Cd = nhwc(dy), pack(w, 1, s, ns), None, Ci
+    base = rnd(*ref.shape, seed=9)
+    dst = nhwc(base)
+    Nn, Hs, Ws, Cs = src.shape
+    _, Hd, Wd, _ = dst.shape
+    slab = torch.full((ksplit * dst.numel(), ), float('nan'), device=DEV)
+    _lib.check(L().dbn_igemm_splitk_f32(src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(), Nn, Hs,
+                                        Ws, Cs, Hd, Wd, Cd, k, k, s, p, mode, 1, 0, ns, ksplit, slab.data_ptr(), stream()), 'splitk')
+    report('splitk conv %s ks=%d' % (case, ksplit), nchw(dst), base + ref.detach(), 1e-4, 1e-4)
+
+
+def test_splitk_plan():
+    plan = L().dbn_igemm_splitk_plan
+    assert plan(16 * 20 * 20, 64, 100 * 256, 256) > 1  # FPN level-3 data gradient: 100 tiles, K = 25600
+    assert plan(16 * 160 * 160, 256, 2304, 256) == 1  # plenty of tiles
+    assert plan(16 * 20 * 20, 64, 100 * 4, 4) == 1  # K order of thin inputs is not splittable
