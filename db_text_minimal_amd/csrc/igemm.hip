@@ -194,9 +194,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
     int q_row_base = 0, q_wpk_off = 0;
     if (MODE == 3) {
         q.Hd = p.Hdf >> 3; q.Wd = p.Wdf >> 3; q.M = p.N * q.Hd * q.Wd;
-        const int mtiles = (q.M + BM - 1) / BM, tpc = mtiles * (p.Cd / BN);
-        const int c = tile / tpc;
-        tile -= c * tpc;
+        // tile order: m-tile major, pixel class minor — the 64 classes of one image region run together, so their
+        // overlapping 3x3 neighbourhoods of the finest level are served by the L2 instead of 9 trips to HBM
+        const int mtiles = (q.M + BM - 1) / BM, ntn_ = p.Cd / BN;
+        const int mt_ = tile / (64 * ntn_), rem_ = tile - mt_ * (64 * ntn_);
+        const int c = rem_ / ntn_;
+        tile = mt_ * ntn_ + (rem_ - c * ntn_);
         q.oh0 = c >> 3; q.ow0 = c & 7;
         q_row_base = c * mtiles;
         q.R = q.S = q.K = q.KT = q.pad_h = q.pad_w = 0;  // per level, see level_setup
