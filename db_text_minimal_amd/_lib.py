@@ -23,6 +23,8 @@ SIGNATURES = {
     'dbn_conv_bn_ws_floats': 'iiiiii',
     'dbn_igemm_splitk_plan': 'iiii',
     'dbn_igemm_splitk_f32': 'pppp' + 'i' * 16 + 'pp',
+    'dbn_binarize_u8': 'piiiifpp',
+    'dbn_box_scores': 'piipiipp',
     'dbn_pyramid_conv_ws_floats': 'iiii',
     'dbn_pyramid_conv_f32': 'p' * 10 + 'i' * 7 + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_conv_bn_f32': 'pppp' + 'i' * 15 + 'pp' + 'ff' + 'ppppppp' + 'p',

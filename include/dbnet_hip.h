@@ -180,6 +180,15 @@ int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, 
 int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
 
+/* ---- array work of SegDetectorRepresenter ahead of the (host, unchanged) OpenCV contour code ---- */
+/* postprocess.py:51-52 `pred > thresh` on channel 0 of pred[N][channels][H][W], as a uint8 {0,1} bitmap out[N][H][W]
+ * (H*W % 4 == 0): the D2H copy the contour tracer needs shrinks 4x. */
+int dbn_binarize_u8(const float* pred, int N, int channels, int H, int W, float thresh, unsigned char* out, void* stream);
+/* postprocess.py:186-198 box_score_fast for K boxes at once: scores[k] = mean of bitmap[H][W] over the cv2.fillPoly
+ * mask of boxes[k][P][2] (x, y; float, as produced by get_mini_boxes / approxPolyDP), P <= 64.  Polygons with fewer
+ * vertices are padded by repeating the last vertex. */
+int dbn_box_scores(const float* bitmap, int H, int W, const float* boxes, int K, int P, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
