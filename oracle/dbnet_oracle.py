@@ -48,31 +48,57 @@ def _bn_entries(prefix, c):
     ]
 
 
-def state_spec():
+ARCHS = {  # name -> (block, layers, dcn) — resnet.py:245-306; models.py:8 registers only resnet18 (SURVEY A4')
+    'resnet18': ('basic', (2, 2, 2, 2), False),
+    'deformable_resnet18': ('basic', (2, 2, 2, 2), True),
+    'resnet50': ('bottleneck', (3, 4, 6, 3), False),
+    'deformable_resnet50': ('bottleneck', (3, 4, 6, 3), True),
+}
+
+
+def backbone_out_channels(arch='resnet18'):
+    e = 1 if ARCHS[arch][0] == 'basic' else 4
+    return [64 * e, 128 * e, 256 * e, 512 * e]
+
+
+def state_spec(arch='resnet18'):
     """[(key, shape, kind)] in the reference's state_dict order."""
+    block, layers, dcn = ARCHS[arch]
+    exp = 1 if block == 'basic' else 4
     s = []
     s.append(('backbone.conv1.weight', (64, 3, 7, 7), 'conv_w'))
     s += _bn_entries('backbone.bn1', 64)
     inpl = 64
     for li, planes in enumerate([64, 128, 256, 512], start=1):
-        for bi in range(2):
+        with_dcn = dcn and li > 1  # resnet.py:176-191: layer1 is built without dcn
+        for bi in range(layers[li - 1]):
             p = 'backbone.layer%d.%d' % (li, bi)
-            cin = inpl if bi == 0 else planes
-            s.append((p + '.conv1.weight', (planes, cin, 3, 3), 'conv_w'))
-            s += _bn_entries(p + '.bn1', planes)
+            cin = inpl if bi == 0 else planes * exp
+            if block == 'basic':
+                s.append((p + '.conv1.weight', (planes, cin, 3, 3), 'conv_w'))
+                s += _bn_entries(p + '.bn1', planes)
+            else:
+                s.append((p + '.conv1.weight', (planes, cin, 1, 1), 'conv_w'))
+                s += _bn_entries(p + '.bn1', planes)
+            if with_dcn:  # resnet.py:54-65 / 111-124: offsets conv (bias) then torchvision DeformConv2d (no bias)
+                s.append((p + '.conv2_offset.weight', (18, planes, 3, 3), 'offset_w'))
+                s.append((p + '.conv2_offset.bias', (18, ), 'offset_b'))
             s.append((p + '.conv2.weight', (planes, planes, 3, 3), 'conv_w'))
             s += _bn_entries(p + '.bn2', planes)
-            if bi == 0 and li > 1:
-                s.append((p + '.downsample.0.weight', (planes, cin, 1, 1), 'conv_w'))
-                s += _bn_entries(p + '.downsample.1', planes)
-        inpl = planes
+            if block == 'bottleneck':
+                s.append((p + '.conv3.weight', (planes * 4, planes, 1, 1), 'conv_w'))
+                s += _bn_entries(p + '.bn3', planes * 4)
+            if bi == 0 and (li > 1 or cin != planes * exp):
+                s.append((p + '.downsample.0.weight', (planes * exp, cin, 1, 1), 'conv_w'))
+                s += _bn_entries(p + '.downsample.1', planes * exp)
+        inpl = planes * exp
     # dead parameters the reference constructs but never uses (resnet.py:192-195)
-    s.append(('backbone.fc.weight', (1000, 512), 'dead'))
+    s.append(('backbone.fc.weight', (1000, 512 * exp), 'dead'))
     s.append(('backbone.fc.bias', (1000, ), 'dead'))
     s.append(('backbone.smooth.weight', (256, 2048, 1, 1), 'dead'))
     s.append(('backbone.smooth.bias', (256, ), 'dead'))
     b = 'segmentation_body.'
-    for name, cin in (('reduce_conv_c2', 64), ('reduce_conv_c3', 128), ('reduce_conv_c4', 256), ('reduce_conv_c5', 512)):
+    for name, cin in zip(('reduce_conv_c2', 'reduce_conv_c3', 'reduce_conv_c4', 'reduce_conv_c5'), backbone_out_channels(arch)):
         s.append((b + name + '.conv.weight', (64, cin, 1, 1), 'conv_w'))
         s.append((b + name + '.conv.bias', (64, ), 'conv_b'))
         s += _bn_entries(b + name + '.bn', 64)
@@ -114,7 +140,9 @@ def procedural_fill(state, seed=0):
     reference state_dict.  Applied identically to the imported reference model
     (when making goldens), to the oracle and to the HIP model, so no weights
     have to be shipped.  Values have trained-net-like scales."""
-    kinds = {k: kind for k, _, kind in state_spec()}
+    kinds = {}
+    for arch in ARCHS:
+        kinds.update({k: kind for k, _, kind in state_spec(arch)})
     for key, t in state.items():
         kind = kinds[key]
         g = torch.Generator().manual_seed(_key_seed(key, seed))
@@ -130,6 +158,10 @@ def procedural_fill(state, seed=0):
             v = torch.randn(shape, generator=g) * math.sqrt(2.0 / max(fan, 1))
         elif kind == 'conv_b':
             v = torch.randn(shape, generator=g) * 0.05
+        elif kind == 'offset_w':  # offsets of a fraction of a pixel (the reference initialises them to 0, resnet.py:204-208)
+            v = torch.randn(shape, generator=g) * (0.3 / math.sqrt(shape[1] * 9))
+        elif kind == 'offset_b':
+            v = torch.randn(shape, generator=g) * 0.3
         elif kind == 'bn_w':
             v = 0.5 + torch.rand(shape, generator=g)
         elif kind == 'bn_b':
@@ -145,16 +177,23 @@ def procedural_fill(state, seed=0):
     return state
 
 
-def new_state(seed=0):
+def new_state(seed=0, arch='resnet18'):
     sd = OrderedDict()
-    for key, shape, kind in state_spec():
+    for key, shape, kind in state_spec(arch):
         sd[key] = torch.zeros(shape, dtype=torch.int64 if kind == 'bn_nbt' else torch.float32)
     return procedural_fill(sd, seed)
 
 
-def trainable_keys(include_dead=False):
+def arch_of(sd):
+    """Architecture of a state dict, from its keys."""
+    bott = 'backbone.layer1.0.conv3.weight' in sd
+    dcn = 'backbone.layer2.0.conv2_offset.weight' in sd
+    return ('deformable_' if dcn else '') + ('resnet50' if bott else 'resnet18')
+
+
+def trainable_keys(include_dead=False, arch='resnet18'):
     out = []
-    for key, _, kind in state_spec():
+    for key, _, kind in state_spec(arch):
         if kind in ('bn_rm', 'bn_rv', 'bn_nbt'):
             continue
         if kind == 'dead' and not include_dead:
@@ -193,11 +232,70 @@ def _bn(sd, prefix, x, training, update_stats):
     return F.batch_norm(x, None, None, w, b, True, BN_MOMENTUM, BN_EPS)
 
 
+def deform_conv2d(x, offset, weight, stride=1, pad=1):
+    """torchvision.ops.deform_conv2d (v0.6.0, deformable_groups = 1, dilation 1, no bias) restated from DCNv1:
+    out[n,co,ho,wo] = sum_{ci,k} w[co,ci,k] * bilinear(x[n,ci], ho*stride - pad + r_k + dy_k, wo*stride - pad + s_k + dx_k),
+    offset channel 2k = dy_k, 2k+1 = dx_k over the R*S taps k = r*S + s; samples outside (-1, H) x (-1, W) are zero and
+    each of the four corner reads is zero when its index is out of range (bilinear_interpolate of deform_conv2d_kernel).
+    Built from gathers, so autograd yields the gradients w.r.t. x, offset and weight.
+    PARITY UNPINNED: torchvision is not installed here and absent from /root/reference; pinned only by the
+    zero-offset identity with F.conv2d and by finite differences (tests/test_oracle_golden.py)."""
+    N, C, H, W = x.shape
+    Co, _, R, S = weight.shape
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    assert offset.shape == (N, 2 * R * S, Ho, Wo), offset.shape
+    ho = torch.arange(Ho, dtype=x.dtype).view(1, Ho, 1) * stride - pad
+    wo = torch.arange(Wo, dtype=x.dtype).view(1, 1, Wo) * stride - pad
+    xf = x.reshape(N, C, H * W)
+    cols = []
+    for k in range(R * S):
+        r, s_ = k // S, k % S
+        y = ho + r + offset[:, 2 * k]  # [N,Ho,Wo]
+        xx = wo + s_ + offset[:, 2 * k + 1]
+        inside = (y > -1) & (y < H) & (xx > -1) & (xx < W)
+        y0, x0 = torch.floor(y), torch.floor(xx)
+        ly, lx = y - y0, xx - x0
+        val = 0
+        for (yy, xc, wgt) in ((y0, x0, (1 - ly) * (1 - lx)), (y0, x0 + 1, (1 - ly) * lx), (y0 + 1, x0, ly * (1 - lx)),
+                              (y0 + 1, x0 + 1, ly * lx)):
+            ok = inside & (yy >= 0) & (yy <= H - 1) & (xc >= 0) & (xc <= W - 1)
+            idx = (yy.clamp(0, H - 1) * W + xc.clamp(0, W - 1)).long().view(N, 1, Ho * Wo).expand(N, C, Ho * Wo)
+            g = torch.gather(xf, 2, idx).view(N, C, Ho, Wo)
+            val = val + g * (wgt * ok.to(x.dtype)).unsqueeze(1)
+        cols.append(val)
+    col = torch.stack(cols, 2)  # [N, C, RS, Ho, Wo]
+    return torch.einsum('ock,nckhw->nohw', weight.reshape(Co, C, R * S), col)
+
+
+def _conv2(sd, p, x, stride):
+    """3x3 conv2 of a block: plain (resnet.py:46-50 / 103-108) or conv2_offset + DeformConv2d (:54-65,81-82 / 111-124,145-146)."""
+    if p + '.conv2_offset.weight' in sd:
+        offset = F.conv2d(x, sd[p + '.conv2_offset.weight'], sd[p + '.conv2_offset.bias'], stride, 1)
+        return deform_conv2d(x, offset, sd[p + '.conv2.weight'], stride, 1)
+    return F.conv2d(x, sd[p + '.conv2.weight'], None, stride, 1)
+
+
+def _bottleneck(sd, p, x, stride, has_down, training, upd):
+    # resnet.py:135-159
+    out = F.conv2d(x, sd[p + '.conv1.weight'], None, 1, 0)
+    out = F.relu(_bn(sd, p + '.bn1', out, training, upd))
+    out = _conv2(sd, p, out, stride)
+    out = F.relu(_bn(sd, p + '.bn2', out, training, upd))
+    out = F.conv2d(out, sd[p + '.conv3.weight'], None, 1, 0)
+    out = _bn(sd, p + '.bn3', out, training, upd)
+    if has_down:
+        res = F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride, 0)
+        res = _bn(sd, p + '.downsample.1', res, training, upd)
+    else:
+        res = x
+    return F.relu(out + res)
+
+
 def _basic_block(sd, p, x, stride, has_down, training, upd):
     # resnet.py:70-91
     out = F.conv2d(x, sd[p + '.conv1.weight'], None, stride, 1)
     out = F.relu(_bn(sd, p + '.bn1', out, training, upd))
-    out = F.conv2d(out, sd[p + '.conv2.weight'], None, 1, 1)
+    out = _conv2(sd, p, out, 1)
     out = _bn(sd, p + '.bn2', out, training, upd)
     if has_down:
         res = F.conv2d(x, sd[p + '.downsample.0.weight'], None, stride, 0)
@@ -241,9 +339,13 @@ def forward(sd, x, training=True, update_stats=True, taps=None):
     y = F.max_pool2d(y, 3, 2, 1)
     t['pool'] = y
     feats = []
+    blockfn = _bottleneck if 'backbone.layer1.0.conv3.weight' in sd else _basic_block
     for li in range(1, 5):
-        y = _basic_block(sd, 'backbone.layer%d.0' % li, y, 1 if li == 1 else 2, li > 1, training, upd)
-        y = _basic_block(sd, 'backbone.layer%d.1' % li, y, 1, False, training, upd)
+        bi = 0
+        while 'backbone.layer%d.%d.conv1.weight' % (li, bi) in sd:  # resnet.py:210-229 (_make_layer)
+            p = 'backbone.layer%d.%d' % (li, bi)
+            y = blockfn(sd, p, y, 2 if (bi == 0 and li > 1) else 1, p + '.downsample.0.weight' in sd, training, upd)
+            bi += 1
         feats.append(y)
         t['c%d' % (li + 1)] = y
     c2, c3, c4, c5 = feats
@@ -375,7 +477,7 @@ class AdamState:
 
 def loss_and_grads(sd, img, gts, update_stats=True, world_scale=1.0, **loss_kw):
     """forward + DBLoss + backward; returns (preds, losses(5 floats), grads dict)."""
-    keys = trainable_keys()
+    keys = trainable_keys(arch=arch_of(sd))
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work = OrderedDict(sd)
     work.update(leaves)

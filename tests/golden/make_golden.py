@@ -52,16 +52,30 @@ def summarize(prefix, t, out, full_below=8192):
         out[prefix + '/sample'] = a[sample_idx(a.size)].astype(np.float32)
 
 
-def make_ref(seed):
-    m = DBTextModel()
+def make_ref(seed, arch='resnet18'):
+    """The reference's DBTextModel.  models.py:8 registers only resnet18 although resnet.py:285-306 defines the
+    Bottleneck nets (SURVEY A4'): for 'resnet50' the registry entry is swapped for the duration of the constructor, so
+    the reference's own __init__/forward assemble resnet50 + FPN([256,512,1024,2048]) + DBHead.  (The deformable
+    variants import torchvision inside the block constructor and cannot be built here.)"""
+    import models as ref_models
+    from modules.resnet import resnet50
+    saved = dict(ref_models.backbone_dict['resnet18'])
+    try:
+        if arch == 'resnet50':
+            ref_models.backbone_dict['resnet18'] = {'models': resnet50, 'out': [256, 512, 1024, 2048]}
+        else:
+            assert arch == 'resnet18'
+        m = DBTextModel()
+    finally:
+        ref_models.backbone_dict['resnet18'] = saved
     O.procedural_fill(m.state_dict(), seed)
     return m
 
 
-def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1):
+def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch='resnet18'):
     print('==', name)
     torch.manual_seed(0)
-    m = make_ref(seed).train()
+    m = make_ref(seed, arch).train()
     crit = DBLoss(alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3)
     opt = torch.optim.Adam(m.parameters(), lr=0.005, weight_decay=0, amsgrad=False)
     img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=img_scale)
@@ -204,11 +218,11 @@ def case_pixel_metrics():
     np.savez_compressed(os.path.join(HERE, 'pixel_metrics.npz'), **out)
 
 
-def check_oracle():
+def check_oracle(arch='resnet18'):
     """Pin the oracle against the imported reference right here."""
-    print('== oracle vs reference')
-    m = make_ref(3).train()
-    sd = O.new_state(3)
+    print('== oracle vs reference', arch)
+    m = make_ref(3, arch).train()
+    sd = O.new_state(3, arch)
     for k, v in m.state_dict().items():
         assert torch.equal(v, sd[k]), k
     assert list(m.state_dict().keys()) == list(sd.keys())
@@ -234,6 +248,11 @@ def check_oracle():
 
 
 if __name__ == '__main__':
+    if '--only-r50' in sys.argv:
+        check_oracle('resnet50')
+        case_train('r50_train_1x64', 1, 64, seed=11, steps=2, arch='resnet50')
+        case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
+        sys.exit(0)
     check_oracle()
     case_pixel_metrics()
     if '--only-metrics' in sys.argv:
@@ -244,6 +263,9 @@ if __name__ == '__main__':
     case_train('train_2x96_scaled', 2, 96, seed=4, img_scale=60.0, steps=1)
     case_eval('eval_2x128', 2, 128, seed=2)
     case_dp('dp_2x1x128', 128, seed=6)
+    check_oracle('resnet50')
+    case_train('r50_train_1x64', 1, 64, seed=11, steps=2, arch='resnet50')
+    case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
     if '--no-640' not in sys.argv:
         case_train('cfg1_2x640', 2, 640, seed=0, full_maps=False, steps=3)
     print('done')

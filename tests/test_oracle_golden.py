@@ -24,13 +24,13 @@ def test_state_spec_matches_reference_layout():
     assert live == 12269378
 
 
-@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled'])
+@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled', 'r50_train_1x64', 'r50_train_2x96'])
 def test_oracle_train_steps_match_reference(golden_dir, name):
     torch.set_num_threads(8)
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     n, size, seed, steps = (int(v) for v in z['meta'])
     img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=float(z['img_scale']))
-    sd = O.new_state(seed)
+    sd = O.new_state(seed, 'resnet50' if name.startswith('r50') else 'resnet18')
     opt = O.AdamState(lr=0.005)
     for it in range(steps):
         if it == 0:
@@ -129,3 +129,45 @@ def test_oracle_pixel_metrics_match_reference(golden_dir):
         sc = O.scores_from_confusion(hist)
         got = [sc[k] for k in ('Overall Acc', 'Mean Acc', 'FreqW Acc', 'Mean IoU')]
         assert np.allclose(got, z['step%d/scores' % step], rtol=1e-12)
+
+
+def test_state_specs_of_the_bottleneck_and_deformable_backbones():
+    """resnet.py:285-306: resnet50 has 161 parameter tensors / 25.6 M backbone+FPN+head parameters; the deformable variants add
+    conv2_offset (18 channels, with bias) to every block of layers 2-4 only (resnet.py:176-191)."""
+    r50 = O.state_spec('resnet50')
+    assert len(r50) == 409 and O.backbone_out_channels('resnet50') == [256, 512, 1024, 2048]
+    d50 = dict((k, s) for k, s, _ in O.state_spec('deformable_resnet50'))
+    offs = [k for k in d50 if 'conv2_offset.weight' in k]
+    assert len(offs) == 4 + 6 + 3 and not any(k.startswith('backbone.layer1.') for k in offs)
+    assert d50['backbone.layer2.0.conv2_offset.weight'] == (18, 128, 3, 3) and d50['backbone.layer2.0.conv2.weight'] == (128, 128, 3, 3)
+    d18 = [k for k, _, _ in O.state_spec('deformable_resnet18') if 'conv2_offset.bias' in k]
+    assert len(d18) == 6
+    for arch in O.ARCHS:
+        assert O.arch_of(O.new_state(0, arch)) == arch
+
+
+def test_deform_conv_oracle_properties():
+    """The restated DCNv1 sampling (torchvision is absent: parity unpinned) — pinned by what must hold for any correct
+    implementation: zero offsets == F.conv2d (how the reference initialises it, resnet.py:204-208); integer offsets ==
+    shifted input; half-pixel offsets == mean of the two neighbours; autograd gradients == finite differences."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 9, 11, generator=g, dtype=torch.double)
+    w = torch.randn(7, 5, 3, 3, generator=g, dtype=torch.double)
+    for stride in (1, 2):
+        ref = F.conv2d(x, w, None, stride, 1)
+        off = torch.zeros(2, 18, ref.shape[2], ref.shape[3], dtype=torch.double)
+        assert (O.deform_conv2d(x, off, w, stride, 1) - ref).abs().max() < 1e-12
+    off = torch.zeros(2, 18, 9, 11, dtype=torch.double)
+    off[:, 0::2] = 1.0
+    shifted = F.conv2d(F.pad(x, (0, 0, 0, 1))[:, :, 1:], w, None, 1, 1)
+    assert (O.deform_conv2d(x, off, w, 1, 1) - shifted)[:, :, 1:].abs().max() < 1e-12
+    off[:, 0::2] = 0.5
+    half = 0.5 * (F.conv2d(x, w, None, 1, 1) + shifted)
+    assert (O.deform_conv2d(x, off, w, 1, 1) - half)[:, :, 1:-1].abs().max() < 1e-12
+    off[:, 0::2] = -40.0  # everything sampled outside the image
+    assert O.deform_conv2d(x, off, w, 1, 1).abs().max() == 0
+    x = torch.randn(1, 2, 5, 6, generator=g, dtype=torch.double, requires_grad=True)
+    w = torch.randn(3, 2, 3, 3, generator=g, dtype=torch.double, requires_grad=True)
+    off = (torch.rand(1, 18, 5, 6, generator=g, dtype=torch.double) * 1.6 - 0.8 + 0.013).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b, c: O.deform_conv2d(a, b, c, 1, 1), (x, off, w), eps=1e-6, atol=1e-5)
