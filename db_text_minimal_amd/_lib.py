@@ -23,6 +23,9 @@ SIGNATURES = {
     'dbn_conv_bn_ws_floats': 'iiiiii',
     'dbn_igemm_splitk_plan': 'iiii',
     'dbn_igemm_splitk_f32': 'pppp' + 'i' * 16 + 'pp',
+    'dbn_deform_im2col': 'ppp' + 'i' * 11 + 'p',
+    'dbn_deform_col2im': 'ppppp' + 'i' * 11 + 'p',
+    'dbn_permute_weight': 'ppiiiifp',
     'dbn_binarize_u8': 'piiiifpp',
     'dbn_box_scores': 'piipiipp',
     'dbn_pyramid_conv_ws_floats': 'iiii',

@@ -1,0 +1,185 @@
+// Deformable convolution (DCNv1, deformable_groups = 1) for the reference's DCN backbones
+// (src/modules/resnet.py:54-65,81-82,111-124,145-146: conv2_offset -> torchvision.ops.DeformConv2d), NHWC fp32.
+//
+// Lowering: the learned offsets only change WHERE the 3x3 taps sample, so the op is
+//   cols[m][tap][c] = bilinear(x[n, :, :, c], ho*stride - pad + r + dy, wo*stride - pad + s + dx)   (this file, HBM-bound)
+//   y[m][co]        = sum_{tap,c} cols[m][tap][c] * W[co][c][tap]                                      (igemm 1x1, MFMA)
+// and the backward is the 1x1 data/weight gradients of the GEMM (igemm / wgrad kernels) plus the adjoint of the
+// sampling: dx (scattered with float atomics: the only non-bit-reproducible kernel of the library) and
+// d(offset) (a reduction over channels).  Sampling rule = torchvision's bilinear_interpolate: a sample outside
+// (-1, H) x (-1, W) is zero; each corner contributes only if its index is inside the image.
+// Offsets: channel 2k = dy, 2k+1 = dx of tap k = r*S + s, stored [M][off_stride] (off_stride >= 2*R*S).
+#include "common.h"
+
+namespace {
+
+struct DeformDims {
+    int N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride;
+};
+
+// one 32-lane team per (output pixel m, tap k); lanes stride over the C/4 channel quads
+struct Sample {
+    bool inside;
+    int y0, x0;
+    float ly, lx;
+    bool ok[4];
+};
+
+__device__ __forceinline__ Sample sample_of(const DeformDims& d, const float* __restrict__ offset, int m, int k, int& n, int& ho,
+                                            int& wo) {
+    const int HWo = d.Ho * d.Wo;
+    n = m / HWo;
+    const int rem = m - n * HWo;
+    ho = rem / d.Wo;
+    wo = rem - ho * d.Wo;
+    const int r = k / d.S, s = k - r * d.S;
+    const float y = (float)(ho * d.stride - d.pad + r) + offset[(long)m * d.off_stride + 2 * k];
+    const float x = (float)(wo * d.stride - d.pad + s) + offset[(long)m * d.off_stride + 2 * k + 1];
+    Sample sp;
+    sp.inside = y > -1.f && y < (float)d.H && x > -1.f && x < (float)d.W;
+    const float fy = floorf(y), fx = floorf(x);
+    sp.y0 = (int)fy;
+    sp.x0 = (int)fx;
+    sp.ly = y - fy;
+    sp.lx = x - fx;
+    const bool ya = sp.y0 >= 0 && sp.y0 <= d.H - 1, yb = sp.y0 + 1 >= 0 && sp.y0 + 1 <= d.H - 1;
+    const bool xa = sp.x0 >= 0 && sp.x0 <= d.W - 1, xb = sp.x0 + 1 >= 0 && sp.x0 + 1 <= d.W - 1;
+    sp.ok[0] = sp.inside && ya && xa;
+    sp.ok[1] = sp.inside && ya && xb;
+    sp.ok[2] = sp.inside && yb && xa;
+    sp.ok[3] = sp.inside && yb && xb;
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                            float* __restrict__ cols, DeformDims d, long teams) {
+    const int lane = threadIdx.x & 31;
+    const int RS = d.R * d.S, c4n = d.C >> 2;
+    for (long t = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5; t < teams; t += ((long)gridDim.x * blockDim.x) >> 5) {
+        const int m = (int)(t / RS), k = (int)(t - (long)m * RS);
+        int n, ho, wo;
+        const Sample sp = sample_of(d, offset, m, k, n, ho, wo);
+        const float w00 = (1.f - sp.ly) * (1.f - sp.lx), w01 = (1.f - sp.ly) * sp.lx, w10 = sp.ly * (1.f - sp.lx), w11 = sp.ly * sp.lx;
+        const long base = ((long)n * d.H + sp.y0) * d.W + sp.x0;  // pixel index of corner (y0, x0); only dereferenced if ok
+        f32x4* out = reinterpret_cast<f32x4*>(cols + ((long)m * RS + k) * d.C);
+        for (int c4 = lane; c4 < c4n; c4 += 32) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v00 = sp.ok[0] ? reinterpret_cast<const f32x4*>(x + base * d.C)[c4] : z;
+            const f32x4 v01 = sp.ok[1] ? reinterpret_cast<const f32x4*>(x + (base + 1) * d.C)[c4] : z;
+            const f32x4 v10 = sp.ok[2] ? reinterpret_cast<const f32x4*>(x + (base + d.W) * d.C)[c4] : z;
+            const f32x4 v11 = sp.ok[3] ? reinterpret_cast<const f32x4*>(x + (base + d.W + 1) * d.C)[c4] : z;
+            out[c4] = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ dcols, const float* __restrict__ x,
+                                                            const float* __restrict__ offset, float* __restrict__ dx,
+                                                            float* __restrict__ doffset, DeformDims d, long teams) {
+    const int lane = threadIdx.x & 31;
+    const int RS = d.R * d.S, c4n = d.C >> 2;
+    for (long t = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5; t < teams; t += ((long)gridDim.x * blockDim.x) >> 5) {
+        const int m = (int)(t / RS), k = (int)(t - (long)m * RS);
+        int n, ho, wo;
+        const Sample sp = sample_of(d, offset, m, k, n, ho, wo);
+        const float hy = 1.f - sp.ly, hx = 1.f - sp.lx;
+        const float w00 = hy * hx, w01 = hy * sp.lx, w10 = sp.ly * hx, w11 = sp.ly * sp.lx;
+        const long base = ((long)n * d.H + sp.y0) * d.W + sp.x0;
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(dcols + ((long)m * RS + k) * d.C);
+        float gy = 0.f, gx = 0.f;  // d(sample)/d(y), d(sample)/d(x) contracted with the column gradient
+        for (int c4 = lane; c4 < c4n; c4 += 32) {
+            const f32x4 g = g4[c4];
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 v00 = sp.ok[0] ? reinterpret_cast<const f32x4*>(x + base * d.C)[c4] : z;
+            const f32x4 v01 = sp.ok[1] ? reinterpret_cast<const f32x4*>(x + (base + 1) * d.C)[c4] : z;
+            const f32x4 v10 = sp.ok[2] ? reinterpret_cast<const f32x4*>(x + (base + d.W) * d.C)[c4] : z;
+            const f32x4 v11 = sp.ok[3] ? reinterpret_cast<const f32x4*>(x + (base + d.W + 1) * d.C)[c4] : z;
+            const f32x4 dvy = hx * (v10 - v00) + sp.lx * (v11 - v01);
+            const f32x4 dvx = hy * (v01 - v00) + sp.ly * (v11 - v10);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gy += g[e] * dvy[e];
+                gx += g[e] * dvx[e];
+                const int c = 4 * c4 + e;
+                if (sp.ok[0]) atomicAdd(dx + base * d.C + c, w00 * g[e]);
+                if (sp.ok[1]) atomicAdd(dx + (base + 1) * d.C + c, w01 * g[e]);
+                if (sp.ok[2]) atomicAdd(dx + (base + d.W) * d.C + c, w10 * g[e]);
+                if (sp.ok[3]) atomicAdd(dx + (base + d.W + 1) * d.C + c, w11 * g[e]);
+            }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            gy += __shfl_xor(gy, o, 64);
+            gx += __shfl_xor(gx, o, 64);
+        }
+        if (lane == 0) {
+            doffset[(long)m * d.off_stride + 2 * k] = gy;
+            doffset[(long)m * d.off_stride + 2 * k + 1] = gx;
+        }
+    }
+}
+
+// dst[o][t][c] = src[o][c][t] (to_ohwi) or dst[o][c][t] = scale * src[o][t][c]: weight layout between OIHW and the
+// GEMM's (tap, channel) column order
+__global__ void permute_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int C, int T, int to_ohwi,
+                                      float scale) {
+    const long total = (long)O * C * T;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / ((long)C * T));
+        const int rem = (int)(i - (long)o * C * T);
+        if (to_ohwi) {
+            const int t = rem / C, c = rem - t * C;
+            dst[i] = scale * src[((long)o * C + c) * T + t];
+        } else {
+            const int c = rem / T, t = rem - c * T;
+            dst[i] = scale * src[((long)o * T + t) * C + c];
+        }
+    }
+}
+
+bool dims_ok(const DeformDims& d) {
+    return d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.C % 4 == 0 && d.R > 0 && d.S > 0 && d.stride > 0 && d.pad >= 0 &&
+           d.Ho == (d.H + 2 * d.pad - d.R) / d.stride + 1 && d.Wo == (d.W + 2 * d.pad - d.S) / d.stride + 1 &&
+           d.off_stride >= 2 * d.R * d.S && (long)d.N * d.Ho * d.Wo * d.R * d.S < (1L << 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+// cols[N*Ho*Wo][R*S][C] = bilinear samples of x[N,H,W,C] at the offset tap positions
+int dbn_deform_im2col(const float* x, const float* offset, float* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
+                      int stride, int pad, int off_stride, void* stream) {
+    const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
+    DBN_REQUIRE(x && offset && cols && dims_ok(d));
+    const long teams = (long)N * Ho * Wo * R * S;
+    hipLaunchKernelGGL(deform_im2col_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, offset,
+                       cols, d, teams);
+    return dbn_status();
+}
+
+// adjoint of the sampling: dx[N,H,W,C] += scatter(dcols) (float atomics; the caller initialises dx),
+// doffset[N*Ho*Wo][off_stride]: channels 0..2RS-1 written, the rest set to zero
+int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
+                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
+    const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
+    DBN_REQUIRE(dcols && x && offset && dx && doffset && dims_ok(d));
+    hipStream_t st = (hipStream_t)stream;
+    if (off_stride > 2 * R * S &&
+        hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess)
+        return dbn_status();
+    const long teams = (long)N * Ho * Wo * R * S;
+    hipLaunchKernelGGL(deform_col2im_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, st, dcols, x, offset, dx, doffset,
+                       d, teams);
+    return dbn_status();
+}
+
+// to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T] (OIHW -> GEMM column order); 0: the inverse
+int dbn_permute_weight(const float* src, float* dst, int O, int C, int T, int to_ohwi, float scale, void* stream) {
+    DBN_REQUIRE(src && dst && O > 0 && C > 0 && T > 0);
+    hipLaunchKernelGGL(permute_weight_kernel, dim3(dbn_grid((long)O * C * T)), dim3(256), 0, (hipStream_t)stream, src, dst, O, C, T,
+                       to_ohwi, scale);
+    return dbn_status();
+}
+
+}  // extern "C"

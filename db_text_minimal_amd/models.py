@@ -11,11 +11,18 @@ import torch
 from torch import nn
 
 from .engine import Engine
-from .modules.resnet import resnet18
+from .modules.resnet import deformable_resnet18, deformable_resnet50, resnet18, resnet50
 from .modules.segmentation_body import FPN
 from .modules.segmentation_head import DBHead
 
-backbone_dict = {'resnet18': {'models': resnet18, 'out': [64, 128, 256, 512]}}
+# models.py:8 registers resnet18 only; the Bottleneck / deformable nets that resnet.py:285-306 defines (BASELINE configs[3])
+# get their registry entries here (SURVEY A4').
+backbone_dict = {
+    'resnet18': {'models': resnet18, 'out': [64, 128, 256, 512]},
+    'deformable_resnet18': {'models': deformable_resnet18, 'out': [64, 128, 256, 512]},
+    'resnet50': {'models': resnet50, 'out': [256, 512, 1024, 2048]},
+    'deformable_resnet50': {'models': deformable_resnet50, 'out': [256, 512, 1024, 2048]},
+}
 segmentation_body_dict = {'FPN': FPN}
 segmentation_head_dict = {'DBHead': DBHead}
 
@@ -44,9 +51,10 @@ class _DBNetFunction(torch.autograd.Function):
 
 
 class DBTextModel(nn.Module):
-    def __init__(self):
+    def __init__(self, backbone='resnet18'):
+        """`DBTextModel()` is the reference's constructor (models.py:14, resnet18); `backbone` selects another registry entry."""
         super().__init__()
-        backbone_name, body_name, head_name = 'resnet18', 'FPN', 'DBHead'
+        backbone_name, body_name, head_name = backbone, 'FPN', 'DBHead'
         # The reference hard-codes pretrained=True and downloads ImageNet weights
         # (models.py:17, resnet.py:253); without network access weights come from load_state_dict.
         self.backbone = backbone_dict[backbone_name]['models'](pretrained=False)

@@ -180,6 +180,21 @@ int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, 
 int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
 
+/* ---- deformable convolution of the DCN backbones (resnet.py:54-65,81-82,111-124,145-146: conv2_offset ->
+ * torchvision.ops.DeformConv2d, deformable_groups = 1), lowered to sampling + GEMM:
+ *   cols = dbn_deform_im2col(x, offset);  y = dbn_igemm_f32(cols as [N,Ho,Wo,R*S*C], 1x1 panels of the permuted weight)
+ * backward: dcols = 1x1 data gradient, dW = 1x1 weight gradient of (dy, cols) permuted back, then dbn_deform_col2im.
+ * offset: [N*Ho*Wo][off_stride] floats, channel 2k = dy and 2k+1 = dx of tap k = r*S + s (torchvision layout);
+ * off_stride >= 2*R*S lets the offsets live in the 64-channel output of the (zero-padded) offset conv. */
+int dbn_deform_im2col(const float* x, const float* offset, float* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
+                      int stride, int pad, int off_stride, void* stream);
+/* dx += adjoint of the sampling applied to dcols (float atomics: summation order not fixed); doffset is written
+ * (channels >= 2*R*S zeroed). */
+int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
+                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
+/* to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T]; 0: dst[O][C][T] = scale * src[O][T][C] */
+int dbn_permute_weight(const float* src, float* dst, int O, int C, int T, int to_ohwi, float scale, void* stream);
+
 /* ---- array work of SegDetectorRepresenter ahead of the (host, unchanged) OpenCV contour code ---- */
 /* postprocess.py:51-52 `pred > thresh` on channel 0 of pred[N][channels][H][W], as a uint8 {0,1} bitmap out[N][H][W]
  * (H*W % 4 == 0): the D2H copy the contour tracer needs shrinks 4x. */

@@ -579,3 +579,49 @@ def test_splitk_plan():
     assert plan(16 * 20 * 20, 64, 100 * 256, 256) > 1  # FPN level-3 data gradient: 100 tiles, K = 25600
     assert plan(16 * 160 * 160, 256, 2304, 256) == 1  # plenty of tiles
     assert plan(16 * 20 * 20, 64, 100 * 4, 4) == 1  # K order of thin inputs is not splittable
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 9, 11, 1), (1, 128, 64, 12, 10, 2), (2, 64, 128, 7, 7, 1)])
+@pytest.mark.parametrize('zero_offsets', [False, True])
+def test_deformable_conv(case, zero_offsets):
+    """conv2_offset -> DeformConv2d (resnet.py:61-65,81-82,119-124,145-146) as deformable im2col + 1x1 GEMM, and its three
+    gradients, vs the restated DCNv1 op (oracle.deform_conv2d + autograd).  Zero offsets (the reference's initial
+    state, resnet.py:204-208) must reproduce the plain conv."""
+    from oracle import dbnet_oracle as O
+    N, C, Co, H, W, stride = case
+    x = rnd(N, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, C, 3, 3, seed=2, scale=(2.0 / (9 * C))**0.5).requires_grad_(True)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    off = (torch.zeros(N, 18, Ho, Wo) if zero_offsets else rnd(N, 18, Ho, Wo, seed=3) * 1.5).requires_grad_(True)
+    ref = O.deform_conv2d(x, off, w, stride, 1)
+    if zero_offsets:
+        report('zero offsets == conv2d', ref.detach(), F.conv2d(x, w, None, stride, 1).detach(), 1e-5, 1e-5)
+    dy = rnd(*ref.shape, seed=4)
+    dx_ref, doff_ref, dw_ref = torch.autograd.grad(ref, (x, off, w), dy)
+    OS = 64  # offsets live in the 64-channel output of the zero-padded offset conv
+    xs = nhwc(x.detach())
+    offs = torch.zeros(N, Ho, Wo, OS, device=DEV)
+    offs[..., :18] = nhwc(off.detach())
+    cols = torch.full((N, Ho, Wo, 9 * C), float('nan'), device=DEV)
+    dims = (N, H, W, C, Ho, Wo, 3, 3, stride, 1, OS)
+    _lib.check(L().dbn_deform_im2col(xs.data_ptr(), offs.data_ptr(), cols.data_ptr(), *dims, stream()), 'deform_im2col')
+    wp = torch.empty(Co, 9 * C, 1, 1, device=DEV)
+    wd_ = w.detach().to(DEV)
+    _lib.check(L().dbn_permute_weight(wd_.data_ptr(), wp.data_ptr(), Co, C, 9, 1, 1.0, stream()), 'permute')
+    y = torch.full((N, Ho, Wo, Co), float('nan'), device=DEV)
+    igemm(cols, pack(wp.cpu(), 0), None, y, 1, 1, 0, 0)
+    report('deform conv fwd', nchw(y), ref.detach(), 1e-4, 1e-4)
+    dys = nhwc(dy)
+    dcols = torch.full((N, Ho, Wo, 9 * C), float('nan'), device=DEV)
+    igemm(dys, pack(wp.cpu(), 1), None, dcols, 1, 1, 0, 1)
+    dx = torch.zeros(N, H, W, C, device=DEV)
+    doffs = torch.full((N, Ho, Wo, OS), float('nan'), device=DEV)
+    _lib.check(L().dbn_deform_col2im(dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx.data_ptr(), doffs.data_ptr(), *dims,
+                                     stream()), 'deform_col2im')
+    report('deform conv dx', nchw(dx), dx_ref, 1e-4, 1e-4)
+    report('deform conv doffset', nchw(doffs[..., :18].contiguous()), doff_ref, 2e-4 * float(doff_ref.abs().max()) + 1e-5, 1e-4)
+    assert float(doffs[..., 18:].abs().max()) == 0.0
+    gp = wgrad(dys, cols, Co, 9 * C, 1, 1, 0)  # [Co, 9C, 1, 1] in (tap, channel) column order
+    g = torch.empty(Co, C, 3, 3, device=DEV)
+    _lib.check(L().dbn_permute_weight(gp.data_ptr(), g.data_ptr(), Co, C, 9, 0, 1.0, stream()), 'permute back')
+    report('deform conv dweight', g.cpu(), dw_ref, 2e-5 * float(dw_ref.abs().max()) + 1e-5, 1e-4)
