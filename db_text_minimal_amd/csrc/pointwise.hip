@@ -13,13 +13,16 @@ namespace {
 constexpr int MAX_PART = 1024;  // max partial blocks for per-channel reductions
 
 // ----------------------------------------------------------------------------------
-// per-channel reductions over [M][C] (C % 4 == 0, C <= 1024): each block reduces a
-// contiguous row range into part[NV*C][block]; a second kernel folds the partials in
-// double precision.  Thread t owns channel quad t % (C/4) and walks rows t / (C/4).
+// per-channel reductions over [M][C] (C % 4 == 0): each block reduces a contiguous row range of one chunk of
+// <= 1024 channels (blockIdx.y) into part[NV*C][block]; a second kernel folds the partials in
+// double precision.  Thread t owns channel quad t % (Cc/4) of the chunk and walks rows t / (Cc/4).
 // ----------------------------------------------------------------------------------
+constexpr int CHUNK_C = 1024;
+
 template <int NV, class F>
-__device__ __forceinline__ void channel_reduce(int M, int C, float* __restrict__ part, F&& body) {
-    const int c4n = C >> 2;
+__device__ __forceinline__ void channel_reduce(int M, int Cfull, float* __restrict__ part, F&& body) {
+    const int cb = blockIdx.y * CHUNK_C, C = min(CHUNK_C, Cfull - cb);
+    const int c4n = C >> 2, cq = cb >> 2;
     const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
     const int nrl = blockDim.x / c4n;
     const int rows_per = (M + gridDim.x - 1) / gridDim.x;
@@ -28,7 +31,7 @@ __device__ __forceinline__ void channel_reduce(int M, int C, float* __restrict__
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (rl < nrl)
-        for (int r = r0 + rl; r < r1; r += nrl) body(r, c4, acc);
+        for (int r = r0 + rl; r < r1; r += nrl) body(r, cq + c4, acc);
     extern __shared__ float red[];  // [nrl][NV][C]
     if (rl < nrl) {
 #pragma unroll
@@ -38,7 +41,8 @@ __device__ __forceinline__ void channel_reduce(int M, int C, float* __restrict__
     for (int i = threadIdx.x; i < NV * C; i += blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nrl; ++k) s += red[(long)k * NV * C + i];
-        part[(long)i * gridDim.x + blockIdx.x] = s;  // transposed: [NV*C][blocks]
+        const int v = i / C, c = i - v * C;
+        part[((long)v * Cfull + cb + c) * gridDim.x + blockIdx.x] = s;  // transposed: [NV*Cfull][blocks]
     }
 }
 
@@ -518,7 +522,9 @@ inline int part_blocks(int M, int C) {
     (void)C;
     return nb;
 }
-inline size_t red_smem(int C, int nv) {
+inline dim3 red_grid(int nb, int C) { return dim3(nb, (C + CHUNK_C - 1) / CHUNK_C); }
+inline size_t red_smem(int Cfull, int nv) {
+    const int C = Cfull < CHUNK_C ? Cfull : CHUNK_C;
     const int nrl = 256 / (C / 4);
     return (size_t)(nrl > 0 ? nrl : 1) * nv * C * sizeof(float);
 }
@@ -534,10 +540,10 @@ int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const f
                        float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                        float* ws, void* stream) {
     DBN_REQUIRE(y && gamma && beta && scale && shift && save_mean && save_rstd && ws);
-    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), red_smem(C, 2), st, y, M, C, ws);
+    hipLaunchKernelGGL(bn_stats_kernel, red_grid(nb, C), dim3(256), red_smem(C, 2), st, y, M, C, ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, y, M, C, gamma, beta, eps,
                        momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
@@ -566,14 +572,14 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale,
                     const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
                     float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
-    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     DBN_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(zmask && mask_scale));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
     float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
     float* c2 = c1 + C;
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nbu), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout, save_mean,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout, save_mean,
                        save_rstd, M, C, ws);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
                        grad_scale);
@@ -584,10 +590,10 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale,
 }
 
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {
-    DBN_REQUIRE(x && out && ws && M > 0 && C % 4 == 0 && C >= 4 && C <= 1024);
+    DBN_REQUIRE(x && out && ws && M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
-    hipLaunchKernelGGL(col_sum_kernel, dim3(nb), dim3(256), red_smem(C, 1), st, x, M, C, ws);
+    hipLaunchKernelGGL(col_sum_kernel, red_grid(nb, C), dim3(256), red_smem(C, 1), st, x, M, C, ws);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, C, out, scale);
     return dbn_status();
 }

@@ -78,6 +78,13 @@ class KernelTimer:
         return out
 
 
+class _VirtualConv:
+    """Conv geometry + a derived weight tensor (zero-padded / permuted copy of a parameter) for the conv helpers."""
+
+    def __init__(self, cin, cout, k, stride, padding, weight, bias):
+        self.cin, self.cout, self.k, self.stride, self.padding, self.weight, self.bias = cin, cout, k, stride, padding, weight, bias
+
+
 class Engine:
     def __init__(self, model):
         self.model = model
@@ -177,7 +184,7 @@ class Engine:
     def reduce_ws(self):
         # one scratch per stream: the side (weight-gradient) stream reduces bias gradients concurrently
         name = '_reduce_ws_side' if self._in_side else '_reduce_ws'
-        return self.scratch(name, self.L.dbn_reduce_ws_floats(512))
+        return self.scratch(name, self.L.dbn_reduce_ws_floats(2048))  # widest BatchNorm: 512 (resnet18) / 2048 (resnet50)
 
     _in_side = False
 
@@ -245,12 +252,12 @@ class Engine:
             check(self.L.dbn_igemm_bf16s(*args, self.ns, self.stream), what)
 
     # ------------------------------------------------------------------ kernels
-    def conv_fwd(self, name, x, conv, out_name):
+    def conv_fwd(self, name, x, conv, out_name, version=None):
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
-        wpk = self.pack(name, conv.weight, 0)
+        wpk = self.pack(name, conv.weight, 0, version=version)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
             self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
@@ -276,18 +283,18 @@ class Engine:
         self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
         return sc, sh
 
-    def conv_bn(self, name, x, conv, out_name, bn_name, bn, train):
+    def conv_bn(self, name, x, conv, out_name, bn_name, bn, train, version=None):
         """conv -> BatchNorm coefficients.  Train mode: one fused call (statistics in the conv epilogue)."""
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         split = self.splitk and self.L.dbn_igemm_splitk_plan(N * Ho * Wo, conv.cout, k * k * C, C) > 1
         if not (train and self.fuse_bn_stats) or split:  # split-K convs take their statistics in a (small) separate pass
-            y = self.conv_fwd(name, x, conv, out_name)
+            y = self.conv_fwd(name, x, conv, out_name, version=version)
             sc, sh = self.bn_coef(bn_name, bn, y, train)
             return y, sc, sh
         assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
-        wpk = self.pack(name, conv.weight, 0)
+        wpk = self.pack(name, conv.weight, 0, version=version)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
             self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
@@ -318,10 +325,10 @@ class Engine:
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
         self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns), flops, 0.0, tag)
 
-    def conv_dgrad(self, name, dy, conv, dx, accumulate):
+    def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None):
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
-        wpk = self.pack(name, conv.weight, 1, conv.stride)
+        wpk = self.pack(name, conv.weight, 1, conv.stride, version=version)
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
             self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1)
         self._igemm('igemm dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
@@ -530,16 +537,105 @@ class Engine:
             self.saved_shape = (N, H, W, Hh, Wh, resample)
         return out
 
+    # ---- deformable conv2 (resnet.py:54-65,81-82,111-124,145-146): offsets conv -> bilinear im2col -> 1x1 GEMM
+    def _offset_conv(self, name, oc):
+        """conv2_offset has 18 output channels; the GEMM kernels want multiples of 64: zero-padded copy of its
+        weight/bias (the offsets then live in channels 0..17 of a 64-channel map)."""
+        w = oc.weight
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        ent = self.packs.get((name, 'pad64'))
+        if ent is None or ent[1] != stamp:
+            wp, bp = ent[0] if ent is not None else (torch.zeros(64, oc.cin, oc.k, oc.k, device=w.device),
+                                                     torch.zeros(64, device=w.device))
+            wp[:w.shape[0]].copy_(w.detach())
+            bp[:w.shape[0]].copy_(oc.bias.detach())
+            self.packs[(name, 'pad64')] = ((wp, bp), stamp)
+        wp, bp = self.packs[(name, 'pad64')][0]
+        return _VirtualConv(oc.cin, 64, oc.k, oc.stride, oc.padding, wp, bp), stamp[:2]
+
+    def _cols_conv(self, name, conv):
+        """The deformable conv's weight [O,C,3,3] as the 1x1 conv [O, 9C] over the sampled columns ((tap, channel) order)."""
+        w = conv.weight
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        ent = self.packs.get((name, 'ohwi'))
+        if ent is None or ent[1] != stamp:
+            wp = ent[0] if ent is not None else torch.empty(conv.cout, conv.k * conv.k * conv.cin, 1, 1, device=w.device)
+            check(self.L.dbn_permute_weight(w.data_ptr(), wp.data_ptr(), conv.cout, conv.cin, conv.k * conv.k, 1, 1.0, self.stream),
+                  'permute_weight')
+            self.packs[(name, 'ohwi')] = (wp, stamp)
+        wp = self.packs[(name, 'ohwi')][0]
+        return _VirtualConv(conv.k * conv.k * conv.cin, conv.cout, 1, 1, 0, wp, None), stamp[:2]
+
+    def _deform_conv_bn(self, name, x, blk, out_name, bn_name, bn, train):
+        conv = blk.conv2
+        voc, ver = self._offset_conv(name + '.conv2_offset', blk.conv2_offset)
+        off = self.conv_fwd(name + '.conv2_offset', x, voc, name + '/offset', version=ver)
+        N, H, W, C = x.shape
+        Ho, Wo = off.shape[1], off.shape[2]
+        cols = self.buf(name + '/cols', N, Ho, Wo, conv.k * conv.k * C)
+        check(self.L.dbn_deform_im2col(x.data_ptr(), off.data_ptr(), cols.data_ptr(), N, H, W, C, Ho, Wo, conv.k, conv.k, conv.stride,
+                                       conv.padding, 64, self.stream), 'deform_im2col')
+        vconv, ver2 = self._cols_conv(name + '.conv2', conv)
+        return self.conv_bn(name + '.conv2', cols, vconv, out_name, bn_name, bn, train, version=ver2)
+
+    def _deform_conv_bwd(self, name, blk, dy, x, dx):
+        """dy: gradient of the deformable conv's output; writes dx (gradient of its input x), the conv2 / conv2_offset
+        weight gradients and the offset-bias gradient."""
+        conv, oc = blk.conv2, blk.conv2_offset
+        B, G = self.bufs, self.grad_views
+        cols, off = B[name + '/cols'], B[name + '/offset']
+        N, H, W, C = x.shape
+        Ho, Wo = off.shape[1], off.shape[2]
+        T = conv.k * conv.k
+        vconv, ver2 = self._cols_conv(name + '.conv2', conv)
+        t = self.buf(name + '/dw_cols', conv.cout, T * C, 1, 1)
+        self.wgrad(name + '.conv2 (cols)', dy, cols, conv.cout, T * C, 1, 1, 0, t)
+        check(self.L.dbn_permute_weight(t.data_ptr(), G[name + '.conv2.weight'].data_ptr(), conv.cout, C, T, 0, 1.0, self.stream),
+              'permute_weight')
+        dcols = self.buf(name + '/dcols', *cols.shape)
+        self.conv_dgrad(name + '.conv2', dy, vconv, dcols, False, version=ver2)
+        doff = self.buf(name + '/doffset', N, Ho, Wo, 64)
+        dx.zero_()
+        check(self.L.dbn_deform_col2im(dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx.data_ptr(), doff.data_ptr(), N, H, W, C, Ho, Wo,
+                                       conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
+        voc, ver = self._offset_conv(name + '.conv2_offset', oc)
+        tg = self.buf(name + '/dw_offset', 64, C, oc.k, oc.k)
+        self.wgrad(name + '.conv2_offset', doff, x, 64, C, oc.k, oc.stride, oc.padding, tg)
+        nreal = oc.weight.shape[0]
+        G[name + '.conv2_offset.weight'].copy_(tg[:nreal])
+        tb = self.buf(name + '/db_offset', 64)
+        self.col_sum(doff, tb)
+        G[name + '.conv2_offset.bias'].copy_(tb[:nreal])
+        self.conv_dgrad(name + '.conv2_offset', doff, voc, dx, True, version=ver)
+
+    def _conv2_bn(self, name, blk, z1, train):
+        if getattr(blk, 'with_dcn', False):
+            return self._deform_conv_bn(name, z1, blk, name + '/y2', name + '.bn2', blk.bn2, train)
+        return self.conv_bn(name + '.conv2', z1, blk.conv2, name + '/y2', name + '.bn2', blk.bn2, train)
+
+    def _conv2_bwd(self, name, blk, dy2, z1, dz1):
+        if getattr(blk, 'with_dcn', False):
+            self._deform_conv_bwd(name, blk, dy2, z1, dz1)
+        else:
+            self.conv_wgrad(name + '.conv2', dy2, z1, blk.conv2)
+            self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False)
+
     def _block_fwd(self, name, blk, x, train):
+        """BasicBlock (resnet.py:70-91) or Bottleneck (resnet.py:135-159)."""
         y1, s1, h1 = self.conv_bn(name + '.conv1', x, blk.conv1, name + '/y1', name + '.bn1', blk.bn1, train)
         z1 = self.bn_apply(y1, s1, h1, name + '/z1')
-        y2, s2, h2 = self.conv_bn(name + '.conv2', z1, blk.conv2, name + '/y2', name + '.bn2', blk.bn2, train)
+        y2, s2, h2 = self._conv2_bn(name, blk, z1, train)
+        if hasattr(blk, 'conv3'):
+            z2 = self.bn_apply(y2, s2, h2, name + '/z2')
+            ylast, s2, h2 = self.conv_bn(name + '.conv3', z2, blk.conv3, name + '/y3', name + '.bn3', blk.bn3, train)
+        else:
+            ylast = y2
         if blk.downsample is not None:
             yd, sd, hd = self.conv_bn(name + '.downsample.0', x, blk.downsample[0], name + '/yd', name + '.downsample.1',
                                       blk.downsample[1], train)
-            out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=yd, rsc=sd, rsh=hd)
+            out = self.bn_apply(ylast, s2, h2, name + '/out', relu=True, res=yd, rsc=sd, rsh=hd)
         else:
-            out = self.bn_apply(y2, s2, h2, name + '/out', relu=True, res=x)
+            out = self.bn_apply(ylast, s2, h2, name + '/out', relu=True, res=x)
         self.bufs[name + '/in'] = x
         return out
 
@@ -608,10 +704,11 @@ class Engine:
             self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc)
 
         # gradient slots of the backbone features (written first by the FPN reduce convs)
-        dC = {k: self.buf('d' + k, *B[k].shape) for k in ('backbone.layer1.1/out', 'backbone.layer2.1/out',
-                                                           'backbone.layer3.1/out', 'backbone.layer4.1/out')}
-        c2, c3, c4, c5 = (B['backbone.layer%d.1/out' % i] for i in (1, 2, 3, 4))
-        dc2, dc3, dc4, dc5 = (dC['backbone.layer%d.1/out' % i] for i in (1, 2, 3, 4))
+        lastb = {i: len(getattr(m.backbone, 'layer%d' % i)) - 1 for i in (1, 2, 3, 4)}  # index of each stage's last block
+        feat = {i: 'backbone.layer%d.%d/out' % (i, lastb[i]) for i in (1, 2, 3, 4)}
+        dC = {k: self.buf('d' + k, *B[k].shape) for k in feat.values()}
+        c2, c3, c4, c5 = (B[feat[i]] for i in (1, 2, 3, 4))
+        dc2, dc3, dc4, dc5 = (dC[feat[i]] for i in (1, 2, 3, 4))
         # p2 = smooth_p2(p2pre), p2pre = up(p3) + r2
         dp2pre = self.buf('dp2pre', *B['p2pre'].shape)
         cbr_bwd('smooth_p2', fpn.smooth_p2, B['p2pre'], dP['smooth_p2'], dp2pre, False)
@@ -631,14 +728,14 @@ class Engine:
         dpool = self.buf('stem/dpool', *B['stem/pool'].shape)
         for li in (4, 3, 2, 1):
             layer = getattr(bb, 'layer%d' % li)
-            for bi in (1, 0):
+            for bi in range(lastb[li], -1, -1):
                 name = 'backbone.layer%d.%d' % (li, bi)
                 dout = self.bufs['d' + name + '/out']
                 xin = B[name + '/in']
-                if bi == 1:
-                    dx, acc = self.buf('d' + 'backbone.layer%d.0/out' % li, *xin.shape), False
+                if bi > 0:
+                    dx, acc = self.buf('d' + 'backbone.layer%d.%d/out' % (li, bi - 1), *xin.shape), False
                 elif li > 1:
-                    dx, acc = dC['backbone.layer%d.1/out' % (li - 1)], True
+                    dx, acc = dC[feat[li - 1]], True
                 else:
                     dx, acc = dpool, False
                 self._block_bwd(name, layer[bi], xin, dout, dx, acc)
@@ -750,16 +847,25 @@ class Engine:
         B = self.bufs
         out = B[name + '/out']
         has_down = blk.downsample is not None
+        last = '3' if hasattr(blk, 'conv3') else '2'  # Bottleneck: the residual joins after bn3
+        ylast = B[name + '/y' + last]
         if has_down:
-            dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], out, dout, name + '/dy2')
+            dyl = self.bn_backward(name + '.bn' + last, ylast, out, dout, name + '/dy' + last)
         else:
             # identity shortcut: the ReLU-masked gradient goes straight to the block input
-            dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], out, dout, name + '/dy2', gout=dx, gout_acc=dx_acc)
+            dyl = self.bn_backward(name + '.bn' + last, ylast, out, dout, name + '/dy' + last, gout=dx, gout_acc=dx_acc)
             dx_acc = True
+        if last == '3':
+            z2 = B[name + '/z2']
+            self.conv_wgrad(name + '.conv3', dyl, z2, blk.conv3)
+            dz2 = self.buf(name + '/dz2', *z2.shape)
+            self.conv_dgrad(name + '.conv3', dyl, blk.conv3, dz2, False)
+            dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], 'self', dz2, name + '/dy2')
+        else:
+            dy2 = dyl
         z1 = B[name + '/z1']
-        self.conv_wgrad(name + '.conv2', dy2, z1, blk.conv2)
         dz1 = self.buf(name + '/dz1', *z1.shape)
-        self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False)
+        self._conv2_bwd(name, blk, dy2, z1, dz1)
         dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], 'self', dz1, name + '/dy1')
         self.conv_wgrad(name + '.conv1', dy1, xin, blk.conv1)
         self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc)

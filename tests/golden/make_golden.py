@@ -250,7 +250,7 @@ def check_oracle(arch='resnet18'):
 if __name__ == '__main__':
     if '--only-r50' in sys.argv:
         check_oracle('resnet50')
-        case_train('r50_train_1x64', 1, 64, seed=11, steps=2, arch='resnet50')
+        case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')
         case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
         sys.exit(0)
     check_oracle()
@@ -264,7 +264,7 @@ if __name__ == '__main__':
     case_eval('eval_2x128', 2, 128, seed=2)
     case_dp('dp_2x1x128', 128, seed=6)
     check_oracle('resnet50')
-    case_train('r50_train_1x64', 1, 64, seed=11, steps=2, arch='resnet50')
+    case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')
     case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
     if '--no-640' not in sys.argv:
         case_train('cfg1_2x640', 2, 640, seed=0, full_maps=False, steps=3)

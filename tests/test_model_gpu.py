@@ -26,9 +26,9 @@ pytestmark = pytest.mark.gpu
 MAP_ATOL, MAP_RTOL = 1e-3, 1e-2  # BASELINE.json north_star
 
 
-def make_model(seed):
-    m = DBTextModel()
-    m.load_state_dict(O.new_state(seed))
+def make_model(seed, arch='resnet18'):
+    m = DBTextModel() if arch == 'resnet18' else DBTextModel(arch)
+    m.load_state_dict(O.new_state(seed, arch))
     return m.to(DEV)
 
 
@@ -38,7 +38,7 @@ def sample_idx(numel, k=256):
     return (np.arange(k, dtype=np.int64) * (numel // k)) + (numel // (2 * k))
 
 
-def check_grad_summary(z, prefix, t, l2_rtol=2e-2, sample_tol=5e-2):
+def check_grad_summary(z, prefix, t, l2_rtol=2e-2, sample_tol=5e-2, cos_min=0.999):
     """Gradient vs golden summary: L2 norm and a strided sample, at ReLU-flip-level tolerances."""
     a = t.detach().double().cpu().reshape(-1)
     st = z[prefix + '/stats']
@@ -52,7 +52,7 @@ def check_grad_summary(z, prefix, t, l2_rtol=2e-2, sample_tol=5e-2):
     print('%s: |g|max %.3e  sample err/scale %.3e  cos %.6f  L2 %.5e vs %.5e' % (prefix, scale, err / scale, cos, l2, st[2]))
     assert torch.isfinite(a).all(), prefix
     assert err <= sample_tol * scale, (prefix, err, scale)
-    assert cos >= 0.999, (prefix, cos)
+    assert cos >= cos_min, (prefix, cos)
     assert abs(l2 - st[2]) <= l2_rtol * st[2], (prefix, l2, st[2])
 
 
@@ -72,12 +72,14 @@ def check_summary(z, prefix, t, atol_scale=2e-4, rtol=2e-3):
     assert abs(l2 - st[2]) <= 1e-3 * st[2] + atol_scale * scale, (prefix, 'L2', l2, st[2])
 
 
-@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled'])
+@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled', 'r50_train_1x128', 'r50_train_2x96'])
 def test_train_steps_vs_reference_golden(golden_dir, name):
+    """r50_*: the Bottleneck backbone of BASELINE configs[3] (resnet.py:94-159,285-293) assembled by the reference's own
+    DBTextModel with the registry entry swapped (tests/golden/make_golden.py)."""
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     n, size, seed, steps = (int(v) for v in z['meta'])
     img, gts = O.synthetic_batch(n, size, seed=seed + 100, img_scale=float(z['img_scale']))
-    model = make_model(seed).train()
+    model = make_model(seed, 'resnet50' if name.startswith('r50') else 'resnet18').train()
     trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     img, gts = img.to(DEV), gts.to(DEV)
     for it in range(steps):
@@ -88,8 +90,11 @@ def test_train_steps_vs_reference_golden(golden_dir, name):
             for k in [f[len('grad/'):-len('/stats')] for f in z.files if f.startswith('grad/') and f.endswith('/stats')]:
                 if k.endswith('.bias') and ('conv.bias' in k or k.endswith(('.0.bias', '.3.bias'))):
                     continue  # conv bias ahead of train-mode BN: analytically zero, reference value is round-off noise
-                check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
-        tol = (1e-5, 2e-3, 2e-2)[it]
+                if name.startswith('r50'):  # 53 conv layers: proportionally more ReLU-mask flips than resnet18
+                    check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k], l2_rtol=0.1, sample_tol=0.5, cos_min=0.99)
+                else:
+                    check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
+        tol = ((1e-5, 1e-2, 5e-2) if name.startswith('r50') else (1e-5, 2e-3, 2e-2))[it]
         report('%s losses step %d' % (name, it), losses.cpu().double(), torch.from_numpy(z['losses'][it]), tol, tol)
     sd = model.state_dict()
     if steps == 1:  # after later Adam steps the statistics inherit the chaotic weight differences
@@ -314,3 +319,53 @@ def test_arbitrary_input_sizes(n, h, w):
         cos = float(a @ b / (a.norm() * b.norm()))
         print('odd-size grad %s cos %.6f' % (k, cos))
         assert cos > 0.995, (k, cos)
+
+
+@pytest.mark.parametrize('arch,n,size', [('deformable_resnet50', 2, 128), ('deformable_resnet18', 2, 64), ('resnet50', 1, 160)])
+def test_bottleneck_and_deformable_backbones_vs_oracle(arch, n, size):
+    """BASELINE configs[3] backbone family (resnet.py:94-159, DCN :54-65,111-124; SURVEY A4'): train step (maps, losses,
+    gradients incl. conv2_offset) and eval forward vs the CPU oracle.  DCN arithmetic: restated DCNv1 (parity unpinned
+    against torchvision, see oracle.deform_conv2d); the Bottleneck net itself is pinned by the r50_* goldens."""
+    seed = 21
+    img, gts = O.synthetic_batch(n, size, seed=seed + 1)
+    sd = O.new_state(seed, arch)
+    # eval mode needs running statistics that match the weights (the procedural ones let activations of a 50-layer net
+    # explode, and a deformable conv then samples chaotically): calibrate them with one momentum-1 train-mode pass
+    O.BN_MOMENTUM = 1.0
+    try:
+        with torch.no_grad():
+            O.forward(sd, img, training=True, update_stats=True)
+    finally:
+        O.BN_MOMENTUM = 0.1
+    model = make_model(seed, arch)
+    model.load_state_dict(sd)
+    model.eval()
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    with torch.no_grad():
+        pe = model(img.to(DEV))
+    report(arch + ' eval preds', pe.cpu(), O.forward(sd, img, training=False), MAP_ATOL, MAP_RTOL)
+    model.train()
+    trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = trainer.step(img.to(DEV), gts.to(DEV))
+    preds_o, losses_o, grads_o = O.loss_and_grads(sd, img, gts)
+    report(arch + ' preds', preds.cpu(), preds_o, MAP_ATOL, MAP_RTOL)
+    report(arch + ' losses', losses.cpu().double(), torch.tensor(losses_o).double(), 1e-4, 1e-4)
+    worst = 1.0
+    for k, g in grads_o.items():
+        if g is None or (k.endswith('.bias') and ('conv.bias' in k or k.endswith(('.0.bias', '.3.bias')))):
+            continue
+        a, b = model.engine.grad_views[k].double().cpu().reshape(-1), g.double().reshape(-1)
+        if float(b.norm()) == 0:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        rel = float((a - b).norm() / b.norm())
+        worst = min(worst, cos)
+        assert cos >= 0.99 and rel <= 0.15, (k, cos, rel)
+    print('%s: worst gradient cosine %.6f' % (arch, worst))
+    if 'deformable' in arch:
+        k = 'backbone.layer2.0.conv2_offset.weight'
+        assert float(model.engine.grad_views[k].abs().max()) > 0
+    assert worst >= (0.995 if 'resnet50' in arch else 0.9999), worst
+    for k, v in model.state_dict().items():  # running statistics after one train step
+        if 'running' in k:
+            assert torch.allclose(v.cpu(), sd[k], atol=1e-4, rtol=1e-3), k

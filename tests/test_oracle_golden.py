@@ -24,7 +24,7 @@ def test_state_spec_matches_reference_layout():
     assert live == 12269378
 
 
-@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled', 'r50_train_1x64', 'r50_train_2x96'])
+@pytest.mark.parametrize('name', ['train_1x64', 'train_2x128', 'train_2x96_scaled', 'r50_train_1x128', 'r50_train_2x96'])
 def test_oracle_train_steps_match_reference(golden_dir, name):
     torch.set_num_threads(8)
     z = np.load(os.path.join(golden_dir, name + '.npz'))
