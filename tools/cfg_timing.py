@@ -1,0 +1,25 @@
+"""GPU: wall time per train step of a BASELINE config shape that is not the bench headline (parity cases).
+usage: python tools/cfg_timing.py <backbone> <batch> <size> <math> [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
+import bench
+
+arch, n, size, math_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+torch.manual_seed(0)
+m = DBTextModel(arch).cuda().train()
+m.engine.set_conv_math(math_)
+tr = DBTrainer(m, DBLoss(), FusedAdam(m))
+img, gts = bench.synthetic(n, size, 42, torch.device('cuda'))
+for _ in range(3):
+    p, l = tr.step(img, gts)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    p, l = tr.step(img, gts)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print('%s bs%d %dx%d %s: %.2f ms/step, %.1f images/s, loss %.4f, peak mem %.1f GB' %
+      (arch, n, size, size, math_, dt * 1e3, n / dt, float(l[4]), torch.cuda.max_memory_allocated() / 2**30))
