@@ -70,7 +70,7 @@ struct IgemmParams {
     int stat_rows;      // total M-tiles of the launch
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
     unsigned src_bytes;
-    // MODE 2 only: per class exclusive end of its workgroup range, first M-tile index, weight-panel offset (floats)
+    // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
     // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
     int ksplit, kt_per;
@@ -204,9 +204,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParam
         q_row_base = c * mtiles;
         q.R = q.S = q.K = q.KT = q.pad_h = q.pad_w = 0;  // per level, see level_setup
     } else if (MODE == 2) {
-        int c = 0;
-        while (c + 1 < p.ncls && tile >= p.tile_end[c]) ++c;
-        tile -= c ? p.tile_end[c - 1] : 0;
+        // tile order: position major, class minor.  The classes differ in taps (4/2/2/1 of a 3x3 at stride 2), so a
+        // class-major order would hand the heavy class to two of the eight XCDs (dbn_xcd_remap gives each XCD a contiguous
+        // run) — measured 1.8x slower; interleaved, every XCD gets the same mix and the classes of one image region share
+        // their source pixels through L2.  Classes with fewer tiles than the largest leave their slot empty.
+        // The class of slot t rotates with t / (8 * ncls): workgroups reach a CU round-robin (every 32nd of an XCD's run),
+        // and without the rotation each CU would again see a single class.
+        const int slot = tile / p.ncls;
+        const int c = (tile + (slot >> 3)) % p.ncls;
+        tile = slot;
+        if (tile >= p.tile_end[c]) return;
         q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
         q_row_base = p.row_base[c];
         q_wpk_off = p.wpk_off[c];
@@ -562,9 +569,10 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
             const int mtiles = (q.K > 0 && q.M > 0) ? dbn_ceil_div(q.M, BM) : 0;
             p.row_base[c] = rows;
             rows += mtiles;
-            grid += mtiles * (p.Cd / BN);
-            p.tile_end[c] = grid;
+            p.tile_end[c] = mtiles * (p.Cd / BN);
+            grid = p.tile_end[c] > grid ? p.tile_end[c] : grid;
         }
+        grid *= p.ncls;  // class-interleaved tile order: ncls slots per position (see the kernel)
     } else {
         rows = dbn_ceil_div(p.N * p.Hdf * p.Wdf, BM);
         grid = rows * (p.Cd / BN);
