@@ -190,7 +190,8 @@ def main():
             'config': {'workload': 'ResNet18-FPN-DBHead DBNet train step (fwd+DBLoss+bwd+Adam), %dx%d, bs %d/GPU, fp32, '
                                    'random-init weights (BASELINE configs[1])' % (args.size, args.size, args.batch),
                        'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
-                       'grad_allreduce': 'one RCCL all-reduce of the flat 49 MB fp32 gradient buffer per step' if world > 1 else None},
+                       'grad_allreduce': ('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, issued as 4 contiguous buckets under '
+                                          'the backward pass (FPN+head, layer4, layer3, rest)') if world > 1 else None},
             'roofline': roofline,
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / ms, 2),
             'kernels': kernels,

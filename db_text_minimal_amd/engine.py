@@ -103,6 +103,7 @@ class Engine:
         self._live = None
         self.nbt_pending = {}
         self.prof = None  # optional KernelTimer
+        self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
         self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = bf16 operands
         self.overlap_wgrad = False  # optional: weight gradients on a second HIP stream (measured +1.3 %, off by default)
         self._side = None
@@ -723,6 +724,9 @@ class Engine:
         self.up_bwd(dp4pre, dP['reduce_conv_c5'], 0, True)
         cbr_bwd('reduce_conv_c4', fpn.reduce_conv_c4, c4, dp4pre, dc4, False)
         cbr_bwd('reduce_conv_c5', fpn.reduce_conv_c5, c5, dP['reduce_conv_c5'], dc5, False)
+        if self.grad_ready_hook is not None:  # every FPN / head gradient kernel has been enqueued
+            self.join_side()
+            self.grad_ready_hook('segmentation')
         # backbone, deepest stage first; dC[...] already holds the FPN contribution
         bb = m.backbone
         dpool = self.buf('stem/dpool', *B['stem/pool'].shape)
@@ -739,6 +743,9 @@ class Engine:
                 else:
                     dx, acc = dpool, False
                 self._block_bwd(name, layer[bi], xin, dout, dx, acc)
+            if self.grad_ready_hook is not None and li >= 3:
+                self.join_side()
+                self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)
         check(L.dbn_bnrelu_maxpool_bwd(y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),

@@ -6,10 +6,12 @@
     optimizer.zero_grad(); total.backward(); optimizer.step()               # :169-172
 
 `DBTrainer.step` issues exactly that sequence as HIP kernels on one stream, with
-no autograd graph, no host synchronisation and (for world_size > 1) ONE
-all-reduce of the flat gradient buffer over RCCL/xGMI per step; the 1/world
-average is folded into the Adam kernel.  BatchNorm statistics and the loss
-normalisers stay per GPU (standard data-parallel semantics).
+no autograd graph, no host synchronisation and (for world_size > 1) one sum
+all-reduce of the flat gradient buffer over RCCL/xGMI per step, issued as four
+contiguous buckets in the order the backward pass completes them (FPN+head, layer4,
+layer3, the rest) so that all but the last ~3 MB travel under the remaining backward
+kernels; the 1/world average is folded into the Adam kernel.  BatchNorm statistics
+and the loss normalisers stay per GPU (standard data-parallel semantics).
 """
 import os
 
@@ -37,6 +39,50 @@ def allreduce_flat_grads(flat_grad, world, group=None):
     return 1.0 / world
 
 
+# backward completes the gradient buffer back to front: FPN+head first, then backbone stages 4..1, stem last
+GRAD_STAGES = ('segmentation', 'layer4', 'layer3', 'rest')
+
+
+def bucket_ranges(names, offsets, total):
+    """[lo, hi) float ranges of the flat gradient buffer per GRAD_STAGES entry.  `names`/`offsets`: the live parameters in
+    flat-buffer order (named_parameters order: backbone stem, layer1..4, FPN, head).  The ranges are contiguous and
+    cover [0, total) exactly once."""
+    def first(prefix):
+        for n, off in zip(names, offsets):
+            if n.startswith(prefix):
+                return off
+        raise KeyError(prefix)
+    l3, l4, seg = first('backbone.layer3.'), first('backbone.layer4.'), first('segmentation_body.')
+    assert 0 < l3 < l4 < seg < total
+    return {'segmentation': (seg, total), 'layer4': (l4, seg), 'layer3': (l3, l4), 'rest': (0, l3)}
+
+
+class BucketedAllReduce:
+    """The data-parallel exchange of one step: the same sum as one all-reduce over the flat gradient buffer, issued per
+    bucket as soon as the backward pass has enqueued that bucket's last gradient kernel (`ready`), asynchronously on the
+    process group's stream, and joined before the optimizer (`finish`)."""
+
+    def __init__(self, flat_grad, ranges, world, group=None):
+        self.flat, self.ranges, self.world, self.group = flat_grad, ranges, world, group
+        self.pending, self.done = [], set()
+
+    def ready(self, stage):
+        lo, hi = self.ranges[stage]
+        assert stage not in self.done
+        self.done.add(stage)
+        self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Issues whatever has not been announced (at least 'rest'), waits for all buckets; returns the mean factor."""
+        for stage in GRAD_STAGES:
+            if stage not in self.done:
+                self.ready(stage)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done = [], set()
+        return 1.0 / self.world
+
+
 class DBTrainer:
     def __init__(self, model, criterion, optimizer=None, process_group=None, lr=0.005):
         self.model = model
@@ -45,7 +91,7 @@ class DBTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._gone = None
-        self.comm_stream = None
+        self.overlap_allreduce = True  # bucketed exchange under the backward pass; False: one all-reduce after it
 
     def _loss(self, preds, gts):
         """dbn_db_loss_fwd + _bwd with d(total)=1; returns (losses[5], dpreds)."""
@@ -89,8 +135,19 @@ class DBTrainer:
         gts = gts.contiguous().float()
         losses, dpreds = self._loss(preds, gts)
         self.optimizer.zero_grad()
-        eng.backward(dpreds)
-        scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
+        distributed = dist.is_available() and dist.is_initialized()
+        if distributed and self.overlap_allreduce:
+            names = [n for n, _ in eng.live_params]
+            ex = BucketedAllReduce(eng.flat_grad, bucket_ranges(names, eng.offsets, eng.flat_grad.numel()), self.world, self.pg)
+            eng.grad_ready_hook = ex.ready
+            try:
+                eng.backward(dpreds)
+            finally:
+                eng.grad_ready_hook = None
+            scale = ex.finish()
+        else:
+            eng.backward(dpreds)
+            scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
         self.optimizer.step(grad_scale=scale)
         return preds, losses
 
