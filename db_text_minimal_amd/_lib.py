@@ -54,9 +54,9 @@ SIGNATURES = {
     'dbn_fpn_scatter_wgrad': 'ppppiipp',
     'dbn_nchw3_to_nhwc4': 'ppiiip',
     'dbn_add_inplace': 'pplp',
-    'dbn_head_tail_fwd': 'ppppppp' + 'iiii' + 'f' + 'p',
+    'dbn_head_tail_fwd': 'p' * 11 + 'iiii' + 'f' + 'p',
     'dbn_head_tail_bwd_ws_floats': '',
-    'dbn_head_tail_bwd': 'p' * 12 + 'iiii' + 'ff' + 'pp',
+    'dbn_head_tail_bwd': 'p' * 16 + 'iiii' + 'ff' + 'pp',
     'dbn_db_loss_ws_bytes': '',
     'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',

@@ -28,9 +28,20 @@ __device__ __forceinline__ float group16_sum(float v) {
 // (ConvTranspose2d weight [64,1,2,2]); out: [N,CH,2Hq,2Wq], CH=3 (train) or 2 (eval).
 __global__ void head_tail_fwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ bias_b,
-                                     const float* __restrict__ bias_t, float* __restrict__ out, int N, int Hq, int Wq, int CH,
+                                     const float* __restrict__ bias_t, const float* __restrict__ sc_b,
+                                     const float* __restrict__ sh_b, const float* __restrict__ sc_t,
+                                     const float* __restrict__ sh_t, float* __restrict__ out, int N, int Hq, int Wq, int CH,
                                      float kstep) {
     const int q = threadIdx.x & 15;
+    // optional fused BatchNorm + ReLU of the inputs (xb/xt are then the pre-BN conv outputs): this lane's 4 channels
+    const bool bn = sc_b != nullptr;
+    f32x4 scb = {1.f, 1.f, 1.f, 1.f}, shb = {0.f, 0.f, 0.f, 0.f}, sct = scb, sht = shb;
+    if (bn) {
+        scb = *reinterpret_cast<const f32x4*>(sc_b + 4 * q);
+        shb = *reinterpret_cast<const f32x4*>(sh_b + 4 * q);
+        sct = *reinterpret_cast<const f32x4*>(sc_t + 4 * q);
+        sht = *reinterpret_cast<const f32x4*>(sh_t + 4 * q);
+    }
     const long npx = (long)N * Hq * Wq;
     const long gstride = (long)gridDim.x * (blockDim.x >> 4);
     // weights of this lane's 4 channels: w[ci][ab]
@@ -44,8 +55,15 @@ __global__ void head_tail_fwd_kernel(const float* __restrict__ xb, const float* 
     const int H = 2 * Hq, W = 2 * Wq;
     const long HW = (long)H * W;
     for (long px = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4); px < npx; px += gstride) {
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
-        const f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
+        f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        if (bn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vb[e] = dbn_affine_relu(vb[e], scb[e], shb[e]);
+                vt[e] = dbn_affine_relu(vt[e], sct[e], sht[e]);
+            }
+        }
         f32x4 sb = {0.f, 0.f, 0.f, 0.f}, stt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -79,10 +97,20 @@ __global__ void head_tail_fwd_kernel(const float* __restrict__ xb, const float* 
 // part: [grid][2*(256+1)] block partials of (dwb[64*4], dbias_b, dwt[64*4], dbias_t).
 __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ preds,
-                                     const float* __restrict__ dpreds, float* __restrict__ dxb, float* __restrict__ dxt,
+                                     const float* __restrict__ dpreds, const float* __restrict__ sc_b,
+                                     const float* __restrict__ sh_b, const float* __restrict__ sc_t,
+                                     const float* __restrict__ sh_t, float* __restrict__ dxb, float* __restrict__ dxt,
                                      float* __restrict__ part, int N, int Hq, int Wq, int CH, float kstep) {
     const int q = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
+    const bool bn = sc_b != nullptr;  // xb/xt are pre-BN conv outputs: the activations are recomputed (same fmaf as the forward)
+    f32x4 scb = {1.f, 1.f, 1.f, 1.f}, shb = {0.f, 0.f, 0.f, 0.f}, sct = scb, sht = shb;
+    if (bn) {
+        scb = *reinterpret_cast<const f32x4*>(sc_b + 4 * q);
+        shb = *reinterpret_cast<const f32x4*>(sh_b + 4 * q);
+        sct = *reinterpret_cast<const f32x4*>(sc_t + 4 * q);
+        sht = *reinterpret_cast<const f32x4*>(sh_t + 4 * q);
+    }
     const long npx = (long)N * Hq * Wq;
     const long gstride = (long)gridDim.x * (blockDim.x >> 4);
     f32x4 wbq[4], wtq[4];
@@ -127,8 +155,15 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
             lb[ab] = __shfl(dlb, (threadIdx.x & 48) + ab, 64);
             lt[ab] = __shfl(dlt, (threadIdx.x & 48) + ab, 64);
         }
-        const f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
-        const f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
+        f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        if (bn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vb[e] = dbn_affine_relu(vb[e], scb[e], shb[e]);
+                vt[e] = dbn_affine_relu(vt[e], sct[e], sht[e]);
+            }
+        }
         f32x4 gb, gt;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -566,11 +601,13 @@ __global__ void pixel_confusion_kernel(const float* __restrict__ preds, long bat
 extern "C" {
 
 int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,
-                      const float* bias_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
+                      const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
     DBN_REQUIRE(xb && xt && wb && wt && bias_b && bias_t && out && (channels == 2 || channels == 3));
+    DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     const long npx = (long)N * Hq * Wq;
     hipLaunchKernelGGL(head_tail_fwd_kernel, dim3(dbn_grid(npx * 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, xb, xt, wb,
-                       wt, bias_b, bias_t, out, N, Hq, Wq, channels, kstep);
+                       wt, bias_b, bias_t, bn_scale_b, bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep);
     return dbn_status();
 }
 
@@ -578,14 +615,17 @@ int dbn_head_tail_bwd_ws_floats() { return 2048 * 2 * 257; }
 
 // dw_b/dw_t: [64*4] (ConvTranspose2d weight grads), dbias_b/dbias_t: [1]
 int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
-                      const float* dpreds, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
+                      const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
                       int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(xb && xt && wb && wt && preds && dpreds && dxb && dxt && dw_b && dbias_b && dw_t && dbias_t && ws);
+    DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     DBN_REQUIRE(channels == 2 || channels == 3);
     hipStream_t st = (hipStream_t)stream;
     const long npx = (long)N * Hq * Wq;
     const int nb = dbn_grid(npx * 16, 256, 2047);
-    hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, dxb, dxt, ws, N, Hq, Wq,
+    hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, bn_scale_b, bn_shift_b,
+                       bn_scale_t, bn_shift_t, dxb, dxt, ws, N, Hq, Wq,
                        channels, kstep);
     // fold partials: layout [dwb 256][dbias_b][dwt 256][dbias_t] -> staged in the tail of ws, then scattered by 4 tiny copies
     float* folded = ws + (long)2048 * 2 * 257 - 2 * 257;

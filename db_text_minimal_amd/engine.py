@@ -516,18 +516,19 @@ class Engine:
             ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train)
             za = self.bn_apply(ya, s_, h_, br + '/z0')
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
-            z1[br] = self.bn_apply(yb, s_, h_, br + '/z1')
+            z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
         ch = 3 if train else 2
-        Hh, Wh = z1['binarize'].shape[1], z1['binarize'].shape[2]
+        (yb_, sb_, hb_), (yt_, st_, ht_) = z1['binarize'], z1['thresh']
+        Hh, Wh = yb_.shape[1], yb_.shape[2]
         resample = (2 * Hh, 2 * Wh) != (H, W)  # only when H or W is not a multiple of 32 (models.py:43-46)
         out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
         head_out = self.buf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
         b6, t6 = head.binarize[6], head.thresh[6]
         if self.prof:  # reads 2 x 64ch at half resolution, writes `ch` full-resolution maps
             self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * Hh * Wh * 128 + 4.0 * N * 4 * Hh * Wh * ch)
-        check(L.dbn_head_tail_fwd(z1['binarize'].data_ptr(), z1['thresh'].data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(),
-                                  b6.bias.data_ptr(), t6.bias.data_ptr(), head_out.data_ptr(), N, Hh, Wh, ch, float(head.k), st),
-              'head_tail_fwd')
+        check(L.dbn_head_tail_fwd(yb_.data_ptr(), yt_.data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(), b6.bias.data_ptr(),
+                                  t6.bias.data_ptr(), sb_.data_ptr(), hb_.data_ptr(), st_.data_ptr(), ht_.data_ptr(),
+                                  head_out.data_ptr(), N, Hh, Wh, ch, float(head.k), st), 'head_tail_fwd')
         if self.prof:
             self.prof.end()
         if resample:
@@ -661,8 +662,11 @@ class Engine:
         dz1t = self.buf('thresh/dz1', N, Hh, Wh, 64)
         ws = self.scratch('_head_ws', L.dbn_head_tail_bwd_ws_floats())
         G = self.grad_views
-        check(L.dbn_head_tail_bwd(B['binarize/z1'].data_ptr(), B['thresh/z1'].data_ptr(), b6.weight.data_ptr(),
-                                  t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), dz1b.data_ptr(), dz1t.data_ptr(),
+        hb, ht = 'segmentation_head.binarize.4', 'segmentation_head.thresh.4'
+        check(L.dbn_head_tail_bwd(B['binarize/y1'].data_ptr(), B['thresh/y1'].data_ptr(), b6.weight.data_ptr(),
+                                  t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), B[hb + '/scale'].data_ptr(),
+                                  B[hb + '/shift'].data_ptr(), B[ht + '/scale'].data_ptr(), B[ht + '/shift'].data_ptr(),
+                                  dz1b.data_ptr(), dz1t.data_ptr(),
                                   G['segmentation_head.binarize.6.weight'].data_ptr(),
                                   G['segmentation_head.binarize.6.bias'].data_ptr(),
                                   G['segmentation_head.thresh.6.weight'].data_ptr(),

@@ -146,12 +146,18 @@ int dbn_fpn_scatter_wgrad(const float* t0, const float* t1, const float* t2, con
 int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream);
 int dbn_add_inplace(const float* x, float* y, long n, void* stream);
 
-/* ---- DB head tail (segmentation_head.py:28-29,35-45,77-79,106-108) */
+/* ---- DB head tail (segmentation_head.py:28-29,35-45,77-79,106-108): last ConvTranspose2d(64,1,2,2) + Sigmoid of both
+ * branches, step_function, concat.  With bn_scale/shift (all four [64], or all NULL) xb/xt are the PRE-BatchNorm outputs
+ * of the preceding ConvTranspose2d and BN+ReLU (segmentation_head.py:27,74-75) is applied on load, so the post-BN
+ * activations of the two largest tensors of the network are never written. */
 int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,
-                      const float* bias_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
+                      const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
 int dbn_head_tail_bwd_ws_floats(void);
+/* dxb/dxt: gradients w.r.t. the (post-ReLU) inputs of the last ConvTranspose2d; the BatchNorm backward applies the mask */
 int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
-                      const float* dpreds, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
+                      const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
                       int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
 
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W] */

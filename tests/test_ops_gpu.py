@@ -249,7 +249,7 @@ def test_head_tail(N, Hq, Wq, ch):
     wbd, wtd, bbd, btd = d(wb), d(wt), d(bb), d(bt)
     out = torch.full(ref.shape, float('nan'), device=DEV)
     _lib.check(L().dbn_head_tail_fwd(xbs.data_ptr(), xts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), bbd.data_ptr(),
-                                     btd.data_ptr(), out.data_ptr(), N, Hq, Wq, ch, 50.0, stream()), 'head fwd')
+                                     btd.data_ptr(), None, None, None, None, out.data_ptr(), N, Hq, Wq, ch, 50.0, stream()), 'head fwd')
     report('head tail fwd', out.cpu(), ref, 2e-6, 1e-5)
     if ch != 3:
         return
@@ -259,7 +259,7 @@ def test_head_tail(N, Hq, Wq, ch):
     ws = torch.empty(L().dbn_head_tail_bwd_ws_floats(), device=DEV)
     dpd = d(dpred)
     _lib.check(L().dbn_head_tail_bwd(xbs.data_ptr(), xts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), out.data_ptr(),
-                                     dpd.data_ptr(), dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
+                                     dpd.data_ptr(), None, None, None, None, dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
                                      dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, ch, 50.0, 1.0, ws.data_ptr(), stream()),
                'head bwd')
     sc = 1e-4
@@ -625,3 +625,41 @@ def test_deformable_conv(case, zero_offsets):
     g = torch.empty(Co, C, 3, 3, device=DEV)
     _lib.check(L().dbn_permute_weight(gp.data_ptr(), g.data_ptr(), Co, C, 9, 0, 1.0, stream()), 'permute back')
     report('deform conv dweight', g.cpu(), dw_ref, 2e-5 * float(dw_ref.abs().max()) + 1e-5, 1e-4)
+
+
+def test_head_tail_with_fused_batchnorm_relu():
+    """bn_scale/shift given: the kernels take the PRE-BN ConvTranspose outputs and apply BN + ReLU on load
+    (segmentation_head.py:27-29,74-79); gradients are w.r.t. the post-ReLU activations."""
+    N, Hq, Wq = 2, 9, 7
+    yb, yt = rnd(N, 64, Hq, Wq, seed=1), rnd(N, 64, Hq, Wq, seed=2)
+    sc = [rnd(64, seed=10 + i) * 0.3 + 1 for i in range(2)]
+    sh = [rnd(64, seed=20 + i) * 0.5 for i in range(2)]
+    zb = torch.relu(yb * sc[0].view(1, 64, 1, 1) + sh[0].view(1, 64, 1, 1)).requires_grad_(True)
+    zt = torch.relu(yt * sc[1].view(1, 64, 1, 1) + sh[1].view(1, 64, 1, 1)).requires_grad_(True)
+    wb = rnd(64, 1, 2, 2, seed=3, scale=0.2).requires_grad_(True)
+    wt = rnd(64, 1, 2, 2, seed=4, scale=0.2).requires_grad_(True)
+    bb, bt = torch.tensor([0.1], requires_grad=True), torch.tensor([-0.2], requires_grad=True)
+    P = torch.sigmoid(F.conv_transpose2d(zb, wb, bb, 2))
+    T = torch.sigmoid(F.conv_transpose2d(zt, wt, bt, 2))
+    ref = torch.cat([P, T, torch.reciprocal(1 + torch.exp(-50 * (P - T)))], 1)
+    dpred = rnd(*ref.shape, seed=5)
+    grads = torch.autograd.grad(ref, (zb, zt, wb, bb, wt, bt), dpred)
+    d = lambda t: t.detach().contiguous().to(DEV)
+    ybs, yts = nhwc(yb), nhwc(yt)
+    wbd, wtd, bbd, btd = d(wb), d(wt), d(bb), d(bt)
+    bn = [d(sc[0]), d(sh[0]), d(sc[1]), d(sh[1])]
+    out = torch.full(ref.shape, float('nan'), device=DEV)
+    _lib.check(L().dbn_head_tail_fwd(ybs.data_ptr(), yts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), bbd.data_ptr(), btd.data_ptr(),
+                                     *[t.data_ptr() for t in bn], out.data_ptr(), N, Hq, Wq, 3, 50.0, stream()), 'head fwd')
+    report('head tail fwd (fused BN+ReLU)', out.cpu(), ref, 2e-6, 1e-5)
+    dxb, dxt = torch.empty_like(ybs), torch.empty_like(yts)
+    dwb, dwt = torch.empty(256, device=DEV), torch.empty(256, device=DEV)
+    dbb, dbt = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    ws = torch.empty(L().dbn_head_tail_bwd_ws_floats(), device=DEV)
+    _lib.check(L().dbn_head_tail_bwd(ybs.data_ptr(), yts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), out.data_ptr(), d(dpred).data_ptr(),
+                                     *[t.data_ptr() for t in bn], dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
+                                     dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, 3, 50.0, 1.0, ws.data_ptr(), stream()), 'head bwd')
+    report('fused head bwd dz_b', nchw(dxb), grads[0], 1e-4, 1e-3)
+    report('fused head bwd dz_t', nchw(dxt), grads[1], 1e-4, 1e-3)
+    report('fused head bwd dwb', dwb.cpu().view(64, 1, 2, 2), grads[2], 1e-3, 1e-3)
+    report('fused head bwd dwt', dwt.cpu().view(64, 1, 2, 2), grads[4], 1e-3, 1e-3)
