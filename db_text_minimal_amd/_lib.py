@@ -43,6 +43,7 @@ SIGNATURES = {
     'dbn_bn_eval_coef': 'ippppfppp',
     'dbn_bn_apply': 'pppppppliip',
     'dbn_bn_backward': 'pppppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
+    'dbn_bn_backward_from_sums': 'ppppppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
     'dbn_col_sum': 'piipfpp',
     'dbn_bnrelu_maxpool_fwd': 'ppppiiiip',
     'dbn_bnrelu_maxpool_bwd': 'ppppppiiiip',
@@ -56,7 +57,7 @@ SIGNATURES = {
     'dbn_add_inplace': 'pplp',
     'dbn_head_tail_fwd': 'p' * 11 + 'iiii' + 'f' + 'p',
     'dbn_head_tail_bwd_ws_floats': '',
-    'dbn_head_tail_bwd': 'p' * 16 + 'iiii' + 'ff' + 'pp',
+    'dbn_head_tail_bwd': 'p' * 21 + 'iiii' + 'ff' + 'pp',
     'dbn_db_loss_ws_bytes': '',
     'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',

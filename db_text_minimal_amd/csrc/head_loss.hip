@@ -26,7 +26,7 @@ __device__ __forceinline__ float group16_sum(float v) {
 
 // xb/xt: [N,Hq,Wq,64] inputs of the last ConvT (already BN+ReLU'd);  wb/wt: [64][4]
 // (ConvTranspose2d weight [64,1,2,2]); out: [N,CH,2Hq,2Wq], CH=3 (train) or 2 (eval).
-__global__ void head_tail_fwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
+__global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ bias_b,
                                      const float* __restrict__ bias_t, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
@@ -95,11 +95,13 @@ __global__ void head_tail_fwd_kernel(const float* __restrict__ xb, const float* 
 // Backward.  For each quarter pixel: dl_b[ab], dl_t[ab] (grad wrt the two logits) from
 // dpreds and the saved maps; dxb = sum_ab dl_b[ab]*wb[ci][ab]; dwb[ci][ab] += xb[ci]*dl_b[ab].
 // part: [grid][2*(256+1)] block partials of (dwb[64*4], dbias_b, dwt[64*4], dbias_t).
-__global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
+__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ preds,
                                      const float* __restrict__ dpreds, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
-                                     const float* __restrict__ sh_t, float* __restrict__ dxb, float* __restrict__ dxt,
+                                     const float* __restrict__ sh_t, const float* __restrict__ mean_b,
+                                     const float* __restrict__ rstd_b, const float* __restrict__ mean_t,
+                                     const float* __restrict__ rstd_t, float* __restrict__ dxb, float* __restrict__ dxt,
                                      float* __restrict__ part, int N, int Hq, int Wq, int CH, float kstep) {
     const int q = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
@@ -119,6 +121,17 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
         wbq[e] = *reinterpret_cast<const f32x4*>(wb + (4 * q + e) * 4);
         wtq[e] = *reinterpret_cast<const f32x4*>(wt + (4 * q + e) * 4);
     }
+    // optional: the two per-channel reductions of the BatchNorm backward that consumes dxb/dxt (sum of the masked
+    // gradient, sum of masked gradient * xhat), so that it does not have to re-read 2 x 2 x 420 MB to form them
+    const bool bnsum = bn && mean_b != nullptr;
+    f32x4 mub = {0.f, 0.f, 0.f, 0.f}, rsb = mub, mut = mub, rst = mub;
+    if (bnsum) {
+        mub = *reinterpret_cast<const f32x4*>(mean_b + 4 * q);
+        rsb = *reinterpret_cast<const f32x4*>(rstd_b + 4 * q);
+        mut = *reinterpret_cast<const f32x4*>(mean_t + 4 * q);
+        rst = *reinterpret_cast<const f32x4*>(rstd_t + 4 * q);
+    }
+    f32x4 s1b = {0.f, 0.f, 0.f, 0.f}, s2b = s1b, s1t = s1b, s2t = s1b;
     const int H = 2 * Hq, W = 2 * Wq;
     const long HW = (long)H * W;
     f32x4 awb[4], awt[4];  // [e][ab]
@@ -157,6 +170,7 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
         }
         f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
         f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        const f32x4 yb = vb, yt = vt;
         if (bn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -174,13 +188,24 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
         }
         *reinterpret_cast<f32x4*>(dxb + px * 64 + 4 * q) = gb;
         *reinterpret_cast<f32x4*>(dxt + px * 64 + 4 * q) = gt;
+        if (bnsum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float mb = vb[e] > 0.f ? gb[e] : 0.f, mt = vt[e] > 0.f ? gt[e] : 0.f;  // ReLU mask as in bn_bwd ('self')
+                s1b[e] += mb;
+                s2b[e] += mb * ((yb[e] - mub[e]) * rsb[e]);
+                s1t[e] += mt;
+                s2t[e] += mt * ((yt[e] - mut[e]) * rst[e]);
+            }
+        }
         if (q == 0) {
             abb += lb[0] + lb[1] + lb[2] + lb[3];
             abt += lt[0] + lt[1] + lt[2] + lt[3];
         }
     }
     // block reduction: groups with the same q hold the same channel slots
-    __shared__ float red[16][2 * 257];  // [grp][...]
+    constexpr int ROWS = 2 * 257 + 4 * 64;  // dwb 256, dbias_b, dwt 256, dbias_t, then the BN sums s1_b, s2_b, s1_t, s2_t [64] each
+    __shared__ float red[16][ROWS];  // [grp][...]
     {
         float* r = red[grp];
 #pragma unroll
@@ -194,12 +219,19 @@ __global__ void head_tail_bwd_kernel(const float* __restrict__ xb, const float* 
             r[256] = abb;
             r[257 + 256] = abt;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[514 + 4 * q + e] = s1b[e];
+            r[514 + 64 + 4 * q + e] = s2b[e];
+            r[514 + 128 + 4 * q + e] = s1t[e];
+            r[514 + 192 + 4 * q + e] = s2t[e];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) {
+    for (int i = threadIdx.x; i < ROWS; i += blockDim.x) {
         float s = 0.f;
         for (int g = 0; g < 16; ++g) s += red[g][i];
-        part[(long)i * gridDim.x + blockIdx.x] = s;  // transposed: [514][blocks]
+        part[(long)i * gridDim.x + blockIdx.x] = s;  // transposed: [ROWS][blocks]
     }
 }
 
@@ -611,24 +643,28 @@ int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const f
     return dbn_status();
 }
 
-int dbn_head_tail_bwd_ws_floats() { return 2048 * 2 * 257; }
+int dbn_head_tail_bwd_ws_floats() { return 2048 * (2 * 257 + 4 * 64); }
 
 // dw_b/dw_t: [64*4] (ConvTranspose2d weight grads), dbias_b/dbias_t: [1]
 int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
                       const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
-                      const float* bn_shift_t, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
-                      int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
+                      const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
+                      const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
+                      float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(xb && xt && wb && wt && preds && dpreds && dxb && dxt && dw_b && dbias_b && dw_t && dbias_t && ws);
     DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     DBN_REQUIRE(channels == 2 || channels == 3);
+    const bool sums = bn_sums != nullptr;
+    DBN_REQUIRE(!sums || (bn_scale_b && bn_mean_b && bn_rstd_b && bn_mean_t && bn_rstd_t));
     hipStream_t st = (hipStream_t)stream;
     const long npx = (long)N * Hq * Wq;
     const int nb = dbn_grid(npx * 16, 256, 2047);
+    constexpr int ROWS = 2 * 257 + 4 * 64;
     hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, bn_scale_b, bn_shift_b,
-                       bn_scale_t, bn_shift_t, dxb, dxt, ws, N, Hq, Wq,
+                       bn_scale_t, bn_shift_t, sums ? bn_mean_b : nullptr, bn_rstd_b, bn_mean_t, bn_rstd_t, dxb, dxt, ws, N, Hq, Wq,
                        channels, kstep);
     // fold partials: layout [dwb 256][dbias_b][dwt 256][dbias_t] -> staged in the tail of ws, then scattered by 4 tiny copies
-    float* folded = ws + (long)2048 * 2 * 257 - 2 * 257;
+    float* folded = ws + (long)2048 * ROWS - 2 * 257;
     // nb <= 2047 partial rows may be used without touching the tail
     if (nb >= 2048) return DBN_ERR_ARG;
     hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(2 * 257, 8)), dim3(256), 0, st, ws, nb, 2 * 257, folded,
@@ -637,6 +673,9 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
     (void)hipMemcpyAsync(dbias_b, folded + 256, sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dw_t, folded + 257, 256 * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(dbias_t, folded + 257 + 256, sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (sums)  // [s1_b | s2_b | s1_t | s2_t]: two [2][64] blocks for dbn_bn_backward_from_sums
+        hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(256, 8)), dim3(256), 0, st, ws + (long)514 * nb, nb, 256, bn_sums,
+                           1.0f);
     return dbn_status();
 }
 

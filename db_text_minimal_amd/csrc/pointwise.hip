@@ -567,10 +567,10 @@ int dbn_bn_apply(const float* y, const float* scale, const float* shift, const f
     return dbn_status();
 }
 
-int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
-                    const float* save_mean, const float* save_rstd,
-                    const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
-                    float grad_scale, float* ws, void* stream) {
+static int bn_backward_impl(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
+                            const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
+                            float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws,
+                            void* stream) {
     DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
     DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     DBN_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(zmask && mask_scale));
@@ -579,14 +579,37 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale,
     float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
     float* c2 = c1 + C;
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout, save_mean,
-                       save_rstd, M, C, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
-                       grad_scale);
+    if (sums) {  // the producer of dout already reduced sum(g) and sum(g * xhat) per channel: [2][C], a single "partial"
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, 1, M, C, dgamma, dbeta, c1, c2,
+                           grad_scale);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout,
+                           save_mean, save_rstd, M, C, ws);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
+                           grad_scale);
+    }
     const long total4 = (long)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout,
                        save_mean, save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
     return dbn_status();
+}
+
+int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
+                    const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout, int gout_accumulate,
+                    float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws, void* stream) {
+    return bn_backward_impl(nullptr, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                            dgamma, dbeta, M, C, grad_scale, ws, stream);
+}
+
+// BatchNorm backward whose two per-channel reductions were already produced by the kernel that wrote dout
+// (sums[0][c] = sum of the ReLU-masked dout, sums[1][c] = sum of masked dout * xhat): only finalize + apply run.
+int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
+                              const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
+                              float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale,
+                              float* ws, void* stream) {
+    DBN_REQUIRE(sums);
+    return bn_backward_impl(sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                            dgamma, dbeta, M, C, grad_scale, ws, stream);
 }
 
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {

@@ -415,7 +415,7 @@ class Engine:
                                   y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
         return out
 
-    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False):
+    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False, sums=None):
         """mask: None (no ReLU), 'self' (ReLU directly on this BN's output: recomputed from y with the
         forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates)."""
         C = y.shape[-1]
@@ -426,11 +426,14 @@ class Engine:
             msc, msh = self.bufs[name + '/scale'], self.bufs[name + '/shift']
         elif mask is not None:
             zmask = mask
-        check(self.L.dbn_bn_backward(y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
-                                     self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
-                                     self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
-                                     self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(), M, C,
-                                     self.grad_scale, self.reduce_ws().data_ptr(), self.stream), 'bn backward ' + name)
+        args = (y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(), self.bufs[name + '/mean'].data_ptr(),
+                self.bufs[name + '/rstd'].data_ptr(), self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
+                self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(), M, C, self.grad_scale,
+                self.reduce_ws().data_ptr(), self.stream)
+        if sums is not None:  # [2][C] reductions already produced by the kernel that wrote dout
+            check(self.L.dbn_bn_backward_from_sums(sums.data_ptr(), *args), 'bn backward ' + name)
+        else:
+            check(self.L.dbn_bn_backward(*args), 'bn backward ' + name)
         return dy
 
     def up_fwd(self, src, addend, dst, coff=0):
@@ -663,10 +666,12 @@ class Engine:
         ws = self.scratch('_head_ws', L.dbn_head_tail_bwd_ws_floats())
         G = self.grad_views
         hb, ht = 'segmentation_head.binarize.4', 'segmentation_head.thresh.4'
+        bn_sums = self.buf('head/bn4_sums', 4, 64)  # the kernel also reduces what the two BatchNorm backwards need
         check(L.dbn_head_tail_bwd(B['binarize/y1'].data_ptr(), B['thresh/y1'].data_ptr(), b6.weight.data_ptr(),
                                   t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), B[hb + '/scale'].data_ptr(),
                                   B[hb + '/shift'].data_ptr(), B[ht + '/scale'].data_ptr(), B[ht + '/shift'].data_ptr(),
-                                  dz1b.data_ptr(), dz1t.data_ptr(),
+                                  B[hb + '/mean'].data_ptr(), B[hb + '/rstd'].data_ptr(), B[ht + '/mean'].data_ptr(),
+                                  B[ht + '/rstd'].data_ptr(), bn_sums.data_ptr(), dz1b.data_ptr(), dz1t.data_ptr(),
                                   G['segmentation_head.binarize.6.weight'].data_ptr(),
                                   G['segmentation_head.binarize.6.bias'].data_ptr(),
                                   G['segmentation_head.thresh.6.weight'].data_ptr(),
@@ -677,7 +682,7 @@ class Engine:
         for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1')
+            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1', sums=bn_sums[2 * i:2 * i + 2])
             dz0 = self.buf(br + '/dz0', *B[br + '/z0'].shape)
             self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0)
             dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0')

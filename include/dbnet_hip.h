@@ -116,6 +116,11 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale,
                     const float* save_mean, const float* save_rstd,
                     const float* gamma, float* dy, float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C,
                     float grad_scale, float* ws, void* stream);
+/* the same with the two per-channel reductions supplied by the kernel that produced dout (sums[2][C]) */
+int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
+                              const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
+                              float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale,
+                              float* ws, void* stream);
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream);
 
 /* ---- stem pooling (nn.MaxPool2d(3,2,1) over relu(bn1(.)): resnet.py:233-235) */
@@ -154,11 +159,14 @@ int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const f
                       const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
                       const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
 int dbn_head_tail_bwd_ws_floats(void);
-/* dxb/dxt: gradients w.r.t. the (post-ReLU) inputs of the last ConvTranspose2d; the BatchNorm backward applies the mask */
+/* dxb/dxt: gradients w.r.t. the (post-ReLU) inputs of the last ConvTranspose2d; the BatchNorm backward applies the mask.
+ * bn_sums (optional, needs the bn_* pointers incl. the saved mean / rstd): [4][64] = per channel sum of the masked
+ * gradient and of masked gradient * xhat for branch b, then t — feed each [2][64] half to dbn_bn_backward_from_sums. */
 int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
                       const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
-                      const float* bn_shift_t, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t, float* dbias_t,
-                      int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
+                      const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
+                      const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
+                      float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
 
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W] */
 int dbn_db_loss_ws_bytes(void);

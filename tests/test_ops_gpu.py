@@ -259,7 +259,7 @@ def test_head_tail(N, Hq, Wq, ch):
     ws = torch.empty(L().dbn_head_tail_bwd_ws_floats(), device=DEV)
     dpd = d(dpred)
     _lib.check(L().dbn_head_tail_bwd(xbs.data_ptr(), xts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), out.data_ptr(),
-                                     dpd.data_ptr(), None, None, None, None, dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
+                                     dpd.data_ptr(), *([None] * 9), dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
                                      dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, ch, 50.0, 1.0, ws.data_ptr(), stream()),
                'head bwd')
     sc = 1e-4
@@ -656,9 +656,19 @@ def test_head_tail_with_fused_batchnorm_relu():
     dwb, dwt = torch.empty(256, device=DEV), torch.empty(256, device=DEV)
     dbb, dbt = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
     ws = torch.empty(L().dbn_head_tail_bwd_ws_floats(), device=DEV)
+    mean, rstd = [rnd(64, seed=30 + i) * 0.2 for i in range(2)], [rnd(64, seed=40 + i).abs() + 0.5 for i in range(2)]
+    stats = [d(mean[0]), d(rstd[0]), d(mean[1]), d(rstd[1])]
+    sums = torch.full((4, 64), float('nan'), device=DEV)
     _lib.check(L().dbn_head_tail_bwd(ybs.data_ptr(), yts.data_ptr(), wbd.data_ptr(), wtd.data_ptr(), out.data_ptr(), d(dpred).data_ptr(),
-                                     *[t.data_ptr() for t in bn], dxb.data_ptr(), dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(),
-                                     dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, 3, 50.0, 1.0, ws.data_ptr(), stream()), 'head bwd')
+                                     *[t.data_ptr() for t in bn], *[t.data_ptr() for t in stats], sums.data_ptr(), dxb.data_ptr(),
+                                     dxt.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), dwt.data_ptr(), dbt.data_ptr(), N, Hq, Wq, 3, 50.0, 1.0,
+                                     ws.data_ptr(), stream()), 'head bwd')
+    # the fused per-channel reductions of the following BatchNorm backward: masked gradient and masked gradient * xhat
+    for i, (yy, zz, g) in enumerate(((yb, zb, grads[0]), (yt, zt, grads[1]))):
+        gm = (g * (zz > 0)).double()
+        xhat = ((yy - mean[i].view(1, 64, 1, 1)) * rstd[i].view(1, 64, 1, 1)).double()
+        report('fused BN sum g (branch %d)' % i, sums[2 * i].cpu(), gm.sum((0, 2, 3)).float(), 1e-4, 1e-4)
+        report('fused BN sum g*xhat (branch %d)' % i, sums[2 * i + 1].cpu(), (gm * xhat).sum((0, 2, 3)).float(), 1e-4, 1e-4)
     report('fused head bwd dz_b', nchw(dxb), grads[0], 1e-4, 1e-3)
     report('fused head bwd dz_t', nchw(dxt), grads[1], 1e-4, 1e-3)
     report('fused head bwd dwb', dwb.cpu().view(64, 1, 2, 2), grads[2], 1e-3, 1e-3)
