@@ -91,7 +91,8 @@ class DBTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._gone = None
-        self.overlap_allreduce = True  # bucketed exchange under the backward pass; False: one all-reduce after it
+        # bucketed exchange under the backward pass; False (or DBN_OVERLAP_ALLREDUCE=0): one all-reduce after it
+        self.overlap_allreduce = os.environ.get('DBN_OVERLAP_ALLREDUCE', '1') != '0'
 
     def _loss(self, preds, gts):
         """dbn_db_loss_fwd + _bwd with d(total)=1; returns (losses[5], dpreds)."""
@@ -162,5 +163,8 @@ def init_distributed():
         torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        # No device_id: the RCCL communicator is then created lazily by the first collective, i.e. after the model's arena
+        # exists.  Creating it eagerly BEFORE the activations are allocated costs 2.4 ms/step (6 %) at bs16 640^2 on MI355X
+        # (tools/dist_probe2.py: 37.6 vs 35.2 ms) — RCCL's buffers come first and the arena lands in a slower placement.
+        dist.init_process_group('nccl', rank=rank, world_size=world)
     return rank, local, world
