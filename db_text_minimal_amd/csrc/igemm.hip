@@ -166,8 +166,20 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 //         in one accumulator: K = Cs * (9 + 4 + {1,2,4} + {1,2,4}) instead of 36 * Cs.
 // The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
 // offset, for which the hardware returns zeros.
+// Register budget: the 128x128 fp32 tile needs 82 VGPR + 64 AGPR = 3 waves per SIMD; asking for 4 waves makes the compiler
+// fit it into the unified 128 (accumulators in VGPRs, 4 spilled scalars outside the k-loop) — one more resident workgroup per
+// CU hides the LDS/global latency of the k-step prologues.  Env/macro DBN_IGEMM_W4=0 restores 3 waves.
+#ifndef DBN_IGEMM_W4
+#define DBN_IGEMM_W4 1
+#endif
+#if DBN_IGEMM_W4
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE) __attribute__((amdgpu_waves_per_eu(((BM) == 128 && (BN) == 128 && (NS) == 0 && (MODE) < 3) ? 4 : 1, 8)))
+#else
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE)
+#endif
+
 template <int BM, int BN, int WM, int WN, int MODE, int NS>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_f32_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void igemm_f32_kernel(const IgemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
