@@ -10,6 +10,7 @@
 // (-1, H) x (-1, W) is zero; each corner contributes only if its index is inside the image.
 // Offsets: channel 2k = dy, 2k+1 = dx of tap k = r*S + s, stored [M][off_stride] (off_stride >= 2*R*S).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -119,6 +120,80 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
     }
 }
 
+// Tiled adjoint of the sampling.  The 9 taps of neighbouring output pixels land on the same few input pixels, so a
+// workgroup owns a T x T tile of output pixels of one image and one chunk of 32 channels, accumulates their corner
+// contributions in an LDS patch of the input region (tile footprint + HALO pixels for the learned offsets; native
+// ds_add_f32) and flushes each patch element with ONE global atomic — 12x fewer global atomics than the scatter per
+// sample.  Samples that leave the patch (|offset| > HALO) fall back to global atomics.  d(offset) sums over channels:
+// a team reduction per (pixel, tap) and one atomic per channel chunk (doffset is zeroed by the caller).
+constexpr int COL2IM_T = 8, COL2IM_HALO = 2, COL2IM_CC = 32;
+
+__global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const float* __restrict__ dcols, const float* __restrict__ x,
+                                                                  const float* __restrict__ offset, float* __restrict__ dx,
+                                                                  float* __restrict__ doffset, DeformDims d, int tiles_x, int tiles_y,
+                                                                  int PD) {
+    extern __shared__ float patch[];  // [PD][PD][CC]
+    constexpr int T = COL2IM_T, CC = COL2IM_CC;
+    const int lane = threadIdx.x & 31, team = threadIdx.x >> 5;
+    const int chunk = blockIdx.y, c = chunk * CC + lane;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int oy0 = ty * T, ox0 = tx * T;                                                       // first output pixel of the tile
+    const int py0 = oy0 * d.stride - d.pad - COL2IM_HALO, px0 = ox0 * d.stride - d.pad - COL2IM_HALO;  // patch origin (input coords)
+    for (int i = threadIdx.x; i < PD * PD * CC; i += blockDim.x) patch[i] = 0.f;
+    __syncthreads();
+    const int RS = d.R * d.S;
+    const bool cok = c < d.C;
+    for (int pair = team; pair < T * T * RS; pair += 8) {
+        const int pi = pair / RS, k = pair - pi * RS;
+        const int ho = oy0 + pi / T, wo = ox0 + pi % T;
+        if (ho >= d.Ho || wo >= d.Wo) continue;
+        const int m = (n * d.Ho + ho) * d.Wo + wo;
+        int n_, ho_, wo_;
+        const Sample sp = sample_of(d, offset, m, k, n_, ho_, wo_);
+        if (!sp.inside) continue;  // zero sample, zero gradients (doffset stays 0)
+        const float hy = 1.f - sp.ly, hx = 1.f - sp.lx;
+        const float wgt[4] = {hy * hx, hy * sp.lx, sp.ly * hx, sp.ly * sp.lx};
+        const float g = cok ? dcols[((long)m * RS + k) * d.C + c] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = sp.y0 + (q >> 1), xx = sp.x0 + (q & 1);
+            v[q] = (sp.ok[q] && cok) ? x[(((long)n * d.H + yy) * d.W + xx) * d.C + c] : 0.f;
+            if (sp.ok[q] && cok) {
+                const int ry = yy - py0, rx = xx - px0;
+                const float add = wgt[q] * g;
+                if ((unsigned)ry < (unsigned)PD && (unsigned)rx < (unsigned)PD)
+                    atomicAdd(&patch[(ry * PD + rx) * CC + lane], add);
+                else
+                    atomicAdd(dx + (((long)n * d.H + yy) * d.W + xx) * d.C + c, add);
+            }
+        }
+        float gy = g * (hx * (v[2] - v[0]) + sp.lx * (v[3] - v[1]));
+        float gx = g * (hy * (v[1] - v[0]) + sp.ly * (v[3] - v[2]));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            gy += __shfl_xor(gy, o, 64);
+            gx += __shfl_xor(gx, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(doffset + (long)m * d.off_stride + 2 * k, gy);
+            atomicAdd(doffset + (long)m * d.off_stride + 2 * k + 1, gx);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PD * PD * CC; i += blockDim.x) {
+        const float vsum = patch[i];
+        if (vsum == 0.f) continue;
+        const int cc = i % CC, pix = i / CC;
+        const int yy = py0 + pix / PD, xx = px0 + pix % PD;
+        if ((unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W && chunk * CC + cc < d.C)
+            atomicAdd(dx + (((long)n * d.H + yy) * d.W + xx) * d.C + chunk * CC + cc, vsum);
+    }
+}
+
 // dst[o][t][c] = src[o][c][t] (to_ohwi) or dst[o][c][t] = scale * src[o][t][c]: weight layout between OIHW and the
 // GEMM's (tap, channel) column order
 __global__ void permute_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int C, int T, int to_ohwi,
@@ -165,6 +240,20 @@ int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, f
     const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
     DBN_REQUIRE(dcols && x && offset && dx && doffset && dims_ok(d));
     hipStream_t st = (hipStream_t)stream;
+    static int tiled = -1;
+    if (tiled < 0) {
+        const char* e = getenv("DBN_COL2IM_TILED");
+        tiled = e ? atoi(e) : 1;
+    }
+    const int PD = (COL2IM_T - 1) * stride + R + 2 * COL2IM_HALO;  // patch edge; R == S for every DCN layer of the reference
+    const size_t lds = (size_t)PD * PD * COL2IM_CC * sizeof(float);
+    if (tiled && R == S && lds <= 64 * 1024) {
+        if (hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess) return dbn_status();
+        const int tiles_x = dbn_ceil_div(Wo, COL2IM_T), tiles_y = dbn_ceil_div(Ho, COL2IM_T);
+        hipLaunchKernelGGL(deform_col2im_tiled_kernel, dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, COL2IM_CC)), dim3(256), lds, st, dcols, x,
+                           offset, dx, doffset, d, tiles_x, tiles_y, PD);
+        return dbn_status();
+    }
     if (off_stride > 2 * R * S &&
         hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess)
         return dbn_status();
