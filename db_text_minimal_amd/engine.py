@@ -177,6 +177,8 @@ class Engine:
         return t
 
     def scratch(self, name, numel):
+        if self._in_side:  # launches on the side stream run concurrently with the main one: private scratch
+            name += '#side'
         t = self.bufs.get(name)
         if t is None or t.numel() < numel or t.device != self.flat.device:
             t = torch.empty(int(numel), device=self.flat.device, dtype=torch.float32)
@@ -199,8 +201,8 @@ class Engine:
         """Run the enclosed launches on the side stream, ordered after everything enqueued so far on
         the current stream (the producer of dy).  Weight gradients only feed the optimizer, so they
         overlap the HBM-bound BatchNorm-backward / dgrad chain; `join_side()` re-joins the streams."""
-        if not self.overlap_wgrad or (self.prof is not None and self.prof.labels is None):  # full profiling serialises
-            yield
+        if not self.overlap_wgrad or (self.prof is not None and self.prof.labels is None) or self._in_side:
+            yield  # single-stream mode, full profiling (serialises), or already on the side stream (re-entrant)
             return
         if self._side is None or self._side.device != self.flat.device:
             self._side = torch.cuda.Stream(device=self.flat.device)
@@ -518,13 +520,19 @@ class Engine:
         f = self.bn_apply(fy, s_, h_, 'fpn/z')
         head = m.segmentation_head
         z1 = {}
-        for br in ('binarize', 'thresh'):
+        def branch(br):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
             ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train)
             za = self.bn_apply(ya, s_, h_, br + '/z0')
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
+
+        # the two branches are independent until the head-tail kernel: the threshold branch runs on the second stream
+        with self.side_stream():
+            branch('thresh')
+        branch('binarize')
+        self.join_side()
         ch = 3 if train else 2
         (yb_, sb_, hb_), (yt_, st_, ht_) = z1['binarize'], z1['thresh']
         Hh, Wh = yb_.shape[1], yb_.shape[2]
@@ -685,6 +693,8 @@ class Engine:
         f = B['fpn/z']
         df = self.buf('fpn/dz', *f.shape)
         for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
+            # (running the two branches' backward on two streams was tried: the join before the FPN backward makes the main
+            # stream wait for every queued weight gradient and costs more than it gains)
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
             dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1', sums=bn_sums[2 * i:2 * i + 2])
