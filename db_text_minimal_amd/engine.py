@@ -477,14 +477,6 @@ class Engine:
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
         check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
               'maxpool fwd')
-        feats = []
-        cur = pool
-        for li in range(1, 5):
-            layer = getattr(bb, 'layer%d' % li)
-            for bi, blk in enumerate(layer):
-                cur = self._block_fwd('backbone.layer%d.%d' % (li, bi), blk, cur, train)
-            feats.append(cur)
-        c2, c3, c4, c5 = feats
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
 
@@ -492,16 +484,26 @@ class Engine:
             y, s_, h_ = self.conv_bn(pre + name + '.conv', xin, mod.conv, name + '/y', pre + name + '.bn', mod.bn, train)
             return self.bn_apply(y, s_, h_, name + '/z')
 
+        feats, lateral = [], {}
+        cur = pool
+        for li in range(1, 5):
+            layer = getattr(bb, 'layer%d' % li)
+            for bi, blk in enumerate(layer):
+                cur = self._block_fwd('backbone.layer%d.%d' % (li, bi), blk, cur, train)
+            feats.append(cur)
+            if li < 4:  # the FPN's lateral 1x1 conv of this stage (tiny, under-filled grid) runs on the second stream
+                with self.side_stream():  # beside the next backbone stage
+                    lateral[li] = cbr('reduce_conv_c%d' % (li + 1), getattr(fpn, 'reduce_conv_c%d' % (li + 1)), cur)
+        c2, c3, c4, c5 = feats
         p5 = cbr('reduce_conv_c5', fpn.reduce_conv_c5, c5)
-        r4 = cbr('reduce_conv_c4', fpn.reduce_conv_c4, c4)
+        self.join_side()
+        r2, r3, r4 = lateral[1], lateral[2], lateral[3]
         p4pre = self.buf('p4pre', *r4.shape)
         self.up_fwd(p5, r4, p4pre)
         p4 = cbr('smooth_p4', fpn.smooth_p4, p4pre)
-        r3 = cbr('reduce_conv_c3', fpn.reduce_conv_c3, c3)
         p3pre = self.buf('p3pre', *r3.shape)
         self.up_fwd(p4, r3, p3pre)
         p3 = cbr('smooth_p3', fpn.smooth_p3, p3pre)
-        r2 = cbr('reduce_conv_c2', fpn.reduce_conv_c2, c2)
         p2pre = self.buf('p2pre', *r2.shape)
         self.up_fwd(p3, r2, p2pre)
         p2 = cbr('smooth_p2', fpn.smooth_p2, p2pre)

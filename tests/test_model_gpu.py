@@ -369,3 +369,23 @@ def test_bottleneck_and_deformable_backbones_vs_oracle(arch, n, size):
     for k, v in model.state_dict().items():  # running statistics after one train step
         if 'running' in k:
             assert torch.allclose(v.cpu(), sd[k], atol=1e-4, rtol=1e-3), k
+
+
+def test_two_stream_step_is_bit_reproducible():
+    """The step's second HIP stream (weight gradients, threshold branch, FPN laterals) changes WHEN kernels run, not what they
+    compute: gradients and updated parameters are bit-identical to the single-stream schedule and from run to run
+    (no atomics on the ResNet-18 path; every reduction has a fixed order)."""
+    seed = 9
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    outs = []
+    for overlap in (True, False, True):
+        model = make_model(seed).train()
+        model.engine.overlap_wgrad = overlap
+        trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        for _ in range(2):
+            preds, losses = trainer.step(img.to(DEV), gts.to(DEV))
+        torch.cuda.synchronize()
+        outs.append((model.engine.flat_grad.clone(), model.engine.flat.clone(), preds.clone(), losses.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
