@@ -105,19 +105,25 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
                                 const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
                                 float* __restrict__ out, long total4, int C, int relu) {
     const int c4n = C >> 2;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
+    // the grid stride is a multiple of C/4 (host side), so a thread keeps its channel quad: per-channel coefficients are
+    // loaded once, and no 64-bit modulo sits in the streaming loop
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;
+    const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
+    f32x4 s2 = s, h2 = h;
+    if (res && rsc) {
+        s2 = *reinterpret_cast<const f32x4*>(rsc + c);
+        h2 = *reinterpret_cast<const f32x4*>(rsh + c);
+    }
+    for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = dbn_affine(v[e], s[e], h[e]);
         if (res) {
             const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
             if (rsc) {
-                const f32x4 s2 = *reinterpret_cast<const f32x4*>(rsc + c);
-                const f32x4 h2 = *reinterpret_cast<const f32x4*>(rsh + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += dbn_affine(r[e], s2[e], h2[e]);
             } else {
@@ -183,8 +189,20 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __
                                     const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
                                     float* __restrict__ dy, float* __restrict__ gout, int gout_acc, long total4, int C) {
     const int c4n = C >> 2;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % c4n) * 4;  // constant per thread: the grid stride is a multiple of C/4 (host side)
+    f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, h_ = s_;
+    if (msc) {
+        s_ = *reinterpret_cast<const f32x4*>(msc + c);
+        h_ = *reinterpret_cast<const f32x4*>(msh + c);
+    }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
+    const f32x4 gr = ga * rs;
+    for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
         f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
         const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
         if (zmask) {
@@ -192,18 +210,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
         } else if (msc) {
-            const f32x4 s_ = *reinterpret_cast<const f32x4*>(msc + c);
-            const f32x4 h_ = *reinterpret_cast<const f32x4*>(msh + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = dbn_affine(v[e], s_[e], h_[e]) > 0.f ? g[e] : 0.f;
         }
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
-        const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
-        const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
         const f32x4 xh = (v - mu) * rs;
-        reinterpret_cast<f32x4*>(dy)[i] = ga * rs * (g - k1 - xh * k2);
+        reinterpret_cast<f32x4*>(dy)[i] = gr * (g - k1 - xh * k2);
         if (gout) {
             if (gout_acc) g += reinterpret_cast<const f32x4*>(gout)[i];
             reinterpret_cast<f32x4*>(gout)[i] = g;
@@ -522,6 +533,14 @@ inline int part_blocks(int M, int C) {
     (void)C;
     return nb;
 }
+// grid of a streaming BN kernel whose threads keep their channel quad: (grid * 256) % (C/4) == 0
+inline int bn_stream_grid(long total4, int C) {
+    int g = dbn_grid(total4);
+    int a = C / 4, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }  // a = gcd(C/4, 256)
+    const int m = (C / 4) / a;                       // grid must be a multiple of m
+    return (g + m - 1) / m * m;
+}
 inline dim3 red_grid(int nb, int C) { return dim3(nb, (C + CHUNK_C - 1) / CHUNK_C); }
 inline size_t red_smem(int Cfull, int nv) {
     const int C = Cfull < CHUNK_C ? Cfull : CHUNK_C;
@@ -562,7 +581,7 @@ int dbn_bn_apply(const float* y, const float* scale, const float* shift, const f
     DBN_REQUIRE(y && scale && shift && out && M > 0 && C % 4 == 0);
     DBN_REQUIRE((res_scale == nullptr) == (res_shift == nullptr));
     const long total4 = M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_stream_grid(total4, C)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
                        res_scale, res_shift, out, total4, C, relu);
     return dbn_status();
 }
@@ -589,7 +608,7 @@ static int bn_backward_impl(const float* sums, const float* y, const float* zmas
                            grad_scale);
     }
     const long total4 = (long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_stream_grid(total4, C)), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout,
                        save_mean, save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
     return dbn_status();
 }
