@@ -168,3 +168,78 @@ def init_distributed():
         # (tools/dist_probe2.py: 37.6 vs 35.2 ms) — RCCL's buffers come first and the arena lands in a slower placement.
         dist.init_process_group('nccl', rank=rank, world_size=world)
     return rank, local, world
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Epoch-level loop: reference src/train.py:146-318 without its Hydra / TensorBoard / OpenCV-metric plumbing.
+# ----------------------------------------------------------------------------------------------------------------------
+def evaluate(model, criterion, loader, thresh=0.3, device=None):
+    """train.py:228-262: eval-mode forward under no_grad, DBLoss on the 2-channel output (single value), the pixel metric
+    on device.  Returns (mean test loss as a float, score dict of the RunningScore over the whole loader)."""
+    from .text_metrics import RunningScore
+    was_training = model.training
+    model.eval()
+    running = RunningScore(2)
+    total, n = None, 0
+    with torch.no_grad():
+        for batch in loader:
+            if device is not None:
+                batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            preds = model(batch['img'])
+            assert preds.size(1) == 2  # train.py:241
+            loss = criterion(preds, stack_gts(batch))
+            total = loss if total is None else total + loss
+            n += 1
+            running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)  # no host sync
+    model.train(was_training)
+    score = running.get_scores()[0] if n else {}
+    return (float(total) / max(n, 1) if total is not None else float('nan')), score
+
+
+def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, scheduler=None, lrs_mode=None, thresh=0.3,
+        best_cp_path=None, last_cp_path=None, device=None, log=None, process_group=None):
+    """The reference's training driver (train.py:146-318): per epoch a pass over `train_loader` through DBTrainer.step
+    (lr scheduler stepped per iteration when lrs_mode == 'poly', train.py:172-173), the running pixel metric
+    (train.py:175-181, on device), then evaluate() on `test_loader`, the reference's best-checkpoint rule
+    (`test_loss <= best_test_loss and train_loss <= best_train_loss`, train.py:301-305; `train_loss` is the epoch SUM as
+    there), ReduceLROnPlateau-style schedulers stepped with the test loss when lrs_mode == 'reduce' (train.py:307-308), and
+    the final state_dict at `last_cp_path` (train.py:316).  Box-level P/R/HMean (train.py:277-299) needs the host OpenCV
+    post-processing and is left to the caller.  Returns a list of per-epoch dicts."""
+    from .text_metrics import RunningScore
+    trainer = DBTrainer(model, criterion, optimizer, process_group=process_group)
+    best_test, best_train = float('inf'), float('inf')
+    history = []
+    steps = 0
+    for epoch in range(epochs):
+        model.train()
+        running = RunningScore(2)
+        train_sum = None
+        for batch in train_loader:
+            if device is not None:
+                batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            steps += 1
+            preds, losses = trainer.step(batch, None)
+            if lrs_mode == 'poly' and scheduler is not None:
+                scheduler.step()
+            running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)
+            train_sum = losses[4] if train_sum is None else train_sum + losses[4]  # device-side sums: no per-step host sync
+        score = running.get_scores()[0] if train_sum is not None else {}
+        train_loss = float(train_sum) if train_sum is not None else float('nan')
+        rec = {'epoch': epoch + 1, 'global_steps': steps, 'lr': optimizer.param_groups[0]['lr'], 'train_loss_sum': train_loss,
+               'train_loss': train_loss / max(len(train_loader), 1), 'train_score': score}
+        if test_loader is not None:
+            test_loss, test_score = evaluate(model, criterion, test_loader, thresh=thresh, device=device)
+            rec.update(test_loss=test_loss, test_score=test_score)
+            if test_loss <= best_test and train_loss <= best_train:
+                best_test, best_train = test_loss, train_loss
+                if best_cp_path:
+                    torch.save(model.state_dict(), best_cp_path)
+                rec['saved_best'] = True
+            if lrs_mode == 'reduce' and scheduler is not None:
+                scheduler.step(test_loss)
+        if log is not None:
+            log(rec)
+        history.append(rec)
+    if last_cp_path:
+        torch.save(model.state_dict(), last_cp_path)
+    return history

@@ -389,3 +389,44 @@ def test_two_stream_step_is_bit_reproducible():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+def test_fit_and_evaluate_epoch_loop(tmp_path):
+    """train.py:146-318: epochs over a loader of reference-style batch dicts, poly/plateau schedulers,
+    eval-mode validation with the pixel metric, the reference's best-checkpoint rule and the final checkpoint."""
+    from db_text_minimal_amd.train import evaluate, fit
+    seed = 3
+
+    def loader(n_batches, base):
+        out = []
+        for i in range(n_batches):
+            img, gts = O.synthetic_batch(2, 64, seed=base + i)
+            out.append({'img': img, 'prob_map': gts[0], 'supervision_mask': gts[1], 'thresh_map': gts[2], 'text_area_map': gts[3]})
+        return out
+
+    train_loader, test_loader = loader(3, 100), loader(2, 200)
+    model = make_model(seed).train()
+    opt = FusedAdam(model, lr=0.005)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.5, patience=0)
+    best, last = str(tmp_path / 'best.pth'), str(tmp_path / 'last.pth')
+    hist = fit(model, DBLoss(), opt, train_loader, test_loader, epochs=3, scheduler=sched, lrs_mode='reduce', thresh=0.3,
+               best_cp_path=best, last_cp_path=last, device=DEV)
+    assert len(hist) == 3 and hist[-1]['global_steps'] == 9
+    assert all(np.isfinite(h['train_loss']) and np.isfinite(h['test_loss']) for h in hist)
+    assert hist[-1]['train_loss'] < hist[0]['train_loss']  # three epochs on three fixed batches: the loss goes down
+    assert hist[0].get('saved_best') and os.path.exists(best) and os.path.exists(last)
+    assert set(hist[0]['test_score']) == {'Overall Acc', 'Mean Acc', 'FreqW Acc', 'Mean IoU'}
+    # the saved checkpoint is the reference's wire format and reproduces the evaluation
+    m2 = DBTextModel()
+    m2.load_state_dict(torch.load(last, map_location='cpu'))
+    m2 = m2.to(DEV)
+    l1, s1 = evaluate(model, DBLoss(), test_loader, device=DEV)
+    l2, s2 = evaluate(m2, DBLoss(), test_loader, device=DEV)
+    assert l1 == l2 and s1 == s2 and abs(l1 - hist[-1]['test_loss']) < 1e-6
+    # the oracle agrees with evaluate() on the final weights
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = 0.0
+    for b in test_loader:
+        p = O.forward(sd, b['img'], training=False)
+        ref += float(O.db_loss(p, torch.stack([b['prob_map'], b['supervision_mask'], b['thresh_map'], b['text_area_map']])))
+    assert abs(ref / len(test_loader) - l1) < 2e-3 * max(1.0, abs(l1))
