@@ -1,6 +1,6 @@
 """Debug helper (GPU box): per-stage forward error of the HIP path vs the CPU oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import torch
 from db_text_minimal_amd import DBTextModel
 from oracle import dbnet_oracle as O
