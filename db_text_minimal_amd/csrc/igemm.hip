@@ -23,6 +23,7 @@
 // (NS = 0) or [split][k/8][row][8 bf16] (NS > 0) so that every lane fetches the k-values of its MFMAs with
 // conflict-free ds_read_b128.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -166,11 +167,12 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 //         in one accumulator: K = Cs * (9 + 4 + {1,2,4} + {1,2,4}) instead of 36 * Cs.
 // The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
 // offset, for which the hardware returns zeros.
-// Register budget: the 128x128 fp32 tile needs 82 VGPR + 64 AGPR = 3 waves per SIMD; asking for 4 waves makes the compiler
-// fit it into the unified 128 (accumulators in VGPRs, 4 spilled scalars outside the k-loop) — one more resident workgroup per
-// CU hides the LDS/global latency of the k-step prologues.  Env/macro DBN_IGEMM_W4=0 restores 3 waves.
+// Register budget: the 128x128 fp32 tile needs 88 VGPR + 64 AGPR = 3 waves per SIMD.  Asking for 4 waves
+// (amdgpu_waves_per_eu) makes the compiler fit it into the unified 128 registers; with a prefetch distance of one k-tile
+// that cost 4 spills and gave +1.6 % on large launches, with the second register set of the two-tile prefetch it spills 56
+// and loses 35 % — so the default is off (DBN_IGEMM_W4=1 re-enables the experiment).
 #ifndef DBN_IGEMM_W4
-#define DBN_IGEMM_W4 1
+#define DBN_IGEMM_W4 0
 #endif
 #if DBN_IGEMM_W4
 #define DBN_IGEMM_OCC(BM, BN, NS, MODE) __attribute__((amdgpu_waves_per_eu(((BM) == 128 && (BN) == 128 && (NS) == 0 && (MODE) < 3) ? 4 : 1, 8)))
@@ -373,17 +375,23 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         k_r = k_s = 0;
     };
 
-    f32x4 ra[A_LD], rb[B_LD];
-    auto issue_loads = [&]() {
+    // two register sets: the global loads of k-tile t+2 are issued while tile t is multiplied and tile t+1 (loaded one
+    // iteration earlier) is staged to LDS — a full k-step (~1 us) more latency tolerance than a prefetch distance of one
+    f32x4 ra_[2][A_LD], rb_[2][B_LD];
+    auto issue_loads = [&](auto SET) {
+        constexpr int st_ = decltype(SET)::value;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) ra[j] = buffer_load_f32x4(rsrc, aoff[j]);
+        for (int j = 0; j < A_LD; ++j) ra_[st_][j] = buffer_load_f32x4(rsrc, aoff[j]);
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
-            if (B_FULL || b_on[j]) rb[j] = *bptr[j];
+            if (B_FULL || b_on[j]) rb_[st_][j] = *bptr[j];
             bptr[j] += b_step;
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, auto SET) {
+        constexpr int st_ = decltype(SET)::value;
+        f32x4 (&ra)[A_LD] = ra_[st_];
+        f32x4 (&rb)[B_LD] = rb_[st_];
         f32x4* As = smem + buf * STAGE;
         f32x4* Bs = As + A_IMG;
         if constexpr (NS == 0) {
@@ -419,16 +427,20 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         level_setup(level);
         kt_end = qKT;
     }
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
     next_offsets();
-    issue_loads();
+    issue_loads(C0{});
     next_offsets();  // offsets of tile 1
-    stage(0);
+    if (kt_begin + 1 < kt_end) issue_loads(C1{});
+    next_offsets();  // offsets of tile 2
+    stage(0, C0{});
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
+    auto k_step = [&](int kt, auto PAR) {
+        constexpr int buf = decltype(PAR)::value;  // parity of kt - kt_begin: LDS buffer and register set of tile kt
         const bool more = kt + 1 < kt_end;
-        if (more) issue_loads();  // tile kt+1 in flight under the MFMAs of tile kt
+        if (kt + 2 < kt_end) issue_loads(PAR);  // tile kt+2 into the register set tile kt was staged from
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
         if constexpr (NS == 0) {
@@ -465,8 +477,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             mfma_split<NS, MI, NI>(af, bf, acc);
             next_offsets();
         }
-        if (more) stage(buf ^ 1);
+        if (more) stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        k_step(kt, C0{});
+        if (kt + 1 < kt_end) k_step(kt + 1, C1{});
     }
     }
 
@@ -752,6 +768,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     // Address math placement (measured): with the long fp32 MFMAs (NS = 0) computing the offsets right before
     // the loads is faster (fewer live registers across the MFMA block); with the short bf16 MFMAs (NS > 0) they
     // are computed one tile ahead, in the shadow of the previous tile's MFMAs.
+    // (a prefetch distance of two k-tiles, which helps the igemm kernel, costs this kernel its occupancy — every thread
+    // holds a 4x4 block per set for the register transpose: 64 -> 130 VGPRs, 100 -> 72 TFLOP/s measured — so it stays at one)
     if (KT > 0) {
         offsets(0);
         issue_loads();
