@@ -1044,6 +1044,70 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, in
     }
 }
 
+// ---- all weight panels of a model in ONE launch (after every optimizer step every panel is stale) ----
+// job = one dbn_pack_weights call; blockIdx.y = job, the job's parity classes are walked inside.
+struct PackJob {
+    const float* w;
+    void* out;
+    int O, I, R, S, mode, Cs, Cd, f;
+};
+
+template <int BF16>
+__global__ void pack_many_kernel(const PackJob* __restrict__ jobs, int NS) {
+    const PackJob j = jobs[blockIdx.y];
+    const float* __restrict__ w = j.w;
+    const int ncls = j.f > 1 ? j.f * j.f : 1;
+    long krow0 = 0;
+    for (int c = 0; c < ncls; ++c) {
+        int Rp = j.R, Sp = j.S, r0 = 0, s0 = 0, rstep = 1;
+        if (j.f > 1) {
+            r0 = c / j.f; s0 = c % j.f; rstep = j.f;
+            Rp = taps_of_class(j.R, r0, j.f);
+            Sp = taps_of_class(j.S, s0, j.f);
+        }
+        const int K = Rp * Sp * j.Cs, Kpad = (K + 15) / 16 * 16;
+        const long total = (long)Kpad * j.Cd;
+        constexpr int G = BF16 ? 8 : 4;  // k-values per 16-byte group of the panel
+        for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+            const int e = (int)(idx % G);
+            const long qd = idx / G;
+            const int cd = (int)(qd % j.Cd);
+            const int kg = (int)(qd / j.Cd);
+            const int k = G * kg + e;
+            float v = 0.f;
+            if (k < K) {
+                int tap, cs;
+                if ((j.Cs & 15) == 0) {
+                    const int blk = k >> 4;
+                    tap = blk % (Rp * Sp);
+                    cs = (blk / (Rp * Sp)) * 16 + (k & 15);
+                } else {
+                    tap = k / j.Cs;
+                    cs = k - tap * j.Cs;
+                }
+                const int rp = tap / Sp, sp = tap - rp * Sp;
+                const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
+                if (j.mode == 0) {
+                    if (cs < j.I) v = w[(((long)cd * j.I + cs) * j.R + r) * j.S + sx];
+                } else {
+                    v = w[(((long)cs * j.I + cd) * j.R + r) * j.S + sx];
+                }
+            }
+            if constexpr (BF16) {
+                unsigned short* out = reinterpret_cast<unsigned short*>(j.out) + krow0 * j.Cd * NS;
+                const int kt = kg >> 1, k8 = kg & 1;
+                for (int t = 0; t < NS; ++t) {
+                    const unsigned bits = bf16_bits_rne(v);
+                    out[((((long)kt * NS + t) * 2 + k8) * j.Cd + cd) * 8 + e] = (unsigned short)bits;
+                    v -= bf16_bits_to_f32(bits);
+                }
+            } else {
+                reinterpret_cast<float*>(j.out)[krow0 * j.Cd + idx] = v;
+            }
+        }
+        krow0 += Kpad;
+    }
+}
 
 }  // namespace
 
@@ -1309,6 +1373,19 @@ static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, i
     else
         hipLaunchKernelGGL(pack_weights_bf16s_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, ns,
                            reinterpret_cast<unsigned short*>(out));
+    return dbn_status();
+}
+
+// Every weight panel of a model in one launch.  jobs: DEVICE array of n records {const float* w; void* out; int O, I, R, S,
+// mode, Cs, Cd, f;} (two pointers + eight ints, 48 bytes; Cs/Cd/f as dbn_pack_weights derives them: Cs = mode 0 ? I rounded
+// up to 4 : O, Cd = mode 0 ? O : I, f = (mode 1 and stride > 1) ? stride : 1).  ns = 0: fp32 panels, 1 / 3: split-bf16.
+int dbn_pack_weights_batched(const void* jobs, int n, int ns, void* stream) {
+    DBN_REQUIRE(jobs && n > 0 && (ns == 0 || ns == 1 || ns == 3));
+    const dim3 grid(48, n);
+    if (ns == 0)
+        hipLaunchKernelGGL(pack_many_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), 0);
+    else
+        hipLaunchKernelGGL(pack_many_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), ns);
     return dbn_status();
 }
 

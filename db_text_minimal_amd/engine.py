@@ -91,6 +91,8 @@ class Engine:
         self.L = _lib.lib()
         self.bufs = {}
         self.packs = {}
+        self.pack_src = {}  # pack key -> parameter tensor, for repack_params()
+        self._pack_jobs = None
         self.param_epoch = 0
         self.generation = 0
         self.saved_generation = -1
@@ -144,7 +146,7 @@ class Engine:
             self.views[n] = v
             self.grad_views[n] = grad[off:off + p.numel()].view(p.shape)
         self.flat, self.flat_grad, self.offsets = flat, grad, offs
-        self.bufs, self.packs = {}, {}
+        self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
         self.param_epoch += 1
 
     def flush_counters(self):
@@ -231,6 +233,8 @@ class Engine:
         stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
+        if version is None:  # a parameter (not a derived tensor): remembered for the one-launch repack of later steps
+            self.pack_src[key] = w
         O, I, R, S = w.shape
         if ns == 0:
             n = self.L.dbn_igemm_panel_floats(O, I, R, S, mode, stride)
@@ -258,6 +262,43 @@ class Engine:
             check(self.L.dbn_igemm_f32(*args, self.stream), what)
         else:
             check(self.L.dbn_igemm_bf16s(*args, self.ns, self.stream), what)
+
+    batched_repack = True
+
+    def repack_params(self):
+        """After an optimizer step every weight panel is stale.  Instead of ~80 dbn_pack_weights launches sprinkled over the
+        next step (one before each conv's first use), all panels that exist already are rebuilt by ONE launch here."""
+        if not self.batched_repack:
+            return
+        ns = self.ns
+        stale = []
+        for key, w in self.pack_src.items():
+            if key[3] != ns:
+                continue
+            ent = self.packs.get(key)
+            stamp = (w._version, self.param_epoch, w.data_ptr())
+            if ent is not None and ent[1] != stamp:
+                stale.append((key, w, ent[0], stamp))
+        if len(stale) < 8:  # first step (nothing packed yet) or nothing changed: the lazy path handles it
+            return
+        sig = tuple((k, w.data_ptr(), out.data_ptr()) for k, w, out, _ in stale)
+        if self._pack_jobs is None or self._pack_jobs[0] != sig:
+            import ctypes
+
+            class Job(ctypes.Structure):
+                _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + [(f, ctypes.c_int) for f in
+                                                                                  ('O', 'I', 'R', 'S', 'mode', 'Cs', 'Cd', 'f')]
+            arr = (Job * len(stale))()
+            for i, ((name, mode, stride, _), w, out, _) in enumerate(stale):
+                O, I, R, S = w.shape
+                arr[i] = Job(w.data_ptr(), out.data_ptr(), O, I, R, S, mode, (I + 3) // 4 * 4 if mode == 0 else O,
+                             O if mode == 0 else I, stride if (mode == 1 and stride > 1) else 1)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self._pack_jobs = (sig, host.to(self.flat.device), len(stale))
+        _, table, n = self._pack_jobs
+        check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
+        for key, _, out, stamp in stale:
+            self.packs[key] = (out, stamp)
 
     # ------------------------------------------------------------------ kernels
     def conv_fwd(self, name, x, conv, out_name, version=None):
@@ -466,6 +507,7 @@ class Engine:
         if H < 32 or W < 32:
             raise ValueError('input must be at least 32x32 (five stride-2 stages); got %dx%d' % (H, W))
         self.ensure_flat()
+        self.repack_params()
         x = x.contiguous().float()
         L, st = self.L, self.stream
         self.generation += 1

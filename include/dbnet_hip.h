@@ -47,6 +47,12 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
  * chain) at 6/16 of the fp32-MFMA cost.  ns = 1: operands rounded to bf16 (BASELINE configs[2]
  * "bf16 compute").  Panels must come from dbn_pack_weights_bf16s with the same (mode, stride, ns). */
 int dbn_pack_weights_bf16s(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream);
+/* All weight panels of a model in one launch (after an optimizer step every panel is stale: ~80 dbn_pack_weights calls of a
+ * few microseconds each otherwise).  jobs: DEVICE array of n records
+ *   struct { const float* w; void* out; int O, I, R, S, mode, Cs, Cd, f; }   (48 bytes)
+ * with Cs = (mode 0 ? I rounded up to 4 : O), Cd = (mode 0 ? O : I), f = (mode 1 && stride > 1 ? stride : 1);
+ * out sized by dbn_igemm_panel_floats / dbn_igemm_bf16s_panel_floats.  ns = 0: fp32 panels; 1, 3: split-bf16 panels. */
+int dbn_pack_weights_batched(const void* jobs, int n, int ns, void* stream);
 long dbn_igemm_bf16s_panel_floats(int O, int I, int R, int S, int mode, int stride, int ns);
 int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                     int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
