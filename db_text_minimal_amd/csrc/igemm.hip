@@ -256,10 +256,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         const int m = m0 + row;
         const bool ok = m < qM;
         const int mm = ok ? m : 0;
-        const int n = mm / HWd;
-        const int rem = mm - n * HWd;
-        const int hd = rem / qWd;
-        const int wd = rem - hd * qWd;
+        int n, rem, hd, wd;  // reciprocal divisions (exact below 2^24): an integer division costs ~35 VALU instructions
+        divmod24(mm, HWd, 1.0f / (float)HWd, n, rem);
+        divmod24(rem, qWd, 1.0f / (float)qWd, hd, wd);
         a_nb[j] = n * p.Hs * p.Ws * p.Cs;
         if (MODE == 3) {
             a_n[j] = n;
@@ -490,27 +489,47 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     // statistics below and the store loop both see the final values
     float* const dstp = (MODE < 2 && p.ksplit > 1) ? p.dst + (long)blockIdx.y * qM * p.Cd : p.dst;
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
-    auto dst_offset = [&](int row) -> long {
-        if (MODE >= 2) {  // the parity class's pixels of the full-resolution output
+    // fn(r, doff) for the 16 rows this lane holds of accumulator block a (rows base + (r&3) + 8*(r>>2)) that are < M.
+    // MODE >= 2 scatters to the parity class's pixels of the full-resolution output: the pixel (n, hd, wd) of the first row
+    // comes from two reciprocal divisions, the other 15 by stepping +1,+1,+1,+5 with carries — the per-row divisions
+    // were 1300 of the 2450 VALU instructions a wave spends on a K = 64 tile (ConvTranspose 2x2), as many cycles as its MFMAs.
+    // offsets are formed in 32 bits (element index < 2^31 is checked on the host) and widened once per row
+    auto for_rows = [&](int a, auto&& fn) {
+        const int rbase = m0 + wm * TM + a * 32 + 4 * lh;
+        if (MODE >= 2) {
             int n, rem, hd, wd;
-            divmod24(row, HWd, rcp_hw, n, rem);
+            divmod24(min(rbase, qM - 1), HWd, rcp_hw, n, rem);
             divmod24(rem, qWd, rcp_w, hd, wd);
-            return (((long)n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * p.Cd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r > 0) {
+                    wd += (r & 3) ? 1 : 5;
+                    while (wd >= qWd) {
+                        wd -= qWd;
+                        if (++hd == qHd) {
+                            hd = 0;
+                            ++n;
+                        }
+                    }
+                }
+                if (rbase + (r & 3) + 8 * (r >> 2) < qM)
+                    fn(r, (long)((unsigned)((n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * (unsigned)p.Cd));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < qM) fn(r, (long)((unsigned)row * (unsigned)p.Cd));
+            }
         }
-        return (long)row * p.Cd;
     };
     if (p.accumulate) {
 #pragma unroll
         for (int a = 0; a < MI; ++a)
+            for_rows(a, [&](int r, long doff) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < qM) {
-                    const long doff = dst_offset(row);
-#pragma unroll
-                    for (int b = 0; b < NI; ++b) acc[a][b][r] += dstp[doff + n0 + wn * TN + b * 32 + li];
-                }
-            }
+                for (int b = 0; b < NI; ++b) acc[a][b][r] += dstp[doff + n0 + wn * TN + b * 32 + li];
+            });
     }
 
     // ---- optional BatchNorm statistics of this tile (train-mode BN follows the conv): per output channel the
@@ -569,20 +588,14 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int a = 0; a < MI; ++a) {
+    for (int a = 0; a < MI; ++a)
+        for_rows(a, [&](int r, long doff) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < qM) {
-                const long doff = dst_offset(row);
-#pragma unroll
-                for (int b = 0; b < NI; ++b) {
-                    const int col = n0 + wn * TN + b * 32 + li;
-                    dstp[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
-                }
+            for (int b = 0; b < NI; ++b) {
+                const int col = n0 + wn * TN + b * 32 + li;
+                dstp[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
             }
-        }
-    }
+        });
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -1164,6 +1177,7 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
     DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
     DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
+    DBN_REQUIRE((long)N * Hd * Wd * Cd < (1L << 32));  // 32-bit element offsets in the epilogue
     hipStream_t st = (hipStream_t)stream;
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
@@ -1313,7 +1327,7 @@ int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, cons
                          float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
-    DBN_REQUIRE((long)N * H * W < (1L << 24) && (long)N * H * W * Cs * 4 < 0xF0000000L);
+    DBN_REQUIRE((long)N * H * W < (1L << 24) && (long)N * H * W * Cs * 4 < 0xF0000000L && (long)N * H * W * Cd < (1L << 32));
     DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
     const bool bn = gamma != nullptr;
     DBN_REQUIRE(!bn || (beta && scale && shift && save_mean && save_rstd && ws));
