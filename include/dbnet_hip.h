@@ -26,7 +26,7 @@ extern "C" {
 
 /* OIHW weights -> GEMM panels [ceil(K/16)*4][Cd][4].  mode 0: forward conv panels
  * (Cs = I rounded up to 4, Cd = O); mode 1: data-gradient / ConvTranspose panels
- * (Cs = O, Cd = I) — for stride 2 four panels, one per output-parity class (only the
+ * (Cs = O, Cd = I) — for stride f = 2, 4, 8: f*f panels, one per output-parity class (only the
  * taps that reach that class).  `out` holds dbn_igemm_panel_floats(...) floats. */
 int dbn_pack_weights(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, float* out, void* stream);
 long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride);
@@ -35,9 +35,11 @@ int dbn_igemm_packed_floats(int K, int Cd);
 /* dst[N,Hd,Wd,Cd] (+)= gather(src[N,Hs,Ws,Cs]) x panels + bias.
  * mode 0: hs = hd*stride - pad + r (Conv2d forward; ConvTranspose2d data gradient)
  * mode 1: hs = (hd + pad - r)/stride when divisible (Conv2d data gradient;
- *         ConvTranspose2d forward); stride 2 runs as four parity-class problems in one
+ *         ConvTranspose2d forward); stride f = 2, 4, 8 runs as f*f parity-class problems in one
  *         launch, so no zero taps are multiplied.  bias may be NULL.  tile_hint 0 = auto.
- * `wpk` must come from dbn_pack_weights with the same (mode, stride). */
+ * `wpk` must come from dbn_pack_weights with the same (mode, stride).
+ * Limits (DBN_ERR_ARG otherwise): Cs % 4 == 0, Cd % 64 == 0, N*Hd*Wd < 2^24 output pixels, the source tensor below
+ * 0xF0000000 bytes (raw buffer addressing), N*Hd*Wd*Cd < 2^32 output elements (32-bit epilogue offsets). */
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                   int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream);
 
