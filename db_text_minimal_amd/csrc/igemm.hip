@@ -527,8 +527,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 #pragma unroll
         for (int a = 0; a < MI; ++a)
             for_rows(a, [&](int r, long doff) {
+                const float* d = dstp + n0 + wn * TN + li + doff;
 #pragma unroll
-                for (int b = 0; b < NI; ++b) acc[a][b][r] += dstp[doff + n0 + wn * TN + b * 32 + li];
+                for (int b = 0; b < NI; ++b) acc[a][b][r] += d[b * 32];
             });
     }
 
@@ -587,14 +588,18 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     }
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // the bias values of this lane's NI columns are loaded once (inside the row loop the compiler re-loaded them for every
+    // row, behind a vmcnt(0) wait, because the stores may alias them)
+    float bv[NI];
+#pragma unroll
+    for (int b = 0; b < NI; ++b) bv[b] = p.bias ? p.bias[n0 + wn * TN + b * 32 + li] : 0.f;
+    float* const dcol = dstp + n0 + wn * TN + li;
 #pragma unroll
     for (int a = 0; a < MI; ++a)
         for_rows(a, [&](int r, long doff) {
+            float* d = dcol + doff;
 #pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                const int col = n0 + wn * TN + b * 32 + li;
-                dstp[doff + col] = acc[a][b][r] + (p.bias ? p.bias[col] : 0.f);
-            }
+            for (int b = 0; b < NI; ++b) d[b * 32] = acc[a][b][r] + bv[b];
         });
 }
 
