@@ -512,24 +512,29 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
                         }
                     }
                 }
-                if (rbase + (r & 3) + 8 * (r >> 2) < qM)
-                    fn(r, (long)((unsigned)((n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * (unsigned)p.Cd));
+                const bool ok = rbase + (r & 3) + 8 * (r >> 2) < qM;
+                const int nn = ok ? n : 0, hh = ok ? hd : 0, ww = ok ? wd : 0;  // invalid rows point at a valid pixel
+                fn(r, ok, (long)((unsigned)((nn * p.Hdf + p.stride * hh + q.oh0) * p.Wdf + p.stride * ww + q.ow0) * (unsigned)p.Cd));
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < qM) fn(r, (long)((unsigned)row * (unsigned)p.Cd));
+                const bool ok = row < qM;
+                fn(r, ok, (long)((unsigned)(ok ? row : m0) * (unsigned)p.Cd));
             }
         }
     };
     if (p.accumulate) {
 #pragma unroll
         for (int a = 0; a < MI; ++a)
-            for_rows(a, [&](int r, long doff) {
-                const float* d = dstp + n0 + wn * TN + li + doff;
+            for_rows(a, [&](int r, bool ok, long doff) {  // unpredicated loads (rows past M read a valid pixel and add 0):
+                const float* d = dstp + n0 + wn * TN + li + doff;  // the 16 x NI loads of a block are in flight together
 #pragma unroll
-                for (int b = 0; b < NI; ++b) acc[a][b][r] += d[b * 32];
+                for (int b = 0; b < NI; ++b) {
+                    const float v = d[b * 32];
+                    acc[a][b][r] += ok ? v : 0.f;
+                }
             });
     }
 
@@ -593,13 +598,20 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     float bv[NI];
 #pragma unroll
     for (int b = 0; b < NI; ++b) bv[b] = p.bias ? p.bias[n0 + wn * TN + b * 32 + li] : 0.f;
+    // ... and pinned in registers BEFORE the (row-predicated) store blocks: a load still pending when a predicated block
+    // is entered makes the compiler wait vmcnt(0) in each of them — and on gfx9 vmcnt also counts the stores, so every
+    // row's store waited for the previous row's store to complete.
+#pragma unroll
+    for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
     float* const dcol = dstp + n0 + wn * TN + li;
 #pragma unroll
     for (int a = 0; a < MI; ++a)
-        for_rows(a, [&](int r, long doff) {
+        for_rows(a, [&](int r, bool ok, long doff) {
             float* d = dcol + doff;
+            if (ok) {
 #pragma unroll
-            for (int b = 0; b < NI; ++b) d[b * 32] = acc[a][b][r] + bv[b];
+                for (int b = 0; b < NI; ++b) d[b * 32] = acc[a][b][r] + bv[b];
+            }
         });
 }
 
