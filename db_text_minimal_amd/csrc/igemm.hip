@@ -376,15 +376,21 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 
     // two register sets: the global loads of k-tile t+2 are issued while tile t is multiplied and tile t+1 (loaded one
     // iteration earlier) is staged to LDS — a full k-step (~1 us) more latency tolerance than a prefetch distance of one
+    // Loads and staging are issued UNCONDITIONALLY every k-step (tiles past the end gather zeros through out-of-range buffer
+    // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
+    // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
     f32x4 ra_[2][A_LD], rb_[2][B_LD];
+    int b_left = 0;  // weight k-tiles that remain beyond the one bptr points at
     auto issue_loads = [&](auto SET) {
         constexpr int st_ = decltype(SET)::value;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) ra_[st_][j] = buffer_load_f32x4(rsrc, aoff[j]);
+        const long adv = b_left > 0 ? b_step : 0;
+        --b_left;
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             if (B_FULL || b_on[j]) rb_[st_][j] = *bptr[j];
-            bptr[j] += b_step;
+            bptr[j] += adv;
         }
     };
     auto stage = [&](int buf, auto SET) {
@@ -428,18 +434,18 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
+    b_left = kt_end - kt_begin - 1;
     next_offsets();
     issue_loads(C0{});
     next_offsets();  // offsets of tile 1
-    if (kt_begin + 1 < kt_end) issue_loads(C1{});
+    issue_loads(C1{});
     next_offsets();  // offsets of tile 2
     stage(0, C0{});
     __syncthreads();
 
     auto k_step = [&](int kt, auto PAR) {
         constexpr int buf = decltype(PAR)::value;  // parity of kt - kt_begin: LDS buffer and register set of tile kt
-        const bool more = kt + 1 < kt_end;
-        if (kt + 2 < kt_end) issue_loads(PAR);  // tile kt+2 into the register set tile kt was staged from
+        issue_loads(PAR);  // tile kt+2 into the register set tile kt was staged from
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
         if constexpr (NS == 0) {
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             mfma_split<NS, MI, NI>(af, bf, acc);
             next_offsets();
         }
-        if (more) stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
+        stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
     };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
