@@ -717,8 +717,12 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 
     // staging roles (wave-uniform): threads [0,BM) transpose the A panel (sm: 16 pixels x BM channels),
     // threads [NT-BN,NT) the B panel (gathered big: 16 pixels x BN (tap,channel) columns).
-    const bool is_a = tid < BM;
-    const bool is_b = tid >= NT - BN;
+    // roles are whole waves (BM, BN multiples of 64): derived from a scalar so that the role branches are scalar branches
+    // and the buffer descriptor of each load is provably uniform — with per-lane predicates the compiler had merged the two
+    // branches and wrapped every buffer load in a readfirstlane "waterfall" loop over the descriptor.
+    const int wave_first = __builtin_amdgcn_readfirstlane(tid) & ~63;
+    const bool is_a = wave_first < BM;
+    const bool is_b = wave_first >= NT - BN;
     const int slot = is_a ? tid : tid - (NT - BN);
     const int qn = is_a ? BM / 4 : BN / 4;
     const int s_c = slot % qn, s_g = slot / qn;  // column quad, pixel group (rows 4g..4g+3)
