@@ -534,14 +534,37 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     if (p.accumulate) {
 #pragma unroll
         for (int a = 0; a < MI; ++a)
-            for_rows(a, [&](int r, bool ok, long doff) {  // unpredicated loads (rows past M read a valid pixel and add 0):
-                const float* d = dstp + n0 + wn * TN + li + doff;  // the 16 x NI loads of a block are in flight together
+        {
+            if constexpr (MODE < 2) {
+                // unpredicated loads (rows past M read a valid pixel and add 0), issued four rows (4 x NI loads) at a time
+                // before their adds: left alone, the scheduler put each load right before its use with a full wait — 64
+                // dependent round trips per tile; whole blocks in flight would cost an occupancy step in registers
+                float old[4][NI];
+                bool okr[4];
+                for_rows(a, [&](int r, bool ok, long doff) {
+                    const float* d = dstp + n0 + wn * TN + li + doff;
+                    okr[r & 3] = ok;
 #pragma unroll
-                for (int b = 0; b < NI; ++b) {
-                    const float v = d[b * 32];
-                    acc[a][b][r] += ok ? v : 0.f;
-                }
-            });
+                    for (int b = 0; b < NI; ++b) old[r & 3][b] = d[b * 32];
+                    if ((r & 3) == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int b = 0; b < NI; ++b) acc[a][b][r - 3 + i] += okr[i] ? old[i][b] : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            } else {  // parity-class scatter: row by row (the pixel walk plus batched loads costs 40 VGPRs = an occupancy step)
+                for_rows(a, [&](int r, bool ok, long doff) {
+                    if (ok) {
+                        const float* d = dstp + n0 + wn * TN + li + doff;
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) acc[a][b][r] += d[b * 32];
+                    }
+                });
+            }
+        }
     }
 
     // ---- optional BatchNorm statistics of this tile (train-mode BN follows the conv): per output channel the
