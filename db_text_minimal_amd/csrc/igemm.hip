@@ -763,6 +763,14 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     unsigned woff[4];
     // byte offsets of this thread's 4 loads for k-tile kt (address math kept apart from the loads so that it
     // can be issued in the shadow of the previous tile's MFMAs)
+    // B role: pixel (n, oh, ow) of this thread's first row in the current k-tile, advanced by 16 pixels per call (offsets()
+    // is called for k-tiles 0, 1, 2, ... in order) instead of two divisions per k-tile
+    int w_n, w_oh, w_ow;
+    {
+        int rem;
+        divmod24(pbeg + 4 * s_g, HWo, p.rcp_HWo, w_n, rem);
+        divmod24(rem, p.Wo, p.rcp_Wo, w_oh, w_ow);
+    }
     auto offsets = [&](int kt) {
         const int pp0 = pbeg + kt * 16 + 4 * s_g;
         if (is_a) {
@@ -772,9 +780,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                 woff[i] = pp < pend ? (unsigned)(pp * p.O + o0 + 4 * s_c) * 4u : OOB_OFFSET;
             }
         } else if (is_b) {
-            int n, rem, oh, ow;
-            divmod24(pp0, HWo, p.rcp_HWo, n, rem);
-            divmod24(rem, p.Wo, p.rcp_Wo, oh, ow);
+            int n = w_n, oh = w_oh, ow = w_ow;
+            w_ow += 16;
+            while (w_ow >= p.Wo) {
+                w_ow -= p.Wo;
+                if (++w_oh == p.Ho) {
+                    w_oh = 0;
+                    ++w_n;
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ih = oh * p.stride + tr, iw = ow * p.stride + ts;
