@@ -673,3 +673,36 @@ def test_head_tail_with_fused_batchnorm_relu():
     report('fused head bwd dz_t', nchw(dxt), grads[1], 1e-4, 1e-3)
     report('fused head bwd dwb', dwb.cpu().view(64, 1, 2, 2), grads[2], 1e-3, 1e-3)
     report('fused head bwd dwt', dwt.cpu().view(64, 1, 2, 2), grads[4], 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('ns', [0, 3])
+def test_batched_weight_pack_equals_single_packs(ns):
+    """dbn_pack_weights_batched (one launch, device job table) produces exactly the panels of the per-weight
+    dbn_pack_weights / dbn_pack_weights_bf16s calls, including the f*f parity-class panels of strided transposed convs."""
+    import ctypes
+    jobs_spec = [((64, 3, 7, 7), 0, 2), ((128, 64, 3, 3), 0, 1), ((128, 64, 3, 3), 1, 2), ((64, 256, 10, 10), 1, 8), ((64, 64, 2, 2), 1, 2),
+                 ((256, 128, 1, 1), 1, 1), ((64, 256, 6, 6), 1, 4)]
+
+    class Job(ctypes.Structure):
+        _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + [(f, ctypes.c_int) for f in ('O', 'I', 'R', 'S', 'mode', 'Cs', 'Cd', 'f')]
+
+    ws, singles, outs = [], [], []
+    arr = (Job * len(jobs_spec))()
+    for i, (shape, mode, stride) in enumerate(jobs_spec):
+        w = rnd(*shape, seed=50 + i)
+        O, I, R, S = shape
+        if (mode == 0 and O % 64) or (mode == 1 and I % 64):
+            continue
+        wd = w.to(DEV)
+        singles.append(pack(w, mode, stride, ns))
+        out = torch.full_like(singles[-1], float('nan'))
+        ws.append(wd)
+        outs.append(out)
+        arr[len(outs) - 1] = Job(wd.data_ptr(), out.data_ptr(), O, I, R, S, mode, (I + 3) // 4 * 4 if mode == 0 else O, O if mode == 0 else I,
+                                 stride if (mode == 1 and stride > 1) else 1)
+    n = len(outs)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)[:n * ctypes.sizeof(Job)].clone().to(DEV)
+    _lib.check(L().dbn_pack_weights_batched(table.data_ptr(), n, ns, stream()), 'pack_batched')
+    torch.cuda.synchronize()
+    for a, b in zip(outs, singles):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
