@@ -10,10 +10,11 @@ libdbnet_hip.so.  Inputs are resident in HBM before the timed region.  One proce
 (launched by torch.distributed.run for N > 1); rank 0 prints ONE JSON line.
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel (fp32 MFMA implicit-GEMM conv): algorithmic FLOP/s from
-                HIP-event brackets around its launches inside the timed region, vs 157.3 TFLOP/s
-  kernels       the same figure for every igemm tile variant, the weight-gradient kernel and the
-                HBM-bound DB-head kernel (instrumented extra step after the timed region)
+  roofline      the dominant kernel (the MFMA kernel — implicit-GEMM conv or weight gradient — with the largest share
+                of the step): algorithmic FLOP/s from HIP-event brackets around its launches inside the timed
+                region, vs the MFMA peak of the conv math in use (157.3 TFLOP/s for exact fp32)
+  kernels       the same figure for every igemm tile variant, the weight-gradient kernels and the
+                HBM-bound DB-head kernels (instrumented extra step after the timed region)
   cpu_baseline  the CPU oracle (oracle/dbnet_oracle.py, plain PyTorch fp32) timed on this host
 """
 import argparse
@@ -29,8 +30,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
-TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem dgrad
+TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem dgrad (dense convolution count)
+# what the matrix pipe computes per conv math mode: dtype of the JSON line, wording of the workload, MFMA peak that bounds it
+# (bf16x3 evaluates six bf16 products per fp32 product: its roofline is the bf16 peak / 6)
+MATH = {
+    'f32': ('f32', 'fp32 (exact-fp32 MFMA)', PEAK_F32_MFMA_TFLOPS),
+    'bf16x3': ('bf16x3', 'fp32 tensors, conv products on the bf16 matrix pipe as an exact 3-way operand split (fp32-accurate)',
+               PEAK_BF16_MFMA_TFLOPS / 6.0),
+    'bf16': ('bf16', 'conv operands rounded to bf16, fp32 accumulate', PEAK_BF16_MFMA_TFLOPS),
+}
 
 
 def synthetic(n, size, seed, dev):
@@ -110,7 +120,7 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', ))
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'wgrad_f32_kernel'))
     TIMED_EVERY = 4
     barrier()
     t0 = time.perf_counter()
@@ -137,15 +147,16 @@ def main():
     eng.prof = None
     serial_summ = timer2.summary()
 
-    # dominant kernel = the igemm tile variant with the largest share of the step when every kernel has the device to itself
-    # (under two streams the concurrent weight-gradient kernels inflate the bracketed durations of the backward launches,
-    # which would otherwise decide the ranking); its figures below are the ones measured INSIDE the timed region.
+    # dominant kernel = the MFMA kernel (any igemm tile variant or weight-gradient variant) with the largest share of the step
+    # when every kernel has the device to itself (under two streams concurrent kernels inflate each other's bracketed
+    # durations, which would otherwise decide the ranking); its figures below are the ones measured INSIDE the timed region.
+    dtype, math_words, peak_mfma = MATH[args.math]
     summ = timer.summary()
-    dname = max((k for k in serial_summ if k.startswith('igemm_f32_kernel') and k in summ), key=lambda k: serial_summ[k]['ms'])
+    dname = max((k for k in serial_summ if serial_summ[k]['flops'] > 0 and k in summ), key=lambda k: serial_summ[k]['ms'])
     d = summ[dname]
     achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': dname, 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+    roofline = {'bound': 'mfma', 'kernel': dname, 'achieved': round(achieved, 2), 'peak': round(peak_mfma, 1),
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak_mfma, 4), 'traffic': None,
                 'launches_per_step': d['launches'] // timed_steps, 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                 'share_of_step_time': round(d['ms'] / timed_steps / (dt / args.steps * 1e3), 4),
@@ -167,8 +178,8 @@ def main():
     serial = serial_summ.get(dname)
     if serial and serial['ms'] > 0:
         a = serial['flops'] / (serial['ms'] * 1e-3) / 1e12
-        roofline_serial = {'kernel': dname, 'achieved': round(a, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(a / PEAK_F32_MFMA_TFLOPS, 4), 'launches': serial['launches'],
+        roofline_serial = {'kernel': dname, 'achieved': round(a, 2), 'peak': round(peak_mfma, 1), 'unit': 'TFLOP/s',
+                           'frac': round(a / peak_mfma, 4), 'launches': serial['launches'],
                            'avg_launch_ms': round(serial['ms'] / serial['launches'], 4),
                            'how': 'one extra step outside the timed region, every launch bracketed by HIP events, single stream'}
     else:
@@ -178,8 +189,8 @@ def main():
             ent = {'kernel': name, 'launches': v['launches'], 'ms_per_step': round(v['ms'], 3)}
             if v['flops'] > 0:
                 a = v['flops'] / (v['ms'] * 1e-3) / 1e12
-                ent.update(bound='mfma', achieved=round(a, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                           frac=round(a / PEAK_F32_MFMA_TFLOPS, 4))
+                ent.update(bound='mfma', achieved=round(a, 2), peak=round(peak_mfma, 1), unit='TFLOP/s',
+                           frac=round(a / peak_mfma, 4))
             elif v['bytes'] > 0:
                 a = v['bytes'] / (v['ms'] * 1e-3) / 1e9
                 ent.update(bound='hbm', achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
@@ -209,15 +220,21 @@ def main():
         line = {
             'metric': 'train images/sec @640x640 bs=16/GPU', 'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'ResNet18-FPN-DBHead DBNet train step (fwd+DBLoss+bwd+Adam), %dx%d, bs %d/GPU, fp32, '
-                                   'random-init weights (BASELINE configs[1])' % (args.size, args.size, args.batch),
+            'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': 'ResNet18-FPN-DBHead DBNet train step (fwd+DBLoss+bwd+Adam), %dx%d, bs %d/GPU, %s, '
+                                   'random-init weights (BASELINE configs[%d])' % (args.size, args.size, args.batch, math_words,
+                                                                                    1 if args.math == 'f32' else 2),
                        'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': ('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, issued as 4 contiguous buckets under '
                                           'the backward pass (FPN+head, layer4, layer3, rest)') if world > 1 else None},
             'roofline': roofline,
             'roofline_serial': roofline_serial,
+            # whole-step rates: on the dense convolution count of SURVEY §8d (an EFFECTIVE rate: the structured FPN kernels
+            # skip ~0.77 TFLOP/step of it) and on the FLOPs the MFMA kernels actually execute (sum over the instrumented step)
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / ms, 2),
+            'step_tflops_executed': round(sum(v['flops'] for v in serial_summ.values()) / 1e9 / ms, 2),
+            'step_tflop_dense': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / 1e3, 3),
+            'step_tflop_executed': round(sum(v['flops'] for v in serial_summ.values()) / 1e12, 3),
             'kernels': kernels,
             'conv_math': args.math,
             'alt_modes': alt,

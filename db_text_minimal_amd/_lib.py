@@ -38,6 +38,8 @@ SIGNATURES = {
     'dbn_wgrad_bf16s': 'pppp' + 'i' * 12 + 'fip',
     'dbn_wgrad_splitk': 'iiiiiii',
     'dbn_wgrad_slab_floats': 'iiiiiii',
+    'dbn_wgrad_splitk_hw': 'iiiiiiiii',
+    'dbn_set_index_limits': 'lll',
     'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
     'dbn_reduce_ws_floats': 'i',
     'dbn_bn_train_stats': 'piippffppppppp' + 'p',
@@ -61,6 +63,7 @@ SIGNATURES = {
     'dbn_head_tail_bwd': 'p' * 21 + 'iiii' + 'ff' + 'pp',
     'dbn_db_loss_ws_bytes': '',
     'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
+    'dbn_db_loss_sum_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
     'dbn_db_loss_ohem_ws_bytes': 'iii',
     'dbn_db_loss_ohem_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',

@@ -243,6 +243,19 @@ __global__ void fold_partials_d_kernel(const float* __restrict__ part, int nb, i
     if (l32 == 0) out[i] = (float)(s * scale);
 }
 
+// partial rows [dwb 256][dbias_b][dwt 256][dbias_t] folded straight into their four destinations
+__global__ void fold_head_grads_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw_b, float* __restrict__ dbias_b,
+                                       float* __restrict__ dw_t, float* __restrict__ dbias_t, float scale) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & 31;
+    if (i >= 2 * 257) return;
+    const double s = dbn_team32_fold(part, nb, i, l32);
+    if (l32 != 0) return;
+    const int j = i < 257 ? i : i - 257;
+    float* dst = i < 257 ? (j < 256 ? dw_b + j : dbias_b) : (j < 256 ? dw_t + j : dbias_t);
+    *dst = (float)(s * scale);
+}
+
 // ----------------------------------------------------------------------------------
 // loss
 // ----------------------------------------------------------------------------------
@@ -328,7 +341,8 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
 //   0: c_bce = (sum_pos + n_neg)/(n_pos+n_neg+eps)/px   1: 1/(sum_A+eps)
 //   2: dice U   3: dice I   4: has_pos flag (n_pos + n_neg > 0 ... always 1; kept for clarity)
 __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb, long px, int CH, float alpha, float beta,
-                                        float negative_ratio, float eps, float* __restrict__ losses, float* __restrict__ coef) {
+                                        float negative_ratio, float eps, int bce_sum, float* __restrict__ losses,
+                                        float* __restrict__ coef) {
     // one 256-thread block: 32 lanes fold each of the NSUM (<= 8) partial columns, thread 0 finishes
     __shared__ double sums[8];
     {
@@ -349,7 +363,9 @@ __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb,
     const long n_neg_expect = (long)((double)n_pos * (double)negative_ratio);
     const long n_neg_cur = (long)(float)s[S_NEG];
     const long n_neg = n_neg_expect < n_neg_cur ? n_neg_expect : n_neg_cur;
-    const float bce = (float)(s[S_BCE] / (double)px);  // reduction='mean': scalar over all pixels
+    // reduction='mean' (default) / 'sum': F.binary_cross_entropy returns ONE scalar over all pixels (losses.py:30)
+    const double bce_div = bce_sum ? 1.0 : (double)px;
+    const float bce = (float)(s[S_BCE] / bce_div);
     // positive_loss.sum() = bce*sum_pos; topk(bce*negative, n_neg).sum() = bce*n_neg for binary maps
     const float denom = (float)((double)(n_pos + n_neg) + (double)eps);
     const float num_w = (float)s[S_POS] + (float)n_neg;
@@ -358,7 +374,7 @@ __global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb,
     const float pt = prob + beta * thr;
     losses[0] = prob;
     losses[1] = thr;
-    coef[0] = num_w / denom / (float)px;
+    coef[0] = num_w / denom / (float)bce_div;
     coef[1] = 1.f / ((float)s[S_A] + eps);
     if (CH == 3) {
         const float U = (float)s[S_BM] + (float)s[S_POS] + eps;
@@ -658,21 +674,12 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
     DBN_REQUIRE(!sums || (bn_scale_b && bn_mean_b && bn_rstd_b && bn_mean_t && bn_rstd_t));
     hipStream_t st = (hipStream_t)stream;
     const long npx = (long)N * Hq * Wq;
-    const int nb = dbn_grid(npx * 16, 256, 2047);
-    constexpr int ROWS = 2 * 257 + 4 * 64;
+    const int nb = dbn_grid(npx * 16, 256, 2047);  // < 2048 partial rows: fits dbn_head_tail_bwd_ws_floats()
     hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, bn_scale_b, bn_shift_b,
                        bn_scale_t, bn_shift_t, sums ? bn_mean_b : nullptr, bn_rstd_b, bn_mean_t, bn_rstd_t, dxb, dxt, ws, N, Hq, Wq,
                        channels, kstep);
-    // fold partials: layout [dwb 256][dbias_b][dwt 256][dbias_t] -> staged in the tail of ws, then scattered by 4 tiny copies
-    float* folded = ws + (long)2048 * ROWS - 2 * 257;
-    // nb <= 2047 partial rows may be used without touching the tail
-    if (nb >= 2048) return DBN_ERR_ARG;
-    hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(2 * 257, 8)), dim3(256), 0, st, ws, nb, 2 * 257, folded,
+    hipLaunchKernelGGL(fold_head_grads_kernel, dim3(dbn_ceil_div(2 * 257, 8)), dim3(256), 0, st, ws, nb, dw_b, dbias_b, dw_t, dbias_t,
                        grad_scale);
-    (void)hipMemcpyAsync(dw_b, folded, 256 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbias_b, folded + 256, sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dw_t, folded + 257, 256 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(dbias_t, folded + 257 + 256, sizeof(float), hipMemcpyDeviceToDevice, st);
     if (sums)  // [s1_b | s2_b | s1_t | s2_t]: two [2][64] blocks for dbn_bn_backward_from_sums
         hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(256, 8)), dim3(256), 0, st, ws + (long)514 * nb, nb, 256, bn_sums,
                            1.0f);
@@ -699,8 +706,8 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     else
         hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
     hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
-                       beta, negative_ratio, eps, losses, coef);
-    if (!per_pixel) return dbn_status();
+                       beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef);
+    if (per_pixel != 1) return dbn_status();
     double* part_pos = (double*)(base + OHEM_OFF_POS);
     double* part_sel = (double*)(base + OHEM_OFF_SEL);
     unsigned long long* state = (unsigned long long*)(base + OHEM_OFF_ST);
@@ -724,6 +731,13 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
 int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                     float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
     return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, 0, losses, coef, ws, stream);
+}
+
+// DBLoss(reduction='sum'): like dbn_db_loss_fwd with the scalar BCE summed instead of averaged (losses.py:30 forwards the
+// reduction string to F.binary_cross_entropy); backward through dbn_db_loss_bwd with the coef written here.
+int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                        float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
+    return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, 2, losses, coef, ws, stream);
 }
 
 // DBLoss(reduction='none'): true per-pixel OHEM (top n_neg negative losses, device radix select).

@@ -25,6 +25,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -68,13 +69,15 @@ struct IgemmParams {
     const float* bias;  // [Cd] or null
     float* dst;         // [N,Hdf,Wdf,Cd]
     int N, Hs, Ws, Cs, Cd, Hdf, Wdf, R, S, stride, pad, accumulate, ncls;
-    int stat_rows;      // total M-tiles of the launch
+    int stat_rows;      // rows of the partials array (all M-tiles of the call; a call over many images runs as several launches)
+    int stat_row0;      // first row this launch writes
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
     unsigned src_bytes;
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
     // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
     int ksplit, kt_per;
+    int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
     const float* seg_src[4];
     const float* seg_wpk[4];
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             }
         }
         __syncthreads();
-        const int trow = q_row_base + mt;
+        const int trow = p.stat_row0 + q_row_base + mt;
         for (int cl = tid; cl < BN; cl += NT) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -664,7 +667,8 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
         rows = dbn_ceil_div(p.N * p.Hdf * p.Wdf, BM);
         grid = rows * (p.Cd / BN);
     }
-    p.stat_rows = rows;
+    if (p.stat_rows <= 0) p.stat_rows = rows;  // a chunked call sets the total itself
+    p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
     if (mode == 0)
@@ -1233,33 +1237,57 @@ static long panel_floats(int K, int Cd, int ns) {
     return ns == 0 ? kp * Cd : kp * Cd * ns / 2;
 }
 
-static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
-                     int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr) {
-    DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
-    DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
-    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
-    DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
-    DBN_REQUIRE((long)N * Hd * Wd < (1L << 24) && (long)N * Hs * Ws * Cs * 4 < 0xF0000000L);
-    DBN_REQUIRE((long)N * Hd * Wd * Cd < (1L << 32));  // 32-bit element offsets in the epilogue
-    hipStream_t st = (hipStream_t)stream;
+// ---- image chunking ---------------------------------------------------------------------------------------------
+// The kernels index pixels with 24-bit reciprocal divisions and address tensors through raw buffer descriptors with 32-bit
+// byte offsets.  Images are independent in every convolution, so a call whose tensors exceed those ranges runs as several
+// launches over consecutive image ranges (same tile configuration; BatchNorm partial rows simply continue).
+static long g_pixel_limit = 1L << 24;        // rows per launch (divmod24)
+static long g_byte_limit = 0xF0000000L;      // bytes addressable through one buffer descriptor
+static long g_elem_limit = 1L << 32;         // 32-bit element offsets of the epilogue
+
+static int chunk_images(int N, long px_rows, long src_bytes_per_image, long dst_elems_per_image, long src2_bytes_per_image = 0) {
+    long n = N;
+    auto fit = [&](long per_image, long limit) {
+        if (per_image > 0 && per_image * n >= limit) n = (limit - 1) / per_image;
+    };
+    fit(px_rows, g_pixel_limit);
+    fit(src_bytes_per_image, g_byte_limit);
+    fit(src2_bytes_per_image, g_byte_limit);
+    fit(dst_elems_per_image, g_elem_limit);
+    return (int)n;  // 0: a single image does not fit
+}
+
+static int resolve_cfg(int M_total, int Cd, int tile_hint) {
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
+    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    return cfg;
+}
+
+static int igemm_run_one(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                         int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
+                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out) {
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
-    p.stats = stats; p.stat_rows = 0;
+    p.stats = stats; p.stat_rows = stat_rows; p.stat_row0 = stat_row0; p.launch_rows = 0;
     p.ksplit = 1; p.kt_per = 0;
     p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
     if (!(mode == 1 && stride > 1)) {
         p.ncls = 1;
-        if (ksplit <= 1) return igemm_dispatch(p, mode, ns, tile_hint, st);
+        if (ksplit <= 1) {
+            const int rc = igemm_dispatch(p, mode, ns, cfg, st);
+            *rows_out = p.launch_rows;
+            return rc;
+        }
         // split-K: slabs of partial sums, then a fixed-order reduction that also applies bias / accumulate
         const int KT = (R * S * Cs + 15) / 16;
         DBN_REQUIRE(slab && !stats && Cs % 16 == 0 && ksplit <= KT && ksplit <= 64);
         p.kt_per = dbn_ceil_div(KT, ksplit);
         p.ksplit = dbn_ceil_div(KT, p.kt_per);
         p.dst = slab; p.bias = nullptr; p.accumulate = 0;
-        const int rc = igemm_dispatch(p, mode, ns, tile_hint, st);
+        const int rc = igemm_dispatch(p, mode, ns, cfg, st);
+        *rows_out = p.launch_rows;
         if (rc) return rc;
         const long total4 = (long)N * Hd * Wd * Cd / 4;
         hipLaunchKernelGGL(splitk_sum_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit, total4, Cd, bias, accumulate,
@@ -1283,8 +1311,49 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
         if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * sizeof(float), st) != hipSuccess) return dbn_status();
         p.accumulate = 1;
     }
+    *rows_out = 0;
     if (covered == 0) return DBN_OK;
-    return igemm_dispatch(p, 2, ns, tile_hint, st);
+    const int rc = igemm_dispatch(p, 2, ns, cfg, st);
+    *rows_out = p.launch_rows;
+    return rc;
+}
+
+// Rows of BatchNorm partials ONE launch over n images produces
+static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg) {
+    const int bm_of[5] = {0, 128, 256, 128, 64};
+    if (!(mode == 1 && stride > 1)) return dbn_ceil_div((long)n * Hd * Wd, bm_of[cfg]);
+    int rows = 0;
+    for (int c = 0; c < stride * stride; ++c) {  // BN follows only tap-complete transposed convs: every class has pixels
+        const int ph = c / stride, pw = c % stride;
+        const int Hc = ph < Hd ? (Hd - ph + stride - 1) / stride : 0, Wc = pw < Wd ? (Wd - pw + stride - 1) / stride : 0;
+        if (Hc > 0 && Wc > 0) rows += dbn_ceil_div((long)n * Hc * Wc, bm_of[cfg]);
+    }
+    return rows;
+}
+
+static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                     int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0) {
+    DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
+    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
+    DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
+    DBN_REQUIRE(tile_hint >= 0 && tile_hint <= 4);
+    hipStream_t st = (hipStream_t)stream;
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * 4, (long)Hd * Wd * Cd);
+    DBN_REQUIRE(nmax >= 1);               // one image must fit the kernel's index ranges
+    DBN_REQUIRE(nmax >= N || ksplit <= 1);  // split-K is for small outputs only
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
+    int row0 = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        int rows = 0;
+        const int rc = igemm_run_one(src + (long)n0 * Hs * Ws * Cs, wpk, bias, dst + (long)n0 * Hd * Wd * Cd, n, Hs, Ws, Cs, Hd, Wd, Cd,
+                                     R, S, stride, pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows);
+        if (rc) return rc;
+        row0 += rows;
+    }
+    return DBN_OK;
 }
 
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -1292,31 +1361,22 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, 0, stream);
 }
 
-// Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32)
-static int bn_tile_rows(int N, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint) {
-    const int bm_of[5] = {0, 128, 256, 128, 64};
-    if (!(mode == 1 && stride > 1)) {
-        const int M = N * Hd * Wd;
-        int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M, Cd);
-        if (cfg == 1 && Cd % 128 != 0) cfg = 3;
-        return dbn_ceil_div(M, bm_of[cfg]);
-    }
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(N * Hd * Wd, Cd);
-    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+// Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32); follows igemm_run's chunking
+static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint) {
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * 4, (long)Hd * Wd * Cd);
+    if (nmax < 1) return 0;
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
     int rows = 0;
-    for (int c = 0; c < stride * stride; ++c) {  // BN follows only tap-complete transposed convs: every class has pixels
-        const int ph = c / stride, pw = c % stride;
-        const int Hc = ph < Hd ? (Hd - ph + stride - 1) / stride : 0, Wc = pw < Wd ? (Wd - pw + stride - 1) / stride : 0;
-        if (Hc > 0 && Wc > 0) rows += dbn_ceil_div(N * Hc * Wc, bm_of[cfg]);
-    }
+    for (int n0 = 0; n0 < N; n0 += nmax) rows += bn_tile_rows_one(std::min(nmax, N - n0), Hd, Wd, mode, stride, cfg);
     return rows;
 }
 
 // floats of scratch for the fused conv + BatchNorm-statistics call
 long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) {
+    // worst case over the tile configurations and the image chunking (one launch per image: every launch rounds up)
     long worst = 0;
     for (int t = 1; t <= 4; ++t) {
-        const long r = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, t);
+        const long r = (long)N * bn_tile_rows_one(1, Hd, Wd, mode, stride, t);
         worst = r > worst ? r : worst;
     }
     return (3L * Cd + 1) * worst;
@@ -1330,8 +1390,10 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
                     const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                     float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
-    const int rows = bn_tile_rows(N, Hd, Wd, Cd, mode, stride, tile_hint);
-    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws);
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint);
+    DBN_REQUIRE(rows > 0);
+    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,
+                             1, nullptr, rows);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
@@ -1381,9 +1443,12 @@ int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
 // ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
-static int pyramid_rows(int N, int H, int W) { return 64 * dbn_ceil_div((long)N * (H >> 3) * (W >> 3), 128); }
+static int pyramid_chunk(int N, int H, int W, int Cs, int Cd) {
+    return chunk_images(N, (long)H * W, (long)H * W * Cs * 4, (long)H * W * Cd);
+}
+static int pyramid_rows_one(int n, int H, int W) { return 64 * dbn_ceil_div((long)n * (H >> 3) * (W >> 3), 128); }
 
-long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * pyramid_rows(N, H, W); }
+long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * N * pyramid_rows_one(1, H, W); }
 
 int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
                          const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
@@ -1391,29 +1456,38 @@ int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, cons
                          float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
-    DBN_REQUIRE((long)N * H * W < (1L << 24) && (long)N * H * W * Cs * 4 < 0xF0000000L && (long)N * H * W * Cd < (1L << 32));
     DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
     const bool bn = gamma != nullptr;
     DBN_REQUIRE(!bn || (beta && scale && shift && save_mean && save_rstd && ws));
-    IgemmParams p;
+    const int nmax = pyramid_chunk(N, H, W, Cs, Cd);  // images per launch (24-bit pixel indices, 32-bit offsets)
+    DBN_REQUIRE(nmax >= 1);
+    int rows_total = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) rows_total += pyramid_rows_one(std::min(nmax, N - n0), H, W);
+    hipStream_t st = (hipStream_t)stream;
     const float* srcs[4] = {s0, s1, s2, s3};
     const float* wpks[4] = {w0, w1, w2, w3};
-    for (int g = 0; g < 4; ++g) {
-        p.seg_src[g] = srcs[g];
-        p.seg_wpk[g] = wpks[g];
-        p.seg_bytes[g] = (unsigned)((long)N * (H >> g) * (W >> g) * Cs * 4);
+    int row0 = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        IgemmParams p;
+        for (int g = 0; g < 4; ++g) {
+            p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs;
+            p.seg_wpk[g] = wpks[g];
+            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * 4);
+        }
+        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = dst + (long)n0 * H * W * Cd;
+        p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
+        p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
+        p.stats = bn ? ws : nullptr;
+        p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
+        p.ksplit = 1; p.kt_per = 0;
+        p.src_bytes = p.seg_bytes[0];
+        const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st);
+        if (rc) return rc;
+        row0 += p.launch_rows;
     }
-    p.src = s0; p.wpk = w0; p.bias = bias; p.dst = dst;
-    p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
-    p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
-    p.stats = bn ? ws : nullptr;
-    p.stat_rows = 0;
-    p.ksplit = 1; p.kt_per = 0;
-    p.src_bytes = p.seg_bytes[0];
-    hipStream_t st = (hipStream_t)stream;
-    const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st);
-    if (rc || !bn) return rc;
-    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(p.stat_rows >= 2048 ? 1024 : 256), 0, st, ws, p.stat_rows, Cd, gamma,
+    if (!bn) return DBN_OK;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows_total >= 2048 ? 1024 : 256), 0, st, ws, rows_total, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
 }
@@ -1492,9 +1566,9 @@ static void wgrad_tiles(int O, int J, int& bm, int& bn) {
     bn = (J >= 128) ? 128 : 64;
 }
 
-// Number of pixel splits dbn_wgrad_f32 will use.
-int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
-    const long P = (long)N * Ho * Wo;
+// Pixel splits of ONE launch over n images
+static int wgrad_splitk_one(int n, int Ho, int Wo, int O, int Cb, int R, int S) {
+    const long P = (long)n * Ho * Wo;
     const int J = R * S * Cb;
     int bm, bn;
     wgrad_tiles(O, J, bm, bn);
@@ -1525,37 +1599,68 @@ int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return (int)((P + pchunk - 1) / pchunk);
 }
 
-// Floats of slab scratch dbn_wgrad_f32 needs: splitk * O * (R*S*Cb rounded up to the tile width).
+// images per launch: 24-bit pixel indices, 32-bit byte offsets into dY and X
+static int wgrad_chunk(int N, int Ho, int Wo, int O, int H, int W, int Cb) {
+    long n = N;
+    const long px = (long)Ho * Wo;
+    if (px * n >= g_pixel_limit - 64) n = (g_pixel_limit - 65) / px;
+    return (int)std::min<long>(n, chunk_images(N, 0, px * O * 4, 0, (long)H * W * Cb * 4));
+}
+
+// Number of pixel splits (slabs) dbn_wgrad_f32 will use, over all its launches.
+int dbn_wgrad_splitk_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int R, int S) {
+    const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb);
+    if (nmax < 1) return 0;
+    int tot = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) tot += wgrad_splitk_one(std::min(nmax, N - n0), Ho, Wo, O, Cb, R, S);
+    return tot;
+}
+// (input size unknown: assumes a stride <= 8 conv, X no larger than 64x dY's pixel count — only the chunking depends on it)
+int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) { return dbn_wgrad_splitk_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S); }
+
+// Floats of slab scratch dbn_wgrad_f32 needs: splits * O * (R*S*Cb rounded up to the tile width).  Upper bound over the image
+// chunking (one launch per image rounds every split count up).
 long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     const int J = R * S * Cb;
     int bm, bn;
     wgrad_tiles(O, J, bm, bn);
     const long Jp = (long)((J + bn - 1) / bn) * bn;
-    return (long)dbn_wgrad_splitk(N, Ho, Wo, O, Cb, R, S) * O * Jp;
+    long splits = wgrad_splitk_one(N, Ho, Wo, O, Cb, R, S);
+    if ((long)N * Ho * Wo >= g_pixel_limit / 8) {  // chunking may apply (X can be up to 64x dY): bound by per-image launches
+        const long per = (long)N * wgrad_splitk_one(1, Ho, Wo, O, Cb, R, S);
+        splits = per > splits ? per : splits;
+    }
+    return splits * O * Jp;
 }
 
 static int wgrad_run(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                      int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream) {
     DBN_REQUIRE(sm && big && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
-    WgradParams p;
-    p.sm = sm; p.big = big; p.slab = slab;
-    p.N = N; p.Ho = Ho; p.Wo = Wo; p.O = O; p.H = H; p.W = W; p.Cb = Cb; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-    p.P = N * Ho * Wo;
-    p.J = R * S * Cb;
-    DBN_REQUIRE((long)N * Ho * Wo < (1L << 24) - 64);
-    DBN_REQUIRE((long)N * Ho * Wo * O * 4 < 0xF0000000L && (long)N * H * W * Cb * 4 < 0xF0000000L);
-    p.rcp_HWo = 1.0f / (float)(Ho * Wo);
-    p.rcp_Wo = 1.0f / (float)Wo;
-    p.sm_bytes = (unsigned)((long)N * Ho * Wo * O * 4);
-    p.big_bytes = (unsigned)((long)N * H * W * Cb * 4);
-    const int splitk = dbn_wgrad_splitk(N, Ho, Wo, O, Cb, R, S);
-    p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
+    const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb);
+    DBN_REQUIRE(nmax >= 1);
     hipStream_t st = (hipStream_t)stream;
     int bm, bn;
-    wgrad_tiles(O, p.J, bm, bn);
-    const int njt = (p.J + bn - 1) / bn;
-    dim3 grid((O / bm) * njt * splitk);
+    const int J = R * S * Cb;
+    wgrad_tiles(O, J, bm, bn);
+    const int njt = (J + bn - 1) / bn;
+    const int Jp = njt * bn;
+    int splits_total = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        WgradParams p;
+        p.sm = sm + (long)n0 * Ho * Wo * O; p.big = big + (long)n0 * H * W * Cb;
+        p.slab = slab + (long)splits_total * O * Jp;
+        p.N = n; p.Ho = Ho; p.Wo = Wo; p.O = O; p.H = H; p.W = W; p.Cb = Cb; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+        p.P = n * Ho * Wo;
+        p.J = J;
+        p.rcp_HWo = 1.0f / (float)(Ho * Wo);
+        p.rcp_Wo = 1.0f / (float)Wo;
+        p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * 4);
+        p.big_bytes = (unsigned)((long)n * H * W * Cb * 4);
+        const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);
+        p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
+        dim3 grid((O / bm) * njt * splitk);
 #define DBN_WGRAD_LAUNCH(NS_)                                                                             \
     do {                                                                                                    \
         if (bn == 192)                                                                                      \
@@ -1567,16 +1672,25 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
         else                                                                                                \
             hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_>), grid, dim3(256), 0, st, p);           \
     } while (0)
-    if (ns == 0) DBN_WGRAD_LAUNCH(0);
-    else if (ns == 1) DBN_WGRAD_LAUNCH(1);
-    else DBN_WGRAD_LAUNCH(3);
+        if (ns == 0) DBN_WGRAD_LAUNCH(0);
+        else if (ns == 1) DBN_WGRAD_LAUNCH(1);
+        else DBN_WGRAD_LAUNCH(3);
 #undef DBN_WGRAD_LAUNCH
-    int rc = dbn_status();
-    if (rc) return rc;
-    const int Jp = njt * bn;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splitk, O, p.J, Jp, bm, bn, Cb, I, R,
-                       S, grad_oihw, scale);
+        const int rc = dbn_status();
+        if (rc) return rc;
+        splits_total += splitk;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn, Cb,
+                       I, R, S, grad_oihw, scale);
     return dbn_status();
+}
+
+// Test hook: lower the per-launch index ranges so that the image chunking runs at small sizes (0 restores a default).
+int dbn_set_index_limits(long pixel_rows, long bytes, long elems) {
+    g_pixel_limit = pixel_rows > 0 ? pixel_rows : (1L << 24);
+    g_byte_limit = bytes > 0 ? bytes : 0xF0000000L;
+    g_elem_limit = elems > 0 ? elems : (1L << 32);
+    return DBN_OK;
 }
 
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

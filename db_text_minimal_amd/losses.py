@@ -10,6 +10,7 @@ The reductions and the gradient are two HIP kernels (dbn_db_loss_fwd/_bwd).
 With the default `reduction='mean'` the reference's "OHEM" term is a scalar BCE
 re-weighted by counts; the kernel evaluates that closed form,
 which is exact for binary gt/mask maps (what the reference's loader produces).
+`reduction='sum'` sums that scalar instead of averaging it (dbn_db_loss_sum_fwd).
 `reduction='none'` is the paper's per-pixel OHEM: the `n_neg` hardest negatives
 are selected on device by a 3-pass radix select (dbn_db_loss_ohem_fwd/_bwd)
 instead of `torch.topk` over 6.5 M elements.
@@ -31,14 +32,15 @@ class _DBLossFunction(torch.autograd.Function):
         st = torch.cuda.current_stream(preds.device).cuda_stream
         losses = torch.empty(5, device=preds.device, dtype=torch.float32)
         coef = torch.zeros(8, device=preds.device, dtype=torch.float32)
-        if per_pixel:
+        if per_pixel == 1:
             ws = torch.empty(L.dbn_db_loss_ohem_ws_bytes(N, H, W) // 4 + 1, device=preds.device, dtype=torch.float32)
             check(L.dbn_db_loss_ohem_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
                                          losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_ohem_fwd')
         else:
             ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=preds.device, dtype=torch.float32)
-            check(L.dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
-                                    losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_fwd')
+            fwd = L.dbn_db_loss_sum_fwd if per_pixel == 2 else L.dbn_db_loss_fwd
+            check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
+                      losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_fwd')
         ctx.save_for_backward(preds, gts, coef, ws)
         ctx.cfg = (alpha, beta, per_pixel)
         if C == 3:
@@ -60,7 +62,7 @@ class _DBLossFunction(torch.autograd.Function):
         else:
             g[4] = gouts[0]
         dpreds = torch.empty_like(preds)
-        if per_pixel:
+        if per_pixel == 1:
             check(L.dbn_db_loss_ohem_bwd(preds.data_ptr(), gts.data_ptr(), coef.data_ptr(), g.data_ptr(), ws.data_ptr(), alpha, beta,
                                          N, H, W, C, dpreds.data_ptr(), st), 'db_loss_ohem_bwd')
         else:
@@ -72,9 +74,8 @@ class _DBLossFunction(torch.autograd.Function):
 class DBLoss(nn.Module):
     def __init__(self, alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3, eps=1e-6):
         super().__init__()
-        if reduction not in ('mean', 'none'):
-            raise NotImplementedError("reduction must be 'mean' (the reference's configured default, example_config.yaml:73) "
-                                      "or 'none' (true per-pixel OHEM)")
+        if reduction not in ('mean', 'sum', 'none'):  # the strings F.binary_cross_entropy accepts (losses.py:30)
+            raise ValueError('%s is not a valid value for reduction' % reduction)
         self.alpha = float(alpha)
         self.beta = float(beta)
         self.reduction = reduction
@@ -89,4 +90,5 @@ class DBLoss(nn.Module):
         assert preds.size(1) in (2, 3) and gts.size(0) == 4 and gts.shape[1:] == (preds.size(0), preds.size(2), preds.size(3))
         preds = preds.contiguous().float()
         gts = gts.contiguous().float()
-        return _DBLossFunction.apply(preds, gts, self.alpha, self.beta, self.negative_ratio, self.eps, self.reduction == 'none')
+        mode = {'mean': 0, 'none': 1, 'sum': 2}[self.reduction]
+        return _DBLossFunction.apply(preds, gts, self.alpha, self.beta, self.negative_ratio, self.eps, mode)

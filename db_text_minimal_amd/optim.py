@@ -26,7 +26,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = None
 
     def zero_grad(self, set_to_none=True):
-        # every step overwrites the flat gradient buffer completely; nothing to clear
+        """Every backward pass OVERWRITES the engine's flat gradient buffer completely, so there is nothing to clear there —
+        and no accumulation either: `step()` consumes the gradients of the LAST backward only (gradient accumulation over
+        several backward passes and in-place edits of `p.grad` such as clip_grad_norm_ are not supported by the fused path;
+        use torch.optim.Adam over `model.parameters()` for those).  On the autograd surface the parameters' `.grad` views are
+        dropped here so they do not keep accumulating across iterations."""
+        for _, p in self.engine.live_params:
+            p.grad = None
         return None
 
     def _ensure_state(self):
@@ -52,12 +58,17 @@ class FusedAdam(torch.optim.Optimizer):
         eng.mark_params_dirty()
 
     def state_dict(self):
+        if self.engine.flat is not None or any(p.is_cuda for _, p in self.engine.live_params):
+            self._ensure_state()  # moments exist (zeros) before the first step, so a fresh optimizer round-trips
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
                 'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
 
     def load_state_dict(self, sd):
         self._ensure_state()
         self.step_count = int(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for name in ('exp_avg', 'exp_avg_sq'):
+            if sd.get(name) is None:  # saved before any state existed
+                getattr(self, name).zero_()
+            else:
+                getattr(self, name).copy_(sd[name])
         self.param_groups[0].update(sd['param_groups'][0])

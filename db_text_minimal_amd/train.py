@@ -93,6 +93,22 @@ class DBTrainer:
         self._gone = None
         # bucketed exchange under the backward pass; False (or DBN_OVERLAP_ALLREDUCE=0): one all-reduce after it
         self.overlap_allreduce = os.environ.get('DBN_OVERLAP_ALLREDUCE', '1') != '0'
+        if self.world > 1:
+            self.sync_from_rank0()
+
+    def sync_from_rank0(self):
+        """Data-parallel replicas must start from identical state: rank 0's flat parameter buffer and its BatchNorm buffers are
+        broadcast once (what DistributedDataParallel does at construction).  During training the parameters stay identical by
+        construction (same averaged gradient, same Adam state); BatchNorm running statistics are NOT synchronised afterwards
+        — each rank tracks its own shard, and checkpoints carry rank 0's."""
+        eng = self.model.engine
+        eng.ensure_flat()
+        eng.flush_counters()
+        src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+        dist.broadcast(eng.flat, src=src, group=self.pg)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src, group=self.pg)
+        eng.mark_params_dirty()
 
     def _loss(self, preds, gts):
         """dbn_db_loss_fwd + _bwd with d(total)=1; returns (losses[5], dpreds)."""
@@ -101,7 +117,8 @@ class DBTrainer:
         N, C, H, W = preds.shape
         dev = preds.device
         st = torch.cuda.current_stream(dev).cuda_stream
-        per_pixel = getattr(c, 'reduction', 'mean') == 'none'
+        reduction = getattr(c, 'reduction', 'mean')
+        per_pixel = reduction == 'none'
         if self._gone is None or self._gone.device != dev:
             self._gone = torch.tensor([0., 0., 0., 0., 1.], device=dev)
             self._coef = torch.zeros(8, device=dev)
@@ -110,7 +127,7 @@ class DBTrainer:
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, device=dev)
         losses = torch.empty(5, device=dev)
-        fwd = L.dbn_db_loss_ohem_fwd if per_pixel else L.dbn_db_loss_fwd
+        fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
         check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
                   self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
         dpreds = self.model.engine.buf('dpreds', N, C, H, W)
@@ -207,6 +224,17 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
     post-processing and is left to the caller.  Returns a list of per-epoch dicts."""
     from .text_metrics import RunningScore
     trainer = DBTrainer(model, criterion, optimizer, process_group=process_group)
+    distributed = dist.is_available() and dist.is_initialized()
+    is_writer = (not distributed) or dist.get_rank(process_group) == 0
+
+    def save(path):
+        """Checkpoints are written by rank 0 only (every rank writing the same path would race); the others wait, so the
+        file is complete when any rank returns.  The BatchNorm buffers in it are rank 0's."""
+        if is_writer:
+            torch.save(model.state_dict(), path)
+        if distributed:
+            dist.barrier(group=process_group)
+
     best_test, best_train = float('inf'), float('inf')
     history = []
     steps = 0
@@ -233,7 +261,7 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
             if test_loss <= best_test and train_loss <= best_train:
                 best_test, best_train = test_loss, train_loss
                 if best_cp_path:
-                    torch.save(model.state_dict(), best_cp_path)
+                    save(best_cp_path)
                 rec['saved_best'] = True
             if lrs_mode == 'reduce' and scheduler is not None:
                 scheduler.step(test_loss)
@@ -241,5 +269,5 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
             log(rec)
         history.append(rec)
     if last_cp_path:
-        torch.save(model.state_dict(), last_cp_path)
+        save(last_cp_path)
     return history

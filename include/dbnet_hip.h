@@ -103,6 +103,12 @@ int dbn_igemm_tile_config(int M, int Cd);
  * sm = [N,Ho,Wo,O] (output-side tensor), big = [N,H,W,Cb] (input-side, Cb >= I).
  * slab: dbn_wgrad_slab_floats(...) floats of scratch (split-K partial sums, reduced deterministically). */
 int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S);
+/* the same when the size of X (H x W) is known; a call whose tensors exceed the kernels' index ranges (2^24 pixel rows,
+ * 32-bit byte offsets) runs as several launches over image ranges, each with its own slabs */
+int dbn_wgrad_splitk_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int R, int S);
+/* Test hook: lower the per-launch index ranges (pixel rows, bytes per tensor, output elements; 0 = default) so that the image
+ * chunking of the conv / weight-gradient entry points can be exercised at small sizes.  Not thread-safe. */
+int dbn_set_index_limits(long pixel_rows, long bytes, long elems);
 long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S);
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                   int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
@@ -182,6 +188,10 @@ int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, i
                     float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
 int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, const float* grad_losses, float alpha, float beta,
                     int N, int H, int W, int channels, float* dpreds, void* stream);
+/* DBLoss(reduction='sum'): losses.py:30 forwards the reduction string to F.binary_cross_entropy, so the scalar BCE of the
+ * OHEM term is summed instead of averaged; everything else as dbn_db_loss_fwd (same ws; backward: dbn_db_loss_bwd). */
+int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                        float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
 
 /* DBLoss(reduction='none') — true per-pixel OHEM (losses.py:30-39 with a per-pixel BCE): the n_neg largest
  * negative losses are found by a 3-pass radix select on device (no sort, no host sync).  `ws` holds

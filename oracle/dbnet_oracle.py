@@ -421,9 +421,9 @@ def db_loss(preds, gts, alpha=1.0, beta=10.0, reduction='mean', negative_ratio=3
     return pt
 
 
-def db_loss_closed_form(preds, gts, alpha=1.0, beta=10.0, negative_ratio=3, eps=1e-6):
-    """What the HIP loss kernel evaluates for reduction='mean' with binary
-    gt/mask: bce_mean * (sum_pos + n_neg) / (n_pos+n_neg+eps).
+def db_loss_closed_form(preds, gts, alpha=1.0, beta=10.0, negative_ratio=3, eps=1e-6, reduction='mean'):
+    """What the HIP loss kernel evaluates for reduction='mean' / 'sum' with binary
+    gt/mask: bce_scalar * (sum_pos + n_neg) / (n_pos+n_neg+eps).
     Float64 sums; used to cross-check the literal restatement above."""
     P, T = preds[:, 0].double(), preds[:, 1].double()
     G, M, Tg, A = (g.double() for g in gts)
@@ -431,7 +431,8 @@ def db_loss_closed_form(preds, gts, alpha=1.0, beta=10.0, negative_ratio=3, eps=
     s_neg = ((1 - G) * M).sum()
     n_pos = int(s_pos)
     n_neg = min(int(n_pos * negative_ratio), int(s_neg))
-    bce = -(G * torch.clamp(torch.log(P), min=-100) + (1 - G) * torch.clamp(torch.log1p(-P), min=-100)).mean()
+    bce = -(G * torch.clamp(torch.log(P), min=-100) + (1 - G) * torch.clamp(torch.log1p(-P), min=-100))
+    bce = bce.sum() if reduction == 'sum' else bce.mean()
     prob = bce * (s_pos + n_neg) / (n_pos + n_neg + eps)
     thr = ((T - Tg).abs() * A).sum() / (A.sum() + eps)
     out = [prob, thr]
@@ -490,6 +491,12 @@ def loss_and_grads(sd, img, gts, update_stats=True, world_scale=1.0, **loss_kw):
     grads = torch.autograd.grad(total, [leaves[k] for k in keys], allow_unused=True)
     grads = {k: (g * world_scale if g is not None else None) for k, g in zip(keys, grads)}
     return preds.detach(), [float(v.detach()) for v in losses], grads
+
+
+def to_dtype(sd, dtype):
+    """Copy of a state dict with the floating tensors in `dtype` (fp64 evaluation of the same weights: the reference in
+    `.double()`, tests/golden/fp64_2x128.npz)."""
+    return OrderedDict((k, v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items())
 
 
 def train_step(sd, opt, img, gts, **loss_kw):

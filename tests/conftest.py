@@ -1,5 +1,8 @@
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -7,9 +10,46 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_RCCL_CHILD = {}
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def pytest_sessionstart(session):
+    """The RCCL test (tests/test_rccl_gpu.py) needs a FRESH process that initialises the GPU itself under
+    torch.distributed.run.  A process that has already initialised the GPU must not exec another program on this pool, so
+    the child is started here — before any test of this session has touched the GPU — and the test only collects its verdict."""
+    markexpr = getattr(session.config.option, 'markexpr', '') or ''
+    if 'gpu' not in markexpr or 'not gpu' in markexpr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:  # counting devices does not initialise the GPU
+            return
+    except Exception:
+        return
+    out = os.path.join(tempfile.mkdtemp(prefix='dbn_rccl_'), 'verdict.json')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('DBN_FORCE_DIST', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_child.py'), out]
+    log = open(out + '.log', 'w')
+    _RCCL_CHILD.update(proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT), out=out, log=out + '.log')
+
+
+@pytest.fixture(scope='session')
+def rccl_child():
+    return _RCCL_CHILD
 
 
 @pytest.fixture(scope='session')

@@ -43,13 +43,13 @@ def sample_idx(numel, k=SAMPLE):
     return (np.arange(k, dtype=np.int64) * (numel // k)) + (numel // (2 * k))
 
 
-def summarize(prefix, t, out, full_below=8192):
+def summarize(prefix, t, out, full_below=8192, k=SAMPLE):
     a = t.detach().double().reshape(-1).numpy()
     out[prefix + '/stats'] = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum()), a.min(), a.max()])
     if a.size <= full_below:
         out[prefix + '/full'] = t.detach().float().numpy()
     else:
-        out[prefix + '/sample'] = a[sample_idx(a.size)].astype(np.float32)
+        out[prefix + '/sample'] = a[sample_idx(a.size, k)].astype(np.float32)
 
 
 def make_ref(seed, arch='resnet18'):
@@ -72,7 +72,7 @@ def make_ref(seed, arch='resnet18'):
     return m
 
 
-def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch='resnet18'):
+def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch='resnet18', map_sample=SAMPLE):
     print('==', name)
     torch.manual_seed(0)
     m = make_ref(seed, arch).train()
@@ -92,7 +92,7 @@ def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch
                 out['preds'] = preds.detach().numpy()
             else:
                 for c, nm in enumerate('PTB'):
-                    summarize('preds_' + nm, preds[:, c], out, full_below=0)
+                    summarize('preds_' + nm, preds[:, c], out, full_below=0, k=map_sample)
             for k, p in m.named_parameters():
                 if p.grad is not None:
                     summarize('grad/' + k, p.grad, out)
@@ -111,6 +111,32 @@ def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch
             summarize('post/' + k, v, out, full_below=0)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     return m
+
+
+def case_fp64(name, n, size, seed):
+    """The reference evaluated in DOUBLE (model.double()) next to its own fp32 run, same weights and inputs: per parameter
+    the fp64 gradient (norm + strided sample) and the distance of the reference's fp32 gradient from it.  The GPU test
+    requires the HIP gradient to be no further from the fp64 gradient than 1.5x that distance (tests/test_model_gpu.py)."""
+    print('==', name)
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    grads = {}
+    out = {'meta': np.array([n, size, seed, 1])}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        m = make_ref(seed).to(dt).train()
+        preds = m(img.to(dt))
+        losses = DBLoss()(preds, gts.to(dt))
+        losses[4].backward()
+        grads[tag] = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+        out['losses_' + tag] = np.array([float(v) for v in losses])
+        out['preds_' + tag + '/sample'] = preds.detach().double().reshape(-1).numpy()[sample_idx(preds.numel(), 4096)]
+    for k, g64 in grads['f64'].items():
+        a = g64.reshape(-1).numpy()
+        out['g64/' + k + '/norm'] = np.array(np.sqrt((a * a).sum()))
+        out['g64/' + k + '/sample'] = a[sample_idx(a.size)]
+        out['ref32_dist/' + k] = np.array(float((grads['f32'][k] - g64).norm()))
+    worst = max(float(out['ref32_dist/' + k] / (out['g64/' + k + '/norm'] + 1e-300)) for k in grads['f64'])
+    print('  worst |g_ref32 - g64| / |g64| = %.3e' % worst)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
 def case_eval(name, n, size, seed):
@@ -168,6 +194,8 @@ def case_loss_kats():
     run('alpha_beta', preds3, gts, DBLoss(alpha=5.0, beta=2.0, negative_ratio=1))
     # contrast: reduction='none' (true per-pixel OHEM) — recorded so a future top-k kernel can be pinned
     run('reduction_none', preds3, gts, DBLoss(reduction='none'))
+    # losses.py:30 hands any torch reduction string to F.binary_cross_entropy: 'sum' = the scalar BCE summed, not averaged
+    run('reduction_sum', preds3, gts, DBLoss(reduction='sum'))
     np.savez_compressed(os.path.join(HERE, 'loss_kats.npz'), **out)
 
 
@@ -248,6 +276,15 @@ def check_oracle(arch='resnet18'):
 
 
 if __name__ == '__main__':
+    if '--only-cfg2' in sys.argv:  # BASELINE configs[1]: the benchmarked workload itself, one train step of the reference
+        case_train('cfg2_16x640', 16, 640, seed=16, full_maps=False, steps=1, map_sample=4096)
+        sys.exit(0)
+    if '--only-kats' in sys.argv:
+        case_loss_kats()
+        sys.exit(0)
+    if '--only-fp64' in sys.argv:
+        case_fp64('fp64_2x128', 2, 128, seed=2)
+        sys.exit(0)
     if '--only-r50' in sys.argv:
         check_oracle('resnet50')
         case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')
@@ -266,6 +303,8 @@ if __name__ == '__main__':
     check_oracle('resnet50')
     case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')
     case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
+    case_fp64('fp64_2x128', 2, 128, seed=2)
     if '--no-640' not in sys.argv:
         case_train('cfg1_2x640', 2, 640, seed=0, full_maps=False, steps=3)
+        case_train('cfg2_16x640', 16, 640, seed=16, full_maps=False, steps=1, map_sample=4096)
     print('done')

@@ -101,8 +101,9 @@ def test_no_cpu_fallback_and_error_surface():
         crit(torch.rand(1, 3, 8, 8), torch.rand(4, 1, 8, 8))
     with pytest.raises(AssertionError):
         crit(torch.rand(3, 8, 8), torch.rand(4, 1, 8, 8))  # losses.py:113-114
-    with pytest.raises(NotImplementedError):
-        DBLoss(reduction='sum')
+    with pytest.raises(ValueError):
+        DBLoss(reduction='bogus')  # F.binary_cross_entropy's error for an unknown reduction string (losses.py:30)
+    assert DBLoss(reduction='sum').reduction == 'sum'
     with pytest.raises(NotImplementedError):
         FusedAdam(m, weight_decay=0.1)
 

@@ -12,7 +12,7 @@ from oracle import dbnet_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_none']
+KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_none', 'reduction_sum']
 
 
 @pytest.mark.parametrize('tag', KATS)
@@ -20,7 +20,7 @@ def test_loss_known_answers(golden_dir, tag):
     z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
     preds = torch.from_numpy(z[tag + '/preds']).to(DEV).requires_grad_(True)
     gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
-    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss(reduction='none') if tag == 'reduction_none' else DBLoss()
+    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss(reduction=tag[len('reduction_'):]) if tag.startswith('reduction_') else DBLoss()
     res = crit(preds, gts)
     res5 = res if isinstance(res, tuple) else (res, )
     got = torch.stack([r.detach() for r in res5]).cpu()

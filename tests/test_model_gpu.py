@@ -67,7 +67,7 @@ def check_summary(z, prefix, t, atol_scale=2e-4, rtol=2e-3):
         report(prefix, a, ref, atol_scale * scale, rtol)
     else:
         ref = torch.from_numpy(z[prefix + '/sample']).double()
-        report(prefix + ' (sample)', a[torch.from_numpy(sample_idx(n))], ref, atol_scale * scale, rtol)
+        report(prefix + ' (sample)', a[torch.from_numpy(sample_idx(n, ref.numel()))], ref, atol_scale * scale, rtol)
     l2 = float(a.pow(2).sum().sqrt())
     assert abs(l2 - st[2]) <= 1e-3 * st[2] + atol_scale * scale, (prefix, 'L2', l2, st[2])
 
@@ -182,6 +182,126 @@ def test_cfg1_2x640_vs_reference_golden(golden_dir):
                 check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
         tol = (1e-5, 2e-3, 2e-2)[it]
         report('cfg1 losses step %d' % it, losses.cpu().double(), torch.from_numpy(z['losses'][it]), tol, tol)
+
+
+def test_cfg2_16x640_vs_reference_golden(golden_dir):
+    """BASELINE configs[1] — the benchmarked workload itself (16x3x640x640, one train step, train.py:160-172) against the
+    REFERENCE's own numbers (tests/golden/make_golden.py --only-cfg2): 4096-point samples + L2 norms of the three maps at
+    the north_star tolerance, the five losses, six representative gradients, the running statistics after the step.
+    Train-mode BatchNorm merges 3200 tile partials per channel here (400 in the 2x640 golden)."""
+    z = np.load(os.path.join(golden_dir, 'cfg2_16x640.npz'))
+    n, size, seed, steps = (int(v) for v in z['meta'])
+    assert (n, size, steps) == (16, 640, 1)
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    model = make_model(seed).train()
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+    for c, nm in enumerate('PTB'):
+        check_summary(z, 'preds_' + nm, preds[:, c], MAP_ATOL, MAP_RTOL)
+    for c, nm in enumerate('PT'):  # and tight: the maps agree far inside the north_star bound
+        check_summary(z, 'preds_' + nm, preds[:, c], 1e-4, 1e-3)
+    for k in ('backbone.conv1.weight', 'backbone.layer2.0.conv1.weight', 'segmentation_body.conv.0.weight',
+              'segmentation_head.binarize.0.weight', 'segmentation_head.thresh.3.weight', 'segmentation_head.binarize.6.weight'):
+        check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
+    report('cfg2 losses', losses.cpu().double(), torch.from_numpy(z['losses'][0]), 1e-5, 1e-5)
+    sd = model.state_dict()
+    for f in z.files:
+        if f.startswith('post/') and f.endswith('/stats') and 'running' in f:
+            k = f[len('post/'):-len('/stats')]
+            check_summary(z, 'post/' + k, sd[k], 1e-4, 1e-3)
+
+
+# conv biases ahead of a train-mode BatchNorm: analytically zero gradient (fp64: ~1e-17), the fp32 value is round-off noise
+_DEAD_BIAS = ('conv.bias', '.0.bias', '.3.bias')
+
+
+def test_gradients_are_as_close_to_fp64_as_the_reference_is(golden_dir):
+    """DESIGN §4's claim as an assertion.  Two fp32 implementations disagree on the gradients by ~1 % in L2 because each
+    flips the ReLU mask of different near-zero activations; neither is "right".  Ground truth: the same weights and inputs
+    evaluated in DOUBLE (oracle in fp64, pinned to the reference's own .double() run by tests/golden/fp64_2x128.npz and
+    tests/test_oracle_golden.py).  Per parameter tensor the HIP gradient must be no further from the fp64 gradient than
+    1.5x the distance of the REFERENCE's fp32 gradient from it (plus 2e-5 of the gradient norm for the tensors where the
+    reference's own distance is at round-off level)."""
+    z = np.load(os.path.join(golden_dir, 'fp64_2x128.npz'))
+    n, size, seed, _ = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, size, seed=seed + 100)
+    sd = O.new_state(seed)
+    _, l64, g64 = O.loss_and_grads(O.to_dtype(sd, torch.float64), img.double(), gts.double())
+    assert np.allclose(l64, z['losses_f64'], rtol=1e-12)
+    model = make_model(seed).train()
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+    report('losses vs fp64', losses.cpu().double(), torch.tensor(l64).double(), 2e-6, 2e-6)
+    worst, worst_k, tot_h, tot_r = 0.0, None, 0.0, 0.0
+    for k, g in g64.items():
+        if g is None or k.endswith(_DEAD_BIAS):
+            continue
+        nrm = float(z['g64/' + k + '/norm'])
+        d_ref = float(z['ref32_dist/' + k])
+        d_hip = float((model.engine.grad_views[k].double().cpu() - g).norm())
+        tot_h += d_hip**2
+        tot_r += d_ref**2
+        ratio = d_hip / (d_ref + 2e-5 * nrm)
+        if ratio > worst:
+            worst, worst_k = ratio, k
+        assert d_hip <= 1.5 * d_ref + 2e-5 * nrm, (k, d_hip, d_ref, nrm)
+    print('fp64 check: worst d_hip/d_ref %.3f (%s); whole-model |g_hip-g64| %.4e vs reference %.4e' %
+          (worst, worst_k, tot_h**0.5, tot_r**0.5))
+    assert tot_h**0.5 <= 1.2 * tot_r**0.5
+
+
+def test_cfg4_r50dcn_800_bs8_f32_and_bf16():
+    """BASELINE configs[3] in its own terms: deformable ResNet-50 backbone (resnet.py:94-159, DCN :54-65,111-124) at
+    8x3x800x800.  Eval mode (images independent: running-stat BatchNorm): images 0 and 7 of the batch per pixel against the
+    CPU oracle; then the 'bf16' conv-math mode on the deformable backbone at the same size (mean error; stated bound);
+    then one train step at full size in both modes (size-independent properties; the Bottleneck/DCN train arithmetic
+    itself is compared per element at 2x128 above).  DCN sampling: restated DCNv1, parity unpinned against torchvision."""
+    seed, arch = 23, 'deformable_resnet50'
+    img, gts = O.synthetic_batch(8, 800, seed=seed + 1)
+    sd = O.new_state(seed, arch)
+    O.BN_MOMENTUM = 1.0  # running statistics that match the weights (see test_bottleneck_and_deformable_backbones_vs_oracle)
+    try:
+        with torch.no_grad():
+            O.forward(sd, img[[0, 7]], training=True, update_stats=True)
+    finally:
+        O.BN_MOMENTUM = 0.1
+    with torch.no_grad():
+        ref = O.forward(sd, img[[0, 7]], training=False)
+    model = make_model(seed, arch)
+    model.load_state_dict(sd)
+    model.eval()
+    imgd, gtsd = img.to(DEV), gts.to(DEV)
+    with torch.no_grad():
+        pe = model(imgd)
+    assert pe.shape == (8, 2, 800, 800)
+    report('cfg4 f32 eval image 0', pe[0].cpu(), ref[0], MAP_ATOL, MAP_RTOL)
+    report('cfg4 f32 eval image 7', pe[7].cpu(), ref[1], MAP_ATOL, MAP_RTOL)
+    model.engine.set_conv_math('bf16')
+    with torch.no_grad():
+        pb = model(imgd)
+    err = (pb[[0, 7]].cpu() - ref).abs()
+    print('cfg4 bf16 conv math, eval: mean abs err %.3e, max %.3e' % (float(err.mean()), float(err.max())))
+    assert torch.isfinite(pb).all() and float(err.mean()) < 2e-2
+    tot = {}
+    for math in ('f32', 'bf16'):
+        m2 = make_model(seed, arch)
+        m2.load_state_dict(sd)
+        m2.train()
+        m2.engine.set_conv_math(math)
+        tr = DBTrainer(m2, DBLoss(), FusedAdam(m2, lr=0.005))
+        preds, losses = tr.step(imgd, gtsd)
+        assert preds.shape == (8, 3, 800, 800) and torch.isfinite(preds).all() and torch.isfinite(losses).all()
+        assert float(preds.min()) >= 0 and float(preds.max()) <= 1
+        assert torch.allclose(preds[:, 2], torch.sigmoid(50 * (preds[:, 0] - preds[:, 1])), atol=1e-5)
+        g = m2.engine.flat_grad
+        assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+        assert float(m2.engine.grad_views['backbone.layer2.0.conv2_offset.weight'].abs().max()) > 0
+        tot[math] = losses.cpu().tolist()
+        del m2, tr
+        torch.cuda.empty_cache()
+    print('cfg4 train losses f32 %s\n                  bf16 %s' % (tot['f32'], tot['bf16']))
+    for a, b in zip(tot['f32'], tot['bf16']):  # the stated bf16 bound on the losses (as test_split_bf16_conv_math_modes)
+        assert abs(a - b) <= 3e-2 * max(abs(a), 1e-3)
 
 
 def test_full_size_bs16_properties():

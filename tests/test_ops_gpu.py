@@ -706,3 +706,76 @@ def test_batched_weight_pack_equals_single_packs(ns):
     torch.cuda.synchronize()
     for a, b in zip(outs, singles):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_image_chunking_beyond_the_index_ranges():
+    """The conv / weight-gradient kernels index pixels in 24 bits and address tensors with 32-bit offsets; a call beyond
+    those ranges (e.g. BASELINE configs[4] at batch sizes above 40: 48 x 1280^2 / 4 px = 19.7 M rows) runs as several
+    launches over image ranges.  With the limits lowered (dbn_set_index_limits) the chunked path must reproduce the
+    single-launch results BIT FOR BIT: conv + fused BN statistics, strided transposed conv, pyramid conv, weight gradient."""
+    N, Ci, Co, H, W = 5, 64, 128, 24, 20
+    x = nhwc(rnd(N, Ci, H, W, seed=1))
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
+    wT = rnd(Ci, Co, 4, 4, seed=3, scale=0.05)
+    bias = rnd(Co, seed=4).to(DEV)
+    dy = nhwc(rnd(N, Co, H, W, seed=5))
+
+    def run_all():
+        out = {}
+        y = torch.full((N, H, W, Co), float('nan'), device=DEV)
+        g_, b_ = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+        rm_, rv_ = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+        ws = torch.empty(L().dbn_conv_bn_ws_floats(N, H, W, Co, 0, 1), device=DEV)
+        _lib.check(L().dbn_conv_bn_f32(x.data_ptr(), pack(w, 0).data_ptr(), bias.data_ptr(), y.data_ptr(), N, H, W, Ci, H, W, Co, 3, 3, 1, 1,
+                                       0, 0, 0, 0, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(), sc.data_ptr(),
+                                       sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
+        out['conv'], out['scale'], out['shift'], out['run_var'] = y, sc, sh, rv_
+        yT = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
+        igemm(x, pack(wT, 1, 2), bias, yT, 4, 2, 1, 1)
+        out['convT'] = yT
+        d = torch.full((N, H, W, Ci), float('nan'), device=DEV)
+        igemm(dy, pack(w, 1, 1), None, d, 3, 1, 1, 1)
+        out['dgrad'] = d
+        out['wgrad'] = wgrad(dy, x, Co, Ci, 3, 1, 1)
+        # pyramid conv over four levels (H, W multiples of 8)
+        Cg = 64
+        zs = [nhwc(rnd(N, Cg, H >> g, W >> g, seed=20 + g)) for g in range(4)]
+        wf = rnd(256, 4 * Cg, 3, 3, seed=6, scale=0.03).to(DEV)
+        wpk = []
+        for g in range(4):
+            k = (1 << g) + 2
+            wdg = torch.empty(Cg, 256, k, k, device=DEV)
+            _lib.check(L().dbn_fpn_combine_weights(wf.data_ptr(), 256, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+            wpk.append(pack(wdg.cpu(), 1, 1 << g))
+        yp = torch.full((N, H, W, 256), float('nan'), device=DEV)
+        sc2, sh2, mu2, rs2 = (torch.empty(256, device=DEV) for _ in range(4))
+        g2, b2 = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+        ws2 = torch.empty(L().dbn_pyramid_conv_ws_floats(N, H, W, 256), device=DEV)
+        _lib.check(L().dbn_pyramid_conv_f32(*[z.data_ptr() for z in zs], *[p.data_ptr() for p in wpk], None, yp.data_ptr(), N, H, W, Cg, 256,
+                                            0, 0, g2.data_ptr(), b2.data_ptr(), 1e-5, 0.1, None, None, sc2.data_ptr(), sh2.data_ptr(),
+                                            mu2.data_ptr(), rs2.data_ptr(), ws2.data_ptr(), stream()), 'pyramid')
+        out['pyramid'], out['pyramid_scale'] = yp, sc2
+        torch.cuda.synchronize()
+        return out
+
+    ref = run_all()
+    assert L().dbn_wgrad_splitk_hw(N, H, W, Co, H, W, Ci, 3, 3) == L().dbn_wgrad_splitk(N, H, W, Co, Ci, 3, 3)
+    try:
+        L().dbn_set_index_limits(2 * H * W + 7, 0, 0)  # at most two images per launch
+        assert L().dbn_wgrad_splitk_hw(N, H, W, Co, H, W, Ci, 3, 3) >= 3
+        got = run_all()
+        L().dbn_set_index_limits(0, H * W * Ci * 4 + 64, 0)  # one image per launch through the byte range
+        got1 = run_all()
+    finally:
+        L().dbn_set_index_limits(0, 0, 0)
+    for k, v in ref.items():
+        if k == 'wgrad':  # the pixel splits (and their fp64 fold order) differ with the chunking: same sum, other rounding
+            report('chunked wgrad', got[k].cpu(), v.cpu(), 1e-5 * float(v.abs().max()), 1e-5)
+            report('chunked wgrad (1/launch)', got1[k].cpu(), v.cpu(), 1e-5 * float(v.abs().max()), 1e-5)
+        elif k in ('scale', 'shift', 'run_var', 'pyramid_scale'):  # tile partials are merged in fp64: identical up to the last bit
+            report('chunked ' + k, got[k].cpu(), v.cpu(), 1e-7, 1e-6)
+            report('chunked ' + k + ' (1/launch)', got1[k].cpu(), v.cpu(), 1e-7, 1e-6)
+        else:
+            assert torch.equal(got[k], v), k
+            assert torch.equal(got1[k], v), k
