@@ -47,6 +47,7 @@ SIGNATURES = {
     'dbn_bn_apply': 'pppppppliip',
     'dbn_bn_backward': 'pppppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
     'dbn_bn_backward_from_sums': 'ppppppppp' + 'pp' + 'i' + 'pp' + 'ii' + 'f' + 'pp',
+    'dbn_bn_backward_ex': 'ppppppppp' + 'pp' + 'i' + 'ppp' + 'ii' + 'f' + 'pp',
     'dbn_col_sum': 'piipfpp',
     'dbn_bnrelu_maxpool_fwd': 'ppppiiiip',
     'dbn_bnrelu_maxpool_bwd': 'ppppppiiiip',

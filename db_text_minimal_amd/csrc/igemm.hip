@@ -952,6 +952,46 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
     }
 }
 
+// The same reduction for layers whose input-channel count is a multiple of 64 (every layer but the stem): one workgroup
+// per (output channel o, block of 64 input channels), so that BOTH sides are coalesced — the slab is read in 64-byte runs
+// (a b128 per lane: four positions = channels 4u+e of one tap) and the OIHW gradient leaves as one contiguous run of
+// 64*R*S floats staged through LDS (the per-element kernel above scatters 4-byte stores at a stride of R*S floats).
+// Same fixed summation order over the splits (fp64), bit-identical results.
+__global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
+                                                             int BN, int Cb, int I, int RS, float* __restrict__ grad, float scale) {
+    extern __shared__ float stage[];  // [64][RS]
+    const int o = blockIdx.x, i0 = blockIdx.y * 64;
+    const int om = o % BM;
+    const int prow = (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
+    const long total4 = ((long)O * Jp) >> 2;
+    for (int t = threadIdx.x; t < RS * 16; t += blockDim.x) {
+        const int tap = t >> 4, e = (t >> 2) & 3, cq = t & 3;
+        const int j0 = tap * Cb + i0;                 // multiple of 64: the 64 channels lie inside one BN-wide tile
+        const int jt = j0 / BN, jl0 = j0 - jt * BN;
+        const int pos = e * (BN / 4) + (jl0 >> 2) + 4 * cq;  // positions pos..pos+3 hold channels i0 + 16cq + 4u + e
+        const f32x4* src = reinterpret_cast<const f32x4*>(slab + (long)prow * Jp + jt * BN + pos);
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        int z = 0;
+        for (; z + 4 <= splitk; z += 4) {
+            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + 1) * total4];
+            const f32x4 v2 = src[(long)(z + 2) * total4], v3 = src[(long)(z + 3) * total4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += ((double)v0[u] + (double)v1[u]) + ((double)v2[u] + (double)v3[u]);
+        }
+        for (; z < splitk; ++z) {
+            const f32x4 v = src[(long)z * total4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += (double)v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+    }
+    __syncthreads();
+    const int n = min(64, I - i0) * RS;  // channels >= I are padding of the activation tensor
+    float* dst = grad + ((long)o * I + i0) * RS;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = stage[k];
+}
+
 // Merge the per-tile BatchNorm partials written by the igemm epilogue (Chan et al. parallel variance, fp64)
 // into scale/shift, saved mean/rstd and the running statistics.  One 256-thread block per channel.
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
@@ -1680,8 +1720,12 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
         if (rc) return rc;
         splits_total += splitk;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn, Cb,
-                       I, R, S, grad_oihw, scale);
+    if (Cb % 64 == 0 && R * S * 64 * 4 <= 64 * 1024)
+        hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(R * S >= 9 ? 256 : 64), (size_t)R * S * 64 * sizeof(float), st,
+                           slab, splits_total, O, J, Jp, bm, bn, Cb, I, R * S, grad_oihw, scale);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
+                           Cb, I, R, S, grad_oihw, scale);
     return dbn_status();
 }
 

@@ -11,6 +11,11 @@
 namespace {
 
 constexpr int MAX_PART = 1024;  // max partial blocks for per-channel reductions
+// The streaming kernels of this file run beside the matrix kernels of the step's other stream.  A small fixed footprint —
+// 3 workgroups of 256 threads per CU, 12 of its 32 wave slots — leaves the MFMA kernels their residency, and UNROLL
+// independent 16-byte loads per lane keep HBM busy without relying on occupancy (8 TB/s x ~1 us needs ~32 KB in flight per CU).
+constexpr int STREAM_BLOCKS = 768;
+constexpr int UNROLL = 4;
 
 // ----------------------------------------------------------------------------------
 // per-channel reductions over [M][C] (C % 4 == 0): each block reduces a contiguous row range of one chunk of
@@ -30,8 +35,10 @@ __device__ __forceinline__ void channel_reduce(int M, int Cfull, float* __restri
     f32x4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (rl < nrl)
-        for (int r = r0 + rl; r < r1; r += nrl) body(r, cq + c4, acc);
+    if (rl < nrl) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += nrl) body(r, cq + c4, acc);  // no stores in the loop: the unrolled loads issue together
+    }
     extern __shared__ float red[];  // [nrl][NV][C]
     if (rl < nrl) {
 #pragma unroll
@@ -101,13 +108,15 @@ __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, cons
 }
 
 // out = act(y*sc+sh [+ res*rsc+rsh | + res])
-__global__ void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
-                                const float* __restrict__ res, const float* __restrict__ rsc, const float* __restrict__ rsh,
-                                float* __restrict__ out, long total4, int C, int relu) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ sc,
+                                                       const float* __restrict__ sh, const float* __restrict__ res,
+                                                       const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                                       float* __restrict__ out, long total4, int C, int relu) {
     const int c4n = C >> 2;
     // the grid stride is a multiple of C/4 (host side), so a thread keeps its channel quad: per-channel coefficients are
     // loaded once, and no 64-bit modulo sits in the streaming loop
     const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
     const int c = (int)(i0 % c4n) * 4;
     const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
     const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
@@ -116,13 +125,14 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
         s2 = *reinterpret_cast<const f32x4*>(rsc + c);
         h2 = *reinterpret_cast<const f32x4*>(rsh + c);
     }
-    for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    auto one = [&](f32x4 v, f32x4 r) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = dbn_affine(v[e], s[e], h[e]);
         if (res) {
-            const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
             if (rsc) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += dbn_affine(r[e], s2[e], h2[e]);
@@ -134,8 +144,19 @@ __global__ void bn_apply_kernel(const float* __restrict__ y, const float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
         }
-        reinterpret_cast<f32x4*>(out)[i] = o;
+        return o;
+    };
+    long i = i0;
+    for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // UNROLL (x2 with a residual) loads in flight per lane
+        f32x4 v[UNROLL], r[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = y4[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) r[u] = res ? r4[i + u * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) o4[i + u * stride] = one(v[u], r[u]);
     }
+    for (; i < total4; i += stride) o4[i] = one(y4[i], res ? r4[i] : f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 // backward reductions: g = dout * (zmask > 0);  sums of g and g*xhat
@@ -182,14 +203,20 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, i
     c2[c] = (float)(s2 / M);
 }
 
-// dy = gamma*rstd*(g - c1 - xhat*c2); optionally also emits g (the ReLU-masked dout)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ msc,
-                                    const float* __restrict__ msh, const float* __restrict__ dout,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ c1, const float* __restrict__ c2,
-                                    float* __restrict__ dy, float* __restrict__ gout, int gout_acc, long total4, int C) {
+// dy = gamma*rstd*(g - c1 - xhat*c2); optionally also emits g (the ReLU-masked dout).
+// bias_part (optional, needs 256 % (C/4) == 0): per-block column sums of dy, [C][gridDim.x] — the gradient of the bias of the
+// conv that feeds this BatchNorm (analytically zero; the reference's value is the round-off of exactly this sum), so that no
+// separate pass re-reads dy for it.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask,
+                                                           const float* __restrict__ msc, const float* __restrict__ msh,
+                                                           const float* __restrict__ dout, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           float* __restrict__ dy, float* __restrict__ gout, int gout_acc,
+                                                           long total4, int C, float* __restrict__ bias_part) {
     const int c4n = C >> 2;
     const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
     const int c = (int)(i0 % c4n) * 4;  // constant per thread: the grid stride is a multiple of C/4 (host side)
     f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, h_ = s_;
     if (msc) {
@@ -202,11 +229,16 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __
     const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
     const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
     const f32x4 gr = ga * rs;
-    for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dout);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(zmask);
+    f32x4* dy4 = reinterpret_cast<f32x4*>(dy);
+    f32x4* g4 = reinterpret_cast<f32x4*>(gout);
+    const bool acc = gout && gout_acc;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bsum = zero;
+    auto one = [&](long i, f32x4 g, f32x4 v, f32x4 z, f32x4 old) {
         if (zmask) {
-            const f32x4 z = reinterpret_cast<const f32x4*>(zmask)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
         } else if (msc) {
@@ -214,10 +246,38 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __
             for (int e = 0; e < 4; ++e) g[e] = dbn_affine(v[e], s_[e], h_[e]) > 0.f ? g[e] : 0.f;
         }
         const f32x4 xh = (v - mu) * rs;
-        reinterpret_cast<f32x4*>(dy)[i] = gr * (g - k1 - xh * k2);
-        if (gout) {
-            if (gout_acc) g += reinterpret_cast<const f32x4*>(gout)[i];
-            reinterpret_cast<f32x4*>(gout)[i] = g;
+        const f32x4 d = gr * (g - k1 - xh * k2);
+        dy4[i] = d;
+        bsum += d;
+        if (gout) g4[i] = acc ? g + old : g;
+    };
+    long i = i0;
+    for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // 2..4 x UNROLL independent loads in flight per lane
+        f32x4 g[UNROLL], v[UNROLL], z[UNROLL], o[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            g[u] = d4[i + u * stride];
+            v[u] = y4[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            z[u] = zmask ? z4[i + u * stride] : zero;
+            o[u] = acc ? g4[i + u * stride] : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) one(i + u * stride, g[u], v[u], z[u], o[u]);
+    }
+    for (; i < total4; i += stride) one(i, d4[i], y4[i], zmask ? z4[i] : zero, acc ? g4[i] : zero);
+    if (bias_part) {  // threads t, t + C/4, t + 2C/4, ... of the block hold the same channel quad
+        __shared__ f32x4 red[256];
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < c4n) {
+            f32x4 t = zero;
+            for (int k = threadIdx.x; k < 256; k += c4n) t += red[k];
+            const int cq = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_part[(long)(cq + e) * gridDim.x + blockIdx.x] = t[e];
         }
     }
 }
@@ -528,14 +588,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 inline int part_blocks(int M, int C) {
     // rows per block >= 64 so partials stay small; <= MAX_PART blocks
     int nb = (M + 63) / 64;
-    if (nb > MAX_PART) nb = MAX_PART;
+    if (nb > STREAM_BLOCKS) nb = STREAM_BLOCKS;
     if (nb < 1) nb = 1;
     (void)C;
     return nb;
 }
 // grid of a streaming BN kernel whose threads keep their channel quad: (grid * 256) % (C/4) == 0
 inline int bn_stream_grid(long total4, int C) {
-    int g = dbn_grid(total4);
+    int g = dbn_grid(total4, 256, STREAM_BLOCKS);
     int a = C / 4, b = 256;
     while (b) { const int t = a % b; a = b; b = t; }  // a = gcd(C/4, 256)
     const int m = (C / 4) / a;                       // grid must be a multiple of m
@@ -588,9 +648,10 @@ int dbn_bn_apply(const float* y, const float* scale, const float* shift, const f
 
 static int bn_backward_impl(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
                             const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
-                            float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws,
-                            void* stream) {
+                            float* gout, int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C,
+                            float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
+    DBN_REQUIRE(!dbias_conv || 256 % (C / 4) == 0);
     DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     DBN_REQUIRE((mask_scale == nullptr) == (mask_shift == nullptr) && !(zmask && mask_scale));
     hipStream_t st = (hipStream_t)stream;
@@ -608,8 +669,12 @@ static int bn_backward_impl(const float* sums, const float* y, const float* zmas
                            grad_scale);
     }
     const long total4 = (long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_stream_grid(total4, C)), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout,
-                       save_mean, save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C);
+    const int grid = bn_stream_grid(total4, C);
+    // the reduce partials at the front of ws have been consumed by the finalize kernel: the bias partials [C][grid] reuse them
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd,
+                       gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
+    if (dbias_conv)
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, grid, C, dbias_conv, grad_scale);
     return dbn_status();
 }
 
@@ -617,7 +682,7 @@ int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale,
                     const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout, int gout_accumulate,
                     float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws, void* stream) {
     return bn_backward_impl(nullptr, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
-                            dgamma, dbeta, M, C, grad_scale, ws, stream);
+                            dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
 }
 
 // BatchNorm backward whose two per-channel reductions were already produced by the kernel that wrote dout
@@ -628,7 +693,18 @@ int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zm
                               float* ws, void* stream) {
     DBN_REQUIRE(sums);
     return bn_backward_impl(sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
-                            dgamma, dbeta, M, C, grad_scale, ws, stream);
+                            dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
+}
+
+// The general form: `sums` optional (as dbn_bn_backward_from_sums), `dbias_conv` optional [C]: column sums of dy (times
+// grad_scale) = gradient of the bias of the convolution that produced y, formed inside the apply pass instead of by a
+// dbn_col_sum pass over dy (needs 256 % (C/4) == 0).
+int dbn_bn_backward_ex(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
+                       const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout,
+                       int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
+                       void* stream) {
+    return bn_backward_impl(sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                            dgamma, dbeta, dbias_conv, M, C, grad_scale, ws, stream);
 }
 
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {

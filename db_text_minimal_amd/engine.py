@@ -104,6 +104,7 @@ class Engine:
         self.grad_scale = 1.0
         self._live = None
         self.nbt_pending = {}
+        self._bias_done = set()
         self.prof = None  # optional KernelTimer
         self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
         self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = bf16 operands
@@ -113,6 +114,7 @@ class Engine:
         # fill each other's ramps and tails: 36.6 -> 34.9 ms/step at bs16 640^2.  (Tried and rejected: letting the weight
         # gradient overlap only the HBM-bound BatchNorm backward of the next layer — slower than a single stream.)
         self.overlap_wgrad = True
+        self.side_priority = None  # HIP stream priority of the side stream (None: default)
         self._side = None
         self._side_used = False
 
@@ -207,7 +209,8 @@ class Engine:
             yield  # single-stream mode, full profiling (serialises), or already on the side stream (re-entrant)
             return
         if self._side is None or self._side.device != self.flat.device:
-            self._side = torch.cuda.Stream(device=self.flat.device)
+            self._side = (torch.cuda.Stream(device=self.flat.device) if self.side_priority is None else
+                          torch.cuda.Stream(device=self.flat.device, priority=self.side_priority))
         main = torch.cuda.current_stream(self.flat.device)
         self._side.wait_stream(main)
         self._side_used = True
@@ -403,7 +406,7 @@ class Engine:
     def conv_wgrad(self, name, dy, x, conv):
         with self.side_stream():
             self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
-            if conv.bias is not None:
+            if conv.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def convT_fwd(self, name, x, ct, out_name):
@@ -430,7 +433,7 @@ class Engine:
             self.prof.end()
         with self.side_stream():
             self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
-            if ct.bias is not None:
+            if ct.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def col_sum(self, x, out):
@@ -463,9 +466,12 @@ class Engine:
                                   y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
         return out
 
-    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False, sums=None):
+    bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
+
+    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False, sums=None, conv_bias=None):
         """mask: None (no ReLU), 'self' (ReLU directly on this BN's output: recomputed from y with the
-        forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates)."""
+        forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates).
+        conv_bias: name of the bias parameter of the conv that produced y (its gradient = column sums of dy)."""
         C = y.shape[-1]
         M = y.numel() // C
         dy = self.buf(dy_name, *y.shape)
@@ -474,14 +480,17 @@ class Engine:
             msc, msh = self.bufs[name + '/scale'], self.bufs[name + '/shift']
         elif mask is not None:
             zmask = mask
-        args = (y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(), self.bufs[name + '/mean'].data_ptr(),
-                self.bufs[name + '/rstd'].data_ptr(), self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
-                self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(), M, C, self.grad_scale,
-                self.reduce_ws().data_ptr(), self.stream)
-        if sums is not None:  # [2][C] reductions already produced by the kernel that wrote dout
-            check(self.L.dbn_bn_backward_from_sums(sums.data_ptr(), *args), 'bn backward ' + name)
-        else:
-            check(self.L.dbn_bn_backward(*args), 'bn backward ' + name)
+        dbias = None
+        if conv_bias is not None and self.bias_grad_in_bn and 256 % (C // 4) == 0:
+            dbias = self.grad_views[conv_bias]
+            self._bias_done.add(conv_bias)
+        # sums: [2][C] reductions already produced by the kernel that wrote dout
+        check(self.L.dbn_bn_backward_ex(_p(sums), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
+                                        self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
+                                        self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
+                                        self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(),
+                                        _p(dbias), M, C, self.grad_scale, self.reduce_ws().data_ptr(), self.stream),
+              'bn backward ' + name)
         return dy
 
     def up_fwd(self, src, addend, dst, coff=0):
@@ -709,6 +718,7 @@ class Engine:
         m, L, st = self.model, self.L, self.stream
         N, H, W, Hh, Wh, resample = self.saved_shape
         B = self.bufs
+        self._bias_done = set()
         out = self.saved_out  # head output before the (optional) final resample
         dpreds = dpreds.contiguous()
         assert dpreds.shape == (N, 3, H, W)
@@ -741,15 +751,18 @@ class Engine:
             # stream wait for every queued weight gradient and costs more than it gains)
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1', sums=bn_sums[2 * i:2 * i + 2])
+            dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1', sums=bn_sums[2 * i:2 * i + 2],
+                                   conv_bias=hp + '3.bias' if seq[3].bias is not None else None)
             dz0 = self.buf(br + '/dz0', *B[br + '/z0'].shape)
             self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0)
-            dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0')
+            dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0',
+                                   conv_bias=hp + '0.bias' if seq[0].bias is not None else None)
             self.conv_wgrad(hp + '0', dy0, f, seq[0])
             self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0))
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
-        dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], 'self', df, 'fpn/dy')
+        dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], 'self', df, 'fpn/dy',
+                               conv_bias=pre + 'conv.0.bias' if fpn.conv[0].bias is not None else None)
         dP = {}
         levels = ('smooth_p2', 'smooth_p3', 'smooth_p4', 'reduce_conv_c5')
         zs = [B[nm + '/z'] for nm in levels]
@@ -768,7 +781,8 @@ class Engine:
                 dP[nm] = d
 
         def cbr_bwd(name, mod, xin, dz, dx, dx_acc):
-            dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], 'self', dz, name + '/dy')
+            dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], 'self', dz, name + '/dy',
+                                  conv_bias=pre + name + '.conv.bias' if mod.conv.bias is not None else None)
             self.conv_wgrad(pre + name + '.conv', dy, xin, mod.conv)
             self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc)
 
@@ -915,7 +929,7 @@ class Engine:
         with self.side_stream():
             check(self.L.dbn_fpn_scatter_wgrad(ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), Co, Cg,
                                                self.grad_views[name + '.weight'].data_ptr(), self.stream), 'fpn_scatter_wgrad')
-            if conv.bias is not None:
+            if conv.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def _block_bwd(self, name, blk, xin, dout, dx, dx_acc):

@@ -135,6 +135,12 @@ int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zm
                               const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
                               float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale,
                               float* ws, void* stream);
+/* General form: sums optional ([2][C] as above), dbias_conv optional ([C]: column sums of dy x grad_scale = gradient of the bias
+ * of the conv that feeds this BatchNorm, formed in the apply pass; needs 256 % (C/4) == 0). */
+int dbn_bn_backward_ex(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
+                       const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout,
+                       int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
+                       void* stream);
 int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream);
 
 /* ---- stem pooling (nn.MaxPool2d(3,2,1) over relu(bn1(.)): resnet.py:233-235) */
