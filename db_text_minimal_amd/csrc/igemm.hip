@@ -956,40 +956,64 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
 // per (output channel o, block of 64 input channels), so that BOTH sides are coalesced — the slab is read in 64-byte runs
 // (a b128 per lane: four positions = channels 4u+e of one tap) and the OIHW gradient leaves as one contiguous run of
 // 64*R*S floats staged through LDS (the per-element kernel above scatters 4-byte stores at a stride of R*S floats).
-// Same fixed summation order over the splits (fp64), bit-identical results.
-__global__ __launch_bounds__(256) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
-                                                             int BN, int Cb, int I, int RS, float* __restrict__ grad, float scale) {
-    extern __shared__ float stage[];  // [64][RS]
+// Layers with few output elements and hundreds of pixel splits (64-channel layers at 160^2: 3 tiles x 340 splits) are
+// latency-bound on the chain of split loads: G thread groups share the splits (group g takes splits g, g+G, ...), their
+// fp64 partial sums are combined through LDS in group order — fixed summation order, bit-reproducible.
+__global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
+                                                              int BN, int Cb, int I, int RS, int G, float* __restrict__ grad,
+                                                              float scale) {
+    extern __shared__ double dsm[];  // [G][items][4] partial sums (G > 1), then the [64][RS] float staging image
+    const int items = RS * 16;
+    float* stage = reinterpret_cast<float*>(dsm + (G > 1 ? (size_t)G * items * 4 : 0));
     const int o = blockIdx.x, i0 = blockIdx.y * 64;
     const int om = o % BM;
     const int prow = (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
     const long total4 = ((long)O * Jp) >> 2;
-    for (int t = threadIdx.x; t < RS * 16; t += blockDim.x) {
+    const int nthr = blockDim.x;
+    for (int w = threadIdx.x; w < items * G; w += nthr) {
+        const int g = w / items, t = w - g * items;
         const int tap = t >> 4, e = (t >> 2) & 3, cq = t & 3;
         const int j0 = tap * Cb + i0;                 // multiple of 64: the 64 channels lie inside one BN-wide tile
         const int jt = j0 / BN, jl0 = j0 - jt * BN;
         const int pos = e * (BN / 4) + (jl0 >> 2) + 4 * cq;  // positions pos..pos+3 hold channels i0 + 16cq + 4u + e
         const f32x4* src = reinterpret_cast<const f32x4*>(slab + (long)prow * Jp + jt * BN + pos);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
-        int z = 0;
-        for (; z + 4 <= splitk; z += 4) {
-            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + 1) * total4];
-            const f32x4 v2 = src[(long)(z + 2) * total4], v3 = src[(long)(z + 3) * total4];
+        int z = g;
+        for (; z + 3 * G < splitk; z += 4 * G) {
+            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + G) * total4];
+            const f32x4 v2 = src[(long)(z + 2 * G) * total4], v3 = src[(long)(z + 3 * G) * total4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += ((double)v0[u] + (double)v1[u]) + ((double)v2[u] + (double)v3[u]);
         }
-        for (; z < splitk; ++z) {
+        for (; z < splitk; z += G) {
             const f32x4 v = src[(long)z * total4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) s[u] += (double)v[u];
         }
+        if (G > 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+            for (int u = 0; u < 4; ++u) dsm[((size_t)g * items + t) * 4 + u] = s[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+        }
+    }
+    if (G > 1) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < items; t += nthr) {
+            const int tap = t >> 4, e = (t >> 2) & 3, cq = t & 3;
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += dsm[((size_t)g * items + t) * 4 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+        }
     }
     __syncthreads();
     const int n = min(64, I - i0) * RS;  // channels >= I are padding of the activation tensor
     float* dst = grad + ((long)o * I + i0) * RS;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = stage[k];
+    for (int k = threadIdx.x; k < n; k += nthr) dst[k] = stage[k];
 }
 
 // Merge the per-tile BatchNorm partials written by the igemm epilogue (Chan et al. parallel variance, fp64)
@@ -1720,10 +1744,16 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
         if (rc) return rc;
         splits_total += splitk;
     }
-    if (Cb % 64 == 0 && R * S * 64 * 4 <= 64 * 1024)
-        hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(R * S >= 9 ? 256 : 64), (size_t)R * S * 64 * sizeof(float), st,
-                           slab, splits_total, O, J, Jp, bm, bn, Cb, I, R * S, grad_oihw, scale);
-    else
+    if (Cb % 64 == 0 && R * S * 64 * 4 <= 32 * 1024) {
+        const int items = R * S * 16;
+        int G = std::min(1024 / items, splits_total / 4);  // thread groups sharing the splits (>= 4 splits each)
+        if (G < 1) G = 1;
+        if (G > 32) G = 32;
+        const int threads = std::min(1024, (items * G + 63) / 64 * 64);
+        const size_t smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)R * S * 64 * sizeof(float);
+        hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,
+                           R * S, G, grad_oihw, scale);
+    } else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
                            Cb, I, R, S, grad_oihw, scale);
     return dbn_status();

@@ -713,7 +713,7 @@ def test_image_chunking_beyond_the_index_ranges():
     those ranges (e.g. BASELINE configs[4] at batch sizes above 40: 48 x 1280^2 / 4 px = 19.7 M rows) runs as several
     launches over image ranges.  With the limits lowered (dbn_set_index_limits) the chunked path must reproduce the
     single-launch results BIT FOR BIT: conv + fused BN statistics, strided transposed conv, pyramid conv, weight gradient."""
-    N, Ci, Co, H, W = 5, 64, 128, 24, 20
+    N, Ci, Co, H, W = 5, 64, 128, 24, 16
     x = nhwc(rnd(N, Ci, H, W, seed=1))
     w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
     wT = rnd(Ci, Co, 4, 4, seed=3, scale=0.05)
