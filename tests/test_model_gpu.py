@@ -259,6 +259,13 @@ def test_cfg4_r50dcn_800_bs8_f32_and_bf16():
     seed, arch = 23, 'deformable_resnet50'
     img, gts = O.synthetic_batch(8, 800, seed=seed + 1)
     sd = O.new_state(seed, arch)
+    # The procedural fill gives every BatchNorm gain ~1, so each of the 16 Bottleneck residual branches is as strong as its
+    # shortcut and the random 53-layer net amplifies a relative perturbation ~1e3x (measured: bf16 operand rounding, 2^-9, comes
+    # out as a 50 % error of the FPN features — tools/bf16_dcn_probe.py).  A trained net is shortcut-dominated; the test net
+    # gets the standard "small last gain" of residual nets (bn3 gain x 0.2), which leaves the arithmetic under test unchanged.
+    for k in sd:
+        if k.endswith('.bn3.weight'):
+            sd[k] = sd[k] * 0.2
     O.BN_MOMENTUM = 1.0  # running statistics that match the weights (see test_bottleneck_and_deformable_backbones_vs_oracle)
     try:
         with torch.no_grad():

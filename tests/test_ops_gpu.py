@@ -765,7 +765,7 @@ def test_image_chunking_beyond_the_index_ranges():
         L().dbn_set_index_limits(2 * H * W + 7, 0, 0)  # at most two images per launch
         assert L().dbn_wgrad_splitk_hw(N, H, W, Co, H, W, Ci, 3, 3) >= 3
         got = run_all()
-        L().dbn_set_index_limits(0, H * W * Ci * 4 + 64, 0)  # one image per launch through the byte range
+        L().dbn_set_index_limits(0, H * W * Co * 4 + 64, 0)  # one image of the widest tensor per launch, through the byte range
         got1 = run_all()
     finally:
         L().dbn_set_index_limits(0, 0, 0)
