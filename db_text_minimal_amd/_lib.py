@@ -72,7 +72,27 @@ SIGNATURES = {
     'dbn_pixel_confusion': 'plppiiifpp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
 }
-LONG_RETURN = {'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+# `_t` forms: activation storage type first (0 fp32, 1 bf16, 2 fp16), see include/dbnet_hip.h
+SIGNATURES.update({
+    'dbn_igemm_t': 'ii' + 'pppp' + 'i' * 14 + 'i' + 'p' + 'p',
+    'dbn_conv_bn_t': 'i' + SIGNATURES['dbn_conv_bn_f32'],
+    'dbn_pyramid_conv_t': 'i' + SIGNATURES['dbn_pyramid_conv_f32'],
+    'dbn_wgrad_t': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
+    'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
+    'dbn_igemm_panel_floats_t': 'i' * 8,
+    'dbn_bn_train_stats_t': 'i' + SIGNATURES['dbn_bn_train_stats'],
+    'dbn_bn_apply_t': 'i' + SIGNATURES['dbn_bn_apply'],
+    'dbn_bn_backward_t': 'i' + SIGNATURES['dbn_bn_backward_ex'],
+    'dbn_col_sum_t': 'i' + SIGNATURES['dbn_col_sum'],
+    'dbn_bnrelu_maxpool_fwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_fwd'],
+    'dbn_bnrelu_maxpool_bwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_bwd'],
+    'dbn_nearest_up_fwd_t': 'i' + SIGNATURES['dbn_nearest_up_fwd'],
+    'dbn_nearest_up_bwd_t': 'i' + SIGNATURES['dbn_nearest_up_bwd'],
+    'dbn_nchw3_to_nhwc4_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
+    'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
+    'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
+})
+LONG_RETURN = {'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

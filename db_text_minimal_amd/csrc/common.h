@@ -72,3 +72,65 @@ __device__ __forceinline__ double dbn_team32_fold(const float* __restrict__ part
 // on float equality with the forward).
 __device__ __forceinline__ float dbn_affine(float y, float sc, float sh) { return fmaf(y, sc, sh); }
 __device__ __forceinline__ float dbn_affine_relu(float y, float sc, float sh) { return fmaxf(fmaf(y, sc, sh), 0.f); }
+
+// ---- activation storage types ---------------------------------------------------------------------------------------
+// AT = 0: fp32 (BASELINE configs[1]), 1: bf16 (configs[2]/[3]: bf16 activations, gradients and weight panels in HBM; fp32
+// accumulators, BatchNorm statistics, loss sums, master weights), 2: fp16 (configs[4]: inference).  Every kernel computes
+// in fp32 registers; only what crosses HBM changes.  Helpers move FOUR consecutive elements (16 B fp32 / 8 B 16-bit).
+#define DBN_AT_F32 0
+#define DBN_AT_BF16 1
+#define DBN_AT_F16 2
+typedef unsigned dbn_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dbn_f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 dbn_bf16x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int dbn_esize(int at) { return at == 0 ? 4 : 2; }
+
+template <int AT>
+__device__ __forceinline__ f32x4 dbn_ld4(const void* __restrict__ p, long i4) {
+    if constexpr (AT == 0) {
+        return reinterpret_cast<const f32x4*>(p)[i4];
+    } else if constexpr (AT == 1) {
+        const dbn_u32x2 v = reinterpret_cast<const dbn_u32x2*>(p)[i4];
+        return f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xFFFF0000u),
+                     __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xFFFF0000u)};
+    } else {
+        const dbn_f16x4 v = reinterpret_cast<const dbn_f16x4*>(p)[i4];
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+template <int AT>
+__device__ __forceinline__ void dbn_st4(void* __restrict__ p, long i4, f32x4 v) {
+    if constexpr (AT == 0) {
+        reinterpret_cast<f32x4*>(p)[i4] = v;
+    } else if constexpr (AT == 1) {  // v_cvt_pk_bf16_f32: round to nearest even
+        const dbn_bf16x2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+        reinterpret_cast<dbn_u32x2*>(p)[i4] = dbn_u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    } else {
+        reinterpret_cast<dbn_f16x4*>(p)[i4] = dbn_f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+}
+
+// one element
+template <int AT>
+__device__ __forceinline__ float dbn_ld1(const void* __restrict__ p, long i) {
+    if constexpr (AT == 0) return reinterpret_cast<const float*>(p)[i];
+    else if constexpr (AT == 1) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+    else return (float)reinterpret_cast<const _Float16*>(p)[i];
+}
+template <int AT>
+__device__ __forceinline__ void dbn_st1(void* __restrict__ p, long i, float v) {
+    if constexpr (AT == 0) reinterpret_cast<float*>(p)[i] = v;
+    else if constexpr (AT == 1) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    else reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
+}
+
+// run `stmt` with a constexpr AT for a runtime activation type
+#define DBN_DISPATCH_AT(at, ...)                          \
+    do {                                                  \
+        if ((at) == 0) { constexpr int AT = 0; __VA_ARGS__; }      \
+        else if ((at) == 1) { constexpr int AT = 1; __VA_ARGS__; } \
+        else if ((at) == 2) { constexpr int AT = 2; __VA_ARGS__; } \
+        else return DBN_ERR_ARG;                          \
+    } while (0)

@@ -26,7 +26,8 @@ __device__ __forceinline__ float group16_sum(float v) {
 
 // xb/xt: [N,Hq,Wq,64] inputs of the last ConvT (already BN+ReLU'd);  wb/wt: [64][4]
 // (ConvTranspose2d weight [64,1,2,2]); out: [N,CH,2Hq,2Wq], CH=3 (train) or 2 (eval).
-__global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
+template <int AT>
+__global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restrict__ xb, const void* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ bias_b,
                                      const float* __restrict__ bias_t, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restr
     const int H = 2 * Hq, W = 2 * Wq;
     const long HW = (long)H * W;
     for (long px = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4); px < npx; px += gstride) {
-        f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
-        f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        f32x4 vb = dbn_ld4<AT>(xb, px * 16 + q);
+        f32x4 vt = dbn_ld4<AT>(xt, px * 16 + q);
         if (bn) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -95,13 +96,14 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const float* __restr
 // Backward.  For each quarter pixel: dl_b[ab], dl_t[ab] (grad wrt the two logits) from
 // dpreds and the saved maps; dxb = sum_ab dl_b[ab]*wb[ci][ab]; dwb[ci][ab] += xb[ci]*dl_b[ab].
 // part: [grid][2*(256+1)] block partials of (dwb[64*4], dbias_b, dwt[64*4], dbias_t).
-__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restrict__ xb, const float* __restrict__ xt, const float* __restrict__ wb,
+template <int AT>
+__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restrict__ xb, const void* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ preds,
                                      const float* __restrict__ dpreds, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
                                      const float* __restrict__ sh_t, const float* __restrict__ mean_b,
                                      const float* __restrict__ rstd_b, const float* __restrict__ mean_t,
-                                     const float* __restrict__ rstd_t, float* __restrict__ dxb, float* __restrict__ dxt,
+                                     const float* __restrict__ rstd_t, void* __restrict__ dxb, void* __restrict__ dxt,
                                      float* __restrict__ part, int N, int Hq, int Wq, int CH, float kstep) {
     const int q = threadIdx.x & 15;
     const int grp = threadIdx.x >> 4;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restr
             lb[ab] = __shfl(dlb, (threadIdx.x & 48) + ab, 64);
             lt[ab] = __shfl(dlt, (threadIdx.x & 48) + ab, 64);
         }
-        f32x4 vb = *reinterpret_cast<const f32x4*>(xb + px * 64 + 4 * q);
-        f32x4 vt = *reinterpret_cast<const f32x4*>(xt + px * 64 + 4 * q);
+        f32x4 vb = dbn_ld4<AT>(xb, px * 16 + q);
+        f32x4 vt = dbn_ld4<AT>(xt, px * 16 + q);
         const f32x4 yb = vb, yt = vt;
         if (bn) {
 #pragma unroll
@@ -186,9 +188,16 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const float* __restr
             awb[e] += vb[e] * lb;
             awt[e] += vt[e] * lt;
         }
-        *reinterpret_cast<f32x4*>(dxb + px * 64 + 4 * q) = gb;
-        *reinterpret_cast<f32x4*>(dxt + px * 64 + 4 * q) = gt;
+        dbn_st4<AT>(dxb, px * 16 + q, gb);
+        dbn_st4<AT>(dxt, px * 16 + q, gt);
         if (bnsum) {
+            if constexpr (AT != 0) {  // the BatchNorm backward's apply pass will read the ROUNDED gradient: sum exactly that
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gb[e] = AT == 1 ? (float)(__bf16)gb[e] : (float)(_Float16)gb[e];
+                    gt[e] = AT == 1 ? (float)(__bf16)gt[e] : (float)(_Float16)gt[e];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float mb = vb[e] > 0.f ? gb[e] : 0.f, mt = vt[e] > 0.f ? gt[e] : 0.f;  // ReLU mask as in bn_bwd ('self')
@@ -648,25 +657,33 @@ __global__ void pixel_confusion_kernel(const float* __restrict__ preds, long bat
 
 extern "C" {
 
-int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,
-                      const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
-                      const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
+// xb/xt are stored in the activation type `at`; the maps `out` are always fp32 (what DBLoss and postprocess.py consume)
+int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* bias_b,
+                        const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                        const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
     DBN_REQUIRE(xb && xt && wb && wt && bias_b && bias_t && out && (channels == 2 || channels == 3));
     DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     const long npx = (long)N * Hq * Wq;
-    hipLaunchKernelGGL(head_tail_fwd_kernel, dim3(dbn_grid(npx * 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, xb, xt, wb,
-                       wt, bias_b, bias_t, bn_scale_b, bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(head_tail_fwd_kernel<AT>, dim3(dbn_grid(npx * 16, 256, 8192)), dim3(256), 0,
+                                           (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b, bn_shift_b, bn_scale_t,
+                                           bn_shift_t, out, N, Hq, Wq, channels, kstep));
     return dbn_status();
+}
+int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,
+                      const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
+    return dbn_head_tail_fwd_t(0, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b, bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq,
+                               channels, kstep, stream);
 }
 
 int dbn_head_tail_bwd_ws_floats() { return 2048 * (2 * 257 + 4 * 64); }
 
 // dw_b/dw_t: [64*4] (ConvTranspose2d weight grads), dbias_b/dbias_t: [1]
-int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
-                      const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
-                      const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
-                      const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
-                      float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
+int dbn_head_tail_bwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* preds,
+                        const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                        const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
+                        const float* bn_rstd_t, float* bn_sums, void* dxb, void* dxt, float* dw_b, float* dbias_b, float* dw_t,
+                        float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
     DBN_REQUIRE(xb && xt && wb && wt && preds && dpreds && dxb && dxt && dw_b && dbias_b && dw_t && dbias_t && ws);
     DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     DBN_REQUIRE(channels == 2 || channels == 3);
@@ -675,15 +692,25 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
     hipStream_t st = (hipStream_t)stream;
     const long npx = (long)N * Hq * Wq;
     const int nb = dbn_grid(npx * 16, 256, 2047);  // < 2048 partial rows: fits dbn_head_tail_bwd_ws_floats()
-    hipLaunchKernelGGL(head_tail_bwd_kernel, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, bn_scale_b, bn_shift_b,
-                       bn_scale_t, bn_shift_t, sums ? bn_mean_b : nullptr, bn_rstd_b, bn_mean_t, bn_rstd_t, dxb, dxt, ws, N, Hq, Wq,
-                       channels, kstep);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(head_tail_bwd_kernel<AT>, dim3(nb), dim3(256), 0, st, xb, xt, wb, wt, preds, dpreds, bn_scale_b,
+                                           bn_shift_b, bn_scale_t, bn_shift_t, sums ? bn_mean_b : nullptr, bn_rstd_b, bn_mean_t,
+                                           bn_rstd_t, dxb, dxt, ws, N, Hq, Wq, channels, kstep));
     hipLaunchKernelGGL(fold_head_grads_kernel, dim3(dbn_ceil_div(2 * 257, 8)), dim3(256), 0, st, ws, nb, dw_b, dbias_b, dw_t, dbias_t,
                        grad_scale);
     if (sums)  // [s1_b | s2_b | s1_t | s2_t]: two [2][64] blocks for dbn_bn_backward_from_sums
         hipLaunchKernelGGL(fold_partials_d_kernel, dim3(dbn_ceil_div(256, 8)), dim3(256), 0, st, ws + (long)514 * nb, nb, 256, bn_sums,
                            1.0f);
     return dbn_status();
+}
+
+int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* preds,
+                      const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                      const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
+                      const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
+                      float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream) {
+    return dbn_head_tail_bwd_t(0, xb, xt, wb, wt, preds, dpreds, bn_scale_b, bn_shift_b, bn_scale_t, bn_shift_t, bn_mean_b, bn_rstd_b,
+                               bn_mean_t, bn_rstd_t, bn_sums, dxb, dxt, dw_b, dbias_b, dw_t, dbias_t, N, Hq, Wq, channels, kstep,
+                               grad_scale, ws, stream);
 }
 
 int dbn_db_loss_ws_bytes() { return 1024 * NSUM * (int)sizeof(double); }

@@ -64,10 +64,10 @@ __host__ __device__ inline IgemmClass class_geom(int c, int f, int R, int S, int
 }
 
 struct IgemmParams {
-    const float* src;   // [N,Hs,Ws,Cs]
+    const void* src;    // [N,Hs,Ws,Cs], activation type AT
     const float* wpk;   // per problem: [KT*4][Cd][4]
     const float* bias;  // [Cd] or null
-    float* dst;         // [N,Hdf,Wdf,Cd]
+    void* dst;          // [N,Hdf,Wdf,Cd], activation type AT (split-K: fp32 slabs)
     int N, Hs, Ws, Cs, Cd, Hdf, Wdf, R, S, stride, pad, accumulate, ncls;
     int stat_rows;      // rows of the partials array (all M-tiles of the call; a call over many images runs as several launches)
     int stat_row0;      // first row this launch writes
@@ -79,7 +79,7 @@ struct IgemmParams {
     int ksplit, kt_per;
     int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
-    const float* seg_src[4];
+    const void* seg_src[4];
     const float* seg_wpk[4];
     unsigned seg_bytes[4];
 };
@@ -143,9 +143,19 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[NS > 0 ? NS :
     }
 }
 
-template <int NS, int MI, int NI>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NS, int MI, int NI, int F16 = 0>
 __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][MI], const bf16x8 (&bf)[NS > 0 ? NS : 1][NI],
                                            f32x16 (&acc)[MI][NI]) {
+    if constexpr (F16) {  // fp16 operands (inference, BASELINE configs[4]): the same 16-byte fragments, v_mfma_f32_32x32x16_f16
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][b]),
+                                                                   acc[a][b], 0, 0, 0);
+        return;
+    }
     // smallest terms first
     constexpr int NPROD = NS == 3 ? 6 : 1;
     constexpr int pi[6] = {2, 0, 1, 1, 0, 0};
@@ -183,12 +193,21 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 #define DBN_IGEMM_OCC(BM, BN, NS, MODE)
 #endif
 
-template <int BM, int BN, int WM, int WN, int MODE, int NS>
+// AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
+// of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
+// stored format), the accumulators are rounded to the storage type on the way out.
+template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void igemm_f32_kernel(const IgemmParams p) {
+    static_assert(AT == 0 || NS == 1, "16-bit activation storage runs on the single-plane 16-bit matrix path");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int A_LD = BM * 4 / NT;  // float4 gathers per thread per k-tile
+    constexpr int ES = AT == 0 ? 4 : 2;            // bytes per stored element
+    constexpr int A_SH = AT == 0 ? 2 : 1;          // threads per row = 1 << A_SH (4 x 4 fp32 channels, or 2 x 8 16-bit channels)
+    constexpr int A_CH = AT == 0 ? 4 : 8;          // channels per 16-byte piece
+    constexpr int A_PIECES = BM << A_SH;           // 16-byte pieces of the A panel per k-tile
+    constexpr int A_LD = (A_PIECES + NT - 1) / NT;  // gathers per thread per k-tile
+    constexpr bool A_FULL = A_PIECES % NT == 0;
     // LDS image in 16-byte units.  NS == 0: [k/4][row][4 f32], chunk stride +2 keeps ds_write_b128 conflict-free.
     // NS > 0: per split [k/8][row][8 bf16], row stride +4 (== 64 B mod 128) keeps the ds_write_b64 conflict-free.
     constexpr int AS = NS == 0 ? BM + 2 : BM + 4, BS = NS == 0 ? BN + 2 : BN + 4;
@@ -246,18 +265,19 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     int qK = q.K, qKT = q.KT, qS = q.S, qR = q.R;  // MODE 3 changes these (and the source) per level
     int gHs = p.Hs, gWs = p.Ws;
 
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
 
     // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
-    const int a_chunk = tid & 3;
+    const int a_chunk = tid & ((1 << A_SH) - 1);
+    const bool a_on = A_FULL || tid < A_PIECES;  // (64-row tiles of the 16-bit path: half of the threads gather)
     int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
     int a_n[MODE == 3 ? A_LD : 1], a_hd[MODE == 3 ? A_LD : 1], a_wd[MODE == 3 ? A_LD : 1];
     const int HWd = qHd * qWd;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const int row = (tid >> 2) + j * (NT / 4);
+        const int row = (tid >> A_SH) + j * (NT >> A_SH);
         const int m = m0 + row;
-        const bool ok = m < qM;
+        const bool ok = m < qM && a_on;
         const int mm = ok ? m : 0;
         int n, rem, hd, wd;  // reciprocal divisions (exact below 2^24): an integer division costs ~35 VALU instructions
         divmod24(mm, HWd, 1.0f / (float)HWd, n, rem);
@@ -280,8 +300,8 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     //                 16-channel block and the R*S taps of a block are consecutive k-tiles, so the 9 re-reads of
     //                 an input pixel's 64-byte slice happen back to back (L1/L2 hits instead of a trip to the fabric);
     //   otherwise (stem, Cs = 4): k = (r*S + s)*Cs + ci.
-    const bool blocked = (p.Cs & 15) == 0;
-    int kidx = 4 * a_chunk;
+    const bool blocked = (p.Cs & 15) == 0;  // (always, for 16-bit storage: checked on the host)
+    int kidx = A_CH * a_chunk;
     int k_ci, k_r, k_s;
     int kt_begin = 0, kt_end = qKT;
     if (MODE < 2 && p.ksplit > 1) {
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     if (blocked) {  // k-tile kt is tap (kt % RS) of channel block (kt / RS)
         const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
         kidx += 16 * kt_begin;
-        k_ci = 16 * cb + 4 * a_chunk;
+        k_ci = 16 * cb + A_CH * a_chunk;
         k_r = tap / qS;
         k_s = tap - k_r * qS;
     } else {
@@ -308,7 +328,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
             const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
             const bool v = kidx < qK && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
-            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * 4u;
+            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES;
             aoff[j] = v ? off : OOB_OFFSET;
         }
         kidx += 16;
@@ -362,7 +382,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         qKT = qK >> 4;
         gHs = p.Hdf >> g;
         gWs = p.Wdf >> g;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
         long krows = 0;  // padded-K rows of the classes packed before (ph, pw)
         for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
         panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2));
@@ -372,8 +392,8 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             a_hb[j] = a_hd[MODE == 3 ? j : 0] * (8 >> g) + (q.oh0 >> g) + padh;
             a_wb[j] = a_wd[MODE == 3 ? j : 0] * (8 >> g) + (q.ow0 >> g) + padw;
         }
-        kidx = 4 * a_chunk;
-        k_ci = 4 * a_chunk;
+        kidx = A_CH * a_chunk;
+        k_ci = A_CH * a_chunk;
         k_r = k_s = 0;
     };
 
@@ -405,6 +425,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         if constexpr (NS == 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
+        } else if constexpr (AT != 0) {
+            // stored 16-bit channels: the piece IS the LDS slot [k/8 = a_chunk][row] of the single-plane image
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j)
+                if (A_FULL || a_on) As[a_chunk * AS + (tid >> A_SH) + j * (NT >> A_SH)] = ra[j];
         } else {
             // chunk c holds k = 4c..4c+3 of the k-tile: bf16 image slot [c>>1][row], 8-byte half (c&1)
 #pragma unroll
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 #pragma unroll
                 for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
             }
-            mfma_split<NS, MI, NI>(af, bf, acc);
+            mfma_split<NS, MI, NI, AT == 2>(af, bf, acc);
             next_offsets();
         }
         stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
@@ -496,7 +521,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 
     // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
     // statistics below and the store loop both see the final values
-    float* const dstp = (MODE < 2 && p.ksplit > 1) ? p.dst + (long)blockIdx.y * qM * p.Cd : p.dst;
+    // split-K launches write fp32 slabs whatever the activation type (the slab sum rounds once)
+    const bool to_slab = MODE < 2 && p.ksplit > 1;
+    float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * qM * p.Cd : 0L);
+    void* const dstv = p.dst;
+    auto ld_dst = [&](long off) -> float { return (AT == 0 || to_slab) ? slabp[off] : dbn_ld1<AT>(dstv, off); };
+    auto st_dst = [&](long off, float v) {
+        if (AT == 0 || to_slab) slabp[off] = v;
+        else dbn_st1<AT>(dstv, off, v);
+    };
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
     // fn(r, doff) for the 16 rows this lane holds of accumulator block a (rows base + (r&3) + 8*(r>>2)) that are < M.
     // MODE >= 2 scatters to the parity class's pixels of the full-resolution output: the pixel (n, hd, wd) of the first row
@@ -545,10 +578,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
                 float old[4][NI];
                 bool okr[4];
                 for_rows(a, [&](int r, bool ok, long doff) {
-                    const float* d = dstp + n0 + wn * TN + li + doff;
+                    const long d = n0 + wn * TN + li + doff;
                     okr[r & 3] = ok;
 #pragma unroll
-                    for (int b = 0; b < NI; ++b) old[r & 3][b] = d[b * 32];
+                    for (int b = 0; b < NI; ++b) old[r & 3][b] = ld_dst(d + b * 32);
                     if ((r & 3) == 3) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -561,9 +594,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             } else {  // parity-class scatter: row by row (the pixel walk plus batched loads costs 40 VGPRs = an occupancy step)
                 for_rows(a, [&](int r, bool ok, long doff) {
                     if (ok) {
-                        const float* d = dstp + n0 + wn * TN + li + doff;
+                        const long d = n0 + wn * TN + li + doff;
 #pragma unroll
-                        for (int b = 0; b < NI; ++b) acc[a][b][r] += d[b * 32];
+                        for (int b = 0; b < NI; ++b) acc[a][b][r] += ld_dst(d + b * 32);
                     }
                 });
             }
@@ -635,19 +668,18 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     // row's store waited for the previous row's store to complete.
 #pragma unroll
     for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
-    float* const dcol = dstp + n0 + wn * TN + li;
+    const long dcol = n0 + wn * TN + li;
 #pragma unroll
     for (int a = 0; a < MI; ++a)
         for_rows(a, [&](int r, bool ok, long doff) {
-            float* d = dcol + doff;
             if (ok) {
 #pragma unroll
-                for (int b = 0; b < NI; ++b) d[b * 32] = acc[a][b][r] + bv[b];
+                for (int b = 0; b < NI; ++b) st_dst(dcol + doff + b * 32, acc[a][b][r] + bv[b]);
             }
         });
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
 int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     int grid = 0, rows = 0;
     if (mode == 3) {
@@ -672,20 +704,23 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     if (grid == 0) return DBN_OK;
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
     if (mode == 0)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 2)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS, AT>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else if constexpr (BM == 128 && BN == 128)  // the pyramid conv is built for the 128x128 tile only
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 3, NS>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 3, NS, AT>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
     else
         return DBN_ERR_ARG;
     return dbn_status();
 }
 
+// ns: matrix math (0 exact fp32, 1 one 16-bit plane, 3 bf16x3); at: activation storage (0 fp32, 1 bf16, 2 fp16; 16-bit storage needs ns 1)
 template <int BM, int BN, int WM, int WN>
-int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st) {
+int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st, int at = 0) {
+    if (at == 1) return ns == 1 ? launch_igemm_ns<BM, BN, WM, WN, 1, 1>(p, mode, st) : DBN_ERR_ARG;
+    if (at == 2) return ns == 1 ? launch_igemm_ns<BM, BN, WM, WN, 1, 2>(p, mode, st) : DBN_ERR_ARG;
     if (ns == 0) return launch_igemm_ns<BM, BN, WM, WN, 0>(p, mode, st);
     if (ns == 1) return launch_igemm_ns<BM, BN, WM, WN, 1>(p, mode, st);
     return launch_igemm_ns<BM, BN, WM, WN, 3>(p, mode, st);
@@ -695,8 +730,8 @@ int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st) {
 // weight gradient
 // --------------------------------------------------------------------------------
 struct WgradParams {
-    const float* sm;   // [N,Ho,Wo,O]  (indexes the reduction)
-    const float* big;  // [N,H,W,Cb]
+    const void* sm;    // [N,Ho,Wo,O]  (indexes the reduction), activation type AT
+    const void* big;   // [N,H,W,Cb], activation type AT
     float* slab;       // [splitk][O][J]
     int N, Ho, Wo, O, H, W, Cb, R, S, stride, pad;
     int P, J, pchunk;
@@ -710,8 +745,12 @@ struct WgradParams {
 // fragments conflict-free.  The accumulators (and the slabs) therefore live in "position space".
 __host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { return 4 * (pos % (B / 4)) + pos / (B / 4); }
 
-template <int BM, int BN, int WM, int WN, int NS>
+// AT = 1 (bf16 activations and gradients in HBM, NS = 1): the staging threads fetch their 4 pixels x 4 channels as four
+// 8-byte loads and transpose the 16-bit values with two bit operations per output word — no conversion.
+template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
+    static_assert(AT == 0 || (AT == 1 && NS == 1), "bf16 storage runs on the single-plane bf16 matrix path");
+    constexpr unsigned ES = AT == 0 ? 4u : 2u;
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -739,8 +778,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int pend = min(p.P, pbeg + p.pchunk);
     const int KT = (pend - pbeg + 15) / 16;
 
-    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.sm), 0, p.sm_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.big), 0, p.big_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
 
     // staging roles (wave-uniform): threads [0,BM) transpose the A panel (sm: 16 pixels x BM channels),
     // threads [NT-BN,NT) the B panel (gathered big: 16 pixels x BN (tap,channel) columns).
@@ -763,7 +802,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int ld = is_a ? AS : BS;
     const int lds_base = (is_a ? 0 : A_IMG) + s_c;
 
-    f32x4 rr[4];
+    f32x4 rr[4];        // AT = 0: 4 pixels x 4 fp32 channels
+    u32x2 rh[4];        // AT = 1: 4 pixels x 4 bf16 channels
     unsigned woff[4];
     // byte offsets of this thread's 4 loads for k-tile kt (address math kept apart from the loads so that it
     // can be issued in the shadow of the previous tile's MFMAs)
@@ -781,7 +821,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pp = pp0 + i;
-                woff[i] = pp < pend ? (unsigned)(pp * p.O + o0 + 4 * s_c) * 4u : OOB_OFFSET;
+                woff[i] = pp < pend ? (unsigned)(pp * p.O + o0 + 4 * s_c) * ES : OOB_OFFSET;
             }
         } else if (is_b) {
             int n = w_n, oh = w_oh, ow = w_ow;
@@ -797,7 +837,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             for (int i = 0; i < 4; ++i) {
                 const int ih = oh * p.stride + tr, iw = ow * p.stride + ts;
                 const bool v = j_ok && (pp0 + i) < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                woff[i] = v ? (unsigned)(((n * p.H + ih) * p.W + iw) * p.Cb + ci) * 4u : OOB_OFFSET;
+                woff[i] = v ? (unsigned)(((n * p.H + ih) * p.W + iw) * p.Cb + ci) * ES : OOB_OFFSET;
                 // next pixel (row-major over n, oh, ow), branch-free carry
                 ++ow;
                 const bool cw = ow == p.Wo;
@@ -810,12 +850,22 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         }
     };
     auto issue_loads = [&]() {
-        if (is_a) {
+        if constexpr (AT == 0) {
+            if (is_a) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_sm, woff[i]);
-        } else if (is_b) {
+                for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_sm, woff[i]);
+            } else if (is_b) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_big, woff[i]);
+                for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_big, woff[i]);
+            }
+        } else {
+            if (is_a) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rh[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_sm, (int)woff[i], 0, 0);
+            } else if (is_b) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rh[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_big, (int)woff[i], 0, 0);
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -824,6 +874,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             if constexpr (NS == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) dst[s_g * ld + e * qn] = f32x4{rr[0][e], rr[1][e], rr[2][e], rr[3][e]};
+            } else if constexpr (AT != 0) {
+                // channel e of pixels 0..3 -> one 8-byte half slot: word = (pixel a | pixel b << 16) of the channel's 16 bits
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned a0 = rh[0][e >> 1], a1 = rh[1][e >> 1], a2 = rh[2][e >> 1], a3 = rh[3][e >> 1];
+                    const u32x2 o = (e & 1) ? u32x2{(a0 >> 16) | (a1 & 0xFFFF0000u), (a2 >> 16) | (a3 & 0xFFFF0000u)}
+                                            : u32x2{(a0 & 0xFFFFu) | (a1 << 16), (a2 & 0xFFFFu) | (a3 << 16)};
+                    reinterpret_cast<u32x2*>(dst + (s_g >> 1) * ld + e * qn)[s_g & 1] = o;
+                }
             } else {
                 // pixel group g = k 4g..4g+3 of the k-tile: bf16 image slot [g>>1][pos], 8-byte half (g&1)
 #pragma unroll
@@ -1075,16 +1134,17 @@ __global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int ro
 // mode 1: data-gradient panels, taps r = r0 + rstep*r', s = s0 + rstep*s' (R', S' of them):
 //         k = (r'*S'+s')*Cs + cs -> w[cs][cd][r][s].
 // dst = [dst +] bias + sum over the split-K slabs, fixed order
+template <int AT>
 __global__ void splitk_sum_kernel(const float* __restrict__ slab, int splits, long total4, int Cd, const float* __restrict__ bias,
-                                  int accumulate, float* __restrict__ dst) {
+                                  int accumulate, void* __restrict__ dst) {
     const int c4n = Cd >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
         f32x4 v = src[0];
         for (int z = 1; z < splits; ++z) v += src[(long)z * total4];
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * (int)(i % c4n));
-        if (accumulate) v += reinterpret_cast<const f32x4*>(dst)[i];
-        reinterpret_cast<f32x4*>(dst)[i] = v;
+        if (accumulate) v += dbn_ld4<AT>(dst, i);
+        dbn_st4<AT>(dst, i, v);
     }
 }
 
@@ -1149,8 +1209,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int I, i
 
 // Split-bf16 weight panels for the NS > 0 kernels: [KT][NS][2][Cd][8 bf16]; element (k, cd, split t)
 // at ((kt*NS + t)*2 + k8)*Cd*8 + cd*8 + e with k = 16*kt + 8*k8 + e.  Same (mode, tap subset) semantics as above.
+__device__ __forceinline__ unsigned f16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); }
+
+// f16 != 0 (NS = 1): fp16 panels for the fp16 inference path instead of bf16
 __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, int I, int R, int S, int mode, int Cs, int Cd, int f,
-                                          int NS, unsigned short* __restrict__ out) {
+                                          int NS, int f16, unsigned short* __restrict__ out) {
     const PackClass q = pack_class(f, R, S, Cs);
     const int K = q.K, Rp = q.Rp, Sp = q.Sp, r0 = q.r0, s0 = q.s0, rstep = q.rstep;
     out += q.krow0 * Cd * NS;
@@ -1181,6 +1244,10 @@ __global__ void pack_weights_bf16s_kernel(const float* __restrict__ w, int O, in
             }
         }
         const int kt = k8g >> 1, k8 = k8g & 1;
+        if (f16) {
+            out[(((long)kt * 2 + k8) * Cd + cd) * 8 + e] = (unsigned short)f16_bits(v);
+            continue;
+        }
         for (int t = 0; t < NS; ++t) {
             const unsigned bits = bf16_bits_rne(v);
             out[((((long)kt * NS + t) * 2 + k8) * Cd + cd) * 8 + e] = (unsigned short)bits;
@@ -1238,7 +1305,11 @@ __global__ void pack_many_kernel(const PackJob* __restrict__ jobs, int NS) {
                     v = w[(((long)cs * j.I + cd) * j.R + r) * j.S + sx];
                 }
             }
-            if constexpr (BF16) {
+            if constexpr (BF16 == 2) {  // fp16 panels (one plane)
+                unsigned short* out = reinterpret_cast<unsigned short*>(j.out) + krow0 * j.Cd;
+                const int kt = kg >> 1, k8 = kg & 1;
+                out[(((long)kt * 2 + k8) * j.Cd + cd) * 8 + e] = (unsigned short)f16_bits(v);
+            } else if constexpr (BF16 == 1) {
                 unsigned short* out = reinterpret_cast<unsigned short*>(j.out) + krow0 * j.Cd * NS;
                 const int kt = kg >> 1, k8 = kg & 1;
                 for (int t = 0; t < NS; ++t) {
@@ -1283,15 +1354,15 @@ int dbn_igemm_tile_config(int M, int Cd) {
     return best;
 }
 
-static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st) {
+static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st, int at = 0) {
     // tile choice from the total row count (for parity classes: all classes together)
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
     switch (cfg) {
-        case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st);
-        case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st);
-        case 3: return launch_igemm<128, 64, 2, 2>(p, kmode, ns, st);
-        default: return launch_igemm<64, 64, 2, 2>(p, kmode, ns, st);
+        case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st, at);
+        case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st, at);
+        case 3: return launch_igemm<128, 64, 2, 2>(p, kmode, ns, st, at);
+        default: return launch_igemm<64, 64, 2, 2>(p, kmode, ns, st, at);
     }
 }
 
@@ -1327,20 +1398,20 @@ static int resolve_cfg(int M_total, int Cd, int tile_hint) {
     return cfg;
 }
 
-static int igemm_run_one(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
-                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out) {
+                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at) {
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.stats = stats; p.stat_rows = stat_rows; p.stat_row0 = stat_row0; p.launch_rows = 0;
     p.ksplit = 1; p.kt_per = 0;
-    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * 4);
+    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * dbn_esize(at));
     if (!(mode == 1 && stride > 1)) {
         p.ncls = 1;
         if (ksplit <= 1) {
-            const int rc = igemm_dispatch(p, mode, ns, cfg, st);
+            const int rc = igemm_dispatch(p, mode, ns, cfg, st, at);
             *rows_out = p.launch_rows;
             return rc;
         }
@@ -1350,12 +1421,12 @@ static int igemm_run_one(const float* src, const float* wpk, const float* bias, 
         p.kt_per = dbn_ceil_div(KT, ksplit);
         p.ksplit = dbn_ceil_div(KT, p.kt_per);
         p.dst = slab; p.bias = nullptr; p.accumulate = 0;
-        const int rc = igemm_dispatch(p, mode, ns, cfg, st);
+        const int rc = igemm_dispatch(p, mode, ns, cfg, st, at);
         *rows_out = p.launch_rows;
         if (rc) return rc;
         const long total4 = (long)N * Hd * Wd * Cd / 4;
-        hipLaunchKernelGGL(splitk_sum_kernel, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit, total4, Cd, bias, accumulate,
-                           dst);
+        DBN_DISPATCH_AT(at, hipLaunchKernelGGL(splitk_sum_kernel<AT>, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit, total4, Cd,
+                                               bias, accumulate, dst));
         return dbn_status();
     }
     DBN_REQUIRE(ksplit <= 1);
@@ -1372,12 +1443,12 @@ static int igemm_run_one(const float* src, const float* wpk, const float* bias, 
     DBN_REQUIRE(off < (1L << 31));
     DBN_REQUIRE(covered == p.ncls || !bias);  // a bias would have to reach the tap-less pixels too
     if (covered < p.ncls && !accumulate) {  // some output pixels receive no tap: they are zero
-        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * sizeof(float), st) != hipSuccess) return dbn_status();
+        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * dbn_esize(at), st) != hipSuccess) return dbn_status();
         p.accumulate = 1;
     }
     *rows_out = 0;
     if (covered == 0) return DBN_OK;
-    const int rc = igemm_dispatch(p, 2, ns, cfg, st);
+    const int rc = igemm_dispatch(p, 2, ns, cfg, st, at);
     *rows_out = p.launch_rows;
     return rc;
 }
@@ -1395,16 +1466,18 @@ static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg
     return rows;
 }
 
-static int igemm_run(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+static int igemm_run(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0) {
+                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0));  // 16-bit storage: 8-channel pieces of 16-channel blocks
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
     DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
     DBN_REQUIRE(tile_hint >= 0 && tile_hint <= 4);
     hipStream_t st = (hipStream_t)stream;
-    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * 4, (long)Hd * Wd * Cd);
+    const int es = dbn_esize(at);
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * es, (long)Hd * Wd * Cd);
     DBN_REQUIRE(nmax >= 1);               // one image must fit the kernel's index ranges
     DBN_REQUIRE(nmax >= N || ksplit <= 1);  // split-K is for small outputs only
     const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
@@ -1412,12 +1485,22 @@ static int igemm_run(const float* src, const float* wpk, const float* bias, floa
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
         int rows = 0;
-        const int rc = igemm_run_one(src + (long)n0 * Hs * Ws * Cs, wpk, bias, dst + (long)n0 * Hd * Wd * Cd, n, Hs, Ws, Cs, Hd, Wd, Cd,
-                                     R, S, stride, pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows);
+        const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
+                                     reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * es, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
+                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at);
         if (rc) return rc;
         row0 += rows;
     }
     return DBN_OK;
+}
+
+// General form.  at: activation storage type of src / dst (DBN_AT_*; 16-bit storage needs ns = 1 and Cs % 16 == 0, panels from
+// dbn_pack_weights_t with kind 1 (bf16) / 2 (fp16)).  ns: matrix math (0, 1, 3).  ksplit > 1: split-K with `slab` scratch.
+int dbn_igemm_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ksplit, float* slab,
+                void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr,
+                     ksplit < 1 ? 1 : ksplit, slab, 0, at);
 }
 
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -1426,8 +1509,8 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
 }
 
 // Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32); follows igemm_run's chunking
-static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint) {
-    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * 4, (long)Hd * Wd * Cd);
+static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint, int at = 0) {
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * dbn_esize(at), (long)Hd * Wd * Cd);
     if (nmax < 1) return 0;
     const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
     int rows = 0;
@@ -1449,19 +1532,28 @@ long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) 
 // Convolution (dbn_igemm_f32 / _bf16s contract; ns = 0, 1, 3) whose epilogue also accumulates the train-mode
 // BatchNorm statistics of its output, followed by the finalize kernel: replaces conv -> separate statistics pass.
 // Outputs like dbn_bn_train_stats.  ws: dbn_conv_bn_ws_floats(...) floats.
-int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
-                    int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
-                    float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                  int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                  const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                  float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
-    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint);
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at);
     DBN_REQUIRE(rows > 0);
+    // (16-bit storage: the statistics are those of the fp32 accumulators, i.e. of the values BEFORE they are rounded for storage)
     const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,
-                             1, nullptr, rows);
+                             1, nullptr, rows, at);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
+}
+
+int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                    int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                    float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_conv_bn_t(0, src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, gamma, beta,
+                         eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
 }
 
 // Same contract as dbn_igemm_f32 with the products evaluated on the bf16 matrix pipe: ns = 3 fp32-accurate
@@ -1507,46 +1599,48 @@ int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
 // ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
-static int pyramid_chunk(int N, int H, int W, int Cs, int Cd) {
-    return chunk_images(N, (long)H * W, (long)H * W * Cs * 4, (long)H * W * Cd);
+static int pyramid_chunk(int N, int H, int W, int Cs, int Cd, int at = 0) {
+    return chunk_images(N, (long)H * W, (long)H * W * Cs * dbn_esize(at), (long)H * W * Cd);
 }
 static int pyramid_rows_one(int n, int H, int W) { return 64 * dbn_ceil_div((long)n * (H >> 3) * (W >> 3), 128); }
 
 long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * N * pyramid_rows_one(1, H, W); }
 
-int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
-                         const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
-                         int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
-                         float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,
+                       const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
+                       int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                       float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1));
+    const int es = dbn_esize(at);
     DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
     DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
     const bool bn = gamma != nullptr;
     DBN_REQUIRE(!bn || (beta && scale && shift && save_mean && save_rstd && ws));
-    const int nmax = pyramid_chunk(N, H, W, Cs, Cd);  // images per launch (24-bit pixel indices, 32-bit offsets)
+    const int nmax = pyramid_chunk(N, H, W, Cs, Cd, at);  // images per launch (24-bit pixel indices, 32-bit offsets)
     DBN_REQUIRE(nmax >= 1);
     int rows_total = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) rows_total += pyramid_rows_one(std::min(nmax, N - n0), H, W);
     hipStream_t st = (hipStream_t)stream;
-    const float* srcs[4] = {s0, s1, s2, s3};
+    const char* srcs[4] = {(const char*)s0, (const char*)s1, (const char*)s2, (const char*)s3};
     const float* wpks[4] = {w0, w1, w2, w3};
     int row0 = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
         IgemmParams p;
         for (int g = 0; g < 4; ++g) {
-            p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs;
+            p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs * es;
             p.seg_wpk[g] = wpks[g];
-            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * 4);
+            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * es);
         }
-        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = dst + (long)n0 * H * W * Cd;
+        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * es;
         p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
         p.ksplit = 1; p.kt_per = 0;
         p.src_bytes = p.seg_bytes[0];
-        const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st);
+        const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st, at);
         if (rc) return rc;
         row0 += p.launch_rows;
     }
@@ -1556,10 +1650,18 @@ int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, cons
     return dbn_status();
 }
 
+int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
+                         const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                         int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                         float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_pyramid_conv_t(0, s0, s1, s2, s3, w0, w1, w2, w3, bias, dst, N, H, W, Cs, Cd, tile_hint, ns, gamma, beta, eps, momentum,
+                              run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
+}
+
 // Floats of the weight panels for (mode, stride): mode 0 and mode 1/stride 1 -> one panel;
 // mode 1/stride f -> f*f parity-class panels back to back.
-static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, int ns) {
-    if (mode == 0) return panel_floats(R * S * ((I + 3) / 4 * 4), O, ns);
+static long panel_floats_all(int O, int I, int R, int S, int mode, int stride, int ns, int cs = 0) {
+    if (mode == 0) return panel_floats(R * S * (cs > 0 ? cs : (I + 3) / 4 * 4), O, ns);
     if (stride == 1) return panel_floats(R * S * O, I, ns);
     long tot = 0;
     for (int c = 0; c < stride * stride; ++c)
@@ -1571,11 +1673,18 @@ long dbn_igemm_panel_floats(int O, int I, int R, int S, int mode, int stride) { 
 long dbn_igemm_bf16s_panel_floats(int O, int I, int R, int S, int mode, int stride, int ns) {
     return panel_floats_all(O, I, R, S, mode, stride, ns);
 }
+// kind: 0 fp32, 1 bf16, 3 bf16x3, 2 fp16 (sized like kind 1).  cs: channels of the source tensor for mode 0 (0: I rounded up
+// to 4; the 16-bit stem input is stored with 16 channels).
+long dbn_igemm_panel_floats_t(int kind, int O, int I, int R, int S, int mode, int stride, int cs) {
+    return panel_floats_all(O, I, R, S, mode, stride, kind == 2 ? 1 : kind, cs);
+}
 
-static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream) {
+static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream, int cs = 0,
+                    int f16 = 0) {
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1));
     DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
-    const int Cs = (mode == 0) ? ((I + 3) / 4) * 4 : O;
+    DBN_REQUIRE(cs == 0 || (mode == 0 && cs >= I && cs % 4 == 0));
+    const int Cs = (mode == 0) ? (cs > 0 ? cs : ((I + 3) / 4) * 4) : O;
     const int Cd = (mode == 0) ? O : I;
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0);
     hipStream_t st = (hipStream_t)stream;
@@ -1587,19 +1696,26 @@ static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, i
     if (ns == 0)
         hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, out);
     else
-        hipLaunchKernelGGL(pack_weights_bf16s_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, ns,
+        hipLaunchKernelGGL(pack_weights_bf16s_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, ns, f16,
                            reinterpret_cast<unsigned short*>(out));
     return dbn_status();
+}
+
+int dbn_pack_weights_t(int kind, const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int cs, float* out, void* stream) {
+    DBN_REQUIRE(kind == 0 || kind == 1 || kind == 2 || kind == 3);
+    return pack_run(w_oihw, O, I, R, S, mode, stride, kind == 2 ? 1 : kind, out, stream, cs, kind == 2);
 }
 
 // Every weight panel of a model in one launch.  jobs: DEVICE array of n records {const float* w; void* out; int O, I, R, S,
 // mode, Cs, Cd, f;} (two pointers + eight ints, 48 bytes; Cs/Cd/f as dbn_pack_weights derives them: Cs = mode 0 ? I rounded
 // up to 4 : O, Cd = mode 0 ? O : I, f = (mode 1 and stride > 1) ? stride : 1).  ns = 0: fp32 panels, 1 / 3: split-bf16.
-int dbn_pack_weights_batched(const void* jobs, int n, int ns, void* stream) {
-    DBN_REQUIRE(jobs && n > 0 && (ns == 0 || ns == 1 || ns == 3));
+int dbn_pack_weights_batched(const void* jobs, int n, int ns, void* stream) {  // ns: panel kind (0 fp32, 1 bf16, 3 bf16x3, 2 fp16)
+    DBN_REQUIRE(jobs && n > 0 && (ns == 0 || ns == 1 || ns == 2 || ns == 3));
     const dim3 grid(48, n);
     if (ns == 0)
         hipLaunchKernelGGL(pack_many_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), 0);
+    else if (ns == 2)
+        hipLaunchKernelGGL(pack_many_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), 1);
     else
         hipLaunchKernelGGL(pack_many_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), ns);
     return dbn_status();
@@ -1664,11 +1780,11 @@ static int wgrad_splitk_one(int n, int Ho, int Wo, int O, int Cb, int R, int S) 
 }
 
 // images per launch: 24-bit pixel indices, 32-bit byte offsets into dY and X
-static int wgrad_chunk(int N, int Ho, int Wo, int O, int H, int W, int Cb) {
+static int wgrad_chunk(int N, int Ho, int Wo, int O, int H, int W, int Cb, int at = 0) {
     long n = N;
     const long px = (long)Ho * Wo;
     if (px * n >= g_pixel_limit - 64) n = (g_pixel_limit - 65) / px;
-    return (int)std::min<long>(n, chunk_images(N, 0, px * O * 4, 0, (long)H * W * Cb * 4));
+    return (int)std::min<long>(n, chunk_images(N, 0, px * O * dbn_esize(at), 0, (long)H * W * Cb * dbn_esize(at)));
 }
 
 // Number of pixel splits (slabs) dbn_wgrad_f32 will use, over all its launches.
@@ -1697,11 +1813,15 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return splits * O * Jp;
 }
 
-static int wgrad_run(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
-                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream) {
-    DBN_REQUIRE(sm && big && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3));
+static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0) {
+    DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(at == 0 || (at == 1 && ns == 1));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
-    const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb);
+    const char* sm = reinterpret_cast<const char*>(sm_);
+    const char* big = reinterpret_cast<const char*>(big_);
+    const int es = dbn_esize(at);
+    const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb, at);
     DBN_REQUIRE(nmax >= 1);
     hipStream_t st = (hipStream_t)stream;
     int bm, bn;
@@ -1713,32 +1833,33 @@ static int wgrad_run(const float* sm, const float* big, float* slab, float* grad
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
         WgradParams p;
-        p.sm = sm + (long)n0 * Ho * Wo * O; p.big = big + (long)n0 * H * W * Cb;
+        p.sm = sm + (long)n0 * Ho * Wo * O * es; p.big = big + (long)n0 * H * W * Cb * es;
         p.slab = slab + (long)splits_total * O * Jp;
         p.N = n; p.Ho = Ho; p.Wo = Wo; p.O = O; p.H = H; p.W = W; p.Cb = Cb; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
         p.P = n * Ho * Wo;
         p.J = J;
         p.rcp_HWo = 1.0f / (float)(Ho * Wo);
         p.rcp_Wo = 1.0f / (float)Wo;
-        p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * 4);
-        p.big_bytes = (unsigned)((long)n * H * W * Cb * 4);
+        p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * es);
+        p.big_bytes = (unsigned)((long)n * H * W * Cb * es);
         const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);
         p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
         dim3 grid((O / bm) * njt * splitk);
-#define DBN_WGRAD_LAUNCH(NS_)                                                                             \
+#define DBN_WGRAD_LAUNCH(NS_, AT_)                                                                            \
     do {                                                                                                    \
         if (bn == 192)                                                                                      \
-            hipLaunchKernelGGL((wgrad_f32_kernel<64, 192, 2, 2, NS_>), grid, dim3(256), 0, st, p);          \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 192, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);     \
         else if (bm == 128 && bn == 128)                                                                    \
-            hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);         \
+            hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);    \
         else if (bn == 128)                                                                                 \
-            hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS_>), grid, dim3(256), 0, st, p);          \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);     \
         else                                                                                                \
-            hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_>), grid, dim3(256), 0, st, p);           \
+            hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);      \
     } while (0)
-        if (ns == 0) DBN_WGRAD_LAUNCH(0);
-        else if (ns == 1) DBN_WGRAD_LAUNCH(1);
-        else DBN_WGRAD_LAUNCH(3);
+        if (at == 1) DBN_WGRAD_LAUNCH(1, 1);
+        else if (ns == 0) DBN_WGRAD_LAUNCH(0, 0);
+        else if (ns == 1) DBN_WGRAD_LAUNCH(1, 0);
+        else DBN_WGRAD_LAUNCH(3, 0);
 #undef DBN_WGRAD_LAUNCH
         const int rc = dbn_status();
         if (rc) return rc;
@@ -1765,6 +1886,12 @@ int dbn_set_index_limits(long pixel_rows, long bytes, long elems) {
     g_byte_limit = bytes > 0 ? bytes : 0xF0000000L;
     g_elem_limit = elems > 0 ? elems : (1L << 32);
     return DBN_OK;
+}
+
+// General form: at = activation type of sm / big (0 fp32; 1 bf16, needs ns = 1), ns = matrix math.
+int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
+    return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, stream, at);
 }
 
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

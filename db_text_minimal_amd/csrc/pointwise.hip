@@ -53,11 +53,13 @@ __device__ __forceinline__ void channel_reduce(int M, int Cfull, float* __restri
     }
 }
 
-__global__ void bn_stats_kernel(const float* __restrict__ y, int M, int C, float* __restrict__ part) {
+template <int AT>
+__global__ void bn_stats_kernel(const void* __restrict__ y, int M, int C, float* __restrict__ part) {
     // shifted sums around the first row (pivot) to avoid E[x^2]-E[x]^2 cancellation
+    const int c4n = C >> 2;
     channel_reduce<2>(M, C, part, [&](int r, int c4, f32x4* acc) {
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(y + 4 * c4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y + (long)r * C + 4 * c4) - pv;
+        const f32x4 pv = dbn_ld4<AT>(y, c4);
+        const f32x4 v = dbn_ld4<AT>(y, (long)r * c4n + c4) - pv;
         acc[0] += v;
         acc[1] += v * v;
     });
@@ -65,7 +67,8 @@ __global__ void bn_stats_kernel(const float* __restrict__ y, int M, int C, float
 
 // out: scale = gamma*rstd, shift = beta - mean*scale, saved mean / rstd; running stats
 // updated in place like F.batch_norm(training=True, momentum) does (unbiased var).
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const float* __restrict__ y, int M, int C,
+template <int AT>
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const void* __restrict__ y, int M, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -76,7 +79,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nb, const
     const double s1 = dbn_team32_fold(part, nb, c, l32);
     const double s2 = dbn_team32_fold(part, nb, (long)C + c, l32);
     if (l32 != 0) return;
-    const double pv = (double)y[c];
+    const double pv = (double)dbn_ld1<AT>(y, c);
     const double dm = s1 / M;
     const double mean = pv + dm;
     double var = s2 / M - dm * dm;
@@ -108,10 +111,11 @@ __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, cons
 }
 
 // out = act(y*sc+sh [+ res*rsc+rsh | + res])
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ sc,
-                                                       const float* __restrict__ sh, const float* __restrict__ res,
+template <int AT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ y, const float* __restrict__ sc,
+                                                       const float* __restrict__ sh, const void* __restrict__ res,
                                                        const float* __restrict__ rsc, const float* __restrict__ rsh,
-                                                       float* __restrict__ out, long total4, int C, int relu) {
+                                                       void* __restrict__ out, long total4, int C, int relu) {
     const int c4n = C >> 2;
     // the grid stride is a multiple of C/4 (host side), so a thread keeps its channel quad: per-channel coefficients are
     // loaded once, and no 64-bit modulo sits in the streaming loop
@@ -125,9 +129,6 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         s2 = *reinterpret_cast<const f32x4*>(rsc + c);
         h2 = *reinterpret_cast<const f32x4*>(rsh + c);
     }
-    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
-    f32x4* o4 = reinterpret_cast<f32x4*>(out);
     auto one = [&](f32x4 v, f32x4 r) {
         f32x4 o;
 #pragma unroll
@@ -150,28 +151,30 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // UNROLL (x2 with a residual) loads in flight per lane
         f32x4 v[UNROLL], r[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = y4[i + u * stride];
+        for (int u = 0; u < UNROLL; ++u) v[u] = dbn_ld4<AT>(y, i + u * stride);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) r[u] = res ? r4[i + u * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UNROLL; ++u) r[u] = res ? dbn_ld4<AT>(res, i + u * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) o4[i + u * stride] = one(v[u], r[u]);
+        for (int u = 0; u < UNROLL; ++u) dbn_st4<AT>(out, i + u * stride, one(v[u], r[u]));
     }
-    for (; i < total4; i += stride) o4[i] = one(y4[i], res ? r4[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+    for (; i < total4; i += stride) dbn_st4<AT>(out, i, one(dbn_ld4<AT>(y, i), res ? dbn_ld4<AT>(res, i) : f32x4{0.f, 0.f, 0.f, 0.f}));
 }
 
 // backward reductions: g = dout * (zmask > 0);  sums of g and g*xhat
 // ReLU mask of g: from a saved activation (zmask), or recomputed from y with the forward's own
 // scale/shift (msc/msh; bit-identical to the forward because both use dbn_affine), or none.
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ zmask, const float* __restrict__ msc,
-                                     const float* __restrict__ msh, const float* __restrict__ dout,
+template <int AT>
+__global__ void bn_bwd_reduce_kernel(const void* __restrict__ y, const void* __restrict__ zmask, const float* __restrict__ msc,
+                                     const float* __restrict__ msh, const void* __restrict__ dout,
                                      const float* __restrict__ mean, const float* __restrict__ rstd, int M, int C,
                                      float* __restrict__ part) {
+    const int c4n = C >> 2;
     channel_reduce<2>(M, C, part, [&](int r, int c4, f32x4* acc) {
-        const long off = (long)r * C + 4 * c4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dout + off);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(y + off);
+        const long off = (long)r * c4n + c4;
+        f32x4 g = dbn_ld4<AT>(dout, off);
+        const f32x4 v = dbn_ld4<AT>(y, off);
         if (zmask) {
-            const f32x4 z = *reinterpret_cast<const f32x4*>(zmask + off);
+            const f32x4 z = dbn_ld4<AT>(zmask, off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
         } else if (msc) {
@@ -207,12 +210,13 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, i
 // bias_part (optional, needs 256 % (C/4) == 0): per-block column sums of dy, [C][gridDim.x] — the gradient of the bias of the
 // conv that feeds this BatchNorm (analytically zero; the reference's value is the round-off of exactly this sum), so that no
 // separate pass re-reads dy for it.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ zmask,
+template <int AT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ y, const void* __restrict__ zmask,
                                                            const float* __restrict__ msc, const float* __restrict__ msh,
-                                                           const float* __restrict__ dout, const float* __restrict__ mean,
+                                                           const void* __restrict__ dout, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,
-                                                           float* __restrict__ dy, float* __restrict__ gout, int gout_acc,
+                                                           void* __restrict__ dy, void* __restrict__ gout, int gout_acc,
                                                            long total4, int C, float* __restrict__ bias_part) {
     const int c4n = C >> 2;
     const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -229,11 +233,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
     const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
     const f32x4 gr = ga * rs;
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dout);
-    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-    const f32x4* z4 = reinterpret_cast<const f32x4*>(zmask);
-    f32x4* dy4 = reinterpret_cast<f32x4*>(dy);
-    f32x4* g4 = reinterpret_cast<f32x4*>(gout);
     const bool acc = gout && gout_acc;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 bsum = zero;
@@ -247,27 +246,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         }
         const f32x4 xh = (v - mu) * rs;
         const f32x4 d = gr * (g - k1 - xh * k2);
-        dy4[i] = d;
+        dbn_st4<AT>(dy, i, d);
         bsum += d;
-        if (gout) g4[i] = acc ? g + old : g;
+        if (gout) dbn_st4<AT>(gout, i, acc ? g + old : g);
     };
     long i = i0;
     for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // 2..4 x UNROLL independent loads in flight per lane
         f32x4 g[UNROLL], v[UNROLL], z[UNROLL], o[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            g[u] = d4[i + u * stride];
-            v[u] = y4[i + u * stride];
+            g[u] = dbn_ld4<AT>(dout, i + u * stride);
+            v[u] = dbn_ld4<AT>(y, i + u * stride);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            z[u] = zmask ? z4[i + u * stride] : zero;
-            o[u] = acc ? g4[i + u * stride] : zero;
+            z[u] = zmask ? dbn_ld4<AT>(zmask, i + u * stride) : zero;
+            o[u] = acc ? dbn_ld4<AT>(gout, i + u * stride) : zero;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) one(i + u * stride, g[u], v[u], z[u], o[u]);
     }
-    for (; i < total4; i += stride) one(i, d4[i], y4[i], zmask ? z4[i] : zero, acc ? g4[i] : zero);
+    for (; i < total4; i += stride)
+        one(i, dbn_ld4<AT>(dout, i), dbn_ld4<AT>(y, i), zmask ? dbn_ld4<AT>(zmask, i) : zero, acc ? dbn_ld4<AT>(gout, i) : zero);
     if (bias_part) {  // threads t, t + C/4, t + 2C/4, ... of the block hold the same channel quad
         __shared__ f32x4 red[256];
         red[threadIdx.x] = bsum;
@@ -283,8 +283,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // generic column sum [M][C] -> part (NV=1)
-__global__ void col_sum_kernel(const float* __restrict__ x, int M, int C, float* __restrict__ part) {
-    channel_reduce<1>(M, C, part, [&](int r, int c4, f32x4* acc) { acc[0] += *reinterpret_cast<const f32x4*>(x + (long)r * C + 4 * c4); });
+template <int AT>
+__global__ void col_sum_kernel(const void* __restrict__ x, int M, int C, float* __restrict__ part) {
+    const int c4n = C >> 2;
+    channel_reduce<1>(M, C, part, [&](int r, int c4, f32x4* acc) { acc[0] += dbn_ld4<AT>(x, (long)r * c4n + c4); });
 }
 
 __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int n, float* __restrict__ out, float scale) {
@@ -298,8 +300,9 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int
 // ----------------------------------------------------------------------------------
 // stem: relu(bn(y)) -> maxpool 3x3 s2 p1, forward and backward
 // ----------------------------------------------------------------------------------
-__global__ void bnrelu_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
-                                          float* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
+template <int AT>
+__global__ void bnrelu_maxpool_fwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          void* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
     const int c4n = C >> 2;
     const long total = (long)N * Ho * Wo * c4n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -318,19 +321,27 @@ __global__ void bnrelu_maxpool_fwd_kernel(const float* __restrict__ y, const flo
             for (int q = 0; q < 3; ++q) {
                 const int iw = ow * 2 - 1 + q;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(y + (((long)n * H + ih) * W + iw) * C + c);
+                const f32x4 v = dbn_ld4<AT>(y, (((long)n * H + ih) * W + iw) * c4n + (c >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], dbn_affine_relu(v[e], s[e], h[e]));
             }
         }
-        reinterpret_cast<f32x4*>(out)[i] = m;
+        dbn_st4<AT>(out, i, m);
     }
 }
 
 // dz[n,ih,iw,c] = [z>0] * sum over windows containing (ih,iw) whose max equals z of dpool
-__global__ void bnrelu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
-                                          const float* __restrict__ pooled, const float* __restrict__ dpool,
-                                          float* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo) {
+// 16-bit storage: the pooled value is the ROUNDED maximum, so equality is tested on the rounded activation
+template <int AT>
+__device__ __forceinline__ float round_to_storage(float v) {
+    if constexpr (AT == 1) return (float)(__bf16)v;
+    else if constexpr (AT == 2) return (float)(_Float16)v;
+    else return v;
+}
+template <int AT>
+__global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                          const void* __restrict__ pooled, const void* __restrict__ dpool,
+                                          void* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo) {
     const int c4n = C >> 2;
     const long total = (long)N * H * W * c4n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -342,24 +353,24 @@ __global__ void bnrelu_maxpool_bwd_kernel(const float* __restrict__ y, const flo
         const int n = (int)(t / H);
         const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
         const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
-        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 v = dbn_ld4<AT>(y, i);
         f32x4 z;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = dbn_affine_relu(v[e], s[e], h[e]);
+        for (int e = 0; e < 4; ++e) z[e] = round_to_storage<AT>(dbn_affine_relu(v[e], s[e], h[e]));
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // windows oh with oh*2-1 <= ih <= oh*2+1
         const int oh_lo = max(0, (ih) / 2), oh_hi = min(Ho - 1, (ih + 1) / 2);
         const int ow_lo = max(0, (iw) / 2), ow_hi = min(Wo - 1, (iw + 1) / 2);
         for (int oh = oh_lo; oh <= oh_hi; ++oh)
             for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
-                const f32x4 pm = *reinterpret_cast<const f32x4*>(pooled + o);
-                const f32x4 dp = *reinterpret_cast<const f32x4*>(dpool + o);
+                const long o = (((long)n * Ho + oh) * Wo + ow) * c4n + (c >> 2);
+                const f32x4 pm = dbn_ld4<AT>(pooled, o);
+                const f32x4 dp = dbn_ld4<AT>(dpool, o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (z[e] > 0.f && z[e] == pm[e]) g[e] += dp[e];
             }
-        reinterpret_cast<f32x4*>(dz)[i] = g;
+        dbn_st4<AT>(dz, i, g);
     }
 }
 
@@ -373,7 +384,8 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
 }
 
 // dst[n,h,w,coff+c] = src[n,nh,nw,c] (+ addend[n,h,w,c])
-__global__ void nearest_up_fwd_kernel(const float* __restrict__ src, const float* __restrict__ addend, float* __restrict__ dst,
+template <int AT>
+__global__ void nearest_up_fwd_kernel(const void* __restrict__ src, const void* __restrict__ addend, void* __restrict__ dst,
                                       int N, int Hs, int Ws, int C, int H, int W, int Cdst, int coff) {
     const int c4n = C >> 2;
     const long total = (long)N * H * W * c4n;
@@ -385,14 +397,15 @@ __global__ void nearest_up_fwd_kernel(const float* __restrict__ src, const float
         const int h = (int)(t % H);
         const int n = (int)(t / H);
         const int sh_ = nearest_src(h, Hs, H), sw_ = nearest_src(w, Ws, W);
-        f32x4 v = *reinterpret_cast<const f32x4*>(src + (((long)n * Hs + sh_) * Ws + sw_) * C + c);
-        if (addend) v += *reinterpret_cast<const f32x4*>(addend + (((long)n * H + h) * W + w) * C + c);
-        *reinterpret_cast<f32x4*>(dst + (((long)n * H + h) * W + w) * Cdst + coff + c) = v;
+        f32x4 v = dbn_ld4<AT>(src, ((((long)n * Hs + sh_) * Ws + sw_) * C + c) >> 2);
+        if (addend) v += dbn_ld4<AT>(addend, ((((long)n * H + h) * W + w) * C + c) >> 2);
+        dbn_st4<AT>(dst, ((((long)n * H + h) * W + w) * Cdst + coff + c) >> 2, v);
     }
 }
 
 // dsrc[n,hs,ws,c] (+)= sum over (h,w) mapping to (hs,ws) of dbig[n,h,w,coff+c]
-__global__ void nearest_up_bwd_kernel(const float* __restrict__ dbig, float* __restrict__ dsrc, int N, int Hs, int Ws, int C,
+template <int AT>
+__global__ void nearest_up_bwd_kernel(const void* __restrict__ dbig, void* __restrict__ dsrc, int N, int Hs, int Ws, int C,
                                       int H, int W, int Cbig, int coff, int accumulate) {
     const int c4n = C >> 2;
     const long total = (long)N * Hs * Ws * c4n;
@@ -413,12 +426,11 @@ __global__ void nearest_up_bwd_kernel(const float* __restrict__ dbig, float* __r
             if (nearest_src(h, Hs, H) != hs) continue;
             for (int w = w0; w <= w1; ++w) {
                 if (nearest_src(w, Ws, W) != ws) continue;
-                g += *reinterpret_cast<const f32x4*>(dbig + (((long)n * H + h) * W + w) * Cbig + coff + c);
+                g += dbn_ld4<AT>(dbig, ((((long)n * H + h) * W + w) * Cbig + coff + c) >> 2);
             }
         }
-        f32x4* d = reinterpret_cast<f32x4*>(dsrc) + i;
-        if (accumulate) g += *d;
-        *d = g;
+        if (accumulate) g += dbn_ld4<AT>(dsrc, i);
+        dbn_st4<AT>(dsrc, i, g);
     }
 }
 
@@ -536,19 +548,31 @@ __global__ void fpn_scatter_wgrad_kernel(const float* __restrict__ t0, const flo
     }
 }
 
-// [N,3,H,W] -> [N,H,W,4] (4th channel zero)
-__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ out, int N, long HW) {
+// [N,3,H,W] fp32 -> [N,H,W,4] (4th channel zero); 16-bit storage: [N,H,W,16] (channels 3..15 zero — the MFMA gather of the
+// 16-bit path fetches 8-channel pieces of 16-channel blocks)
+template <int AT>
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, void* __restrict__ out, int N, long HW) {
     const long total = (long)N * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long n = i / HW, p = i - n * HW;
         const float* b = x + n * 3 * HW + p;
-        reinterpret_cast<f32x4*>(out)[i] = f32x4{b[0], b[HW], b[2 * HW], 0.f};
+        const f32x4 v = {b[0], b[HW], b[2 * HW], 0.f};
+        if constexpr (AT == 0) {
+            dbn_st4<0>(out, i, v);
+        } else {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dbn_st4<AT>(out, 4 * i, v);
+            dbn_st4<AT>(out, 4 * i + 1, z);
+            dbn_st4<AT>(out, 4 * i + 2, z);
+            dbn_st4<AT>(out, 4 * i + 3, z);
+        }
     }
 }
 
-__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long total4) {
+template <int AT>
+__global__ void axpy_kernel(const void* __restrict__ x, void* __restrict__ y, long total4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
-        reinterpret_cast<f32x4*>(y)[i] += reinterpret_cast<const f32x4*>(x)[i];
+        dbn_st4<AT>(y, i, dbn_ld4<AT>(y, i) + dbn_ld4<AT>(x, i));
 }
 
 // ----------------------------------------------------------------------------------
@@ -612,20 +636,31 @@ inline size_t red_smem(int Cfull, int nv) {
 
 extern "C" {
 
+// Entry points come in two forms: `dbn_x(...)` with fp32 activation tensors (the contract of BASELINE configs[1]) and
+// `dbn_x_t(at, ...)` with the activation storage type first (DBN_AT_F32 / _BF16 / _F16): tensors marked `void*` are stored
+// in that type, everything `float*` (coefficients, statistics, partial sums, gradients of parameters) stays fp32.
+
 // floats of scratch needed by the per-channel reduction entry points below
 int dbn_reduce_ws_floats(int C) { return MAX_PART * 2 * C; }
 
-int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
-                       float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
-                       float* ws, void* stream) {
+int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                         float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                         float* ws, void* stream) {
     DBN_REQUIRE(y && gamma && beta && scale && shift && save_mean && save_rstd && ws);
     DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
-    hipLaunchKernelGGL(bn_stats_kernel, red_grid(nb, C), dim3(256), red_smem(C, 2), st, y, M, C, ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, y, M, C, gamma, beta, eps,
-                       momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    DBN_DISPATCH_AT(at, {
+        hipLaunchKernelGGL(bn_stats_kernel<AT>, red_grid(nb, C), dim3(256), red_smem(C, 2), st, y, M, C, ws);
+        hipLaunchKernelGGL(bn_finalize_kernel<AT>, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, y, M, C, gamma, beta, eps,
+                           momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    });
     return dbn_status();
+}
+int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                       float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                       float* ws, void* stream) {
+    return dbn_bn_train_stats_t(0, y, M, C, gamma, beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
 }
 
 int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
@@ -636,20 +671,27 @@ int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* 
     return dbn_status();
 }
 
-int dbn_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
-                 const float* res_shift, float* out, long M, int C, int relu, void* stream) {
+int dbn_bn_apply_t(int at, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                   const float* res_shift, void* out, long M, int C, int relu, void* stream) {
     DBN_REQUIRE(y && scale && shift && out && M > 0 && C % 4 == 0);
     DBN_REQUIRE((res_scale == nullptr) == (res_shift == nullptr));
     const long total4 = M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_stream_grid(total4, C)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
-                       res_scale, res_shift, out, total4, C, relu);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bn_apply_kernel<AT>, dim3(bn_stream_grid(total4, C)), dim3(256), 0, (hipStream_t)stream, y,
+                                           scale, shift, res, res_scale, res_shift, out, total4, C, relu));
     return dbn_status();
 }
+int dbn_bn_apply(const float* y, const float* scale, const float* shift, const float* res, const float* res_scale,
+                 const float* res_shift, float* out, long M, int C, int relu, void* stream) {
+    return dbn_bn_apply_t(0, y, scale, shift, res, res_scale, res_shift, out, M, C, relu, stream);
+}
 
-static int bn_backward_impl(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
-                            const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy,
-                            float* gout, int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C,
-                            float grad_scale, float* ws, void* stream) {
+// The general BatchNorm backward.  `sums` optional: [2][C] reductions already produced by the kernel that wrote dout (then
+// only finalize + apply run).  `dbias_conv` optional [C]: column sums of dy (times grad_scale) = gradient of the bias of the
+// convolution that produced y, formed inside the apply pass instead of by a dbn_col_sum pass over dy (needs 256 % (C/4) == 0).
+int dbn_bn_backward_t(int at, const float* sums, const void* y, const void* zmask, const float* mask_scale, const float* mask_shift,
+                      const void* dout, const float* save_mean, const float* save_rstd, const float* gamma, void* dy, void* gout,
+                      int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
+                      void* stream) {
     DBN_REQUIRE(y && dout && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
     DBN_REQUIRE(!dbias_conv || 256 % (C / 4) == 0);
     DBN_REQUIRE(M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
@@ -659,20 +701,22 @@ static int bn_backward_impl(const float* sums, const float* y, const float* zmas
     float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
     float* c2 = c1 + C;
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
-    if (sums) {  // the producer of dout already reduced sum(g) and sum(g * xhat) per channel: [2][C], a single "partial"
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, 1, M, C, dgamma, dbeta, c1, c2,
-                           grad_scale);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale, mask_shift, dout,
-                           save_mean, save_rstd, M, C, ws);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
-                           grad_scale);
-    }
     const long total4 = (long)M * (C / 4);
     const int grid = bn_stream_grid(total4, C);
-    // the reduce partials at the front of ws have been consumed by the finalize kernel: the bias partials [C][grid] reuse them
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd,
-                       gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
+    DBN_DISPATCH_AT(at, {
+        if (sums) {  // a single "partial"
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, 1, M, C, dgamma, dbeta, c1, c2,
+                               grad_scale);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale,
+                               mask_shift, dout, save_mean, save_rstd, M, C, ws);
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nbu, M, C, dgamma, dbeta, c1, c2,
+                               grad_scale);
+        }
+        // the reduce partials at the front of ws have been consumed by the finalize kernel: the bias partials [C][grid] reuse them
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
+                           save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
+    });
     if (dbias_conv)
         hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, grid, C, dbias_conv, grad_scale);
     return dbn_status();
@@ -681,8 +725,8 @@ static int bn_backward_impl(const float* sums, const float* y, const float* zmas
 int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
                     const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout, int gout_accumulate,
                     float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws, void* stream) {
-    return bn_backward_impl(nullptr, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
-                            dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
+    return dbn_bn_backward_t(0, nullptr, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                             dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
 }
 
 // BatchNorm backward whose two per-channel reductions were already produced by the kernel that wrote dout
@@ -692,71 +736,89 @@ int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zm
                               float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale,
                               float* ws, void* stream) {
     DBN_REQUIRE(sums);
-    return bn_backward_impl(sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
-                            dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
+    return dbn_bn_backward_t(0, sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                             dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
 }
 
-// The general form: `sums` optional (as dbn_bn_backward_from_sums), `dbias_conv` optional [C]: column sums of dy (times
-// grad_scale) = gradient of the bias of the convolution that produced y, formed inside the apply pass instead of by a
-// dbn_col_sum pass over dy (needs 256 % (C/4) == 0).
 int dbn_bn_backward_ex(const float* sums, const float* y, const float* zmask, const float* mask_scale, const float* mask_shift,
                        const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout,
                        int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
                        void* stream) {
-    return bn_backward_impl(sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
-                            dgamma, dbeta, dbias_conv, M, C, grad_scale, ws, stream);
+    return dbn_bn_backward_t(0, sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+                             dgamma, dbeta, dbias_conv, M, C, grad_scale, ws, stream);
 }
 
-int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {
+int dbn_col_sum_t(int at, const void* x, int M, int C, float* out, float scale, float* ws, void* stream) {
     DBN_REQUIRE(x && out && ws && M > 0 && C % 4 == 0 && C >= 4 && C <= 4096 && (C <= CHUNK_C || C % CHUNK_C == 0));
     hipStream_t st = (hipStream_t)stream;
     const int nb = part_blocks(M, C);
-    hipLaunchKernelGGL(col_sum_kernel, red_grid(nb, C), dim3(256), red_smem(C, 1), st, x, M, C, ws);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(col_sum_kernel<AT>, red_grid(nb, C), dim3(256), red_smem(C, 1), st, x, M, C, ws));
     hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, nb, C, out, scale);
     return dbn_status();
 }
+int dbn_col_sum(const float* x, int M, int C, float* out, float scale, float* ws, void* stream) {
+    return dbn_col_sum_t(0, x, M, C, out, scale, ws, stream);
+}
 
-int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
-                           void* stream) {
+int dbn_bnrelu_maxpool_fwd_t(int at, const void* y, const float* scale, const float* shift, void* out, int N, int H, int W, int C,
+                             void* stream) {
     DBN_REQUIRE(y && scale && shift && out && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel, dim3(dbn_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel<AT>, dim3(dbn_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+                                           (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo));
     return dbn_status();
 }
+int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shift, float* out, int N, int H, int W, int C,
+                           void* stream) {
+    return dbn_bnrelu_maxpool_fwd_t(0, y, scale, shift, out, N, H, W, C, stream);
+}
 
-int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
-                           float* dz, int N, int H, int W, int C, void* stream) {
+int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const float* shift, const void* pooled, const void* dpool,
+                             void* dz, int N, int H, int W, int C, void* stream) {
     DBN_REQUIRE(y && scale && shift && pooled && dpool && dz && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel<AT>, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0,
+                                           (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo));
     return dbn_status();
 }
+int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
+                           float* dz, int N, int H, int W, int C, void* stream) {
+    return dbn_bnrelu_maxpool_bwd_t(0, y, scale, shift, pooled, dpool, dz, N, H, W, C, stream);
+}
 
-int dbn_nearest_up_fwd(const float* src, const float* addend, float* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
-                       int coff, void* stream) {
+int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
+                         int coff, void* stream) {
     DBN_REQUIRE(src && dst && C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0 && coff + C <= Cdst);
     DBN_REQUIRE(addend == nullptr || (Cdst == C && coff == 0));
-    hipLaunchKernelGGL(nearest_up_fwd_kernel, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, src,
-                       addend, dst, N, Hs, Ws, C, H, W, Cdst, coff);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nearest_up_fwd_kernel<AT>, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0,
+                                           (hipStream_t)stream, src, addend, dst, N, Hs, Ws, C, H, W, Cdst, coff));
     return dbn_status();
 }
+int dbn_nearest_up_fwd(const float* src, const float* addend, float* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
+                       int coff, void* stream) {
+    return dbn_nearest_up_fwd_t(0, src, addend, dst, N, Hs, Ws, C, H, W, Cdst, coff, stream);
+}
 
+int dbn_nearest_up_bwd_t(int at, const void* dbig, void* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
+                         int accumulate, void* stream) {
+    DBN_REQUIRE(dbig && dsrc && C % 4 == 0 && Cbig % 4 == 0 && coff % 4 == 0 && coff + C <= Cbig);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nearest_up_bwd_kernel<AT>, dim3(dbn_grid((long)N * Hs * Ws * (C / 4))), dim3(256), 0,
+                                           (hipStream_t)stream, dbig, dsrc, N, Hs, Ws, C, H, W, Cbig, coff, accumulate));
+    return dbn_status();
+}
 int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
                        int accumulate, void* stream) {
-    DBN_REQUIRE(dbig && dsrc && C % 4 == 0 && Cbig % 4 == 0 && coff % 4 == 0 && coff + C <= Cbig);
-    hipLaunchKernelGGL(nearest_up_bwd_kernel, dim3(dbn_grid((long)N * Hs * Ws * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       dbig, dsrc, N, Hs, Ws, C, H, W, Cbig, coff, accumulate);
-    return dbn_status();
+    return dbn_nearest_up_bwd_t(0, dbig, dsrc, N, Hs, Ws, C, H, W, Cbig, coff, accumulate, stream);
 }
 
-int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) {
+// x: [N,3,H,W] fp32.  out: [N,H,W,4] fp32 (at = 0) or [N,H,W,16] in the 16-bit storage type (channels 3.. zero).
+int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W, void* stream) {
     DBN_REQUIRE(x && out && N > 0);
-    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, N,
-                       (long)H * W);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                                           x, out, N, (long)H * W));
     return dbn_status();
 }
+int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) { return dbn_nchw3_to_nhwc4_t(0, x, out, N, H, W, stream); }
 
 static float bilinear_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
@@ -796,7 +858,7 @@ int dbn_fpn_scatter_wgrad(const float* t0, const float* t1, const float* t2, con
 
 int dbn_add_inplace(const float* x, float* y, long n, void* stream) {
     DBN_REQUIRE(x && y && n % 4 == 0);
-    hipLaunchKernelGGL(axpy_kernel, dim3(dbn_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4);
+    hipLaunchKernelGGL(axpy_kernel<0>, dim3(dbn_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y, n / 4);
     return dbn_status();
 }
 

@@ -39,8 +39,9 @@ def flat_layout(numels):
     return offs, total
 
 
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d>',
-                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d>'}  # rocprof names
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d>'}  # rocprof names
+ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
 class KernelTimer:
@@ -107,7 +108,8 @@ class Engine:
         self._bias_done = set()
         self.prof = None  # optional KernelTimer
         self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
-        self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = bf16 operands
+        self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = one 16-bit plane
+        self.at = 0  # activation storage in HBM: 0 = fp32, 1 = bf16, 2 = fp16 (inference only); see set_conv_math
         # Weight gradients (+ their slab reductions and bias column sums) run on a second HIP stream: they only feed the
         # optimizer, so they are ordered behind the producer of dy and otherwise free.  Two MFMA kernels with different
         # register / LDS footprints co-resident on a CU keep the matrix pipe busier than either alone (occupancy 3 each) and
@@ -161,24 +163,49 @@ class Engine:
             mods[name].num_batches_tracked += cnt
         self.nbt_pending = {}
 
-    MATH_MODES = {'f32': 0, 'bf16x3': 3, 'bf16': 1}
+    MATH_MODES = {'f32': (0, 0), 'bf16x3': (3, 0), 'bf16c': (1, 0), 'bf16': (1, 1), 'fp16': (1, 2)}  # name -> (ns, at)
 
     def set_conv_math(self, mode):
-        """'f32' (default): v_mfma_f32_32x32x2_f32, bit-exact fp32 products.  'bf16x3': fp32 operands split
-        into three bf16 terms, six bf16 MFMAs per product group, fp32 accumulate (fp32-accurate).
-        'bf16': operands rounded to bf16 (BASELINE configs[2] compute mode).  Tensors stay fp32 in HBM."""
-        self.ns = self.MATH_MODES[mode]
+        """Precision mode of the whole path.
+        'f32' (default, BASELINE configs[1]): fp32 tensors, v_mfma_f32_32x32x2_f32 (bit-exact fp32 products).
+        'bf16x3': fp32 tensors, every operand split exactly into three bf16 terms, six bf16 MFMAs per product group, fp32
+                  accumulate (fp32-accurate).
+        'bf16'  (BASELINE configs[2]/[3]): NATIVE bf16 — activations, their gradients and the weight panels are stored in
+                  bf16 in HBM (every HBM-bound kernel moves half the bytes), bf16 MFMA with fp32 accumulation; fp32 master
+                  weights, BatchNorm statistics (taken from the fp32 accumulators), loss sums, weight gradients, Adam state.
+        'fp16'  (BASELINE configs[4]): NATIVE fp16 inference — eval-mode forward only; fp16 activations and weight panels,
+                  v_mfma_f32_32x32x16_f16, fp32 accumulation; the output maps are fp32 (what postprocess.py consumes).
+        'bf16c': the round-1 compute-only mode (fp32 tensors in HBM, operands rounded to bf16 when staged)."""
+        ns, at = self.MATH_MODES[mode]
+        if at != self.at:  # other storage type: every activation buffer and weight panel is stale
+            self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
+            self.saved_generation = -1
+        self.ns, self.at = ns, at
+        self.math_mode = mode
+
+    math_mode = 'f32'
+
+    @property
+    def kind(self):
+        """weight-panel kind: 0 fp32, 1 bf16, 3 bf16x3, 2 fp16"""
+        return 2 if self.at == 2 else self.ns
 
     def mark_params_dirty(self):
         self.param_epoch += 1
 
-    def buf(self, name, *shape):
+    def buf(self, name, *shape, dtype=None):
+        """Persistent ACTIVATION buffer (stored in the engine's activation type)."""
+        dtype = ACT_DTYPES[self.at] if dtype is None else dtype
         t = self.bufs.get(name)
         dev = self.flat.device
-        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
-            t = torch.empty(shape, device=dev, dtype=torch.float32)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != dev or t.dtype != dtype:
+            t = torch.empty(shape, device=dev, dtype=dtype)
             self.bufs[name] = t
         return t
+
+    def fbuf(self, name, *shape):
+        """Persistent fp32 buffer (coefficients, statistics, maps, parameter-shaped temporaries)."""
+        return self.buf(name, *shape, dtype=torch.float32)
 
     def scratch(self, name, numel):
         if self._in_side:  # launches on the side stream run concurrently with the main one: private scratch
@@ -227,44 +254,34 @@ class Engine:
             self._side_used = False
 
     # ------------------------------------------------------------ weight panels
-    def pack(self, name, w, mode, stride=1, version=None):
+    def pack(self, name, w, mode, stride=1, version=None, cs=0):
         """Weight panels of `w` for (mode, stride), cached until `w` changes.  `version` replaces w._version for tensors
-        that are rewritten through raw pointers (the FPN's combined weights)."""
-        ns = self.ns
+        that are rewritten through raw pointers (the FPN's combined weights).  cs: channels of the source tensor (mode 0)."""
+        ns = self.kind
         key = (name, mode, stride, ns)
         ent = self.packs.get(key)
         stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
-        if version is None:  # a parameter (not a derived tensor): remembered for the one-launch repack of later steps
-            self.pack_src[key] = w
         O, I, R, S = w.shape
-        if ns == 0:
-            n = self.L.dbn_igemm_panel_floats(O, I, R, S, mode, stride)
-        else:
-            n = self.L.dbn_igemm_bf16s_panel_floats(O, I, R, S, mode, stride, ns)
+        cs = cs if mode == 0 else 0
+        if version is None:  # a parameter (not a derived tensor): remembered for the one-launch repack of later steps
+            self.pack_src[key] = (w, cs if cs else (I + 3) // 4 * 4)
+        n = self.L.dbn_igemm_panel_floats_t(ns, O, I, R, S, mode, stride, cs)
         out = ent[0] if ent is not None else torch.empty(n, device=w.device, dtype=torch.float32)
-        if ns == 0:
-            check(self.L.dbn_pack_weights(w.data_ptr(), O, I, R, S, mode, stride, out.data_ptr(), self.stream), 'pack_weights')
-        else:
-            check(self.L.dbn_pack_weights_bf16s(w.data_ptr(), O, I, R, S, mode, stride, ns, out.data_ptr(), self.stream),
-                  'pack_weights_bf16s')
+        check(self.L.dbn_pack_weights_t(ns, w.data_ptr(), O, I, R, S, mode, stride, cs, out.data_ptr(), self.stream), 'pack_weights')
         self.packs[key] = (out, stamp)
         return out
 
     def _igemm(self, what, *args):
         """args = the dbn_igemm_f32 argument list without the trailing stream."""
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
+        ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):
             ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
             if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
                 slab = self.scratch('_splitk_slab', ks * N * Hd * Wd * Cd)
-                check(self.L.dbn_igemm_splitk_f32(*args, self.ns, ks, slab.data_ptr(), self.stream), what)
-                return
-        if self.ns == 0:
-            check(self.L.dbn_igemm_f32(*args, self.stream), what)
-        else:
-            check(self.L.dbn_igemm_bf16s(*args, self.ns, self.stream), what)
+        check(self.L.dbn_igemm_t(self.at, self.ns, *args, ks, _p(slab), self.stream), what)
 
     batched_repack = True
 
@@ -273,18 +290,18 @@ class Engine:
         next step (one before each conv's first use), all panels that exist already are rebuilt by ONE launch here."""
         if not self.batched_repack:
             return
-        ns = self.ns
+        ns = self.kind
         stale = []
-        for key, w in self.pack_src.items():
+        for key, (w, cs) in self.pack_src.items():
             if key[3] != ns:
                 continue
             ent = self.packs.get(key)
             stamp = (w._version, self.param_epoch, w.data_ptr())
             if ent is not None and ent[1] != stamp:
-                stale.append((key, w, ent[0], stamp))
+                stale.append((key, w, ent[0], stamp, cs))
         if len(stale) < 8:  # first step (nothing packed yet) or nothing changed: the lazy path handles it
             return
-        sig = tuple((k, w.data_ptr(), out.data_ptr()) for k, w, out, _ in stale)
+        sig = tuple((k, w.data_ptr(), out.data_ptr()) for k, w, out, _, _ in stale)
         if self._pack_jobs is None or self._pack_jobs[0] != sig:
             import ctypes
 
@@ -292,15 +309,15 @@ class Engine:
                 _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + [(f, ctypes.c_int) for f in
                                                                                   ('O', 'I', 'R', 'S', 'mode', 'Cs', 'Cd', 'f')]
             arr = (Job * len(stale))()
-            for i, ((name, mode, stride, _), w, out, _) in enumerate(stale):
+            for i, ((name, mode, stride, _), w, out, _, cs) in enumerate(stale):
                 O, I, R, S = w.shape
-                arr[i] = Job(w.data_ptr(), out.data_ptr(), O, I, R, S, mode, (I + 3) // 4 * 4 if mode == 0 else O,
+                arr[i] = Job(w.data_ptr(), out.data_ptr(), O, I, R, S, mode, cs if mode == 0 else O,
                              O if mode == 0 else I, stride if (mode == 1 and stride > 1) else 1)
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._pack_jobs = (sig, host.to(self.flat.device), len(stale))
         _, table, n = self._pack_jobs
         check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
-        for key, _, out, stamp in stale:
+        for key, _, out, stamp, _ in stale:
             self.packs[key] = (out, stamp)
 
     # ------------------------------------------------------------------ kernels
@@ -308,8 +325,8 @@ class Engine:
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
-        wpk = self.pack(name, conv.weight, 0, version=version)
+        assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
+        wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
             self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
@@ -325,11 +342,11 @@ class Engine:
     def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride, accumulate=0):
         """args: dbn_igemm_f32's arguments up to and including `mode` (without accumulate / tile_hint / stream)."""
         C = y.shape[-1]
-        sc, sh = self.buf(bn_name + '/scale', C), self.buf(bn_name + '/shift', C)
-        mu, rs = self.buf(bn_name + '/mean', C), self.buf(bn_name + '/rstd', C)
+        sc, sh = self.fbuf(bn_name + '/scale', C), self.fbuf(bn_name + '/shift', C)
+        mu, rs = self.fbuf(bn_name + '/mean', C), self.fbuf(bn_name + '/rstd', C)
         N, Hd, Wd = y.shape[0], y.shape[1], y.shape[2]
         ws = self.scratch('_conv_bn_ws', self.L.dbn_conv_bn_ws_floats(N, Hd, Wd, C, mode, stride))
-        check(self.L.dbn_conv_bn_f32(*args, accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+        check(self.L.dbn_conv_bn_t(self.at, *args, accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), what)
         self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
@@ -345,8 +362,8 @@ class Engine:
             y = self.conv_fwd(name, x, conv, out_name, version=version)
             sc, sh = self.bn_coef(bn_name, bn, y, train)
             return y, sc, sh
-        assert C == (conv.cin + 3) // 4 * 4, (name, C, conv.cin)
-        wpk = self.pack(name, conv.weight, 0, version=version)
+        assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
+        wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
             self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
@@ -375,7 +392,7 @@ class Engine:
         return y, sc, sh
 
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
-        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns), flops, 0.0, tag)
+        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns, self.at), flops, 0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None):
         N, Ho, Wo, O = dy.shape
@@ -394,12 +411,8 @@ class Engine:
         slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k))
         if self.prof:
             self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
-        args = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride, pad,
-                self.grad_scale)
-        if self.ns == 0:
-            check(self.L.dbn_wgrad_f32(*args, self.stream), 'wgrad ' + name)
-        else:
-            check(self.L.dbn_wgrad_bf16s(*args, self.ns, self.stream), 'wgrad ' + name)
+        check(self.L.dbn_wgrad_t(self.at, self.ns, sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W,
+                                 Cb, I, k, k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
         if self.prof:
             self.prof.end()
 
@@ -439,16 +452,16 @@ class Engine:
     def col_sum(self, x, out):
         C = x.shape[-1]
         M = x.numel() // C
-        check(self.L.dbn_col_sum(x.data_ptr(), M, C, out.data_ptr(), self.grad_scale, self.reduce_ws().data_ptr(), self.stream),
-              'col_sum')
+        check(self.L.dbn_col_sum_t(self.at, x.data_ptr(), M, C, out.data_ptr(), self.grad_scale, self.reduce_ws().data_ptr(),
+                                   self.stream), 'col_sum')
 
     def bn_coef(self, name, bn, y, train):
         C = y.shape[-1]
         M = y.numel() // C
-        sc, sh = self.buf(name + '/scale', C), self.buf(name + '/shift', C)
+        sc, sh = self.fbuf(name + '/scale', C), self.fbuf(name + '/shift', C)
         if train:
-            mu, rs = self.buf(name + '/mean', C), self.buf(name + '/rstd', C)
-            check(self.L.dbn_bn_train_stats(y.data_ptr(), M, C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+            mu, rs = self.fbuf(name + '/mean', C), self.fbuf(name + '/rstd', C)
+            check(self.L.dbn_bn_train_stats_t(self.at, y.data_ptr(), M, C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                             mu.data_ptr(), rs.data_ptr(), self.reduce_ws().data_ptr(), self.stream),
                   'bn stats ' + name)
@@ -462,8 +475,8 @@ class Engine:
     def bn_apply(self, y, sc, sh, out_name, relu=True, res=None, rsc=None, rsh=None):
         C = y.shape[-1]
         out = self.buf(out_name, *y.shape)
-        check(self.L.dbn_bn_apply(y.data_ptr(), sc.data_ptr(), sh.data_ptr(), _p(res), _p(rsc), _p(rsh), out.data_ptr(),
-                                  y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
+        check(self.L.dbn_bn_apply_t(self.at, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), _p(res), _p(rsc), _p(rsh), out.data_ptr(),
+                                    y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
         return out
 
     bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
@@ -485,7 +498,7 @@ class Engine:
             dbias = self.grad_views[conv_bias]
             self._bias_done.add(conv_bias)
         # sums: [2][C] reductions already produced by the kernel that wrote dout
-        check(self.L.dbn_bn_backward_ex(_p(sums), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
+        check(self.L.dbn_bn_backward_t(self.at, _p(sums), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
                                         self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
                                         self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
                                         self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(),
@@ -496,13 +509,13 @@ class Engine:
     def up_fwd(self, src, addend, dst, coff=0):
         N, Hs, Ws, C = src.shape
         _, H, W, Cd = dst.shape
-        check(self.L.dbn_nearest_up_fwd(src.data_ptr(), _p(addend), dst.data_ptr(), N, Hs, Ws, C, H, W, Cd, coff, self.stream),
+        check(self.L.dbn_nearest_up_fwd_t(self.at, src.data_ptr(), _p(addend), dst.data_ptr(), N, Hs, Ws, C, H, W, Cd, coff, self.stream),
               'nearest_up_fwd')
 
     def up_bwd(self, dbig, dsrc, coff, accumulate):
         N, Hs, Ws, C = dsrc.shape
         _, H, W, Cb = dbig.shape
-        check(self.L.dbn_nearest_up_bwd(dbig.data_ptr(), dsrc.data_ptr(), N, Hs, Ws, C, H, W, Cb, coff, int(accumulate),
+        check(self.L.dbn_nearest_up_bwd_t(self.at, dbig.data_ptr(), dsrc.data_ptr(), N, Hs, Ws, C, H, W, Cb, coff, int(accumulate),
                                         self.stream), 'nearest_up_bwd')
 
     # ------------------------------------------------------------------ forward
@@ -516,17 +529,22 @@ class Engine:
         if H < 32 or W < 32:
             raise ValueError('input must be at least 32x32 (five stride-2 stages); got %dx%d' % (H, W))
         self.ensure_flat()
+        if self.at == 2 and train:
+            raise RuntimeError("conv math 'fp16' is the inference path (BASELINE configs[4]): call model.eval() first")
+        if self.at != 0 and getattr(m.backbone.layer2[0], 'with_dcn', False):
+            raise NotImplementedError("16-bit activation storage is not implemented for the deformable backbones "
+                                      "(use set_conv_math('bf16c'): fp32 tensors, bf16 operands)")
         self.repack_params()
         x = x.contiguous().float()
         L, st = self.L, self.stream
         self.generation += 1
         bb = m.backbone
-        x4 = self.buf('x4', N, H, W, 4)
-        check(L.dbn_nchw3_to_nhwc4(x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
+        x4 = self.buf('x4', N, H, W, 4 if self.at == 0 else 16)  # 16-bit storage: 16-channel blocks (channels 3.. are zero)
+        check(L.dbn_nchw3_to_nhwc4_t(self.at, x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
         y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
-        check(L.dbn_bnrelu_maxpool_fwd(y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
+        check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
               'maxpool fwd')
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
@@ -591,11 +609,11 @@ class Engine:
         Hh, Wh = yb_.shape[1], yb_.shape[2]
         resample = (2 * Hh, 2 * Wh) != (H, W)  # only when H or W is not a multiple of 32 (models.py:43-46)
         out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
-        head_out = self.buf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
+        head_out = self.fbuf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
         b6, t6 = head.binarize[6], head.thresh[6]
         if self.prof:  # reads 2 x 64ch at half resolution, writes `ch` full-resolution maps
             self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * Hh * Wh * 128 + 4.0 * N * 4 * Hh * Wh * ch)
-        check(L.dbn_head_tail_fwd(yb_.data_ptr(), yt_.data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(), b6.bias.data_ptr(),
+        check(L.dbn_head_tail_fwd_t(self.at, yb_.data_ptr(), yt_.data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(), b6.bias.data_ptr(),
                                   t6.bias.data_ptr(), sb_.data_ptr(), hb_.data_ptr(), st_.data_ptr(), ht_.data_ptr(),
                                   head_out.data_ptr(), N, Hh, Wh, ch, float(head.k), st), 'head_tail_fwd')
         if self.prof:
@@ -659,7 +677,7 @@ class Engine:
         Ho, Wo = off.shape[1], off.shape[2]
         T = conv.k * conv.k
         vconv, ver2 = self._cols_conv(name + '.conv2', conv)
-        t = self.buf(name + '/dw_cols', conv.cout, T * C, 1, 1)
+        t = self.fbuf(name + '/dw_cols', conv.cout, T * C, 1, 1)
         self.wgrad(name + '.conv2 (cols)', dy, cols, conv.cout, T * C, 1, 1, 0, t)
         check(self.L.dbn_permute_weight(t.data_ptr(), G[name + '.conv2.weight'].data_ptr(), conv.cout, C, T, 0, 1.0, self.stream),
               'permute_weight')
@@ -670,11 +688,11 @@ class Engine:
         check(self.L.dbn_deform_col2im(dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx.data_ptr(), doff.data_ptr(), N, H, W, C, Ho, Wo,
                                        conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
         voc, ver = self._offset_conv(name + '.conv2_offset', oc)
-        tg = self.buf(name + '/dw_offset', 64, C, oc.k, oc.k)
+        tg = self.fbuf(name + '/dw_offset', 64, C, oc.k, oc.k)
         self.wgrad(name + '.conv2_offset', doff, x, 64, C, oc.k, oc.stride, oc.padding, tg)
         nreal = oc.weight.shape[0]
         G[name + '.conv2_offset.weight'].copy_(tg[:nreal])
-        tb = self.buf(name + '/db_offset', 64)
+        tb = self.fbuf(name + '/db_offset', 64)
         self.col_sum(doff, tb)
         G[name + '.conv2_offset.bias'].copy_(tb[:nreal])
         self.conv_dgrad(name + '.conv2_offset', doff, voc, dx, True, version=ver)
@@ -723,7 +741,7 @@ class Engine:
         dpreds = dpreds.contiguous()
         assert dpreds.shape == (N, 3, H, W)
         if resample:
-            dhead = self.buf('head/dout', *out.shape)
+            dhead = self.fbuf('head/dout', *out.shape)
             check(L.dbn_bilinear_bwd(dpreds.data_ptr(), dhead.data_ptr(), N * 3, 2 * Hh, 2 * Wh, H, W, st), 'bilinear_bwd')
             dpreds = dhead
         head = m.segmentation_head
@@ -733,8 +751,8 @@ class Engine:
         ws = self.scratch('_head_ws', L.dbn_head_tail_bwd_ws_floats())
         G = self.grad_views
         hb, ht = 'segmentation_head.binarize.4', 'segmentation_head.thresh.4'
-        bn_sums = self.buf('head/bn4_sums', 4, 64)  # the kernel also reduces what the two BatchNorm backwards need
-        check(L.dbn_head_tail_bwd(B['binarize/y1'].data_ptr(), B['thresh/y1'].data_ptr(), b6.weight.data_ptr(),
+        bn_sums = self.fbuf('head/bn4_sums', 4, 64)  # the kernel also reduces what the two BatchNorm backwards need
+        check(L.dbn_head_tail_bwd_t(self.at, B['binarize/y1'].data_ptr(), B['thresh/y1'].data_ptr(), b6.weight.data_ptr(),
                                   t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), B[hb + '/scale'].data_ptr(),
                                   B[hb + '/shift'].data_ptr(), B[ht + '/scale'].data_ptr(), B[ht + '/shift'].data_ptr(),
                                   B[hb + '/mean'].data_ptr(), B[hb + '/rstd'].data_ptr(), B[ht + '/mean'].data_ptr(),
@@ -830,7 +848,7 @@ class Engine:
                     self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)
-        check(L.dbn_bnrelu_maxpool_bwd(y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
+        check(L.dbn_bnrelu_maxpool_bwd_t(self.at, y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
                                        B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, y0.shape[1], y0.shape[2], 64, st),
               'maxpool bwd')
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy')
@@ -868,18 +886,18 @@ class Engine:
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d>' % self.ns, flops, 0.0, 'fwd %s (pyramid)' % name)
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d>' % (self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co
-                sc, sh = self.buf(bn_name + '/scale', C), self.buf(bn_name + '/shift', C)
-                mu, rs = self.buf(bn_name + '/mean', C), self.buf(bn_name + '/rstd', C)
+                sc, sh = self.fbuf(bn_name + '/scale', C), self.fbuf(bn_name + '/shift', C)
+                mu, rs = self.fbuf(bn_name + '/mean', C), self.fbuf(bn_name + '/rstd', C)
                 ws = self.scratch('_conv_bn_ws', self.L.dbn_pyramid_conv_ws_floats(N, H, W, Co))
                 bnargs = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
                           bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr())
                 self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
             else:
                 bnargs = (None, None, 0.0, 0.0) + (None, ) * 7
-            check(self.L.dbn_pyramid_conv_f32(*[z.data_ptr() for z in zs], *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
+            check(self.L.dbn_pyramid_conv_t(self.at, *[z.data_ptr() for z in zs], *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
                                               N, H, W, Cg, Co, 0, self.ns, *bnargs, self.stream), 'pyramid_conv')
             if self.prof:
                 self.prof.end()
@@ -922,7 +940,7 @@ class Engine:
             if self.prof:
                 self.prof.end()
             dP[nm] = d
-            t = self.buf('%s#t%d' % (name, g), Cg, Co, k, k)
+            t = self.fbuf('%s#t%d' % (name, g), Cg, Co, k, k)
             with self.side_stream():
                 self.wgrad('%s level %d' % (name, g), z, dy, Cg, Co, k, f, 1, t)
             ts.append(t)

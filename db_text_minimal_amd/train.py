@@ -130,7 +130,7 @@ class DBTrainer:
         fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
         check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
                   self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
-        dpreds = self.model.engine.buf('dpreds', N, C, H, W)
+        dpreds = self.model.engine.fbuf('dpreds', N, C, H, W)
         if per_pixel:
             check(L.dbn_db_loss_ohem_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(),
                                          self._ws.data_ptr(), c.alpha, c.beta, N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')

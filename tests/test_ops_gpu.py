@@ -720,7 +720,7 @@ def test_image_chunking_beyond_the_index_ranges():
     bias = rnd(Co, seed=4).to(DEV)
     dy = nhwc(rnd(N, Co, H, W, seed=5))
 
-    def run_all():
+    def run_all(convT_limit=0):
         out = {}
         y = torch.full((N, H, W, Co), float('nan'), device=DEV)
         g_, b_ = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
@@ -732,7 +732,11 @@ def test_image_chunking_beyond_the_index_ranges():
                                        sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
         out['conv'], out['scale'], out['shift'], out['run_var'] = y, sc, sh, rv_
         yT = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
+        if convT_limit:  # its output has 4x the pixels: one image must still fit a launch
+            L().dbn_set_index_limits(convT_limit, 0, 0)
         igemm(x, pack(wT, 1, 2), bias, yT, 4, 2, 1, 1)
+        if convT_limit:
+            L().dbn_set_index_limits(2 * H * W + 7, 0, 0)
         out['convT'] = yT
         d = torch.full((N, H, W, Ci), float('nan'), device=DEV)
         igemm(dy, pack(w, 1, 1), None, d, 3, 1, 1, 1)
@@ -764,7 +768,7 @@ def test_image_chunking_beyond_the_index_ranges():
     try:
         L().dbn_set_index_limits(2 * H * W + 7, 0, 0)  # at most two images per launch
         assert L().dbn_wgrad_splitk_hw(N, H, W, Co, H, W, Ci, 3, 3) >= 3
-        got = run_all()
+        got = run_all(convT_limit=8 * H * W + 7)
         L().dbn_set_index_limits(0, H * W * Co * 4 + 64, 0)  # one image of the widest tensor per launch, through the byte range
         got1 = run_all()
     finally:
