@@ -39,7 +39,9 @@ MATH = {
     'f32': ('f32', 'fp32 (exact-fp32 MFMA)', PEAK_F32_MFMA_TFLOPS),
     'bf16x3': ('bf16x3', 'fp32 tensors, conv products on the bf16 matrix pipe as an exact 3-way operand split (fp32-accurate)',
                PEAK_BF16_MFMA_TFLOPS / 6.0),
-    'bf16': ('bf16', 'conv operands rounded to bf16, fp32 accumulate', PEAK_BF16_MFMA_TFLOPS),
+    'bf16': ('bf16', 'native bf16: activations, gradients and weight panels stored in bf16, bf16 MFMA, fp32 accumulate / BN statistics / '
+                     'loss sums / master weights', PEAK_BF16_MFMA_TFLOPS),
+    'bf16c': ('bf16', 'fp32 tensors, conv operands rounded to bf16 when staged, fp32 accumulate', PEAK_BF16_MFMA_TFLOPS),
 }
 
 
@@ -87,8 +89,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE: 16)')
     ap.add_argument('--size', type=int, default=640)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16'],
-                    help="conv math: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; bf16 = bf16 operands")
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16c'],
+                    help="precision mode: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; "
+                         "bf16 = native bf16 storage + MFMA (BASELINE configs[2]); bf16c = fp32 tensors, bf16 operands")
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
     args = ap.parse_args()
@@ -210,9 +213,7 @@ def main():
                 trainer.step(img, gts)
             barrier()
             alt[mode] = {'images_per_s': round(world * args.batch * args.steps / (time.perf_counter() - t1), 2),
-                         'note': {'bf16x3': 'fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs, fp32 accumulate (fp32-accurate)',
-                                  'bf16': 'conv operands rounded to bf16, fp32 accumulate/storage (BASELINE configs[2] compute mode)',
-                                  'f32': 'exact-fp32 MFMA'}[mode]}
+                         'dtype': MATH[mode][0], 'note': MATH[mode][1]}
         eng.set_conv_math(args.math)
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -223,7 +224,7 @@ def main():
             'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': 'ResNet18-FPN-DBHead DBNet train step (fwd+DBLoss+bwd+Adam), %dx%d, bs %d/GPU, %s, '
                                    'random-init weights (BASELINE configs[%d])' % (args.size, args.size, args.batch, math_words,
-                                                                                    1 if args.math == 'f32' else 2),
+                                                                                    1 if args.math in ('f32', 'bf16x3') else 2),
                        'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': ('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, issued as 4 contiguous buckets under '
                                           'the backward pass (FPN+head, layer4, layer3, rest)') if world > 1 else None},

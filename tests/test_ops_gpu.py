@@ -783,3 +783,165 @@ def test_image_chunking_beyond_the_index_ranges():
         else:
             assert torch.equal(got[k], v), k
             assert torch.equal(got1[k], v), k
+
+
+AT_OF = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def igemm_t(src, wpk, bias, dst, R, stride, pad, mode, accumulate=0, tile=0, ns=1, ksplit=1, slab=None):
+    N, Hs, Ws, Cs = src.shape
+    _, Hd, Wd, Cd = dst.shape
+    _lib.check(L().dbn_igemm_t(AT_OF[src.dtype], ns, src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(),
+                               N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, mode, accumulate, tile, ksplit,
+                               None if slab is None else slab.data_ptr(), stream()), 'igemm_t')
+
+
+def pack_t(w, mode, stride, kind, cs=0):
+    O, I, R, S = w.shape
+    wd = w.contiguous().to(DEV)
+    out = torch.empty(L().dbn_igemm_panel_floats_t(kind, O, I, R, S, mode, stride, cs), device=DEV)
+    _lib.check(L().dbn_pack_weights_t(kind, wd.data_ptr(), O, I, R, S, mode, stride, cs, out.data_ptr(), stream()), 'pack_t')
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+def test_convolutions_on_16bit_storage(dtype, tile):
+    """dbn_igemm_t with bf16 / fp16 activation storage (BASELINE configs[2]/[4]): the source is read as stored (8-channel
+    pieces straight into the LDS image), the weights come from bf16 / fp16 panels, products accumulate in fp32 and the result is
+    rounded once to the storage type.  Reference: F.conv2d / conv_transpose2d in fp64 on the SAME rounded operands; the only
+    error left is the output rounding (2^-9 bf16, 2^-11 fp16, relative) plus fp32 accumulation noise."""
+    kind = 1 if dtype == torch.bfloat16 else 2
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    rq = lambda t: t.to(dtype).double()  # rounded to storage, as fp64
+    N, Ci, Co, H, W = 3, 64, 128, 14, 18
+    x = rnd(N, Ci, H, W, seed=1)
+    xs = nhwc(x).to(dtype)
+    b = rnd(Co, seed=3)
+    for (k, s_, p_) in ((3, 1, 1), (1, 1, 0), (3, 2, 1)):
+        w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+        ref = F.conv2d(rq(x), rq(w), b.double(), s_, p_)
+        y = torch.full((N, ref.shape[2], ref.shape[3], Co), float('nan'), device=DEV, dtype=dtype)
+        igemm_t(xs, pack_t(w, 0, s_, kind, Ci), b.to(DEV), y, k, s_, p_, 0, tile=tile)
+        report('conv k%d s%d %s' % (k, s_, dtype), nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+    # data gradient (mode 1, stride 1, accumulate) and ConvTranspose2d (mode 1, stride 2: parity classes)
+    w = rnd(Co, Ci, 3, 3, seed=4, scale=0.05)
+    dy = rnd(N, Co, H, W, seed=5)
+    base = rnd(N, Ci, H, W, seed=6)
+    ref = rq(base) + F.conv_transpose2d(rq(dy), rq(w), None, 1, 1)
+    d = nhwc(base).to(dtype)
+    igemm_t(nhwc(dy).to(dtype), pack_t(w, 1, 1, kind), None, d, 3, 1, 1, 1, accumulate=1, tile=tile)
+    report('dgrad+acc %s' % dtype, nchw(d.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+    wT = rnd(Ci, Co, 2, 2, seed=7, scale=0.1)
+    ref = F.conv_transpose2d(rq(x), rq(wT), b.double(), 2, 0)
+    yT = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV, dtype=dtype)
+    igemm_t(xs, pack_t(wT, 1, 2, kind), b.to(DEV), yT, 2, 2, 0, 1, tile=tile)
+    report('convT k2 s2 %s' % dtype, nchw(yT.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+    # split-K (fp32 slabs, one rounding in the slab sum)
+    w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
+    ref = F.conv2d(rq(x), rq(w), b.double(), 1, 1)
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+    slab = torch.empty(4 * y.numel(), device=DEV)
+    igemm_t(xs, pack_t(w, 0, 1, kind, Ci), b.to(DEV), y, 3, 1, 1, 0, tile=tile, ksplit=4, slab=slab)
+    report('split-K conv %s' % dtype, nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+
+
+def test_stem_conv_on_16_channel_bf16_input():
+    """The 16-bit path stores the model input with 16 channels (3 real): nchw3_to_nhwc4_t + the 7x7 stride-2 stem conv."""
+    N, H, W = 2, 40, 48
+    x = rnd(N, 3, H, W, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=0.1)
+    xd = x.to(DEV)
+    x16 = torch.full((N, H, W, 16), float('nan'), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().dbn_nchw3_to_nhwc4_t(1, xd.data_ptr(), x16.data_ptr(), N, H, W, stream()), 'nchw3_to_nhwc16')
+    assert torch.equal(x16[..., :3].float().cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and float(x16[..., 3:].abs().max()) == 0
+    ref = F.conv2d(x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double(), None, 2, 3)
+    y = torch.full((N, ref.shape[2], ref.shape[3], 64), float('nan'), device=DEV, dtype=torch.bfloat16)
+    igemm_t(x16, pack_t(w, 0, 2, 1, 16), None, y, 7, 2, 3, 0)
+    report('stem conv bf16', nchw(y.float()), ref, 2.0**-9 * float(ref.abs().max()), 2.0**-8)
+    # its weight gradient: X has 16 stored channels, 3 real ones
+    dy = rnd(N, 64, ref.shape[2], ref.shape[3], seed=3)
+    dys = nhwc(dy).to(torch.bfloat16)
+    slab = torch.empty(L().dbn_wgrad_slab_floats(N, ref.shape[2], ref.shape[3], 64, 16, 7, 7), device=DEV)
+    g = torch.full((64, 3, 7, 7), float('nan'), device=DEV)
+    _lib.check(L().dbn_wgrad_t(1, 1, dys.data_ptr(), x16.data_ptr(), slab.data_ptr(), g.data_ptr(), N, ref.shape[2], ref.shape[3], 64, H, W,
+                               16, 3, 7, 7, 2, 3, 1.0, stream()), 'wgrad_t')
+    xr = x.to(torch.bfloat16).double().requires_grad_(False)
+    wr = w.double().requires_grad_(True)
+    (gref, ) = torch.autograd.grad(F.conv2d(xr, wr, None, 2, 3), wr, dy.to(torch.bfloat16).double())
+    report('stem wgrad bf16', g.cpu(), gref, 1e-5 * float(gref.abs().max()), 1e-4)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 20, 12), (3, 128, 256, 1, 1, 0, 9, 7), (2, 64, 128, 3, 2, 1, 16, 16), (1, 256, 256, 3, 1, 1, 12, 12),
+                                  (2, 64, 64, 2, 2, 0, 10, 12)])
+def test_weight_gradient_on_bf16_storage(case):
+    """dbn_wgrad_t(at = bf16): dY and X are read as stored, transposed in registers, multiplied on the bf16 matrix pipe with
+    fp32 accumulation into fp32 slabs: equals the fp64 weight gradient of the ROUNDED tensors to fp32 accumulation noise."""
+    N, Ci, Co, k, s_, p_, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2).double().requires_grad_(True)
+    y = F.conv2d(x.to(torch.bfloat16).double(), w, None, s_, p_)
+    dy = rnd(*y.shape, seed=3)
+    (gref, ) = torch.autograd.grad(y, w, dy.to(torch.bfloat16).double())
+    xs, dys = nhwc(x).to(torch.bfloat16), nhwc(dy).to(torch.bfloat16)
+    Ho, Wo = y.shape[2], y.shape[3]
+    slab = torch.empty(L().dbn_wgrad_slab_floats(N, Ho, Wo, Co, Ci, k, k), device=DEV)
+    g = torch.full((Co, Ci, k, k), float('nan'), device=DEV)
+    _lib.check(L().dbn_wgrad_t(1, 1, dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, Co, H, W, Ci, Ci, k, k, s_, p_,
+                               0.5, stream()), 'wgrad_t')
+    report('wgrad bf16 storage', g.cpu(), 0.5 * gref, 2e-5 * float(gref.abs().max()), 1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_batchnorm_and_pool_kernels_on_16bit_storage(dtype):
+    """The HBM-bound kernels with 16-bit tensors == the fp32 kernels on the same (rounded) inputs, up to one output rounding."""
+    at = AT_OF[dtype]
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    N, C, H, W = 3, 64, 10, 14
+    M = N * H * W
+    y32 = nhwc(rnd(N, C, H, W, seed=1)).to(dtype).float()
+    res32 = nhwc(rnd(N, C, H, W, seed=2)).to(dtype).float()
+    dout32 = nhwc(rnd(N, C, H, W, seed=3)).to(dtype).float()
+    gamma, beta = (rnd(C, seed=4) * 0.3 + 1).to(DEV), rnd(C, seed=5).to(DEV)
+    ws = reduce_ws()
+
+    def run(at_, conv):
+        y, res, dout = conv(y32), conv(res32), conv(dout32)
+        dt = y.dtype
+        sc, sh, mu, rs = (torch.empty(C, device=DEV) for _ in range(4))
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        _lib.check(L().dbn_bn_train_stats_t(at_, y.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(),
+                                            rv.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(),
+                                            stream()), 'stats')
+        out = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        _lib.check(L().dbn_bn_apply_t(at_, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), None, None, out.data_ptr(), M, C, 1,
+                                      stream()), 'apply')
+        dy = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        gout = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        dg, db, dbias = (torch.empty(C, device=DEV) for _ in range(3))
+        _lib.check(L().dbn_bn_backward_t(at_, None, y.data_ptr(), out.data_ptr(), None, None, dout.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                                         gamma.data_ptr(), dy.data_ptr(), gout.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
+                                         M, C, 1.0, ws.data_ptr(), stream()), 'bn backward')
+        pool = torch.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), float('nan'), device=DEV, dtype=dt)
+        _lib.check(L().dbn_bnrelu_maxpool_fwd_t(at_, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H, W, C, stream()), 'pool')
+        dpool = conv(nhwc(rnd(N, C, pool.shape[1], pool.shape[2], seed=7)).to(dtype).float())
+        dz = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        _lib.check(L().dbn_bnrelu_maxpool_bwd_t(at_, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), dpool.data_ptr(), dz.data_ptr(),
+                                                N, H, W, C, stream()), 'pool bwd')
+        up = torch.full((N, 2 * H, 2 * W, C), float('nan'), device=DEV, dtype=dt)
+        _lib.check(L().dbn_nearest_up_fwd_t(at_, y.data_ptr(), None, up.data_ptr(), N, H, W, C, 2 * H, 2 * W, C, 0, stream()), 'up')
+        dn = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        _lib.check(L().dbn_nearest_up_bwd_t(at_, up.data_ptr(), dn.data_ptr(), N, H, W, C, 2 * H, 2 * W, C, 0, 0, stream()), 'up bwd')
+        return {k: v.float().cpu() for k, v in dict(sc=sc, sh=sh, out=out, dy=dy, gout=gout, dg=dg, db=db, dbias=dbias, pool=pool, dz=dz,
+                                                     up=up, dn=dn).items()}
+
+    a = run(at, lambda t: t.to(dtype))
+    b = run(0, lambda t: t.clone())
+    for k in a:
+        tol = 1e-5 if k in ('sc', 'sh', 'dg', 'db') else eps
+        if k == 'dbias':  # column sums of dy: of the ROUNDED dy in 16-bit storage... of values that cancel analytically
+            continue
+        if k == 'dz':  # equality with the pooled maximum is tested on rounded values: ties can differ from the fp32 run
+            assert float((a[k] - b[k]).abs().gt(eps * (1 + b[k].abs())).float().mean()) < 0.02
+            continue
+        report('16-bit %s %s' % (dtype, k), a[k], b[k], tol * float(b[k].abs().max()), tol)
