@@ -82,10 +82,11 @@ SIGNATURES.update({
     'dbn_igemm_panel_floats_t': 'i' * 8,
     'dbn_bn_train_stats_t': 'i' + SIGNATURES['dbn_bn_train_stats'],
     'dbn_bn_apply_t': 'i' + SIGNATURES['dbn_bn_apply'],
-    'dbn_bn_backward_t': 'i' + SIGNATURES['dbn_bn_backward_ex'],
+    'dbn_bn_backward_t': 'ipi' + SIGNATURES['dbn_bn_backward_ex'][1:],
     'dbn_col_sum_t': 'i' + SIGNATURES['dbn_col_sum'],
     'dbn_bnrelu_maxpool_fwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_fwd'],
-    'dbn_bnrelu_maxpool_bwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_bwd'],
+    'dbn_bnrelu_maxpool_bwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_bwd'][:-1] + 'pppp',
+    'dbn_maxpool_bwd_parts': 'iiii',
     'dbn_nearest_up_fwd_t': 'i' + SIGNATURES['dbn_nearest_up_fwd'],
     'dbn_nearest_up_bwd_t': 'i' + SIGNATURES['dbn_nearest_up_bwd'],
     'dbn_nchw3_to_nhwc4_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],

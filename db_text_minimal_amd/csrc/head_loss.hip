@@ -16,13 +16,27 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.f / (1.f + expf(-x)); }
 
 // 16 lanes cooperate on one quarter-resolution pixel: lane q owns channels 4q..4q+3.
+// The 16-lane sums and broadcasts use DPP row operations (a DPP "row" IS 16 lanes): full-rate VALU instructions.  __shfl_xor
+// compiles to ds_bpermute_b32, and at 32 of them per four pixels the forward kernel was bound by the LDS pipe, not by HBM
+// (215 us for 917 MB = 4.3 TB/s).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);         // every lane of a quad: the quad's sum
+    v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);   // lane i <-> 7-i: the other quad of the half
+    v += dpp_f32<DPP_ROW_MIRROR>(v);        // lane i <-> 15-i: the other half
     return v;
 }
+// value of lane `k` (0..3) of this lane's quad
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) { return dpp_f32<K | (K << 2) | (K << 4) | (K << 6)>(v); }
 
 // xb/xt: [N,Hq,Wq,64] inputs of the last ConvT (already BN+ReLU'd);  wb/wt: [64][4]
 // (ConvTranspose2d weight [64,1,2,2]); out: [N,CH,2Hq,2Wq], CH=3 (train) or 2 (eval).
@@ -147,10 +161,12 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restri
         const long n = px / ((long)Hq * Wq);
         const long rem = px - n * (long)Hq * Wq;
         const int hq = (int)(rem / Wq), wq = (int)(rem - (long)hq * Wq);
-        // lanes 0..3 of the group each evaluate one (a,b) position, then broadcast
+        // lane k of every quad evaluates the (a,b) = (k>>1, k&1) position (the four quads redundantly: same cache lines, same
+        // instruction count), then a quad-local DPP broadcast hands all four to every lane — no cross-lane LDS traffic
         float dlb = 0.f, dlt = 0.f;
-        if (q < 4) {
-            const long o = (long)(2 * hq + (q >> 1)) * W + 2 * wq + (q & 1);
+        {
+            const int ab = q & 3;
+            const long o = (long)(2 * hq + (ab >> 1)) * W + 2 * wq + (ab & 1);
             const float* pb = preds + n * CH * HW + o;
             const float* db = dpreds + n * CH * HW + o;
             const float P = pb[0], T = pb[HW];
@@ -164,12 +180,8 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restri
             dlb = dP * P * (1.f - P);
             dlt = dT * T * (1.f - T);
         }
-        f32x4 lb, lt;
-#pragma unroll
-        for (int ab = 0; ab < 4; ++ab) {
-            lb[ab] = __shfl(dlb, (threadIdx.x & 48) + ab, 64);
-            lt[ab] = __shfl(dlt, (threadIdx.x & 48) + ab, 64);
-        }
+        const f32x4 lb = {quad_bcast<0>(dlb), quad_bcast<1>(dlb), quad_bcast<2>(dlb), quad_bcast<3>(dlb)};
+        const f32x4 lt = {quad_bcast<0>(dlt), quad_bcast<1>(dlt), quad_bcast<2>(dlt), quad_bcast<3>(dlt)};
         f32x4 vb = dbn_ld4<AT>(xb, px * 16 + q);
         f32x4 vt = dbn_ld4<AT>(xt, px * 16 + q);
         const f32x4 yb = vb, yt = vt;

@@ -338,12 +338,22 @@ __device__ __forceinline__ float round_to_storage(float v) {
     else if constexpr (AT == 2) return (float)(_Float16)v;
     else return v;
 }
+// bn_part (optional, needs 256 % (C/4) == 0 so that a thread keeps its channel quad): per-block partial sums of the two
+// reductions of the BatchNorm backward that consumes dz — sum(dz) and sum(dz * xhat) per channel, [2*C][gridDim.x] — so that
+// the stem's BatchNorm backward does not re-read y and dz (2 x 420 MB at bs16) to form them.
 template <int AT>
 __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                           const void* __restrict__ pooled, const void* __restrict__ dpool,
-                                          void* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo) {
+                                          void* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ bn_part) {
     const int c4n = C >> 2;
     const long total = (long)N * H * W * c4n;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1;
+    if (bn_part) {
+        const int cq = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;
+        mu = *reinterpret_cast<const f32x4*>(mean + cq);
+        rs = *reinterpret_cast<const f32x4*>(rstd + cq);
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         long t = i / c4n;
@@ -371,6 +381,27 @@ __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const floa
                     if (z[e] > 0.f && z[e] == pm[e]) g[e] += dp[e];
             }
         dbn_st4<AT>(dz, i, g);
+        if (bn_part) {
+            f32x4 gr = g;  // the BatchNorm backward reads the STORED gradient
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gr[e] = round_to_storage<AT>(g[e]);
+            s1 += gr;
+            s2 += gr * ((v - mu) * rs);
+        }
+    }
+    if (bn_part) {  // threads t, t + C/4, ... of the block hold the same channel quad
+        __shared__ f32x4 red[2][256];
+        red[0][threadIdx.x] = s1;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * c4n) {
+            const int which = threadIdx.x / c4n, t0 = threadIdx.x - which * c4n;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int k = t0; k < 256; k += c4n) t += red[which][k];
+            const int cq = (int)((blockIdx.x * (long)blockDim.x + t0) % c4n) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bn_part[((long)which * C + cq + e) * gridDim.x + blockIdx.x] = t[e];
+        }
     }
 }
 
@@ -688,7 +719,8 @@ int dbn_bn_apply(const float* y, const float* scale, const float* shift, const f
 // The general BatchNorm backward.  `sums` optional: [2][C] reductions already produced by the kernel that wrote dout (then
 // only finalize + apply run).  `dbias_conv` optional [C]: column sums of dy (times grad_scale) = gradient of the bias of the
 // convolution that produced y, formed inside the apply pass instead of by a dbn_col_sum pass over dy (needs 256 % (C/4) == 0).
-int dbn_bn_backward_t(int at, const float* sums, const void* y, const void* zmask, const float* mask_scale, const float* mask_shift,
+// sums_parts: number of partial columns of `sums` ([2*C][sums_parts], 1 = already folded; ignored without `sums`).
+int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, const void* zmask, const float* mask_scale, const float* mask_shift,
                       const void* dout, const float* save_mean, const float* save_rstd, const float* gamma, void* dy, void* gout,
                       int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
                       void* stream) {
@@ -704,9 +736,9 @@ int dbn_bn_backward_t(int at, const float* sums, const void* y, const void* zmas
     const long total4 = (long)M * (C / 4);
     const int grid = bn_stream_grid(total4, C);
     DBN_DISPATCH_AT(at, {
-        if (sums) {  // a single "partial"
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, 1, M, C, dgamma, dbeta, c1, c2,
-                               grad_scale);
+        if (sums) {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, sums_parts > 0 ? sums_parts : 1, M,
+                               C, dgamma, dbeta, c1, c2, grad_scale);
         } else {
             hipLaunchKernelGGL(bn_bwd_reduce_kernel<AT>, red_grid(nbu, C), dim3(256), red_smem(C, 2), st, y, zmask, mask_scale,
                                mask_shift, dout, save_mean, save_rstd, M, C, ws);
@@ -725,7 +757,7 @@ int dbn_bn_backward_t(int at, const float* sums, const void* y, const void* zmas
 int dbn_bn_backward(const float* y, const float* zmask, const float* mask_scale, const float* mask_shift, const float* dout,
                     const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout, int gout_accumulate,
                     float* dgamma, float* dbeta, int M, int C, float grad_scale, float* ws, void* stream) {
-    return dbn_bn_backward_t(0, nullptr, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+    return dbn_bn_backward_t(0, nullptr, 0, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
                              dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
 }
 
@@ -736,7 +768,7 @@ int dbn_bn_backward_from_sums(const float* sums, const float* y, const float* zm
                               float* gout, int gout_accumulate, float* dgamma, float* dbeta, int M, int C, float grad_scale,
                               float* ws, void* stream) {
     DBN_REQUIRE(sums);
-    return dbn_bn_backward_t(0, sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+    return dbn_bn_backward_t(0, sums, 1, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
                              dgamma, dbeta, nullptr, M, C, grad_scale, ws, stream);
 }
 
@@ -744,7 +776,7 @@ int dbn_bn_backward_ex(const float* sums, const float* y, const float* zmask, co
                        const float* dout, const float* save_mean, const float* save_rstd, const float* gamma, float* dy, float* gout,
                        int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C, float grad_scale, float* ws,
                        void* stream) {
-    return dbn_bn_backward_t(0, sums, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
+    return dbn_bn_backward_t(0, sums, 1, y, zmask, mask_scale, mask_shift, dout, save_mean, save_rstd, gamma, dy, gout, gout_accumulate,
                              dgamma, dbeta, dbias_conv, M, C, grad_scale, ws, stream);
 }
 
@@ -773,17 +805,24 @@ int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shif
     return dbn_bnrelu_maxpool_fwd_t(0, y, scale, shift, out, N, H, W, C, stream);
 }
 
+// bn_mean / bn_rstd / bn_part optional (all or none): also emit the partial sums of the following BatchNorm backward,
+// bn_part = [2*C][dbn_maxpool_bwd_parts(...)] floats — feed them to dbn_bn_backward_t as `sums` with that `sums_parts`.
+int dbn_maxpool_bwd_parts(int N, int H, int W, int C) { return dbn_grid((long)N * H * W * (C / 4), 256, 2048); }
 int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const float* shift, const void* pooled, const void* dpool,
-                             void* dz, int N, int H, int W, int C, void* stream) {
+                             void* dz, int N, int H, int W, int C, const float* bn_mean, const float* bn_rstd, float* bn_part,
+                             void* stream) {
     DBN_REQUIRE(y && scale && shift && pooled && dpool && dz && C % 4 == 0);
+    DBN_REQUIRE((bn_part == nullptr) == (bn_mean == nullptr) && (bn_part == nullptr) == (bn_rstd == nullptr));
+    DBN_REQUIRE(!bn_part || 256 % (C / 4) == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel<AT>, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0,
-                                           (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo));
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel<AT>, dim3(dbn_maxpool_bwd_parts(N, H, W, C)), dim3(256), 0,
+                                           (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo, bn_mean, bn_rstd,
+                                           bn_part));
     return dbn_status();
 }
 int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
                            float* dz, int N, int H, int W, int C, void* stream) {
-    return dbn_bnrelu_maxpool_bwd_t(0, y, scale, shift, pooled, dpool, dz, N, H, W, C, stream);
+    return dbn_bnrelu_maxpool_bwd_t(0, y, scale, shift, pooled, dpool, dz, N, H, W, C, nullptr, nullptr, nullptr, stream);
 }
 
 int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,

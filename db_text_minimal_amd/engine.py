@@ -481,7 +481,7 @@ class Engine:
 
     bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
 
-    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False, sums=None, conv_bias=None):
+    def bn_backward(self, name, y, mask, dout, dy_name, gout=None, gout_acc=False, sums=None, conv_bias=None, sums_parts=1):
         """mask: None (no ReLU), 'self' (ReLU directly on this BN's output: recomputed from y with the
         forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates).
         conv_bias: name of the bias parameter of the conv that produced y (its gradient = column sums of dy)."""
@@ -498,7 +498,7 @@ class Engine:
             dbias = self.grad_views[conv_bias]
             self._bias_done.add(conv_bias)
         # sums: [2][C] reductions already produced by the kernel that wrote dout
-        check(self.L.dbn_bn_backward_t(self.at, _p(sums), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
+        check(self.L.dbn_bn_backward_t(self.at, _p(sums), int(sums_parts), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
                                         self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
                                         self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
                                         self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(),
@@ -848,10 +848,14 @@ class Engine:
                     self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)
+        # the max-pool backward also emits the partial sums of the stem BatchNorm's backward (it has y and dz in registers)
+        nparts = L.dbn_maxpool_bwd_parts(N, y0.shape[1], y0.shape[2], 64)
+        parts = self.scratch('_stem_bn_parts', 2 * 64 * nparts)
         check(L.dbn_bnrelu_maxpool_bwd_t(self.at, y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
-                                       B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, y0.shape[1], y0.shape[2], 64, st),
+                                         B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, y0.shape[1], y0.shape[2], 64,
+                                         B['backbone.bn1/mean'].data_ptr(), B['backbone.bn1/rstd'].data_ptr(), parts.data_ptr(), st),
               'maxpool bwd')
-        dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy')
+        dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy', sums=parts, sums_parts=nparts)
         self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)
         self.join_side()
         self.saved_generation = -1

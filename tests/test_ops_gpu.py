@@ -919,15 +919,27 @@ def test_batchnorm_and_pool_kernels_on_16bit_storage(dtype):
         dy = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
         gout = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
         dg, db, dbias = (torch.empty(C, device=DEV) for _ in range(3))
-        _lib.check(L().dbn_bn_backward_t(at_, None, y.data_ptr(), out.data_ptr(), None, None, dout.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+        _lib.check(L().dbn_bn_backward_t(at_, None, 0, y.data_ptr(), out.data_ptr(), None, None, dout.data_ptr(), mu.data_ptr(), rs.data_ptr(),
                                          gamma.data_ptr(), dy.data_ptr(), gout.data_ptr(), 0, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(),
                                          M, C, 1.0, ws.data_ptr(), stream()), 'bn backward')
         pool = torch.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), float('nan'), device=DEV, dtype=dt)
         _lib.check(L().dbn_bnrelu_maxpool_fwd_t(at_, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H, W, C, stream()), 'pool')
         dpool = conv(nhwc(rnd(N, C, pool.shape[1], pool.shape[2], seed=7)).to(dtype).float())
         dz = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
+        nparts = L().dbn_maxpool_bwd_parts(N, H, W, C)
+        parts = torch.empty(2 * C * nparts, device=DEV)
         _lib.check(L().dbn_bnrelu_maxpool_bwd_t(at_, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), dpool.data_ptr(), dz.data_ptr(),
-                                                N, H, W, C, stream()), 'pool bwd')
+                                                N, H, W, C, mu.data_ptr(), rs.data_ptr(), parts.data_ptr(), stream()), 'pool bwd')
+        # the BatchNorm backward fed with those partial sums == the one that reduces dz itself
+        dy_a, dy_b = (torch.full(y.shape, float('nan'), device=DEV, dtype=dt) for _ in range(2))
+        dg_a, db_a, dg_b, db_b = (torch.empty(C, device=DEV) for _ in range(4))
+        for sums, np_, dyo, dgo, dbo in ((parts, nparts, dy_a, dg_a, db_a), (None, 0, dy_b, dg_b, db_b)):
+            _lib.check(L().dbn_bn_backward_t(at_, None if sums is None else sums.data_ptr(), np_, y.data_ptr(), None, None, None, dz.data_ptr(),
+                                             mu.data_ptr(), rs.data_ptr(), gamma.data_ptr(), dyo.data_ptr(), None, 0, dgo.data_ptr(),
+                                             dbo.data_ptr(), None, M, C, 1.0, ws.data_ptr(), stream()), 'bn backward from pool sums')
+        report('pool-fused BN sums: dgamma', dg_a.cpu(), dg_b.cpu(), 2e-5 * float(dg_b.abs().max()), 1e-4)
+        report('pool-fused BN sums: dbeta', db_a.cpu(), db_b.cpu(), 2e-5 * float(db_b.abs().max()), 1e-4)
+        report('pool-fused BN sums: dy', dy_a.float().cpu(), dy_b.float().cpu(), 2.0**-7 * float(dy_b.float().abs().max()), 2.0**-7)
         up = torch.full((N, 2 * H, 2 * W, C), float('nan'), device=DEV, dtype=dt)
         _lib.check(L().dbn_nearest_up_fwd_t(at_, y.data_ptr(), None, up.data_ptr(), N, H, W, C, 2 * H, 2 * W, C, 0, stream()), 'up')
         dn = torch.full(y.shape, float('nan'), device=DEV, dtype=dt)
