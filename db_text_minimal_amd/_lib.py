@@ -39,6 +39,7 @@ SIGNATURES = {
     'dbn_wgrad_splitk': 'iiiiiii',
     'dbn_wgrad_slab_floats': 'iiiiiii',
     'dbn_wgrad_splitk_hw': 'iiiiiiiii',
+    'dbn_wgrad_slab_floats_hw': 'iiiiiiiiii',
     'dbn_set_index_limits': 'lll',
     'dbn_wgrad_f32': 'pppp' + 'i' * 12 + 'fp',
     'dbn_reduce_ws_floats': 'i',
@@ -93,7 +94,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

@@ -1798,19 +1798,22 @@ int dbn_wgrad_splitk_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int 
 // (input size unknown: assumes a stride <= 8 conv, X no larger than 64x dY's pixel count — only the chunking depends on it)
 int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S) { return dbn_wgrad_splitk_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S); }
 
-// Floats of slab scratch dbn_wgrad_f32 needs: splits * O * (R*S*Cb rounded up to the tile width).  Upper bound over the image
-// chunking (one launch per image rounds every split count up).
-long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
+// Floats of slab scratch dbn_wgrad_f32 / dbn_wgrad_t need: total splits * O * (R*S*Cb rounded up to the tile width).
+// es: bytes per activation element (4, or 2 for bf16 storage) — the image chunking depends on the tensors' byte sizes.
+long dbn_wgrad_slab_floats_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int R, int S, int es) {
     const int J = R * S * Cb;
     int bm, bn;
     wgrad_tiles(O, J, bm, bn);
     const long Jp = (long)((J + bn - 1) / bn) * bn;
-    long splits = wgrad_splitk_one(N, Ho, Wo, O, Cb, R, S);
-    if ((long)N * Ho * Wo >= g_pixel_limit / 8) {  // chunking may apply (X can be up to 64x dY): bound by per-image launches
-        const long per = (long)N * wgrad_splitk_one(1, Ho, Wo, O, Cb, R, S);
-        splits = per > splits ? per : splits;
-    }
+    const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb, es == 2 ? 1 : 0);
+    if (nmax < 1) return 0;
+    long splits = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) splits += wgrad_splitk_one(std::min(nmax, N - n0), Ho, Wo, O, Cb, R, S);
     return splits * O * Jp;
+}
+// (without the size of X: exact for calls that run as one launch — N*Ho*Wo < 2^24 pixels and X below 3.75 GB)
+long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
+    return dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S, 4);
 }
 
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

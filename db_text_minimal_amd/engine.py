@@ -408,7 +408,7 @@ class Engine:
     def wgrad(self, name, sm, big, O, I, k, stride, pad, gview):
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
-        slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k))
+        slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
         if self.prof:
             self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
         check(self.L.dbn_wgrad_t(self.at, self.ns, sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W,

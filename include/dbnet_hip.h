@@ -106,6 +106,8 @@ int dbn_wgrad_splitk(int N, int Ho, int Wo, int O, int Cb, int R, int S);
 /* the same when the size of X (H x W) is known; a call whose tensors exceed the kernels' index ranges (2^24 pixel rows,
  * 32-bit byte offsets) runs as several launches over image ranges, each with its own slabs */
 int dbn_wgrad_splitk_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int R, int S);
+/* slab floats for a call with X of size H x W stored with `es` bytes per element (4 fp32, 2 bf16): exact under the chunking */
+long dbn_wgrad_slab_floats_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb, int R, int S, int es);
 /* Test hook: lower the per-launch index ranges (pixel rows, bytes per tensor, output elements; 0 = default) so that the image
  * chunking of the conv / weight-gradient entry points can be exercised at small sizes.  Not thread-safe. */
 int dbn_set_index_limits(long pixel_rows, long bytes, long elems);

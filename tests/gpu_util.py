@@ -66,7 +66,7 @@ def igemm(src, wpk, bias, dst, R, stride, pad, mode, accumulate=0, tile=0, ns=0)
 def wgrad(sm, big, O, I, k, stride, pad, scale=1.0, ns=0):
     N, Ho, Wo, _ = sm.shape
     _, H, W, Cb = big.shape
-    slab = torch.empty(L().dbn_wgrad_slab_floats(N, Ho, Wo, O, Cb, k, k), device=DEV)
+    slab = torch.empty(L().dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4), device=DEV)
     g = torch.full((O, I, k, k), float('nan'), device=DEV)
     args = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride, pad, scale)
     if ns == 0:
