@@ -244,6 +244,79 @@ int dbn_binarize_u8(const float* pred, int N, int channels, int H, int W, float 
  * vertices are padded by repeating the last vertex. */
 int dbn_box_scores(const float* bitmap, int H, int W, const float* boxes, int K, int P, float* scores, void* stream);
 
+
+/* =====================================================================================================================
+ * Activation storage types (BASELINE configs[2]-[4]).  Every entry point above that moves activation tensors has a `_t`
+ * form with the storage type first: DBN_AT_F32 (0, the fp32 contract above), DBN_AT_BF16 (1: activations, their gradients
+ * and the weight panels are stored in bf16 in HBM; bf16 MFMA, fp32 accumulators / BatchNorm statistics / loss sums / weight
+ * gradients / master weights), DBN_AT_F16 (2: fp16 inference).  Tensors typed `void*` are stored in that type; everything
+ * typed `float*` stays fp32.  The reference has one dtype (fp32, src/train.py:96-98); these are the native data paths of the
+ * reduced-precision configurations.
+ * ===================================================================================================================== */
+#define DBN_AT_F32 0
+#define DBN_AT_BF16 1
+#define DBN_AT_F16 2
+
+/* weight panels: kind 0 fp32, 1 bf16, 3 bf16x3 (three bf16 planes), 2 fp16.  cs: channels of the source tensor for mode 0
+ * (0: I rounded up to 4; the 16-bit model input is stored with 16 channels) */
+long dbn_igemm_panel_floats_t(int kind, int O, int I, int R, int S, int mode, int stride, int cs);
+int dbn_pack_weights_t(int kind, const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int cs, float* out, void* stream);
+
+/* dbn_igemm_f32 / _bf16s / _splitk_f32 in one: at = storage of src / dst (16-bit storage: ns = 1, Cs % 16 == 0), ns = matrix math
+ * (0 exact fp32, 1 one 16-bit plane, 3 bf16x3), ksplit > 1 with `slab` (ksplit * N*Hd*Wd*Cd floats) = split-K */
+int dbn_igemm_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ksplit, float* slab,
+                void* stream);
+/* dbn_conv_bn_f32 with typed tensors; the BatchNorm statistics are those of the fp32 accumulators (before the storage rounding) */
+int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                  int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                  const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                  float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
+int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,
+                       const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
+                       int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                       float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
+/* weight gradient with typed dY (sm) and X (big): at = 0 (any ns) or 1 (bf16, ns = 1); slabs and the gradient stay fp32 */
+int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
+                int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
+
+int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                         float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                         float* ws, void* stream);
+int dbn_bn_apply_t(int at, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                   const float* res_shift, void* out, long M, int C, int relu, void* stream);
+/* The general BatchNorm backward: `sums` optional — [2*C][sums_parts] partial sums (or [2][C] with sums_parts = 1) of the masked
+ * gradient and of masked gradient * xhat produced by the kernel that wrote dout (dbn_head_tail_bwd, dbn_bnrelu_maxpool_bwd_t);
+ * dbias_conv optional as in dbn_bn_backward_ex */
+int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, const void* zmask, const float* mask_scale,
+                      const float* mask_shift, const void* dout, const float* save_mean, const float* save_rstd, const float* gamma,
+                      void* dy, void* gout, int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C,
+                      float grad_scale, float* ws, void* stream);
+int dbn_col_sum_t(int at, const void* x, int M, int C, float* out, float scale, float* ws, void* stream);
+int dbn_bnrelu_maxpool_fwd_t(int at, const void* y, const float* scale, const float* shift, void* out, int N, int H, int W, int C,
+                             void* stream);
+/* bn_mean / bn_rstd / bn_part optional (all or none): also emit the partial sums of the BatchNorm backward that consumes dz,
+ * bn_part = [2*C][dbn_maxpool_bwd_parts(N,H,W,C)] floats (needs 256 % (C/4) == 0) */
+int dbn_maxpool_bwd_parts(int N, int H, int W, int C);
+int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const float* shift, const void* pooled, const void* dpool,
+                             void* dz, int N, int H, int W, int C, const float* bn_mean, const float* bn_rstd, float* bn_part,
+                             void* stream);
+int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
+                         int coff, void* stream);
+int dbn_nearest_up_bwd_t(int at, const void* dbig, void* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,
+                         int accumulate, void* stream);
+/* x [N,3,H,W] fp32 -> [N,H,W,4] fp32 (at = 0) or [N,H,W,16] in the 16-bit type (channels 3.. zero) */
+int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W, void* stream);
+/* head tail with typed 64-channel inputs / input gradients; the maps, dpreds and the ConvT parameter gradients are fp32 */
+int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* bias_b,
+                        const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                        const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
+int dbn_head_tail_bwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* preds,
+                        const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
+                        const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,
+                        const float* bn_rstd_t, float* bn_sums, void* dxb, void* dxt, float* dw_b, float* dbias_b, float* dw_t,
+                        float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
