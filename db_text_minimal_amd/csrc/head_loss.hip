@@ -69,7 +69,22 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
     const float bb = bias_b[0], bt = bias_t[0];
     const int H = 2 * Hq, W = 2 * Wq;
     const long HW = (long)H * W;
-    for (long px = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4); px < npx; px += gstride) {
+    // (n, hq, wq) of the pixel: divided out once, then advanced by the grid stride with carries — a 64-bit division per pixel
+    // (~100 VALU instructions, executed by the whole wave) had made this kernel instruction-bound at 4.3 TB/s
+    const long px0 = blockIdx.x * (long)(blockDim.x >> 4) + (threadIdx.x >> 4);
+    const long HWq = (long)Hq * Wq;
+    long n = px0 / HWq;
+    int hq = (int)((px0 - n * HWq) / Wq), wq = (int)((px0 - n * HWq) - (long)hq * Wq);
+    const long g_n = gstride / HWq;
+    const int g_h = (int)((gstride - g_n * HWq) / Wq), g_w = (int)((gstride - g_n * HWq) - (long)g_h * Wq);
+    auto advance = [&]() {
+        wq += g_w;
+        if (wq >= Wq) { wq -= Wq; ++hq; }
+        hq += g_h;
+        if (hq >= Hq) { hq -= Hq; ++n; }
+        n += g_n;
+    };
+    for (long px = px0; px < npx; px += gstride, advance()) {
         f32x4 vb = dbn_ld4<AT>(xb, px * 16 + q);
         f32x4 vt = dbn_ld4<AT>(xt, px * 16 + q);
         if (bn) {
@@ -95,9 +110,6 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
             const float lp = (ab == 0 ? sb[0] : ab == 1 ? sb[1] : ab == 2 ? sb[2] : sb[3]) + bb;
             const float lt = (ab == 0 ? stt[0] : ab == 1 ? stt[1] : ab == 2 ? stt[2] : stt[3]) + bt;
             const float P = sigmoid_acc(lp), T = sigmoid_acc(lt);
-            const long n = px / ((long)Hq * Wq);
-            const long rem = px - n * (long)Hq * Wq;
-            const int hq = (int)(rem / Wq), wq = (int)(rem - (long)hq * Wq);
             const long o = (long)(2 * hq + (ab >> 1)) * W + 2 * wq + (ab & 1);
             float* base = out + n * CH * HW + o;
             base[0] = P;
@@ -157,10 +169,20 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restri
         awt[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float abb = 0.f, abt = 0.f;
-    for (long px = blockIdx.x * (long)(blockDim.x >> 4) + grp; px < npx; px += gstride) {
-        const long n = px / ((long)Hq * Wq);
-        const long rem = px - n * (long)Hq * Wq;
-        const int hq = (int)(rem / Wq), wq = (int)(rem - (long)hq * Wq);
+    const long px0 = blockIdx.x * (long)(blockDim.x >> 4) + grp;
+    const long HWq = (long)Hq * Wq;
+    long n = px0 / HWq;  // pixel walk by the grid stride with carries (no division in the loop, see the forward kernel)
+    int hq = (int)((px0 - n * HWq) / Wq), wq = (int)((px0 - n * HWq) - (long)hq * Wq);
+    const long g_n = gstride / HWq;
+    const int g_h = (int)((gstride - g_n * HWq) / Wq), g_w = (int)((gstride - g_n * HWq) - (long)g_h * Wq);
+    auto advance = [&]() {
+        wq += g_w;
+        if (wq >= Wq) { wq -= Wq; ++hq; }
+        hq += g_h;
+        if (hq >= Hq) { hq -= Hq; ++n; }
+        n += g_n;
+    };
+    for (long px = px0; px < npx; px += gstride, advance()) {
         // lane k of every quad evaluates the (a,b) = (k>>1, k&1) position (the four quads redundantly: same cache lines, same
         // instruction count), then a quad-local DPP broadcast hands all four to every lane — no cross-lane LDS traffic
         float dlb = 0.f, dlt = 0.f;

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     // statistics below and the store loop both see the final values
     // split-K launches write fp32 slabs whatever the activation type (the slab sum rounds once)
     const bool to_slab = MODE < 2 && p.ksplit > 1;
-    float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * qM * p.Cd : 0L);
+    float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * ((long)qM * p.Cd + 1088) : 0L);
     void* const dstv = p.dst;
     auto ld_dst = [&](long off) -> float { return (AT == 0 || to_slab) ? slabp[off] : dbn_ld1<AT>(dstv, off); };
     auto st_dst = [&](long off, float v) {
@@ -729,6 +729,11 @@ int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st, int at = 0) {
 // --------------------------------------------------------------------------------
 // weight gradient
 // --------------------------------------------------------------------------------
+// Distance (floats) between the slabs of consecutive pixel splits.  O*Jp alone is a multiple of 64 KB for most layers
+// (e.g. 64 x 2304 floats = 9 x 64 KB): the reduction then reads its `splits` addends from addresses that all map to the same
+// HBM channel / L2 slice and crawls (50 MB in 130 us).  4352 bytes of padding rotate consecutive slabs across the channels.
+__host__ __device__ inline long wgrad_slab_stride(long O, long Jp) { return O * Jp + 1088; }
+
 struct WgradParams {
     const void* sm;    // [N,Ho,Wo,O]  (indexes the reduction), activation type AT
     const void* big;   // [N,H,W,Cb], activation type AT
@@ -962,7 +967,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 
     // slab in position space: [split][O (tile-major positions)][Jp = njt*BN]
     const int Jp = njt * BN;
-    float* out = p.slab + (long)split * p.O * Jp;
+    float* out = p.slab + (long)split * wgrad_slab_stride(p.O, Jp);
 #pragma unroll
     for (int a = 0; a < MI; ++a)
 #pragma unroll
@@ -979,8 +984,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
                                     int R, int S, float* __restrict__ grad, float scale) {
     // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
-    const long total = (long)O * Jp, total4 = total >> 2;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
+    const long total = (long)O * Jp, count4 = total >> 2, total4 = wgrad_slab_stride(O, Jp) >> 2;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < count4; q += (long)gridDim.x * blockDim.x) {
         const long idx = q << 2;
         const f32x4* src = reinterpret_cast<const f32x4*>(slab) + q;
         double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __res
     const int o = blockIdx.x, i0 = blockIdx.y * 64;
     const int om = o % BM;
     const int prow = (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
-    const long total4 = ((long)O * Jp) >> 2;
+    const long total4 = wgrad_slab_stride(O, Jp) >> 2;
     const int nthr = blockDim.x;
     for (int w = threadIdx.x; w < items * G; w += nthr) {
         const int g = w / items, t = w - g * items;
@@ -1138,10 +1143,11 @@ template <int AT>
 __global__ void splitk_sum_kernel(const float* __restrict__ slab, int splits, long total4, int Cd, const float* __restrict__ bias,
                                   int accumulate, void* __restrict__ dst) {
     const int c4n = Cd >> 2;
+    const long stride4 = total4 + 272;  // slabs are 1088 floats apart beyond their size (HBM channel rotation, see wgrad_slab_stride)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
         f32x4 v = src[0];
-        for (int z = 1; z < splits; ++z) v += src[(long)z * total4];
+        for (int z = 1; z < splits; ++z) v += src[(long)z * stride4];
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * (int)(i % c4n));
         if (accumulate) v += dbn_ld4<AT>(dst, i);
         dbn_st4<AT>(dst, i, v);
@@ -1809,7 +1815,7 @@ long dbn_wgrad_slab_floats_hw(int N, int Ho, int Wo, int O, int H, int W, int Cb
     if (nmax < 1) return 0;
     long splits = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) splits += wgrad_splitk_one(std::min(nmax, N - n0), Ho, Wo, O, Cb, R, S);
-    return splits * O * Jp;
+    return splits * wgrad_slab_stride(O, Jp);
 }
 // (without the size of X: exact for calls that run as one launch — N*Ho*Wo < 2^24 pixels and X below 3.75 GB)
 long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
@@ -1837,7 +1843,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         const int n = std::min(nmax, N - n0);
         WgradParams p;
         p.sm = sm + (long)n0 * Ho * Wo * O * es; p.big = big + (long)n0 * H * W * Cb * es;
-        p.slab = slab + (long)splits_total * O * Jp;
+        p.slab = slab + (long)splits_total * wgrad_slab_stride(O, Jp);
         p.N = n; p.Ho = Ho; p.Wo = Wo; p.O = O; p.H = H; p.W = W; p.Cb = Cb; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
         p.P = n * Ho * Wo;
         p.J = J;

@@ -280,7 +280,7 @@ class Engine:
         if self.splitk and (mode == 0 or stride == 1):
             ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
             if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
-                slab = self.scratch('_splitk_slab', ks * N * Hd * Wd * Cd)
+                slab = self.scratch('_splitk_slab', ks * (N * Hd * Wd * Cd + 1088))  # slabs are padded apart (HBM channel rotation)
         check(self.L.dbn_igemm_t(self.at, self.ns, *args, ks, _p(slab), self.stream), what)
 
     batched_repack = True

@@ -77,7 +77,7 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
  * `ksplit` workgroup rows each reduce a contiguous range of k-tiles into their own slab, a second kernel sums the
  * slabs in fixed order and applies bias / accumulate.  mode 0, or mode 1 with stride 1; Cs % 16 == 0.
  * dbn_igemm_splitk_plan returns the split count the library would pick (1 = do not split);
- * slab: ksplit * N*Hd*Wd*Cd floats. */
+ * slab: ksplit * (N*Hd*Wd*Cd + 1088) floats (the slabs are padded apart so that consecutive splits land on different HBM channels). */
 int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs);
 int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
@@ -263,7 +263,7 @@ long dbn_igemm_panel_floats_t(int kind, int O, int I, int R, int S, int mode, in
 int dbn_pack_weights_t(int kind, const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int cs, float* out, void* stream);
 
 /* dbn_igemm_f32 / _bf16s / _splitk_f32 in one: at = storage of src / dst (16-bit storage: ns = 1, Cs % 16 == 0), ns = matrix math
- * (0 exact fp32, 1 one 16-bit plane, 3 bf16x3), ksplit > 1 with `slab` (ksplit * N*Hd*Wd*Cd floats) = split-K */
+ * (0 exact fp32, 1 one 16-bit plane, 3 bf16x3), ksplit > 1 with `slab` (ksplit * (N*Hd*Wd*Cd + 1088) floats) = split-K */
 int dbn_igemm_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                 int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ksplit, float* slab,
                 void* stream);

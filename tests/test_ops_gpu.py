@@ -568,7 +568,7 @@ def test_conv_splitk(case, ksplit, ns):
     dst = nhwc(base)
     Nn, Hs, Ws, Cs = src.shape
     _, Hd, Wd, _ = dst.shape
-    slab = torch.full((ksplit * dst.numel(), ), float('nan'), device=DEV)
+    slab = torch.full((ksplit * (dst.numel() + 1088), ), float('nan'), device=DEV)
     _lib.check(L().dbn_igemm_splitk_f32(src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(), Nn, Hs,
                                         Ws, Cs, Hd, Wd, Cd, k, k, s, p, mode, 1, 0, ns, ksplit, slab.data_ptr(), stream()), 'splitk')
     report('splitk conv %s ks=%d' % (case, ksplit), nchw(dst), base + ref.detach(), 1e-4, 1e-4)
@@ -841,7 +841,7 @@ def test_convolutions_on_16bit_storage(dtype, tile):
     w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
     ref = F.conv2d(rq(x), rq(w), b.double(), 1, 1)
     y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
-    slab = torch.empty(4 * y.numel(), device=DEV)
+    slab = torch.empty(4 * (y.numel() + 1088), device=DEV)
     igemm_t(xs, pack_t(w, 0, 1, kind, Ci), b.to(DEV), y, 3, 1, 1, 0, tile=tile, ksplit=4, slab=slab)
     report('split-K conv %s' % dtype, nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
 
