@@ -1879,6 +1879,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         int G = std::min(1024 / items, splits_total / 4);  // thread groups sharing the splits (>= 4 splits each)
         if (G < 1) G = 1;
         if (G > 32) G = 32;
+        if (const char* e = getenv("DBN_REDUCE_G")) G = std::max(1, std::min(atoi(e), 1024 / items > 0 ? 1024 / items : 1));  // experiments
         const int threads = std::min(1024, (items * G + 63) / 64 * 64);
         const size_t smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)R * S * 64 * sizeof(float);
         hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,

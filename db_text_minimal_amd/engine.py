@@ -116,6 +116,7 @@ class Engine:
         # fill each other's ramps and tails: 36.6 -> 34.9 ms/step at bs16 640^2.  (Tried and rejected: letting the weight
         # gradient overlap only the HBM-bound BatchNorm backward of the next layer — slower than a single stream.)
         self.overlap_wgrad = True
+        self.overlap_head_branches = True  # forward: threshold branch of the head on the second stream
         self.side_priority = None  # HIP stream priority of the side stream (None: default)
         self._side = None
         self._side_used = False
@@ -599,11 +600,15 @@ class Engine:
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
 
-        # the two branches are independent until the head-tail kernel: the threshold branch runs on the second stream
-        with self.side_stream():
+        # the two branches are independent until the head-tail kernel: the threshold branch may run on the second stream
+        if self.overlap_head_branches:
+            with self.side_stream():
+                branch('thresh')
+            branch('binarize')
+            self.join_side()
+        else:
             branch('thresh')
-        branch('binarize')
-        self.join_side()
+            branch('binarize')
         ch = 3 if train else 2
         (yb_, sb_, hb_), (yt_, st_, ht_) = z1['binarize'], z1['thresh']
         Hh, Wh = yb_.shape[1], yb_.shape[2]
