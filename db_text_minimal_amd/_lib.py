@@ -79,6 +79,8 @@ SIGNATURES.update({
     'dbn_conv_bn_t': 'i' + SIGNATURES['dbn_conv_bn_f32'],
     'dbn_pyramid_conv_t': 'i' + SIGNATURES['dbn_pyramid_conv_f32'],
     'dbn_wgrad_t': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
+    'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
+    'dbn_wgrad_tile_config': 'ii',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,
     'dbn_bn_train_stats_t': 'i' + SIGNATURES['dbn_bn_train_stats'],

@@ -1822,9 +1822,18 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S, 4);
 }
 
+// Tile variant dbn_wgrad_* uses for O output channels and J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64
+// (wgrad_f32_kernel<BM, BN, 2, 2, ns, at> in a rocprofv3 trace)
+int dbn_wgrad_tile_config(int O, int J) {
+    int bm, bn;
+    wgrad_tiles(O, J, bm, bn);
+    return bn == 192 ? 1 : (bm == 128 ? 2 : (bn == 128 ? 3 : 4));
+}
+
+// phases: 1 = the MFMA kernels (activations -> slabs), 2 = the slab reduction (slabs -> gradient), 3 = both
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
-                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0) {
-    DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3));
+                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0, int phases = 3) {
+    DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3) && phases >= 1 && phases <= 3);
     DBN_REQUIRE(at == 0 || (at == 1 && ns == 1));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
     const char* sm = reinterpret_cast<const char*>(sm_);
@@ -1854,6 +1863,10 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);
         p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
         dim3 grid((O / bm) * njt * splitk);
+        if (!(phases & 1)) {
+            splits_total += splitk;
+            continue;
+        }
 #define DBN_WGRAD_LAUNCH(NS_, AT_)                                                                            \
     do {                                                                                                    \
         if (bn == 192)                                                                                      \
@@ -1874,6 +1887,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         if (rc) return rc;
         splits_total += splitk;
     }
+    if (!(phases & 2)) return DBN_OK;
     if (Cb % 64 == 0 && R * S * 64 * 4 <= 32 * 1024) {
         const int items = R * S * 16;
         int G = std::min(1024 / items, splits_total / 4);  // thread groups sharing the splits (>= 4 splits each)
@@ -1902,6 +1916,14 @@ int dbn_set_index_limits(long pixel_rows, long bytes, long elems) {
 int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                 int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
     return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, stream, at);
+}
+// The two phases of dbn_wgrad_t as separate calls (same arguments): phase 1 = the matrix kernels (-> slabs), phase 2 = the
+// slab reduction (-> grad_oihw).  For instrumentation (an event bracket around one kernel symbol) and for callers that want to
+// put other work between them.
+int dbn_wgrad_phase_t(int phase, int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo,
+                      int O, int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
+    DBN_REQUIRE(phase == 1 || phase == 2);
+    return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, stream, at, phase);
 }
 
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

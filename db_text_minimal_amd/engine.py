@@ -41,6 +41,8 @@ def flat_layout(numels):
 
 IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d>',
                     3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d>'}  # rocprof names
+WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d>',
+                    3: 'wgrad_f32_kernel<64,128,2,2,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d>'}
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
@@ -116,7 +118,11 @@ class Engine:
         # fill each other's ramps and tails: 36.6 -> 34.9 ms/step at bs16 640^2.  (Tried and rejected: letting the weight
         # gradient overlap only the HBM-bound BatchNorm backward of the next layer — slower than a single stream.)
         self.overlap_wgrad = True
-        self.overlap_head_branches = True  # forward: threshold branch of the head on the second stream
+        # forward: the threshold branch of the head beside the binarize branch on the second stream?  Two MFMA-bound kernels
+        # sharing the matrix pipe is zero-sum (measured: two conv streams take exactly 2x each); what the overlap hides is the few
+        # HBM-bound kernels in between: 31.9 vs 32.05 ms/step, at the price of every launch of the two big 256->64 convs running
+        # at half speed.  Off: the kernels run undisturbed (the dominant kernel's timed-region rate 76 -> 94 TFLOP/s).
+        self.overlap_head_branches = False
         self.side_priority = None  # HIP stream priority of the side stream (None: default)
         self._side = None
         self._side_used = False
@@ -410,12 +416,18 @@ class Engine:
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
         slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
-        if self.prof:
-            self.prof.begin('wgrad_f32_kernel+reduce', 2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
-        check(self.L.dbn_wgrad_t(self.at, self.ns, sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W,
-                                 Cb, I, k, k, stride, pad, self.grad_scale, self.stream), 'wgrad ' + name)
-        if self.prof:
+        args = (self.at, self.ns, sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride,
+                pad, self.grad_scale, self.stream)
+        if self.prof:  # bracket the matrix kernel alone (its rocprofv3 symbol), then the slab reduction
+            self.prof.begin(WGRAD_TILE_NAMES[self.L.dbn_wgrad_tile_config(O, k * k * Cb)] % (self.ns, self.at),
+                            2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
+            check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)
             self.prof.end()
+            self.prof.begin('wgrad_reduce_kernel', 0.0, 0.0, 'wgrad reduce ' + name)
+            check(self.L.dbn_wgrad_phase_t(2, *args), 'wgrad reduce ' + name)
+            self.prof.end()
+        else:
+            check(self.L.dbn_wgrad_t(*args), 'wgrad ' + name)
 
     def conv_wgrad(self, name, dy, x, conv):
         with self.side_stream():

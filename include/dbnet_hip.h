@@ -280,6 +280,12 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
 int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                 int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
 
+/* tile variant of the weight-gradient kernel for O output channels, J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64 */
+int dbn_wgrad_tile_config(int O, int J);
+/* dbn_wgrad_t in two calls: phase 1 = matrix kernels (-> slabs), phase 2 = slab reduction (-> grad_oihw) */
+int dbn_wgrad_phase_t(int phase, int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo,
+                      int O, int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
+
 int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
                          float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                          float* ws, void* stream);
