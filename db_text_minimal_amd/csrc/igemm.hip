@@ -73,6 +73,7 @@ struct IgemmParams {
     int stat_row0;      // first row this launch writes
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
     unsigned src_bytes;
+    unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
     // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
@@ -82,6 +83,7 @@ struct IgemmParams {
     const void* seg_src[4];
     const float* seg_wpk[4];
     unsigned seg_bytes[4];
+    unsigned seg_plane_bytes[4];  // AT = 3
 };
 
 constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
@@ -196,16 +198,21 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 // AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
 // of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
 // stored format), the accumulators are rounded to the storage type on the way out.
+// AT = 3 (NS = 3): src is the PRE-SPLIT form of an fp32 tensor — three bf16 planes [3][N,H,W,C] with a0 + a1 + a2 == a exactly
+// (dbn_split3) — gathered the same way (3 x 2 pieces per row and k-tile, no conversion: splitting at staging time redid the
+// split for every one of the 9 taps that re-reads an element and made the bf16x3 kernels VALU-bound); dst is fp32.
 template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void igemm_f32_kernel(const IgemmParams p) {
-    static_assert(AT == 0 || NS == 1, "16-bit activation storage runs on the single-plane 16-bit matrix path");
+    static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int ES = AT == 0 ? 4 : 2;            // bytes per stored element
-    constexpr int A_SH = AT == 0 ? 2 : 1;          // threads per row = 1 << A_SH (4 x 4 fp32 channels, or 2 x 8 16-bit channels)
+    constexpr int ES = AT == 0 ? 4 : 2;            // bytes per stored source element
+    constexpr bool DST_F32 = AT == 0 || AT == 3;
+    constexpr int NP = AT == 3 ? 3 : 1;            // 16-bit planes of the source
+    constexpr int A_SH = AT == 0 ? 2 : 1;          // pieces per row and plane = 1 << A_SH (4 x 4 fp32 channels, or 2 x 8 16-bit channels)
     constexpr int A_CH = AT == 0 ? 4 : 8;          // channels per 16-byte piece
-    constexpr int A_PIECES = BM << A_SH;           // 16-byte pieces of the A panel per k-tile
+    constexpr int A_PIECES = (BM << A_SH) * NP;    // 16-byte pieces of the A panel per k-tile
     constexpr int A_LD = (A_PIECES + NT - 1) / NT;  // gathers per thread per k-tile
     constexpr bool A_FULL = A_PIECES % NT == 0;
     // LDS image in 16-byte units.  NS == 0: [k/4][row][4 f32], chunk stride +2 keeps ds_write_b128 conflict-free.
@@ -268,16 +275,23 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
 
     // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
+    // piece q = tid + j*NT of the k-tile: fp32 source: chunk q & 3 of row q >> 2; 16-bit source: half q & 1 of row (q >> 1) % BM
+    // of plane (q >> 1) / BM
     const int a_chunk = tid & ((1 << A_SH) - 1);
-    const bool a_on = A_FULL || tid < A_PIECES;  // (64-row tiles of the 16-bit path: half of the threads gather)
+    auto a_row = [&](int j) { return AT == 0 ? (tid >> 2) + j * (NT / 4) : ((tid + j * NT) >> 1) % BM; };
+    auto a_plane = [&](int j) { return AT == 0 ? 0 : ((tid + j * NT) >> 1) / BM; };
+    auto a_on = [&](int j) { return A_FULL || tid + j * NT < A_PIECES; };  // (the last j of tiles whose piece count is not a multiple of NT)
     int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
+    unsigned a_pl[A_LD];  // byte offset of the piece's plane
+    unsigned plane_bytes = p.plane_bytes;
     int a_n[MODE == 3 ? A_LD : 1], a_hd[MODE == 3 ? A_LD : 1], a_wd[MODE == 3 ? A_LD : 1];
     const int HWd = qHd * qWd;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const int row = (tid >> A_SH) + j * (NT >> A_SH);
+        const int row = a_row(j);
         const int m = m0 + row;
-        const bool ok = m < qM && a_on;
+        const bool ok = m < qM && a_on(j);
+        a_pl[j] = (unsigned)a_plane(j) * plane_bytes;
         const int mm = ok ? m : 0;
         int n, rem, hd, wd;  // reciprocal divisions (exact below 2^24): an integer division costs ~35 VALU instructions
         divmod24(mm, HWd, 1.0f / (float)HWd, n, rem);
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
             const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
             const bool v = kidx < qK && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
-            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES;
+            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES + (AT == 3 ? a_pl[j] : 0u);
             aoff[j] = v ? off : OOB_OFFSET;
         }
         kidx += 16;
@@ -383,6 +397,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         gHs = p.Hdf >> g;
         gWs = p.Wdf >> g;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        if (AT == 3) {
+            plane_bytes = p.seg_plane_bytes[g];
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) a_pl[j] = (unsigned)a_plane(j) * plane_bytes;
+        }
         long krows = 0;  // padded-K rows of the classes packed before (ph, pw)
         for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
         panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2));
@@ -426,10 +445,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
         } else if constexpr (AT != 0) {
-            // stored 16-bit channels: the piece IS the LDS slot [k/8 = a_chunk][row] of the single-plane image
+            // stored 16-bit channels: the piece IS the LDS slot [plane][k/8 = a_chunk][row] of the image
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
-                if (A_FULL || a_on) As[a_chunk * AS + (tid >> A_SH) + j * (NT >> A_SH)] = ra[j];
+                if (a_on(j)) As[(a_plane(j) * 2 + a_chunk) * AS + a_row(j)] = ra[j];
         } else {
             // chunk c holds k = 4c..4c+3 of the k-tile: bf16 image slot [c>>1][row], 8-byte half (c&1)
 #pragma unroll
@@ -525,10 +544,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     const bool to_slab = MODE < 2 && p.ksplit > 1;
     float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * ((long)qM * p.Cd + 1088) : 0L);
     void* const dstv = p.dst;
-    auto ld_dst = [&](long off) -> float { return (AT == 0 || to_slab) ? slabp[off] : dbn_ld1<AT>(dstv, off); };
+    auto ld_dst = [&](long off) -> float { return (DST_F32 || to_slab) ? slabp[off] : dbn_ld1 < DST_F32 ? 0 : AT > (dstv, off); };
     auto st_dst = [&](long off, float v) {
-        if (AT == 0 || to_slab) slabp[off] = v;
-        else dbn_st1<AT>(dstv, off, v);
+        if (DST_F32 || to_slab) slabp[off] = v;
+        else dbn_st1 < DST_F32 ? 0 : AT > (dstv, off, v);
     };
     const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
     // fn(r, doff) for the 16 rows this lane holds of accumulator block a (rows base + (r&3) + 8*(r>>2)) that are < M.
@@ -721,6 +740,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_igemm(IgemmParams& p, int mode, int ns, hipStream_t st, int at = 0) {
     if (at == 1) return ns == 1 ? launch_igemm_ns<BM, BN, WM, WN, 1, 1>(p, mode, st) : DBN_ERR_ARG;
     if (at == 2) return ns == 1 ? launch_igemm_ns<BM, BN, WM, WN, 1, 2>(p, mode, st) : DBN_ERR_ARG;
+    if (at == 3) return ns == 3 ? launch_igemm_ns<BM, BN, WM, WN, 3, 3>(p, mode, st) : DBN_ERR_ARG;
     if (ns == 0) return launch_igemm_ns<BM, BN, WM, WN, 0>(p, mode, st);
     if (ns == 1) return launch_igemm_ns<BM, BN, WM, WN, 1>(p, mode, st);
     return launch_igemm_ns<BM, BN, WM, WN, 3>(p, mode, st);
@@ -742,6 +762,7 @@ struct WgradParams {
     int P, J, pchunk;
     float rcp_HWo, rcp_Wo;
     unsigned sm_bytes, big_bytes;
+    unsigned sm_plane_bytes, big_plane_bytes;  // AT = 3: distance of the three bf16 planes of each operand
 };
 
 // Position <-> index permutation of a tile edge of length B (B % 4 == 0): the staging threads
@@ -754,8 +775,10 @@ __host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { retu
 // 8-byte loads and transpose the 16-bit values with two bit operations per output word — no conversion.
 template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
-    static_assert(AT == 0 || (AT == 1 && NS == 1), "bf16 storage runs on the single-plane bf16 matrix path");
+    // AT = 3 (NS = 3): both operands are pre-split fp32 tensors (three bf16 planes each, dbn_split3): as AT = 1, three times.
+    static_assert(AT == 0 || (AT == 1 && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     constexpr unsigned ES = AT == 0 ? 4u : 2u;
+    constexpr int NP = AT == 3 ? 3 : 1;
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -808,7 +831,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int lds_base = (is_a ? 0 : A_IMG) + s_c;
 
     f32x4 rr[4];        // AT = 0: 4 pixels x 4 fp32 channels
-    u32x2 rh[4];        // AT = 1: 4 pixels x 4 bf16 channels
+    u32x2 rh[NP][4];    // AT = 1 / 3: per plane 4 pixels x 4 bf16 channels
     unsigned woff[4];
     // byte offsets of this thread's 4 loads for k-tile kt (address math kept apart from the loads so that it
     // can be issued in the shadow of the previous tile's MFMAs)
@@ -864,12 +887,20 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                 for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs_big, woff[i]);
             }
         } else {
+            // (an out-of-range offset must stay out of range: the plane distance is added to valid offsets only)
+            const unsigned pl = is_a ? p.sm_plane_bytes : p.big_plane_bytes;
             if (is_a) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rh[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_sm, (int)woff[i], 0, 0);
+                for (int t = 0; t < NP; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        rh[t][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_sm, (int)(woff[i] == OOB_OFFSET ? OOB_OFFSET : woff[i] + t * pl), 0, 0);
             } else if (is_b) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rh[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_big, (int)woff[i], 0, 0);
+                for (int t = 0; t < NP; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        rh[t][i] = __builtin_amdgcn_raw_buffer_load_b64(rs_big, (int)(woff[i] == OOB_OFFSET ? OOB_OFFSET : woff[i] + t * pl), 0, 0);
             }
         }
     };
@@ -882,12 +913,14 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             } else if constexpr (AT != 0) {
                 // channel e of pixels 0..3 -> one 8-byte half slot: word = (pixel a | pixel b << 16) of the channel's 16 bits
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned a0 = rh[0][e >> 1], a1 = rh[1][e >> 1], a2 = rh[2][e >> 1], a3 = rh[3][e >> 1];
-                    const u32x2 o = (e & 1) ? u32x2{(a0 >> 16) | (a1 & 0xFFFF0000u), (a2 >> 16) | (a3 & 0xFFFF0000u)}
-                                            : u32x2{(a0 & 0xFFFFu) | (a1 << 16), (a2 & 0xFFFFu) | (a3 << 16)};
-                    reinterpret_cast<u32x2*>(dst + (s_g >> 1) * ld + e * qn)[s_g & 1] = o;
-                }
+                for (int t = 0; t < NP; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned a0 = rh[t][0][e >> 1], a1 = rh[t][1][e >> 1], a2 = rh[t][2][e >> 1], a3 = rh[t][3][e >> 1];
+                        const u32x2 o = (e & 1) ? u32x2{(a0 >> 16) | (a1 & 0xFFFF0000u), (a2 >> 16) | (a3 & 0xFFFF0000u)}
+                                                : u32x2{(a0 & 0xFFFFu) | (a1 << 16), (a2 & 0xFFFFu) | (a3 << 16)};
+                        reinterpret_cast<u32x2*>(dst + (t * 2 + (s_g >> 1)) * ld + e * qn)[s_g & 1] = o;
+                    }
             } else {
                 // pixel group g = k 4g..4g+3 of the k-tile: bf16 image slot [g>>1][pos], 8-byte half (g&1)
 #pragma unroll
@@ -1331,6 +1364,20 @@ __global__ void pack_many_kernel(const PackJob* __restrict__ jobs, int NS) {
     }
 }
 
+// fp32 -> three bf16 planes with a0 + a1 + a2 == a exactly (round-to-nearest-even at each step; 24 mantissa bits = 3 x 8):
+// planes[t][i], t = 0..2, plane distance `plane_elems` elements.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ planes, long n4,
+                                                     long plane_elems) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+        u32x2 sp[3];
+        split4<3>(v, sp);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) reinterpret_cast<u32x2*>(planes + t * plane_elems)[i] = sp[t];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1398,6 +1445,10 @@ static int chunk_images(int N, long px_rows, long src_bytes_per_image, long dst_
     return (int)n;  // 0: a single image does not fit
 }
 
+// bytes per element of the destination of a conv (at = 3: pre-split bf16 planes in, fp32 out) and planes of its source
+static inline int dst_esize(int at) { return (at == 0 || at == 3) ? 4 : 2; }
+static inline int src_planes(int at) { return at == 3 ? 3 : 1; }
+
 static int resolve_cfg(int M_total, int Cd, int tile_hint) {
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
@@ -1406,14 +1457,17 @@ static int resolve_cfg(int M_total, int Cd, int tile_hint) {
 
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
-                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at) {
+                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
+                         long plane_bytes) {
     IgemmParams p;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
     p.stats = stats; p.stat_rows = stat_rows; p.stat_row0 = stat_row0; p.launch_rows = 0;
     p.ksplit = 1; p.kt_per = 0;
-    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * dbn_esize(at));
+    // (at = 3: planes 1 and 2 lie plane_bytes and 2*plane_bytes behind the image range of plane 0 this launch covers)
+    p.plane_bytes = (unsigned)plane_bytes;
+    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * dbn_esize(at) + (src_planes(at) - 1) * plane_bytes);
     if (!(mode == 1 && stride > 1)) {
         p.ncls = 1;
         if (ksplit <= 1) {
@@ -1431,8 +1485,8 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
         *rows_out = p.launch_rows;
         if (rc) return rc;
         const long total4 = (long)N * Hd * Wd * Cd / 4;
-        DBN_DISPATCH_AT(at, hipLaunchKernelGGL(splitk_sum_kernel<AT>, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit, total4, Cd,
-                                               bias, accumulate, dst));
+        DBN_DISPATCH_AT(at == 3 ? 0 : at, hipLaunchKernelGGL(splitk_sum_kernel<AT>, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit,
+                                                             total4, Cd, bias, accumulate, dst));
         return dbn_status();
     }
     DBN_REQUIRE(ksplit <= 1);
@@ -1449,7 +1503,7 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     DBN_REQUIRE(off < (1L << 31));
     DBN_REQUIRE(covered == p.ncls || !bias);  // a bias would have to reach the tap-less pixels too
     if (covered < p.ncls && !accumulate) {  // some output pixels receive no tap: they are zero
-        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * dbn_esize(at), st) != hipSuccess) return dbn_status();
+        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * dst_esize(at), st) != hipSuccess) return dbn_status();
         p.accumulate = 1;
     }
     *rows_out = 0;
@@ -1476,13 +1530,16 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                      void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
-    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0));  // 16-bit storage: 8-channel pieces of 16-channel blocks
+    // 16-bit storage / pre-split planes: 8-channel pieces of 16-channel blocks
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0) || (at == 3 && ns == 3 && Cs % 16 == 0));
     DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
     DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
     DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
     DBN_REQUIRE(tile_hint >= 0 && tile_hint <= 4);
     hipStream_t st = (hipStream_t)stream;
-    const int es = dbn_esize(at);
+    const int es = dbn_esize(at), des = dst_esize(at);
+    const long plane_bytes = at == 3 ? (long)N * Hs * Ws * Cs * 2 : 0;  // the planes of the WHOLE tensor are this far apart
+    DBN_REQUIRE(3 * plane_bytes < g_byte_limit);
     const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * es, (long)Hd * Wd * Cd);
     DBN_REQUIRE(nmax >= 1);               // one image must fit the kernel's index ranges
     DBN_REQUIRE(nmax >= N || ksplit <= 1);  // split-K is for small outputs only
@@ -1492,12 +1549,20 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
         const int n = std::min(nmax, N - n0);
         int rows = 0;
         const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
-                                     reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * es, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
-                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at);
+                                     reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
+                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes);
         if (rc) return rc;
         row0 += rows;
     }
     return DBN_OK;
+}
+
+// planes: [3][n] bf16 (n % 4 == 0) — the pre-split form of an fp32 tensor that the at = 3 entry points consume
+int dbn_split3(const float* src, void* planes, long n, void* stream) {
+    DBN_REQUIRE(src && planes && n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(split3_kernel, dim3(dbn_grid(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, src,
+                       reinterpret_cast<unsigned short*>(planes), n / 4, n);
+    return dbn_status();
 }
 
 // General form.  at: activation storage type of src / dst (DBN_AT_*; 16-bit storage needs ns = 1 and Cs % 16 == 0, panels from
@@ -1617,8 +1682,8 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
                        int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
                        float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
-    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1));
-    const int es = dbn_esize(at);
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1) || (at == 3 && ns == 3));
+    const int es = dbn_esize(at), des = dst_esize(at);
     DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
     DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
     const bool bn = gamma != nullptr;
@@ -1637,9 +1702,12 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         for (int g = 0; g < 4; ++g) {
             p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs * es;
             p.seg_wpk[g] = wpks[g];
-            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * es);
+            const long pl = at == 3 ? (long)N * (H >> g) * (W >> g) * Cs * 2 : 0;  // plane distance of level g (whole tensor)
+            p.seg_plane_bytes[g] = (unsigned)pl;
+            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * es + 2 * pl);
         }
-        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * es;
+        p.plane_bytes = p.seg_plane_bytes[0];
+        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * des;
         p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
         p.stats = bn ? ws : nullptr;
@@ -1834,8 +1902,10 @@ int dbn_wgrad_tile_config(int O, int J) {
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                      int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0, int phases = 3) {
     DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3) && phases >= 1 && phases <= 3);
-    DBN_REQUIRE(at == 0 || (at == 1 && ns == 1));
+    DBN_REQUIRE(at == 0 || (at == 1 && ns == 1) || (at == 3 && ns == 3));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
+    const long sm_plane = at == 3 ? (long)N * Ho * Wo * O * 2 : 0, big_plane = at == 3 ? (long)N * H * W * Cb * 2 : 0;
+    DBN_REQUIRE(3 * sm_plane < g_byte_limit && 3 * big_plane < g_byte_limit);
     const char* sm = reinterpret_cast<const char*>(sm_);
     const char* big = reinterpret_cast<const char*>(big_);
     const int es = dbn_esize(at);
@@ -1858,8 +1928,10 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         p.J = J;
         p.rcp_HWo = 1.0f / (float)(Ho * Wo);
         p.rcp_Wo = 1.0f / (float)Wo;
-        p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * es);
-        p.big_bytes = (unsigned)((long)n * H * W * Cb * es);
+        p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * es + 2 * sm_plane);
+        p.big_bytes = (unsigned)((long)n * H * W * Cb * es + 2 * big_plane);
+        p.sm_plane_bytes = (unsigned)sm_plane;
+        p.big_plane_bytes = (unsigned)big_plane;
         const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);
         p.pchunk = (int)((((long)p.P + splitk - 1) / splitk + 15) / 16 * 16);
         dim3 grid((O / bm) * njt * splitk);
@@ -1879,6 +1951,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
             hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);      \
     } while (0)
         if (at == 1) DBN_WGRAD_LAUNCH(1, 1);
+        else if (at == 3) DBN_WGRAD_LAUNCH(3, 3);
         else if (ns == 0) DBN_WGRAD_LAUNCH(0, 0);
         else if (ns == 1) DBN_WGRAD_LAUNCH(1, 0);
         else DBN_WGRAD_LAUNCH(3, 0);

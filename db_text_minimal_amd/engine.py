@@ -108,6 +108,12 @@ class Engine:
         self._live = None
         self.nbt_pending = {}
         self._bias_done = set()
+        self._by_ptr = {}       # data_ptr -> activation buffer (to find the pre-split planes of an operand)
+        self._plane_cache = {}  # data_ptr -> (planes, generation)
+        # 'bf16x3' mode: MFMA operands are read from pre-split bf16 planes (made once per tensor and step by dbn_split3) instead
+        # of being split when staged — the split was redone for every tap that re-reads an element (9x in a 3x3 conv, again in
+        # the data and weight gradients) and made the bf16x3 kernels VALU-bound
+        self.presplit = True
         self.prof = None  # optional KernelTimer
         self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
         self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = one 16-bit plane
@@ -158,6 +164,7 @@ class Engine:
             self.grad_views[n] = grad[off:off + p.numel()].view(p.shape)
         self.flat, self.flat_grad, self.offsets = flat, grad, offs
         self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
+        self._by_ptr, self._plane_cache = {}, {}
         self.param_epoch += 1
 
     def flush_counters(self):
@@ -186,6 +193,7 @@ class Engine:
         ns, at = self.MATH_MODES[mode]
         if at != self.at:  # other storage type: every activation buffer and weight panel is stale
             self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
+            self._by_ptr, self._plane_cache = {}, {}
             self.saved_generation = -1
         self.ns, self.at = ns, at
         self.math_mode = mode
@@ -208,6 +216,7 @@ class Engine:
         if t is None or tuple(t.shape) != tuple(shape) or t.device != dev or t.dtype != dtype:
             t = torch.empty(shape, device=dev, dtype=dtype)
             self.bufs[name] = t
+            self._by_ptr[t.data_ptr()] = t
         return t
 
     def fbuf(self, name, *shape):
@@ -280,15 +289,48 @@ class Engine:
         self.packs[key] = (out, stamp)
         return out
 
+    def _planes(self, t):
+        """The pre-split form [3][...] (bf16) of the fp32 activation tensor `t`, made once per step on first use."""
+        key = t.data_ptr()
+        ent = self._plane_cache.get(key)
+        if ent is not None and ent[1] == self.generation:
+            return ent[0]
+        # (inside a side-stream region this runs on the side stream: fine for tensors produced there — the main stream only sees
+        # them after join_side(); operands that BOTH streams read are pre-split on the main stream first, see _presplit)
+        pl = self.buf('#planes/%x' % key, 3, *t.shape, dtype=torch.bfloat16)
+        check(self.L.dbn_split3(t.data_ptr(), pl.data_ptr(), t.numel(), self.stream), 'split3')
+        self._plane_cache[key] = (pl, self.generation)
+        return pl
+
+    @property
+    def _use_planes(self):
+        return self.at == 0 and self.ns == 3 and self.presplit
+
+    def _presplit(self, *tensors):
+        """Make sure the planes of these operands exist (on the CURRENT stream) before work is handed to the side stream."""
+        if self._use_planes:
+            for t in tensors:
+                if t is not None and t.dtype == torch.float32 and t.numel() % 4 == 0:
+                    self._planes(t)
+
+    def _src(self, ptr, C):
+        """(activation type, pointer) of the source operand of a conv: its pre-split planes in the bf16x3 mode."""
+        if self._use_planes and C % 16 == 0:
+            t = self._by_ptr.get(ptr)
+            if t is not None and t.dtype == torch.float32 and t.data_ptr() == ptr:
+                return 3, self._planes(t).data_ptr()
+        return self.at, ptr
+
     def _igemm(self, what, *args):
         """args = the dbn_igemm_f32 argument list without the trailing stream."""
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
+        at, srcp = self._src(args[0], Cs)
         ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):
             ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
             if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
                 slab = self.scratch('_splitk_slab', ks * (N * Hd * Wd * Cd + 1088))  # slabs are padded apart (HBM channel rotation)
-        check(self.L.dbn_igemm_t(self.at, self.ns, *args, ks, _p(slab), self.stream), what)
+        check(self.L.dbn_igemm_t(at, self.ns, srcp, *args[1:], ks, _p(slab), self.stream), what)
 
     batched_repack = True
 
@@ -353,7 +395,8 @@ class Engine:
         mu, rs = self.fbuf(bn_name + '/mean', C), self.fbuf(bn_name + '/rstd', C)
         N, Hd, Wd = y.shape[0], y.shape[1], y.shape[2]
         ws = self.scratch('_conv_bn_ws', self.L.dbn_conv_bn_ws_floats(N, Hd, Wd, C, mode, stride))
-        check(self.L.dbn_conv_bn_t(self.at, *args, accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+        at, srcp = self._src(args[0], args[7])
+        check(self.L.dbn_conv_bn_t(at, srcp, *args[1:], accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), what)
         self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
@@ -399,7 +442,8 @@ class Engine:
         return y, sc, sh
 
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
-        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns, self.at), flops, 0.0, tag)
+        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns, 3 if self._use_planes else self.at), flops,
+                        0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None):
         N, Ho, Wo, O = dy.shape
@@ -416,10 +460,13 @@ class Engine:
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
         slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
-        args = (self.at, self.ns, sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride,
+        at, smp, bigp = self.at, sm.data_ptr(), big.data_ptr()
+        if self._use_planes and sm.dtype == torch.float32 and big.dtype == torch.float32:
+            at, smp, bigp = 3, self._planes(sm).data_ptr(), self._planes(big).data_ptr()
+        args = (at, self.ns, smp, bigp, slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride,
                 pad, self.grad_scale, self.stream)
         if self.prof:  # bracket the matrix kernel alone (its rocprofv3 symbol), then the slab reduction
-            self.prof.begin(WGRAD_TILE_NAMES[self.L.dbn_wgrad_tile_config(O, k * k * Cb)] % (self.ns, self.at),
+            self.prof.begin(WGRAD_TILE_NAMES[self.L.dbn_wgrad_tile_config(O, k * k * Cb)] % (self.ns, at),
                             2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
             check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)
             self.prof.end()
@@ -430,6 +477,7 @@ class Engine:
             check(self.L.dbn_wgrad_t(*args), 'wgrad ' + name)
 
     def conv_wgrad(self, name, dy, x, conv):
+        self._presplit(dy, x)
         with self.side_stream():
             self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
             if conv.bias is not None and name + '.bias' not in self._bias_done:
@@ -457,6 +505,7 @@ class Engine:
                     2, 0, 0, 0, 0)
         if self.prof:
             self.prof.end()
+        self._presplit(x, dy)
         with self.side_stream():
             self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
             if ct.bias is not None and name + '.bias' not in self._bias_done:
@@ -574,6 +623,7 @@ class Engine:
                 cur = self._block_fwd('backbone.layer%d.%d' % (li, bi), blk, cur, train)
             feats.append(cur)
             if li < 4:  # the FPN's lateral 1x1 conv of this stage (tiny, under-filled grid) runs on the second stream
+                self._presplit(cur)
                 with self.side_stream():  # beside the next backbone stage
                     lateral[li] = cbr('reduce_conv_c%d' % (li + 1), getattr(fpn, 'reduce_conv_c%d' % (li + 1)), cur)
         c2, c3, c4, c5 = feats
@@ -614,6 +664,7 @@ class Engine:
 
         # the two branches are independent until the head-tail kernel: the threshold branch may run on the second stream
         if self.overlap_head_branches:
+            self._presplit(f)
             with self.side_stream():
                 branch('thresh')
             branch('binarize')
@@ -907,7 +958,8 @@ class Engine:
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d>' % (self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                                'fwd %s (pyramid)' % name)
             if fused:
                 C = Co
                 sc, sh = self.fbuf(bn_name + '/scale', C), self.fbuf(bn_name + '/shift', C)
@@ -918,7 +970,10 @@ class Engine:
                 self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
             else:
                 bnargs = (None, None, 0.0, 0.0) + (None, ) * 7
-            check(self.L.dbn_pyramid_conv_t(self.at, *[z.data_ptr() for z in zs], *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
+            pat, zp = self.at, [z.data_ptr() for z in zs]
+            if self._use_planes and Cg % 16 == 0:
+                pat, zp = 3, [self._planes(z).data_ptr() for z in zs]
+            check(self.L.dbn_pyramid_conv_t(pat, *zp, *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
                                               N, H, W, Cg, Co, 0, self.ns, *bnargs, self.stream), 'pyramid_conv')
             if self.prof:
                 self.prof.end()
@@ -962,6 +1017,7 @@ class Engine:
                 self.prof.end()
             dP[nm] = d
             t = self.fbuf('%s#t%d' % (name, g), Cg, Co, k, k)
+            self._presplit(z, dy)
             with self.side_stream():
                 self.wgrad('%s level %d' % (name, g), z, dy, Cg, Co, k, f, 1, t)
             ts.append(t)

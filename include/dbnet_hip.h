@@ -256,6 +256,10 @@ int dbn_box_scores(const float* bitmap, int H, int W, const float* boxes, int K,
 #define DBN_AT_F32 0
 #define DBN_AT_BF16 1
 #define DBN_AT_F16 2
+/* conv / weight-gradient entry points only, with ns = 3 (bf16x3): the source operand(s) are PRE-SPLIT fp32 tensors — three
+ * bf16 planes [3][N,H,W,C] with a0 + a1 + a2 == a exactly, made by dbn_split3 — gathered without conversion; dst stays fp32 */
+#define DBN_AT_SPLIT3 3
+int dbn_split3(const float* src, void* planes, long n, void* stream);
 
 /* weight panels: kind 0 fp32, 1 bf16, 3 bf16x3 (three bf16 planes), 2 fp16.  cs: channels of the source tensor for mode 0
  * (0: I rounded up to 4; the 16-bit model input is stored with 16 channels) */

@@ -957,3 +957,36 @@ def test_batchnorm_and_pool_kernels_on_16bit_storage(dtype):
             assert float((a[k] - b[k]).abs().gt(eps * (1 + b[k].abs())).float().mean()) < 0.02
             continue
         report('16-bit %s %s' % (dtype, k), a[k], b[k], tol * float(b[k].abs().max()), tol)
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 4])
+def test_presplit_bf16x3_operands(tile):
+    """dbn_split3 + the at = DBN_AT_SPLIT3 entry points: an fp32 tensor split once into three bf16 planes (a0 + a1 + a2 == a
+    exactly) and gathered as stored gives BIT-IDENTICAL results to the ns = 3 path that splits at staging time (same terms, same
+    MFMA order) — forward conv, data gradient, strided transposed conv, weight gradient."""
+    N, Ci, Co, H, W = 3, 64, 128, 14, 18
+    x = nhwc(rnd(N, Ci, H, W, seed=1))
+    planes = torch.empty((3, ) + tuple(x.shape), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().dbn_split3(x.data_ptr(), planes.data_ptr(), x.numel(), stream()), 'split3')
+    assert torch.equal(planes.float().sum(0), x), 'the three bf16 terms do not sum to the fp32 value exactly'
+    assert float((planes[1].float().abs() - 2.0**-7 * planes[0].float().abs()).clamp_min(0).max()) == 0  # |a1| <= ulp(a0)/2
+    for (k, s_, p_, mode, wshape) in ((3, 1, 1, 0, (Co, Ci, 3, 3)), (3, 2, 1, 0, (Co, Ci, 3, 3)), (3, 1, 1, 1, (Ci, Co, 3, 3)), (2, 2, 0, 1, (Ci, Co, 2, 2))):
+        w = rnd(*wshape, seed=2, scale=0.05)
+        wpk = pack_t(w, mode, s_, 3, Ci if mode == 0 else 0)
+        Hd = (H + 2 * p_ - k) // s_ + 1 if mode == 0 else (H if s_ == 1 else 2 * H)
+        Wd = (W + 2 * p_ - k) // s_ + 1 if mode == 0 else (W if s_ == 1 else 2 * W)
+        ya, yb = (torch.full((N, Hd, Wd, Co), float('nan'), device=DEV) for _ in range(2))
+        igemm_t(x, wpk, None, ya, k, s_, p_, mode, tile=tile, ns=3)
+        _lib.check(L().dbn_igemm_t(3, 3, planes.data_ptr(), wpk.data_ptr(), None, yb.data_ptr(), N, H, W, Ci, Hd, Wd, Co, k, k, s_, p_, mode,
+                                   0, tile, 1, None, stream()), 'igemm_t split3')
+        assert torch.equal(ya, yb), ('pre-split operands change the result', k, s_, mode)
+    dy = nhwc(rnd(N, Co, H, W, seed=5))
+    dyp = torch.empty((3, ) + tuple(dy.shape), device=DEV, dtype=torch.bfloat16)
+    _lib.check(L().dbn_split3(dy.data_ptr(), dyp.data_ptr(), dy.numel(), stream()), 'split3')
+    slab = torch.empty(L().dbn_wgrad_slab_floats_hw(N, H, W, Co, H, W, Ci, 3, 3, 4), device=DEV)
+    ga, gb = (torch.full((Co, Ci, 3, 3), float('nan'), device=DEV) for _ in range(2))
+    _lib.check(L().dbn_wgrad_t(0, 3, dy.data_ptr(), x.data_ptr(), slab.data_ptr(), ga.data_ptr(), N, H, W, Co, H, W, Ci, Ci, 3, 3, 1, 1, 1.0,
+                               stream()), 'wgrad ns3')
+    _lib.check(L().dbn_wgrad_t(3, 3, dyp.data_ptr(), planes.data_ptr(), slab.data_ptr(), gb.data_ptr(), N, H, W, Co, H, W, Ci, Ci, 3, 3, 1, 1,
+                               1.0, stream()), 'wgrad split3')
+    assert torch.equal(ga, gb)
