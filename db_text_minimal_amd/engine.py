@@ -16,6 +16,7 @@ Data layout in HBM
     whenever the parameters change.
 """
 import contextlib
+import os
 
 import torch
 
@@ -110,10 +111,12 @@ class Engine:
         self._bias_done = set()
         self._by_ptr = {}       # data_ptr -> activation buffer (to find the pre-split planes of an operand)
         self._plane_cache = {}  # data_ptr -> (planes, generation)
-        # 'bf16x3' mode: MFMA operands are read from pre-split bf16 planes (made once per tensor and step by dbn_split3) instead
-        # of being split when staged — the split was redone for every tap that re-reads an element (9x in a 3x3 conv, again in
-        # the data and weight gradients) and made the bf16x3 kernels VALU-bound
-        self.presplit = True
+        # 'bf16x3' mode, optional (DBN_PRESPLIT=1 / engine.presplit): MFMA operands read from pre-split bf16 planes (made once per
+        # tensor and step by dbn_split3) instead of being split when staged.  Bit-identical results — and SLOWER (520 vs 634
+        # images/s): the planes are three separate tensors, so a row's k-tile arrives as 6 pieces of 16 B from 3 distant lines
+        # instead of one 64-byte run, and the gather, not the split arithmetic, is what bounds these kernels (igemm<128,64> 382 vs
+        # 273 us; 165 us would be MFMA-bound).  Kept as an option; an interleaved [.., C/16][3][16] plane layout is the next step.
+        self.presplit = os.environ.get('DBN_PRESPLIT', '0') == '1'
         self.prof = None  # optional KernelTimer
         self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
         self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = one 16-bit plane
