@@ -82,6 +82,9 @@ SIGNATURES.update({
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',
     'dbn_split3': 'pplp',
+    'dbn_deform_im2col_t': 'i' + SIGNATURES['dbn_deform_im2col'],
+    'dbn_deform_col2im_t': 'i' + SIGNATURES['dbn_deform_col2im'],
+    'dbn_cast_f32': 'ipplp',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,
     'dbn_bn_train_stats_t': 'i' + SIGNATURES['dbn_bn_train_stats'],

@@ -26,7 +26,8 @@ struct Sample {
     bool ok[4];
 };
 
-__device__ __forceinline__ Sample sample_of(const DeformDims& d, const float* __restrict__ offset, int m, int k, int& n, int& ho,
+template <int AT = 0>
+__device__ __forceinline__ Sample sample_of(const DeformDims& d, const void* __restrict__ offset, int m, int k, int& n, int& ho,
                                             int& wo) {
     const int HWo = d.Ho * d.Wo;
     n = m / HWo;
@@ -34,8 +35,8 @@ __device__ __forceinline__ Sample sample_of(const DeformDims& d, const float* __
     ho = rem / d.Wo;
     wo = rem - ho * d.Wo;
     const int r = k / d.S, s = k - r * d.S;
-    const float y = (float)(ho * d.stride - d.pad + r) + offset[(long)m * d.off_stride + 2 * k];
-    const float x = (float)(wo * d.stride - d.pad + s) + offset[(long)m * d.off_stride + 2 * k + 1];
+    const float y = (float)(ho * d.stride - d.pad + r) + dbn_ld1<AT>(offset, (long)m * d.off_stride + 2 * k);
+    const float x = (float)(wo * d.stride - d.pad + s) + dbn_ld1<AT>(offset, (long)m * d.off_stride + 2 * k + 1);
     Sample sp;
     sp.inside = y > -1.f && y < (float)d.H && x > -1.f && x < (float)d.W;
     const float fy = floorf(y), fx = floorf(x);
@@ -52,24 +53,26 @@ __device__ __forceinline__ Sample sample_of(const DeformDims& d, const float* __
     return sp;
 }
 
-__global__ __launch_bounds__(256) void deform_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                            float* __restrict__ cols, DeformDims d, long teams) {
+// AT: storage type of x, offset and cols (16-bit: BASELINE configs[3] in native bf16)
+template <int AT>
+__global__ __launch_bounds__(256) void deform_im2col_kernel(const void* __restrict__ x, const void* __restrict__ offset,
+                                                            void* __restrict__ cols, DeformDims d, long teams) {
     const int lane = threadIdx.x & 31;
     const int RS = d.R * d.S, c4n = d.C >> 2;
     for (long t = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5; t < teams; t += ((long)gridDim.x * blockDim.x) >> 5) {
         const int m = (int)(t / RS), k = (int)(t - (long)m * RS);
         int n, ho, wo;
-        const Sample sp = sample_of(d, offset, m, k, n, ho, wo);
+        const Sample sp = sample_of<AT>(d, offset, m, k, n, ho, wo);
         const float w00 = (1.f - sp.ly) * (1.f - sp.lx), w01 = (1.f - sp.ly) * sp.lx, w10 = sp.ly * (1.f - sp.lx), w11 = sp.ly * sp.lx;
         const long base = ((long)n * d.H + sp.y0) * d.W + sp.x0;  // pixel index of corner (y0, x0); only dereferenced if ok
-        f32x4* out = reinterpret_cast<f32x4*>(cols + ((long)m * RS + k) * d.C);
+        const long out4 = ((long)m * RS + k) * c4n;
         for (int c4 = lane; c4 < c4n; c4 += 32) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v00 = sp.ok[0] ? reinterpret_cast<const f32x4*>(x + base * d.C)[c4] : z;
-            const f32x4 v01 = sp.ok[1] ? reinterpret_cast<const f32x4*>(x + (base + 1) * d.C)[c4] : z;
-            const f32x4 v10 = sp.ok[2] ? reinterpret_cast<const f32x4*>(x + (base + d.W) * d.C)[c4] : z;
-            const f32x4 v11 = sp.ok[3] ? reinterpret_cast<const f32x4*>(x + (base + d.W + 1) * d.C)[c4] : z;
-            out[c4] = w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11;
+            const f32x4 v00 = sp.ok[0] ? dbn_ld4<AT>(x, base * c4n + c4) : z;
+            const f32x4 v01 = sp.ok[1] ? dbn_ld4<AT>(x, (base + 1) * c4n + c4) : z;
+            const f32x4 v10 = sp.ok[2] ? dbn_ld4<AT>(x, (base + d.W) * c4n + c4) : z;
+            const f32x4 v11 = sp.ok[3] ? dbn_ld4<AT>(x, (base + d.W + 1) * c4n + c4) : z;
+            dbn_st4<AT>(cols, out4 + c4, w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11);
         }
     }
 }
@@ -128,8 +131,11 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
 // a team reduction per (pixel, tap) and one atomic per channel chunk (doffset is zeroed by the caller).
 constexpr int COL2IM_T = 8, COL2IM_HALO = 2, COL2IM_CC = 32;
 
-__global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const float* __restrict__ dcols, const float* __restrict__ x,
-                                                                  const float* __restrict__ offset, float* __restrict__ dx,
+// AT: storage type of dcols, x and offset; dx and doffset are ALWAYS fp32 (they are accumulated with float atomics: in 16-bit
+// storage the caller gives fp32 scratch and rounds once afterwards, dbn_cast_f32)
+template <int AT>
+__global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const void* __restrict__ dcols, const void* __restrict__ x,
+                                                                  const void* __restrict__ offset, float* __restrict__ dx,
                                                                   float* __restrict__ doffset, DeformDims d, int tiles_x, int tiles_y,
                                                                   int PD) {
     extern __shared__ float patch[];  // [PD][PD][CC]
@@ -152,16 +158,16 @@ __global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const float* _
         if (ho >= d.Ho || wo >= d.Wo) continue;
         const int m = (n * d.Ho + ho) * d.Wo + wo;
         int n_, ho_, wo_;
-        const Sample sp = sample_of(d, offset, m, k, n_, ho_, wo_);
+        const Sample sp = sample_of<AT>(d, offset, m, k, n_, ho_, wo_);
         if (!sp.inside) continue;  // zero sample, zero gradients (doffset stays 0)
         const float hy = 1.f - sp.ly, hx = 1.f - sp.lx;
         const float wgt[4] = {hy * hx, hy * sp.lx, sp.ly * hx, sp.ly * sp.lx};
-        const float g = cok ? dcols[((long)m * RS + k) * d.C + c] : 0.f;
+        const float g = cok ? dbn_ld1<AT>(dcols, ((long)m * RS + k) * d.C + c) : 0.f;
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int yy = sp.y0 + (q >> 1), xx = sp.x0 + (q & 1);
-            v[q] = (sp.ok[q] && cok) ? x[(((long)n * d.H + yy) * d.W + xx) * d.C + c] : 0.f;
+            v[q] = (sp.ok[q] && cok) ? dbn_ld1<AT>(x, (((long)n * d.H + yy) * d.W + xx) * d.C + c) : 0.f;
             if (sp.ok[q] && cok) {
                 const int ry = yy - py0, rx = xx - px0;
                 const float add = wgt[q] * g;
@@ -194,6 +200,13 @@ __global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const float* _
     }
 }
 
+// fp32 -> activation storage type (one rounding)
+template <int AT>
+__global__ void cast_f32_kernel(const float* __restrict__ src, void* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        dbn_st4<AT>(dst, i, reinterpret_cast<const f32x4*>(src)[i]);
+}
+
 // dst[o][t][c] = src[o][c][t] (to_ohwi) or dst[o][c][t] = scale * src[o][t][c]: weight layout between OIHW and the
 // GEMM's (tap, channel) column order
 __global__ void permute_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int O, int C, int T, int to_ohwi,
@@ -223,20 +236,33 @@ bool dims_ok(const DeformDims& d) {
 extern "C" {
 
 // cols[N*Ho*Wo][R*S][C] = bilinear samples of x[N,H,W,C] at the offset tap positions
-int dbn_deform_im2col(const float* x, const float* offset, float* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
-                      int stride, int pad, int off_stride, void* stream) {
+int dbn_deform_im2col_t(int at, const void* x, const void* offset, void* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
+                        int stride, int pad, int off_stride, void* stream) {
     const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
     DBN_REQUIRE(x && offset && cols && dims_ok(d));
     const long teams = (long)N * Ho * Wo * R * S;
-    hipLaunchKernelGGL(deform_im2col_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, (hipStream_t)stream, x, offset,
-                       cols, d, teams);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(deform_im2col_kernel<AT>, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0,
+                                           (hipStream_t)stream, x, offset, cols, d, teams));
+    return dbn_status();
+}
+int dbn_deform_im2col(const float* x, const float* offset, float* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
+                      int stride, int pad, int off_stride, void* stream) {
+    return dbn_deform_im2col_t(0, x, offset, cols, N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride, stream);
+}
+
+// dst (activation type `at`) = src (fp32), n % 4 == 0: the one rounding of results that had to be accumulated in fp32
+int dbn_cast_f32(int at, const float* src, void* dst, long n, void* stream) {
+    DBN_REQUIRE(src && dst && n > 0 && n % 4 == 0);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(cast_f32_kernel<AT>, dim3(dbn_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n / 4));
     return dbn_status();
 }
 
 // adjoint of the sampling: dx[N,H,W,C] += scatter(dcols) (float atomics; the caller initialises dx),
 // doffset[N*Ho*Wo][off_stride]: channels 0..2RS-1 written, the rest set to zero
-int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
-                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
+// dcols / x / offset in the activation type `at`; dx and doffset are fp32 in every mode (float atomics) — 16-bit callers pass
+// fp32 scratch and round with dbn_cast_f32
+int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, float* dx, float* doffset, int N, int H, int W,
+                        int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
     const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
     DBN_REQUIRE(dcols && x && offset && dx && doffset && dims_ok(d));
     hipStream_t st = (hipStream_t)stream;
@@ -250,17 +276,22 @@ int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, f
     if (tiled && R == S && lds <= 64 * 1024) {
         if (hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess) return dbn_status();
         const int tiles_x = dbn_ceil_div(Wo, COL2IM_T), tiles_y = dbn_ceil_div(Ho, COL2IM_T);
-        hipLaunchKernelGGL(deform_col2im_tiled_kernel, dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, COL2IM_CC)), dim3(256), lds, st, dcols, x,
-                           offset, dx, doffset, d, tiles_x, tiles_y, PD);
+        DBN_DISPATCH_AT(at, hipLaunchKernelGGL(deform_col2im_tiled_kernel<AT>, dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, COL2IM_CC)),
+                                               dim3(256), lds, st, dcols, x, offset, dx, doffset, d, tiles_x, tiles_y, PD));
         return dbn_status();
     }
+    DBN_REQUIRE(at == 0);  // the per-sample scatter below exists for fp32 tensors only
     if (off_stride > 2 * R * S &&
         hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess)
         return dbn_status();
     const long teams = (long)N * Ho * Wo * R * S;
-    hipLaunchKernelGGL(deform_col2im_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, st, dcols, x, offset, dx, doffset,
-                       d, teams);
+    hipLaunchKernelGGL(deform_col2im_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, st, (const float*)dcols,
+                       (const float*)x, (const float*)offset, dx, doffset, d, teams);
     return dbn_status();
+}
+int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
+                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
+    return dbn_deform_col2im_t(0, dcols, x, offset, dx, doffset, N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride, stream);
 }
 
 // to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T] (OIHW -> GEMM column order); 0: the inverse

@@ -596,9 +596,6 @@ class Engine:
         self.ensure_flat()
         if self.at == 2 and train:
             raise RuntimeError("conv math 'fp16' is the inference path (BASELINE configs[4]): call model.eval() first")
-        if self.at != 0 and getattr(m.backbone.layer2[0], 'with_dcn', False):
-            raise NotImplementedError("16-bit activation storage is not implemented for the deformable backbones "
-                                      "(use set_conv_math('bf16c'): fp32 tensors, bf16 operands)")
         self.repack_params()
         x = x.contiguous().float()
         L, st = self.L, self.stream
@@ -733,8 +730,8 @@ class Engine:
         N, H, W, C = x.shape
         Ho, Wo = off.shape[1], off.shape[2]
         cols = self.buf(name + '/cols', N, Ho, Wo, conv.k * conv.k * C)
-        check(self.L.dbn_deform_im2col(x.data_ptr(), off.data_ptr(), cols.data_ptr(), N, H, W, C, Ho, Wo, conv.k, conv.k, conv.stride,
-                                       conv.padding, 64, self.stream), 'deform_im2col')
+        check(self.L.dbn_deform_im2col_t(self.at, x.data_ptr(), off.data_ptr(), cols.data_ptr(), N, H, W, C, Ho, Wo, conv.k, conv.k,
+                                         conv.stride, conv.padding, 64, self.stream), 'deform_im2col')
         vconv, ver2 = self._cols_conv(name + '.conv2', conv)
         return self.conv_bn(name + '.conv2', cols, vconv, out_name, bn_name, bn, train, version=ver2)
 
@@ -755,9 +752,16 @@ class Engine:
         dcols = self.buf(name + '/dcols', *cols.shape)
         self.conv_dgrad(name + '.conv2', dy, vconv, dcols, False, version=ver2)
         doff = self.buf(name + '/doffset', N, Ho, Wo, 64)
-        dx.zero_()
-        check(self.L.dbn_deform_col2im(dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx.data_ptr(), doff.data_ptr(), N, H, W, C, Ho, Wo,
-                                       conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
+        # the adjoint of the sampling accumulates with float atomics: fp32 targets in every mode (16-bit storage: fp32 scratch,
+        # rounded once afterwards)
+        dx32 = dx if self.at == 0 else self.scratch('_dcn_dx32', dx.numel()).view(dx.shape)
+        doff32 = doff if self.at == 0 else self.scratch('_dcn_doff32', doff.numel()).view(doff.shape)
+        dx32.zero_()
+        check(self.L.dbn_deform_col2im_t(self.at, dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx32.data_ptr(), doff32.data_ptr(), N, H,
+                                         W, C, Ho, Wo, conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
+        if self.at != 0:
+            check(self.L.dbn_cast_f32(self.at, dx32.data_ptr(), dx.data_ptr(), dx.numel(), self.stream), 'cast dx')
+            check(self.L.dbn_cast_f32(self.at, doff32.data_ptr(), doff.data_ptr(), doff.numel(), self.stream), 'cast doffset')
         voc, ver = self._offset_conv(name + '.conv2_offset', oc)
         tg = self.fbuf(name + '/dw_offset', 64, C, oc.k, oc.k)
         self.wgrad(name + '.conv2_offset', doff, x, 64, C, oc.k, oc.stride, oc.padding, tg)

@@ -290,6 +290,14 @@ int dbn_wgrad_tile_config(int O, int J);
 int dbn_wgrad_phase_t(int phase, int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo,
                       int O, int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
 
+/* deformable conv (resnet.py:54-65,111-124) on typed tensors; dx / doffset of the adjoint are fp32 in every mode (float atomics):
+ * 16-bit callers accumulate into fp32 scratch and round once with dbn_cast_f32 */
+int dbn_deform_im2col_t(int at, const void* x, const void* offset, void* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
+                        int stride, int pad, int off_stride, void* stream);
+int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, float* dx, float* doffset, int N, int H, int W,
+                        int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
+int dbn_cast_f32(int at, const float* src, void* dst, long n, void* stream);
+
 int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
                          float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                          float* ws, void* stream);
