@@ -754,8 +754,8 @@ class Engine:
         doff = self.buf(name + '/doffset', N, Ho, Wo, 64)
         # the adjoint of the sampling accumulates with float atomics: fp32 targets in every mode (16-bit storage: fp32 scratch,
         # rounded once afterwards)
-        dx32 = dx if self.at == 0 else self.scratch('_dcn_dx32', dx.numel()).view(dx.shape)
-        doff32 = doff if self.at == 0 else self.scratch('_dcn_doff32', doff.numel()).view(doff.shape)
+        dx32 = dx if self.at == 0 else self.scratch('_dcn_dx32', dx.numel())[:dx.numel()].view(dx.shape)
+        doff32 = doff if self.at == 0 else self.scratch('_dcn_doff32', doff.numel())[:doff.numel()].view(doff.shape)
         dx32.zero_()
         check(self.L.dbn_deform_col2im_t(self.at, dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx32.data_ptr(), doff32.data_ptr(), N, H,
                                          W, C, Ho, Wo, conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
