@@ -586,7 +586,9 @@ def test_native_bf16_on_bottleneck_and_deformable_backbones(arch):
     tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = tr.step(img.to(DEV), gts.to(DEV))
     preds_o, losses_o, grads_o = O.loss_and_grads(sd, img, gts)
-    report(arch + ' bf16 maps', preds[:, :2].cpu(), preds_o[:, :2], 8e-2, 8e-2)
+    # stated bf16 bound on P,T for these deeper / deformable nets: 99.9 % of the pixels within 8e-2 (+8e-2 rel), mean |err| <= 2e-2
+    report_robust(arch + ' bf16 maps', preds[:, :2].cpu(), preds_o[:, :2], 8e-2, 8e-2, 0.999)
+    assert float((preds[:, :2].cpu() - preds_o[:, :2]).abs().mean()) <= 2e-2
     report(arch + ' bf16 losses', losses.cpu().double(), torch.tensor(losses_o).double(), 4e-2, 4e-2)
     keys = ['backbone.conv1.weight', 'segmentation_body.conv.0.weight', 'segmentation_head.binarize.3.weight']
     if 'deformable' in arch:
