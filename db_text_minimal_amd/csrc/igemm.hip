@@ -222,7 +222,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     constexpr int B_PIECES = NS == 0 ? 4 * BN : NS * 2 * BN;  // 16-byte pieces of the weight panel per k-tile
     constexpr int B_LD = (B_PIECES + NT - 1) / NT;
     constexpr bool B_FULL = B_PIECES % NT == 0;  // every thread owns B_LD pieces
-    constexpr int STAGE = A_IMG + B_IMG;
+    // K advances 16 per UNIT; KU units share one barrier.  fp32 / bf16x3 products keep a wave's matrix pipe busy for 1024 / 384
+    // cycles per unit, so one unit per barrier is enough; a single bf16 / fp16 MFMA per accumulator is 32 cycles (64-128 per unit
+    // and wave), less than the barrier, the staging and the address walk cost — the 16-bit storage paths take four units at a time.
+    constexpr int KU = (AT == 1 || AT == 2) ? 4 : 1;
+    constexpr int UNIT = A_IMG + B_IMG;
+    constexpr int STAGE = KU * UNIT;
     constexpr int NSX = NS > 0 ? NS : 1;
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
     __shared__ f32x4 smem[2 * STAGE];
@@ -335,15 +340,16 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         k_s = k_tap - k_r * qS;
     }
 
-    unsigned aoff[A_LD];
-    auto next_offsets = [&]() {  // offsets of the current k position, then advance by one tile (16 k)
+    unsigned aoff[KU][A_LD];
+    int kend = (MODE < 2 && p.ksplit > 1) ? min(qK, 16 * kt_end) : qK;  // units past the end (of K, or of this split's range) gather zeros
+    auto next_offsets = [&](int u = 0) {  // offsets of the current k position (unit u of the barrier interval), then advance by 16 k
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
             const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
-            const bool v = kidx < qK && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+            const bool v = kidx < kend && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
             const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES + (AT == 3 ? a_pl[j] : 0u);
-            aoff[j] = v ? off : OOB_OFFSET;
+            aoff[u][j] = v ? off : OOB_OFFSET;
         }
         kidx += 16;
         if (blocked) {  // next tap of the same channel block; after the last tap, the next block (branch-free)
@@ -421,25 +427,29 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     // Loads and staging are issued UNCONDITIONALLY every k-step (tiles past the end gather zeros through out-of-range buffer
     // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
     // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
-    f32x4 ra_[2][A_LD], rb_[2][B_LD];
+    f32x4 ra_[2][KU][A_LD], rb_[2][KU][B_LD];
     int b_left = 0;  // weight k-tiles that remain beyond the one bptr points at
     auto issue_loads = [&](auto SET) {
         constexpr int st_ = decltype(SET)::value;
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) ra_[st_][j] = buffer_load_f32x4(rsrc, aoff[j]);
-        const long adv = b_left > 0 ? b_step : 0;
-        --b_left;
+        for (int u = 0; u < KU; ++u) {
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            if (B_FULL || b_on[j]) rb_[st_][j] = *bptr[j];
-            bptr[j] += adv;
+            for (int j = 0; j < A_LD; ++j) ra_[st_][u][j] = buffer_load_f32x4(rsrc, aoff[u][j]);
+            const long adv = b_left > 0 ? b_step : 0;
+            --b_left;
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) {
+                if (B_FULL || b_on[j]) rb_[st_][u][j] = *bptr[j];
+                bptr[j] += adv;
+            }
         }
     };
-    auto stage = [&](int buf, auto SET) {
+    auto stage_unit = [&](int buf, auto SET, auto UU) {
         constexpr int st_ = decltype(SET)::value;
-        f32x4 (&ra)[A_LD] = ra_[st_];
-        f32x4 (&rb)[B_LD] = rb_[st_];
-        f32x4* As = smem + buf * STAGE;
+        constexpr int u_ = decltype(UU)::value;
+        f32x4 (&ra)[A_LD] = ra_[st_][u_];
+        f32x4 (&rb)[B_LD] = rb_[st_][u_];
+        f32x4* As = smem + buf * STAGE + u_ * UNIT;
         f32x4* Bs = As + A_IMG;
         if constexpr (NS == 0) {
 #pragma unroll
@@ -465,6 +475,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         for (int j = 0; j < B_LD; ++j)
             if (B_FULL || b_on[j]) Bs[b_lds[j]] = rb[j];
     };
+    auto stage = [&](int buf, auto SET) {
+        stage_unit(buf, SET, std::integral_constant<int, 0>{});
+        if constexpr (KU > 1) {
+            stage_unit(buf, SET, std::integral_constant<int, 1>{});
+            stage_unit(buf, SET, std::integral_constant<int, 2>{});
+            stage_unit(buf, SET, std::integral_constant<int, 3>{});
+        }
+    };
+    static_assert(KU == 1 || KU == 4, "stage() spells the units out");
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -478,24 +497,41 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     if (MODE == 3) {
         level_setup(level);
         kt_end = qKT;
+        kend = qK;
     }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
     b_left = kt_end - kt_begin - 1;
-    next_offsets();
+    auto offsets_of_interval = [&]() {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) next_offsets(u);
+    };
+    offsets_of_interval();
     issue_loads(C0{});
-    next_offsets();  // offsets of tile 1
+    offsets_of_interval();  // offsets of interval 1
     issue_loads(C1{});
-    next_offsets();  // offsets of tile 2
+    offsets_of_interval();  // offsets of interval 2
     stage(0, C0{});
     __syncthreads();
 
     auto k_step = [&](int kt, auto PAR) {
-        constexpr int buf = decltype(PAR)::value;  // parity of kt - kt_begin: LDS buffer and register set of tile kt
-        issue_loads(PAR);  // tile kt+2 into the register set tile kt was staged from
+        constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
+        issue_loads(PAR);  // interval +2 into the register set this interval was staged from
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
-        if constexpr (NS == 0) {
+        if constexpr (KU > 1) {
+            // four 16-k units per barrier: fragments of unit u+1 are read while unit u multiplies
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                bf16x8 af[1][MI], bf[1][NI];
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[0][a] = __builtin_bit_cast(bf16x8, As[u * UNIT + lh * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[0][b] = __builtin_bit_cast(bf16x8, Bs[u * UNIT + lh * BS + wn * TN + b * 32 + li]);
+                mfma_split<1, MI, NI, AT == 2>(af, bf, acc);
+            }
+            offsets_of_interval();
+        } else if constexpr (NS == 0) {
             // all fragment reads of the k-tile up front: the second half's LDS latency hides under the first half's MFMAs
             f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
@@ -532,9 +568,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
         stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
     };
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+    for (int kt = kt_begin; kt < kt_end; kt += 2 * KU) {
         k_step(kt, C0{});
-        if (kt + 1 < kt_end) k_step(kt + 1, C1{});
+        if (kt + KU < kt_end) k_step(kt + KU, C1{});
     }
     }
 
