@@ -222,10 +222,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     constexpr int B_PIECES = NS == 0 ? 4 * BN : NS * 2 * BN;  // 16-byte pieces of the weight panel per k-tile
     constexpr int B_LD = (B_PIECES + NT - 1) / NT;
     constexpr bool B_FULL = B_PIECES % NT == 0;  // every thread owns B_LD pieces
-    // K advances 16 per UNIT; KU units share one barrier.  fp32 / bf16x3 products keep a wave's matrix pipe busy for 1024 / 384
-    // cycles per unit, so one unit per barrier is enough; a single bf16 / fp16 MFMA per accumulator is 32 cycles (64-128 per unit
-    // and wave), less than the barrier, the staging and the address walk cost — the 16-bit storage paths take four units at a time.
-    constexpr int KU = (AT == 1 || AT == 2) ? 4 : 1;
+    // K advances 16 per UNIT; KU units share one barrier (1 or 4).  Measured on the 16-bit storage paths, whose single MFMA per
+    // accumulator and unit (32 cycles) is far shorter than a unit's staging / address walk: KU = 4 is SLOWER (1116 vs 1199 images/s
+    // in native bf16; 51 KB of LDS and a second register set of 4 units cost occupancy, and the barrier was not what bounds them —
+    // the instruction stream per unit is).  Every path runs with one unit per barrier.
+    constexpr int KU = 1;
     constexpr int UNIT = A_IMG + B_IMG;
     constexpr int STAGE = KU * UNIT;
     constexpr int NSX = NS > 0 ? NS : 1;
