@@ -1450,14 +1450,6 @@ static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipS
     // tile choice from the total row count (for parity classes: all classes together)
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
-    static int tile16 = -1;
-    if (tile16 < 0) {
-        const char* e = getenv("DBN_TILE16");
-        tile16 = e ? atoi(e) : 0;
-    }
-    // 16-bit storage: one MFMA per accumulator and k-unit is short, the instruction stream around it is what bounds the kernel:
-    // 64x64 per wave (256x64 workgroup tile) issues four MFMAs per unit instead of two of the 128x64 tile
-    if (tile16 && (at == 1 || at == 2) && cfg == 3 && tile_hint == 0 && (long)p.N * p.Hdf * p.Wdf >= 256L * 512) cfg = 2;
     switch (cfg) {
         case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st, at);
         case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st, at);
