@@ -1053,8 +1053,156 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         }
 }
 
+// ---- weight gradient, LDS-DMA form (exact fp32 MFMA; the default for fp32 tensors) -------------------------------------------
+// Same GEMM (M = Cout tile, N = (tap, ci) tile, K = a range of output pixels) with the operands staged the way they lie in memory:
+// the LDS image of a stage is [16 pixels][BM] of dY and [16 pixels][BN] of the gathered X, PIXEL-major.  The f32 MFMA wants, per lane,
+// A[i = lane & 31][k = lane >> 5] — one word of pixel row k, channel i: lanes 0-31 read 32 consecutive words of a pixel row
+// (ds_read_b32, conflict-free), so no transpose is needed anywhere and the panels can be written by LDS-DMA
+// (buffer_load_dwordx4 ... lds: 64 lanes x 16 B = 1 KiB per instruction, out-of-range lanes — padding taps, pixel tails,
+// columns past J — deliver zeros).  No staging registers, hence a three-stage ring with two stages in flight across raw barriers
+// (counted vmcnt), where the register-transposing kernel above could only afford a prefetch distance of one: its loads were
+// exposed every k-step once the workgroups of a launch (all started together, equally long) ran in lockstep.
+// The accumulators, and therefore the slabs, are in natural (o, j) order here (`natural` flag of the reduction kernels).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
+    constexpr int KP = 16;  // pixels per stage
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+    constexpr int A_F4 = KP * BM / 4, B_F4 = KP * BN / 4;    // float4 items of the two panels of a stage
+    constexpr int A_INSTR = A_F4 / 64, B_INSTR = B_F4 / 64;  // wave-level DMA instructions (1 KiB each)
+    constexpr int PER_WAVE = (A_INSTR + B_INSTR) / 4;
+    static_assert((A_INSTR + B_INSTR) % 4 == 0 && WM * WN == 4, "DMA instructions are dealt to four waves");
+    constexpr int NSTG = 3;
+    constexpr int STAGE_F4 = A_F4 + B_F4;
+    __shared__ f32x4 smem[NSTG * STAGE_F4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int njt = (p.J + BN - 1) / BN;
+    const int ntiles = (p.O / BM) * njt;
+    const int work = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / ntiles, tile_ = work - split * ntiles;
+    const int ot = tile_ / njt, jt = tile_ - ot * njt;
+    const int o0 = ot * BM, j0 = jt * BN;
+    const int pbeg = split * p.pchunk;
+    const int pend = min(p.P, pbeg + p.pchunk);
+    const int KT = (pend - pbeg + KP - 1) / KP;
+
+    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
+
+    // this wave's DMA instructions t = wave*PER_WAVE + i (A panel first, then B); per instruction the lane's item:
+    //   A: pixel row ra, channel quad qa   -> byte offset ((pixel*O + o0 + 4 qa) * 4), advancing 16 pixels per stage
+    //   B: pixel row rb, column quad qb    -> (tap, ci) fixed, the pixel (n, oh, ow) walks 16 pixels per stage
+    const int HWo = p.Ho * p.Wo;
+    unsigned a_off[PER_WAVE];          // A: offset of the lane's item in stage 0 (OOB handled per stage)
+    int a_px[PER_WAVE];                // A: pixel index of the item in the current stage
+    int b_n[PER_WAVE], b_oh[PER_WAVE], b_ow[PER_WAVE], b_px[PER_WAVE], b_ci[PER_WAVE], b_tr[PER_WAVE], b_ts[PER_WAVE];
+    bool b_ok[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int t = wave * PER_WAVE + i;
+        a_off[i] = 0; a_px[i] = 0; b_n[i] = b_oh[i] = b_ow[i] = b_px[i] = b_ci[i] = b_tr[i] = b_ts[i] = 0; b_ok[i] = false;
+        if (t < A_INSTR) {
+            const int f = t * 64 + lane, row = f / (BM / 4), quad = f - row * (BM / 4);
+            a_px[i] = pbeg + row;
+            a_off[i] = (unsigned)(o0 + 4 * quad) * 4u;
+        } else {
+            const int f = (t - A_INSTR) * 64 + lane, row = f / (BN / 4), quad = f - row * (BN / 4);
+            const int jj = j0 + 4 * quad;
+            b_ok[i] = jj < p.J;
+            const int tap = b_ok[i] ? jj / p.Cb : 0;
+            b_ci[i] = b_ok[i] ? jj - tap * p.Cb : 0;
+            b_tr[i] = tap / p.S - p.pad;
+            b_ts[i] = tap % p.S - p.pad;
+            b_px[i] = pbeg + row;
+            int rem;
+            divmod24(min(b_px[i], p.P - 1), HWo, p.rcp_HWo, b_n[i], rem);
+            divmod24(rem, p.Wo, p.rcp_Wo, b_oh[i], b_ow[i]);
+        }
+    }
+    auto issue_stage = [&](int slot) {  // DMA of the NEXT not yet issued stage into ring slot `slot`; advances the per-item pixel state
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int t = wave * PER_WAVE + i;
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_F4 + t * 64);
+            if (t < A_INSTR) {
+                const unsigned off = a_px[i] < pend ? (unsigned)a_px[i] * (unsigned)p.O * 4u + a_off[i] : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sm, dst, 16, (int)off, 0, 0, 0);
+                a_px[i] += KP;
+            } else {
+                const int ih = b_oh[i] * p.stride + b_tr[i], iw = b_ow[i] * p.stride + b_ts[i];
+                const bool v = b_ok[i] && b_px[i] < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const unsigned off = v ? (unsigned)(((b_n[i] * p.H + ih) * p.W + iw) * p.Cb + b_ci[i]) * 4u : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, dst, 16, (int)off, 0, 0, 0);
+                b_px[i] += KP;
+                b_ow[i] += KP;
+                while (b_ow[i] >= p.Wo) {  // next pixel row(s) / image
+                    b_ow[i] -= p.Wo;
+                    if (++b_oh[i] == p.Ho) {
+                        b_oh[i] = 0;
+                        ++b_n[i];
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (KT > 0) issue_stage(0);
+    if (KT > 1) issue_stage(1);
+    const float* lds = reinterpret_cast<const float*>(smem);
+    for (int kt = 0; kt < KT; ++kt) {
+        // this wave's DMA of stage kt has landed once at most the PER_WAVE instructions of stage kt+1 are outstanding
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS; everyone is done reading slot (kt-1) % 3
+        if (kt + 2 < KT) issue_stage((kt + 2) % NSTG);
+        const float* As = lds + (kt % NSTG) * STAGE_F4 * 4;
+        const float* Bs = As + A_F4 * 4;
+#pragma unroll
+        for (int kk = 0; kk < KP / 2; ++kk) {
+            const int r = 2 * kk + lh;
+            float af[MI], bf[NI];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) af[a] = As[r * BM + wm * TM + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bf[b] = Bs[r * BN + wn * TN + b * 32 + li];
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // slab in natural order: [split][O][Jp = njt*BN]
+    const int Jp = njt * BN;
+    float* out = p.slab + (long)split * wgrad_slab_stride(p.O, Jp);
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int col = j0 + wn * TN + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = o0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(long)row * Jp + col] = acc[a][b][r];
+            }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
-                                    int R, int S, float* __restrict__ grad, float scale) {
+                                    int R, int S, float* __restrict__ grad, float scale, int natural) {
     // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
     const long total = (long)O * Jp, count4 = total >> 2, total4 = wgrad_slab_stride(O, Jp) >> 2;
     for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < count4; q += (long)gridDim.x * blockDim.x) {
@@ -1075,11 +1223,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
         }
         const int prow = (int)(idx / Jp);
         const int pcol0 = (int)(idx - (long)prow * Jp);
-        const int o = (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
+        const int o = natural ? prow : (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int pcol = pcol0 + e;
-            const int j = (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
+            const int j = natural ? pcol : (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
             if (j >= J) continue;
             const int tap = j / Cb, i = j - tap * Cb;
             if (i >= I) continue;
@@ -1097,13 +1245,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
 // fp64 partial sums are combined through LDS in group order — fixed summation order, bit-reproducible.
 __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
                                                               int BN, int Cb, int I, int RS, int G, float* __restrict__ grad,
-                                                              float scale) {
+                                                              float scale, int natural) {
     extern __shared__ double dsm[];  // [G][items][4] partial sums (G > 1), then the [64][RS] float staging image
     const int items = RS * 16;
     float* stage = reinterpret_cast<float*>(dsm + (G > 1 ? (size_t)G * items * 4 : 0));
     const int o = blockIdx.x, i0 = blockIdx.y * 64;
     const int om = o % BM;
-    const int prow = (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
+    const int prow = natural ? o : (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
     const long total4 = wgrad_slab_stride(O, Jp) >> 2;
     const int nthr = blockDim.x;
     for (int w = threadIdx.x; w < items * G; w += nthr) {
@@ -1111,7 +1259,9 @@ __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __res
         const int tap = t >> 4, e = (t >> 2) & 3, cq = t & 3;
         const int j0 = tap * Cb + i0;                 // multiple of 64: the 64 channels lie inside one BN-wide tile
         const int jt = j0 / BN, jl0 = j0 - jt * BN;
-        const int pos = e * (BN / 4) + (jl0 >> 2) + 4 * cq;  // positions pos..pos+3 hold channels i0 + 16cq + 4u + e
+        // position space: positions pos..pos+3 hold channels i0 + 16cq + 4u + e; natural order: lane (e, cq) takes the four
+        // consecutive channels i0 + 4*(4e + cq) + u
+        const int pos = natural ? jl0 + 4 * (4 * e + cq) : e * (BN / 4) + (jl0 >> 2) + 4 * cq;
         const f32x4* src = reinterpret_cast<const f32x4*>(slab + (long)prow * Jp + jt * BN + pos);
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         int z = g;
@@ -1131,7 +1281,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __res
             for (int u = 0; u < 4; ++u) dsm[((size_t)g * items + t) * 4 + u] = s[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+            for (int u = 0; u < 4; ++u) stage[(natural ? 4 * (4 * e + cq) + u : 16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
         }
     }
     if (G > 1) {
@@ -1143,7 +1293,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __res
 #pragma unroll
                 for (int u = 0; u < 4; ++u) s[u] += dsm[((size_t)g * items + t) * 4 + u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) stage[(16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
+            for (int u = 0; u < 4; ++u) stage[(natural ? 4 * (4 * e + cq) + u : 16 * cq + 4 * u + e) * RS + tap] = (float)(s[u] * scale);
         }
     }
     __syncthreads();
@@ -1951,6 +2101,12 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
     const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb, at);
     DBN_REQUIRE(nmax >= 1);
     hipStream_t st = (hipStream_t)stream;
+    static int dma_env = -1;
+    if (dma_env < 0) {
+        const char* e = getenv("DBN_WGRAD_DMA");
+        dma_env = e ? atoi(e) : 1;
+    }
+    const bool dma = dma_env && ns == 0 && at == 0;  // LDS-DMA kernel (natural slab order) for exact-fp32 math on fp32 tensors
     int bm, bn;
     const int J = R * S * Cb;
     wgrad_tiles(O, J, bm, bn);
@@ -1991,7 +2147,16 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
     } while (0)
         if (at == 1) DBN_WGRAD_LAUNCH(1, 1);
         else if (at == 3) DBN_WGRAD_LAUNCH(3, 3);
-        else if (ns == 0) DBN_WGRAD_LAUNCH(0, 0);
+        else if (ns == 0 && dma) {
+            if (bn == 192)
+                hipLaunchKernelGGL((wgrad_dma_kernel<64, 192, 2, 2>), grid, dim3(256), 0, st, p);
+            else if (bm == 128 && bn == 128)
+                hipLaunchKernelGGL((wgrad_dma_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+            else if (bn == 128)
+                hipLaunchKernelGGL((wgrad_dma_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((wgrad_dma_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+        } else if (ns == 0) DBN_WGRAD_LAUNCH(0, 0);
         else if (ns == 1) DBN_WGRAD_LAUNCH(1, 0);
         else DBN_WGRAD_LAUNCH(3, 0);
 #undef DBN_WGRAD_LAUNCH
@@ -2009,10 +2174,10 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         const int threads = std::min(1024, (items * G + 63) / 64 * 64);
         const size_t smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)R * S * 64 * sizeof(float);
         hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,
-                           R * S, G, grad_oihw, scale);
+                           R * S, G, grad_oihw, scale, dma ? 1 : 0);
     } else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
-                           Cb, I, R, S, grad_oihw, scale);
+                           Cb, I, R, S, grad_oihw, scale, dma ? 1 : 0);
     return dbn_status();
 }
 
