@@ -2079,6 +2079,13 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S, 4);
 }
 
+static int g_wgrad_variant = -1;  // -1: read DBN_WGRAD_DMA on first use; 0: register-transposing kernel; 1: LDS-DMA kernel
+int dbn_set_wgrad_variant(int v) {
+    DBN_REQUIRE(v == 0 || v == 1);
+    g_wgrad_variant = v;
+    return DBN_OK;
+}
+
 // Tile variant dbn_wgrad_* uses for O output channels and J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64
 // (wgrad_f32_kernel<BM, BN, 2, 2, ns, at> in a rocprofv3 trace)
 int dbn_wgrad_tile_config(int O, int J) {
@@ -2101,12 +2108,15 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
     const int nmax = wgrad_chunk(N, Ho, Wo, O, H, W, Cb, at);
     DBN_REQUIRE(nmax >= 1);
     hipStream_t st = (hipStream_t)stream;
-    static int dma_env = -1;
-    if (dma_env < 0) {
+    if (g_wgrad_variant < 0) {
         const char* e = getenv("DBN_WGRAD_DMA");
-        dma_env = e ? atoi(e) : 1;
+        g_wgrad_variant = e ? atoi(e) : 0;
     }
-    const bool dma = dma_env && ns == 0 && at == 0;  // LDS-DMA kernel (natural slab order) for exact-fp32 math on fp32 tensors
+    // variant 1: the LDS-DMA kernel (natural slab order) for exact-fp32 math on fp32 tensors.  Measured against the register-
+    // transposing kernel on the layer shapes of the model (tools/reduce_probe.py): 303-319 vs 268-301 us — not faster (its 48 KB
+    // ring admits 3 workgroups per CU instead of 4, and the transposing kernel was not load-latency-bound after all), so it is
+    // selectable (DBN_WGRAD_DMA=1 / dbn_set_wgrad_variant) but not the default.
+    const bool dma = g_wgrad_variant == 1 && ns == 0 && at == 0;
     int bm, bn;
     const int J = R * S * Cb;
     wgrad_tiles(O, J, bm, bn);

@@ -284,6 +284,9 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
 int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                 int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
 
+/* weight-gradient kernel for exact-fp32 math on fp32 tensors: 0 = register-transposing kernel (default), 1 = LDS-DMA kernel
+ * (pixel-major LDS image, three-stage ring; same results up to the summation order inside a split) */
+int dbn_set_wgrad_variant(int variant);
 /* tile variant of the weight-gradient kernel for O output channels, J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64 */
 int dbn_wgrad_tile_config(int O, int J);
 /* dbn_wgrad_t in two calls: phase 1 = matrix kernels (-> slabs), phase 2 = slab reduction (-> grad_oihw) */

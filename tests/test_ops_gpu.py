@@ -990,3 +990,25 @@ def test_presplit_bf16x3_operands(tile):
     _lib.check(L().dbn_wgrad_t(3, 3, dyp.data_ptr(), planes.data_ptr(), slab.data_ptr(), gb.data_ptr(), N, H, W, Co, H, W, Ci, Ci, 3, 3, 1, 1,
                                1.0, stream()), 'wgrad split3')
     assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 20, 12), (3, 128, 256, 1, 1, 0, 9, 7), (2, 64, 128, 3, 2, 1, 16, 16), (1, 256, 256, 3, 1, 1, 12, 12),
+                                  (2, 3, 64, 7, 2, 3, 32, 40), (2, 64, 64, 2, 2, 0, 10, 12)])
+def test_weight_gradient_lds_dma_variant(case):
+    """dbn_set_wgrad_variant(1): the LDS-DMA weight-gradient kernel (operands staged pixel-major by buffer_load ... lds, out-of-range
+    lanes delivering zeros; no register transposes; natural slab order) == autograd of F.conv2d, like the default kernel."""
+    N, Ci, Co, k, s_, p_, H, W = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, None, s_, p_)
+    dy = rnd(*y.shape, seed=3)
+    (gref, ) = torch.autograd.grad(y, w, dy)
+    xs = nhwc(pad_c(x, (Ci + 3) // 4 * 4))
+    try:
+        L().dbn_set_wgrad_variant(1)
+        g = wgrad(nhwc(dy), xs, Co, Ci, k, s_, p_, scale=0.5)
+    finally:
+        L().dbn_set_wgrad_variant(0)
+    g0 = wgrad(nhwc(dy), xs, Co, Ci, k, s_, p_, scale=0.5)
+    report('wgrad (LDS-DMA variant)', g.cpu(), 0.5 * gref, 2e-5 * float(gref.abs().max()), 1e-4)
+    report('wgrad variants agree', g.cpu(), g0.cpu(), 1e-5 * float(gref.abs().max()), 1e-5)
