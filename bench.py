@@ -169,13 +169,15 @@ def main():
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
 
     # HBM traffic of that kernel from the committed PMC passes (profiles/, tools/pmc_traffic.py), per launch
-    try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels'].get(dname)
+    for tag in ('r02', 'r01'):  # newest committed PMC summary that knows this kernel (tools/profile_round.sh)
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))['kernels'].get(dname)
+        except (OSError, ValueError, KeyError):
+            tr = None
         if tr:
             roofline['traffic'] = tr['hbm_bytes_per_launch']
-            roofline['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/r01_pmc_traffic.json)'
-    except (OSError, ValueError, KeyError):
-        pass
+            roofline['traffic_unit'] = ('bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/%s_pmc_traffic.json)' % tag)
+            break
 
     kernels = []
     serial = serial_summ.get(dname)
@@ -199,6 +201,16 @@ def main():
                 ent.update(bound='hbm', achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
             kernels.append(ent)
 
+    if rank == 0:  # the weight gradient as a whole (every tile variant + the slab reductions), serial
+        wg = [v for k, v in serial_summ.items() if k.startswith('wgrad_f32_kernel')]
+        red = serial_summ.get('wgrad_reduce_kernel')
+        if wg:
+            ms_w = sum(v['ms'] for v in wg) + (red['ms'] if red else 0.0)
+            fl_w = sum(v['flops'] for v in wg)
+            a = fl_w / (ms_w * 1e-3) / 1e12
+            kernels.append({'kernel': 'wgrad_f32_kernel (all tile variants) + wgrad_reduce_kernel', 'launches': sum(v['launches'] for v in wg),
+                            'ms_per_step': round(ms_w, 3), 'bound': 'mfma', 'achieved': round(a, 2), 'peak': round(peak_mfma, 1),
+                            'unit': 'TFLOP/s', 'frac': round(a / peak_mfma, 4)})
     alt = {}
     if not args.no_alt_modes:
         for mode in ('f32', 'bf16x3', 'bf16'):

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: kernel trace + two PMC passes + the plain bench line of one round.  Usage (through gpurun):
-#   gpurun -- 'bash tools/profile_round.sh r01e'
-# Writes gpurun_out/<tag>/{trace,pmc_fetch,pmc_write}/r01_results.db, bench_under_rocprof.json, bench_n1.json;
-# summarise with tools/rocpd_stats.py and tools/pmc_traffic.py and copy the summaries into profiles/.
+#   gpurun -- 'bash tools/profile_round.sh r02'
+# Writes gpurun_out/<tag>/: kernel_stats.md (rocprofv3 --kernel-trace of bench.py), step_breakdown.txt, pmc_traffic.json (two PMC
+# passes), bench_under_rocprof.json, bench_n1.json (+ the same for --math bf16); copy the summaries into profiles/.
 set -u
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -15,10 +15,16 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o r01 -- python3 $R/bench.py --steps
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A > $O/pmc_write.log 2>&1
 cd $R
 python3 tools/rocpd_stats.py $O/trace/r01_results.db $O/kernel_stats.md > /dev/null
+python3 tools/step_breakdown.py $O/trace/r01_results.db 6 > $O/step_breakdown.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch/r01_results.db $O/pmc_write/r01_results.db $O/pmc_traffic.json > /dev/null
 grep '^{"metric"' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
-cp $O/pmc_traffic.json profiles/r01_pmc_traffic.json   # bench.py reads the per-kernel traffic from here
+cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # bench.py reads the per-kernel traffic of the newest round from profiles/
 python3 bench.py --steps 20 --warmup 5 > $O/bench_n1.log 2>&1
 grep '^{"metric"' $O/bench_n1.log > $O/bench_n1.json
-rm -rf $O/pmc_fetch $O/pmc_write   # the DBs are large; the summaries above are what is kept
+cd /tmp
+rocprofv3 --kernel-trace -d $O/trace_bf16 -o r01 -- python3 $R/bench.py --steps 10 --warmup 3 $A --math bf16 > $O/bench_bf16_under_rocprof.log 2>&1
+cd $R
+python3 tools/rocpd_stats.py $O/trace_bf16/r01_results.db $O/kernel_stats_bf16.md > /dev/null
+grep '^{"metric"' $O/bench_bf16_under_rocprof.log > $O/bench_bf16_under_rocprof.json
+rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16   # the DBs are large; the summaries above are what is kept
 ls -la $O
