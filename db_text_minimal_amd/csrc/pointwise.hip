@@ -300,33 +300,47 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int
 // ----------------------------------------------------------------------------------
 // stem: relu(bn(y)) -> maxpool 3x3 s2 p1, forward and backward
 // ----------------------------------------------------------------------------------
+// One thread: the channel quad of TWO vertically adjacent outputs (rows 2k, 2k+1): their windows share input row 4k+1, so the 5
+// input rows are read once (15 loads for 2 outputs instead of 18).  Horizontal neighbours re-read through L1/L2 as before; it was
+// the vertical overlap that went back to HBM (FETCH_SIZE 1.54x the tensor with one output per thread, 1.25x the ideal now).
 template <int AT>
 __global__ void bnrelu_maxpool_fwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                           void* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
     const int c4n = C >> 2;
-    const long total = (long)N * Ho * Wo * c4n;
+    const int Hp = (Ho + 1) >> 1;
+    const long total = (long)N * Hp * Wo * c4n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
+        const int c4 = (int)(i % c4n);
         long t = i / c4n;
         const int ow = (int)(t % Wo);
         t /= Wo;
-        const int oh = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
-        f32x4 m = {0.f, 0.f, 0.f, 0.f};  // relu output >= 0, so 0 is a neutral start (padding never wins)
-        for (int r = 0; r < 3; ++r) {
-            const int ih = oh * 2 - 1 + r;
+        const int k = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + 4 * c4);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + 4 * c4);
+        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;  // relu output >= 0, so 0 is a neutral start (padding never wins)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int ih = 4 * k - 1 + r;
             if ((unsigned)ih >= (unsigned)H) continue;
+            f32x4 rm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int iw = ow * 2 - 1 + q;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = dbn_ld4<AT>(y, (((long)n * H + ih) * W + iw) * c4n + (c >> 2));
+                const f32x4 v = dbn_ld4<AT>(y, (((long)n * H + ih) * W + iw) * c4n + c4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], dbn_affine_relu(v[e], s[e], h[e]));
+                for (int e = 0; e < 4; ++e) rm[e] = fmaxf(rm[e], dbn_affine_relu(v[e], s[e], h[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (r <= 2) m0[e] = fmaxf(m0[e], rm[e]);
+                if (r >= 2) m1[e] = fmaxf(m1[e], rm[e]);
             }
         }
-        dbn_st4<AT>(out, i, m);
+        const long o = (((long)n * Ho + 2 * k) * Wo + ow) * c4n + c4;
+        dbn_st4<AT>(out, o, m0);
+        if (2 * k + 1 < Ho) dbn_st4<AT>(out, o + (long)Wo * c4n, m1);
     }
 }
 
@@ -346,48 +360,70 @@ __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const floa
                                           const void* __restrict__ pooled, const void* __restrict__ dpool,
                                           void* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ bn_part) {
+    // One thread: the channel quad of a 2x2 block of input pixels (rows 2a, 2a+1, columns 2b, 2b+1).  The four pixels lie in the
+    // windows (a..a+1) x (b..b+1) only, so 4 loads of the pooled maxima and 4 of their gradients serve all four (a thread per
+    // pixel read 9 + 9: FETCH_SIZE 1.43x the tensors).
     const int c4n = C >> 2;
-    const long total = (long)N * H * W * c4n;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const long total = (long)N * Hb * Wb * c4n;
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1;
+    const int cq0 = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;  // constant per thread (256 % (C/4) == 0, host side)
     if (bn_part) {
-        const int cq = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;
-        mu = *reinterpret_cast<const f32x4*>(mean + cq);
-        rs = *reinterpret_cast<const f32x4*>(rstd + cq);
+        mu = *reinterpret_cast<const f32x4*>(mean + cq0);
+        rs = *reinterpret_cast<const f32x4*>(rstd + cq0);
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
+        const int c4 = (int)(i % c4n);
         long t = i / c4n;
-        const int iw = (int)(t % W);
-        t /= W;
-        const int ih = (int)(t % H);
-        const int n = (int)(t / H);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
-        const f32x4 v = dbn_ld4<AT>(y, i);
-        f32x4 z;
+        const int b = (int)(t % Wb);
+        t /= Wb;
+        const int a = (int)(t % Hb);
+        const int n = (int)(t / Hb);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + 4 * c4);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + 4 * c4);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // windows (a + u, b + w), u, w in {0, 1}
+        f32x4 pm[2][2], dp[2][2];
+        bool wok[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = round_to_storage<AT>(dbn_affine_relu(v[e], s[e], h[e]));
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        // windows oh with oh*2-1 <= ih <= oh*2+1
-        const int oh_lo = max(0, (ih) / 2), oh_hi = min(Ho - 1, (ih + 1) / 2);
-        const int ow_lo = max(0, (iw) / 2), ow_hi = min(Wo - 1, (iw + 1) / 2);
-        for (int oh = oh_lo; oh <= oh_hi; ++oh)
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const long o = (((long)n * Ho + oh) * Wo + ow) * c4n + (c >> 2);
-                const f32x4 pm = dbn_ld4<AT>(pooled, o);
-                const f32x4 dp = dbn_ld4<AT>(dpool, o);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (z[e] > 0.f && z[e] == pm[e]) g[e] += dp[e];
+            for (int w = 0; w < 2; ++w) {
+                wok[u][w] = a + u < Ho && b + w < Wo;
+                const long o = (((long)n * Ho + a + u) * Wo + b + w) * c4n + c4;
+                pm[u][w] = wok[u][w] ? dbn_ld4<AT>(pooled, o) : zero;
+                dp[u][w] = wok[u][w] ? dbn_ld4<AT>(dpool, o) : zero;
             }
-        dbn_st4<AT>(dz, i, g);
-        if (bn_part) {
-            f32x4 gr = g;  // the BatchNorm backward reads the STORED gradient
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gr[e] = round_to_storage<AT>(g[e]);
-            s1 += gr;
-            s2 += gr * ((v - mu) * rs);
-        }
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                const int ih = 2 * a + dy_, iw = 2 * b + dx_;
+                if (ih >= H || iw >= W) continue;
+                const long pi = (((long)n * H + ih) * W + iw) * c4n + c4;
+                const f32x4 v = dbn_ld4<AT>(y, pi);
+                f32x4 z, g = zero;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = round_to_storage<AT>(dbn_affine_relu(v[e], s[e], h[e]));
+                // pixel row 2a lies in window row a only, row 2a+1 in rows a and a+1 (same for columns)
+#pragma unroll
+                for (int u = 0; u <= dy_; ++u)
+#pragma unroll
+                    for (int w = 0; w <= dx_; ++w) {
+                        if (!wok[u][w]) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (z[e] > 0.f && z[e] == pm[u][w][e]) g[e] += dp[u][w][e];
+                    }
+                dbn_st4<AT>(dz, pi, g);
+                if (bn_part) {
+                    f32x4 gr = g;  // the BatchNorm backward reads the STORED gradient
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gr[e] = round_to_storage<AT>(g[e]);
+                    s1 += gr;
+                    s2 += gr * ((v - mu) * rs);
+                }
+            }
     }
     if (bn_part) {  // threads t, t + C/4, ... of the block hold the same channel quad
         __shared__ f32x4 red[2][256];
@@ -796,7 +832,7 @@ int dbn_bnrelu_maxpool_fwd_t(int at, const void* y, const float* scale, const fl
                              void* stream) {
     DBN_REQUIRE(y && scale && shift && out && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel<AT>, dim3(dbn_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0,
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel<AT>, dim3(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 4))), dim3(256), 0,
                                            (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo));
     return dbn_status();
 }
@@ -807,7 +843,7 @@ int dbn_bnrelu_maxpool_fwd(const float* y, const float* scale, const float* shif
 
 // bn_mean / bn_rstd / bn_part optional (all or none): also emit the partial sums of the following BatchNorm backward,
 // bn_part = [2*C][dbn_maxpool_bwd_parts(...)] floats — feed them to dbn_bn_backward_t as `sums` with that `sums_parts`.
-int dbn_maxpool_bwd_parts(int N, int H, int W, int C) { return dbn_grid((long)N * H * W * (C / 4), 256, 2048); }
+int dbn_maxpool_bwd_parts(int N, int H, int W, int C) { return dbn_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4), 256, 2048); }
 int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const float* shift, const void* pooled, const void* dpool,
                              void* dz, int N, int H, int W, int C, const float* bn_mean, const float* bn_rstd, float* bn_part,
                              void* stream) {
