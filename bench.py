@@ -92,6 +92,9 @@ def main():
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16c'],
                     help="precision mode: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; "
                          "bf16 = native bf16 storage + MFMA (BASELINE configs[2]); bf16c = fp32 tensors, bf16 operands")
+    ap.add_argument('--single-allreduce', action='store_true',
+                    help="N>1: one all-reduce of the flat gradient buffer after the backward pass (north_star's wording) instead of "
+                         "the default 4 buckets issued under it; results are bit-identical (tests/test_dp_gloo.py, tests/test_rccl_gpu.py)")
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
     args = ap.parse_args()
@@ -110,6 +113,8 @@ def main():
     model = DBTextModel().to(dev).train()
     model.engine.set_conv_math(args.math)
     trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
+    if args.single_allreduce:
+        trainer.overlap_allreduce = False
     img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
     eng = model.engine
 
@@ -238,8 +243,11 @@ def main():
                                    'random-init weights (BASELINE configs[%d])' % (args.size, args.size, args.batch, math_words,
                                                                                     1 if args.math in ('f32', 'bf16x3') else 2),
                        'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
-                       'grad_allreduce': ('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, issued as 4 contiguous buckets under '
-                                          'the backward pass (FPN+head, layer4, layer3, rest)') if world > 1 else None},
+                       'grad_allreduce': (('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, ' +
+                                           ('one call after the backward pass (--single-allreduce)' if not trainer.overlap_allreduce else
+                                            'issued as 4 contiguous buckets under the backward pass (FPN+head, layer4, layer3, rest); '
+                                            'north_star names a single call: --single-allreduce times that form'))
+                                          if world > 1 else None)},
             'roofline': roofline,
             'roofline_serial': roofline_serial,
             # whole-step rates: on the dense convolution count of SURVEY §8d (an EFFECTIVE rate: the structured FPN kernels
