@@ -82,6 +82,7 @@ SIGNATURES.update({
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
+    'dbn_set_patch_conv': 'i',
     'dbn_split3': 'pplp',
     'dbn_deform_im2col_t': 'i' + SIGNATURES['dbn_deform_im2col'],
     'dbn_deform_col2im_t': 'i' + SIGNATURES['dbn_deform_col2im'],

@@ -79,6 +79,7 @@ struct IgemmParams {
     // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
     int ksplit, kt_per;
     int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
+    int patch;          // host only: use the pixel-patch form (3x3, stride 1; see igemm_dispatch)
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
     const void* seg_src[4];
     const float* seg_wpk[4];
@@ -201,9 +202,12 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 // AT = 3 (NS = 3): src is the PRE-SPLIT form of an fp32 tensor — three bf16 planes [3][N,H,W,C] with a0 + a1 + a2 == a exactly
 // (dbn_split3) — gathered the same way (3 x 2 pieces per row and k-tile, no conversion: splitting at staging time redid the
 // split for every one of the 9 taps that re-reads an element and made the bf16x3 kernels VALU-bound); dst is fp32.
-template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0>
+// PATCH (3x3, stride 1, pad 1, 16-bit matrix math; Hd % 8 == 0, Wd % 16 == 0, Cs % 32 == 0): the M tile is an 8 x 16 PIXEL PATCH
+// and the A operand is not gathered per tap at all — see the main loop.
+template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void igemm_f32_kernel(const IgemmParams p) {
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
+    static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -231,7 +235,16 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     constexpr int STAGE = KU * UNIT;
     constexpr int NSX = NS > 0 ? NS : 1;
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
-    __shared__ f32x4 smem[2 * STAGE];
+    // 16-bit storage (AT != 0): LDS-DMA ring (see the main loop): stages of DMA_SU units, unpadded images [plane][k/8][row]
+    constexpr int DMA_SU = 2;
+    constexpr int DMA_UNIT = NP * 2 * BM + NSX * 2 * BN;  // 16-byte slots of one unit
+    constexpr int DMA_STAGE = DMA_SU * DMA_UNIT;
+    constexpr int DMA_NSTG = DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
+    // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
+    constexpr int P_PATCH = NSX * 4 * 180;
+    constexpr int P_BUNIT = NSX * 2 * BN, P_BSTAGE = 2 * P_BUNIT;
+    constexpr int P_NSTG = NSX == 1 ? 4 : 3;
+    __shared__ f32x4 smem[PATCH ? 2 * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -275,6 +288,14 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     const int qM = q.M, qHd = q.Hd, qWd = q.Wd;
+    int pn = 0, ph0 = 0, pw0 = 0;  // PATCH: image and top-left output pixel of this tile
+    if constexpr (PATCH) {
+        const int tw = qWd >> 4, tpi = (qHd >> 3) * tw;
+        pn = mt / tpi;
+        const int t = mt - pn * tpi, ty = t / tw;
+        ph0 = ty * 8;
+        pw0 = (t - ty * tw) * 16;
+    }
     int qK = q.K, qKT = q.KT, qS = q.S, qR = q.R;  // MODE 3 changes these (and the source) per level
     int gHs = p.Hs, gWs = p.Ws;
 
@@ -496,6 +517,314 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    if constexpr (PATCH) {
+    // ---- 3x3 / stride 1 on the bf16 matrix pipe: pixel-patch tiles -------------------------------------------------------------
+    // The texture unit handles about one 128-byte line per clock per CU whatever the lanes take from it (tools/probes/
+    // gather_rate.hip), and an im2col gather touches one line per row and tap: at one 32-cycle MFMA per accumulator and unit that
+    // gather, not the matrix pipe, bounds the kernel (4 x 35-71 clocks per unit against 64).  Here a tile is an 8 x 16 patch of
+    // output pixels, and the 10 x 18 input patch around it is brought to LDS ONCE per 32-channel block (contiguous 64/128-byte
+    // runs per pixel; fp32 sources are split into their bf16 planes on the way, once instead of once per tap).  The nine taps are
+    // then plain LDS address offsets of the fragment reads: image [plane][k/8 slice][patch pixel][16 B], and MFMA row i is the
+    // pixel (y, x) = (2*blk + parity(i >> 2), 4*(i >> 3) + (i & 3)) so that each 16-lane group of a ds_read_b128 (lanes
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31}) reads 16 consecutive pixels of one patch row — conflict-free for every tap.
+    // The weight panels stream through a ring of DMA stages as in the generic 16-bit loop below.
+    constexpr int PPX = 180, PROW = 18;
+    constexpr int CHUNKS = AT == 0 ? 8 : 4;           // 16-byte pieces per pixel of a 32-channel block
+    constexpr int PL = (PPX * CHUNKS + NT - 1) / NT;  // pieces per thread
+    constexpr int B_I = NSX * 2 * (BN / 64);          // DMA instructions per unit
+    static_assert((2 * B_I) % 4 == 0 && NT == 256, "weight DMA is dealt evenly to four waves");
+    constexpr int PWB = 2 * B_I / 4;
+    f32x4* const patch = smem;
+    f32x4* const ring = smem + 2 * P_PATCH;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    unsigned poff[PL];
+    int pslot[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        const int idx = tid + j * NT;
+        const bool on = idx < PPX * CHUNKS;
+        const int chunk = idx % CHUNKS, pix = on ? idx / CHUNKS : 0;
+        const int py = pix / PROW, px = pix - py * PROW;
+        const int hs = ph0 - 1 + py, ws = pw0 - 1 + px;
+        const bool v = on && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * (unsigned)ES + (unsigned)chunk * 16u : OOB_OFFSET;
+        // fp32 source: chunk = 4 channels = one 8-byte half of slice chunk >> 1 (slot in 8-byte units); 16-bit: chunk = slice
+        pslot[j] = !on ? -1 : AT == 0 ? ((chunk >> 1) * PPX + pix) * 2 + (chunk & 1) : chunk * PPX + pix;
+    }
+    f32x4 pr[PL];
+    const int ncb = p.Cs >> 5;
+    auto load_patch = [&](int cb) {  // (cb == ncb: the loads are issued all the same, so that the counted waits stay constant)
+        const unsigned add = (unsigned)(cb * 32 * ES);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
+    };
+    auto store_patch = [&](int buf) {
+        f32x4* const P = patch + buf * P_PATCH;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            if (pslot[j] < 0) continue;
+            if constexpr (AT == 0) {
+                u32x2 sp[NSX];
+                split4<NS>(pr[j], sp);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) reinterpret_cast<u32x2*>(P + t * 4 * PPX)[pslot[j]] = sp[t];
+            } else {
+                P[pslot[j]] = pr[j];
+            }
+        }
+    };
+    // weight DMA: instruction t = wave + 4 i of a stage: unit t / B_I, (plane, slice) and 64-column group from t % B_I
+    int b_lds[PWB], b_u[PWB];
+    unsigned b_add[PWB];
+#pragma unroll
+    for (int i = 0; i < PWB; ++i) {
+        const int t = wave_u + 4 * i, u = t / B_I, rr = t - u * B_I, c = rr & 1, gp = rr >> 1;
+        const int g = gp % (BN / 64), plane = gp / (BN / 64);
+        b_u[i] = u;
+        b_lds[i] = u * P_BUNIT + (plane * 2 + c) * BN + 64 * g;
+        b_add[i] = (unsigned)((plane * 2 + c) * p.Cd + n0 + 64 * g + lane) * 16u;
+    }
+    const unsigned bstep_bytes = (unsigned)(2 * NSX * p.Cd) * 16u;
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk + q_wpk_off), 0,
+                                                                           (unsigned)qKT * bstep_bytes, 0x00020000);
+    int g_kt = 0;  // next k-tile to fetch (two per stage; k-tiles past the end are out of range: zeros)
+    auto issue_b = [&](int slot_) {
+#pragma unroll
+        for (int i = 0; i < PWB; ++i) {
+            auto* dst = (__attribute__((address_space(3))) void*)(ring + slot_ * P_BSTAGE + b_lds[i]);
+            const int kt = g_kt + b_u[i];
+            const unsigned off = kt < qKT ? (unsigned)kt * bstep_bytes + b_add[i] : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, dst, 16, (int)off, 0, 0, 0);
+        }
+        g_kt += 2;
+    };
+    // this lane's patch pixel for accumulator block a (rows 2*(wm*MI + a) .. +1 of the tile), before the tap offset
+    const int q4 = li >> 2;
+    const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1) + 0) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
+
+    load_patch(0);
+#pragma unroll
+    for (int s_ = 0; s_ < P_NSTG - 1; ++s_) issue_b(s_);
+    store_patch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int slot = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const f32x4* const P = patch + (cb & 1) * P_PATCH;
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            // stage `st` of this channel block has landed once only the younger stages — and, for the first P_NSTG - 1 stages
+            // after their issue, the next block's patch loads — are outstanding
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((P_NSTG - 2) * PWB + ((st >= 1 && st <= P_NSTG - 1) ? PL : 0)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence: keep the LDS reads of this stage behind it)
+            issue_b(slot == 0 ? P_NSTG - 1 : slot - 1);
+            if (st == 0) {
+                // the counted waits below assume the patch loads are YOUNGER than this interval's weight stage (vmcnt retires in
+                // order): keep the compiler from hoisting them above the DMA instructions
+                asm volatile("" ::: "memory");
+                load_patch(cb + 1);
+                asm volatile("" ::: "memory");
+            }
+            const f32x4* const Bst = ring + slot * P_BSTAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ui = 2 * st + u, h = ui / 9, tap = ui - h * 9;  // compile-time after unrolling
+                const int tr = MODE == 0 ? tap / 3 : 2 - tap / 3, ts = MODE == 0 ? tap % 3 : 2 - tap % 3;
+                const f32x4* const Bs = Bst + u * P_BUNIT;
+                bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+                for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+                        af[t][a] = __builtin_bit_cast(bf16x8, P[(t * 4 + 2 * h) * PPX + a_pix + (2 * a + tr) * PROW + ts]);
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BN + wn * TN + b * 32 + li]);
+                }
+                mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+            }
+            slot = slot + 1 == P_NSTG ? 0 : slot + 1;
+        }
+        if (cb + 1 < ncb) {
+            store_patch((cb + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    } else if constexpr (AT != 0) {
+    // ---- stored 16-bit operands: LDS-DMA ring ------------------------------------------------------------------------------
+    // One 32x32x16 MFMA per accumulator and unit is 32 cycles; a register-staged loop with a prefetch distance of one unit kept the
+    // waves parked on vmcnt / the barrier for 70-80 % of their cycles (SQ_WAIT_ANY; MFMA busy 15 %).  The stored format IS the LDS
+    // image ([plane][k/8][row][8 x 16 bit]), so the panels are written by buffer_load ... lds (64 lanes x 16 B = 64 rows of one
+    // k/8 slice per instruction, padding taps / row tails / units past the end deliver zeros through out-of-range offsets): no
+    // staging registers, hence a ring of DMA_NSTG stages of DMA_SU units with DMA_NSTG - 1 stages in flight across raw barriers
+    // (counted vmcnt).  The instructions of a stage are dealt round-robin to the waves; tap / k-tile state is wave-uniform.
+    constexpr int NW = NT / 64;
+    // A: lanes 2j, 2j+1 fetch the two k/8 slices (32 contiguous bytes) of row j of the instruction's 32 rows — the texture unit
+    // handles ~one 128-byte line per clock whatever the lanes take from it (tools/probes/gather_rate.hip: 71 clocks per instruction
+    // with 64 lines, 35 with 32), and the gather, not the MFMA, bounds these kernels.  The A image is therefore row-major
+    // [plane][row][2 slices]; the fragment reads (stride 32 B) pay a 2-way bank conflict for it.
+    constexpr int A_I = NP * (BM / 32), B_I = NSX * 2 * (BN / 64), U_I = A_I + B_I;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && (DMA_SU * U_I) % NW == 0, "DMA instructions are dealt evenly to the waves");
+    constexpr int PW = DMA_SU * U_I / NW;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int i_u[PW], i_lds[PW];
+    bool i_isA[PW];
+    unsigned i_add[PW];  // A: byte offset of the k/8 slice (+ plane) within a pixel's block; B: byte offset of the lane's piece in a k-tile
+    int i_plane[PW];
+    int r_hb[PW], r_wb[PW], r_nb[PW];
+    int r_n[MODE == 3 ? PW : 1], r_hd[MODE == 3 ? PW : 1], r_wd[MODE == 3 ? PW : 1];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int t = wave_u + NW * i, u = t / U_I, r = t - u * U_I;
+        const bool isA = r < A_I;
+        const int rr = isA ? r : r - A_I, c = rr & 1, gp = rr >> 1;
+        const int g = isA ? r % (BM / 32) : gp % (BN / 64), plane = isA ? r / (BM / 32) : gp / (BN / 64);
+        i_u[i] = u;
+        i_isA[i] = isA;
+        i_plane[i] = plane;
+        i_lds[i] = u * DMA_UNIT + (isA ? plane * 2 * BM + 64 * g : NP * 2 * BM + (plane * 2 + c) * BN + 64 * g);
+        i_add[i] = isA ? (unsigned)(lane & 1) * 16u : (unsigned)((plane * 2 + c) * p.Cd + n0 + 64 * g + lane) * 16u;
+        r_hb[i] = r_wb[i] = r_nb[i] = 0;
+        if (MODE == 3) r_n[MODE == 3 ? i : 0] = r_hd[MODE == 3 ? i : 0] = r_wd[MODE == 3 ? i : 0] = 0;
+        if (isA) {
+            const int m = m0 + 32 * g + (lane >> 1);
+            const bool ok = m < qM;
+            int n, rem, hd, wd;
+            divmod24(ok ? m : 0, HWd, 1.0f / (float)HWd, n, rem);
+            divmod24(rem, qWd, 1.0f / (float)qWd, hd, wd);
+            r_nb[i] = n * p.Hs * p.Ws * p.Cs;
+            if (MODE == 3) {
+                r_n[MODE == 3 ? i : 0] = n;
+                r_hd[MODE == 3 ? i : 0] = ok ? hd : -(1 << 20);
+                r_wd[MODE == 3 ? i : 0] = wd;
+            } else if (MODE == 0) {
+                r_hb[i] = ok ? hd * p.stride - q.pad_h : -(1 << 20);
+                r_wb[i] = wd * p.stride - q.pad_w;
+            } else {
+                r_hb[i] = ok ? hd + q.pad_h : -(1 << 20);
+                r_wb[i] = wd + q.pad_w;
+            }
+        }
+    }
+    // wave-uniform walk over the units: tap (g_r, g_s) of channel block g_cb, k-tile g_kt of the weight panel
+    int g_left, g_kt, g_r, g_s, g_cb, g_level = 0;
+    const unsigned bstep_bytes = (unsigned)(2 * NSX * p.Cd) * 16u;
+    __amdgpu_buffer_rsrc_t rsrcB;
+    auto level_dma = [&](int g) {  // MODE 3: source, tap geometry, weight panel of pyramid level g (see level_setup)
+        const int f = 1 << g, kk = f + 2;
+        const int oh0g = q.oh0 & (f - 1), ow0g = q.ow0 & (f - 1);
+        const int ph = (oh0g + 1) & (f - 1), pw = (ow0g + 1) & (f - 1);
+        qR = taps_of_class(kk, ph, f);
+        qS = taps_of_class(kk, pw, f);
+        const int padh = (oh0g + 1 - ph) >> g, padw = (ow0g + 1 - pw) >> g;
+        qK = qR * qS * p.Cs;
+        qKT = qK >> 4;
+        gHs = p.Hdf >> g;
+        gWs = p.Wdf >> g;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        if (AT == 3) plane_bytes = p.seg_plane_bytes[g];
+        long krows = 0;
+        for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_wpk[g] + krows * p.Cd * NSX / 2), 0, (unsigned)qKT * bstep_bytes,
+                                                  0x00020000);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            r_nb[i] = r_n[MODE == 3 ? i : 0] * gHs * gWs * p.Cs;
+            r_hb[i] = r_hd[MODE == 3 ? i : 0] * (8 >> g) + (q.oh0 >> g) + padh;
+            r_wb[i] = r_wd[MODE == 3 ? i : 0] * (8 >> g) + (q.ow0 >> g) + padw;
+        }
+        g_left = qKT;
+        g_kt = g_r = g_s = g_cb = 0;
+    };
+    int nstages;
+    if (MODE == 3) {
+        nstages = 0;
+        for (int g = 0; g < 4; ++g) {
+            const int f = 1 << g, kk = f + 2;
+            const int ph = ((q.oh0 & (f - 1)) + 1) & (f - 1), pw = ((q.ow0 & (f - 1)) + 1) & (f - 1);
+            nstages += (taps_of_class(kk, ph, f) * taps_of_class(kk, pw, f) * (p.Cs >> 4) + DMA_SU - 1) / DMA_SU;
+        }
+        level_dma(0);
+    } else {
+        const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
+        g_cb = 16 * cb;
+        g_r = tap / qS;
+        g_s = tap - g_r * qS;
+        g_kt = kt_begin;
+        g_left = kt_end - kt_begin;
+        nstages = (g_left + DMA_SU - 1) / DMA_SU;
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk + q_wpk_off), 0, (unsigned)qKT * bstep_bytes, 0x00020000);
+    }
+    auto issue_stage = [&](int slot) {
+        if (MODE == 3 && g_left <= 0 && g_level < 3) level_dma(++g_level);
+        bool uv[DMA_SU];
+        int ur[DMA_SU], us[DMA_SU], ucb[DMA_SU], ukt[DMA_SU];
+#pragma unroll
+        for (int u = 0; u < DMA_SU; ++u) {
+            uv[u] = g_left > 0;
+            ur[u] = g_r; us[u] = g_s; ucb[u] = g_cb; ukt[u] = g_kt;
+            --g_left;
+            ++g_kt;
+            ++g_s;
+            const bool ws_ = g_s == qS;
+            g_s = ws_ ? 0 : g_s;
+            g_r += ws_ ? 1 : 0;
+            const bool wr_ = g_r == qR;
+            g_r = wr_ ? 0 : g_r;
+            g_cb += wr_ ? 16 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int u = i_u[i];
+            const bool v_u = u == 0 ? uv[0] : uv[DMA_SU - 1];
+            const int tr = u == 0 ? ur[0] : ur[DMA_SU - 1], ts = u == 0 ? us[0] : us[DMA_SU - 1];
+            const int tcb = u == 0 ? ucb[0] : ucb[DMA_SU - 1], tkt = u == 0 ? ukt[0] : ukt[DMA_SU - 1];
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * DMA_STAGE + i_lds[i]);
+            if (i_isA[i]) {
+                const int hs = MODE == 0 ? r_hb[i] + tr : r_hb[i] - tr;
+                const int ws = MODE == 0 ? r_wb[i] + ts : r_wb[i] - ts;
+                const bool v = v_u && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+                const unsigned off = (unsigned)(r_nb[i] + (hs * gWs + ws) * p.Cs + tcb) * 2u + i_add[i] + (AT == 3 ? (unsigned)i_plane[i] * plane_bytes : 0u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (int)(v ? off : OOB_OFFSET), 0, 0, 0);
+            } else {
+                const unsigned off = v_u ? (unsigned)tkt * bstep_bytes + i_add[i] : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, dst, 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+    static_assert(DMA_SU == 2, "issue_stage selects between two units");
+#pragma unroll
+    for (int s_ = 0; s_ < DMA_NSTG - 1; ++s_) issue_stage(s_);
+    int slot = 0;
+    for (int st_ = 0; st_ < nstages; ++st_) {
+        // this wave's part of stage st_ has landed once at most the DMA_NSTG - 2 younger stages are outstanding
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW * (DMA_NSTG - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part is in LDS, and everyone is done reading the slot of stage st_ - 1
+        asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence)
+        const int fill = slot == 0 ? DMA_NSTG - 1 : slot - 1;
+        issue_stage(fill);
+        const f32x4* Sg = smem + slot * DMA_STAGE;
+#pragma unroll
+        for (int u = 0; u < DMA_SU; ++u) {
+            const f32x4* As = Sg + u * DMA_UNIT;
+            const f32x4* Bs = As + NP * 2 * BM;
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * BM + wm * TM + a * 32 + li) * 2 + lh]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BN + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+        }
+        slot = slot + 1 == DMA_NSTG ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-filled stages issued past the end
+    __syncthreads();
+    } else {
     for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
     if (MODE == 3) {
         level_setup(level);
@@ -577,6 +906,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     }
     }
 
+    }
     // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
     // statistics below and the store loop both see the final values
     // split-K launches write fp32 slabs whatever the activation type (the slab sum rounds once)
@@ -596,7 +926,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     // offsets are formed in 32 bits (element index < 2^31 is checked on the host) and widened once per row
     auto for_rows = [&](int a, auto&& fn) {
         const int rbase = m0 + wm * TM + a * 32 + 4 * lh;
-        if (MODE >= 2) {
+        if constexpr (PATCH) {  // row i = (r & 3) + 8 (r >> 2) + 4 lh is the pixel (2 blk + parity(i >> 2), 4 (i >> 3) + (i & 3))
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int y = ph0 + 2 * (wm * MI + a) + ((__builtin_popcount(r >> 2) + lh) & 1), x = pw0 + (r >> 2) * 4 + (r & 3);
+                fn(r, true, (long)((unsigned)((pn * p.Hdf + y) * p.Wdf + x) * (unsigned)p.Cd));
+            }
+        } else if (MODE >= 2) {
             int n, rem, hd, wd;
             divmod24(min(rbase, qM - 1), HWd, rcp_hw, n, rem);
             divmod24(rem, qWd, rcp_w, hd, wd);
@@ -727,6 +1063,56 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
 #pragma unroll
     for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
     const long dcol = n0 + wn * TN + li;
+    if constexpr (!DST_F32) {
+        if (!to_slab) {
+            // 16-bit output: a lane holds ONE column of 16 rows, so direct stores are 2-byte scatters (MI*NI*16 store instructions
+            // per lane, 64 contiguous bytes per row each) — as many texture-unit cycles as the whole k-loop of a K = 576 tile.  The
+            // tile goes through LDS instead: written in the storage type, read back row-major, stored 16 bytes per lane
+            // (BN/8 lanes cover a row's 2*BN contiguous bytes): BM*BN/(8*NT) store instructions per lane.
+            constexpr int PITCH = BN + 8;  // 16-bit elements; +16 bytes keeps the 16-byte reads aligned and rotates the banks
+            static_assert((long)BM * PITCH * 2 <= (long)sizeof(smem), "output tile must fit the LDS panels");
+            unsigned short* const T = reinterpret_cast<unsigned short*>(smem);
+            __syncthreads();  // the panels / the statistics scratch are dead
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        dbn_st1<DST_F32 ? 1 : AT>(T, row * PITCH + wn * TN + b * 32 + li, acc[a][b][r] + bv[b]);
+                    }
+            __syncthreads();
+            constexpr int LPR = BN / 8, RPP = NT / LPR;
+            static_assert(BM % RPP == 0, "whole passes");
+            const int piece = tid % LPR;
+#pragma unroll
+            for (int ps = 0; ps < BM / RPP; ++ps) {
+                const int row = ps * RPP + tid / LPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * PITCH + piece * 8);
+                bool ok;
+                long doff;
+                if constexpr (PATCH) {
+                    const int blk = row >> 5, q4r = (row & 31) >> 2;
+                    const int y = ph0 + 2 * blk + (__builtin_popcount(q4r) & 1), x = pw0 + (q4r >> 1) * 4 + (row & 3);
+                    ok = true;
+                    doff = (long)((unsigned)((pn * p.Hdf + y) * p.Wdf + x) * (unsigned)p.Cd);
+                } else if (MODE >= 2) {
+                    int n, rem, hd, wd;
+                    const int m = m0 + row;
+                    ok = m < qM;
+                    divmod24(ok ? m : 0, HWd, rcp_hw, n, rem);
+                    divmod24(rem, qWd, rcp_w, hd, wd);
+                    doff = (long)((unsigned)((n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * (unsigned)p.Cd);
+                } else {
+                    ok = m0 + row < qM;
+                    doff = (long)((unsigned)(m0 + row) * (unsigned)p.Cd);
+                }
+                if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(dstv) + doff + n0 + piece * 8) = v;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < MI; ++a)
         for_rows(a, [&](int r, bool ok, long doff) {
@@ -761,6 +1147,16 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
+    if constexpr (BM == 128 && WM == 2 && WN == 2 && NS > 0 && AT != 3) {
+        if (p.patch && mode < 2) {
+            if (mode == 0)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, true>), dim3(grid), dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT, true>), dim3(grid), dim3(256), 0, st, p);
+            return dbn_status();
+        }
+    }
+    if (p.patch) return DBN_ERR_ARG;
     if (mode == 0)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)
@@ -1164,9 +1560,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
     const float* lds = reinterpret_cast<const float*>(smem);
     for (int kt = 0; kt < KT; ++kt) {
         // this wave's DMA of stage kt has landed once at most the PER_WAVE instructions of stage kt+1 are outstanding
-        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's part of stage kt is in LDS; everyone is done reading slot (kt-1) % 3
+        asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence)
         if (kt + 2 < KT) issue_stage((kt + 2) % NSTG);
         const float* As = lds + (kt % NSTG) * STAGE_F4 * 4;
         const float* Bs = As + A_F4 * 4;
@@ -1596,10 +1993,26 @@ int dbn_igemm_tile_config(int M, int Cd) {
     return best;
 }
 
+static int g_patch_enabled = 1;
+static int g_patch_bn64 = getenv("DBN_PATCH_BN64") ? atoi(getenv("DBN_PATCH_BN64")) : 1;
+int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
+    const int old = g_patch_enabled;
+    g_patch_enabled = on != 0;
+    return old;
+}
 static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st, int at = 0) {
     // tile choice from the total row count (for parity classes: all classes together)
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
+    // pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
+    // partial rows of a launch are the same N*H*W/128 either way)
+    p.patch = g_patch_enabled && (kmode == 0 || kmode == 1) && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && p.R == 3 && p.S == 3 &&
+              p.stride == 1 && p.pad == 1 && p.Hs == p.Hdf && p.Ws == p.Wdf && p.Hdf % 8 == 0 && p.Wdf % 16 == 0 && p.Cs % 32 == 0 &&
+              p.ksplit <= 1;
+    // 128 x 64 tiles also where the generic loop takes 128 x 128: K is short (two to eight channel blocks), so twice the workgroups
+    // hide the prologue / epilogue better than the wider tile saves weight traffic (measured: 120.8 GFLOP launch 509 -> ~270 us;
+    // step +1-3 %); the BatchNorm partial rows depend on BM only.  DBN_PATCH_BN64=0 keeps the generic choice.
+    if (p.patch && cfg == 1 && g_patch_bn64) cfg = 3;
     switch (cfg) {
         case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st, at);
         case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st, at);
@@ -1901,7 +2314,7 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
-        p.ksplit = 1; p.kt_per = 0;
+        p.ksplit = 1; p.kt_per = 0; p.patch = 0;
         p.src_bytes = p.seg_bytes[0];
         const int rc = launch_igemm<128, 128, 2, 2>(p, 3, ns, st, at);
         if (rc) return rc;

@@ -287,6 +287,9 @@ int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, fl
 /* weight-gradient kernel for exact-fp32 math on fp32 tensors: 0 = register-transposing kernel (default), 1 = LDS-DMA kernel
  * (pixel-major LDS image, three-stage ring; same results up to the summation order inside a split) */
 int dbn_set_wgrad_variant(int variant);
+/* 0: route 3x3 / stride-1 convolutions of the 16-bit matrix modes through the generic gather loop instead of the pixel-patch
+   form (A/B and test hook; returns the previous setting) */
+int dbn_set_patch_conv(int on);
 /* tile variant of the weight-gradient kernel for O output channels, J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64 */
 int dbn_wgrad_tile_config(int O, int J);
 /* dbn_wgrad_t in two calls: phase 1 = matrix kernels (-> slabs), phase 2 = slab reduction (-> grad_oihw) */

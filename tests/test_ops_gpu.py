@@ -1012,3 +1012,73 @@ def test_weight_gradient_lds_dma_variant(case):
     g0 = wgrad(nhwc(dy), xs, Co, Ci, k, s_, p_, scale=0.5)
     report('wgrad (LDS-DMA variant)', g.cpu(), 0.5 * gref, 2e-5 * float(gref.abs().max()), 1e-4)
     report('wgrad variants agree', g.cpu(), g0.cpu(), 1e-5 * float(gref.abs().max()), 1e-5)
+
+
+@pytest.mark.parametrize('mode_name', ['bf16x3', 'bf16c', 'bf16', 'fp16'])
+@pytest.mark.parametrize('Co,tile', [(64, 3), (128, 1), (128, 3)])
+def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
+    """3x3 / stride-1 convolutions and their data gradients in the 16-bit matrix modes run in the pixel-patch form (the input patch
+    of an 8 x 16 output tile staged in LDS once per 32-channel block, taps as LDS offsets).  Same k order, same MFMA sequence per
+    accumulator as the generic gather loop: the results are BIT-IDENTICAL to it (dbn_set_patch_conv(0)), including the fused
+    bias, the accumulate form and, through it, everything the generic loop is tested against."""
+    ns, dtype = {'bf16x3': (3, torch.float32), 'bf16c': (1, torch.float32), 'bf16': (1, torch.bfloat16), 'fp16': (1, torch.float16)}[mode_name]
+    kind = 2 if dtype == torch.float16 else ns
+    N, Ci, H, W = 2, 128, 24, 48   # four 32-channel blocks, 3 x 3 patches per image
+    x = nhwc(rnd(N, Ci, H, W, seed=11)).to(dtype)
+    w = rnd(Co, Ci, 3, 3, seed=12, scale=(2.0 / (Ci * 9))**0.5)
+    b = rnd(Co, seed=13).to(DEV)
+    dy = nhwc(rnd(N, Co, H, W, seed=14)).to(dtype)
+    base = nhwc(rnd(N, Ci, H, W, seed=15)).to(dtype)
+
+    def run():
+        y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+        igemm_t(x, pack_t(w, 0, 1, kind, Ci), b, y, 3, 1, 1, 0, ns=ns, tile=tile)  # (the patch form needs a 128-row tile: 1 or 3)
+        d = base.clone()
+        igemm_t(dy, pack_t(w, 1, 1, kind), None, d, 3, 1, 1, 1, accumulate=1, ns=ns, tile=tile)
+        torch.cuda.synchronize()
+        return y, d
+
+    try:
+        assert L().dbn_set_patch_conv(1) in (0, 1)
+        y1, d1 = run()
+        L().dbn_set_patch_conv(0)
+        y0, d0 = run()
+    finally:
+        L().dbn_set_patch_conv(1)
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(d1.float()).all()
+    assert torch.equal(y1, y0), 'forward: max |diff| %g' % float((y1.float() - y0.float()).abs().max())
+    assert torch.equal(d1, d0), 'data gradient: max |diff| %g' % float((d1.float() - d0.float()).abs().max())
+    # and against fp64: on the operands as stored for 16-bit storage; bf16x3 is fp32-accurate on fp32 operands
+    wq = w.to(dtype).double() if dtype != torch.float32 else w.double()
+    ref = F.conv2d(nchw(x.double()), wq, b.double().cpu(), 1, 1)
+    tol = {'bf16x3': 2e-6, 'bf16c': 2e-2, 'bf16': 2e-2, 'fp16': 3e-3}[mode_name]
+    err = float((nchw(y1.double()) - ref).abs().max()) / float(ref.abs().max())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize('mode_name', ['bf16', 'bf16x3'])
+def test_pixel_patch_convolution_is_race_free_at_full_size(mode_name):
+    """The pixel-patch kernels pipeline LDS-DMA weight stages and register-staged patches across raw barriers (counted vmcnt,
+    lgkmcnt(0) before each barrier).  A missing wait does not show on small grids — every workgroup alone on its CU — but did at
+    the benchmark's size (several workgroups per CU, thousands of tiles): repeat full-size launches (16 x 160 x 160, both 128-row
+    tiles, forward and data gradient) and require every run to equal the generic gather form bit for bit."""
+    ns, dtype = {'bf16x3': (3, torch.float32), 'bf16': (1, torch.bfloat16)}[mode_name]
+    N, H, W = 16, 160, 160
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for (Ci, Co, tile, mode) in ((64, 256, 1, 1), (256, 64, 3, 0), (128, 128, 1, 1), (128, 128, 1, 0)):
+        w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
+        cin, cout = (Ci, Co) if mode == 0 else (Co, Ci)
+        x = torch.randn(N, H, W, cin, device=DEV, generator=g).to(dtype)
+        wp = pack_t(w, mode, 1, ns, Ci) if mode == 0 else pack_t(w, 1, 1, ns)
+        try:
+            L().dbn_set_patch_conv(0)
+            ref = torch.zeros(N, H, W, cout, device=DEV, dtype=dtype)
+            igemm_t(x, wp, None, ref, 3, 1, 1, mode, ns=ns, tile=tile)
+        finally:
+            L().dbn_set_patch_conv(1)
+        for run in range(3):
+            y = torch.zeros_like(ref)
+            igemm_t(x, wp, None, y, 3, 1, 1, mode, ns=ns, tile=tile)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref), '%s Ci %d Co %d tile %d mode %d run %d: %d elements differ' % (
+                mode_name, Ci, Co, tile, mode, run, int((y != ref).sum()))
