@@ -83,6 +83,7 @@ SIGNATURES.update({
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
     'dbn_set_patch_conv': 'i',
+    'dbn_igemm_kernel_config': 'i' * 16,
     'dbn_split3': 'pplp',
     'dbn_deform_im2col_t': 'i' + SIGNATURES['dbn_deform_im2col'],
     'dbn_deform_col2im_t': 'i' + SIGNATURES['dbn_deform_col2im'],

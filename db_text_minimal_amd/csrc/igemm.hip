@@ -2000,19 +2000,35 @@ int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 
     g_patch_enabled = on != 0;
     return old;
 }
+// pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
+// partial rows of a launch are the same N*H*W/128 either way); kmode: kernel MODE
+static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int stride, int pad, int Hs, int Ws, int Hd, int Wd, int Cs,
+                           int ksplit) {
+    return g_patch_enabled && (kmode == 0 || kmode == 1) && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && R == 3 && S == 3 && stride == 1 &&
+           pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 && Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
+}
+static int patch_cfg(int cfg) { return (cfg == 1 && g_patch_bn64) ? 3 : cfg; }
+
+// What one (unchunked) dbn_igemm_t call launches: tile configuration (1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64) + 16 if the
+// pixel-patch kernel is used — i.e. the template arguments <BM,BN,WM,WN,MODE,NS,AT,PATCH> of its rocprofv3 symbol.
+// kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid.
+int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,
+                            int pad, int tile_hint, int ksplit) {
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(N * Hd * Wd, Cd);
+    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    if (patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) return patch_cfg(cfg) + 16;
+    return cfg;
+}
+
 static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st, int at = 0) {
     // tile choice from the total row count (for parity classes: all classes together)
     int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
-    // pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
-    // partial rows of a launch are the same N*H*W/128 either way)
-    p.patch = g_patch_enabled && (kmode == 0 || kmode == 1) && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && p.R == 3 && p.S == 3 &&
-              p.stride == 1 && p.pad == 1 && p.Hs == p.Hdf && p.Ws == p.Wdf && p.Hdf % 8 == 0 && p.Wdf % 16 == 0 && p.Cs % 32 == 0 &&
-              p.ksplit <= 1;
+    p.patch = patch_eligible(kmode, ns, at, cfg, p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hdf, p.Wdf, p.Cs, p.ksplit);
     // 128 x 64 tiles also where the generic loop takes 128 x 128: K is short (two to eight channel blocks), so twice the workgroups
     // hide the prologue / epilogue better than the wider tile saves weight traffic (measured: 120.8 GFLOP launch 509 -> ~270 us;
     // step +1-3 %); the BatchNorm partial rows depend on BM only.  DBN_PATCH_BN64=0 keeps the generic choice.
-    if (p.patch && cfg == 1 && g_patch_bn64) cfg = 3;
+    if (p.patch) cfg = patch_cfg(cfg);
     switch (cfg) {
         case 1: return launch_igemm<128, 128, 2, 2>(p, kmode, ns, st, at);
         case 2: return launch_igemm<256, 64, 4, 1>(p, kmode, ns, st, at);

@@ -40,8 +40,8 @@ def flat_layout(numels):
     return offs, total
 
 
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d>',
-                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d>'}  # rocprof names
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s>'}  # rocprof names
 WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d>',
                     3: 'wgrad_f32_kernel<64,128,2,2,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d>'}
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
@@ -381,7 +381,8 @@ class Engine:
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
-            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
+            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0,
+                             (N, H, W, C, Ho, Wo, k, s, p))
         self._igemm('igemm fwd ' + name, x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k,
                     k, s, p, 0, 0, 0)
         if self.prof:
@@ -419,7 +420,8 @@ class Engine:
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
-            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0)
+            self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0,
+                             (N, H, W, C, Ho, Wo, k, s, p))
         sc, sh = self._conv_bn_call('conv+bn ' + name, bn_name, bn, y,
                                     (x.data_ptr(), wpk.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Ho, Wo, conv.cout, k, k,
                                      s, p, 0), 0, s)
@@ -444,16 +446,24 @@ class Engine:
             self.prof.end()
         return y, sc, sh
 
-    def _prof_igemm(self, M, Cd, flops, tag='', mode=0):
-        self.prof.begin(IGEMM_TILE_NAMES[self.L.dbn_igemm_tile_config(M, Cd)] % (mode, self.ns, 3 if self._use_planes else self.at), flops,
-                        0.0, tag)
+    def _prof_igemm(self, M, Cd, flops, tag='', mode=0, geom=None):
+        """geom = (N, Hs, Ws, Cs, Hd, Wd, R, stride, pad) of a forward / stride-1 data-gradient call: only those can take the
+        pixel-patch kernel (the last template argument of the symbol)."""
+        cfg = self.L.dbn_igemm_tile_config(M, Cd)
+        at = 3 if self._use_planes else self.at
+        if geom is not None and mode < 2:
+            N, Hs, Ws, Cs, Hd, Wd, R, stride, pad = geom
+            ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * R * Cs, Cs) if self.splitk else 1
+            cfg = self.L.dbn_igemm_kernel_config(at, self.ns, mode, N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, 0, ks)
+        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false'), flops, 0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None):
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
         wpk = self.pack(name, conv.weight, 1, conv.stride, version=version)
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
-            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1)
+            self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1,
+                             (N, Ho, Wo, O, H, W, conv.k, conv.stride, conv.padding))
         self._igemm('igemm dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
                     conv.stride, conv.padding, 1, int(accumulate), 0)
         if self.prof:
@@ -965,7 +975,7 @@ class Engine:
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co

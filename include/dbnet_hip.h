@@ -290,6 +290,10 @@ int dbn_set_wgrad_variant(int variant);
 /* 0: route 3x3 / stride-1 convolutions of the 16-bit matrix modes through the generic gather loop instead of the pixel-patch
    form (A/B and test hook; returns the previous setting) */
 int dbn_set_patch_conv(int on);
+/* what one (unchunked) dbn_igemm_t call launches: tile configuration as dbn_igemm_tile_config, + 16 for the pixel-patch kernel
+   (kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid) — the template arguments of its rocprofv3 symbol */
+int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,
+                            int pad, int tile_hint, int ksplit);
 /* tile variant of the weight-gradient kernel for O output channels, J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64 */
 int dbn_wgrad_tile_config(int O, int J);
 /* dbn_wgrad_t in two calls: phase 1 = matrix kernels (-> slabs), phase 2 = slab reduction (-> grad_oihw) */
