@@ -547,11 +547,19 @@ class Engine:
                   'bn eval ' + name)
         return sc, sh
 
+    def _prof_hbm(self, kernel, nbytes):
+        """Bracket an HBM-bound launch with its ALGORITHMIC bytes (tensors read + written once); pair with self.prof.end()."""
+        if self.prof:
+            self.prof.begin(kernel, 0.0, float(nbytes))
+
     def bn_apply(self, y, sc, sh, out_name, relu=True, res=None, rsc=None, rsh=None):
         C = y.shape[-1]
         out = self.buf(out_name, *y.shape)
+        self._prof_hbm('bn_apply_kernel', y.numel() * y.element_size() * (2 + (res is not None)))
         check(self.L.dbn_bn_apply_t(self.at, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), _p(res), _p(rsc), _p(rsh), out.data_ptr(),
                                     y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
+        if self.prof:
+            self.prof.end()
         return out
 
     bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
@@ -573,12 +581,17 @@ class Engine:
             dbias = self.grad_views[conv_bias]
             self._bias_done.add(conv_bias)
         # sums: [2][C] reductions already produced by the kernel that wrote dout
+        nb = y.numel() * y.element_size()
+        rd = 2 + (zmask is not None)  # tensors a pass reads: dout, y (+ the ReLU mask source)
+        self._prof_hbm('bn_bwd_reduce_kernel + bn_bwd_finalize_kernel + bn_bwd_apply_kernel', nb * ((0 if sums is not None else rd) + rd + 1 + (gout is not None) * (1 + bool(gout_acc))))
         check(self.L.dbn_bn_backward_t(self.at, _p(sums), int(sums_parts), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
                                         self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
                                         self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),
                                         self.grad_views[name + '.weight'].data_ptr(), self.grad_views[name + '.bias'].data_ptr(),
                                         _p(dbias), M, C, self.grad_scale, self.reduce_ws().data_ptr(), self.stream),
               'bn backward ' + name)
+        if self.prof:
+            self.prof.end()
         return dy
 
     def up_fwd(self, src, addend, dst, coff=0):
@@ -616,8 +629,11 @@ class Engine:
         y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
+        self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
         check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
               'maxpool fwd')
+        if self.prof:
+            self.prof.end()
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
 
@@ -690,7 +706,7 @@ class Engine:
         head_out = self.fbuf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
         b6, t6 = head.binarize[6], head.thresh[6]
         if self.prof:  # reads 2 x 64ch at half resolution, writes `ch` full-resolution maps
-            self.prof.begin('head_tail_fwd_kernel', 0.0, 4.0 * N * Hh * Wh * 128 + 4.0 * N * 4 * Hh * Wh * ch)
+            self.prof.begin('head_tail_fwd_kernel', 0.0, float(yb_.element_size()) * N * Hh * Wh * 128 + 4.0 * N * 4 * Hh * Wh * ch)
         check(L.dbn_head_tail_fwd_t(self.at, yb_.data_ptr(), yt_.data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(), b6.bias.data_ptr(),
                                   t6.bias.data_ptr(), sb_.data_ptr(), hb_.data_ptr(), st_.data_ptr(), ht_.data_ptr(),
                                   head_out.data_ptr(), N, Hh, Wh, ch, float(head.k), st), 'head_tail_fwd')
@@ -837,6 +853,8 @@ class Engine:
         G = self.grad_views
         hb, ht = 'segmentation_head.binarize.4', 'segmentation_head.thresh.4'
         bn_sums = self.fbuf('head/bn4_sums', 4, 64)  # the kernel also reduces what the two BatchNorm backwards need
+        # reads both 64-channel ConvT outputs, the maps and their gradients; writes both 64-channel gradients
+        self._prof_hbm('head_tail_bwd_kernel + fold_head_grads_kernel + fold_partials_d_kernel', 4.0 * dz1b.element_size() * dz1b.numel() + 4.0 * (out.numel() + dpreds.numel()))
         check(L.dbn_head_tail_bwd_t(self.at, B['binarize/y1'].data_ptr(), B['thresh/y1'].data_ptr(), b6.weight.data_ptr(),
                                   t6.weight.data_ptr(), out.data_ptr(), dpreds.data_ptr(), B[hb + '/scale'].data_ptr(),
                                   B[hb + '/shift'].data_ptr(), B[ht + '/scale'].data_ptr(), B[ht + '/shift'].data_ptr(),
@@ -847,6 +865,8 @@ class Engine:
                                   G['segmentation_head.thresh.6.weight'].data_ptr(),
                                   G['segmentation_head.thresh.6.bias'].data_ptr(), N, Hh, Wh, 3, float(head.k),
                                   self.grad_scale, ws.data_ptr(), st), 'head_tail_bwd')
+        if self.prof:
+            self.prof.end()
         f = B['fpn/z']
         df = self.buf('fpn/dz', *f.shape)
         for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
@@ -936,10 +956,13 @@ class Engine:
         # the max-pool backward also emits the partial sums of the stem BatchNorm's backward (it has y and dz in registers)
         nparts = L.dbn_maxpool_bwd_parts(N, y0.shape[1], y0.shape[2], 64)
         parts = self.scratch('_stem_bn_parts', 2 * 64 * nparts)
+        self._prof_hbm('bnrelu_maxpool_bwd_kernel', (2 * y0.numel() + 2 * dpool.numel()) * y0.element_size())  # y, pooled, dpool -> dz
         check(L.dbn_bnrelu_maxpool_bwd_t(self.at, y0.data_ptr(), B['backbone.bn1/scale'].data_ptr(), B['backbone.bn1/shift'].data_ptr(),
                                          B['stem/pool'].data_ptr(), dpool.data_ptr(), dz.data_ptr(), N, y0.shape[1], y0.shape[2], 64,
                                          B['backbone.bn1/mean'].data_ptr(), B['backbone.bn1/rstd'].data_ptr(), parts.data_ptr(), st),
               'maxpool bwd')
+        if self.prof:
+            self.prof.end()
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy', sums=parts, sums_parts=nparts)
         self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)
         self.join_side()

@@ -128,8 +128,14 @@ class DBTrainer:
             self._ws = torch.empty(need, device=dev)
         losses = torch.empty(5, device=dev)
         fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
+        eng = self.model.engine
+        if eng.prof:  # reads the 3 maps and the 4 targets once
+            eng.prof.begin('db_loss_fwd_kernel', 0.0, 4.0 * (preds.numel() + gts.numel()))
         check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
                   self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
+        if eng.prof:
+            eng.prof.end()
+            eng.prof.begin('db_loss_bwd_kernel', 0.0, 4.0 * (2 * preds.numel() + gts.numel()))  # + writes the 3 map gradients
         dpreds = self.model.engine.fbuf('dpreds', N, C, H, W)
         if per_pixel:
             check(L.dbn_db_loss_ohem_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(),
@@ -137,6 +143,8 @@ class DBTrainer:
         else:
             check(L.dbn_db_loss_bwd(preds.data_ptr(), gts.data_ptr(), self._coef.data_ptr(), self._gone.data_ptr(), c.alpha, c.beta,
                                     N, H, W, C, dpreds.data_ptr(), st), 'db_loss_bwd')
+        if eng.prof:
+            eng.prof.end()
         return losses, dpreds
 
     def step(self, img, gts):
