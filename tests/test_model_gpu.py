@@ -184,16 +184,21 @@ def test_cfg1_2x640_vs_reference_golden(golden_dir):
         report('cfg1 losses step %d' % it, losses.cpu().double(), torch.from_numpy(z['losses'][it]), tol, tol)
 
 
-def test_cfg2_16x640_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize('math', ['f32', 'bf16x3'])
+def test_cfg2_16x640_vs_reference_golden(golden_dir, math):
     """BASELINE configs[1] — the benchmarked workload itself (16x3x640x640, one train step, train.py:160-172) against the
     REFERENCE's own numbers (tests/golden/make_golden.py --only-cfg2): 4096-point samples + L2 norms of the three maps at
     the north_star tolerance, the five losses, six representative gradients, the running statistics after the step.
-    Train-mode BatchNorm merges 3200 tile partials per channel here (400 in the 2x640 golden)."""
+    Train-mode BatchNorm merges 3200 tile partials per channel here (400 in the 2x640 golden).
+    `bf16x3` (fp32 tensors, every product as an exact three-way bf16 split on the bf16 matrix pipe — here through the
+    pixel-patch kernels) has to meet the SAME bounds as the exact-fp32 instruction: it is the fp32-accurate alternative line
+    of bench.py (`alt_modes.bf16x3`)."""
     z = np.load(os.path.join(golden_dir, 'cfg2_16x640.npz'))
     n, size, seed, steps = (int(v) for v in z['meta'])
     assert (n, size, steps) == (16, 640, 1)
     img, gts = O.synthetic_batch(n, size, seed=seed + 100)
     model = make_model(seed).train()
+    model.engine.set_conv_math(math)
     tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = tr.step(img.to(DEV), gts.to(DEV))
     for c, nm in enumerate('PTB'):
