@@ -191,9 +191,10 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 #define DBN_IGEMM_W4 0
 #endif
 #if DBN_IGEMM_W4
-#define DBN_IGEMM_OCC(BM, BN, NS, MODE) __attribute__((amdgpu_waves_per_eu(((BM) == 128 && (BN) == 128 && (NS) == 0 && (MODE) < 3) ? 4 : 1, 8)))
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) __attribute__((amdgpu_waves_per_eu(((BM) == 128 && (BN) == 128 && (NS) == 0 && (MODE) < 3) ? 4 : 1, 8)))
 #else
-#define DBN_IGEMM_OCC(BM, BN, NS, MODE)
+// pixel-patch kernels with three planes: two waves per SIMD (<= 256 registers; the fully unrolled nine stages had taken 257)
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : 1, 8)))
 #endif
 
 // AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
@@ -205,7 +206,7 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
 // PATCH (3x3, stride 1, pad 1, 16-bit matrix math; Hd % 8 == 0, Wd % 16 == 0, Cs % 32 == 0): the M tile is an 8 x 16 PIXEL PATCH
 // and the A operand is not gathered per tap at all — see the main loop.
 template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false>
-__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void igemm_f32_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) void igemm_f32_kernel(const IgemmParams p) {
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     constexpr int P_PATCH = NSX * 4 * 180;
     constexpr int P_BUNIT = NSX * 2 * BN, P_BSTAGE = 2 * P_BUNIT;
     constexpr int P_NSTG = NSX == 1 ? 4 : 3;
-    __shared__ f32x4 smem[PATCH ? 2 * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE];
+    // three planes: ONE patch buffer (refilled between two barriers at a channel-block boundary) keeps the workgroup at 70 KB
+    // so that two fit a CU; with a second buffer it was alone on its CU (103 KB, one wave per SIMD: every LDS latency exposed)
+    constexpr int P_NBUF = NSX == 1 ? 2 : 1;
+    __shared__ f32x4 smem[PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     static_assert((2 * B_I) % 4 == 0 && NT == 256, "weight DMA is dealt evenly to four waves");
     constexpr int PWB = 2 * B_I / 4;
     f32x4* const patch = smem;
-    f32x4* const ring = smem + 2 * P_PATCH;
+    f32x4* const ring = smem + P_NBUF * P_PATCH;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     unsigned poff[PL];
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int slot = 0;
     for (int cb = 0; cb < ncb; ++cb) {
-        const f32x4* const P = patch + (cb & 1) * P_PATCH;
+        const f32x4* const P = patch + (P_NBUF == 2 ? (cb & 1) : 0) * P_PATCH;
 #pragma unroll
         for (int st = 0; st < 9; ++st) {
             // stage `st` of this channel block has landed once only the younger stages — and, for the first P_NSTG - 1 stages
@@ -620,6 +624,14 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence: keep the LDS reads of this stage behind it)
             issue_b(slot == 0 ? P_NSTG - 1 : slot - 1);
             if (st == 0) {
+                if constexpr (P_NBUF == 1) {
+                    if (cb > 0) {  // everyone is past the barrier above, i.e. done with the previous block's patch: refill it
+                        store_patch(0);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                }
                 // the counted waits below assume the patch loads are YOUNGER than this interval's weight stage (vmcnt retires in
                 // order): keep the compiler from hoisting them above the DMA instructions
                 asm volatile("" ::: "memory");
@@ -645,7 +657,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE) void i
             }
             slot = slot + 1 == P_NSTG ? 0 : slot + 1;
         }
-        if (cb + 1 < ncb) {
+        if (P_NBUF == 2 && cb + 1 < ncb) {
             store_patch((cb + 1) & 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -1265,9 +1277,15 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int ld = is_a ? AS : BS;
     const int lds_base = (is_a ? 0 : A_IMG) + s_c;
 
-    f32x4 rr[4];        // AT = 0: 4 pixels x 4 fp32 channels
-    u32x2 rh[NP][4];    // AT = 1 / 3: per plane 4 pixels x 4 bf16 channels
-    unsigned woff[4];
+    // Prefetch distance D (register sets).  The bf16 matrix math makes a 16-pixel k-step 96 (one plane) or 576 (three planes)
+    // matrix-pipe clocks per wave; with a distance of one every k-step waited out a full memory round trip (measured: 2.05 us per
+    // k-step round whatever the number of resident workgroups — more pixel splits per CU changed nothing), i.e. the kernel ran at
+    // (workgroups per CU) k-steps per latency.  A stored-bf16 set is 8 registers, an fp32 one 16: D = 4 / 3 keep the occupancy.
+    // Exact fp32 (NS = 0: 1536 clocks per k-step and wave) stays at one: the second set cost it an occupancy step (100 -> 72 TFLOP/s).
+    constexpr int D = NS == 0 || AT == 3 ? 1 : (AT == 0 ? 3 : 4);
+    f32x4 rr_[D][4];        // AT = 0: 4 pixels x 4 fp32 channels
+    u32x2 rh_[D][NP][4];    // AT = 1 / 3: per plane 4 pixels x 4 bf16 channels
+    unsigned woff[4] = {OOB_OFFSET, OOB_OFFSET, OOB_OFFSET, OOB_OFFSET};
     // byte offsets of this thread's 4 loads for k-tile kt (address math kept apart from the loads so that it
     // can be issued in the shadow of the previous tile's MFMAs)
     // B role: pixel (n, oh, ow) of this thread's first row in the current k-tile, advanced by 16 pixels per call (offsets()
@@ -1312,7 +1330,27 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             }
         }
     };
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](auto SET) {
+        f32x4 (&rr)[4] = rr_[decltype(SET)::value];
+        u32x2 (&rh)[NP][4] = rh_[decltype(SET)::value];
+        if constexpr (D > 1) {
+            // ONE code path for both roles (descriptor and plane distance picked by the wave-uniform role; threads without a role
+            // load from out-of-range offsets): with the loads inside role branches the compiler's wait counts at the merge point
+            // fell back to vmcnt(0) and drained every set each k-step
+            const __amdgpu_buffer_rsrc_t rs = is_a ? rs_sm : rs_big;
+            if constexpr (AT == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs, woff[i]);
+            } else {
+                const unsigned pl = is_a ? p.sm_plane_bytes : p.big_plane_bytes;
+#pragma unroll
+                for (int t = 0; t < NP; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        rh[t][i] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(woff[i] == OOB_OFFSET ? OOB_OFFSET : woff[i] + t * pl), 0, 0);
+            }
+            return;
+        }
         if constexpr (AT == 0) {
             if (is_a) {
 #pragma unroll
@@ -1339,7 +1377,9 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             }
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, auto SET) {
+        f32x4 (&rr)[4] = rr_[decltype(SET)::value];
+        u32x2 (&rh)[NP][4] = rh_[decltype(SET)::value];
         if (is_a || is_b) {
             f32x4* dst = smem + buf * STAGE + lds_base;
             if constexpr (NS == 0) {
@@ -1383,11 +1423,13 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     // are computed one tile ahead, in the shadow of the previous tile's MFMAs.
     // (a prefetch distance of two k-tiles, which helps the igemm kernel, costs this kernel its occupancy — every thread
     // holds a 4x4 block per set for the register transpose: 64 -> 130 VGPRs, 100 -> 72 TFLOP/s measured — so it stays at one)
+    using C0 = std::integral_constant<int, 0>;
+    if constexpr (D == 1) {
     if (KT > 0) {
         offsets(0);
-        issue_loads();
+        issue_loads(C0{});
         if (NS > 0) offsets(1);
-        stage(0);
+        stage(0, C0{});
     }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
@@ -1395,7 +1437,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         const bool more = kt + 1 < KT;
         if (more) {
             if (NS == 0) offsets(kt + 1);
-            issue_loads();
+            issue_loads(C0{});
         }
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
@@ -1429,8 +1471,74 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             mfma_split<NS, MI, NI>(af, bf, acc);
         }
         if (NS > 0) offsets(kt + 2);  // independent of the MFMAs above: overlaps their execution
-        if (more) stage(buf ^ 1);
+        if (more) stage(buf ^ 1, C0{});
         __syncthreads();
+    }
+    } else {
+    // distance D: sets hold k-tiles kt+1 .. kt+D-1 (+ the one being issued); loads and staging are unconditional (k-tiles past the
+    // end gather zeros through out-of-range offsets) so that the compiler's counted waits stay partial
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        offsets(d);
+        if (d == 0) issue_loads(std::integral_constant<int, 0>{});
+        if (d == 1) issue_loads(std::integral_constant<int, 1 % D>{});
+        if (d == 2) issue_loads(std::integral_constant<int, 2 % D>{});
+        if (d == 3) issue_loads(std::integral_constant<int, 3 % D>{});
+    }
+    stage(0, C0{});
+    __syncthreads();
+    auto step = [&](int kt, auto UU) {
+        constexpr int U = decltype(UU)::value;
+        const int buf = kt & 1;
+        offsets(kt + D);
+        issue_loads(UU);  // the set k-tile kt was staged from
+        const f32x4* As = smem + buf * STAGE;
+        const f32x4* Bs = As + A_IMG;
+        if constexpr (NS == 0) {
+            f32x4 af[2][MI], bf[2][NI];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
+        } else {
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * 2 + lh) * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NS, MI, NI>(af, bf, acc);
+        }
+        stage(buf ^ 1, std::integral_constant<int, (U + 1) % D>{});
+        __syncthreads();
+    };
+    static_assert(D <= 4, "the k-loop spells the sets out");
+    // whole rounds of D steps (no conditional step inside the loop: a skipped step would reach the loop header with a different
+    // number of loads pending, and the compiler then drains with vmcnt(0) there), then the remainder
+    int kt = 0;
+    for (; kt + D <= KT; kt += D) {
+        step(kt, std::integral_constant<int, 0>{});
+        if constexpr (D > 1) step(kt + 1, std::integral_constant<int, 1 % D>{});
+        if constexpr (D > 2) step(kt + 2, std::integral_constant<int, 2 % D>{});
+        if constexpr (D > 3) step(kt + 3, std::integral_constant<int, 3 % D>{});
+    }
+    if (kt < KT) step(kt, std::integral_constant<int, 0>{});
+    if (D > 2 && kt + 1 < KT) step(kt + 1, std::integral_constant<int, 1 % D>{});
+    if (D > 3 && kt + 2 < KT) step(kt + 2, std::integral_constant<int, 2 % D>{});
     }
 
     // slab in position space: [split][O (tile-major positions)][Jp = njt*BN]
@@ -2455,7 +2563,9 @@ static int wgrad_splitk_one(int n, int Ho, int Wo, int O, int Cb, int R, int S) 
         const char* e = getenv("DBN_WGRAD_PREFER");
         prefer = e ? atof(e) : 0.0;  // with the two-stream step fewer, longer splits win (32.4 -> 32.2 ms); single stream: 0.02
     }
-    for (int k = 4; k >= 2; --k) {
+    static int kmax = -1;
+    if (kmax < 0) kmax = getenv("DBN_WGRAD_KMAX") ? atoi(getenv("DBN_WGRAD_KMAX")) : 4;
+    for (int k = kmax; k >= 2; --k) {
         long cand = (256L * k) / tiles;
         if (cand < 1) cand = 1;
         if (cand > maxsk) cand = maxsk;
