@@ -82,6 +82,7 @@ SIGNATURES.update({
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
+    'dbn_wgrad_kernel_config': 'iiiii',
     'dbn_set_patch_conv': 'i',
     'dbn_igemm_kernel_config': 'i' * 16,
     'dbn_split3': 'pplp',

@@ -24,6 +24,7 @@
 // conflict-free ds_read_b128.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -1706,6 +1707,195 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradParams p) {
         }
 }
 
+// compile-time loop (the transposing LDS reads below take their offsets as instruction immediates)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read_b64(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// ---- weight gradient on stored bf16 operands: LDS-DMA + transposing LDS reads ----------------------------------------------------
+// The register-transposing kernel above spends ~27 VALU instructions per MFMA on bf16 tensors (four pixel addresses per thread and
+// k-step for 8-byte loads, 4x4 transposes as bit operations): with one 32-cycle MFMA per accumulator and k-step it is bound by
+// instruction issue, not by the matrix pipe or memory (measured: 0.14 of the bf16 peak alone, unchanged by more workgroups per CU
+// or a deeper prefetch).  Here both operands stay the way they lie in memory — pixel-major, per 32-channel block an LDS image
+// [32 pixels][64 B] written by LDS-DMA (16 pixels x 4 pieces of 16 B per instruction; out-of-range lanes deliver zeros) — and the
+// K(pixel)-contiguous MFMA fragments come out of ds_read_b64_tr_b16: the 16 lanes of a group pass the addresses of a [4 pixels][16
+// channels] block (lane 4r+c: pixel r, channels 4c..4c+3) and lane t receives channel t of the four pixels
+// (tools/probes/tr_read.hip).  Two such reads are the 8 k-values of a 32x32x16 fragment; the 64-byte rows make the four rows of
+// the two groups of a 32-lane phase cover 256 distinct bytes: conflict-free.  Slabs in natural (o, j) order.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgradParams p) {
+    constexpr int KP = 32;  // pixels per stage (two 16-wide MFMA k-steps)
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+    constexpr int A_BLK = BM / 32, B_BLK = BN / 32;      // 32-wide channel / column blocks
+    constexpr int BLK_SL = KP * 4;                       // 16-byte slots of one block image [KP pixels][64 B]
+    constexpr int INSTR = (A_BLK + B_BLK) * (KP / 16);   // DMA instructions per stage (1 KiB each)
+    static_assert(INSTR % 4 == 0 && WM * WN == 4 && MI >= 1 && NI >= 1, "DMA instructions are dealt to four waves");
+    constexpr int PER_WAVE = INSTR / 4;
+    constexpr int NSTG = 3;
+    constexpr int STAGE_SL = (A_BLK + B_BLK) * BLK_SL;
+    __shared__ f32x4 smem[NSTG * STAGE_SL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int njt = (p.J + BN - 1) / BN;
+    const int ntiles = (p.O / BM) * njt;
+    const int work = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / ntiles, tile_ = work - split * ntiles;
+    const int ot = tile_ / njt, jt = tile_ - ot * njt;
+    const int o0 = ot * BM, j0 = jt * BN;
+    const int pbeg = split * p.pchunk;
+    const int pend = min(p.P, pbeg + p.pchunk);
+    const int KT = (pend - pbeg + KP - 1) / KP;
+
+    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
+
+    // instruction t = wave*PER_WAVE + i of a stage: block t / 2 (A blocks first), pixel half t % 2; the lane's item is pixel
+    // 16*half + lane/4 of the stage, piece lane % 4 (8 channels)
+    const int HWo = p.Ho * p.Wo;
+    unsigned a_off[PER_WAVE];
+    int a_px[PER_WAVE];
+    int b_n[PER_WAVE], b_oh[PER_WAVE], b_ow[PER_WAVE], b_px[PER_WAVE], b_ci[PER_WAVE], b_tr[PER_WAVE], b_ts[PER_WAVE];
+    bool b_ok[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int t = wave * PER_WAVE + i, blk = t >> 1, half = t & 1;
+        const int px = pbeg + 16 * half + (lane >> 2), piece = lane & 3;
+        a_off[i] = 0; a_px[i] = px; b_n[i] = b_oh[i] = b_ow[i] = b_ci[i] = b_tr[i] = b_ts[i] = 0; b_px[i] = px; b_ok[i] = false;
+        if (blk < A_BLK) {
+            a_off[i] = (unsigned)(o0 + 32 * blk + 8 * piece) * 2u;
+        } else {
+            const int jj = j0 + 32 * (blk - A_BLK) + 8 * piece;
+            b_ok[i] = jj < p.J;
+            const int tap = b_ok[i] ? jj / p.Cb : 0;
+            b_ci[i] = b_ok[i] ? jj - tap * p.Cb : 0;
+            b_tr[i] = tap / p.S - p.pad;
+            b_ts[i] = tap % p.S - p.pad;
+            int rem;
+            divmod24(min(px, p.P - 1), HWo, p.rcp_HWo, b_n[i], rem);
+            divmod24(rem, p.Wo, p.rcp_Wo, b_oh[i], b_ow[i]);
+        }
+    }
+    auto issue_stage = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int t = wave * PER_WAVE + i, blk = t >> 1, half = t & 1;
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_SL + blk * BLK_SL + half * 64);
+            if (blk < A_BLK) {
+                const unsigned off = a_px[i] < pend ? (unsigned)a_px[i] * (unsigned)p.O * 2u + a_off[i] : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sm, dst, 16, (int)off, 0, 0, 0);
+                a_px[i] += KP;
+            } else {
+                const int ih = b_oh[i] * p.stride + b_tr[i], iw = b_ow[i] * p.stride + b_ts[i];
+                const bool v = b_ok[i] && b_px[i] < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const unsigned off = v ? (unsigned)(((b_n[i] * p.H + ih) * p.W + iw) * p.Cb + b_ci[i]) * 2u : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, dst, 16, (int)off, 0, 0, 0);
+                b_px[i] += KP;
+                b_ow[i] += KP;
+                while (b_ow[i] >= p.Wo) {
+                    b_ow[i] -= p.Wo;
+                    if (++b_oh[i] == p.Ho) {
+                        b_oh[i] = 0;
+                        ++b_n[i];
+                    }
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposing read: group g = lane >> 4 covers channels 16 (g & 1) .. +15 of the block and k = 8 (g >> 1) .. +7 (two reads of 4)
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)smem;
+    const unsigned lane_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned a_base = lds0 + lane_off + (unsigned)(wm * MI) * (BLK_SL * 16);
+    const unsigned b_base = lds0 + lane_off + (unsigned)(A_BLK + wn * NI) * (BLK_SL * 16);
+
+    if (KT > 0) issue_stage(0);
+    if (KT > 1) issue_stage(1);
+    int slot = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < KT) issue_stage(slot >= 1 ? slot - 1 : NSTG - 1);
+        const unsigned sbase = (unsigned)slot * (STAGE_SL * 16);
+        static_for<KP / 16>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            u32x2 fa[MI][2], fb[NI][2];
+            static_for<MI>([&](auto A_) {
+                static_for<2>([&](auto H_) {
+                    constexpr int a = decltype(A_)::value, h2 = decltype(H_)::value;
+                    fa[a][h2] = tr_read_b64<a * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(a_base + sbase);
+                });
+            });
+            static_for<NI>([&](auto B_) {
+                static_for<2>([&](auto H_) {
+                    constexpr int b = decltype(B_)::value, h2 = decltype(H_)::value;
+                    fb[b][h2] = tr_read_b64<b * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(b_base + sbase);
+                });
+            });
+            // the compiler does not track inline-asm LDS reads: wait here, and tie every result register to the wait
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]) : : "memory");
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fa[a][h2]));
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fb[b][h2]));
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            bf16x8 af[MI], bf[NI];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) af[a] = __builtin_bit_cast(bf16x8, u32x4_{fa[a][0][0], fa[a][0][1], fa[a][1][0], fa[a][1][1]});
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bf[b] = __builtin_bit_cast(bf16x8, u32x4_{fb[b][0][0], fb[b][0][1], fb[b][1][0], fb[b][1][1]});
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        });
+        slot = slot + 1 == NSTG ? 0 : slot + 1;
+    }
+
+    // slab in natural order: [split][O][Jp = njt*BN]
+    const int Jp = njt * BN;
+    float* out = p.slab + (long)split * wgrad_slab_stride(p.O, Jp);
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int col = j0 + wn * TN + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = o0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(long)row * Jp + col] = acc[a][b][r];
+            }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
                                     int R, int S, float* __restrict__ grad, float scale, int natural) {
     // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
@@ -2618,9 +2808,11 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
     return dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, Ho, Wo, Cb, R, S, 4);
 }
 
-static int g_wgrad_variant = -1;  // -1: read DBN_WGRAD_DMA on first use; 0: register-transposing kernel; 1: LDS-DMA kernel
+// -1: read DBN_WGRAD_DMA on first use; 0: defaults (fp32 tensors: register-transposing kernel; bf16 tensors: LDS-DMA + transposing
+// reads); 1: LDS-DMA kernel for exact-fp32 math on fp32 tensors; 2: register-transposing kernel for bf16 tensors too
+static int g_wgrad_variant = -1;
 int dbn_set_wgrad_variant(int v) {
-    DBN_REQUIRE(v == 0 || v == 1);
+    DBN_REQUIRE(v == 0 || v == 1 || v == 2);
     g_wgrad_variant = v;
     return DBN_OK;
 }
@@ -2634,6 +2826,16 @@ int dbn_wgrad_tile_config(int O, int J) {
 }
 
 // phases: 1 = the MFMA kernels (activations -> slabs), 2 = the slab reduction (slabs -> gradient), 3 = both
+static bool wgrad_uses_tr(int at, int ns, int Cb) {
+    static const int tr_env = getenv("DBN_WGRAD_TR") ? atoi(getenv("DBN_WGRAD_TR")) : 1;
+    return at == 1 && ns == 1 && Cb % 32 == 0 && tr_env && g_wgrad_variant != 2;
+}
+// tile variant as dbn_wgrad_tile_config, + 16 when the launch is wgrad_tr_kernel<BM,BN,2,2> (bf16 tensors) instead of
+// wgrad_f32_kernel<BM,BN,2,2,ns,at> — the rocprofv3 symbol of the matrix kernel of a dbn_wgrad_t call
+int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb) {
+    return dbn_wgrad_tile_config(O, J) + (wgrad_uses_tr(at, ns, Cb) ? 16 : 0);
+}
+
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                      int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0, int phases = 3) {
     DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3) && phases >= 1 && phases <= 3);
@@ -2656,6 +2858,10 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
     // ring admits 3 workgroups per CU instead of 4, and the transposing kernel was not load-latency-bound after all), so it is
     // selectable (DBN_WGRAD_DMA=1 / dbn_set_wgrad_variant) but not the default.
     const bool dma = g_wgrad_variant == 1 && ns == 0 && at == 0;
+    // stored bf16 operands: the LDS-DMA + transposing-read kernel (32-column blocks must not straddle taps: Cb % 32 == 0);
+    // DBN_WGRAD_TR=0 / dbn_set_wgrad_variant(2) route them through the register-transposing kernel instead
+    const bool trk = wgrad_uses_tr(at, ns, Cb);
+    const bool natural = dma || trk;
     int bm, bn;
     const int J = R * S * Cb;
     wgrad_tiles(O, J, bm, bn);
@@ -2694,7 +2900,16 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         else                                                                                                \
             hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);      \
     } while (0)
-        if (at == 1) DBN_WGRAD_LAUNCH(1, 1);
+        if (trk) {
+            if (bn == 192)
+                hipLaunchKernelGGL((wgrad_tr_kernel<64, 192, 2, 2>), grid, dim3(256), 0, st, p);
+            else if (bm == 128 && bn == 128)
+                hipLaunchKernelGGL((wgrad_tr_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+            else if (bn == 128)
+                hipLaunchKernelGGL((wgrad_tr_kernel<64, 128, 2, 2>), grid, dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((wgrad_tr_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+        } else if (at == 1) DBN_WGRAD_LAUNCH(1, 1);
         else if (at == 3) DBN_WGRAD_LAUNCH(3, 3);
         else if (ns == 0 && dma) {
             if (bn == 192)
@@ -2723,10 +2938,10 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         const int threads = std::min(1024, (items * G + 63) / 64 * 64);
         const size_t smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)R * S * 64 * sizeof(float);
         hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,
-                           R * S, G, grad_oihw, scale, dma ? 1 : 0);
+                           R * S, G, grad_oihw, scale, natural ? 1 : 0);
     } else
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
-                           Cb, I, R, S, grad_oihw, scale, dma ? 1 : 0);
+                           Cb, I, R, S, grad_oihw, scale, natural ? 1 : 0);
     return dbn_status();
 }
 

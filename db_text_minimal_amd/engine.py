@@ -479,7 +479,11 @@ class Engine:
         args = (at, self.ns, smp, bigp, slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride,
                 pad, self.grad_scale, self.stream)
         if self.prof:  # bracket the matrix kernel alone (its rocprofv3 symbol), then the slab reduction
-            self.prof.begin(WGRAD_TILE_NAMES[self.L.dbn_wgrad_tile_config(O, k * k * Cb)] % (self.ns, at),
+            cfg = self.L.dbn_wgrad_kernel_config(at, self.ns, O, k * k * Cb, Cb)
+            wname = WGRAD_TILE_NAMES[cfg & 15] % (self.ns, at)
+            if cfg & 16:  # bf16 tensors: LDS-DMA + transposing LDS reads
+                wname = 'wgrad_tr_kernel<' + wname.split('<')[1].rsplit(',', 2)[0] + '>'
+            self.prof.begin(wname,
                             2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
             check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)
             self.prof.end()

@@ -874,9 +874,11 @@ def test_stem_conv_on_16_channel_bf16_input():
 
 @pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 20, 12), (3, 128, 256, 1, 1, 0, 9, 7), (2, 64, 128, 3, 2, 1, 16, 16), (1, 256, 256, 3, 1, 1, 12, 12),
                                   (2, 64, 64, 2, 2, 0, 10, 12)])
-def test_weight_gradient_on_bf16_storage(case):
-    """dbn_wgrad_t(at = bf16): dY and X are read as stored, transposed in registers, multiplied on the bf16 matrix pipe with
-    fp32 accumulation into fp32 slabs: equals the fp64 weight gradient of the ROUNDED tensors to fp32 accumulation noise."""
+@pytest.mark.parametrize('variant', [0, 2])
+def test_weight_gradient_on_bf16_storage(case, variant):
+    """dbn_wgrad_t(at = bf16): dY and X are read as stored and multiplied on the bf16 matrix pipe with fp32 accumulation into fp32
+    slabs: equals the fp64 weight gradient of the ROUNDED tensors to fp32 accumulation noise.  variant 0 (default): LDS-DMA
+    panels in memory order + transposing LDS reads (wgrad_tr_kernel); variant 2: the register-transposing kernel."""
     N, Ci, Co, k, s_, p_, H, W = case
     x = rnd(N, Ci, H, W, seed=1)
     w = rnd(Co, Ci, k, k, seed=2).double().requires_grad_(True)
@@ -887,9 +889,14 @@ def test_weight_gradient_on_bf16_storage(case):
     Ho, Wo = y.shape[2], y.shape[3]
     slab = torch.empty(L().dbn_wgrad_slab_floats(N, Ho, Wo, Co, Ci, k, k), device=DEV)
     g = torch.full((Co, Ci, k, k), float('nan'), device=DEV)
-    _lib.check(L().dbn_wgrad_t(1, 1, dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, Co, H, W, Ci, Ci, k, k, s_, p_,
-                               0.5, stream()), 'wgrad_t')
-    report('wgrad bf16 storage', g.cpu(), 0.5 * gref, 2e-5 * float(gref.abs().max()), 1e-4)
+    try:
+        _lib.check(L().dbn_set_wgrad_variant(variant), 'variant')
+        _lib.check(L().dbn_wgrad_t(1, 1, dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, Ho, Wo, Co, H, W, Ci, Ci, k, k, s_, p_,
+                                   0.5, stream()), 'wgrad_t')
+        torch.cuda.synchronize()
+    finally:
+        L().dbn_set_wgrad_variant(0)
+    report('wgrad bf16 storage variant %d' % variant, g.cpu(), 0.5 * gref, 2e-5 * float(gref.abs().max()), 1e-4)
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
