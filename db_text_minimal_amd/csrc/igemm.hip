@@ -1841,37 +1841,45 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgradParams p) {
         asm volatile("" ::: "memory");
         if (kt + 2 < KT) issue_stage(slot >= 1 ? slot - 1 : NSTG - 1);
         const unsigned sbase = (unsigned)slot * (STAGE_SL * 16);
-        static_for<KP / 16>([&](auto KK) {
+        // all fragment reads of the stage are issued first; the second k-step's land under the first one's MFMAs
+        constexpr int KS = KP / 16, RPK = 2 * (MI + NI);  // k-steps per stage, reads per k-step
+        u32x2 fa[KS][MI][2], fb[KS][NI][2];
+        static_for<KS>([&](auto KK) {
             constexpr int kk = decltype(KK)::value;
-            u32x2 fa[MI][2], fb[NI][2];
             static_for<MI>([&](auto A_) {
                 static_for<2>([&](auto H_) {
                     constexpr int a = decltype(A_)::value, h2 = decltype(H_)::value;
-                    fa[a][h2] = tr_read_b64<a * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(a_base + sbase);
+                    fa[kk][a][h2] = tr_read_b64<a * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(a_base + sbase);
                 });
             });
             static_for<NI>([&](auto B_) {
                 static_for<2>([&](auto H_) {
                     constexpr int b = decltype(B_)::value, h2 = decltype(H_)::value;
-                    fb[b][h2] = tr_read_b64<b * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(b_base + sbase);
+                    fb[kk][b][h2] = tr_read_b64<b * BLK_SL * 16 + (16 * kk + 4 * h2) * 64>(b_base + sbase);
                 });
             });
-            // the compiler does not track inline-asm LDS reads: wait here, and tie every result register to the wait
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]) : : "memory");
+        });
+        static_for<KS>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;
+            // the compiler does not track inline-asm LDS reads: counted wait (LDS returns in order), and every result register
+            // of this k-step is tied to it
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[kk][0][0]) : "n"((KS - 1 - kk) * RPK) : "memory");
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fa[a][h2]));
+                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fa[kk][a][h2]));
 #pragma unroll
             for (int b = 0; b < NI; ++b)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fb[b][h2]));
+                for (int h2 = 0; h2 < 2; ++h2) asm volatile("" : "+v"(fb[kk][b][h2]));
             typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
             bf16x8 af[MI], bf[NI];
 #pragma unroll
-            for (int a = 0; a < MI; ++a) af[a] = __builtin_bit_cast(bf16x8, u32x4_{fa[a][0][0], fa[a][0][1], fa[a][1][0], fa[a][1][1]});
+            for (int a = 0; a < MI; ++a)
+                af[a] = __builtin_bit_cast(bf16x8, u32x4_{fa[kk][a][0][0], fa[kk][a][0][1], fa[kk][a][1][0], fa[kk][a][1][1]});
 #pragma unroll
-            for (int b = 0; b < NI; ++b) bf[b] = __builtin_bit_cast(bf16x8, u32x4_{fb[b][0][0], fb[b][0][1], fb[b][1][0], fb[b][1][1]});
+            for (int b = 0; b < NI; ++b)
+                bf[b] = __builtin_bit_cast(bf16x8, u32x4_{fb[kk][b][0][0], fb[kk][b][0][1], fb[kk][b][1][0], fb[kk][b][1][1]});
 #pragma unroll
             for (int a = 0; a < MI; ++a)
 #pragma unroll
