@@ -2281,8 +2281,15 @@ int dbn_igemm_tile_config(int M, int Cd) {
     // Workgroups are handed to the 256 CUs as they free up, so a launch lasts about
     // ceil(blocks/256) tiles per CU; pick the tile that minimises tiles-per-CU x tile area / efficiency
     // (efficiency = measured steady-state MFMA utilisation of each variant).
+    // Round 2 re-measured the variants alone on the backbone's four stage shapes (tools/tile_probe.py): with the two-tile prefetch
+    // the 64x64 tile is the fastest at 80x80x128 and 40x40x256 (115 / 103 TFLOP/s against 109 / 97 for the choices below).  In
+    // the two-stream step that does not carry over: efficiencies {0.89, 0.85, 0.845, 0.83} everywhere gave +0.5 % (within noise)
+    // with the dominant kernel's in-step rate down from 0.60 to 0.56, on the layer3/4-sized grids only -0.6 % — small tiles lose
+    // more to the co-resident weight-gradient workgroups.  The table stays (DBN_TILE_EFF_R2=1 selects the re-measured one).
     const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 64, 64};
-    const double eff[4] = {0.89, 0.83, 0.80, 0.72};
+    static const bool r2_eff = getenv("DBN_TILE_EFF_R2") != nullptr;
+    const double eff_r1[4] = {0.89, 0.83, 0.80, 0.72}, eff_r2[4] = {0.89, 0.85, 0.845, 0.83};
+    const double* eff = r2_eff ? eff_r2 : eff_r1;
     int best = 4;
     double best_t = 1e300;
     for (int c = 0; c < 4; ++c) {
@@ -2315,13 +2322,23 @@ static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int
 }
 static int patch_cfg(int cfg) { return (cfg == 1 && g_patch_bn64) ? 3 : cfg; }
 
+// Tile configuration of a dbn_igemm / dbn_conv_bn call (`mode`, `stride` as the caller passes them).  The convolutions that can take
+// the pixel-patch kernel get a 128-row tile whatever the generic heuristic says.
+static int resolve_cfg(int M_total, int Cd, int tile_hint, int at = 0, int ns = 0, int mode = 0, int R = 0, int S = 0, int stride = 1,
+                       int pad = 0, int Hs = 0, int Ws = 0, int Hd = 0, int Wd = 0, int Cs = 0, int ksplit = 1) {
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
+    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    if (tile_hint == 0 && !(mode == 1 && stride > 1) && patch_eligible(mode, ns, at, 3, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) cfg = 3;
+    return cfg;
+}
+
 // What one (unchunked) dbn_igemm_t call launches: tile configuration (1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64) + 16 if the
 // pixel-patch kernel is used — i.e. the template arguments <BM,BN,WM,WN,MODE,NS,AT,PATCH> of its rocprofv3 symbol.
 // kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid.
 int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,
                             int pad, int tile_hint, int ksplit) {
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(N * Hd * Wd, Cd);
-    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    const int cfg = resolve_cfg(N * Hd * Wd, Cd, tile_hint, at, ns, kmode >= 2 ? 1 : kmode, R, S, kmode == 2 && stride == 1 ? 2 : stride, pad, Hs,
+                                Ws, Hd, Wd, Cs, ksplit);
     if (patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) return patch_cfg(cfg) + 16;
     return cfg;
 }
@@ -2372,12 +2389,6 @@ static int chunk_images(int N, long px_rows, long src_bytes_per_image, long dst_
 // bytes per element of the destination of a conv (at = 3: pre-split bf16 planes in, fp32 out) and planes of its source
 static inline int dst_esize(int at) { return (at == 0 || at == 3) ? 4 : 2; }
 static inline int src_planes(int at) { return at == 3 ? 3 : 1; }
-
-static int resolve_cfg(int M_total, int Cd, int tile_hint) {
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
-    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
-    return cfg;
-}
 
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
@@ -2467,7 +2478,8 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
     const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * es, (long)Hd * Wd * Cd);
     DBN_REQUIRE(nmax >= 1);               // one image must fit the kernel's index ranges
     DBN_REQUIRE(nmax >= N || ksplit <= 1);  // split-K is for small outputs only
-    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint, at, ns, mode, R, S, stride, pad, Hs, Ws,
+                                Hd, Wd, Cs, ksplit);
     int row0 = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
@@ -2504,10 +2516,12 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
 }
 
 // Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32); follows igemm_run's chunking
-static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint, int at = 0) {
+static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint, int at, int ns, int R,
+                        int S, int pad) {
     const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * dbn_esize(at), (long)Hd * Wd * Cd);
     if (nmax < 1) return 0;
-    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint);
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint, at, ns, mode, R, S, stride, pad, Hs, Ws,
+                                Hd, Wd, Cs, 1);
     int rows = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) rows += bn_tile_rows_one(std::min(nmax, N - n0), Hd, Wd, mode, stride, cfg);
     return rows;
@@ -2532,7 +2546,7 @@ int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, 
                   const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                   float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
-    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at);
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
     DBN_REQUIRE(rows > 0);
     // (16-bit storage: the statistics are those of the fp32 accumulators, i.e. of the values BEFORE they are rounded for storage)
     const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,

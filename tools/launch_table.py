@@ -1,20 +1,27 @@
-"""GPU: per-launch table (time, algorithmic TFLOP/s) of every MFMA launch of one bs16 640x640 train step."""
+"""GPU box: every bracketed launch of one serialised train step with its tag, duration and rate.  usage: launch_table.py [math]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import bench
 from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
 from db_text_minimal_amd.engine import KernelTimer
-sys.argv = sys.argv[:1]
-import bench
+math = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 torch.manual_seed(42)
 m = DBTextModel().cuda().train()
-tr = DBTrainer(m, DBLoss(), FusedAdam(m))
+m.engine.set_conv_math(math)
+tr = DBTrainer(m, DBLoss(), FusedAdam(m, lr=0.005))
 img, gts = bench.synthetic(16, 640, 42, torch.device('cuda'))
-for _ in range(2): tr.step(img, gts)
-t = KernelTimer(); m.engine.prof = t
-tr.step(img, gts); torch.cuda.synchronize(); m.engine.prof = None
-tot = 0
-for label, flops, nbytes, e0, e1, tag in t.records:
-    ms = e0.elapsed_time(e1); tot += ms
-    print('%-34s %-52s %8.3f ms %7.1f TF' % (label, tag, ms, flops / ms / 1e9 if flops else 0))
-print('total', tot)
+for _ in range(3):
+    tr.step(img, gts)
+t = KernelTimer()
+m.engine.prof = t
+tr.step(img, gts)
+torch.cuda.synchronize()
+m.engine.prof = None
+rows = [(e0.elapsed_time(e1), label, tag, flops, nbytes) for label, flops, nbytes, e0, e1, tag in t.records]
+peak = bench.MATH[math][2]
+tot = sum(r[0] for r in rows)
+print('%d launches, %.2f ms bracketed' % (len(rows), tot))
+for ms, label, tag, flops, nbytes in sorted(rows, key=lambda r: -r[0])[:70]:
+    rate = ('%6.1f TF/s %.2f' % (flops / ms / 1e9, flops / ms / 1e9 / peak)) if flops else (('%6.0f GB/s' % (nbytes / ms / 1e6)) if nbytes else '')
+    print('%7.3f ms  %-44s %-34s %s' % (ms, label[:44], tag[:34], rate))
