@@ -1089,3 +1089,57 @@ def test_pixel_patch_convolution_is_race_free_at_full_size(mode_name):
             torch.cuda.synchronize()
             assert torch.equal(y, ref), '%s Ci %d Co %d tile %d mode %d run %d: %d elements differ' % (
                 mode_name, Ci, Co, tile, mode, run, int((y != ref).sum()))
+
+
+def test_image_chunking_on_bf16_storage():
+    """The same chunking (dbn_set_index_limits) on stored-bf16 tensors: conv + fused BN statistics (pixel-patch kernel: H % 8 = 0,
+    W % 16 = 0), a stride-2 conv (LDS-DMA ring), the stride-1 data gradient and the weight gradient (wgrad_tr_kernel) — chunked ==
+    single launch bit for bit (the weight gradient to fp32 summation-order noise)."""
+    bf = torch.bfloat16
+    N, Ci, Co, H, W = 5, 64, 128, 24, 16
+    x = nhwc(rnd(N, Ci, H, W, seed=1)).to(bf)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
+    bias = rnd(Co, seed=4).to(DEV)
+    dy = nhwc(rnd(N, Co, H, W, seed=5)).to(bf)
+
+    def run_all():
+        out = {}
+        y = torch.zeros((N, H, W, Co), device=DEV, dtype=bf)
+        g_, b_ = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+        rm_, rv_ = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+        ws = torch.empty(L().dbn_conv_bn_ws_floats(N, H, W, Co, 0, 1), device=DEV)
+        _lib.check(L().dbn_conv_bn_t(1, x.data_ptr(), pack_t(w, 0, 1, 1, Ci).data_ptr(), bias.data_ptr(), y.data_ptr(), N, H, W, Ci, H, W, Co,
+                                     3, 3, 1, 1, 0, 0, 3, 1, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                     sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn_t')
+        out['conv'], out['scale'], out['run_var'] = y, sc, rv_
+        y2 = torch.zeros((N, H // 2, W // 2, Co), device=DEV, dtype=bf)
+        igemm_t(x, pack_t(w, 0, 2, 1, Ci), bias, y2, 3, 2, 1, 0)
+        out['conv_s2'] = y2
+        d = torch.zeros((N, H, W, Ci), device=DEV, dtype=bf)
+        igemm_t(dy, pack_t(w, 1, 1, 1), None, d, 3, 1, 1, 1, tile=3)
+        out['dgrad'] = d
+        slab = torch.empty(L().dbn_wgrad_slab_floats_hw(N, H, W, Co, H, W, Ci, 3, 3, 2), device=DEV)
+        g = torch.zeros((Co, Ci, 3, 3), device=DEV)
+        _lib.check(L().dbn_wgrad_t(1, 1, dy.data_ptr(), x.data_ptr(), slab.data_ptr(), g.data_ptr(), N, H, W, Co, H, W, Ci, Ci, 3, 3, 1, 1,
+                                   1.0, stream()), 'wgrad_t')
+        out['wgrad'] = g
+        torch.cuda.synchronize()
+        return out
+
+    ref = run_all()
+    try:
+        L().dbn_set_index_limits(2 * H * W + 7, 0, 0)   # at most two images per launch
+        got = run_all()
+        L().dbn_set_index_limits(0, H * W * Co * 2 + 64, 0)  # one image of the widest (bf16) tensor per launch
+        got1 = run_all()
+    finally:
+        L().dbn_set_index_limits(0, 0, 0)
+    for k, v in ref.items():
+        for tag, gk in (('2/launch', got[k]), ('1/launch', got1[k])):
+            if k == 'wgrad':
+                report('chunked bf16 wgrad ' + tag, gk.cpu(), v.cpu(), 1e-5 * float(v.abs().max()), 1e-5)
+            elif k in ('scale', 'run_var'):
+                report('chunked bf16 %s %s' % (k, tag), gk.cpu(), v.cpu(), 1e-7, 1e-6)
+            else:
+                assert torch.equal(gk, v), (k, tag)
