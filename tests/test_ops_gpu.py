@@ -1143,3 +1143,59 @@ def test_image_chunking_on_bf16_storage():
                 report('chunked bf16 %s %s' % (k, tag), gk.cpu(), v.cpu(), 1e-7, 1e-6)
             else:
                 assert torch.equal(gk, v), (k, tag)
+
+
+def test_dma_ring_kernels_are_race_free_at_full_size():
+    """The generic 16-bit convolution loop (LDS-DMA ring; here a stride-2 3x3 conv and a parity-class data gradient) and the bf16
+    weight gradient (LDS-DMA + transposing reads) at the benchmark's size (16 x 160 x 160): every repetition is bit-identical to
+    the first, and the results agree with an independent evaluation (torch on the same rounded operands / the register-transposing
+    weight-gradient kernel)."""
+    bf = torch.bfloat16
+    N, H, W, Ci, Co = 16, 160, 160, 64, 128
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(bf)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
+    wq = w.to(bf).float().to(DEV)
+    # stride-2 forward conv
+    wp = pack_t(w, 0, 2, 1, Ci)
+    outs = []
+    for _ in range(3):
+        y = torch.zeros(N, H // 2, W // 2, Co, device=DEV, dtype=bf)
+        igemm_t(x, wp, None, y, 3, 2, 1, 0)
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), 'stride-2 conv differs between runs'
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, 2, 1).permute(0, 2, 3, 1)
+    assert float((outs[0].float() - ref).abs().max()) <= 2.0**-7 * float(ref.abs().max())
+    # its data gradient (four parity classes)
+    dy = torch.randn(N, H // 2, W // 2, Co, device=DEV, generator=g).to(bf)
+    wpd = pack_t(w, 1, 2, 1)
+    outs = []
+    for _ in range(3):
+        d = torch.zeros(N, H, W, Ci, device=DEV, dtype=bf)
+        igemm_t(dy, wpd, None, d, 3, 2, 1, 1)
+        torch.cuda.synchronize()
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), 'stride-2 data gradient differs between runs'
+    ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wq, None, 2, 1, output_padding=1).permute(0, 2, 3, 1)
+    assert float((outs[0].float() - ref).abs().max()) <= 2.0**-7 * float(ref.abs().max())
+    # weight gradient of a 3x3 / stride-1 layer: wgrad_tr_kernel, repeated, against the register-transposing kernel
+    xs = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(bf)
+    dys = torch.randn(N, H, W, Ci, device=DEV, generator=g).to(bf)
+    slab = torch.empty(L().dbn_wgrad_slab_floats_hw(N, H, W, Ci, H, W, Ci, 3, 3, 2), device=DEV)
+
+    def wg(variant):
+        gr = torch.zeros(Ci, Ci, 3, 3, device=DEV)
+        try:
+            _lib.check(L().dbn_set_wgrad_variant(variant), 'variant')
+            _lib.check(L().dbn_wgrad_t(1, 1, dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), gr.data_ptr(), N, H, W, Ci, H, W, Ci, Ci, 3, 3,
+                                       1, 1, 1.0, stream()), 'wgrad_t')
+            torch.cuda.synchronize()
+        finally:
+            L().dbn_set_wgrad_variant(0)
+        return gr
+
+    runs = [wg(0) for _ in range(3)]
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), 'bf16 weight gradient differs between runs'
+    other = wg(2)
+    report('wgrad_tr vs register-transposing kernel', runs[0].cpu(), other.cpu(), 2e-5 * float(other.abs().max()), 1e-4)
