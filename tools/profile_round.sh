@@ -2,7 +2,7 @@
 # GPU box: kernel trace + two PMC passes + the plain bench line of one round.  Usage (through gpurun):
 #   gpurun -- 'bash tools/profile_round.sh r02'
 # Writes gpurun_out/<tag>/: kernel_stats.md (rocprofv3 --kernel-trace of bench.py), step_breakdown.txt, pmc_traffic.json (two PMC
-# passes), bench_under_rocprof.json, bench_n1.json (+ the same for --math bf16); copy the summaries into profiles/.
+# passes), bench_under_rocprof.json, bench_n1.json, kernel stats + bench lines for --math bf16 and bf16x3; copy the summaries into profiles/.
 set -u
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -26,5 +26,13 @@ rocprofv3 --kernel-trace -d $O/trace_bf16 -o r01 -- python3 $R/bench.py --steps 
 cd $R
 python3 tools/rocpd_stats.py $O/trace_bf16/r01_results.db $O/kernel_stats_bf16.md > /dev/null
 grep '^{"metric"' $O/bench_bf16_under_rocprof.log > $O/bench_bf16_under_rocprof.json
-rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16   # the DBs are large; the summaries above are what is kept
+cd /tmp
+rocprofv3 --kernel-trace -d $O/trace_x3 -o r01 -- python3 $R/bench.py --steps 10 --warmup 3 $A --math bf16x3 > $O/bench_bf16x3_under_rocprof.log 2>&1
+cd $R
+python3 tools/rocpd_stats.py $O/trace_x3/r01_results.db $O/kernel_stats_bf16x3.md > /dev/null
+grep '^{"metric"' $O/bench_bf16x3_under_rocprof.log > $O/bench_bf16x3_under_rocprof.json
+for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-modes --math $m 2>/dev/null | grep '^{"metric"' > $O/bench_n1_$m.json
+done
+rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3   # the DBs are large; the summaries above are what is kept
 ls -la $O
