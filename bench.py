@@ -128,7 +128,7 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel'))
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel'))
     TIMED_EVERY = 4
     barrier()
     t0 = time.perf_counter()
@@ -207,13 +207,13 @@ def main():
             kernels.append(ent)
 
     if rank == 0:  # the weight gradient as a whole (every tile variant + the slab reductions), serial
-        wg = [v for k, v in serial_summ.items() if k.startswith(('wgrad_f32_kernel', 'wgrad_tr_kernel'))]
+        wg = [v for k, v in serial_summ.items() if k.startswith(('wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel'))]
         red = serial_summ.get('wgrad_reduce_kernel')
         if wg:
             ms_w = sum(v['ms'] for v in wg) + (red['ms'] if red else 0.0)
             fl_w = sum(v['flops'] for v in wg)
             a = fl_w / (ms_w * 1e-3) / 1e12
-            kernels.append({'kernel': 'weight gradient: every wgrad_f32_kernel / wgrad_tr_kernel tile variant + wgrad_reduce_kernel', 'launches': sum(v['launches'] for v in wg),
+            kernels.append({'kernel': 'weight gradient: every wgrad_f32_kernel / wgrad_tr_kernel / wgrad_patch_kernel variant + wgrad_reduce_kernel', 'launches': sum(v['launches'] for v in wg),
                             'ms_per_step': round(ms_w, 3), 'bound': 'mfma', 'achieved': round(a, 2), 'peak': round(peak_mfma, 1),
                             'unit': 'TFLOP/s', 'frac': round(a / peak_mfma, 4)})
     alt = {}

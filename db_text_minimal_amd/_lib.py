@@ -83,6 +83,7 @@ SIGNATURES.update({
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
     'dbn_wgrad_kernel_config': 'iiiii',
+    'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',
     'dbn_igemm_kernel_config': 'i' * 16,
     'dbn_split3': 'pplp',

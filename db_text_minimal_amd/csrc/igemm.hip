@@ -1904,6 +1904,176 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgradParams p) {
         }
 }
 
+// ---- weight gradient of 3x3 / stride-1 convolutions on the bf16 matrix pipe: pixel patches --------------------------------------
+// dW[o][(tap, ci)] = sum_p dY[p][o] * X[p + tap][ci].  A workgroup owns 64 output channels x 64 input channels x ONE TAP ROW r (three
+// taps: a 64 x 192 accumulator tile like <64,192> above) and walks a range of 4 x 16 pixel patches.  Per patch the dY patch (64
+// pixels x 64 channels) and the four X rows it needs (rows y + r - 1, 18 pixels wide: 72 pixels x 64 channels) go to LDS once, in
+// memory order — per 32-channel block an image [pixel][64 B], fp32 sources split into their bf16 planes on the way — and the three
+// taps of the row are LDS address offsets of the B-fragment reads.  K(pixel)-contiguous fragments come out of ds_read_b64_tr_b16
+// (see wgrad_tr_kernel): a k-step of 16 is one patch row.  Against wgrad_tr_kernel / the register-transposing kernel this loads
+// 17 KB instead of 32 KB per 64 pixels (bf16), computes no per-tap pixel addresses and transposes nothing in registers.
+// Needs H % 4 == 0, W % 16 == 0, O % 64 == 0, Cb % 64 == 0.  Slabs in natural (o, j) order, one per patch range.
+// (three planes: 172 registers as written = two waves per SIMD; the attribute asks for three — 52 KB of LDS admit three workgroups)
+template <int NS, int AT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 3 ? 3 : 1, 8))) void wgrad_patch_kernel(const WgradParams p) {
+    static_assert((NS == 1 || NS == 3) && (AT == 0 || AT == 1), "bf16 matrix math on fp32 or stored-bf16 tensors");
+    constexpr int ES = AT == 0 ? 4 : 2;
+    constexpr int CH = 16 / ES;                  // channels per 16-byte piece
+    constexpr int CPP = 64 / CH;                 // pieces per pixel (64 channels)
+    constexpr int APX = 64, BPX = 72;            // pixels of the dY patch / of the four X rows
+    constexpr int A_SL = 2 * APX * 4, B_SL = 2 * BPX * 4;   // 16-byte slots per plane: [2 blocks][pixels][64 B]
+    constexpr int PLANE_SL = A_SL + B_SL;
+    constexpr int ITEMS = (APX + BPX) * CPP;
+    constexpr int PL = (ITEMS + 255) / 256;
+    constexpr int AJ = APX * CPP / 256;          // items j < AJ of every thread are dY pieces, the others X pieces
+    static_assert(APX * CPP % 256 == 0, "the operand of an item must not depend on the thread (uniform buffer descriptor)");
+    __shared__ f32x4 smem[NS * PLANE_SL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ncb = p.Cb >> 6;
+    const int ntiles = (p.O >> 6) * ncb * 3;
+    const int work = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = work / ntiles, tile_ = work - split * ntiles;
+    const int ot = tile_ / (ncb * 3), rem_ = tile_ - ot * (ncb * 3);
+    const int cb = rem_ / 3, r = rem_ - cb * 3;       // input-channel block, tap row
+    const int o0 = ot * 64, ci0 = cb * 64;
+    // p.pchunk: patches per split here
+    const int PWn = p.W >> 4, PPI = (p.H >> 2) * PWn;  // patches per row / per image
+    const int qbeg = split * p.pchunk, qend = min(p.N * PPI, qbeg + p.pchunk);
+
+    const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
+
+    // this thread's pieces: item = tid + j*256; items [0, APX*CPP): dY pixel item / CPP, channel piece item % CPP; then the X rows
+    bool it_on[PL];
+    int it_y[PL], it_x[PL], it_lds[PL];   // pixel inside the patch (X: row 0..3, column 0..17), LDS slot (16-byte units; fp32: 8-byte units)
+    unsigned it_c[PL];                    // byte offset of the piece inside its pixel
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        const int item = tid + j * 256;
+        it_on[j] = item < ITEMS;
+        const bool isa = j < AJ;
+        const int q = isa ? item : (it_on[j] ? item - APX * CPP : 0);
+        const int px = q / CPP, piece = q - px * CPP;
+        const int roww = isa ? 16 : 18;
+        it_y[j] = px / roww;
+        it_x[j] = px - it_y[j] * roww;
+        const int ch = piece * CH;            // channel inside the 64-channel block
+        it_c[j] = (unsigned)((isa ? o0 : ci0) + ch) * (unsigned)ES;
+        // slot of the piece: [block ch/32][pixel][64 B]; 16-bit source: 16-byte slot; fp32 source: 8-byte half slots
+        const int base = (isa ? 0 : A_SL) + (ch >> 5) * (isa ? APX : BPX) * 4 + px * 4;
+        it_lds[j] = AT == 0 ? base * 2 + ((ch & 31) >> 2) : base + ((ch & 31) >> 3);
+    }
+    f32x4 pr[PL];
+    auto load_patch = [&](int q) {  // patch q: image n, top-left output pixel (h0, w0)
+        int n, rem, ty, tx;
+        divmod24(q < qend ? q : qbeg, PPI, 1.0f / (float)PPI, n, rem);
+        divmod24(rem, PWn, 1.0f / (float)PWn, ty, tx);
+        const int h0 = ty * 4, w0 = tx * 16;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            const bool isa = j < AJ;  // (compile-time after unrolling)
+            const int h = isa ? h0 + it_y[j] : h0 - 1 + r + it_y[j];
+            const int w = isa ? w0 + it_x[j] : w0 - 1 + it_x[j];
+            const bool v = it_on[j] && q < qend && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            const unsigned off = (unsigned)((n * p.H + h) * p.W + w) * (unsigned)((isa ? p.O : p.Cb) * ES) + it_c[j];
+            pr[j] = buffer_load_f32x4(isa ? rs_sm : rs_big, v ? off : OOB_OFFSET);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            if (!it_on[j]) continue;
+            if constexpr (AT == 0) {
+                u32x2 sp[NS];
+                split4<NS>(pr[j], sp);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) reinterpret_cast<u32x2*>(smem + t * PLANE_SL)[it_lds[j]] = sp[t];
+            } else {
+                smem[it_lds[j]] = pr[j];
+            }
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+
+    // transposing reads (wgrad_tr_kernel): group g = lane >> 4 covers channels 16 (g & 1) .. +15 of a 32-channel block and
+    // k = 8 (g >> 1) .. +7 of the 16-pixel row (two reads of 4 pixels)
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) f32x4*)smem;
+    const unsigned lane_off = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned a_base = lds0 + lane_off + (unsigned)wm * (APX * 64);
+    unsigned b_base[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int cblk = 3 * wn + b, s_ = cblk >> 1, half = cblk & 1;  // tap of the row, 32-channel half of the input block
+        b_base[b] = lds0 + lane_off + (unsigned)(A_SL * 16 + half * (BPX * 64) + s_ * 64);
+    }
+
+    load_patch(qbeg);
+    for (int q = qbeg; q < qend; ++q) {
+        __syncthreads();        // everyone is done with the previous patch's fragments
+        store_patch();
+        load_patch(q + 1);      // (past the end: out-of-range loads, so the waits stay the same)
+        __syncthreads();
+        static_for<4>([&](auto KK) {
+            constexpr int kk = decltype(KK)::value;   // patch row = k-step of 16 pixels
+            u32x2 fa[NS][2], fb[NS][3][2];
+            static_for<NS>([&](auto T_) {
+                constexpr int t = decltype(T_)::value;
+                static_for<2>([&](auto H_) {
+                    constexpr int h2 = decltype(H_)::value;
+                    fa[t][h2] = tr_read_b64<t * PLANE_SL * 16 + (16 * kk + 4 * h2) * 64>(a_base);
+                    fb[t][0][h2] = tr_read_b64<t * PLANE_SL * 16 + (18 * kk + 4 * h2) * 64>(b_base[0]);
+                    fb[t][1][h2] = tr_read_b64<t * PLANE_SL * 16 + (18 * kk + 4 * h2) * 64>(b_base[1]);
+                    fb[t][2][h2] = tr_read_b64<t * PLANE_SL * 16 + (18 * kk + 4 * h2) * 64>(b_base[2]);
+                });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]) : : "memory");
+#pragma unroll
+            for (int t = 0; t < NS; ++t)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    asm volatile("" : "+v"(fa[t][h2]));
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) asm volatile("" : "+v"(fb[t][b][h2]));
+                }
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            bf16x8 af[NS][1], bf[NS][3];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                af[t][0] = __builtin_bit_cast(bf16x8, u32x4_{fa[t][0][0], fa[t][0][1], fa[t][1][0], fa[t][1][1]});
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    bf[t][b] = __builtin_bit_cast(bf16x8, u32x4_{fb[t][b][0][0], fb[t][b][0][1], fb[t][b][1][0], fb[t][b][1][1]});
+            }
+            f32x16 (&acc2)[1][3] = reinterpret_cast<f32x16 (&)[1][3]>(acc);
+            mfma_split<NS, 1, 3>(af, bf, acc2);
+        });
+    }
+
+    // slab in natural order [split][O][J]: this tile's columns are the three taps (3r + s) of input channels ci0 ..
+    float* out = p.slab + (long)split * wgrad_slab_stride(p.O, p.J);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int cblk = 3 * wn + b, s_ = cblk >> 1, half = cblk & 1;
+        const int col = (3 * r + s_) * p.Cb + ci0 + 32 * half + li;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = o0 + 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            out[(long)row * p.J + col] = acc[b][e];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
                                     int R, int S, float* __restrict__ grad, float scale, int natural) {
     // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
@@ -2848,14 +3018,25 @@ int dbn_wgrad_tile_config(int O, int J) {
 }
 
 // phases: 1 = the MFMA kernels (activations -> slabs), 2 = the slab reduction (slabs -> gradient), 3 = both
+static bool wgrad_uses_patch(int at, int ns, int O, int Cb, int R, int S, int stride, int pad, int Ho, int Wo, int H, int W) {
+    static const int env = getenv("DBN_WGRAD_PATCH") ? atoi(getenv("DBN_WGRAD_PATCH")) : 1;
+    return env && g_wgrad_variant != 2 && ((ns == 1 && (at == 0 || at == 1)) || (ns == 3 && at == 0)) && R == 3 && S == 3 && stride == 1 &&
+           pad == 1 && Ho == H && Wo == W && H % 4 == 0 && W % 16 == 0 && O % 64 == 0 && Cb % 64 == 0;
+}
 static bool wgrad_uses_tr(int at, int ns, int Cb) {
     static const int tr_env = getenv("DBN_WGRAD_TR") ? atoi(getenv("DBN_WGRAD_TR")) : 1;
     return at == 1 && ns == 1 && Cb % 32 == 0 && tr_env && g_wgrad_variant != 2;
 }
+// (wgrad_uses_patch is defined above)
 // tile variant as dbn_wgrad_tile_config, + 16 when the launch is wgrad_tr_kernel<BM,BN,2,2> (bf16 tensors) instead of
 // wgrad_f32_kernel<BM,BN,2,2,ns,at> — the rocprofv3 symbol of the matrix kernel of a dbn_wgrad_t call
 int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb) {
     return dbn_wgrad_tile_config(O, J) + (wgrad_uses_tr(at, ns, Cb) ? 16 : 0);
+}
+// ... with the layer geometry: + 32 when the launch is wgrad_patch_kernel<ns, at> (3x3 / stride 1 on the bf16 matrix pipe)
+int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int stride, int pad, int Ho, int Wo, int H, int W) {
+    if (wgrad_uses_patch(at, ns, O, Cb, R, S, stride, pad, Ho, Wo, H, W)) return dbn_wgrad_tile_config(O, R * S * Cb) + 32;
+    return dbn_wgrad_kernel_config(at, ns, O, R * S * Cb, Cb);
 }
 
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
@@ -2883,12 +3064,14 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
     // stored bf16 operands: the LDS-DMA + transposing-read kernel (32-column blocks must not straddle taps: Cb % 32 == 0);
     // DBN_WGRAD_TR=0 / dbn_set_wgrad_variant(2) route them through the register-transposing kernel instead
     const bool trk = wgrad_uses_tr(at, ns, Cb);
-    const bool natural = dma || trk;
+    // 3x3 / stride 1 / pad 1 on the bf16 matrix pipe with whole 4 x 16 patches: the pixel-patch kernel (natural slabs, row length J)
+    const bool pk = wgrad_uses_patch(at, ns, O, Cb, R, S, stride, pad, Ho, Wo, H, W);
+    const bool natural = dma || trk || pk;
     int bm, bn;
     const int J = R * S * Cb;
     wgrad_tiles(O, J, bm, bn);
     const int njt = (J + bn - 1) / bn;
-    const int Jp = njt * bn;
+    const int Jp = pk ? J : njt * bn;
     int splits_total = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
@@ -2922,7 +3105,14 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         else                                                                                                \
             hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS_, AT_>), grid, dim3(256), 0, st, p);      \
     } while (0)
-        if (trk) {
+        if (pk) {
+            const int patches = n * (H / 4) * (W / 16);
+            p.pchunk = (patches + splitk - 1) / splitk;
+            const dim3 pgrid((O / 64) * (Cb / 64) * 3 * splitk);  // (a split past the last patch writes a zero slab)
+            if (at == 1) hipLaunchKernelGGL((wgrad_patch_kernel<1, 1>), pgrid, dim3(256), 0, st, p);
+            else if (ns == 1) hipLaunchKernelGGL((wgrad_patch_kernel<1, 0>), pgrid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((wgrad_patch_kernel<3, 0>), pgrid, dim3(256), 0, st, p);
+        } else if (trk) {
             if (bn == 192)
                 hipLaunchKernelGGL((wgrad_tr_kernel<64, 192, 2, 2>), grid, dim3(256), 0, st, p);
             else if (bm == 128 && bn == 128)

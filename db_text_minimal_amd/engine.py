@@ -479,9 +479,11 @@ class Engine:
         args = (at, self.ns, smp, bigp, slab.data_ptr(), gview.data_ptr(), N, Ho, Wo, O, H, W, Cb, I, k, k, stride,
                 pad, self.grad_scale, self.stream)
         if self.prof:  # bracket the matrix kernel alone (its rocprofv3 symbol), then the slab reduction
-            cfg = self.L.dbn_wgrad_kernel_config(at, self.ns, O, k * k * Cb, Cb)
+            cfg = self.L.dbn_wgrad_kernel_config_hw(at, self.ns, O, Cb, k, k, stride, pad, Ho, Wo, H, W)
             wname = WGRAD_TILE_NAMES[cfg & 15] % (self.ns, at)
-            if cfg & 16:  # bf16 tensors: LDS-DMA + transposing LDS reads
+            if cfg & 32:  # 3x3 / stride 1 in the 16-bit matrix modes: pixel-patch kernel
+                wname = 'wgrad_patch_kernel<%d,%d>' % (self.ns, at)
+            elif cfg & 16:  # bf16 tensors: LDS-DMA + transposing LDS reads
                 wname = 'wgrad_tr_kernel<' + wname.split('<')[1].rsplit(',', 2)[0] + '>'
             self.prof.begin(wname,
                             2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)

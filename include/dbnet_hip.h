@@ -286,10 +286,13 @@ int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, fl
 
 /* weight-gradient kernel selection (same results up to the summation order inside a split): 0 = defaults — fp32 tensors: the
  * register-transposing kernel; bf16 tensors: LDS-DMA panels + transposing LDS reads (wgrad_tr_kernel); 1 = LDS-DMA kernel for
- * exact-fp32 math on fp32 tensors (pixel-major LDS image, three-stage ring); 2 = register-transposing kernel for bf16 tensors too */
+ * exact-fp32 math on fp32 tensors (pixel-major LDS image, three-stage ring); 2 = the register-transposing kernel also where the
+ * defaults take wgrad_tr_kernel or wgrad_patch_kernel (3x3 / stride-1 layers in the 16-bit matrix modes) */
 int dbn_set_wgrad_variant(int variant);
 /* tile variant as dbn_wgrad_tile_config, + 16 when the matrix kernel is wgrad_tr_kernel<BM,BN,2,2> (its rocprofv3 symbol) */
 int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb);
+/* ... with the layer geometry: + 32 when the matrix kernel is wgrad_patch_kernel<ns, at> (3x3 / stride 1, 16-bit matrix modes) */
+int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int stride, int pad, int Ho, int Wo, int H, int W);
 /* 0: route 3x3 / stride-1 convolutions of the 16-bit matrix modes through the generic gather loop instead of the pixel-patch
    form (A/B and test hook; returns the previous setting) */
 int dbn_set_patch_conv(int on);

@@ -1199,3 +1199,38 @@ def test_dma_ring_kernels_are_race_free_at_full_size():
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), 'bf16 weight gradient differs between runs'
     other = wg(2)
     report('wgrad_tr vs register-transposing kernel', runs[0].cpu(), other.cpu(), 2e-5 * float(other.abs().max()), 1e-4)
+
+
+@pytest.mark.parametrize('mode_name', ['bf16x3', 'bf16c', 'bf16'])
+@pytest.mark.parametrize('case', [(3, 64, 64, 12, 32), (2, 128, 64, 8, 16), (2, 64, 128, 16, 48), (1, 256, 256, 4, 16), (5, 64, 192, 20, 16)])
+def test_pixel_patch_weight_gradient(case, mode_name):
+    """3x3 / stride-1 weight gradients in the 16-bit matrix modes (H % 4 = 0, W % 16 = 0, channels in blocks of 64) run in the
+    pixel-patch form (wgrad_patch_kernel: dY patch and the X rows of a tap row staged in LDS once, taps as LDS offsets, transposing
+    LDS reads).  Reference: the fp64 weight gradient on the operands as the mode sees them (stored bf16 / rounded to bf16 / exact
+    for the three-way split); and the generic kernels (dbn_set_wgrad_variant(2)) must agree to summation-order noise."""
+    N, Ci, Co, H, W = case
+    ns, at = {'bf16x3': (3, 0), 'bf16c': (1, 0), 'bf16': (1, 1)}[mode_name]
+    x = rnd(N, Ci, H, W, seed=1)
+    dy = rnd(N, Co, H, W, seed=3)
+    rq = (lambda t: t.to(torch.bfloat16).double()) if ns == 1 else (lambda t: t.double())
+    w = rnd(Co, Ci, 3, 3, seed=2).double().requires_grad_(True)
+    (gref, ) = torch.autograd.grad(F.conv2d(rq(x), w, None, 1, 1), w, rq(dy))
+    dt = torch.bfloat16 if at == 1 else torch.float32
+    xs, dys = nhwc(x).to(dt), nhwc(dy).to(dt)
+    slab = torch.empty(L().dbn_wgrad_slab_floats_hw(N, H, W, Co, H, W, Ci, 3, 3, 2 if at == 1 else 4), device=DEV)
+
+    def run(variant):
+        g = torch.full((Co, Ci, 3, 3), float('nan'), device=DEV)
+        try:
+            _lib.check(L().dbn_set_wgrad_variant(variant), 'variant')
+            _lib.check(L().dbn_wgrad_t(at, ns, dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, H, W, Co, H, W, Ci, Ci, 3, 3,
+                                       1, 1, 0.5, stream()), 'wgrad_t')
+            torch.cuda.synchronize()
+        finally:
+            L().dbn_set_wgrad_variant(0)
+        return g.cpu()
+
+    g = run(0)
+    scale = float(gref.abs().max())
+    report('patch wgrad %s %s' % (mode_name, case), g, 0.5 * gref, 2e-5 * scale, 1e-4)
+    report('patch vs generic kernels', g, run(2), 2e-5 * scale, 1e-4)
