@@ -632,6 +632,9 @@ class Engine:
         bb = m.backbone
         x4 = self.buf('x4', N, H, W, 4 if self.at == 0 else 16)  # 16-bit storage: 16-channel blocks (channels 3.. are zero)
         check(L.dbn_nchw3_to_nhwc4_t(self.at, x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
+        if train and self.at != 0:  # the stem's weight gradient wants (tap, channel) columns without the 13 zero channels per block
+            x4w = self.buf('x4w', N, H, W, 4)
+            check(L.dbn_nchw3_to_nhwc4_packed_t(self.at, x.data_ptr(), x4w.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4_packed')
         y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
@@ -970,7 +973,7 @@ class Engine:
         if self.prof:
             self.prof.end()
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy', sums=parts, sums_parts=nparts)
-        self.conv_wgrad('backbone.conv1', dy0, B['x4'], bb.conv1)
+        self.conv_wgrad('backbone.conv1', dy0, B['x4w' if self.at != 0 else 'x4'], bb.conv1)
         self.join_side()
         self.saved_generation = -1
 
