@@ -681,23 +681,35 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
     constexpr int A_I = NP * (BM / 32), B_I = NSX * 2 * (BN / 64), U_I = A_I + B_I;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && (DMA_SU * U_I) % NW == 0, "DMA instructions are dealt evenly to the waves");
     constexpr int PW = DMA_SU * U_I / NW;
+    // Dealing: a wave's slot i of a stage has a COMPILE-TIME kind (A panel / weight panel) and, where a unit has at least one
+    // instruction per wave, a compile-time unit — the first version dealt t = wave + 4 i round-robin, which made kind and unit
+    // wave-dependent: every slot carried both code paths behind scalar branches and five scalar selects, ~100 SALU instructions
+    // per stage against its 2-8 MFMAs per wave (PMC: 24-35 SALU per MFMA in the generic 16-bit kernels).  Slots [0, PA): A panel
+    // (A_I % 4 == 0: unit i / RA, instruction wave*RA + i % RA of that unit; otherwise unit wave >> 1, instruction (wave & 1)*RA + i);
+    // slots [PA, PW): weight panel, the same way.
+    // (a unit with fewer than four instructions per panel is shared by two waves: unit wave >> 1, instructions (wave & 1)*R + j)
+    static_assert(NW == 2 * DMA_SU && A_I % 2 == 0 && B_I % 2 == 0, "per-unit dealing, or two waves per unit");
+    constexpr bool A_PER_UNIT = A_I % NW == 0, B_PER_UNIT = B_I % NW == 0;
+    constexpr int RA = A_PER_UNIT ? A_I / NW : A_I / 2, RB = B_PER_UNIT ? B_I / NW : B_I / 2;
+    constexpr int PA = A_PER_UNIT ? DMA_SU * RA : RA;
+    static_assert(PA + (B_PER_UNIT ? DMA_SU * RB : RB) == PW, "slot count");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int i_u[PW], i_lds[PW];
-    bool i_isA[PW];
+    const int uw = wave_u >> 1;  // the unit of a slot dealt per stage
+    int i_lds[PW];       // slot of the instruction's destination inside its UNIT (16-byte units)
     unsigned i_add[PW];  // A: byte offset of the k/8 slice (+ plane) within a pixel's block; B: byte offset of the lane's piece in a k-tile
     int i_plane[PW];
     int r_hb[PW], r_wb[PW], r_nb[PW];
     int r_n[MODE == 3 ? PW : 1], r_hd[MODE == 3 ? PW : 1], r_wd[MODE == 3 ? PW : 1];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int t = wave_u + NW * i, u = t / U_I, r = t - u * U_I;
-        const bool isA = r < A_I;
-        const int rr = isA ? r : r - A_I, c = rr & 1, gp = rr >> 1;
+        const bool isA = i < PA;
+        // index of the instruction inside its unit
+        const int r = isA ? (A_PER_UNIT ? wave_u * RA + i % RA : (wave_u & 1) * RA + i)
+                          : (B_PER_UNIT ? wave_u * RB + (i - PA) % RB : (wave_u & 1) * RB + (i - PA));
+        const int c = r & 1, gp = r >> 1;
         const int g = isA ? r % (BM / 32) : gp % (BN / 64), plane = isA ? r / (BM / 32) : gp / (BN / 64);
-        i_u[i] = u;
-        i_isA[i] = isA;
         i_plane[i] = plane;
-        i_lds[i] = u * DMA_UNIT + (isA ? plane * 2 * BM + 64 * g : NP * 2 * BM + (plane * 2 + c) * BN + 64 * g);
+        i_lds[i] = isA ? plane * 2 * BM + 64 * g : NP * 2 * BM + (plane * 2 + c) * BN + 64 * g;
         i_add[i] = isA ? (unsigned)(lane & 1) * 16u : (unsigned)((plane * 2 + c) * p.Cd + n0 + 64 * g + lane) * 16u;
         r_hb[i] = r_wb[i] = r_nb[i] = 0;
         if (MODE == 3) r_n[MODE == 3 ? i : 0] = r_hd[MODE == 3 ? i : 0] = r_wd[MODE == 3 ? i : 0] = 0;
@@ -790,12 +802,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int u = i_u[i];
-            const bool v_u = u == 0 ? uv[0] : uv[DMA_SU - 1];
-            const int tr = u == 0 ? ur[0] : ur[DMA_SU - 1], ts = u == 0 ? us[0] : us[DMA_SU - 1];
-            const int tcb = u == 0 ? ucb[0] : ucb[DMA_SU - 1], tkt = u == 0 ? ukt[0] : ukt[DMA_SU - 1];
-            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * DMA_STAGE + i_lds[i]);
-            if (i_isA[i]) {
+            const bool isA = i < PA;  // compile-time after unrolling, like `fixed` and `uc`
+            const bool fixed = isA ? A_PER_UNIT : B_PER_UNIT;
+            const int uc = isA ? i / RA : (i - PA) / RB;  // the unit of a per-unit slot
+            const int u = fixed ? uc : uw;
+            const bool v_u = fixed ? uv[uc] : (uw ? uv[DMA_SU - 1] : uv[0]);
+            const int tr = fixed ? ur[uc] : (uw ? ur[DMA_SU - 1] : ur[0]), ts = fixed ? us[uc] : (uw ? us[DMA_SU - 1] : us[0]);
+            const int tcb = fixed ? ucb[uc] : (uw ? ucb[DMA_SU - 1] : ucb[0]), tkt = fixed ? ukt[uc] : (uw ? ukt[DMA_SU - 1] : ukt[0]);
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * DMA_STAGE + u * DMA_UNIT + i_lds[i]);
+            if (isA) {
                 const int hs = MODE == 0 ? r_hb[i] + tr : r_hb[i] - tr;
                 const int ws = MODE == 0 ? r_wb[i] + ts : r_wb[i] - ts;
                 const bool v = v_u && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
