@@ -1818,54 +1818,61 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const WgradParams p) {
     const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
 
-    // instruction t = wave*PER_WAVE + i of a stage: block t / 2 (A blocks first), pixel half t % 2; the lane's item is pixel
-    // 16*half + lane/4 of the stage, piece lane % 4 (8 channels)
+    // Dealing with COMPILE-TIME kinds per slot (see the generic 16-bit convolution loop): slots [0, PA) of a wave are dY
+    // instructions a = wave*PA + j, slots [PA, PER_WAVE) X instructions b = wave*PB + j; instruction x covers block x / 2,
+    // pixel half x % 2; the lane's item is pixel 16*half + lane/4 of the stage, piece lane % 4 (8 channels)
+    constexpr int PA = A_BLK * (KP / 16) / 4, PB = B_BLK * (KP / 16) / 4;
+    static_assert(PA * 4 == A_BLK * (KP / 16) && PB * 4 == B_BLK * (KP / 16) && PA + PB == PER_WAVE, "whole slots per wave");
     const int HWo = p.Ho * p.Wo;
-    unsigned a_off[PER_WAVE];
-    int a_px[PER_WAVE];
-    int b_n[PER_WAVE], b_oh[PER_WAVE], b_ow[PER_WAVE], b_px[PER_WAVE], b_ci[PER_WAVE], b_tr[PER_WAVE], b_ts[PER_WAVE];
-    bool b_ok[PER_WAVE];
+    unsigned a_off[PA];
+    int a_px[PA], a_lds[PA];
+    int b_n[PB], b_oh[PB], b_ow[PB], b_px[PB], b_ci[PB], b_tr[PB], b_ts[PB], b_lds[PB];
+    bool b_ok[PB];
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-        const int t = wave * PER_WAVE + i, blk = t >> 1, half = t & 1;
-        const int px = pbeg + 16 * half + (lane >> 2), piece = lane & 3;
-        a_off[i] = 0; a_px[i] = px; b_n[i] = b_oh[i] = b_ow[i] = b_ci[i] = b_tr[i] = b_ts[i] = 0; b_px[i] = px; b_ok[i] = false;
-        if (blk < A_BLK) {
-            a_off[i] = (unsigned)(o0 + 32 * blk + 8 * piece) * 2u;
-        } else {
-            const int jj = j0 + 32 * (blk - A_BLK) + 8 * piece;
-            b_ok[i] = jj < p.J;
-            const int tap = b_ok[i] ? jj / p.Cb : 0;
-            b_ci[i] = b_ok[i] ? jj - tap * p.Cb : 0;
-            b_tr[i] = tap / p.S - p.pad;
-            b_ts[i] = tap % p.S - p.pad;
-            int rem;
-            divmod24(min(px, p.P - 1), HWo, p.rcp_HWo, b_n[i], rem);
-            divmod24(rem, p.Wo, p.rcp_Wo, b_oh[i], b_ow[i]);
-        }
+    for (int j = 0; j < PA; ++j) {
+        const int x = wave * PA + j, blk = x >> 1, half = x & 1;
+        a_px[j] = pbeg + 16 * half + (lane >> 2);
+        a_off[j] = (unsigned)(o0 + 32 * blk + 8 * (lane & 3)) * 2u;
+        a_lds[j] = blk * BLK_SL + half * 64;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int x = wave * PB + j, blk = x >> 1, half = x & 1;
+        const int px = pbeg + 16 * half + (lane >> 2);
+        const int jj = j0 + 32 * blk + 8 * (lane & 3);
+        b_px[j] = px;
+        b_lds[j] = (A_BLK + blk) * BLK_SL + half * 64;
+        b_ok[j] = jj < p.J;
+        const int tap = b_ok[j] ? jj / p.Cb : 0;
+        b_ci[j] = b_ok[j] ? jj - tap * p.Cb : 0;
+        b_tr[j] = tap / p.S - p.pad;
+        b_ts[j] = tap % p.S - p.pad;
+        int rem;
+        divmod24(min(px, p.P - 1), HWo, p.rcp_HWo, b_n[j], rem);
+        divmod24(rem, p.Wo, p.rcp_Wo, b_oh[j], b_ow[j]);
     }
     auto issue_stage = [&](int slot) {
 #pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const int t = wave * PER_WAVE + i, blk = t >> 1, half = t & 1;
-            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_SL + blk * BLK_SL + half * 64);
-            if (blk < A_BLK) {
-                const unsigned off = a_px[i] < pend ? (unsigned)a_px[i] * (unsigned)p.O * 2u + a_off[i] : OOB_OFFSET;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sm, dst, 16, (int)off, 0, 0, 0);
-                a_px[i] += KP;
-            } else {
-                const int ih = b_oh[i] * p.stride + b_tr[i], iw = b_ow[i] * p.stride + b_ts[i];
-                const bool v = b_ok[i] && b_px[i] < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const unsigned off = v ? (unsigned)(((b_n[i] * p.H + ih) * p.W + iw) * p.Cb + b_ci[i]) * 2u : OOB_OFFSET;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, dst, 16, (int)off, 0, 0, 0);
-                b_px[i] += KP;
-                b_ow[i] += KP;
-                while (b_ow[i] >= p.Wo) {
-                    b_ow[i] -= p.Wo;
-                    if (++b_oh[i] == p.Ho) {
-                        b_oh[i] = 0;
-                        ++b_n[i];
-                    }
+        for (int j = 0; j < PA; ++j) {
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_SL + a_lds[j]);
+            const unsigned off = a_px[j] < pend ? (unsigned)a_px[j] * (unsigned)p.O * 2u + a_off[j] : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sm, dst, 16, (int)off, 0, 0, 0);
+            a_px[j] += KP;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * STAGE_SL + b_lds[j]);
+            const int ih = b_oh[j] * p.stride + b_tr[j], iw = b_ow[j] * p.stride + b_ts[j];
+            const bool v = b_ok[j] && b_px[j] < pend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned off = v ? (unsigned)(((b_n[j] * p.H + ih) * p.W + iw) * p.Cb + b_ci[j]) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, dst, 16, (int)off, 0, 0, 0);
+            b_px[j] += KP;
+            b_ow[j] += KP;
+            while (b_ow[j] >= p.Wo) {
+                b_ow[j] -= p.Wo;
+                if (++b_oh[j] == p.Ho) {
+                    b_oh[j] = 0;
+                    ++b_n[j];
                 }
             }
         }
