@@ -1336,8 +1336,11 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     // matrix-pipe clocks per wave; with a distance of one every k-step waited out a full memory round trip (measured: 2.05 us per
     // k-step round whatever the number of resident workgroups — more pixel splits per CU changed nothing), i.e. the kernel ran at
     // (workgroups per CU) k-steps per latency.  A stored-bf16 set is 8 registers, an fp32 one 16: D = 4 / 3 keep the occupancy.
-    // Exact fp32 (NS = 0: 1536 clocks per k-step and wave) stays at one: the second set cost it an occupancy step (100 -> 72 TFLOP/s).
-    constexpr int D = NS == 0 || AT == 3 ? 1 : (AT == 0 ? 3 : 4);
+    // Exact fp32 (NS = 0: 1536 clocks per k-step and wave): two for the 64-row tiles (120 registers, still four waves per SIMD:
+    // the head convs' weight gradients 1.084 -> 1.045 ms, all weight gradients 0.648 -> 0.663 of peak, step +0.4 %), one for
+    // 128 x 128 (152 registers = an occupancy step: 0.256 -> 0.279 ms).  Round 1's attempt at two had lost 28 % — with the loads
+    // inside role branches the compiler drained every set each k-step (see issue_loads).
+    constexpr int D = AT == 3 ? 1 : NS == 0 ? (BM == 64 ? 2 : 1) : (AT == 0 ? 3 : 4);
     f32x4 rr_[D][4];        // AT = 0: 4 pixels x 4 fp32 channels
     u32x2 rh_[D][NP][4];    // AT = 1 / 3: per plane 4 pixels x 4 bf16 channels
     unsigned woff[4] = {OOB_OFFSET, OOB_OFFSET, OOB_OFFSET, OOB_OFFSET};
