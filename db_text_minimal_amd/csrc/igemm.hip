@@ -606,7 +606,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
     };
     // this lane's patch pixel for accumulator block a (rows 2*(wm*MI + a) .. +1 of the tile), before the tap offset
     const int q4 = li >> 2;
-    const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1) + 0) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
+    const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1)) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
 
     load_patch(0);
 #pragma unroll
