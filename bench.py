@@ -54,9 +54,20 @@ def synthetic(n, size, seed, dev):
     return img, gts
 
 
-def cpu_baseline(max_seconds=30.0):
-    """Oracle train step (fwd + DBLoss + backward + Adam) on the host cores, BASELINE configs[0]
-    shape (2x3x640x640).  Bounded sample: 1 warm-up + up to 3 timed steps."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(max_seconds=30.0, n16_budget_s=60.0):
+    """Oracle train step (fwd + DBLoss + backward + Adam) on the host cores: BASELINE configs[0]'s shape
+    (2x3x640x640; 1 warm-up + up to 3 timed steps, median) and ONE step at the benchmarked batch (16x3x640x640, no warm-up;
+    skipped when the N = 2 timing predicts more than `n16_budget_s`)."""
     from oracle import dbnet_oracle as O
     threads = torch.get_num_threads()
     n, size = 2, 640
@@ -74,9 +85,48 @@ def cpu_baseline(max_seconds=30.0):
             break
     times.sort()
     med = times[len(times) // 2]
-    return {'value': round(n / med, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d train steps (fwd+DBLoss+bwd+Adam) of the CPU oracle at 2x3x640x640 fp32, median; '
-                      'torch CPU threads=%d' % (len(times), threads)}
+    out = {'value': round(n / med, 4), 'unit': 'images/s', 'cores': threads, 'cpu_model': cpu_model(),
+           'logical_cpus': os.cpu_count(), 'kind': 'port',
+           'sample': '%d train steps (fwd+DBLoss+bwd+Adam) of the CPU oracle at 2x3x640x640 fp32, median; '
+                     'torch CPU threads=%d' % (len(times), threads)}
+    predicted = 8.0 * med
+    if predicted <= n16_budget_s:
+        img16, gts16 = O.synthetic_batch(16, size, seed=42)
+        t0 = time.time()
+        O.train_step(sd, opt, img16, gts16)
+        t16 = time.time() - t0
+        out['n16'] = {'value': round(16 / t16, 4), 'unit': 'images/s', 'seconds': round(t16, 2),
+                      'sample': 'one train step of the CPU oracle at 16x3x640x640 fp32 (the benchmarked batch), no warm-up'}
+    else:
+        out['n16'] = {'value': None, 'skipped': 'predicted %.0f s per step on this host (> %.0f s budget)' % (predicted, n16_budget_s)}
+    return out
+
+
+class ClockProbe:
+    """Sustained shader clock during the timed region: dbn_clock_probe (one wave, s_memtime vs s_memrealtime over 200 us)
+    launched on its own stream at the start of every timed step, beside the step's kernels."""
+
+    def __init__(self, dev, steps):
+        from db_text_minimal_amd import _lib
+        self.L = _lib.lib()
+        self.buf = torch.zeros(steps, 2, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.khz = self.L.dbn_wall_clock_khz()
+        self.i = 0
+
+    def sample(self):
+        if self.i < self.buf.shape[0]:
+            self.L.dbn_clock_probe(self.buf[self.i].data_ptr(), 200, self.stream.cuda_stream)
+            self.i += 1
+
+    def result(self):
+        v = self.buf[:self.i].cpu().double()
+        mhz = sorted((v[:, 0] / v[:, 1].clamp(min=1) * self.khz / 1000.0).tolist())
+        if not mhz:
+            return None
+        return {'median_mhz': round(mhz[len(mhz) // 2], 1), 'min_mhz': round(mhz[0], 1), 'max_mhz': round(mhz[-1], 1),
+                'samples': len(mhz), 'nominal_mhz': 2400,
+                'how': 's_memtime / s_memrealtime over 200 us, one wave on its own stream at the start of every timed step'}
 
 
 def main():
@@ -92,9 +142,12 @@ def main():
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16', 'bf16c'],
                     help="precision mode: f32 = exact-fp32 MFMA (default, BASELINE configs[1]); bf16x3 = fp32-accurate split; "
                          "bf16 = native bf16 storage + MFMA (BASELINE configs[2]); bf16c = fp32 tensors, bf16 operands")
-    ap.add_argument('--single-allreduce', action='store_true',
-                    help="N>1: one all-reduce of the flat gradient buffer after the backward pass (north_star's wording) instead of "
-                         "the default 4 buckets issued under it; results are bit-identical (tests/test_dp_gloo.py, tests/test_rccl_gpu.py)")
+    ap.add_argument('--single-allreduce', action='store_true', help="(the default since round 3; accepted for compatibility)")
+    ap.add_argument('--bucketed-allreduce', action='store_true',
+                    help="N>1: time the 4-bucket exchange issued under the backward pass as the headline instead of north_star's one "
+                         "all-reduce after it (the other form is always timed too and reported under grad_allreduce_other); results are "
+                         "bit-identical (tests/test_dp_gloo.py, tests/test_rccl_gpu.py)")
+    ap.add_argument('--serial-steps', type=int, default=3, help='instrumented single-stream steps for the kernels[] table (median)')
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
     args = ap.parse_args()
@@ -113,8 +166,7 @@ def main():
     model = DBTextModel().to(dev).train()
     model.engine.set_conv_math(args.math)
     trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
-    if args.single_allreduce:
-        trainer.overlap_allreduce = False
+    trainer.overlap_allreduce = bool(args.bucketed_allreduce)
     img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
     eng = model.engine
 
@@ -130,15 +182,22 @@ def main():
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
     timer = KernelTimer(labels=('igemm_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
+    clock = ClockProbe(dev, args.steps)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    trainer.exchange_events = [] if world > 1 else None
     barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
+        step_ev[it].record()
+        clock.sample()
         eng.prof = timer if it % TIMED_EVERY == 0 else None
         preds, losses = trainer.step(img, gts)
+    step_ev[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
     eng.prof = None
     timed_steps = len(range(0, args.steps, TIMED_EVERY))
+    per_step = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     if dist.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -147,13 +206,55 @@ def main():
     if not (final_loss == final_loss):
         raise SystemExit('non-finite loss')
 
-    # every kernel family once more, outside the timed region, on a single stream (full bracketing serialises the streams)
-    timer2 = KernelTimer()
-    eng.prof = timer2
-    trainer.step(img, gts)  # every rank takes the step (it contains the gradient all-reduce); rank 0 reports
-    torch.cuda.synchronize()
-    eng.prof = None
-    serial_summ = timer2.summary()
+    # ---- N > 1 diagnostics: exposed part of the exchange, the other exchange form, replica divergence ------------------
+    def exposed_ms(events):
+        v = sorted(a.elapsed_time(b) for a, b in events)
+        return round(v[len(v) // 2], 4) if v else None
+
+    dp_diag = None
+    if world > 1:
+        form = 'bucketed' if trainer.overlap_allreduce else 'single'
+        dp_diag = {'form': form, 'allreduce_exposed_ms': exposed_ms(trainer.exchange_events),
+                   'how': 'HIP events on the main stream after the last backward kernel was enqueued and after the exchange was '
+                          'joined: the time the step waits for the collective(s); median over the timed steps'}
+        # the other form, same number of steps, same bracket
+        trainer.overlap_allreduce = not trainer.overlap_allreduce
+        trainer.exchange_events = []
+        for _ in range(2):
+            trainer.step(img, gts)
+        trainer.exchange_events = []
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(img, gts)
+        barrier()
+        t_other = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_other, op=dist.ReduceOp.MAX)
+        dp_diag['other'] = {'form': 'bucketed' if trainer.overlap_allreduce else 'single',
+                            'ms_per_step': round(float(t_other.item()) / args.steps * 1e3, 3),
+                            'images_per_s': round(world * args.batch * args.steps / float(t_other.item()), 2),
+                            'allreduce_exposed_ms': exposed_ms(trainer.exchange_events)}
+        trainer.overlap_allreduce = not trainer.overlap_allreduce
+        trainer.exchange_events = None
+        (psum, psq), spread = trainer.param_checksum()
+        dp_diag['param_checksum'] = {'sum': psum, 'sum_sq': psq, 'max_spread_over_ranks': spread}
+        if spread != 0.0:
+            raise SystemExit('data-parallel replicas diverged: parameter checksum spread %g over %d ranks' % (spread, world))
+
+    # every kernel family again, outside the timed region, on a single stream (full bracketing serialises the streams):
+    # `--serial-steps` instrumented steps, per-label MEDIAN of the step totals (one such step is too noisy to compare runs)
+    serial_runs = []
+    for _ in range(max(1, args.serial_steps)):
+        timer2 = KernelTimer()
+        eng.prof = timer2
+        trainer.step(img, gts)  # every rank takes the step (it contains the gradient all-reduce); rank 0 reports
+        torch.cuda.synchronize()
+        eng.prof = None
+        serial_runs.append(timer2.summary())
+    serial_summ = {}
+    for k, v in serial_runs[0].items():
+        ms = sorted(r[k]['ms'] for r in serial_runs if k in r)
+        serial_summ[k] = dict(v, ms=ms[len(ms) // 2], ms_min=ms[0], ms_max=ms[-1])
 
     # dominant kernel = the MFMA kernel (any igemm tile variant or weight-gradient variant) with the largest share of the step
     # when every kernel has the device to itself (under two streams concurrent kernels inflate each other's bracketed
@@ -174,7 +275,7 @@ def main():
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
 
     # HBM traffic of that kernel from the committed PMC passes (profiles/, tools/pmc_traffic.py), per launch
-    for tag in ('r02', 'r01'):  # newest committed PMC summary that knows this kernel (tools/profile_round.sh)
+    for tag in ('r03', 'r02', 'r01'):  # newest committed PMC summary that knows this kernel (tools/profile_round.sh)
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))['kernels'].get(dname)
         except (OSError, ValueError, KeyError):
@@ -191,12 +292,13 @@ def main():
         roofline_serial = {'kernel': dname, 'achieved': round(a, 2), 'peak': round(peak_mfma, 1), 'unit': 'TFLOP/s',
                            'frac': round(a / peak_mfma, 4), 'launches': serial['launches'],
                            'avg_launch_ms': round(serial['ms'] / serial['launches'], 4),
-                           'how': 'one extra step outside the timed region, every launch bracketed by HIP events, single stream'}
+                           'how': 'median of %d extra steps outside the timed region, every launch bracketed by HIP events, single stream' % len(serial_runs)}
     else:
         roofline_serial = None
     if rank == 0:
         for name, v in sorted(serial_summ.items(), key=lambda kv: -kv[1]['ms']):
-            ent = {'kernel': name, 'launches': v['launches'], 'ms_per_step': round(v['ms'], 3)}
+            ent = {'kernel': name, 'launches': v['launches'], 'ms_per_step': round(v['ms'], 3),
+                   'ms_min_max': [round(v['ms_min'], 3), round(v['ms_max'], 3)]}
             if v['flops'] > 0:
                 a = v['flops'] / (v['ms'] * 1e-3) / 1e12
                 ent.update(bound='mfma', achieved=round(a, 2), peak=round(peak_mfma, 1), unit='TFLOP/s',
@@ -244,10 +346,18 @@ def main():
                                                                                     1 if args.math in ('f32', 'bf16x3') else 2),
                        'global_batch': world * args.batch, 'img_size': args.size, 'parallelism': 'dp%d' % world,
                        'grad_allreduce': (('RCCL sum all-reduce of the flat 49 MB fp32 gradient buffer per step, ' +
-                                           ('one call after the backward pass (--single-allreduce)' if not trainer.overlap_allreduce else
-                                            'issued as 4 contiguous buckets under the backward pass (FPN+head, layer4, layer3, rest); '
-                                            'north_star names a single call: --single-allreduce times that form'))
+                                           ("ONE call after the backward pass (north_star's single collective)" if not trainer.overlap_allreduce else
+                                            'issued as 4 contiguous buckets under the backward pass (FPN+head, layer4, layer3, rest; '
+                                            '--bucketed-allreduce)'))
                                           if world > 1 else None)},
+            'timing': {'value_from': 'wall time of the K steps between two barrier+synchronize brackets, max over ranks (driver contract)',
+                       'ms_per_step_median': round(per_step[len(per_step) // 2], 3), 'ms_per_step_min': round(per_step[0], 3),
+                       'ms_per_step_max': round(per_step[-1], 3),
+                       'instrumented_steps_in_region': timed_steps,
+                       'note': 'per-step figures from HIP events on the main stream at the step boundaries (rank 0); '
+                               '%d of the K steps carry event brackets around their MFMA launches (roofline), which costs those steps ~2 %%' % timed_steps},
+            'engine_clock': clock.result(),
+            'data_parallel': dp_diag,
             'roofline': roofline,
             'roofline_serial': roofline_serial,
             # whole-step rates: on the dense convolution count of SURVEY §8d (an EFFECTIVE rate: the structured FPN kernels

@@ -72,6 +72,8 @@ SIGNATURES = {
     'dbn_db_loss_ohem_bwd': 'ppppp' + 'ff' + 'iiii' + 'pp',
     'dbn_pixel_confusion': 'plppiiifpp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
+    'dbn_clock_probe': 'pip',
+    'dbn_wall_clock_khz': '',
 }
 # `_t` forms: activation storage type first (0 fp32, 1 bf16, 2 fp16), see include/dbnet_hip.h
 SIGNATURES.update({

@@ -701,6 +701,24 @@ inline size_t red_smem(int Cfull, int nv) {
 
 }  // namespace
 
+// Measurement aid (bench.py): the shader clock the chip SUSTAINS while the step runs.  One wave samples s_memtime (ticks at
+// the shader clock) and s_memrealtime (constant reference clock) around `ref_ticks` of s_sleep; launched on its own stream
+// beside the step's kernels it costs one wave slot and no matrix-pipe time.  out = {shader cycles, reference ticks}.
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ out, unsigned long long ref_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ref_ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
 extern "C" {
 
 // Entry points come in two forms: `dbn_x(...)` with fp32 activation tensors (the contract of BASELINE configs[1]) and
@@ -954,6 +972,23 @@ int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
     hipLaunchKernelGGL(adam_kernel, dim3(dbn_grid(n / 4 + 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
     return dbn_status();
+}
+
+int dbn_clock_probe(void* out2, int microseconds, void* stream) {
+    DBN_REQUIRE(out2 && microseconds > 0 && microseconds <= 100000);
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        khz = 100000;  // gfx9 reference clock: 100 MHz
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out2,
+                       (unsigned long long)microseconds * (unsigned long long)khz / 1000ull);
+    return dbn_status();
+}
+
+int dbn_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        return 100000;
+    return khz;
 }
 
 }  // extern "C"

@@ -6,11 +6,11 @@
     optimizer.zero_grad(); total.backward(); optimizer.step()               # :169-172
 
 `DBTrainer.step` issues exactly that sequence as HIP kernels on one stream, with
-no autograd graph, no host synchronisation and (for world_size > 1) one sum
-all-reduce of the flat gradient buffer over RCCL/xGMI per step, issued as four
-contiguous buckets in the order the backward pass completes them (FPN+head, layer4,
-layer3, the rest) so that all but the last ~3 MB travel under the remaining backward
-kernels; the 1/world average is folded into the Adam kernel.  BatchNorm statistics
+no autograd graph, no host synchronisation and (for world_size > 1) ONE sum
+all-reduce of the flat gradient buffer over RCCL/xGMI per step (north_star's single
+collective; optionally the same sum as four contiguous buckets issued in the order the
+backward pass completes them — `overlap_allreduce`); the 1/world average is folded
+into the Adam kernel.  BatchNorm statistics
 and the loss normalisers stay per GPU (standard data-parallel semantics).
 """
 import os
@@ -37,6 +37,20 @@ def allreduce_flat_grads(flat_grad, world, group=None):
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
+
+
+def replica_divergence(flat, group=None):
+    """((sum, sum of squares) of `flat` in fp64, max over both of |max over ranks - min over ranks|).  The second value is
+    0.0 exactly when every replica holds the same buffer — data-parallel replicas must (same start, same averaged gradient,
+    same Adam state).  Two tiny all-reduces; bench.py fails an N > 1 run on divergence."""
+    f = flat.double()
+    mine = torch.stack([f.sum(), (f * f).sum()])
+    if not (dist.is_available() and dist.is_initialized()):
+        return mine.tolist(), 0.0
+    hi, lo = mine.clone(), mine.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    return mine.tolist(), float((hi - lo).abs().max())
 
 
 # backward completes the gradient buffer back to front: FPN+head first, then backbone stages 4..1, stem last
@@ -91,16 +105,24 @@ class DBTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._gone = None
-        # bucketed exchange under the backward pass; False (or DBN_OVERLAP_ALLREDUCE=0): one all-reduce after it
-        self.overlap_allreduce = os.environ.get('DBN_OVERLAP_ALLREDUCE', '1') != '0'
-        if self.world > 1:
-            self.sync_from_rank0()
+        # The data-parallel exchange: ONE sum all-reduce of the flat gradient buffer after the backward pass — the step of
+        # BASELINE's north_star (reference train.py:169-172 is the sequence being parallelised).  overlap_allreduce = True
+        # (DBN_OVERLAP_ALLREDUCE=1, bench.py --bucketed-allreduce) issues the same sum as four contiguous buckets under the
+        # backward pass instead (bit-identical results, tests/test_dp_gloo.py, tests/test_rccl_gpu.py).
+        self.overlap_allreduce = os.environ.get('DBN_OVERLAP_ALLREDUCE', '0') == '1'
+        # Replicas start from rank 0's state.  The broadcast is the first collective, and the first collective creates the
+        # RCCL communicator — which should happen AFTER the activation arena exists (init_distributed: creating it first
+        # cost 2.4 ms/step at bs16 640^2).  So the sync is deferred to the first step(), which knows the batch shape: it
+        # takes one dry forward+backward to allocate every buffer, restores the BatchNorm buffers, then broadcasts.
+        self._need_sync = dist.is_available() and dist.is_initialized()  # (also with one forced rank: tests/dist_child.py)
+        self.exchange_events = None  # set to [] to collect (issue, done) HIP event pairs around the exchange (bench.py)
 
     def sync_from_rank0(self):
-        """Data-parallel replicas must start from identical state: rank 0's flat parameter buffer and its BatchNorm buffers are
-        broadcast once (what DistributedDataParallel does at construction).  During training the parameters stay identical by
-        construction (same averaged gradient, same Adam state); BatchNorm running statistics are NOT synchronised afterwards
-        — each rank tracks its own shard, and checkpoints carry rank 0's."""
+        """Data-parallel replicas must start from identical state: rank 0's flat parameter buffer, its BatchNorm buffers and
+        (when it exists) the Adam state are broadcast once (what DistributedDataParallel does at construction).  During
+        training the parameters stay identical by construction (same averaged gradient, same Adam state); BatchNorm running
+        statistics are NOT synchronised afterwards — each rank tracks its own shard, and checkpoints carry rank 0's
+        (SURVEY.md §8e)."""
         eng = self.model.engine
         eng.ensure_flat()
         eng.flush_counters()
@@ -108,7 +130,38 @@ class DBTrainer:
         dist.broadcast(eng.flat, src=src, group=self.pg)
         for b in self.model.buffers():
             dist.broadcast(b, src=src, group=self.pg)
+        opt = self.optimizer
+        if isinstance(opt, FusedAdam):
+            opt._ensure_state()
+            cnt = torch.tensor([opt.step_count], device=eng.flat.device, dtype=torch.int64)
+            dist.broadcast(cnt, src=src, group=self.pg)
+            opt.step_count = int(cnt.item())
+            dist.broadcast(opt.exp_avg, src=src, group=self.pg)
+            dist.broadcast(opt.exp_avg_sq, src=src, group=self.pg)
         eng.mark_params_dirty()
+        self._need_sync = False
+
+    def _warm_arena_then_sync(self, img, gts):
+        """One dry forward + loss + backward so that every activation / gradient / scratch buffer of this batch shape exists,
+        with the BatchNorm buffers put back afterwards (the dry pass must leave no trace), THEN the start-up broadcast."""
+        model, eng = self.model, self.model.engine
+        eng.ensure_flat()
+        eng.flush_counters()
+        saved = [b.detach().clone() for b in model.buffers()]
+        preds = eng.forward(img, train=True)
+        _, dpreds = self._loss(preds, gts)
+        eng.backward(dpreds)
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer._ensure_state()
+        eng.nbt_pending = {}
+        with torch.no_grad():
+            for b, s in zip(model.buffers(), saved):
+                b.copy_(s)
+        self.sync_from_rank0()
+
+    def param_checksum(self):
+        """See replica_divergence(): ((sum, sum of squares) of this rank's parameters, spread over the ranks)."""
+        return replica_divergence(self.model.engine.flat, self.pg)
 
     def _loss(self, preds, gts):
         """dbn_db_loss_fwd + _bwd with d(total)=1; returns (losses[5], dpreds)."""
@@ -156,9 +209,11 @@ class DBTrainer:
         model, eng = self.model, self.model.engine
         if not model.training:
             raise RuntimeError('DBTrainer.step requires model.train()')
+        gts = gts.contiguous().float()
+        if self._need_sync:
+            self._warm_arena_then_sync(img, gts)
         preds = eng.forward(img, train=True)
         assert preds.size(1) == 3  # train.py:161
-        gts = gts.contiguous().float()
         losses, dpreds = self._loss(preds, gts)
         self.optimizer.zero_grad()
         distributed = dist.is_available() and dist.is_initialized()
@@ -170,12 +225,27 @@ class DBTrainer:
                 eng.backward(dpreds)
             finally:
                 eng.grad_ready_hook = None
+            ev = self._exchange_event()  # backward fully enqueued: what the exchange still takes from here on is exposed
             scale = ex.finish()
+            self._exchange_event(ev)
         else:
             eng.backward(dpreds)
+            ev = self._exchange_event()
             scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
+            self._exchange_event(ev)
         self.optimizer.step(grad_scale=scale)
         return preds, losses
+
+    def _exchange_event(self, start=None):
+        """HIP events on the main stream before / after the gradient exchange (when `exchange_events` is a list): the elapsed
+        time between them is the part of the collective(s) the step waits for — everything not hidden under backward kernels."""
+        if self.exchange_events is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        if start is not None:
+            self.exchange_events.append((start, e))
+        return e
 
 
 def init_distributed():
@@ -198,13 +268,35 @@ def init_distributed():
 # ----------------------------------------------------------------------------------------------------------------------
 # Epoch-level loop: reference src/train.py:146-318 without its Hydra / TensorBoard / OpenCV-metric plumbing.
 # ----------------------------------------------------------------------------------------------------------------------
-def evaluate(model, criterion, loader, thresh=0.3, device=None):
+def _mean_over_ranks(values, group, device):
+    """Rank-uniform floats: the mean over the ranks of each value (one small all-reduce).  Every decision of the epoch loop
+    that leads to a collective (checkpoint barrier) or changes the optimizer (plateau scheduler) must be taken from these —
+    the per-rank losses differ (each rank sees its own shard and tracks its own BatchNorm running statistics), and ranks
+    that disagree about saving would enter different collectives."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return (t / dist.get_world_size(group)).tolist()
+
+
+def _collective_device(model):
+    """Device for the small control all-reduces: the model's (RCCL needs device tensors, gloo takes host ones)."""
+    backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+    if backend == 'nccl':
+        return next(model.parameters()).device
+    return torch.device('cpu')
+
+
+def evaluate(model, criterion, loader, thresh=0.3, device=None, pixel_metric=True):
     """train.py:228-262: eval-mode forward under no_grad, DBLoss on the 2-channel output (single value), the pixel metric
     on device.  Returns (mean test loss as a float, score dict of the RunningScore over the whole loader)."""
-    from .text_metrics import RunningScore
     was_training = model.training
     model.eval()
-    running = RunningScore(2)
+    running = None
+    if pixel_metric:
+        from .text_metrics import RunningScore
+        running = RunningScore(2)
     total, n = None, 0
     with torch.no_grad():
         for batch in loader:
@@ -215,29 +307,40 @@ def evaluate(model, criterion, loader, thresh=0.3, device=None):
             loss = criterion(preds, stack_gts(batch))
             total = loss if total is None else total + loss
             n += 1
-            running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)  # no host sync
+            if running is not None:
+                running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)  # no host sync
     model.train(was_training)
-    score = running.get_scores()[0] if n else {}
+    score = running.get_scores()[0] if (n and running is not None) else {}
     return (float(total) / max(n, 1) if total is not None else float('nan')), score
 
 
 def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, scheduler=None, lrs_mode=None, thresh=0.3,
-        best_cp_path=None, last_cp_path=None, device=None, log=None, process_group=None):
+        best_cp_path=None, last_cp_path=None, device=None, log=None, process_group=None, trainer=None, pixel_metric=True):
     """The reference's training driver (train.py:146-318): per epoch a pass over `train_loader` through DBTrainer.step
     (lr scheduler stepped per iteration when lrs_mode == 'poly', train.py:172-173), the running pixel metric
     (train.py:175-181, on device), then evaluate() on `test_loader`, the reference's best-checkpoint rule
     (`test_loss <= best_test_loss and train_loss <= best_train_loss`, train.py:301-305; `train_loss` is the epoch SUM as
     there), ReduceLROnPlateau-style schedulers stepped with the test loss when lrs_mode == 'reduce' (train.py:307-308), and
     the final state_dict at `last_cp_path` (train.py:316).  Box-level P/R/HMean (train.py:277-299) needs the host OpenCV
-    post-processing and is left to the caller.  Returns a list of per-epoch dicts."""
-    from .text_metrics import RunningScore
-    trainer = DBTrainer(model, criterion, optimizer, process_group=process_group)
+    post-processing and is left to the caller.  Returns a list of per-epoch dicts.
+
+    Data parallel: each rank iterates its own shard of the loaders.  The epoch's train-loss sum and the test loss are
+    AVERAGED OVER THE RANKS before they are compared, recorded or given to the scheduler, so every rank takes the same
+    save / no-save decision (the checkpoint barrier is reached by all or none) and the same learning-rate schedule.
+    `trainer`: a ready DBTrainer (default: built here); `pixel_metric=False` skips the device pixel metric."""
+    if trainer is None:
+        trainer = DBTrainer(model, criterion, optimizer, process_group=process_group)
     distributed = dist.is_available() and dist.is_initialized()
     is_writer = (not distributed) or dist.get_rank(process_group) == 0
+    ctl_dev = _collective_device(model) if distributed else None
+    RunningScore = None
+    if pixel_metric:
+        from .text_metrics import RunningScore
 
     def save(path):
         """Checkpoints are written by rank 0 only (every rank writing the same path would race); the others wait, so the
-        file is complete when any rank returns.  The BatchNorm buffers in it are rank 0's."""
+        file is complete when any rank returns.  The BatchNorm buffers in it are rank 0's.  Called at rank-uniform points
+        only (the decision values are all-reduced first)."""
         if is_writer:
             torch.save(model.state_dict(), path)
         if distributed:
@@ -248,7 +351,7 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
     steps = 0
     for epoch in range(epochs):
         model.train()
-        running = RunningScore(2)
+        running = RunningScore(2) if RunningScore is not None else None
         train_sum = None
         for batch in train_loader:
             if device is not None:
@@ -257,14 +360,21 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
             preds, losses = trainer.step(batch, None)
             if lrs_mode == 'poly' and scheduler is not None:
                 scheduler.step()
-            running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)
+            if running is not None:
+                running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)
             train_sum = losses[4] if train_sum is None else train_sum + losses[4]  # device-side sums: no per-step host sync
-        score = running.get_scores()[0] if train_sum is not None else {}
+        score = running.get_scores()[0] if (train_sum is not None and running is not None) else {}
         train_loss = float(train_sum) if train_sum is not None else float('nan')
+        test_loss, test_score = float('nan'), {}
+        if test_loader is not None:
+            test_loss, test_score = evaluate(model, criterion, test_loader, thresh=thresh, device=device, pixel_metric=pixel_metric)
+        local = (train_loss, test_loss)
+        train_loss, test_loss = _mean_over_ranks(local, process_group, ctl_dev)  # rank-uniform from here on
         rec = {'epoch': epoch + 1, 'global_steps': steps, 'lr': optimizer.param_groups[0]['lr'], 'train_loss_sum': train_loss,
                'train_loss': train_loss / max(len(train_loader), 1), 'train_score': score}
+        if distributed:
+            rec['rank_local'] = {'train_loss_sum': local[0], 'test_loss': local[1]}
         if test_loader is not None:
-            test_loss, test_score = evaluate(model, criterion, test_loader, thresh=thresh, device=device)
             rec.update(test_loss=test_loss, test_score=test_score)
             if test_loss <= best_test and train_loss <= best_train:
                 best_test, best_train = test_loss, train_loss

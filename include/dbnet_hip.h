@@ -220,6 +220,12 @@ int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, 
 int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
 
+/* ---- measurement aid (bench.py, no reference counterpart): one wave samples the shader clock (s_memtime) against the constant
+ * reference clock (s_memrealtime) over `microseconds`; out2 = {shader cycles, reference ticks} (two uint64 in device memory).
+ * dbn_wall_clock_khz: the reference clock's rate.  sustained MHz = cycles / ticks * khz / 1000 */
+int dbn_clock_probe(void* out2, int microseconds, void* stream);
+int dbn_wall_clock_khz(void);
+
 /* ---- deformable convolution of the DCN backbones (resnet.py:54-65,81-82,111-124,145-146: conv2_offset ->
  * torchvision.ops.DeformConv2d, deformable_groups = 1), lowered to sampling + GEMM:
  *   cols = dbn_deform_im2col(x, offset);  y = dbn_igemm_f32(cols as [N,Ho,Wo,R*S*C], 1x1 panels of the permuted weight)

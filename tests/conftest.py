@@ -25,12 +25,12 @@ def _free_port():
     return p
 
 
-def pytest_sessionstart(session):
+def pytest_collection_finish(session):
     """The RCCL test (tests/test_rccl_gpu.py) needs a FRESH process that initialises the GPU itself under
     torch.distributed.run.  A process that has already initialised the GPU must not exec another program on this pool, so
-    the child is started here — before any test of this session has touched the GPU — and the test only collects its verdict."""
-    markexpr = getattr(session.config.option, 'markexpr', '') or ''
-    if 'gpu' not in markexpr or 'not gpu' in markexpr:
+    the child is started here — after collection (only when that test is among the selected items) and before any test of
+    this session has touched the GPU — and the test only collects its verdict."""
+    if not any(item.fspath.basename == 'test_rccl_gpu.py' for item in session.items):
         return
     try:
         import torch
@@ -44,7 +44,26 @@ def pytest_sessionstart(session):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_child.py'), out]
     log = open(out + '.log', 'w')
-    _RCCL_CHILD.update(proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT), out=out, log=out + '.log')
+    # its own process group, so that pytest_sessionfinish can end the launcher AND the worker it spawned
+    _RCCL_CHILD.update(proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True),
+                       out=out, log=out + '.log')
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Do not leave the child behind (-x, Ctrl-C, or a session that never reached the RCCL test)."""
+    proc = _RCCL_CHILD.get('proc')
+    if proc is None or proc.poll() is not None:
+        return
+    import signal
+    try:
+        os.killpg(proc.pid, signal.SIGTERM)  # exactly the process group started above
+        proc.wait(timeout=20)
+    except Exception:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait(timeout=10)
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope='session')

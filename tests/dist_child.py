@@ -49,11 +49,21 @@ def main(out_path):
                 same = all(torch.equal(a, b) for a, b in zip(ref, got))
                 verdict['cases'].append({'overlap_allreduce': ar, 'overlap_wgrad': wg, 'bit_identical': bool(same),
                                          'max_abs_grad_diff': float((ref[0] - got[0]).abs().max())})
+        # the N > 1 diagnostics of bench.py: replicas hold identical parameters; the exposed part of the exchange is timed
+        _, spread = tr.param_checksum()
+        tr.exchange_events = []
+        tr.step(img.to('cuda'), gts.to('cuda'))
+        torch.cuda.synchronize()
+        verdict['param_spread'] = spread
+        verdict['exchange_ms'] = [a.elapsed_time(b) for a, b in tr.exchange_events]
+        verdict['diagnostics_ok'] = bool(spread == 0.0 and len(verdict['exchange_ms']) == 1 and verdict['exchange_ms'][0] >= 0.0
+                                         and not tr._need_sync)
         # a real collective went through RCCL: sum over one rank of a device tensor, on the trainer's path
         t = torch.arange(8, device='cuda', dtype=torch.float32)
         dist.all_reduce(t)
         verdict['allreduce_identity'] = bool(torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32)))
-        verdict['ok'] = all(c['bit_identical'] for c in verdict['cases']) and verdict['allreduce_identity']
+        verdict['ok'] = (all(c['bit_identical'] for c in verdict['cases']) and verdict['allreduce_identity']
+                         and verdict['diagnostics_ok'])
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # the parent test reports it

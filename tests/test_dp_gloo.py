@@ -107,3 +107,79 @@ def test_bucketed_allreduce_equals_the_single_collective(tmp_path):
     # layer4 alone is two thirds of the buffer: it travels under the backward of layers 3..1
     sizes = {tuple(x): x[1] - x[0] for x in rg}
     assert max(sizes.values()) > 0.6 * int(r['total'])
+
+
+# ---- epoch loop under data parallelism: rank-uniform decisions (train.fit) ------------------------------------------------
+class _StubModel(torch.nn.Module):
+    """A stand-in with the module contract fit()/evaluate() use (the real model needs an MI355X): eval output [N,2,H,W]."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return torch.stack([x[:, 0], x[:, 1]], 1) * 0 + self.w
+
+
+class _StubTrainer:
+    """step() returns a loss that depends on the rank's shard, like a real data-parallel step does."""
+
+    def __init__(self, rank, train_losses):
+        self.rank, self.train_losses, self.i = rank, train_losses, 0
+
+    def step(self, batch, gts):
+        # every real step contains the gradient all-reduce: a rank that skipped ahead would pair it with a barrier
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        v = self.train_losses[self.i]
+        self.i += 1
+        return batch['img'][:, :3], torch.tensor([0., 0., 0., 0., v])
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from db_text_minimal_amd.train import fit, replica_divergence
+        model = _StubModel()
+        opt = torch.optim.SGD(model.parameters(), lr=1.0)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.5, patience=0)
+        batch = {'img': torch.zeros(1, 3, 8, 8), 'prob_map': torch.zeros(1, 8, 8), 'supervision_mask': torch.ones(1, 8, 8),
+                 'thresh_map': torch.zeros(1, 8, 8), 'text_area_map': torch.zeros(1, 8, 8)}
+        # per-epoch losses chosen so that the RANK-LOCAL best-checkpoint rule disagrees between the ranks in epochs 2 and 3
+        # (rank 0 alone would save in epoch 2, rank 1 alone in epoch 3) while the rank-mean rule saves in epochs 1 and 3
+        train = {0: [4.0, 3.0, 3.5], 1: [4.0, 5.5, 3.0]}[rank]
+        test = {0: [2.0, 1.5, 1.8], 1: [2.0, 2.7, 1.0]}[rank]
+        ep = {'i': 0}
+
+        def criterion(preds, gts):
+            return torch.tensor(test[ep['i']])
+
+        def log(rec):
+            ep['i'] += 1
+
+        hist = fit(model, criterion, opt, [batch], test_loader=[batch], epochs=3, scheduler=sched, lrs_mode='reduce',
+                   best_cp_path=os.path.join(out_dir, 'best.pth'), last_cp_path=os.path.join(out_dir, 'last.pth'), log=log,
+                   trainer=_StubTrainer(rank, train), pixel_metric=False)
+        _, spread_same = replica_divergence(torch.arange(5.))
+        _, spread_diff = replica_divergence(torch.arange(5.) + rank)
+        torch.save({'saved': [bool(h.get('saved_best')) for h in hist], 'test': [h['test_loss'] for h in hist],
+                    'train': [h['train_loss_sum'] for h in hist], 'lr': opt.param_groups[0]['lr'],
+                    'local': [h['rank_local'] for h in hist], 'spread': (spread_same, spread_diff)},
+                   os.path.join(out_dir, 'r%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_fit_takes_rank_uniform_decisions_when_shard_losses_differ(tmp_path):
+    """the best-checkpoint barrier and the plateau scheduler must see rank-uniform losses — with
+    rank-local ones the ranks pair a barrier with the next epoch's gradient all-reduce (hang) and their learning rates drift."""
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)  # a hang would hit the timeout
+    r0, r1 = (torch.load(str(tmp_path / ('r%d.pt' % r))) for r in (0, 1))
+    assert r0['saved'] == r1['saved'] == [True, False, True]
+    assert r0['test'] == r1['test'] == [2.0, pytest.approx(2.1), pytest.approx(1.4)]
+    assert r0['train'] == r1['train'] and r0['lr'] == r1['lr'] == 0.5  # one plateau (epoch 2) on the mean test loss
+    assert r0['local'] != r1['local']  # the shards really disagreed
+    assert r0['spread'] == (0.0, pytest.approx(25.0)) and (tmp_path / 'best.pth').exists() and (tmp_path / 'last.pth').exists()
