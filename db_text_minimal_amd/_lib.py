@@ -73,6 +73,7 @@ SIGNATURES = {
     'dbn_pixel_confusion': 'plppiiifpp',
     'dbn_adam_step': 'pppp' + 'l' + 'ffff' + 'i' + 'f' + 'p',
     'dbn_clock_probe': 'pip',
+    'dbn_has_experiments': '',
     'dbn_wall_clock_khz': '',
 }
 # `_t` forms: activation storage type first (0 fp32, 1 bf16, 2 fp16), see include/dbnet_hip.h
@@ -118,7 +119,7 @@ class HipLibraryError(RuntimeError):
 
 def build(verbose=False):
     """Compile csrc/*.hip for gfx950 into libdbnet_hip.so (hipcc cross-compiles without a GPU)."""
-    res = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    res = subprocess.run(['make', '-C', CSRC, '-j8'], capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])

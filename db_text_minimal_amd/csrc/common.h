@@ -6,6 +6,21 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#include <stdlib.h>
+
+// Build flavour.  The default library carries the product kernels only.  -DDBN_EXPERIMENTS adds the variants that were
+// measured and rejected (kept for the record, each with its own test): pre-split bf16 planes (AT = 3, dbn_split3), the
+// LDS-DMA fp32 weight gradient (wgrad_dma_kernel), and the environment overrides of the tile / split heuristics.
+#ifdef DBN_EXPERIMENTS
+#define DBN_HAS_EXPERIMENTS 1
+static inline int dbn_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline double dbn_env_double(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
+#else
+#define DBN_HAS_EXPERIMENTS 0
+static inline constexpr int dbn_env_int(const char*, int dflt) { return dflt; }
+static inline constexpr double dbn_env_double(const char*, double dflt) { return dflt; }
+#endif
+
 #define DBN_OK 0
 #define DBN_ERR_ARG 1
 

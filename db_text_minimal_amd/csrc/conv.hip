@@ -1,0 +1,463 @@
+// Convolution entry points of the C ABI (include/dbnet_hip.h): tile choice, image chunking, split-K, parity classes, the fused
+// conv + BatchNorm-statistics call and the pyramid conv.  The kernels live in igemm_kernel.h (instantiated by conv_f32.hip,
+// conv_x3.hip, conv_b16.hip).
+//
+// Replaces the ATen convolution calls under /root/reference/src/modules/resnet.py:70-91,231-242,
+// modules/basic.py:32-36, modules/segmentation_body.py:64-77 and modules/segmentation_head.py:24-29,64-79
+// (Conv2d / ConvTranspose2d forward and their data gradients).
+#include "igemm_common.h"
+
+long dbn_g_pixel_limit = 1L << 24;
+long dbn_g_byte_limit = 0xF0000000L;
+long dbn_g_elem_limit = 1L << 32;
+
+namespace {
+
+// Merge the per-tile BatchNorm partials written by the igemm epilogue (Chan et al. parallel variance, fp64)
+// into scale/shift, saved mean/rstd and the running statistics.  One 256-thread block per channel.
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = dbn_wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+__global__ void bn_finalize_tiles_kernel(const float* __restrict__ stats, int rows, int C, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float eps, float momentum, float* __restrict__ run_mean,
+                                         float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    const float* pv = stats + (0L * C + c) * rows;
+    const float* s1 = stats + (1L * C + c) * rows;
+    const float* s2 = stats + (2L * C + c) * rows;
+    const float* cn = stats + 3L * C * rows;
+    // one pass: shift every tile's sums from its own pivot to the first tile's pivot P0 (exact algebra, fp64):
+    //   sum (x-P0) = s1 + n d,   sum (x-P0)^2 = s2 + 2 d s1 + n d^2,   d = pivot - P0
+    const double p0 = (double)pv[0];
+    double n = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int t = threadIdx.x; t < rows; t += blockDim.x) {
+        const double nt = (double)cn[t], d = (double)pv[t] - p0, t1 = (double)s1[t];
+        n += nt;
+        a1 += t1 + nt * d;
+        a2 += (double)s2[t] + d * (2.0 * t1 + nt * d);
+    }
+    n = block_sum_d(n, red);
+    a1 = block_sum_d(a1, red);
+    a2 = block_sum_d(a2, red);
+    const double m1 = a1 / n;
+    const double mean = p0 + m1;
+    const double m2 = a2 - a1 * m1;
+    if (threadIdx.x != 0) return;
+    double var = m2 / n;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = fmaf(-meanf, sc, beta[c]);
+    mean_out[c] = meanf;
+    rstd_out[c] = rstd;
+    if (run_mean) {
+        const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * meanf;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// dst = [dst +] bias + sum over the split-K slabs, fixed order
+template <int AT>
+__global__ void splitk_sum_kernel(const float* __restrict__ slab, int splits, long total4, int Cd, const float* __restrict__ bias,
+                                  int accumulate, void* __restrict__ dst) {
+    const int c4n = Cd >> 2;
+    const long stride4 = total4 + 272;  // slabs are 1088 floats apart beyond their size (HBM channel rotation, see wgrad_slab_stride)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
+        f32x4 v = src[0];
+        for (int z = 1; z < splits; ++z) v += src[(long)z * stride4];
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + 4 * (int)(i % c4n));
+        if (accumulate) v += dbn_ld4<AT>(dst, i);
+        dbn_st4<AT>(dst, i, v);
+    }
+}
+
+// ns: matrix math (0 exact fp32, 1 one 16-bit plane, 3 bf16x3); at: activation storage (0 fp32, 1 bf16, 2 fp16; 16-bit storage needs ns 1)
+int launch_igemm(IgemmParams& p, int cfg, int mode, int ns, hipStream_t st, int at) {
+    if (at == 1 || at == 2) return ns == 1 ? dbn_launch_igemm_b16(p, cfg, mode, at, st) : DBN_ERR_ARG;
+    if (at == 3) return dbn_launch_igemm_x(p, cfg, mode, ns, at, st);
+    if (ns == 0) return dbn_launch_igemm_f32(p, cfg, mode, st);
+    return dbn_launch_igemm_x(p, cfg, mode, ns, 0, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dbn_has_experiments(void) { return DBN_HAS_EXPERIMENTS; }
+
+
+// Tile configuration dbn_igemm_f32 picks for an M x Cd output (tile_hint 0):
+// 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64 — the largest tile that still yields
+// >= ~2 workgroups per CU on 256 CUs.
+int dbn_igemm_tile_config(int M, int Cd) {
+    // Workgroups are handed to the 256 CUs as they free up, so a launch lasts about
+    // ceil(blocks/256) tiles per CU; pick the tile that minimises tiles-per-CU x tile area / efficiency
+    // (efficiency = measured steady-state MFMA utilisation of each variant).
+    // Round 2 re-measured the variants alone on the backbone's four stage shapes (tools/tile_probe.py): with the two-tile prefetch
+    // the 64x64 tile is the fastest at 80x80x128 and 40x40x256 (115 / 103 TFLOP/s against 109 / 97 for the choices below).  In
+    // the two-stream step that does not carry over: efficiencies {0.89, 0.85, 0.845, 0.83} everywhere gave +0.5 % (within noise)
+    // with the dominant kernel's in-step rate down from 0.60 to 0.56, on the layer3/4-sized grids only -0.6 % — small tiles lose
+    // more to the co-resident weight-gradient workgroups.  The table stays (DBN_TILE_EFF_R2=1 selects the re-measured one).
+    const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 64, 64};
+    static const bool r2_eff = dbn_env_int("DBN_TILE_EFF_R2", 0) != 0;
+    const double eff_r1[4] = {0.89, 0.83, 0.80, 0.72}, eff_r2[4] = {0.89, 0.85, 0.845, 0.83};
+    const double* eff = r2_eff ? eff_r2 : eff_r1;
+    int best = 4;
+    double best_t = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        if (Cd % bn[c]) continue;
+        const long blocks = (long)dbn_ceil_div(M, bm[c]) * (Cd / bn[c]);
+        const long per_cu = (blocks + 255) / 256;
+        double t = (double)per_cu * bm[c] * bn[c] / eff[c];
+        if (blocks < 512) t *= 1.0 + 0.25 * (512 - blocks) / 512.0;  // too few workgroups to hide latency
+        if (t < best_t) {
+            best_t = t;
+            best = c + 1;
+        }
+    }
+    return best;
+}
+
+static int g_patch_enabled = 1;
+static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
+int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
+    const int old = g_patch_enabled;
+    g_patch_enabled = on != 0;
+    return old;
+}
+// pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
+// partial rows of a launch are the same N*H*W/128 either way); kmode: kernel MODE
+static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int stride, int pad, int Hs, int Ws, int Hd, int Wd, int Cs,
+                           int ksplit) {
+    return g_patch_enabled && (kmode == 0 || kmode == 1) && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && R == 3 && S == 3 && stride == 1 &&
+           pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 && Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
+}
+static int patch_cfg(int cfg) { return (cfg == 1 && g_patch_bn64) ? 3 : cfg; }
+
+// Tile configuration of a dbn_igemm / dbn_conv_bn call (`mode`, `stride` as the caller passes them).  The convolutions that can take
+// the pixel-patch kernel get a 128-row tile whatever the generic heuristic says.
+static int resolve_cfg(int M_total, int Cd, int tile_hint, int at = 0, int ns = 0, int mode = 0, int R = 0, int S = 0, int stride = 1,
+                       int pad = 0, int Hs = 0, int Ws = 0, int Hd = 0, int Wd = 0, int Cs = 0, int ksplit = 1) {
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
+    if (cfg == 1 && Cd % 128 != 0) cfg = 3;
+    if (tile_hint == 0 && !(mode == 1 && stride > 1) && patch_eligible(mode, ns, at, 3, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) cfg = 3;
+    return cfg;
+}
+
+// What one (unchunked) dbn_igemm_t call launches: tile configuration (1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64) + 16 if the
+// pixel-patch kernel is used — i.e. the template arguments <BM,BN,WM,WN,MODE,NS,AT,PATCH> of its rocprofv3 symbol.
+// kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid.
+int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,
+                            int pad, int tile_hint, int ksplit) {
+    const int cfg = resolve_cfg(N * Hd * Wd, Cd, tile_hint, at, ns, kmode >= 2 ? 1 : kmode, R, S, kmode == 2 && stride == 1 ? 2 : stride, pad, Hs,
+                                Ws, Hd, Wd, Cs, ksplit);
+    if (patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) return patch_cfg(cfg) + 16;
+    return cfg;
+}
+
+static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st, int at = 0) {
+    // tile choice from the total row count (for parity classes: all classes together)
+    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
+    if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
+    p.patch = patch_eligible(kmode, ns, at, cfg, p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hdf, p.Wdf, p.Cs, p.ksplit);
+    // 128 x 64 tiles also where the generic loop takes 128 x 128: K is short (two to eight channel blocks), so twice the workgroups
+    // hide the prologue / epilogue better than the wider tile saves weight traffic (measured: 120.8 GFLOP launch 509 -> ~270 us;
+    // step +1-3 %); the BatchNorm partial rows depend on BM only.  DBN_PATCH_BN64=0 keeps the generic choice.
+    if (p.patch) cfg = patch_cfg(cfg);
+    return launch_igemm(p, cfg, kmode, ns, st, at);
+}
+
+// bytes per element of the destination of a conv (at = 3: pre-split bf16 planes in, fp32 out) and planes of its source
+static inline int dst_esize(int at) { return (at == 0 || at == 3) ? 4 : 2; }
+static inline int src_planes(int at) { return at == 3 ? 3 : 1; }
+
+static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                         int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
+                         hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
+                         long plane_bytes) {
+    IgemmParams p;
+    p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
+    p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
+    p.stats = stats; p.stat_rows = stat_rows; p.stat_row0 = stat_row0; p.launch_rows = 0;
+    p.ksplit = 1; p.kt_per = 0;
+    // (at = 3: planes 1 and 2 lie plane_bytes and 2*plane_bytes behind the image range of plane 0 this launch covers)
+    p.plane_bytes = (unsigned)plane_bytes;
+    p.src_bytes = (unsigned)((long)N * Hs * Ws * Cs * dbn_esize(at) + (src_planes(at) - 1) * plane_bytes);
+    if (!(mode == 1 && stride > 1)) {
+        p.ncls = 1;
+        if (ksplit <= 1) {
+            const int rc = igemm_dispatch(p, mode, ns, cfg, st, at);
+            *rows_out = p.launch_rows;
+            return rc;
+        }
+        // split-K: slabs of partial sums, then a fixed-order reduction that also applies bias / accumulate
+        const int KT = (R * S * Cs + 15) / 16;
+        DBN_REQUIRE(slab && !stats && Cs % 16 == 0 && ksplit <= KT && ksplit <= 64);
+        p.kt_per = dbn_ceil_div(KT, ksplit);
+        p.ksplit = dbn_ceil_div(KT, p.kt_per);
+        p.dst = slab; p.bias = nullptr; p.accumulate = 0;
+        const int rc = igemm_dispatch(p, mode, ns, cfg, st, at);
+        *rows_out = p.launch_rows;
+        if (rc) return rc;
+        const long total4 = (long)N * Hd * Wd * Cd / 4;
+        DBN_DISPATCH_AT(at == 3 ? 0 : at, hipLaunchKernelGGL(splitk_sum_kernel<AT>, dim3(dbn_grid(total4)), dim3(256), 0, st, slab, p.ksplit,
+                                                             total4, Cd, bias, accumulate, dst));
+        return dbn_status();
+    }
+    DBN_REQUIRE(ksplit <= 1);
+    // stride-f data gradient / transposed conv: one problem per output parity class
+    p.ncls = stride * stride;
+    long off = 0;
+    int covered = 0;
+    for (int c = 0; c < p.ncls; ++c) {
+        const IgemmClass q = class_geom(c, stride, R, S, pad, N, Hd, Wd, Cs);
+        p.wpk_off[c] = (int)off;
+        if (q.K > 0 && q.M > 0) ++covered;
+        off += panel_floats(q.K, Cd, ns);
+    }
+    DBN_REQUIRE(off < (1L << 31));
+    DBN_REQUIRE(covered == p.ncls || !bias);  // a bias would have to reach the tap-less pixels too
+    if (covered < p.ncls && !accumulate) {  // some output pixels receive no tap: they are zero
+        if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * dst_esize(at), st) != hipSuccess) return dbn_status();
+        p.accumulate = 1;
+    }
+    *rows_out = 0;
+    if (covered == 0) return DBN_OK;
+    const int rc = igemm_dispatch(p, 2, ns, cfg, st, at);
+    *rows_out = p.launch_rows;
+    return rc;
+}
+
+// Rows of BatchNorm partials ONE launch over n images produces
+static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg) {
+    const int bm_of[5] = {0, 128, 256, 128, 64};
+    if (!(mode == 1 && stride > 1)) return dbn_ceil_div((long)n * Hd * Wd, bm_of[cfg]);
+    int rows = 0;
+    for (int c = 0; c < stride * stride; ++c) {  // BN follows only tap-complete transposed convs: every class has pixels
+        const int ph = c / stride, pw = c % stride;
+        const int Hc = ph < Hd ? (Hd - ph + stride - 1) / stride : 0, Wc = pw < Wd ? (Wd - pw + stride - 1) / stride : 0;
+        if (Hc > 0 && Wc > 0) rows += dbn_ceil_div((long)n * Hc * Wc, bm_of[cfg]);
+    }
+    return rows;
+}
+
+static int igemm_run(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                     int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0) {
+    DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
+    // 16-bit storage / pre-split planes: 8-channel pieces of 16-channel blocks
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0) || (at == 3 && ns == 3 && Cs % 16 == 0));
+    DBN_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && R > 0 && S > 0 && pad >= 0);
+    DBN_REQUIRE(Cs % 4 == 0 && Cd % 64 == 0 && (mode == 0 || mode == 1));
+    DBN_REQUIRE(stride == 1 || stride == 2 || stride == 4 || stride == 8 || (mode == 0 && stride >= 1));
+    DBN_REQUIRE(tile_hint >= 0 && tile_hint <= 4);
+    hipStream_t st = (hipStream_t)stream;
+    const int es = dbn_esize(at), des = dst_esize(at);
+    const long plane_bytes = at == 3 ? (long)N * Hs * Ws * Cs * 2 : 0;  // the planes of the WHOLE tensor are this far apart
+    DBN_REQUIRE(3 * plane_bytes < dbn_g_byte_limit);
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * es, (long)Hd * Wd * Cd);
+    DBN_REQUIRE(nmax >= 1);               // one image must fit the kernel's index ranges
+    DBN_REQUIRE(nmax >= N || ksplit <= 1);  // split-K is for small outputs only
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint, at, ns, mode, R, S, stride, pad, Hs, Ws,
+                                Hd, Wd, Cs, ksplit);
+    int row0 = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        int rows = 0;
+        const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
+                                     reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
+                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes);
+        if (rc) return rc;
+        row0 += rows;
+    }
+    return DBN_OK;
+}
+
+// General form.  at: activation storage type of src / dst (DBN_AT_*; 16-bit storage needs ns = 1 and Cs % 16 == 0, panels from
+// dbn_pack_weights_t with kind 1 (bf16) / 2 (fp16)).  ns: matrix math (0, 1, 3).  ksplit > 1: split-K with `slab` scratch.
+int dbn_igemm_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ksplit, float* slab,
+                void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr,
+                     ksplit < 1 ? 1 : ksplit, slab, 0, at);
+}
+
+int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                  int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, 0, stream);
+}
+
+// Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32); follows igemm_run's chunking
+static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint, int at, int ns, int R,
+                        int S, int pad) {
+    const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * dbn_esize(at), (long)Hd * Wd * Cd);
+    if (nmax < 1) return 0;
+    const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint, at, ns, mode, R, S, stride, pad, Hs, Ws,
+                                Hd, Wd, Cs, 1);
+    int rows = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) rows += bn_tile_rows_one(std::min(nmax, N - n0), Hd, Wd, mode, stride, cfg);
+    return rows;
+}
+
+// floats of scratch for the fused conv + BatchNorm-statistics call
+long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) {
+    // worst case over the tile configurations and the image chunking (one launch per image: every launch rounds up)
+    long worst = 0;
+    for (int t = 1; t <= 4; ++t) {
+        const long r = (long)N * bn_tile_rows_one(1, Hd, Wd, mode, stride, t);
+        worst = r > worst ? r : worst;
+    }
+    return (3L * Cd + 1) * worst;
+}
+
+// Convolution (dbn_igemm_f32 / _bf16s contract; ns = 0, 1, 3) whose epilogue also accumulates the train-mode
+// BatchNorm statistics of its output, followed by the finalize kernel: replaces conv -> separate statistics pass.
+// Outputs like dbn_bn_train_stats.  ws: dbn_conv_bn_ws_floats(...) floats.
+int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                  int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                  const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                  float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
+    DBN_REQUIRE(rows > 0);
+    // (16-bit storage: the statistics are those of the fp32 accumulators, i.e. of the values BEFORE they are rounded for storage)
+    const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,
+                             1, nullptr, rows, at);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
+                       beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
+}
+
+int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
+                    int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                    float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_conv_bn_t(0, src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, gamma, beta,
+                         eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
+}
+
+// Same contract as dbn_igemm_f32 with the products evaluated on the bf16 matrix pipe: ns = 3 fp32-accurate
+// three-way operand split (6 bf16 MFMAs per product group), ns = 1 plain bf16 operands.  Panels from
+// dbn_pack_weights_bf16s with the same (mode, stride, ns).
+int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                    int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                    void* stream) {
+    DBN_REQUIRE(ns == 1 || ns == 3);
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream);
+}
+
+// Split-K plan for a conv whose output grid alone cannot fill the chip (few pixels x few channels, long reduction —
+// the coarse FPN levels' data gradients): number of K splits (1 = none) for M rows, Cd channels, K = R*S*Cs.
+int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) {
+    if (Cs % 16 != 0) return 1;
+    const int cfg0 = dbn_igemm_tile_config(M, Cd);
+    const int cfg = (cfg0 == 1 && Cd % 128 != 0) ? 3 : cfg0;
+    static const int bm_of[5] = {0, 128, 256, 128, 64}, bn_of[5] = {0, 128, 64, 64, 64};
+    const long tiles = (long)dbn_ceil_div(M, bm_of[cfg]) * (Cd / bn_of[cfg]);
+    const int KT = (K + 15) / 16;
+    static const int max_tiles = dbn_env_int("DBN_SPLITK_MAX_TILES", 256);
+    if (tiles > max_tiles) return 1;
+    long sk = 1024 / tiles;      // about four workgroups per CU
+    if (sk > KT / 32) sk = KT / 32;  // at least 32 k-tiles per split
+    if (sk > 64) sk = 64;
+    return sk < 2 ? 1 : (int)sk;
+}
+
+// dbn_igemm_f32 with the reduction split `ksplit` ways (mode 0, or mode 1 with stride 1; Cs % 16 == 0).
+// slab: ksplit * N*Hd*Wd*Cd floats of scratch.  Bit-reproducible (fixed summation order).
+int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                         int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
+                         int ksplit, float* slab, void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream,
+                     nullptr, ksplit, slab);
+}
+
+int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
+
+// ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
+static int pyramid_chunk(int N, int H, int W, int Cs, int Cd, int at = 0) {
+    return chunk_images(N, (long)H * W, (long)H * W * Cs * dbn_esize(at), (long)H * W * Cd);
+}
+static int pyramid_rows_one(int n, int H, int W) { return 64 * dbn_ceil_div((long)n * (H >> 3) * (W >> 3), 128); }
+
+long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * N * pyramid_rows_one(1, H, W); }
+
+int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,
+                       const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
+                       int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                       float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
+    DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1) || (at == 3 && ns == 3));
+    const int es = dbn_esize(at), des = dst_esize(at);
+    DBN_REQUIRE(N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && Cs % 16 == 0 && Cd % 128 == 0);
+    DBN_REQUIRE(tile_hint == 0 || tile_hint == 1);
+    const bool bn = gamma != nullptr;
+    DBN_REQUIRE(!bn || (beta && scale && shift && save_mean && save_rstd && ws));
+    const int nmax = pyramid_chunk(N, H, W, Cs, Cd, at);  // images per launch (24-bit pixel indices, 32-bit offsets)
+    DBN_REQUIRE(nmax >= 1);
+    int rows_total = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) rows_total += pyramid_rows_one(std::min(nmax, N - n0), H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const char* srcs[4] = {(const char*)s0, (const char*)s1, (const char*)s2, (const char*)s3};
+    const float* wpks[4] = {w0, w1, w2, w3};
+    int row0 = 0;
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        IgemmParams p;
+        for (int g = 0; g < 4; ++g) {
+            p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs * es;
+            p.seg_wpk[g] = wpks[g];
+            const long pl = at == 3 ? (long)N * (H >> g) * (W >> g) * Cs * 2 : 0;  // plane distance of level g (whole tensor)
+            p.seg_plane_bytes[g] = (unsigned)pl;
+            p.seg_bytes[g] = (unsigned)((long)n * (H >> g) * (W >> g) * Cs * es + 2 * pl);
+        }
+        p.plane_bytes = p.seg_plane_bytes[0];
+        p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * des;
+        p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
+        p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
+        p.stats = bn ? ws : nullptr;
+        p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
+        p.ksplit = 1; p.kt_per = 0; p.patch = 0;
+        p.src_bytes = p.seg_bytes[0];
+        const int rc = launch_igemm(p, 1, 3, ns, st, at);
+        if (rc) return rc;
+        row0 += p.launch_rows;
+    }
+    if (!bn) return DBN_OK;
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows_total >= 2048 ? 1024 : 256), 0, st, ws, rows_total, Cd, gamma,
+                       beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
+}
+
+int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,
+                         const float* w2, const float* w3, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                         int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                         float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_pyramid_conv_t(0, s0, s1, s2, s3, w0, w1, w2, w3, bias, dst, N, H, W, Cs, Cd, tile_hint, ns, gamma, beta, eps, momentum,
+                              run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
+}
+
+// Test hook: lower the per-launch index ranges so that the image chunking runs at small sizes (0 restores a default).
+int dbn_set_index_limits(long pixel_rows, long bytes, long elems) {
+    dbn_g_pixel_limit = pixel_rows > 0 ? pixel_rows : (1L << 24);
+    dbn_g_byte_limit = bytes > 0 ? bytes : 0xF0000000L;
+    dbn_g_elem_limit = elems > 0 ? elems : (1L << 32);
+    return DBN_OK;
+}
+
+}  // extern "C"

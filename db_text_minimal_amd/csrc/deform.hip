@@ -266,11 +266,7 @@ int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* of
     const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
     DBN_REQUIRE(dcols && x && offset && dx && doffset && dims_ok(d));
     hipStream_t st = (hipStream_t)stream;
-    static int tiled = -1;
-    if (tiled < 0) {
-        const char* e = getenv("DBN_COL2IM_TILED");
-        tiled = e ? atoi(e) : 1;
-    }
+    static const int tiled = dbn_env_int("DBN_COL2IM_TILED", 1);  // (0: per-sample scatter; -DDBN_EXPERIMENTS builds only)
     const int PD = (COL2IM_T - 1) * stride + R + 2 * COL2IM_HALO;  // patch edge; R == S for every DCN layer of the reference
     const size_t lds = (size_t)PD * PD * COL2IM_CC * sizeof(float);
     if (tiled && R == S && lds <= 64 * 1024) {

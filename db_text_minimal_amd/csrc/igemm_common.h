@@ -1,0 +1,211 @@
+// Shared definitions of the implicit-GEMM translation units (conv_*.hip, conv.hip, wgrad*.hip, pack.hip).
+//
+//
+//   dbn_igemm_f32 / dbn_igemm_bf16s   forward conv (gather mode 0) and data-gradient / transposed conv
+//                                     (gather mode 1; stride 2 as four output-parity problems) over NHWC
+//   dbn_wgrad_f32 / dbn_wgrad_bf16s   weight gradient: split-K over output pixels into fp32 slabs
+//                                     + deterministic slab reduction scattered into OIHW gradients
+//   dbn_pack_weights[_bf16s]          OIHW -> GEMM panels
+//
+// Replaces the ATen convolution calls under /root/reference/src/modules/resnet.py:70-91,231-242,
+// modules/basic.py:32-36, modules/segmentation_body.py:64-77 and modules/segmentation_head.py:24-29,64-79
+// (Conv2d / ConvTranspose2d forward and their autograd backward).
+//
+// Matrix instruction (template parameter NS):
+//   NS = 0  v_mfma_f32_32x32x2_f32 — exact fp32 products, 64 FLOP/clk/SIMD, 157 TFLOP/s chip peak (default)
+//   NS = 3  v_mfma_f32_32x32x16_bf16 on an exact three-way bf16 split of every fp32 operand, six partial
+//           products, fp32 accumulate: fp32-accurate at 6/16 of the fp32-MFMA cost
+//   NS = 1  the same with operands rounded to bf16 (BASELINE configs[2] compute mode)
+//
+// Tiling: a workgroup of 4 waves owns a BM x BN output tile, each wave a (BM/WM) x (BN/WN)
+// sub-tile of 32x32 f32 accumulators.  K is walked in steps of 16; the A panel (im2col gather, 16 B per lane
+// = 4 consecutive input channels of one tap, branch-free buffer loads that return 0 out of range) and the B
+// panel (pre-packed weights) are staged through a double-buffered LDS image laid out [k/4][row][4 f32]
+// (NS = 0) or [split][k/8][row][8 bf16] (NS > 0) so that every lane fetches the k-values of its MFMAs with
+// conflict-free ds_read_b128.
+#pragma once
+#include "common.h"
+#include <type_traits>
+#include <utility>
+#include <stdlib.h>
+#include <algorithm>
+
+// Geometry of one GEMM problem of a launch.  A stride-f data gradient / transposed conv (f = 2, 4, 8) is split into
+// f*f output-parity classes — each a dense stride-1 transposed conv over 1/f^2 of the output pixels with only the
+// taps that reach it — so no zero taps are multiplied.  Classes are derived from the class index by class_geom()
+// on both host and device; the launch carries only per-class tile ranges and weight-panel offsets.
+struct IgemmClass {
+    int Hd, Wd;        // output sub-grid of this problem
+    int M, K, KT;      // rows, reduction length, k-tiles
+    int R, S;          // taps of this problem
+    int pad_h, pad_w;  // MODE 0: conv padding; MODE 1/2: hs = hd + pad_h - r
+    int oh0, ow0;      // MODE 2: dst pixel = (f*hd + oh0, f*wd + ow0)
+};
+
+constexpr int MAX_CLASSES = 64;
+
+__host__ __device__ inline int taps_of_class(int R, int ph, int f) { return ph < R ? (R - ph + f - 1) / f : 0; }
+
+// class c = ph*f + pw of a transposed conv (R x S taps, stride f, padding pad) onto an Hdf x Wdf output
+__host__ __device__ inline IgemmClass class_geom(int c, int f, int R, int S, int pad, int N, int Hdf, int Wdf, int Cs) {
+    IgemmClass q;
+    const int ph = c / f, pw = c - ph * f;
+    q.R = taps_of_class(R, ph, f);
+    q.S = taps_of_class(S, pw, f);
+    q.oh0 = (((ph - pad) % f) + f) % f;
+    q.ow0 = (((pw - pad) % f) + f) % f;
+    q.Hd = q.oh0 < Hdf ? (Hdf - q.oh0 + f - 1) / f : 0;
+    q.Wd = q.ow0 < Wdf ? (Wdf - q.ow0 + f - 1) / f : 0;
+    q.pad_h = (q.oh0 + pad - ph) / f;  // exact: oh0 + pad - ph is a multiple of f
+    q.pad_w = (q.ow0 + pad - pw) / f;
+    q.M = N * q.Hd * q.Wd;
+    q.K = q.R * q.S * Cs;
+    q.KT = (q.K + 15) / 16;
+    return q;
+}
+
+struct IgemmParams {
+    const void* src;    // [N,Hs,Ws,Cs], activation type AT
+    const float* wpk;   // per problem: [KT*4][Cd][4]
+    const float* bias;  // [Cd] or null
+    void* dst;          // [N,Hdf,Wdf,Cd], activation type AT (split-K: fp32 slabs)
+    int N, Hs, Ws, Cs, Cd, Hdf, Wdf, R, S, stride, pad, accumulate, ncls;
+    int stat_rows;      // rows of the partials array (all M-tiles of the call; a call over many images runs as several launches)
+    int stat_row0;      // first row this launch writes
+    float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
+    unsigned src_bytes;
+    unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
+    // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)
+    int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
+    // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
+    int ksplit, kt_per;
+    int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
+    int patch;          // host only: use the pixel-patch form (3x3, stride 1; see igemm_dispatch)
+    // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
+    const void* seg_src[4];
+    const float* seg_wpk[4];
+    unsigned seg_bytes[4];
+    unsigned seg_plane_bytes[4];  // AT = 3
+};
+
+namespace {
+
+constexpr unsigned OOB_OFFSET = 0xF8000000u;  // beyond any tensor (< 0xF0000000 bytes): buffer loads return 0
+
+__device__ __forceinline__ f32x4 buffer_load_f32x4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// q = p / d, r = p % d for 0 <= p < 2^24 using a float reciprocal (exact after one correction step)
+__device__ __forceinline__ void divmod24(int p, int d, float rd, int& q, int& r) {
+    q = (int)((float)p * rd);
+    r = p - q * d;
+    if (r < 0) {
+        r += d;
+        --q;
+    } else if (r >= d) {
+        r -= d;
+        ++q;
+    }
+}
+
+
+// ---- split-bf16 matrix math (NS > 0) ------------------------------------------------------------
+// NS = 1: operands rounded to bf16 (bf16 MFMA, fp32 accumulate).
+// NS = 3: every fp32 operand is split exactly into three bf16 terms (a = a0 + a1 + a2, 24 mantissa
+//         bits) and the product is evaluated as a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 on the bf16
+//         matrix pipe with fp32 accumulation: fp32-accurate (mean rel. error 1.3e-7 at K=2304, lower than
+//         a plain fp32 fmaf chain) at 6/16 of the fp32-MFMA cost.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bf16_bits_rne(float x) {  // round-to-nearest-even fp32 -> bf16 bit pattern
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+
+// four fp32 values -> NS x (four bf16 packed in 8 bytes).  The casts compile to v_cvt_pk_bf16_f32
+// (round-to-nearest-even); the residual a - bf16(a) is exact in fp32.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[NS > 0 ? NS : 1]) {
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bf16x2 lo = {(__bf16)r[0], (__bf16)r[1]};
+        const bf16x2 hi = {(__bf16)r[2], (__bf16)r[3]};
+        const unsigned ulo = __builtin_bit_cast(unsigned, lo), uhi = __builtin_bit_cast(unsigned, hi);
+        out[s] = u32x2{ulo, uhi};
+        if (s + 1 < NS) {
+            r[0] -= __builtin_bit_cast(float, ulo << 16);
+            r[1] -= __builtin_bit_cast(float, ulo & 0xFFFF0000u);
+            r[2] -= __builtin_bit_cast(float, uhi << 16);
+            r[3] -= __builtin_bit_cast(float, uhi & 0xFFFF0000u);
+        }
+    }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NS, int MI, int NI, int F16 = 0>
+__device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][MI], const bf16x8 (&bf)[NS > 0 ? NS : 1][NI],
+                                           f32x16 (&acc)[MI][NI]) {
+    if constexpr (F16) {  // fp16 operands (inference, BASELINE configs[4]): the same 16-byte fragments, v_mfma_f32_32x32x16_f16
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0][a]), __builtin_bit_cast(f16x8, bf[0][b]),
+                                                                   acc[a][b], 0, 0, 0);
+        return;
+    }
+    // smallest terms first
+    constexpr int NPROD = NS == 3 ? 6 : 1;
+    constexpr int pi[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int pj[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < NPROD; ++t) {
+        const int i = NS == 3 ? pi[t] : 0, j = NS == 3 ? pj[t] : 0;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][a], bf[j][b], acc[a][b], 0, 0, 0);
+    }
+}
+
+// panel size in floats of one problem: fp32 panels Kpad*Cd; split-bf16 panels Kpad*Cd*ns/2
+inline long panel_floats(int K, int Cd, int ns) {
+    const long kp = ((K + 15) / 16) * 16;
+    return ns == 0 ? kp * Cd : kp * Cd * ns / 2;
+}
+
+}  // namespace
+
+// ---- image chunking ---------------------------------------------------------------------------------------------
+// The kernels index pixels with 24-bit reciprocal divisions and address tensors through raw buffer descriptors with 32-bit
+// byte offsets.  Images are independent in every convolution, so a call whose tensors exceed those ranges runs as several
+// launches over consecutive image ranges (same tile configuration; BatchNorm partial rows simply continue).
+// (defined in conv.hip; dbn_set_index_limits lowers them for the tests)
+extern long dbn_g_pixel_limit;  // rows per launch (divmod24)
+extern long dbn_g_byte_limit;   // bytes addressable through one buffer descriptor
+extern long dbn_g_elem_limit;   // 32-bit element offsets of the epilogue
+
+static inline int chunk_images(int N, long px_rows, long src_bytes_per_image, long dst_elems_per_image, long src2_bytes_per_image = 0) {
+    long n = N;
+    auto fit = [&](long per_image, long limit) {
+        if (per_image > 0 && per_image * n >= limit) n = (limit - 1) / per_image;
+    };
+    fit(px_rows, dbn_g_pixel_limit);
+    fit(src_bytes_per_image, dbn_g_byte_limit);
+    fit(src2_bytes_per_image, dbn_g_byte_limit);
+    fit(dst_elems_per_image, dbn_g_elem_limit);
+    return (int)n;  // 0: a single image does not fit
+}
+
+// launchers of the kernel translation units.  cfg: 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64; mode: kernel MODE 0..3
+int dbn_launch_igemm_f32(IgemmParams& p, int cfg, int mode, hipStream_t st);                    // conv_f32.hip: exact fp32 (ns 0, at 0)
+int dbn_launch_igemm_x(IgemmParams& p, int cfg, int mode, int ns, int at, hipStream_t st);      // conv_x3.hip: fp32 tensors, bf16 math
+int dbn_launch_igemm_b16(IgemmParams& p, int cfg, int mode, int at, hipStream_t st);            // conv_b16.hip: bf16 / fp16 storage

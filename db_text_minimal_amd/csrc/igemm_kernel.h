@@ -1,0 +1,1075 @@
+// The implicit-GEMM convolution kernel and its launcher; instantiated per conv-math family by
+// conv_f32.hip / conv_x3.hip / conv_b16.hip.
+#pragma once
+#include "igemm_common.h"
+
+namespace {
+
+// MODE 0: hs = hd*stride - pad + r (forward conv, stride 1 or 2)
+// MODE 1: hs = hd + pad - r        (stride-1 data gradient)
+// MODE 2: like MODE 1 per output-parity class, dst pixel = (f*hd+oh0, f*wd+ow0) (stride-f data
+//         gradient / ConvTranspose2d forward, f = 2, 4, 8)
+// MODE 3: pyramid conv: dst = sum over levels g = 0..3 of the transposed conv (k = 2^g + 2, stride 2^g, pad 1) of
+//         seg_src[g] — a 3x3 conv over the concatenation of four nearest-upsampled maps without the
+//         concatenation.  One workgroup owns a tile of one pixel class mod 8 and walks the four levels' taps
+//         in one accumulator: K = Cs * (9 + 4 + {1,2,4} + {1,2,4}) instead of 36 * Cs.
+// The gather is branch-free: an invalid tap (padding, M or K tail) gets an out-of-range buffer
+// offset, for which the hardware returns zeros.
+// Register budget: the 128x128 fp32 tile needs 88 VGPR + 64 AGPR = 3 waves per SIMD.  Asking for 4 waves
+// (amdgpu_waves_per_eu) makes the compiler fit it into the unified 128 registers; with a prefetch distance of one k-tile
+// that cost 4 spills and gave +1.6 % on large launches, with the second register set of the two-tile prefetch it spills 56
+// and loses 35 % — the experiment (round 1-2: DBN_IGEMM_W4) was removed in round 3.
+// pixel-patch kernels with three planes: two waves per SIMD (<= 256 registers; the fully unrolled nine stages had taken 257)
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : 1, 8)))
+
+// AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
+// of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
+// stored format), the accumulators are rounded to the storage type on the way out.
+// AT = 3 (NS = 3): src is the PRE-SPLIT form of an fp32 tensor — three bf16 planes [3][N,H,W,C] with a0 + a1 + a2 == a exactly
+// (dbn_split3) — gathered the same way (3 x 2 pieces per row and k-tile, no conversion: splitting at staging time redid the
+// split for every one of the 9 taps that re-reads an element and made the bf16x3 kernels VALU-bound); dst is fp32.
+// PATCH (3x3, stride 1, pad 1, 16-bit matrix math; Hd % 8 == 0, Wd % 16 == 0, Cs % 32 == 0): the M tile is an 8 x 16 PIXEL PATCH
+// and the A operand is not gathered per tap at all — see the main loop.
+template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false>
+__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) void igemm_f32_kernel(const IgemmParams p) {
+    static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
+    static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int ES = AT == 0 ? 4 : 2;            // bytes per stored source element
+    constexpr bool DST_F32 = AT == 0 || AT == 3;
+    constexpr int NP = AT == 3 ? 3 : 1;            // 16-bit planes of the source
+    constexpr int A_SH = AT == 0 ? 2 : 1;          // pieces per row and plane = 1 << A_SH (4 x 4 fp32 channels, or 2 x 8 16-bit channels)
+    constexpr int A_CH = AT == 0 ? 4 : 8;          // channels per 16-byte piece
+    constexpr int A_PIECES = (BM << A_SH) * NP;    // 16-byte pieces of the A panel per k-tile
+    constexpr int A_LD = (A_PIECES + NT - 1) / NT;  // gathers per thread per k-tile
+    constexpr bool A_FULL = A_PIECES % NT == 0;
+    // LDS image in 16-byte units.  NS == 0: [k/4][row][4 f32], chunk stride +2 keeps ds_write_b128 conflict-free.
+    // NS > 0: per split [k/8][row][8 bf16], row stride +4 (== 64 B mod 128) keeps the ds_write_b64 conflict-free.
+    constexpr int AS = NS == 0 ? BM + 2 : BM + 4, BS = NS == 0 ? BN + 2 : BN + 4;
+    constexpr int A_IMG = NS == 0 ? 4 * AS : NS * 2 * AS, B_IMG = NS == 0 ? 4 * BS : NS * 2 * BS;
+    constexpr int B_PIECES = NS == 0 ? 4 * BN : NS * 2 * BN;  // 16-byte pieces of the weight panel per k-tile
+    constexpr int B_LD = (B_PIECES + NT - 1) / NT;
+    constexpr bool B_FULL = B_PIECES % NT == 0;  // every thread owns B_LD pieces
+    // K advances 16 per UNIT; KU units share one barrier (1 or 4).  Measured on the 16-bit storage paths, whose single MFMA per
+    // accumulator and unit (32 cycles) is far shorter than a unit's staging / address walk: KU = 4 is SLOWER (1116 vs 1199 images/s
+    // in native bf16; 51 KB of LDS and a second register set of 4 units cost occupancy, and the barrier was not what bounds them —
+    // the instruction stream per unit is).  Every path runs with one unit per barrier.
+    constexpr int KU = 1;
+    constexpr int UNIT = A_IMG + B_IMG;
+    constexpr int STAGE = KU * UNIT;
+    constexpr int NSX = NS > 0 ? NS : 1;
+    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
+    // 16-bit storage (AT != 0): LDS-DMA ring (see the main loop): stages of DMA_SU units, unpadded images [plane][k/8][row]
+    constexpr int DMA_SU = 2;
+    constexpr int DMA_UNIT = NP * 2 * BM + NSX * 2 * BN;  // 16-byte slots of one unit
+    constexpr int DMA_STAGE = DMA_SU * DMA_UNIT;
+    constexpr int DMA_NSTG = DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
+    // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
+    constexpr int P_PATCH = NSX * 4 * 180;
+    constexpr int P_BUNIT = NSX * 2 * BN, P_BSTAGE = 2 * P_BUNIT;
+    constexpr int P_NSTG = NSX == 1 ? 4 : 3;
+    // three planes: ONE patch buffer (refilled between two barriers at a channel-block boundary) keeps the workgroup at 70 KB
+    // so that two fit a CU; with a second buffer it was alone on its CU (103 KB, one wave per SIMD: every LDS latency exposed)
+    constexpr int P_NBUF = NSX == 1 ? 2 : 1;
+    __shared__ f32x4 smem[PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    IgemmClass q;
+    int q_row_base = 0, q_wpk_off = 0;
+    if (MODE == 3) {
+        q.Hd = p.Hdf >> 3; q.Wd = p.Wdf >> 3; q.M = p.N * q.Hd * q.Wd;
+        // tile order: m-tile major, pixel class minor — the 64 classes of one image region run together, so their
+        // overlapping 3x3 neighbourhoods of the finest level are served by the L2 instead of 9 trips to HBM
+        const int mtiles = (q.M + BM - 1) / BM, ntn_ = p.Cd / BN;
+        const int mt_ = tile / (64 * ntn_), rem_ = tile - mt_ * (64 * ntn_);
+        const int c = rem_ / ntn_;
+        tile = mt_ * ntn_ + (rem_ - c * ntn_);
+        q.oh0 = c >> 3; q.ow0 = c & 7;
+        q_row_base = c * mtiles;
+        q.R = q.S = q.K = q.KT = q.pad_h = q.pad_w = 0;  // per level, see level_setup
+    } else if (MODE == 2) {
+        // tile order: position major, class minor.  The classes differ in taps (4/2/2/1 of a 3x3 at stride 2), so a
+        // class-major order would hand the heavy class to two of the eight XCDs (dbn_xcd_remap gives each XCD a contiguous
+        // run) — measured 1.8x slower; interleaved, every XCD gets the same mix and the classes of one image region share
+        // their source pixels through L2.  Classes with fewer tiles than the largest leave their slot empty.
+        // The class of slot t rotates with t / (8 * ncls): workgroups reach a CU round-robin (every 32nd of an XCD's run),
+        // and without the rotation each CU would again see a single class.
+        const int slot = tile / p.ncls;
+        const int c = (tile + (slot >> 3)) % p.ncls;
+        tile = slot;
+        if (tile >= p.tile_end[c]) return;
+        q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
+        q_row_base = p.row_base[c];
+        q_wpk_off = p.wpk_off[c];
+    } else {
+        q.Hd = p.Hdf; q.Wd = p.Wdf; q.M = p.N * p.Hdf * p.Wdf; q.R = p.R; q.S = p.S;
+        q.K = p.R * p.S * p.Cs; q.KT = (q.K + 15) / 16;
+        q.pad_h = q.pad_w = p.pad; q.oh0 = q.ow0 = 0;
+    }
+    const int ntn = p.Cd / BN;
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int qM = q.M, qHd = q.Hd, qWd = q.Wd;
+    int pn = 0, ph0 = 0, pw0 = 0;  // PATCH: image and top-left output pixel of this tile
+    if constexpr (PATCH) {
+        const int tw = qWd >> 4, tpi = (qHd >> 3) * tw;
+        pn = mt / tpi;
+        const int t = mt - pn * tpi, ty = t / tw;
+        ph0 = ty * 8;
+        pw0 = (t - ty * tw) * 16;
+    }
+    int qK = q.K, qKT = q.KT, qS = q.S, qR = q.R;  // MODE 3 changes these (and the source) per level
+    int gHs = p.Hs, gWs = p.Ws;
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+
+    // ---- per-thread gather state: A_LD rows, one 4-channel chunk -------------------
+    // piece q = tid + j*NT of the k-tile: fp32 source: chunk q & 3 of row q >> 2; 16-bit source: half q & 1 of row (q >> 1) % BM
+    // of plane (q >> 1) / BM
+    const int a_chunk = tid & ((1 << A_SH) - 1);
+    auto a_row = [&](int j) { return AT == 0 ? (tid >> 2) + j * (NT / 4) : ((tid + j * NT) >> 1) % BM; };
+    auto a_plane = [&](int j) { return AT == 0 ? 0 : ((tid + j * NT) >> 1) / BM; };
+    auto a_on = [&](int j) { return A_FULL || tid + j * NT < A_PIECES; };  // (the last j of tiles whose piece count is not a multiple of NT)
+    int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
+    unsigned a_pl[A_LD];  // byte offset of the piece's plane
+    unsigned plane_bytes = p.plane_bytes;
+    int a_n[MODE == 3 ? A_LD : 1], a_hd[MODE == 3 ? A_LD : 1], a_wd[MODE == 3 ? A_LD : 1];
+    const int HWd = qHd * qWd;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int row = a_row(j);
+        const int m = m0 + row;
+        const bool ok = m < qM && a_on(j);
+        a_pl[j] = (unsigned)a_plane(j) * plane_bytes;
+        const int mm = ok ? m : 0;
+        int n, rem, hd, wd;  // reciprocal divisions (exact below 2^24): an integer division costs ~35 VALU instructions
+        divmod24(mm, HWd, 1.0f / (float)HWd, n, rem);
+        divmod24(rem, qWd, 1.0f / (float)qWd, hd, wd);
+        a_nb[j] = n * p.Hs * p.Ws * p.Cs;
+        if (MODE == 3) {
+            a_n[j] = n;
+            a_hd[j] = ok ? hd : -(1 << 20);
+            a_wd[j] = wd;
+        } else if (MODE == 0) {
+            a_hb[j] = ok ? hd * p.stride - q.pad_h : -(1 << 20);  // a far-away row can never be in range
+            a_wb[j] = wd * p.stride - q.pad_w;
+        } else {
+            a_hb[j] = ok ? hd + q.pad_h : -(1 << 20);
+            a_wb[j] = wd + q.pad_w;
+        }
+    }
+    // K order (must match the weight panels, pack_weights_kernel):
+    //   Cs % 16 == 0: k = ((cb*R + r)*S + s)*16 + cl with ci = 16*cb + cl — every k-tile is one tap of one
+    //                 16-channel block and the R*S taps of a block are consecutive k-tiles, so the 9 re-reads of
+    //                 an input pixel's 64-byte slice happen back to back (L1/L2 hits instead of a trip to the fabric);
+    //   otherwise (stem, Cs = 4): k = (r*S + s)*Cs + ci.
+    // (always, for 16-bit storage and pre-split planes — checked on the host: a compile-time fact there, which removes the
+    // non-blocked walk and its branches from the k-loop)
+    const bool blocked = AT != 0 || (p.Cs & 15) == 0;
+    int kidx = A_CH * a_chunk;
+    int k_ci, k_r, k_s;
+    int kt_begin = 0, kt_end = qKT;
+    if (MODE < 2 && p.ksplit > 1) {
+        kt_begin = blockIdx.y * p.kt_per;
+        kt_end = min(qKT, kt_begin + p.kt_per);
+    }
+    if (blocked) {  // k-tile kt is tap (kt % RS) of channel block (kt / RS)
+        const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
+        kidx += 16 * kt_begin;
+        k_ci = 16 * cb + A_CH * a_chunk;
+        k_r = tap / qS;
+        k_s = tap - k_r * qS;
+    } else {
+        const int k_tap = kidx / p.Cs;
+        k_ci = kidx - k_tap * p.Cs;
+        k_r = k_tap / qS;
+        k_s = k_tap - k_r * qS;
+    }
+
+    unsigned aoff[KU][A_LD];
+    int kend = (MODE < 2 && p.ksplit > 1) ? min(qK, 16 * kt_end) : qK;  // units past the end (of K, or of this split's range) gather zeros
+    auto next_offsets = [&](int u = 0) {  // offsets of the current k position (unit u of the barrier interval), then advance by 16 k
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
+            const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
+            const bool v = kidx < kend && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES + (AT == 3 ? a_pl[j] : 0u);
+            aoff[u][j] = v ? off : OOB_OFFSET;
+        }
+        kidx += 16;
+        if (blocked) {  // next tap of the same channel block; after the last tap, the next block (branch-free)
+            ++k_s;
+            const bool ws_ = k_s == qS;
+            k_s = ws_ ? 0 : k_s;
+            k_r += ws_ ? 1 : 0;
+            const bool wr_ = k_r == qR;
+            k_r = wr_ ? 0 : k_r;
+            k_ci += wr_ ? 16 : 0;
+        } else {
+            k_ci += 16;
+            while (k_ci >= p.Cs) {  // stem (Cs = 4): several taps per step
+                k_ci -= p.Cs;
+                if (++k_s == qS) {
+                    k_s = 0;
+                    ++k_r;
+                }
+            }
+        }
+    };
+    const f32x4* bptr[B_LD];
+    int b_lds[B_LD];
+    bool b_on[B_LD];
+    auto panel_setup = [&](const float* panel) {
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int idx = tid + j * NT;
+            b_on[j] = B_FULL || idx < B_PIECES;
+            const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
+            bptr[j] = reinterpret_cast<const f32x4*>(panel) + (long)c * p.Cd + n0 + n;
+            b_lds[j] = c * BS + n;
+        }
+    };
+    const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
+    if (MODE != 3) {
+        panel_setup(p.wpk + q_wpk_off);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) bptr[j] += kt_begin * b_step;
+    }
+    // MODE 3: source, tap geometry and weight panel of pyramid level g for this tile's pixel class
+    auto level_setup = [&](int g) {
+        const int f = 1 << g, kk = f + 2;
+        const int oh0g = q.oh0 & (f - 1), ow0g = q.ow0 & (f - 1);
+        const int ph = (oh0g + 1) & (f - 1), pw = (ow0g + 1) & (f - 1);
+        qR = taps_of_class(kk, ph, f);
+        qS = taps_of_class(kk, pw, f);
+        const int padh = (oh0g + 1 - ph) >> g, padw = (ow0g + 1 - pw) >> g;
+        qK = qR * qS * p.Cs;
+        qKT = qK >> 4;
+        gHs = p.Hdf >> g;
+        gWs = p.Wdf >> g;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        if (AT == 3) {
+            plane_bytes = p.seg_plane_bytes[g];
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) a_pl[j] = (unsigned)a_plane(j) * plane_bytes;
+        }
+        long krows = 0;  // padded-K rows of the classes packed before (ph, pw)
+        for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
+        panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2));
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            a_nb[j] = a_n[MODE == 3 ? j : 0] * gHs * gWs * p.Cs;
+            a_hb[j] = a_hd[MODE == 3 ? j : 0] * (8 >> g) + (q.oh0 >> g) + padh;
+            a_wb[j] = a_wd[MODE == 3 ? j : 0] * (8 >> g) + (q.ow0 >> g) + padw;
+        }
+        kidx = A_CH * a_chunk;
+        k_ci = A_CH * a_chunk;
+        k_r = k_s = 0;
+    };
+
+    // two register sets: the global loads of k-tile t+2 are issued while tile t is multiplied and tile t+1 (loaded one
+    // iteration earlier) is staged to LDS — a full k-step (~1 us) more latency tolerance than a prefetch distance of one
+    // Loads and staging are issued UNCONDITIONALLY every k-step (tiles past the end gather zeros through out-of-range buffer
+    // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
+    // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
+    f32x4 ra_[2][KU][A_LD], rb_[2][KU][B_LD];
+    int b_left = 0;  // weight k-tiles that remain beyond the one bptr points at
+    auto issue_loads = [&](auto SET) {
+        constexpr int st_ = decltype(SET)::value;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) ra_[st_][u][j] = buffer_load_f32x4(rsrc, aoff[u][j]);
+            const long adv = b_left > 0 ? b_step : 0;
+            --b_left;
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) {
+                if (B_FULL || b_on[j]) rb_[st_][u][j] = *bptr[j];
+                bptr[j] += adv;
+            }
+        }
+    };
+    auto stage_unit = [&](int buf, auto SET, auto UU) {
+        constexpr int st_ = decltype(SET)::value;
+        constexpr int u_ = decltype(UU)::value;
+        f32x4 (&ra)[A_LD] = ra_[st_][u_];
+        f32x4 (&rb)[B_LD] = rb_[st_][u_];
+        f32x4* As = smem + buf * STAGE + u_ * UNIT;
+        f32x4* Bs = As + A_IMG;
+        if constexpr (NS == 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
+        } else if constexpr (AT != 0) {
+            // stored 16-bit channels: the piece IS the LDS slot [plane][k/8 = a_chunk][row] of the image
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j)
+                if (a_on(j)) As[(a_plane(j) * 2 + a_chunk) * AS + a_row(j)] = ra[j];
+        } else {
+            // chunk c holds k = 4c..4c+3 of the k-tile: bf16 image slot [c>>1][row], 8-byte half (c&1)
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                u32x2 sp[NSX];
+                split4<NS>(ra[j], sp);
+                const int row = (tid >> 2) + j * (NT / 4);
+#pragma unroll
+                for (int t = 0; t < NS; ++t)
+                    reinterpret_cast<u32x2*>(As + (t * 2 + (a_chunk >> 1)) * AS + row)[a_chunk & 1] = sp[t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            if (B_FULL || b_on[j]) Bs[b_lds[j]] = rb[j];
+    };
+    auto stage = [&](int buf, auto SET) {
+        stage_unit(buf, SET, std::integral_constant<int, 0>{});
+        if constexpr (KU > 1) {
+            stage_unit(buf, SET, std::integral_constant<int, 1>{});
+            stage_unit(buf, SET, std::integral_constant<int, 2>{});
+            stage_unit(buf, SET, std::integral_constant<int, 3>{});
+        }
+    };
+    static_assert(KU == 1 || KU == 4, "stage() spells the units out");
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if constexpr (PATCH) {
+    // ---- 3x3 / stride 1 on the bf16 matrix pipe: pixel-patch tiles -------------------------------------------------------------
+    // The texture unit handles about one 128-byte line per clock per CU whatever the lanes take from it (tools/probes/
+    // gather_rate.hip), and an im2col gather touches one line per row and tap: at one 32-cycle MFMA per accumulator and unit that
+    // gather, not the matrix pipe, bounds the kernel (4 x 35-71 clocks per unit against 64).  Here a tile is an 8 x 16 patch of
+    // output pixels, and the 10 x 18 input patch around it is brought to LDS ONCE per 32-channel block (contiguous 64/128-byte
+    // runs per pixel; fp32 sources are split into their bf16 planes on the way, once instead of once per tap).  The nine taps are
+    // then plain LDS address offsets of the fragment reads: image [plane][k/8 slice][patch pixel][16 B], and MFMA row i is the
+    // pixel (y, x) = (2*blk + parity(i >> 2), 4*(i >> 3) + (i & 3)) so that each 16-lane group of a ds_read_b128 (lanes
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31}) reads 16 consecutive pixels of one patch row — conflict-free for every tap.
+    // The weight panels stream through a ring of DMA stages as in the generic 16-bit loop below.
+    constexpr int PPX = 180, PROW = 18;
+    constexpr int CHUNKS = AT == 0 ? 8 : 4;           // 16-byte pieces per pixel of a 32-channel block
+    constexpr int PL = (PPX * CHUNKS + NT - 1) / NT;  // pieces per thread
+    constexpr int B_I = NSX * 2 * (BN / 64);          // DMA instructions per unit
+    static_assert((2 * B_I) % 4 == 0 && NT == 256, "weight DMA is dealt evenly to four waves");
+    constexpr int PWB = 2 * B_I / 4;
+    f32x4* const patch = smem;
+    f32x4* const ring = smem + P_NBUF * P_PATCH;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    unsigned poff[PL];
+    int pslot[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        const int idx = tid + j * NT;
+        const bool on = idx < PPX * CHUNKS;
+        const int chunk = idx % CHUNKS, pix = on ? idx / CHUNKS : 0;
+        const int py = pix / PROW, px = pix - py * PROW;
+        const int hs = ph0 - 1 + py, ws = pw0 - 1 + px;
+        const bool v = on && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * (unsigned)ES + (unsigned)chunk * 16u : OOB_OFFSET;
+        // fp32 source: chunk = 4 channels = one 8-byte half of slice chunk >> 1 (slot in 8-byte units); 16-bit: chunk = slice
+        pslot[j] = !on ? -1 : AT == 0 ? ((chunk >> 1) * PPX + pix) * 2 + (chunk & 1) : chunk * PPX + pix;
+    }
+    f32x4 pr[PL];
+    const int ncb = p.Cs >> 5;
+    auto load_patch = [&](int cb) {  // (cb == ncb: the loads are issued all the same, so that the counted waits stay constant)
+        const unsigned add = (unsigned)(cb * 32 * ES);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
+    };
+    auto store_patch = [&](int buf) {
+        f32x4* const P = patch + buf * P_PATCH;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+            if (pslot[j] < 0) continue;
+            if constexpr (AT == 0) {
+                u32x2 sp[NSX];
+                split4<NS>(pr[j], sp);
+#pragma unroll
+                for (int t = 0; t < NS; ++t) reinterpret_cast<u32x2*>(P + t * 4 * PPX)[pslot[j]] = sp[t];
+            } else {
+                P[pslot[j]] = pr[j];
+            }
+        }
+    };
+    // weight DMA: instruction t = wave + 4 i of a stage: unit t / B_I, (plane, slice) and 64-column group from t % B_I
+    int b_lds[PWB], b_u[PWB];
+    unsigned b_add[PWB];
+#pragma unroll
+    for (int i = 0; i < PWB; ++i) {
+        const int t = wave_u + 4 * i, u = t / B_I, rr = t - u * B_I, c = rr & 1, gp = rr >> 1;
+        const int g = gp % (BN / 64), plane = gp / (BN / 64);
+        b_u[i] = u;
+        b_lds[i] = u * P_BUNIT + (plane * 2 + c) * BN + 64 * g;
+        b_add[i] = (unsigned)((plane * 2 + c) * p.Cd + n0 + 64 * g + lane) * 16u;
+    }
+    const unsigned bstep_bytes = (unsigned)(2 * NSX * p.Cd) * 16u;
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk + q_wpk_off), 0,
+                                                                           (unsigned)qKT * bstep_bytes, 0x00020000);
+    int g_kt = 0;  // next k-tile to fetch (two per stage; k-tiles past the end are out of range: zeros)
+    auto issue_b = [&](int slot_) {
+#pragma unroll
+        for (int i = 0; i < PWB; ++i) {
+            auto* dst = (__attribute__((address_space(3))) void*)(ring + slot_ * P_BSTAGE + b_lds[i]);
+            const int kt = g_kt + b_u[i];
+            const unsigned off = kt < qKT ? (unsigned)kt * bstep_bytes + b_add[i] : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, dst, 16, (int)off, 0, 0, 0);
+        }
+        g_kt += 2;
+    };
+    // this lane's patch pixel for accumulator block a (rows 2*(wm*MI + a) .. +1 of the tile), before the tap offset
+    const int q4 = li >> 2;
+    const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1)) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
+
+    load_patch(0);
+#pragma unroll
+    for (int s_ = 0; s_ < P_NSTG - 1; ++s_) issue_b(s_);
+    store_patch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int slot = 0;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const f32x4* const P = patch + (P_NBUF == 2 ? (cb & 1) : 0) * P_PATCH;
+#pragma unroll
+        for (int st = 0; st < 9; ++st) {
+            // stage `st` of this channel block has landed once only the younger stages — and, for the first P_NSTG - 1 stages
+            // after their issue, the next block's patch loads — are outstanding
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((P_NSTG - 2) * PWB + ((st >= 1 && st <= P_NSTG - 1) ? PL : 0)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence: keep the LDS reads of this stage behind it)
+            issue_b(slot == 0 ? P_NSTG - 1 : slot - 1);
+            if (st == 0) {
+                if constexpr (P_NBUF == 1) {
+                    if (cb > 0) {  // everyone is past the barrier above, i.e. done with the previous block's patch: refill it
+                        store_patch(0);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                // the counted waits below assume the patch loads are YOUNGER than this interval's weight stage (vmcnt retires in
+                // order): keep the compiler from hoisting them above the DMA instructions
+                asm volatile("" ::: "memory");
+                load_patch(cb + 1);
+                asm volatile("" ::: "memory");
+            }
+            const f32x4* const Bst = ring + slot * P_BSTAGE;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ui = 2 * st + u, h = ui / 9, tap = ui - h * 9;  // compile-time after unrolling
+                const int tr = MODE == 0 ? tap / 3 : 2 - tap / 3, ts = MODE == 0 ? tap % 3 : 2 - tap % 3;
+                const f32x4* const Bs = Bst + u * P_BUNIT;
+                bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+                for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+                        af[t][a] = __builtin_bit_cast(bf16x8, P[(t * 4 + 2 * h) * PPX + a_pix + (2 * a + tr) * PROW + ts]);
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BN + wn * TN + b * 32 + li]);
+                }
+                mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+            }
+            slot = slot + 1 == P_NSTG ? 0 : slot + 1;
+        }
+        if (P_NBUF == 2 && cb + 1 < ncb) {
+            store_patch((cb + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    } else if constexpr (AT != 0) {
+    // ---- stored 16-bit operands: LDS-DMA ring ------------------------------------------------------------------------------
+    // One 32x32x16 MFMA per accumulator and unit is 32 cycles; a register-staged loop with a prefetch distance of one unit kept the
+    // waves parked on vmcnt / the barrier for 70-80 % of their cycles (SQ_WAIT_ANY; MFMA busy 15 %).  The stored format IS the LDS
+    // image ([plane][k/8][row][8 x 16 bit]), so the panels are written by buffer_load ... lds (64 lanes x 16 B = 64 rows of one
+    // k/8 slice per instruction, padding taps / row tails / units past the end deliver zeros through out-of-range offsets): no
+    // staging registers, hence a ring of DMA_NSTG stages of DMA_SU units with DMA_NSTG - 1 stages in flight across raw barriers
+    // (counted vmcnt).  The instructions of a stage are dealt round-robin to the waves; tap / k-tile state is wave-uniform.
+    constexpr int NW = NT / 64;
+    // A: lanes 2j, 2j+1 fetch the two k/8 slices (32 contiguous bytes) of row j of the instruction's 32 rows — the texture unit
+    // handles ~one 128-byte line per clock whatever the lanes take from it (tools/probes/gather_rate.hip: 71 clocks per instruction
+    // with 64 lines, 35 with 32), and the gather, not the MFMA, bounds these kernels.  The A image is therefore row-major
+    // [plane][row][2 slices]; the fragment reads (stride 32 B) pay a 2-way bank conflict for it.
+    constexpr int A_I = NP * (BM / 32), B_I = NSX * 2 * (BN / 64), U_I = A_I + B_I;
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && (DMA_SU * U_I) % NW == 0, "DMA instructions are dealt evenly to the waves");
+    constexpr int PW = DMA_SU * U_I / NW;
+    // Dealing: a wave's slot i of a stage has a COMPILE-TIME kind (A panel / weight panel) and, where a unit has at least one
+    // instruction per wave, a compile-time unit — the first version dealt t = wave + 4 i round-robin, which made kind and unit
+    // wave-dependent: every slot carried both code paths behind scalar branches and five scalar selects, ~100 SALU instructions
+    // per stage against its 2-8 MFMAs per wave (PMC: 24-35 SALU per MFMA in the generic 16-bit kernels).  Slots [0, PA): A panel
+    // (A_I % 4 == 0: unit i / RA, instruction wave*RA + i % RA of that unit; otherwise unit wave >> 1, instruction (wave & 1)*RA + i);
+    // slots [PA, PW): weight panel, the same way.
+    // (a unit with fewer than four instructions per panel is shared by two waves: unit wave >> 1, instructions (wave & 1)*R + j)
+    static_assert(NW == 2 * DMA_SU && A_I % 2 == 0 && B_I % 2 == 0, "per-unit dealing, or two waves per unit");
+    constexpr bool A_PER_UNIT = A_I % NW == 0, B_PER_UNIT = B_I % NW == 0;
+    constexpr int RA = A_PER_UNIT ? A_I / NW : A_I / 2, RB = B_PER_UNIT ? B_I / NW : B_I / 2;
+    constexpr int PA = A_PER_UNIT ? DMA_SU * RA : RA;
+    static_assert(PA + (B_PER_UNIT ? DMA_SU * RB : RB) == PW, "slot count");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int uw = wave_u >> 1;  // the unit of a slot dealt per stage
+    int i_lds[PW];       // slot of the instruction's destination inside its UNIT (16-byte units)
+    unsigned i_add[PW];  // A: byte offset of the k/8 slice (+ plane) within a pixel's block; B: byte offset of the lane's piece in a k-tile
+    int i_plane[PW];
+    int r_hb[PW], r_wb[PW], r_nb[PW];
+    int r_n[MODE == 3 ? PW : 1], r_hd[MODE == 3 ? PW : 1], r_wd[MODE == 3 ? PW : 1];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const bool isA = i < PA;
+        // index of the instruction inside its unit
+        const int r = isA ? (A_PER_UNIT ? wave_u * RA + i % RA : (wave_u & 1) * RA + i)
+                          : (B_PER_UNIT ? wave_u * RB + (i - PA) % RB : (wave_u & 1) * RB + (i - PA));
+        const int c = r & 1, gp = r >> 1;
+        const int g = isA ? r % (BM / 32) : gp % (BN / 64), plane = isA ? r / (BM / 32) : gp / (BN / 64);
+        i_plane[i] = plane;
+        i_lds[i] = isA ? plane * 2 * BM + 64 * g : NP * 2 * BM + (plane * 2 + c) * BN + 64 * g;
+        i_add[i] = isA ? (unsigned)(lane & 1) * 16u : (unsigned)((plane * 2 + c) * p.Cd + n0 + 64 * g + lane) * 16u;
+        r_hb[i] = r_wb[i] = r_nb[i] = 0;
+        if (MODE == 3) r_n[MODE == 3 ? i : 0] = r_hd[MODE == 3 ? i : 0] = r_wd[MODE == 3 ? i : 0] = 0;
+        if (isA) {
+            const int m = m0 + 32 * g + (lane >> 1);
+            const bool ok = m < qM;
+            int n, rem, hd, wd;
+            divmod24(ok ? m : 0, HWd, 1.0f / (float)HWd, n, rem);
+            divmod24(rem, qWd, 1.0f / (float)qWd, hd, wd);
+            r_nb[i] = n * p.Hs * p.Ws * p.Cs;
+            if (MODE == 3) {
+                r_n[MODE == 3 ? i : 0] = n;
+                r_hd[MODE == 3 ? i : 0] = ok ? hd : -(1 << 20);
+                r_wd[MODE == 3 ? i : 0] = wd;
+            } else if (MODE == 0) {
+                r_hb[i] = ok ? hd * p.stride - q.pad_h : -(1 << 20);
+                r_wb[i] = wd * p.stride - q.pad_w;
+            } else {
+                r_hb[i] = ok ? hd + q.pad_h : -(1 << 20);
+                r_wb[i] = wd + q.pad_w;
+            }
+        }
+    }
+    // wave-uniform walk over the units: tap (g_r, g_s) of channel block g_cb, k-tile g_kt of the weight panel
+    int g_left, g_kt, g_r, g_s, g_cb, g_level = 0;
+    const unsigned bstep_bytes = (unsigned)(2 * NSX * p.Cd) * 16u;
+    __amdgpu_buffer_rsrc_t rsrcB;
+    auto level_dma = [&](int g) {  // MODE 3: source, tap geometry, weight panel of pyramid level g (see level_setup)
+        const int f = 1 << g, kk = f + 2;
+        const int oh0g = q.oh0 & (f - 1), ow0g = q.ow0 & (f - 1);
+        const int ph = (oh0g + 1) & (f - 1), pw = (ow0g + 1) & (f - 1);
+        qR = taps_of_class(kk, ph, f);
+        qS = taps_of_class(kk, pw, f);
+        const int padh = (oh0g + 1 - ph) >> g, padw = (ow0g + 1 - pw) >> g;
+        qK = qR * qS * p.Cs;
+        qKT = qK >> 4;
+        gHs = p.Hdf >> g;
+        gWs = p.Wdf >> g;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.seg_src[g]), 0, p.seg_bytes[g], 0x00020000);
+        if (AT == 3) plane_bytes = p.seg_plane_bytes[g];
+        long krows = 0;
+        for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_wpk[g] + krows * p.Cd * NSX / 2), 0, (unsigned)qKT * bstep_bytes,
+                                                  0x00020000);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            r_nb[i] = r_n[MODE == 3 ? i : 0] * gHs * gWs * p.Cs;
+            r_hb[i] = r_hd[MODE == 3 ? i : 0] * (8 >> g) + (q.oh0 >> g) + padh;
+            r_wb[i] = r_wd[MODE == 3 ? i : 0] * (8 >> g) + (q.ow0 >> g) + padw;
+        }
+        g_left = qKT;
+        g_kt = g_r = g_s = g_cb = 0;
+    };
+    int nstages;
+    if (MODE == 3) {
+        nstages = 0;
+        for (int g = 0; g < 4; ++g) {
+            const int f = 1 << g, kk = f + 2;
+            const int ph = ((q.oh0 & (f - 1)) + 1) & (f - 1), pw = ((q.ow0 & (f - 1)) + 1) & (f - 1);
+            nstages += (taps_of_class(kk, ph, f) * taps_of_class(kk, pw, f) * (p.Cs >> 4) + DMA_SU - 1) / DMA_SU;
+        }
+        level_dma(0);
+    } else {
+        const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
+        g_cb = 16 * cb;
+        g_r = tap / qS;
+        g_s = tap - g_r * qS;
+        g_kt = kt_begin;
+        g_left = kt_end - kt_begin;
+        nstages = (g_left + DMA_SU - 1) / DMA_SU;
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk + q_wpk_off), 0, (unsigned)qKT * bstep_bytes, 0x00020000);
+    }
+    auto issue_stage = [&](int slot) {
+        if (MODE == 3 && g_left <= 0 && g_level < 3) level_dma(++g_level);
+        bool uv[DMA_SU];
+        int ur[DMA_SU], us[DMA_SU], ucb[DMA_SU], ukt[DMA_SU];
+#pragma unroll
+        for (int u = 0; u < DMA_SU; ++u) {
+            uv[u] = g_left > 0;
+            ur[u] = g_r; us[u] = g_s; ucb[u] = g_cb; ukt[u] = g_kt;
+            --g_left;
+            ++g_kt;
+            ++g_s;
+            const bool ws_ = g_s == qS;
+            g_s = ws_ ? 0 : g_s;
+            g_r += ws_ ? 1 : 0;
+            const bool wr_ = g_r == qR;
+            g_r = wr_ ? 0 : g_r;
+            g_cb += wr_ ? 16 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const bool isA = i < PA;  // compile-time after unrolling, like `fixed` and `uc`
+            const bool fixed = isA ? A_PER_UNIT : B_PER_UNIT;
+            const int uc = isA ? i / RA : (i - PA) / RB;  // the unit of a per-unit slot
+            const int u = fixed ? uc : uw;
+            const bool v_u = fixed ? uv[uc] : (uw ? uv[DMA_SU - 1] : uv[0]);
+            const int tr = fixed ? ur[uc] : (uw ? ur[DMA_SU - 1] : ur[0]), ts = fixed ? us[uc] : (uw ? us[DMA_SU - 1] : us[0]);
+            const int tcb = fixed ? ucb[uc] : (uw ? ucb[DMA_SU - 1] : ucb[0]), tkt = fixed ? ukt[uc] : (uw ? ukt[DMA_SU - 1] : ukt[0]);
+            auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * DMA_STAGE + u * DMA_UNIT + i_lds[i]);
+            if (isA) {
+                const int hs = MODE == 0 ? r_hb[i] + tr : r_hb[i] - tr;
+                const int ws = MODE == 0 ? r_wb[i] + ts : r_wb[i] - ts;
+                const bool v = v_u && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+                const unsigned off = (unsigned)(r_nb[i] + (hs * gWs + ws) * p.Cs + tcb) * 2u + i_add[i] + (AT == 3 ? (unsigned)i_plane[i] * plane_bytes : 0u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (int)(v ? off : OOB_OFFSET), 0, 0, 0);
+            } else {
+                const unsigned off = v_u ? (unsigned)tkt * bstep_bytes + i_add[i] : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, dst, 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+    static_assert(DMA_SU == 2, "issue_stage selects between two units");
+#pragma unroll
+    for (int s_ = 0; s_ < DMA_NSTG - 1; ++s_) issue_stage(s_);
+    int slot = 0;
+    for (int st_ = 0; st_ < nstages; ++st_) {
+        // this wave's part of stage st_ has landed once at most the DMA_NSTG - 2 younger stages are outstanding
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW * (DMA_NSTG - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part is in LDS, and everyone is done reading the slot of stage st_ - 1
+        asm volatile("" ::: "memory");  // (the barrier builtin is no compiler fence)
+        const int fill = slot == 0 ? DMA_NSTG - 1 : slot - 1;
+        issue_stage(fill);
+        const f32x4* Sg = smem + slot * DMA_STAGE;
+#pragma unroll
+        for (int u = 0; u < DMA_SU; ++u) {
+            const f32x4* As = Sg + u * DMA_UNIT;
+            const f32x4* Bs = As + NP * 2 * BM;
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * BM + wm * TM + a * 32 + li) * 2 + lh]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BN + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+        }
+        slot = slot + 1 == DMA_NSTG ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-filled stages issued past the end
+    __syncthreads();
+    } else {
+    for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
+    if (MODE == 3) {
+        level_setup(level);
+        kt_end = qKT;
+        kend = qK;
+    }
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    b_left = kt_end - kt_begin - 1;
+    auto offsets_of_interval = [&]() {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) next_offsets(u);
+    };
+    offsets_of_interval();
+    issue_loads(C0{});
+    offsets_of_interval();  // offsets of interval 1
+    issue_loads(C1{});
+    offsets_of_interval();  // offsets of interval 2
+    stage(0, C0{});
+    __syncthreads();
+
+    auto k_step = [&](int kt, auto PAR) {
+        constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
+        issue_loads(PAR);  // interval +2 into the register set this interval was staged from
+        const f32x4* As = smem + buf * STAGE;
+        const f32x4* Bs = As + A_IMG;
+        if constexpr (KU > 1) {
+            // four 16-k units per barrier: fragments of unit u+1 are read while unit u multiplies
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                bf16x8 af[1][MI], bf[1][NI];
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[0][a] = __builtin_bit_cast(bf16x8, As[u * UNIT + lh * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[0][b] = __builtin_bit_cast(bf16x8, Bs[u * UNIT + lh * BS + wn * TN + b * 32 + li]);
+                mfma_split<1, MI, NI, AT == 2>(af, bf, acc);
+            }
+            offsets_of_interval();
+        } else if constexpr (NS == 0) {
+            // all fragment reads of the k-tile up front: the second half's LDS latency hides under the first half's MFMAs
+            f32x4 af[2][MI], bf[2][NI];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
+                if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
+            }
+        } else {
+            // one 32x32x16 bf16 MFMA k-step per k-tile: lane half lh owns k = 8*lh .. 8*lh+7
+            bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+#pragma unroll
+                for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * 2 + lh) * AS + wm * TM + a * 32 + li]);
+#pragma unroll
+                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+            }
+            mfma_split<NS, MI, NI, AT == 2>(af, bf, acc);
+            next_offsets();
+        }
+        stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
+        __syncthreads();
+    };
+    for (int kt = kt_begin; kt < kt_end; kt += 2 * KU) {
+        k_step(kt, C0{});
+        if (kt + KU < kt_end) k_step(kt + KU, C1{});
+    }
+    }
+
+    }
+    // ---- accumulate mode: fold the previous contents of dst into the accumulators first, so that the BatchNorm
+    // statistics below and the store loop both see the final values
+    // split-K launches write fp32 slabs whatever the activation type (the slab sum rounds once)
+    const bool to_slab = MODE < 2 && p.ksplit > 1;
+    float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * ((long)qM * p.Cd + 1088) : 0L);
+    void* const dstv = p.dst;
+    auto ld_dst = [&](long off) -> float { return (DST_F32 || to_slab) ? slabp[off] : dbn_ld1 < DST_F32 ? 0 : AT > (dstv, off); };
+    auto st_dst = [&](long off, float v) {
+        if (DST_F32 || to_slab) slabp[off] = v;
+        else dbn_st1 < DST_F32 ? 0 : AT > (dstv, off, v);
+    };
+    const float rcp_hw = 1.0f / (float)HWd, rcp_w = 1.0f / (float)qWd;
+    // fn(r, doff) for the 16 rows this lane holds of accumulator block a (rows base + (r&3) + 8*(r>>2)) that are < M.
+    // MODE >= 2 scatters to the parity class's pixels of the full-resolution output: the pixel (n, hd, wd) of the first row
+    // comes from two reciprocal divisions, the other 15 by stepping +1,+1,+1,+5 with carries — the per-row divisions
+    // were 1300 of the 2450 VALU instructions a wave spends on a K = 64 tile (ConvTranspose 2x2), as many cycles as its MFMAs.
+    // offsets are formed in 32 bits (element index < 2^31 is checked on the host) and widened once per row
+    auto for_rows = [&](int a, auto&& fn) {
+        const int rbase = m0 + wm * TM + a * 32 + 4 * lh;
+        if constexpr (PATCH) {  // row i = (r & 3) + 8 (r >> 2) + 4 lh is the pixel (2 blk + parity(i >> 2), 4 (i >> 3) + (i & 3))
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int y = ph0 + 2 * (wm * MI + a) + ((__builtin_popcount(r >> 2) + lh) & 1), x = pw0 + (r >> 2) * 4 + (r & 3);
+                fn(r, true, (long)((unsigned)((pn * p.Hdf + y) * p.Wdf + x) * (unsigned)p.Cd));
+            }
+        } else if (MODE >= 2) {
+            int n, rem, hd, wd;
+            divmod24(min(rbase, qM - 1), HWd, rcp_hw, n, rem);
+            divmod24(rem, qWd, rcp_w, hd, wd);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r > 0) {
+                    wd += (r & 3) ? 1 : 5;
+                    while (wd >= qWd) {
+                        wd -= qWd;
+                        if (++hd == qHd) {
+                            hd = 0;
+                            ++n;
+                        }
+                    }
+                }
+                const bool ok = rbase + (r & 3) + 8 * (r >> 2) < qM;
+                const int nn = ok ? n : 0, hh = ok ? hd : 0, ww = ok ? wd : 0;  // invalid rows point at a valid pixel
+                fn(r, ok, (long)((unsigned)((nn * p.Hdf + p.stride * hh + q.oh0) * p.Wdf + p.stride * ww + q.ow0) * (unsigned)p.Cd));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = row < qM;
+                fn(r, ok, (long)((unsigned)(ok ? row : m0) * (unsigned)p.Cd));
+            }
+        }
+    };
+    // destination offset (elements) of tile row `row` (0 .. BM-1) — the row-major passes of 16-bit destinations below
+    auto tile_row = [&](int row, bool& ok, long& doff) {
+        if constexpr (PATCH) {
+            const int blk = row >> 5, q4r = (row & 31) >> 2;
+            const int y = ph0 + 2 * blk + (__builtin_popcount(q4r) & 1), x = pw0 + (q4r >> 1) * 4 + (row & 3);
+            ok = true;
+            doff = (long)((unsigned)((pn * p.Hdf + y) * p.Wdf + x) * (unsigned)p.Cd);
+        } else if (MODE >= 2) {
+            int n, rem, hd, wd;
+            const int m = m0 + row;
+            ok = m < qM;
+            divmod24(ok ? m : 0, HWd, rcp_hw, n, rem);
+            divmod24(rem, qWd, rcp_w, hd, wd);
+            doff = (long)((unsigned)((n * p.Hdf + p.stride * hd + q.oh0) * p.Wdf + p.stride * wd + q.ow0) * (unsigned)p.Cd);
+        } else {
+            ok = m0 + row < qM;
+            doff = (long)((unsigned)(m0 + row) * (unsigned)p.Cd);
+        }
+    };
+    constexpr int T_PITCH = BN + 8;  // 16-bit elements; +16 bytes keeps the 16-byte accesses aligned and rotates the banks
+    constexpr int T_LPR = BN / 8, T_RPP = NT / T_LPR;  // lanes per row (16 B each), rows per pass
+    bool acc_done = false;
+    if constexpr (!DST_F32) {
+        if (p.accumulate && !to_slab) {
+            // 16-bit destination: the old tile comes in row-major, 16 bytes per lane, through LDS — a lane holds one column of 16
+            // rows, so reading its own elements directly is MI*NI*16 two-byte loads per lane (measured: a bf16 data gradient with
+            // accumulate took 97 us against 58 us for the same convolution without)
+            static_assert((long)BM * T_PITCH * 2 <= (long)sizeof(smem) && BM % T_RPP == 0, "tile must fit the LDS panels");
+            unsigned short* const T = reinterpret_cast<unsigned short*>(smem);
+            const int piece = tid % T_LPR;
+#pragma unroll
+            for (int ps = 0; ps < BM / T_RPP; ++ps) {
+                const int row = ps * T_RPP + tid / T_LPR;
+                bool ok;
+                long doff;
+                tile_row(row, ok, doff);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(dstv) + doff + n0 + piece * 8);
+                *reinterpret_cast<f32x4*>(T + row * T_PITCH + piece * 8) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        acc[a][b][r] += dbn_ld1<DST_F32 ? 1 : AT>(T, row * T_PITCH + wn * TN + b * 32 + li);
+                    }
+            __syncthreads();  // (the statistics scratch and the output staging reuse the region)
+            acc_done = true;
+        }
+    }
+    if (p.accumulate && !acc_done) {
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+        {
+            if constexpr (MODE < 2) {
+                // unpredicated loads (rows past M read a valid pixel and add 0), issued four rows (4 x NI loads) at a time
+                // before their adds: left alone, the scheduler put each load right before its use with a full wait — 64
+                // dependent round trips per tile; whole blocks in flight would cost an occupancy step in registers
+                float old[4][NI];
+                bool okr[4];
+                for_rows(a, [&](int r, bool ok, long doff) {
+                    const long d = n0 + wn * TN + li + doff;
+                    okr[r & 3] = ok;
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) old[r & 3][b] = ld_dst(d + b * 32);
+                    if ((r & 3) == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int b = 0; b < NI; ++b) acc[a][b][r - 3 + i] += okr[i] ? old[i][b] : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            } else {  // parity-class scatter: row by row (the pixel walk plus batched loads costs 40 VGPRs = an occupancy step)
+                for_rows(a, [&](int r, bool ok, long doff) {
+                    if (ok) {
+                        const long d = n0 + wn * TN + li + doff;
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) acc[a][b][r] += ld_dst(d + b * 32);
+                    }
+                });
+            }
+        }
+    }
+
+    // ---- optional BatchNorm statistics of this tile (train-mode BN follows the conv): per output channel the
+    // pivot (first row of the tile), sum and sum of squares of (value - pivot) over the tile's valid rows.  A
+    // per-tile pivot keeps the fp32 sums free of cancellation; the finalize kernel merges tiles in fp64.
+    if (p.stats) {
+        float* red = reinterpret_cast<float*>(smem);  // the LDS panels are dead after the last barrier of the k-loop
+        float* piv = red;                             // [BN]
+        float* r1 = red + BN;                         // [WM][BN]
+        float* r2 = r1 + WM * BN;                     // [WM][BN]
+        if (wm == 0 && lh == 0) {
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                const int cl = wn * TN + b * 32 + li;
+                piv[cl] = acc[0][b][0] + (p.bias ? p.bias[n0 + cl] : 0.f);  // row m0 (< M always)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int cl = wn * TN + b * 32 + li;
+            const float pv = piv[cl], bv = p.bias ? p.bias[n0 + cl] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float d = (acc[a][b][r] + bv) - pv;
+                    s1 += row < qM ? d : 0.f;
+                    s2 += row < qM ? d * d : 0.f;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                r1[wm * BN + cl] = s1;
+                r2[wm * BN + cl] = s2;
+            }
+        }
+        __syncthreads();
+        const int trow = p.stat_row0 + q_row_base + mt;
+        for (int cl = tid; cl < BN; cl += NT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += r1[w * BN + cl];
+                s2 += r2[w * BN + cl];
+            }
+            const long c = n0 + cl;
+            p.stats[(0L * p.Cd + c) * p.stat_rows + trow] = piv[cl];
+            p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
+            p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
+        }
+        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)min(BM, qM - m0);
+    }
+
+    // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // the bias values of this lane's NI columns are loaded once (inside the row loop the compiler re-loaded them for every
+    // row, behind a vmcnt(0) wait, because the stores may alias them)
+    float bv[NI];
+#pragma unroll
+    for (int b = 0; b < NI; ++b) bv[b] = p.bias ? p.bias[n0 + wn * TN + b * 32 + li] : 0.f;
+    // ... and pinned in registers BEFORE the (row-predicated) store blocks: a load still pending when a predicated block
+    // is entered makes the compiler wait vmcnt(0) in each of them — and on gfx9 vmcnt also counts the stores, so every
+    // row's store waited for the previous row's store to complete.
+#pragma unroll
+    for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
+    const long dcol = n0 + wn * TN + li;
+    if constexpr (!DST_F32) {
+        if (!to_slab) {
+            // 16-bit output: a lane holds ONE column of 16 rows, so direct stores are 2-byte scatters (MI*NI*16 store instructions
+            // per lane, 64 contiguous bytes per row each) — as many texture-unit cycles as the whole k-loop of a K = 576 tile.  The
+            // tile goes through LDS instead: written in the storage type, read back row-major, stored 16 bytes per lane
+            // (BN/8 lanes cover a row's 2*BN contiguous bytes): BM*BN/(8*NT) store instructions per lane.
+            constexpr int PITCH = T_PITCH;
+            static_assert((long)BM * PITCH * 2 <= (long)sizeof(smem), "output tile must fit the LDS panels");
+            unsigned short* const T = reinterpret_cast<unsigned short*>(smem);
+            __syncthreads();  // the panels / the statistics scratch are dead
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        dbn_st1<DST_F32 ? 1 : AT>(T, row * PITCH + wn * TN + b * 32 + li, acc[a][b][r] + bv[b]);
+                    }
+            __syncthreads();
+            constexpr int LPR = T_LPR, RPP = T_RPP;
+            static_assert(BM % RPP == 0, "whole passes");
+            const int piece = tid % LPR;
+#pragma unroll
+            for (int ps = 0; ps < BM / RPP; ++ps) {
+                const int row = ps * RPP + tid / LPR;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * PITCH + piece * 8);
+                bool ok;
+                long doff;
+                tile_row(row, ok, doff);
+                if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(dstv) + doff + n0 + piece * 8) = v;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+        for_rows(a, [&](int r, bool ok, long doff) {
+            if (ok) {
+#pragma unroll
+                for (int b = 0; b < NI; ++b) st_dst(dcol + doff + b * 32, acc[a][b][r] + bv[b]);
+            }
+        });
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
+int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
+    int grid = 0, rows = 0;
+    if (mode == 3) {
+        rows = 64 * dbn_ceil_div(p.N * (p.Hdf >> 3) * (p.Wdf >> 3), BM);
+        grid = rows * (p.Cd / BN);
+    } else if (mode == 2) {
+        for (int c = 0; c < p.ncls; ++c) {
+            const IgemmClass q = class_geom(c, p.stride, p.R, p.S, p.pad, p.N, p.Hdf, p.Wdf, p.Cs);
+            const int mtiles = (q.K > 0 && q.M > 0) ? dbn_ceil_div(q.M, BM) : 0;
+            p.row_base[c] = rows;
+            rows += mtiles;
+            p.tile_end[c] = mtiles * (p.Cd / BN);
+            grid = p.tile_end[c] > grid ? p.tile_end[c] : grid;
+        }
+        grid *= p.ncls;  // class-interleaved tile order: ncls slots per position (see the kernel)
+    } else {
+        rows = dbn_ceil_div(p.N * p.Hdf * p.Wdf, BM);
+        grid = rows * (p.Cd / BN);
+    }
+    if (p.stat_rows <= 0) p.stat_rows = rows;  // a chunked call sets the total itself
+    p.launch_rows = rows;
+    if (grid == 0) return DBN_OK;
+    const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
+    if constexpr (BM == 128 && WM == 2 && WN == 2 && NS > 0 && AT != 3) {
+        if (p.patch && mode < 2) {
+            if (mode == 0)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, true>), dim3(grid), dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT, true>), dim3(grid), dim3(256), 0, st, p);
+            return dbn_status();
+        }
+    }
+    if (p.patch) return DBN_ERR_ARG;
+    if (mode == 0)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
+    else if (mode == 1)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
+    else if (mode == 2)
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS, AT>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else if constexpr (BM == 128 && BN == 128)  // the pyramid conv is built for the 128x128 tile only
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 3, NS, AT>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+    else
+        return DBN_ERR_ARG;
+    return dbn_status();
+}
+
+// the four tile configurations of one (NS, AT) family
+template <int NS, int AT>
+int launch_igemm_cfg(IgemmParams& p, int cfg, int mode, hipStream_t st) {
+    switch (cfg) {
+        case 1: return launch_igemm_ns<128, 128, 2, 2, NS, AT>(p, mode, st);
+        case 2: return launch_igemm_ns<256, 64, 4, 1, NS, AT>(p, mode, st);
+        case 3: return launch_igemm_ns<128, 64, 2, 2, NS, AT>(p, mode, st);
+        default: return launch_igemm_ns<64, 64, 2, 2, NS, AT>(p, mode, st);
+    }
+}
+
+}  // namespace

@@ -116,7 +116,7 @@ class Engine:
         # images/s): the planes are three separate tensors, so a row's k-tile arrives as 6 pieces of 16 B from 3 distant lines
         # instead of one 64-byte run, and the gather, not the split arithmetic, is what bounds these kernels (igemm<128,64> 382 vs
         # 273 us; 165 us would be MFMA-bound).  Kept as an option; an interleaved [.., C/16][3][16] plane layout is the next step.
-        self.presplit = os.environ.get('DBN_PRESPLIT', '0') == '1'
+        self.presplit = os.environ.get('DBN_PRESPLIT', '0') == '1' and bool(self.L.dbn_has_experiments())  # (EXP=1 builds only)
         self.prof = None  # optional KernelTimer
         self.grad_ready_hook = None  # optional callable(stage): a contiguous part of the flat gradient buffer is final (train.GRAD_STAGES)
         self.ns = 0  # conv math: 0 = exact-fp32 MFMA, 3 = fp32-accurate bf16x3 split, 1 = one 16-bit plane

@@ -220,6 +220,11 @@ int dbn_pixel_confusion(const float* preds, long batch_stride, const float* gt, 
 int dbn_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, int step,
                   float grad_scale, void* stream);
 
+/* 1 when the library was built with -DDBN_EXPERIMENTS (make -C csrc EXP=1): adds the variants that were measured and rejected —
+ * pre-split bf16 planes (at = 3, dbn_split3), the LDS-DMA fp32 weight gradient (dbn_set_wgrad_variant(1)), DBN_* environment
+ * overrides of the tile / split heuristics.  The product library (default) has none of them: no getenv anywhere. */
+int dbn_has_experiments(void);
+
 /* ---- measurement aid (bench.py, no reference counterpart): one wave samples the shader clock (s_memtime) against the constant
  * reference clock (s_memrealtime) over `microseconds`; out2 = {shader cycles, reference ticks} (two uint64 in device memory).
  * dbn_wall_clock_khz: the reference clock's rate.  sustained MHz = cycles / ticks * khz / 1000 */

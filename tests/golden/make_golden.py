@@ -113,29 +113,50 @@ def case_train(name, n, size, seed, img_scale=1.0, full_maps=True, steps=1, arch
     return m
 
 
-def case_fp64(name, n, size, seed):
-    """The reference evaluated in DOUBLE (model.double()) next to its own fp32 run, same weights and inputs: per parameter
-    the fp64 gradient (norm + strided sample) and the distance of the reference's fp32 gradient from it.  The GPU test
-    requires the HIP gradient to be no further from the fp64 gradient than 1.5x that distance (tests/test_model_gpu.py)."""
+def case_fp64(name, n, size, seed, arch='resnet18', bn3_gain=None):
+    """The reference evaluated in DOUBLE (model.double()) next to its own fp32 run AND its own run under
+    torch.autocast('cpu', dtype=torch.bfloat16) (the forward in autocast, DBLoss on preds.float() — how the reference would
+    be run in bf16), same weights and inputs.  Stored: the fp64 losses / maps (strided sample) / per-parameter gradients
+    (norm + strided sample), and for the fp32 and the bf16-autocast run the losses, the same map samples and the per-parameter
+    distance of the gradient from the fp64 one.  The GPU tests require the HIP paths to be no further from fp64 than a small
+    multiple of what the reference's own arithmetic at that precision is (tests/test_model_gpu.py)."""
     print('==', name)
     img, gts = O.synthetic_batch(n, size, seed=seed + 100)
     grads = {}
-    out = {'meta': np.array([n, size, seed, 1])}
-    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
-        m = make_ref(seed).to(dt).train()
-        preds = m(img.to(dt))
+    out = {'meta': np.array([n, size, seed, 1]), 'bn3_gain': np.array(1.0 if bn3_gain is None else bn3_gain)}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64), ('bf16ac', torch.float32)):
+        m = make_ref(seed, arch)
+        if bn3_gain is not None:  # the same conditioning the GPU tests apply to the 53-layer nets (tools/bf16_dcn_probe.py)
+            with torch.no_grad():
+                for k, p in m.named_parameters():
+                    if k.endswith('bn3.weight'):
+                        p.mul_(bn3_gain)
+        m = m.to(dt).train()
+        if tag == 'bf16ac':
+            with torch.autocast('cpu', dtype=torch.bfloat16):
+                preds = m(img)
+            preds = preds.float()
+        else:
+            preds = m(img.to(dt))
         losses = DBLoss()(preds, gts.to(dt))
         losses[4].backward()
         grads[tag] = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
         out['losses_' + tag] = np.array([float(v) for v in losses])
-        out['preds_' + tag + '/sample'] = preds.detach().double().reshape(-1).numpy()[sample_idx(preds.numel(), 4096)]
+        out['preds_' + tag + '/sample'] = preds.detach().double().reshape(-1).numpy()[sample_idx(preds.numel(), 16384)]
     for k, g64 in grads['f64'].items():
         a = g64.reshape(-1).numpy()
         out['g64/' + k + '/norm'] = np.array(np.sqrt((a * a).sum()))
         out['g64/' + k + '/sample'] = a[sample_idx(a.size)]
         out['ref32_dist/' + k] = np.array(float((grads['f32'][k] - g64).norm()))
-    worst = max(float(out['ref32_dist/' + k] / (out['g64/' + k + '/norm'] + 1e-300)) for k in grads['f64'])
-    print('  worst |g_ref32 - g64| / |g64| = %.3e' % worst)
+        out['refbf16_dist/' + k] = np.array(float((grads['bf16ac'][k] - g64).norm()))
+        out['refbf16_cos/' + k] = np.array(float((grads['bf16ac'][k] * g64).sum() / (grads['bf16ac'][k].norm() * g64.norm() + 1e-300)))
+    for tag in ('ref32_dist', 'refbf16_dist'):
+        worst = max(float(out[tag + '/' + k] / (out['g64/' + k + '/norm'] + 1e-300)) for k in grads['f64'])
+        tot = np.sqrt(sum(float(out[tag + '/' + k])**2 for k in grads['f64']) / sum(float(out['g64/' + k + '/norm'])**2 for k in grads['f64']))
+        print('  %s: worst per-tensor |g - g64| / |g64| = %.3e, whole model %.3e' % (tag, worst, tot))
+    for tag in ('f32', 'bf16ac'):
+        d = np.abs(out['preds_' + tag + '/sample'] - out['preds_f64/sample'])
+        print('  maps %s vs f64: max %.3e mean %.3e; losses %s' % (tag, d.max(), d.mean(), out['losses_' + tag] - out['losses_f64']))
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
@@ -284,6 +305,8 @@ if __name__ == '__main__':
         sys.exit(0)
     if '--only-fp64' in sys.argv:
         case_fp64('fp64_2x128', 2, 128, seed=2)
+        case_fp64('fp64_r50_2x96', 2, 96, seed=12, arch='resnet50')
+        case_fp64('fp64_r50_2x96_bn3x02', 2, 96, seed=12, arch='resnet50', bn3_gain=0.2)
         sys.exit(0)
     if '--only-r50' in sys.argv:
         check_oracle('resnet50')
@@ -304,6 +327,8 @@ if __name__ == '__main__':
     case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')
     case_train('r50_train_2x96', 2, 96, seed=12, steps=1, arch='resnet50')
     case_fp64('fp64_2x128', 2, 128, seed=2)
+    case_fp64('fp64_r50_2x96', 2, 96, seed=12, arch='resnet50')
+    case_fp64('fp64_r50_2x96_bn3x02', 2, 96, seed=12, arch='resnet50', bn3_gain=0.2)
     if '--no-640' not in sys.argv:
         case_train('cfg1_2x640', 2, 640, seed=0, full_maps=False, steps=3)
         case_train('cfg2_16x640', 16, 640, seed=16, full_maps=False, steps=1, map_sample=4096)

@@ -220,39 +220,79 @@ def test_cfg2_16x640_vs_reference_golden(golden_dir, math):
 _DEAD_BIAS = ('conv.bias', '.0.bias', '.3.bias')
 
 
-def test_gradients_are_as_close_to_fp64_as_the_reference_is(golden_dir):
-    """DESIGN §4's claim as an assertion.  Two fp32 implementations disagree on the gradients by ~1 % in L2 because each
+# (golden, backbone, precision mode): the reference's own distance from fp64 at that precision is the yardstick
+_FP64_CASES = [('fp64_2x128', 'resnet18', 'f32'), ('fp64_r50_2x96', 'resnet50', 'f32'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'f32'),
+               ('fp64_2x128', 'resnet18', 'bf16x3'), ('fp64_2x128', 'resnet18', 'bf16'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'bf16'),
+               ('fp64_r50_2x96', 'resnet50', 'bf16')]
+
+
+@pytest.mark.parametrize('case,arch,math', _FP64_CASES)
+def test_distance_to_fp64_is_within_the_references_own(golden_dir, case, arch, math):
+    """DESIGN §4's claim as an assertion, for every precision mode and both block types (BasicBlock: resnet.py:70-91,
+    Bottleneck: resnet.py:94-159).  Two implementations at the same precision disagree on the gradients because each
     flips the ReLU mask of different near-zero activations; neither is "right".  Ground truth: the same weights and inputs
-    evaluated in DOUBLE (oracle in fp64, pinned to the reference's own .double() run by tests/golden/fp64_2x128.npz and
-    tests/test_oracle_golden.py).  Per parameter tensor the HIP gradient must be no further from the fp64 gradient than
-    1.5x the distance of the REFERENCE's fp32 gradient from it (plus 2e-5 of the gradient norm for the tensors where the
-    reference's own distance is at round-off level)."""
-    z = np.load(os.path.join(golden_dir, 'fp64_2x128.npz'))
+    evaluated in DOUBLE (oracle in fp64, pinned to the reference's own .double() run by the golden and
+    tests/test_oracle_golden.py).  Yardstick: how far the REFERENCE ITSELF is from that ground truth — in fp32 for the
+    'f32' / 'bf16x3' modes, under torch.autocast('cpu', bfloat16) for the native 'bf16' mode (tests/golden/make_golden.py
+    case_fp64).  Required of the HIP path:
+      per parameter tensor  |g_hip - g64| <= F_t * |g_ref - g64| + 2e-5 |g64|       (F_t = 1.5 fp32, 2.0 bf16)
+      whole model           |g_hip - g64| <= F_m * |g_ref - g64|                     (F_m = 1.2 fp32, 1.5 bf16)
+      maps (strided sample) mean |map_hip - map64| <= 1.5 * reference's + 1e-6; P,T max likewise (+2e-5)
+      losses                max_i |l_hip - l64| <= 1.5 * max_i |l_ref - l64| + 2e-6.
+    '_bn3x02': every bn3 gain scaled by 0.2 (the conditioning of the deep-net bf16 tests; the as-initialised 53-layer net
+    amplifies perturbations ~1e3x — measured and stated by the 'fp64_r50_2x96' rows, which run the unconditioned net)."""
+    z = np.load(os.path.join(golden_dir, case + '.npz'))
     n, size, seed, _ = (int(v) for v in z['meta'])
     img, gts = O.synthetic_batch(n, size, seed=seed + 100)
-    sd = O.new_state(seed)
+    sd = O.new_state(seed, arch)
+    gain = float(z['bn3_gain'])
+    if gain != 1.0:
+        for k in sd:
+            if k.endswith('bn3.weight'):
+                sd[k] = sd[k] * gain
     _, l64, g64 = O.loss_and_grads(O.to_dtype(sd, torch.float64), img.double(), gts.double())
-    assert np.allclose(l64, z['losses_f64'], rtol=1e-12)
-    model = make_model(seed).train()
+    assert np.allclose(l64, z['losses_f64'], rtol=1e-10)
+    bf16 = math == 'bf16'
+    ref_tag, dist_tag = ('bf16ac', 'refbf16_dist/') if bf16 else ('f32', 'ref32_dist/')
+    f_t, f_m = (2.0, 1.5) if bf16 else (1.5, 1.2)
+    model = make_model(seed, arch)
+    model.load_state_dict(sd)
+    model = model.train()
+    model.engine.set_conv_math(math)
     tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = tr.step(img.to(DEV), gts.to(DEV))
-    report('losses vs fp64', losses.cpu().double(), torch.tensor(l64).double(), 2e-6, 2e-6)
-    worst, worst_k, tot_h, tot_r = 0.0, None, 0.0, 0.0
+    # losses
+    dl_h = np.abs(losses.cpu().double().numpy() - z['losses_f64']).max()
+    dl_r = np.abs(z['losses_' + ref_tag] - z['losses_f64']).max()
+    # maps on the golden's strided sample
+    p64 = z['preds_f64/sample']
+    idx = torch.from_numpy(sample_idx(preds.numel(), p64.size))
+    ph = preds.detach().double().cpu().reshape(-1)[idx].numpy()
+    ch = (idx.numpy() // (size * size)) % 3
+    d_h, d_r = np.abs(ph - p64), np.abs(z['preds_' + ref_tag + '/sample'] - p64)
+    print('%s %s %s: losses max|d| hip %.3e ref %.3e; maps mean hip %.3e ref %.3e; P,T max hip %.3e ref %.3e' %
+          (case, arch, math, dl_h, dl_r, d_h.mean(), d_r.mean(), d_h[ch < 2].max(), d_r[ch < 2].max()))
+    worst, worst_k, tot_h, tot_r, bad = 0.0, None, 0.0, 0.0, []
     for k, g in g64.items():
         if g is None or k.endswith(_DEAD_BIAS):
             continue
         nrm = float(z['g64/' + k + '/norm'])
-        d_ref = float(z['ref32_dist/' + k])
+        d_ref = float(z[dist_tag + k])
         d_hip = float((model.engine.grad_views[k].double().cpu() - g).norm())
         tot_h += d_hip**2
         tot_r += d_ref**2
         ratio = d_hip / (d_ref + 2e-5 * nrm)
         if ratio > worst:
             worst, worst_k = ratio, k
-        assert d_hip <= 1.5 * d_ref + 2e-5 * nrm, (k, d_hip, d_ref, nrm)
-    print('fp64 check: worst d_hip/d_ref %.3f (%s); whole-model |g_hip-g64| %.4e vs reference %.4e' %
-          (worst, worst_k, tot_h**0.5, tot_r**0.5))
-    assert tot_h**0.5 <= 1.2 * tot_r**0.5
+        if d_hip > f_t * d_ref + 2e-5 * nrm:
+            bad.append((k, d_hip, d_ref, nrm))
+    print('fp64 check: worst d_hip/d_ref %.3f (%s); whole-model |g_hip-g64| %.4e vs reference %.4e (ratio %.3f)' %
+          (worst, worst_k, tot_h**0.5, tot_r**0.5, (tot_h / tot_r)**0.5))
+    assert dl_h <= 1.5 * dl_r + 2e-6
+    assert d_h.mean() <= 1.5 * d_r.mean() + 1e-6
+    assert d_h[ch < 2].max() <= 1.5 * d_r[ch < 2].max() + 2e-5
+    assert not bad, bad
+    assert tot_h**0.5 <= f_m * tot_r**0.5
 
 
 def test_cfg4_r50dcn_800_bs8_f32_and_bf16():

@@ -966,6 +966,11 @@ def test_batchnorm_and_pool_kernels_on_16bit_storage(dtype):
         report('16-bit %s %s' % (dtype, k), a[k], b[k], tol * float(b[k].abs().max()), tol)
 
 
+needs_experiments = pytest.mark.skipif(not _lib.lib().dbn_has_experiments(),
+                                       reason='variant measured slower and left out of the product library (make -C csrc EXP=1 builds it)')
+
+
+@needs_experiments
 @pytest.mark.parametrize('tile', [0, 1, 2, 4])
 def test_presplit_bf16x3_operands(tile):
     """dbn_split3 + the at = DBN_AT_SPLIT3 entry points: an fp32 tensor split once into three bf16 planes (a0 + a1 + a2 == a
@@ -999,6 +1004,7 @@ def test_presplit_bf16x3_operands(tile):
     assert torch.equal(ga, gb)
 
 
+@needs_experiments
 @pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 20, 12), (3, 128, 256, 1, 1, 0, 9, 7), (2, 64, 128, 3, 2, 1, 16, 16), (1, 256, 256, 3, 1, 1, 12, 12),
                                   (2, 3, 64, 7, 2, 3, 32, 40), (2, 64, 64, 2, 2, 0, 10, 12)])
 def test_weight_gradient_lds_dma_variant(case):

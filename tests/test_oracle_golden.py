@@ -65,14 +65,22 @@ def test_oracle_cfg2_full_size_golden_is_self_consistent(golden_dir):
     assert abs(l[3] - (l[0] + 10.0 * l[1])) < 1e-5 and abs(l[4] - (l[2] + l[3])) < 1e-5  # losses.py:129-136
 
 
-def test_oracle_fp64_matches_reference_in_double(golden_dir):
-    """The fp64 fixture (reference .double() next to its own fp32 run, tests/golden/make_golden.py:case_fp64) pins the
-    oracle evaluated in double, which the GPU gradient test uses as the ground truth."""
+@pytest.mark.parametrize('case,arch', [('fp64_2x128', 'resnet18'), ('fp64_r50_2x96', 'resnet50'), ('fp64_r50_2x96_bn3x02', 'resnet50')])
+def test_oracle_fp64_matches_reference_in_double(golden_dir, case, arch):
+    """The fp64 fixtures (reference .double() next to its own fp32 and bf16-autocast runs, tests/golden/make_golden.py:case_fp64)
+    pin the oracle evaluated in double, which the GPU gradient tests use as the ground truth — BasicBlock and Bottleneck nets."""
     torch.set_num_threads(8)
-    z = np.load(os.path.join(golden_dir, 'fp64_2x128.npz'))
+    z = np.load(os.path.join(golden_dir, case + '.npz'))
     n, size, seed, _ = (int(v) for v in z['meta'])
     img, gts = O.synthetic_batch(n, size, seed=seed + 100)
-    sd = O.new_state(seed)
+    sd = O.new_state(seed, arch)
+    if float(z['bn3_gain']) != 1.0:
+        for k in sd:
+            if k.endswith('bn3.weight'):
+                sd[k] = sd[k] * float(z['bn3_gain'])
+    # the autocast leg is a yardstick, not something the oracle restates: it must at least be the noisier one
+    assert sum(float(z['refbf16_dist/' + k[4:-5]])**2 for k in z.files if k.startswith('g64/') and k.endswith('/norm')) > \
+        sum(float(z['ref32_dist/' + k[4:-5]])**2 for k in z.files if k.startswith('g64/') and k.endswith('/norm'))
     _, l64, g64 = O.loss_and_grads(O.to_dtype(sd, torch.float64), img.double(), gts.double())
     _, l32, g32 = O.loss_and_grads(sd, img, gts)
     assert np.allclose(l64, z['losses_f64'], rtol=1e-12) and np.allclose(l32, z['losses_f32'], rtol=1e-6)
