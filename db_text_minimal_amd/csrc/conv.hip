@@ -184,11 +184,22 @@ static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipS
 static inline int dst_esize(int at) { return (at == 0 || at == 3) ? 4 : 2; }
 static inline int src_planes(int at) { return at == 3 ? 3 : 1; }
 
+// optional BatchNorm-backward sums of a call (IgemmParams::bnb_*); y / zmask advance with dst over image chunks
+struct IgemmBnb {
+    const void *y, *zmask;
+    const float *msc, *msh, *mean, *rstd;
+    float* part;
+};
+
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
                          hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
-                         long plane_bytes) {
+                         long plane_bytes, const IgemmBnb* bnb = nullptr) {
     IgemmParams p;
+    p.bnb_y = bnb ? bnb->y : nullptr; p.bnb_zmask = bnb ? bnb->zmask : nullptr;
+    p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
+    p.bnb_mean = bnb ? bnb->mean : nullptr; p.bnb_rstd = bnb ? bnb->rstd : nullptr;
+    p.bnb_part = bnb ? bnb->part : nullptr;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
@@ -206,7 +217,7 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
         }
         // split-K: slabs of partial sums, then a fixed-order reduction that also applies bias / accumulate
         const int KT = (R * S * Cs + 15) / 16;
-        DBN_REQUIRE(slab && !stats && Cs % 16 == 0 && ksplit <= KT && ksplit <= 64);
+        DBN_REQUIRE(slab && !stats && !bnb && Cs % 16 == 0 && ksplit <= KT && ksplit <= 64);
         p.kt_per = dbn_ceil_div(KT, ksplit);
         p.ksplit = dbn_ceil_div(KT, p.kt_per);
         p.dst = slab; p.bias = nullptr; p.accumulate = 0;
@@ -231,6 +242,7 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     }
     DBN_REQUIRE(off < (1L << 31));
     DBN_REQUIRE(covered == p.ncls || !bias);  // a bias would have to reach the tap-less pixels too
+    DBN_REQUIRE(covered == p.ncls || !bnb);   // ... and so would the BatchNorm-backward sums
     if (covered < p.ncls && !accumulate) {  // some output pixels receive no tap: they are zero
         if (hipMemsetAsync(dst, 0, (size_t)N * Hd * Wd * Cd * dst_esize(at), st) != hipSuccess) return dbn_status();
         p.accumulate = 1;
@@ -257,7 +269,8 @@ static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg
 
 static int igemm_run(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
-                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0) {
+                     void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0,
+                     const IgemmBnb* bnb = nullptr) {
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     // 16-bit storage / pre-split planes: 8-channel pieces of 16-channel blocks
     DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0) || (at == 3 && ns == 3 && Cs % 16 == 0));
@@ -278,9 +291,16 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
         int rows = 0;
+        IgemmBnb b;
+        if (bnb) {
+            b = *bnb;
+            b.y = reinterpret_cast<const char*>(bnb->y) + (long)n0 * Hd * Wd * Cd * des;
+            if (bnb->zmask) b.zmask = reinterpret_cast<const char*>(bnb->zmask) + (long)n0 * Hd * Wd * Cd * des;
+        }
         const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
                                      reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
-                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes);
+                                     pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes,
+                                     bnb ? &b : nullptr);
         if (rc) return rc;
         row0 += rows;
     }
@@ -311,6 +331,32 @@ static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, i
     int rows = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) rows += bn_tile_rows_one(std::min(nmax, N - n0), Hd, Wd, mode, stride, cfg);
     return rows;
+}
+
+// Rows of per-tile partials a dbn_conv_bn_t / dbn_igemm_bnsums_t call with these arguments writes (its `part` array is
+// [2][Cd][rows] floats; dbn_bn_backward_t takes it as `sums` with sums_parts = rows).
+int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode,
+                      int tile_hint) {
+    return bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
+}
+
+// dbn_igemm_t (no split-K) whose epilogue ALSO reduces, per channel and output tile, the two sums of the BatchNorm backward that
+// consumes dst: dst is the gradient of the (ReLU'd) output of a BatchNorm with input y (same shape / storage as dst), saved
+// mean / rstd, and ReLU mask either `zmask` > 0 (a saved activation of that shape) or fma(y, mask_scale, mask_shift) > 0 (the
+// BatchNorm's own output recomputed).  The sums are taken over the FINAL dst values (after `accumulate`), so the call must be
+// the last writer of dst.  part: [2][Cd][dbn_igemm_bn_rows(...)] floats.  Replaces the reduce pass of dbn_bn_backward_t (which
+// re-reads dst and y): pass `part` as its `sums`.  Exact-fp32 math on fp32 tensors (at = 0, ns = 0) only.
+int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                       int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
+                       const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
+                       const float* save_rstd, float* part, void* stream) {
+    DBN_REQUIRE(at == 0 && ns == 0 && y && save_mean && save_rstd && part && (zmask || (mask_scale && mask_shift)));
+    DBN_REQUIRE(!(mode == 1 && stride > 1));  // (parity-class launches: not built, see launch_igemm_ns)
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
+    DBN_REQUIRE(rows > 0);
+    const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part};
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr, 1,
+                     nullptr, rows, at, &b);
 }
 
 // floats of scratch for the fused conv + BatchNorm-statistics call
@@ -430,6 +476,7 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * des;
         p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
+        p.bnb_y = p.bnb_zmask = nullptr; p.bnb_msc = p.bnb_msh = p.bnb_mean = p.bnb_rstd = nullptr; p.bnb_part = nullptr;
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
         p.ksplit = 1; p.kt_per = 0; p.patch = 0;

@@ -73,6 +73,15 @@ struct IgemmParams {
     int stat_rows;      // rows of the partials array (all M-tiles of the call; a call over many images runs as several launches)
     int stat_row0;      // first row this launch writes
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
+    // optional (EPI = 1 instantiations): dst is the gradient dz of a BatchNorm's (ReLU'd) output; the epilogue also reduces, per
+    // channel and tile, the two sums of that BatchNorm's backward over the FINAL dst values (after accumulate):
+    //   g = dz * [mask > 0],  bnb_part[0][c][row] = sum g,  bnb_part[1][c][row] = sum g * (y - mean[c]) * rstd[c]
+    // y (the BatchNorm's input, same shape / layout / storage type as dst); mask = bnb_zmask (a saved activation of that shape)
+    // or, without it, the BatchNorm's own output recomputed as fma(y, bnb_msc[c], bnb_msh[c]); rows as for `stats`.
+    const void* bnb_y;
+    const void* bnb_zmask;
+    const float *bnb_msc, *bnb_msh, *bnb_mean, *bnb_rstd;
+    float* bnb_part;
     unsigned src_bytes;
     unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)

@@ -30,8 +30,10 @@ namespace {
 // split for every one of the 9 taps that re-reads an element and made the bf16x3 kernels VALU-bound); dst is fp32.
 // PATCH (3x3, stride 1, pad 1, 16-bit matrix math; Hd % 8 == 0, Wd % 16 == 0, Cs % 32 == 0): the M tile is an 8 x 16 PIXEL PATCH
 // and the A operand is not gathered per tap at all — see the main loop.
-template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false>
+// EPI = 1: the epilogue also produces the partial sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_*).
+template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) void igemm_f32_kernel(const IgemmParams p) {
+    static_assert(EPI == 0 || (AT == 0 && MODE < 2 && !PATCH), "BatchNorm-backward sums: fp32 storage, generic loop, no parity classes");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
@@ -957,6 +959,111 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
         if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)min(BM, qM - m0);
     }
 
+    // ---- optional sums of the BatchNorm backward that consumes dst (see IgemmParams::bnb_part).  The accumulators hold the final
+    // dz values here.  y (and the mask tensor) have dst's layout, so a lane reads them at the offsets it stores to: per row 32
+    // consecutive floats per half-wave, four rows (4 x NI loads, twice with a mask tensor) in flight before their use.
+    if constexpr (EPI == 1) {
+        __syncthreads();  // (the LDS panels are dead after the k-loop; the accumulate path may have used the region too)
+        float* red = reinterpret_cast<float*>(smem);
+        float* r1 = red;            // [WM][BN]
+        float* r2 = r1 + WM * BN;   // [WM][BN]
+        const float* const yb = reinterpret_cast<const float*>(p.bnb_y);
+        const float* const zb = reinterpret_cast<const float*>(p.bnb_zmask);
+        float mu[NI], rs[NI], msc[NI], msh[NI], s1[NI], s2[NI];
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int c = n0 + wn * TN + b * 32 + li;
+            mu[b] = p.bnb_mean[c];
+            rs[b] = p.bnb_rstd[c];
+            msc[b] = zb ? 0.f : p.bnb_msc[c];
+            msh[b] = zb ? 0.f : p.bnb_msh[c];
+            s1[b] = s2[b] = 0.f;
+        }
+        const long ycol = n0 + wn * TN + li;
+        // branch-free bodies (one per mask kind): with a conditional load or a short-circuit `&&` inside, the row groups become
+        // basic blocks of their own, the scheduling fences below no longer bound anything, and the compiler issued all MI*16*NI
+        // loads of the tile before the first use (246 registers, one wave per SIMD)
+        auto sums = [&](auto ZM) {
+            constexpr bool kZ = decltype(ZM)::value;
+            constexpr int RB = NI >= 2 ? 2 : 4;  // rows in flight (RB * NI loads per tensor)
+            auto body = [&](int a, int r0, const unsigned (&off)[RB], unsigned okm) {
+                float yv[RB][NI], zv[RB][kZ ? NI : 1];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        // (rows past M point at a valid pixel: the loads are unpredicated, the sums are not)
+                        yv[i][b] = yb[(long)off[i] + ycol + b * 32];
+                        if constexpr (kZ) zv[i][b] = zb[(long)off[i] + ycol + b * 32];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        const float y_ = yv[i][b];
+                        float m_;
+                        if constexpr (kZ) m_ = zv[i][b];
+                        else m_ = dbn_affine(y_, msc[b], msh[b]);
+                        const bool on = ((okm >> i) & 1u) & (m_ > 0.f);
+                        const float g = on ? acc[a][b][r0 + i] : 0.f;
+                        s1[b] += g;
+                        s2[b] += g * ((y_ - mu[b]) * rs[b]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int a = 0; a < MI; ++a) {
+                if constexpr (MODE >= 2) {
+                    // the parity-class pixel walk has loops: all 16 row offsets first, then branch-free load / use groups
+                    unsigned offs[16], okm = 0;
+                    for_rows(a, [&](int r, bool ok, long doff) {
+                        offs[r] = (unsigned)doff;  // (element offsets fit 32 bits: checked on the host)
+                        okm |= (ok ? 1u : 0u) << r;
+                    });
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += RB) {
+                        unsigned o_[RB];
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) o_[i] = offs[r0 + i];
+                        body(a, r0, o_, okm >> r0);
+                    }
+                } else {
+                    unsigned o_[RB], okm = 0;
+                    for_rows(a, [&](int r, bool ok, long doff) {
+                        o_[r % RB] = (unsigned)doff;
+                        okm = (r % RB == 0 ? 0u : okm) | ((ok ? 1u : 0u) << (r % RB));
+                        if (r % RB == RB - 1) body(a, r - (RB - 1), o_, okm);
+                    });
+                }
+            }
+        };
+        if (zb) sums(std::true_type{});
+        else sums(std::false_type{});
+#pragma unroll
+        for (int b = 0; b < NI; ++b) {
+            const int cl = wn * TN + b * 32 + li;
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32, 64), t2 = s2[b] + __shfl_xor(s2[b], 32, 64);
+            if (lh == 0) {
+                r1[wm * BN + cl] = t1;
+                r2[wm * BN + cl] = t2;
+            }
+        }
+        __syncthreads();
+        const int trow = p.stat_row0 + q_row_base + mt;
+        for (int cl = tid; cl < BN; cl += NT) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                t1 += r1[w * BN + cl];
+                t2 += r2[w * BN + cl];
+            }
+            const long c = n0 + cl;
+            p.bnb_part[(0L * p.Cd + c) * p.stat_rows + trow] = t1;
+            p.bnb_part[(1L * p.Cd + c) * p.stat_rows + trow] = t2;
+        }
+    }
+
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // the bias values of this lane's NI columns are loaded once (inside the row loop the compiler re-loaded them for every
     // row, behind a vmcnt(0) wait, because the stores may alias them)
@@ -1048,6 +1155,20 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
         }
     }
     if (p.patch) return DBN_ERR_ARG;
+    if (p.bnb_part) {  // with the sums of the BatchNorm backward that consumes dst (exact fp32 on fp32 tensors only)
+        if constexpr (NS == 0 && AT == 0) {
+            if (gy != 1 || !p.bnb_y || !p.bnb_mean || !p.bnb_rstd || !(p.bnb_zmask || (p.bnb_msc && p.bnb_msh))) return DBN_ERR_ARG;
+            if (mode == 0)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+            else if (mode == 1)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+            else  // (parity classes: not instantiated — the pixel walk's loops keep the epilogue at one wave per SIMD; the callers
+                return DBN_ERR_ARG;  //  take the separate reduce pass there)
+            return dbn_status();
+        } else {
+            return DBN_ERR_ARG;
+        }
+    }
     if (mode == 0)
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT>), dim3(grid, gy), dim3(WM * WN * 64), 0, st, p);
     else if (mode == 1)

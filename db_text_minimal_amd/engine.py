@@ -40,8 +40,9 @@ def flat_layout(numels):
     return offs, total
 
 
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s>',
-                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s>'}  # rocprof names
+# rocprof names: <BM,BN,WM,WN,MODE,NS,AT,PATCH,EPI> (EPI = 1: epilogue with the sums of the consuming BatchNorm's backward)
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s,%d>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s,%d>'}
 WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d>',
                     3: 'wgrad_f32_kernel<64,128,2,2,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d>'}
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
@@ -109,6 +110,7 @@ class Engine:
         self._live = None
         self.nbt_pending = {}
         self._bias_done = set()
+        self._bnb_sums = {}     # bn name -> (partials [2][C][rows], rows) produced by the data gradient that wrote its dout
         self._by_ptr = {}       # data_ptr -> activation buffer (to find the pre-split planes of an operand)
         self._plane_cache = {}  # data_ptr -> (planes, generation)
         # 'bf16x3' mode, optional (DBN_PRESPLIT=1 / engine.presplit): MFMA operands read from pre-split bf16 planes (made once per
@@ -324,10 +326,40 @@ class Engine:
                 return 3, self._planes(t).data_ptr()
         return self.at, ptr
 
-    def _igemm(self, what, *args):
-        """args = the dbn_igemm_f32 argument list without the trailing stream."""
+    fuse_bn_bwd_sums = True  # data gradients also reduce the two sums of the BatchNorm backward that consumes their output
+
+    def _bnb_eligible(self, args):
+        """Can this igemm call (dbn_igemm_f32 argument list) carry the BatchNorm-backward sums of its consumer?"""
+        N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
+        if not self.fuse_bn_bwd_sums or self.at != 0 or self.ns != 0 or self._use_planes or (mode == 1 and stride > 1):
+            return False
+        if self.prof is not None and self.prof.labels is None and not self.prof_fused:
+            return False
+        return not (self.splitk and self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs) > 1)
+
+    prof_fused = True
+
+    def _igemm(self, what, *args, consumer=None):
+        """args = the dbn_igemm_f32 argument list without the trailing stream.
+        consumer: (bn_name, y, zmask) — the BatchNorm whose output gradient this call is the LAST writer of (zmask None: ReLU
+        directly on that BatchNorm, mask recomputed from y).  When the call is eligible its epilogue also produces that
+        BatchNorm-backward's two per-channel sums; they wait in self._bnb_sums[bn_name] for bn_backward()."""
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
         at, srcp = self._src(args[0], Cs)
+        if consumer is not None and self._bnb_eligible(args):
+            bn_name, y, zmask = consumer
+            assert tuple(y.shape) == (N, Hd, Wd, Cd) and (zmask is None or zmask.shape == y.shape), (what, bn_name)
+            hint = args[17]
+            rows = self.L.dbn_igemm_bn_rows(at, self.ns, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, hint)
+            part = self.fbuf(bn_name + '/bnb_part', 2 * Cd * rows)
+            msc = msh = None
+            if zmask is None:
+                msc, msh = self.bufs[bn_name + '/scale'], self.bufs[bn_name + '/shift']
+            check(self.L.dbn_igemm_bnsums_t(at, self.ns, srcp, *args[1:], y.data_ptr(), _p(zmask), _p(msc), _p(msh),
+                                            self.bufs[bn_name + '/mean'].data_ptr(), self.bufs[bn_name + '/rstd'].data_ptr(),
+                                            part.data_ptr(), self.stream), what)
+            self._bnb_sums[bn_name] = (part, rows)
+            return
         ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):
             ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
@@ -446,7 +478,7 @@ class Engine:
             self.prof.end()
         return y, sc, sh
 
-    def _prof_igemm(self, M, Cd, flops, tag='', mode=0, geom=None):
+    def _prof_igemm(self, M, Cd, flops, tag='', mode=0, geom=None, epi=0):
         """geom = (N, Hs, Ws, Cs, Hd, Wd, R, stride, pad) of a forward / stride-1 data-gradient call: only those can take the
         pixel-patch kernel (the last template argument of the symbol)."""
         cfg = self.L.dbn_igemm_tile_config(M, Cd)
@@ -455,17 +487,21 @@ class Engine:
             N, Hs, Ws, Cs, Hd, Wd, R, stride, pad = geom
             ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * R * Cs, Cs) if self.splitk else 1
             cfg = self.L.dbn_igemm_kernel_config(at, self.ns, mode, N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, 0, ks)
-        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false'), flops, 0.0, tag)
+        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi), flops, 0.0, tag)
 
-    def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None):
+    def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None, consumer=None):
+        """consumer: see _igemm — the BatchNorm that will consume dx, when this call is dx's last writer."""
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
         wpk = self.pack(name, conv.weight, 1, conv.stride, version=version)
+        args = (dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k, conv.stride, conv.padding, 1,
+                int(accumulate), 0)
+        if consumer is not None and not self._bnb_eligible(args):
+            consumer = None
         if self.prof:  # algorithmic FLOPs of a data gradient = those of the forward conv
             self._prof_igemm(N * H * W, I, 2.0 * N * Ho * Wo * O * I * conv.k * conv.k, 'dgrad ' + name, 2 if conv.stride == 2 else 1,
-                             (N, Ho, Wo, O, H, W, conv.k, conv.stride, conv.padding))
-        self._igemm('igemm dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k,
-                    conv.stride, conv.padding, 1, int(accumulate), 0)
+                             (N, Ho, Wo, O, H, W, conv.k, conv.stride, conv.padding), epi=int(consumer is not None))
+        self._igemm('igemm dgrad ' + name, *args, consumer=consumer)
         if self.prof:
             self.prof.end()
 
@@ -514,14 +550,16 @@ class Engine:
             self.prof.end()
         return y
 
-    def convT_bwd(self, name, dy, x, ct, dx):
+    def convT_bwd(self, name, dy, x, ct, dx, consumer=None):
         N, H2, W2, Co = dy.shape
         _, H, W, Ci = x.shape
         wpk = self.pack(name, ct.weight, 0)
+        args = (dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2, 2, 0, 0, 0, 0)
+        if consumer is not None and not self._bnb_eligible(args):
+            consumer = None
         if self.prof:
-            self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4, 'convT dgrad ' + name, 0)
-        self._igemm('igemm convT dgrad ' + name, dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, H2, W2, Co, H, W, Ci, 2, 2,
-                    2, 0, 0, 0, 0)
+            self._prof_igemm(N * H * W, Ci, 2.0 * N * H * W * Ci * Co * 4, 'convT dgrad ' + name, 0, epi=int(consumer is not None))
+        self._igemm('igemm convT dgrad ' + name, *args, consumer=consumer)
         if self.prof:
             self.prof.end()
         self._presplit(x, dy)
@@ -582,6 +620,8 @@ class Engine:
             msc, msh = self.bufs[name + '/scale'], self.bufs[name + '/shift']
         elif mask is not None:
             zmask = mask
+        if sums is None and name in self._bnb_sums:  # produced by the epilogue of the data gradient that wrote dout
+            sums, sums_parts = self._bnb_sums.pop(name)
         dbias = None
         if conv_bias is not None and self.bias_grad_in_bn and 256 % (C // 4) == 0:
             dbias = self.grad_views[conv_bias]
@@ -817,7 +857,7 @@ class Engine:
             self._deform_conv_bwd(name, blk, dy2, z1, dz1)
         else:
             self.conv_wgrad(name + '.conv2', dy2, z1, blk.conv2)
-            self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False)
+            self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False, consumer=(name + '.bn1', self.bufs[name + '/y1'], None))
 
     def _block_fwd(self, name, blk, x, train):
         """BasicBlock (resnet.py:70-91) or Bottleneck (resnet.py:135-159)."""
@@ -847,6 +887,7 @@ class Engine:
         N, H, W, Hh, Wh, resample = self.saved_shape
         B = self.bufs
         self._bias_done = set()
+        self._bnb_sums = {}
         out = self.saved_out  # head output before the (optional) final resample
         dpreds = dpreds.contiguous()
         assert dpreds.shape == (N, 3, H, W)
@@ -878,6 +919,8 @@ class Engine:
             self.prof.end()
         f = B['fpn/z']
         df = self.buf('fpn/dz', *f.shape)
+        fpn = m.segmentation_body
+        pre = 'segmentation_body.'
         for i, (br, dz1) in enumerate((('binarize', dz1b), ('thresh', dz1t))):
             # (running the two branches' backward on two streams was tried: the join before the FPN backward makes the main
             # stream wait for every queued weight gradient and costs more than it gains)
@@ -886,11 +929,13 @@ class Engine:
             dy1 = self.bn_backward(hp + '4', B[br + '/y1'], 'self', dz1, br + '/dy1', sums=bn_sums[2 * i:2 * i + 2],
                                    conv_bias=hp + '3.bias' if seq[3].bias is not None else None)
             dz0 = self.buf(br + '/dz0', *B[br + '/z0'].shape)
-            self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0)
+            self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0, consumer=(hp + '1', B[br + '/y0'], None))
             dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0',
                                    conv_bias=hp + '0.bias' if seq[0].bias is not None else None)
             self.conv_wgrad(hp + '0', dy0, f, seq[0])
-            self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0))
+            # (the second branch's data gradient is the last writer of df: it carries the sums of the FPN output BatchNorm)
+            self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0),
+                            consumer=(pre + 'conv.1', B['fpn/y'], None) if i > 0 else None)
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
         dfy = self.bn_backward(pre + 'conv.1', B['fpn/y'], 'self', df, 'fpn/dy',
@@ -912,11 +957,13 @@ class Engine:
                 self.up_bwd(dcat, d, 64 * i, False)
                 dP[nm] = d
 
-        def cbr_bwd(name, mod, xin, dz, dx, dx_acc):
+        def cbr_bwd(name, mod, xin, dz, dx, dx_acc, consumer=None):
+            """consumer: lateral conv whose BatchNorm consumes dx next (dx = gradient of `up(..) + lateral`: same tensor)"""
             dy = self.bn_backward(pre + name + '.bn', B[name + '/y'], 'self', dz, name + '/dy',
                                   conv_bias=pre + name + '.conv.bias' if mod.conv.bias is not None else None)
             self.conv_wgrad(pre + name + '.conv', dy, xin, mod.conv)
-            self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc)
+            self.conv_dgrad(pre + name + '.conv', dy, mod.conv, dx, dx_acc,
+                            consumer=(pre + consumer + '.bn', B[consumer + '/y'], None) if consumer else None)
 
         # gradient slots of the backbone features (written first by the FPN reduce convs)
         lastb = {i: len(getattr(m.backbone, 'layer%d' % i)) - 1 for i in (1, 2, 3, 4)}  # index of each stage's last block
@@ -926,15 +973,15 @@ class Engine:
         dc2, dc3, dc4, dc5 = (dC[feat[i]] for i in (1, 2, 3, 4))
         # p2 = smooth_p2(p2pre), p2pre = up(p3) + r2
         dp2pre = self.buf('dp2pre', *B['p2pre'].shape)
-        cbr_bwd('smooth_p2', fpn.smooth_p2, B['p2pre'], dP['smooth_p2'], dp2pre, False)
+        cbr_bwd('smooth_p2', fpn.smooth_p2, B['p2pre'], dP['smooth_p2'], dp2pre, False, consumer='reduce_conv_c2')
         self.up_bwd(dp2pre, dP['smooth_p3'], 0, True)
         cbr_bwd('reduce_conv_c2', fpn.reduce_conv_c2, c2, dp2pre, dc2, False)
         dp3pre = self.buf('dp3pre', *B['p3pre'].shape)
-        cbr_bwd('smooth_p3', fpn.smooth_p3, B['p3pre'], dP['smooth_p3'], dp3pre, False)
+        cbr_bwd('smooth_p3', fpn.smooth_p3, B['p3pre'], dP['smooth_p3'], dp3pre, False, consumer='reduce_conv_c3')
         self.up_bwd(dp3pre, dP['smooth_p4'], 0, True)
         cbr_bwd('reduce_conv_c3', fpn.reduce_conv_c3, c3, dp3pre, dc3, False)
         dp4pre = self.buf('dp4pre', *B['p4pre'].shape)
-        cbr_bwd('smooth_p4', fpn.smooth_p4, B['p4pre'], dP['smooth_p4'], dp4pre, False)
+        cbr_bwd('smooth_p4', fpn.smooth_p4, B['p4pre'], dP['smooth_p4'], dp4pre, False, consumer='reduce_conv_c4')
         self.up_bwd(dp4pre, dP['reduce_conv_c5'], 0, True)
         cbr_bwd('reduce_conv_c4', fpn.reduce_conv_c4, c4, dp4pre, dc4, False)
         cbr_bwd('reduce_conv_c5', fpn.reduce_conv_c5, c5, dP['reduce_conv_c5'], dc5, False)
@@ -956,7 +1003,8 @@ class Engine:
                     dx, acc = dC[feat[li - 1]], True
                 else:
                     dx, acc = dpool, False
-                self._block_bwd(name, layer[bi], xin, dout, dx, acc)
+                # (a stage's first block writes dx with parity-class launches: the previous stage's BatchNorm keeps its reduce pass)
+                self._block_bwd(name, layer[bi], xin, dout, dx, acc, prev='backbone.layer%d.%d' % (li, bi - 1) if bi > 0 else None)
             if self.grad_ready_hook is not None and li >= 3:
                 with self.side_stream():
                     self.grad_ready_hook('layer%d' % li)
@@ -1007,7 +1055,7 @@ class Engine:
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co
@@ -1058,10 +1106,14 @@ class Engine:
             d = self.buf(nm + '/dz', *z.shape)
             wpk = self.pack('%s#g%d' % (name, g), wds[g], 0, f, version=wver)
             flops = 2.0 * N * Hg * Wg * Cg * Co * k * k
+            args = (dy.data_ptr(), wpk.data_ptr(), None, d.data_ptr(), N, H, W, Co, Hg, Wg, Cg, k, k, f, 1, 0, 0, 0)
+            # level 0 (p2) receives nothing else: its gradient is final here and carries the sums of smooth_p2's BatchNorm; the
+            # coarser levels are completed by the nearest-upsample adjoints later
+            bn_ = 'segmentation_body.%s.bn' % nm
+            consumer = (bn_, self.bufs[nm + '/y'], None) if (g == 0 and self._bnb_eligible(args)) else None
             if self.prof:
-                self._prof_igemm(N * Hg * Wg, Cg, flops, 'dgrad %s level %d' % (name, g), 0)
-            self._igemm('igemm fpn dgrad', dy.data_ptr(), wpk.data_ptr(), None, d.data_ptr(), N, H, W, Co, Hg, Wg, Cg, k, k, f, 1, 0,
-                        0, 0)
+                self._prof_igemm(N * Hg * Wg, Cg, flops, 'dgrad %s level %d' % (name, g), 0, epi=int(consumer is not None))
+            self._igemm('igemm fpn dgrad', *args, consumer=consumer)
             if self.prof:
                 self.prof.end()
             dP[nm] = d
@@ -1076,7 +1128,10 @@ class Engine:
             if conv.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
-    def _block_bwd(self, name, blk, xin, dout, dx, dx_acc):
+    def _block_bwd(self, name, blk, xin, dout, dx, dx_acc, prev=None):
+        """prev: name of the block whose output is this block's input (None: the stem's pooled map, or a stage boundary) — its
+        last BatchNorm consumes dx with the ReLU mask of its output; the data gradient that writes dx last carries that
+        BatchNorm-backward's sums in its epilogue (stride-1 data gradients only)."""
         B = self.bufs
         out = B[name + '/out']
         has_down = blk.downsample is not None
@@ -1092,7 +1147,7 @@ class Engine:
             z2 = B[name + '/z2']
             self.conv_wgrad(name + '.conv3', dyl, z2, blk.conv3)
             dz2 = self.buf(name + '/dz2', *z2.shape)
-            self.conv_dgrad(name + '.conv3', dyl, blk.conv3, dz2, False)
+            self.conv_dgrad(name + '.conv3', dyl, blk.conv3, dz2, False, consumer=(name + '.bn2', B[name + '/y2'], None))
             dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], 'self', dz2, name + '/dy2')
         else:
             dy2 = dyl
@@ -1101,8 +1156,14 @@ class Engine:
         self._conv2_bwd(name, blk, dy2, z1, dz1)
         dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], 'self', dz1, name + '/dy1')
         self.conv_wgrad(name + '.conv1', dy1, xin, blk.conv1)
-        self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc)
         if has_down:
+            # the shortcut's gradient first: conv1's data gradient then is the last writer of dx
             dyd = self.bn_backward(name + '.downsample.1', B[name + '/yd'], out, dout, name + '/dyd')
             self.conv_wgrad(name + '.downsample.0', dyd, xin, blk.downsample[0])
-            self.conv_dgrad(name + '.downsample.0', dyd, blk.downsample[0], dx, True)
+            self.conv_dgrad(name + '.downsample.0', dyd, blk.downsample[0], dx, dx_acc)
+            dx_acc = True
+        consumer = None
+        if prev is not None:
+            plast = '3' if (prev + '/y3') in B else '2'
+            consumer = (prev + '.bn' + plast, B[prev + '/y' + plast], B[prev + '/out'])
+        self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc, consumer=consumer)

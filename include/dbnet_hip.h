@@ -62,6 +62,23 @@ int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float
 int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream);
 
+/* Data gradient (any dbn_igemm_t mode, no split-K) whose epilogue also reduces the two per-channel sums of the BatchNorm
+ * backward that consumes its output — the backward of the conv -> BN -> ReLU chain of resnet.py:70-91 / basic.py:32-36 with one
+ * pass over dz and y fewer.  dst is the gradient dz of the (ReLU'd) output of a BatchNorm with input y (same shape and storage as
+ * dst), saved mean / rstd; ReLU mask: `zmask` > 0 (a saved activation of that shape) or, with zmask NULL, the BatchNorm's own
+ * output recomputed as fma(y, mask_scale[c], mask_shift[c]) > 0.  Per output tile (row) and channel:
+ *   part[0][c][row] = sum g,   part[1][c][row] = sum g * (y - mean[c]) * rstd[c],   g = dz_final * [mask > 0]
+ * over the FINAL dst values (after `accumulate`): the call must be the last writer of dst.  part: [2][Cd][rows] floats with
+ * rows = dbn_igemm_bn_rows(same geometry); hand it to dbn_bn_backward_t as `sums` with sums_parts = rows.  Exact-fp32 math on
+ * fp32 tensors (at = 0, ns = 0); mode 0 (any stride) and mode 1 with stride 1 (the parity-class launches of strided
+ * transposed convs keep the separate reduce pass). */
+int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode,
+                      int tile_hint);
+int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
+                       int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
+                       const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
+                       const float* save_rstd, float* part, void* stream);
+
 /* Convolution whose epilogue also accumulates the train-mode BatchNorm statistics of its output (per-tile pivot,
  * sum, sum of squares; merged in fp64 by a finalize kernel): one call replaces conv + statistics pass.
  * Arguments: dbn_igemm_f32's, ns = 0 (fp32 MFMA) / 3 / 1 (split-bf16), then dbn_bn_train_stats' BN arguments.

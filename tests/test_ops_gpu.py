@@ -1240,3 +1240,70 @@ def test_pixel_patch_weight_gradient(case, mode_name):
     scale = float(gref.abs().max())
     report('patch wgrad %s %s' % (mode_name, case), g, 0.5 * gref, 2e-5 * scale, 1e-4)
     report('patch vs generic kernels', g, run(2), 2e-5 * scale, 1e-4)
+
+
+# N, Cin (of the forward conv = channels of dx), Cout, k, s, p, H, W, as_forward
+BNSUM_CASES = [(2, 64, 64, 3, 1, 1, 16, 12, False), (1, 256, 128, 3, 1, 1, 12, 12, False), (3, 128, 64, 1, 1, 0, 9, 7, False),
+               (2, 64, 64, 2, 2, 0, 10, 12, True), (1, 64, 128, 3, 2, 1, 18, 14, True), (2, 64, 64, 3, 1, 1, 40, 24, False)]
+
+
+@pytest.mark.parametrize('case', BNSUM_CASES)
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('mask', ['self', 'tensor'])
+@pytest.mark.parametrize('accumulate', [0, 1])
+def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate):
+    """dbn_igemm_bnsums_t: a data gradient (mode 1, stride 1) or a forward-form conv (mode 0, any stride: the ConvTranspose2d
+    data gradient of the head) whose epilogue also reduces the two per-channel sums of the BatchNorm backward that consumes its
+    output (the conv -> BN -> ReLU chain of resnet.py:70-91 / basic.py:32-36 backwards): dst must equal the plain call's bit for
+    bit, and the folded partials must equal sum(g), sum(g * xhat) with g = dz * [mask > 0] evaluated in fp64 on the final dz."""
+    N, Ci, Co, k, s, p, H, W, as_forward = case
+    if tile == 1 and (Co if as_forward else Ci) % 128 != 0:
+        pytest.skip('128-wide tile needs Cd % 128 == 0')
+    if as_forward:  # dst = conv(src): mode 0
+        src = rnd(N, Ci, H, W, seed=1)
+        w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+        dzc = F.conv2d(src, w, None, s, p)
+        wpk, mode, Cd = pack(w, 0), 0, Co
+    else:  # dst = d(input) of conv: mode 1
+        x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+        w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+        yf = F.conv2d(x, w, None, s, p)
+        src = rnd(*yf.shape, seed=4)
+        (dzc, ) = torch.autograd.grad(yf, x, src)
+        wpk, mode, Cd = pack(w, 1, s), 1, Ci
+    Hd, Wd = dzc.shape[2:]
+    srcs = nhwc(src)
+    y = rnd(N, Cd, Hd, Wd, seed=7)
+    mean, rstd = rnd(Cd, seed=8, scale=0.2), rnd(Cd, seed=9).abs() + 0.5
+    msc, msh = rnd(Cd, seed=10), rnd(Cd, seed=11, scale=0.3)
+    z = rnd(N, Cd, Hd, Wd, seed=12)
+    old = rnd(N, Cd, Hd, Wd, seed=13)
+    ys, zs = nhwc(y), nhwc(z)
+    dst = nhwc(old).clone() if accumulate else torch.full((N, Hd, Wd, Cd), float('nan'), device=DEV)
+    plain = nhwc(old).clone() if accumulate else torch.full((N, Hd, Wd, Cd), float('nan'), device=DEV)
+    igemm(srcs, wpk, None, plain, k, s, p, mode, accumulate, tile)
+    a = (0, 0, N, srcs.shape[1], srcs.shape[2], srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode, tile)
+    rows = L().dbn_igemm_bn_rows(*a)
+    assert rows > 0
+    part = torch.full((2, Cd, rows), float('nan'), device=DEV)
+    dev = lambda t: t.to(DEV)
+    mean_d, rstd_d, msc_d, msh_d = dev(mean), dev(rstd), dev(msc), dev(msh)
+    _lib.check(L().dbn_igemm_bnsums_t(0, 0, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), N, srcs.shape[1], srcs.shape[2],
+                                      srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode, accumulate, tile, ys.data_ptr(),
+                                      zs.data_ptr() if mask == 'tensor' else None, None if mask == 'tensor' else msc_d.data_ptr(),
+                                      None if mask == 'tensor' else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(),
+                                      part.data_ptr(), stream()), 'igemm_bnsums')
+    torch.cuda.synchronize()
+    assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
+    dz = nchw(dst).double()
+    m = z.double() if mask == 'tensor' else torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1)).double()
+    if mask == 'self':  # the kernel evaluates fmaf(y, sc, sh) in fp32: elements within round-off of zero may flip
+        m32 = torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1))
+        safe = m32.abs() > 1e-6
+        assert bool(safe.all()), 'test data has a mask value at round-off level'
+    g = dz * (m > 0)
+    xhat = (y.double() - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
+    s1, s2 = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
+    got = part.double().sum(2).cpu()
+    sc = float(g.abs().sum((0, 2, 3)).max()) + 1e-9
+    report('bn-backward sums %s tile %d %s acc %d' % (case, tile, mask, accumulate), got, torch.stack([s1, s2]), 2e-6 * sc, 1e-5)

@@ -25,8 +25,8 @@ side = torch.cuda.Stream(device=dev)
 khz = L.dbn_wall_clock_khz()
 
 
-def probe(n, us=200):
-    buf = torch.zeros(n, 2, dtype=torch.int64, device=dev)
+def probe(buf, us=200):
+    n = buf.shape[0]
     for i in range(n):
         L.dbn_clock_probe(buf[i].data_ptr(), us, side.cuda_stream)
     return buf
@@ -54,14 +54,17 @@ def load_hbm(reps):
 
 for name, fn, reps in (('fp32 MFMA (pyramid conv, 1.85 ms x 40)', load_mfma, 40), ('HBM-bound (bn_apply 840 MB x 300)', load_hbm, 300),
                        ('whole train step x 3', lambda r: [tr.step(img, gts) for _ in range(r)], 3)):
+    b = torch.zeros(60 if 'MFMA' in name else 40, 2, dtype=torch.int64, device=dev)  # (before the load is queued: same stream)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn(reps)
     e1.record()
-    b = probe(60 if 'MFMA' in name else 40)
+    probe(b)
     torch.cuda.synchronize()
     print('%-45s %s   [load ran %.1f ms]' % (name, mhz(b), e0.elapsed_time(e1)))
+b = torch.zeros(10, 2, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
-print('%-45s %s' % ('idle', mhz(probe(10))))
+probe(b)
 torch.cuda.synchronize()
+print('%-45s %s' % ('idle', mhz(b)))
