@@ -351,7 +351,6 @@ int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const 
                        const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
                        const float* save_rstd, float* part, void* stream) {
     DBN_REQUIRE(at == 0 && ns == 0 && y && save_mean && save_rstd && part && (zmask || (mask_scale && mask_shift)));
-    DBN_REQUIRE(!(mode == 1 && stride > 1));  // (parity-class launches: not built, see launch_igemm_ns)
     const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
     DBN_REQUIRE(rows > 0);
     const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part};

@@ -20,7 +20,10 @@ namespace {
 // that cost 4 spills and gave +1.6 % on large launches, with the second register set of the two-tile prefetch it spills 56
 // and loses 35 % — the experiment (round 1-2: DBN_IGEMM_W4) was removed in round 3.
 // pixel-patch kernels with three planes: two waves per SIMD (<= 256 registers; the fully unrolled nine stages had taken 257)
-#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : 1, 8)))
+// exact-fp32 16K-element tiles with the BatchNorm-backward epilogue (EPI = 1): three waves per SIMD like the plain kernel (the row
+// sweep of that epilogue peaks 1-3 registers above the 104 that three waves allow; the attribute makes the allocator fit it)
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) \
+    __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : 1, 8)))
 
 // AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
 // of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
@@ -32,8 +35,8 @@ namespace {
 // and the A operand is not gathered per tap at all — see the main loop.
 // EPI = 1: the epilogue also produces the partial sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_*).
 template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0>
-__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH) void igemm_f32_kernel(const IgemmParams p) {
-    static_assert(EPI == 0 || (AT == 0 && MODE < 2 && !PATCH), "BatchNorm-backward sums: fp32 storage, generic loop, no parity classes");
+__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) void igemm_f32_kernel(const IgemmParams p) {
+    static_assert(EPI == 0 || (AT == 0 && MODE < 3 && !PATCH), "BatchNorm-backward sums: fp32 storage, generic loop");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
@@ -959,111 +962,6 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
         if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)min(BM, qM - m0);
     }
 
-    // ---- optional sums of the BatchNorm backward that consumes dst (see IgemmParams::bnb_part).  The accumulators hold the final
-    // dz values here.  y (and the mask tensor) have dst's layout, so a lane reads them at the offsets it stores to: per row 32
-    // consecutive floats per half-wave, four rows (4 x NI loads, twice with a mask tensor) in flight before their use.
-    if constexpr (EPI == 1) {
-        __syncthreads();  // (the LDS panels are dead after the k-loop; the accumulate path may have used the region too)
-        float* red = reinterpret_cast<float*>(smem);
-        float* r1 = red;            // [WM][BN]
-        float* r2 = r1 + WM * BN;   // [WM][BN]
-        const float* const yb = reinterpret_cast<const float*>(p.bnb_y);
-        const float* const zb = reinterpret_cast<const float*>(p.bnb_zmask);
-        float mu[NI], rs[NI], msc[NI], msh[NI], s1[NI], s2[NI];
-#pragma unroll
-        for (int b = 0; b < NI; ++b) {
-            const int c = n0 + wn * TN + b * 32 + li;
-            mu[b] = p.bnb_mean[c];
-            rs[b] = p.bnb_rstd[c];
-            msc[b] = zb ? 0.f : p.bnb_msc[c];
-            msh[b] = zb ? 0.f : p.bnb_msh[c];
-            s1[b] = s2[b] = 0.f;
-        }
-        const long ycol = n0 + wn * TN + li;
-        // branch-free bodies (one per mask kind): with a conditional load or a short-circuit `&&` inside, the row groups become
-        // basic blocks of their own, the scheduling fences below no longer bound anything, and the compiler issued all MI*16*NI
-        // loads of the tile before the first use (246 registers, one wave per SIMD)
-        auto sums = [&](auto ZM) {
-            constexpr bool kZ = decltype(ZM)::value;
-            constexpr int RB = NI >= 2 ? 2 : 4;  // rows in flight (RB * NI loads per tensor)
-            auto body = [&](int a, int r0, const unsigned (&off)[RB], unsigned okm) {
-                float yv[RB][NI], zv[RB][kZ ? NI : 1];
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b) {
-                        // (rows past M point at a valid pixel: the loads are unpredicated, the sums are not)
-                        yv[i][b] = yb[(long)off[i] + ycol + b * 32];
-                        if constexpr (kZ) zv[i][b] = zb[(long)off[i] + ycol + b * 32];
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int b = 0; b < NI; ++b) {
-                        const float y_ = yv[i][b];
-                        float m_;
-                        if constexpr (kZ) m_ = zv[i][b];
-                        else m_ = dbn_affine(y_, msc[b], msh[b]);
-                        const bool on = ((okm >> i) & 1u) & (m_ > 0.f);
-                        const float g = on ? acc[a][b][r0 + i] : 0.f;
-                        s1[b] += g;
-                        s2[b] += g * ((y_ - mu[b]) * rs[b]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-#pragma unroll
-            for (int a = 0; a < MI; ++a) {
-                if constexpr (MODE >= 2) {
-                    // the parity-class pixel walk has loops: all 16 row offsets first, then branch-free load / use groups
-                    unsigned offs[16], okm = 0;
-                    for_rows(a, [&](int r, bool ok, long doff) {
-                        offs[r] = (unsigned)doff;  // (element offsets fit 32 bits: checked on the host)
-                        okm |= (ok ? 1u : 0u) << r;
-                    });
-#pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += RB) {
-                        unsigned o_[RB];
-#pragma unroll
-                        for (int i = 0; i < RB; ++i) o_[i] = offs[r0 + i];
-                        body(a, r0, o_, okm >> r0);
-                    }
-                } else {
-                    unsigned o_[RB], okm = 0;
-                    for_rows(a, [&](int r, bool ok, long doff) {
-                        o_[r % RB] = (unsigned)doff;
-                        okm = (r % RB == 0 ? 0u : okm) | ((ok ? 1u : 0u) << (r % RB));
-                        if (r % RB == RB - 1) body(a, r - (RB - 1), o_, okm);
-                    });
-                }
-            }
-        };
-        if (zb) sums(std::true_type{});
-        else sums(std::false_type{});
-#pragma unroll
-        for (int b = 0; b < NI; ++b) {
-            const int cl = wn * TN + b * 32 + li;
-            const float t1 = s1[b] + __shfl_xor(s1[b], 32, 64), t2 = s2[b] + __shfl_xor(s2[b], 32, 64);
-            if (lh == 0) {
-                r1[wm * BN + cl] = t1;
-                r2[wm * BN + cl] = t2;
-            }
-        }
-        __syncthreads();
-        const int trow = p.stat_row0 + q_row_base + mt;
-        for (int cl = tid; cl < BN; cl += NT) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                t1 += r1[w * BN + cl];
-                t2 += r2[w * BN + cl];
-            }
-            const long c = n0 + cl;
-            p.bnb_part[(0L * p.Cd + c) * p.stat_rows + trow] = t1;
-            p.bnb_part[(1L * p.Cd + c) * p.stat_rows + trow] = t2;
-        }
-    }
-
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // the bias values of this lane's NI columns are loaded once (inside the row loop the compiler re-loaded them for every
     // row, behind a vmcnt(0) wait, because the stores may alias them)
@@ -1076,6 +974,111 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH)
 #pragma unroll
     for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
     const long dcol = n0 + wn * TN + li;
+    // ---- EPI = 1: store + the sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_part), ROW-MAJOR through LDS.
+    // The accumulators hold the final dz values.  Reading y (and the mask tensor) at the accumulator layout — a lane owns one
+    // column of 16 rows — is MI*NI*16 four-byte loads per lane and tensor, with every accumulator copied out of the AGPRs and
+    // live beside them (measured: 138-246 registers, 128x128 tiles at two waves per SIMD, the data gradients 13 % slower).
+    // Instead the tile goes to LDS once (conflict-free ds_write_b32: a half-wave writes 32 consecutive floats of a row), and a
+    // second pass walks it row-major: a thread owns one channel quad, reads dz from LDS and y / mask from HBM as 16-byte pieces
+    // (a row's BN*4 contiguous bytes per BN/4 lanes), accumulates its quad's two sums over the rows it visits, and stores dz with
+    // 16-byte stores.  Tiles larger than the LDS panels (128x128, 256x64) take two passes (accumulator blocks a < MI/2, then the rest).
+    if constexpr (EPI == 1) {
+        constexpr int PITCH = BN;                            // floats per LDS row (the b32 writes and b128 reads below are conflict-free unpadded)
+        constexpr int HALVES = ((long)BM * PITCH * 4 > (long)sizeof(smem)) ? 2 : 1;
+        constexpr int MI_H = MI / HALVES, RH = BM / HALVES;  // accumulator blocks / tile rows per pass
+        constexpr int LPR = BN / 4, RSTEP = NT / LPR;        // lanes per row, rows per sweep of the workgroup
+        static_assert(MI % HALVES == 0 && (long)RH * PITCH * 4 <= (long)sizeof(smem) && RH % RSTEP == 0 && NT % LPR == 0, "tile / LDS");
+        static_assert(2L * RSTEP * BN * 4 <= (long)sizeof(smem), "reduction scratch");
+        float* const T = reinterpret_cast<float*>(smem);
+        const float* const yb = reinterpret_cast<const float*>(p.bnb_y);
+        const float* const zb = reinterpret_cast<const float*>(p.bnb_zmask);
+        float* const dstf = reinterpret_cast<float*>(p.dst);
+        const int c4 = tid % LPR, rq = tid / LPR;
+        const int cg = n0 + 4 * c4;  // first of this thread's four channels
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + cg), rs = *reinterpret_cast<const f32x4*>(p.bnb_rstd + cg);
+        f32x4 msc = {0.f, 0.f, 0.f, 0.f}, msh = msc;
+        if (!zb) {
+            msc = *reinterpret_cast<const f32x4*>(p.bnb_msc + cg);
+            msh = *reinterpret_cast<const f32x4*>(p.bnb_msh + cg);
+        }
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        auto sweep = [&](int h, auto ZM) {
+            constexpr bool kZ = decltype(ZM)::value;
+            constexpr int UN = 2;  // rows in flight per thread
+            static_assert((RH / RSTEP) % UN == 0, "whole groups");
+#pragma unroll 1
+            for (int j0 = rq; j0 < RH; j0 += UN * RSTEP) {
+                f32x4 yv[UN], zv[UN];
+                long doff[UN];
+                bool ok[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int j = j0 + u * RSTEP;                          // LDS row
+                    const int w_ = j / (32 * MI_H), rem = j - w_ * (32 * MI_H);
+                    const int trow = w_ * TM + h * (32 * MI_H) + rem;      // tile row (rows of block a are 32 apart per wave row)
+                    tile_row(trow, ok[u], doff[u]);
+                    const long o = ok[u] ? doff[u] + cg : (long)cg;        // rows past M read a valid pixel, contribute nothing
+                    yv[u] = *reinterpret_cast<const f32x4*>(yb + o);
+                    if constexpr (kZ) zv[u] = *reinterpret_cast<const f32x4*>(zb + o);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int j = j0 + u * RSTEP;
+                    const f32x4 dz = *reinterpret_cast<const f32x4*>(T + j * PITCH + 4 * c4);
+                    if (ok[u]) *reinterpret_cast<f32x4*>(dstf + doff[u] + cg) = dz;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m_;
+                        if constexpr (kZ) m_ = zv[u][e];
+                        else m_ = dbn_affine(yv[u][e], msc[e], msh[e]);
+                        const float g = (ok[u] & (m_ > 0.f)) ? dz[e] : 0.f;
+                        s1[e] += g;
+                        s2[e] += g * ((yv[u][e] - mu[e]) * rs[e]);
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+            __syncthreads();  // the panels / the previous pass are dead
+#pragma unroll
+            for (int al = 0; al < MI_H; ++al)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = wm * (32 * MI_H) + al * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        // read the accumulator element where it is consumed: left to itself the compiler copies ALL accumulators
+                        // out of the AGPRs right after the k-loop and keeps the copies live beside everything below
+                        float v_;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(acc[h * MI_H + al][b][r]));
+                        T[j * PITCH + wn * TN + b * 32 + li] = v_ + bv[b];
+                    }
+            __syncthreads();
+            if (zb) sweep(h, std::true_type{});
+            else sweep(h, std::false_type{});
+        }
+        // fold the RSTEP row groups of each channel (fixed order) and write this tile's partial row
+        __syncthreads();
+        float* const r1 = T;               // [RSTEP][BN]
+        float* const r2 = T + RSTEP * BN;  // [RSTEP][BN]
+        *reinterpret_cast<f32x4*>(r1 + rq * BN + 4 * c4) = s1;
+        *reinterpret_cast<f32x4*>(r2 + rq * BN + 4 * c4) = s2;
+        __syncthreads();
+        const int trow_ = p.stat_row0 + q_row_base + mt;
+        for (int cl = tid; cl < BN; cl += NT) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RSTEP; ++w) {
+                t1 += r1[w * BN + cl];
+                t2 += r2[w * BN + cl];
+            }
+            const long c = n0 + cl;
+            p.bnb_part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
+            p.bnb_part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+        }
+        return;
+    }
     if constexpr (!DST_F32) {
         if (!to_slab) {
             // 16-bit output: a lane holds ONE column of 16 rows, so direct stores are 2-byte scatters (MI*NI*16 store instructions
@@ -1162,8 +1165,10 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
                 hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
             else if (mode == 1)
                 hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
-            else  // (parity classes: not instantiated — the pixel walk's loops keep the epilogue at one wave per SIMD; the callers
-                return DBN_ERR_ARG;  //  take the separate reduce pass there)
+            else if (mode == 2)
+                hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 2, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+            else
+                return DBN_ERR_ARG;
             return dbn_status();
         } else {
             return DBN_ERR_ARG;

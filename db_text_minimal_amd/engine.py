@@ -331,7 +331,9 @@ class Engine:
     def _bnb_eligible(self, args):
         """Can this igemm call (dbn_igemm_f32 argument list) carry the BatchNorm-backward sums of its consumer?"""
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
-        if not self.fuse_bn_bwd_sums or self.at != 0 or self.ns != 0 or self._use_planes or (mode == 1 and stride > 1):
+        if not self.fuse_bn_bwd_sums or self.at != 0 or self.ns != 0 or self._use_planes:
+            return False
+        if mode == 1 and stride > 1 and (R < stride or S < stride):  # a parity class without taps: pixels the launch never visits
             return False
         if self.prof is not None and self.prof.labels is None and not self.prof_fused:
             return False
@@ -1003,8 +1005,8 @@ class Engine:
                     dx, acc = dC[feat[li - 1]], True
                 else:
                     dx, acc = dpool, False
-                # (a stage's first block writes dx with parity-class launches: the previous stage's BatchNorm keeps its reduce pass)
-                self._block_bwd(name, layer[bi], xin, dout, dx, acc, prev='backbone.layer%d.%d' % (li, bi - 1) if bi > 0 else None)
+                prev = 'backbone.layer%d.%d' % ((li, bi - 1) if bi > 0 else (li - 1, lastb[li - 1])) if (bi > 0 or li > 1) else None
+                self._block_bwd(name, layer[bi], xin, dout, dx, acc, prev=prev)
             if self.grad_ready_hook is not None and li >= 3:
                 with self.side_stream():
                     self.grad_ready_hook('layer%d' % li)
@@ -1129,9 +1131,9 @@ class Engine:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
     def _block_bwd(self, name, blk, xin, dout, dx, dx_acc, prev=None):
-        """prev: name of the block whose output is this block's input (None: the stem's pooled map, or a stage boundary) — its
-        last BatchNorm consumes dx with the ReLU mask of its output; the data gradient that writes dx last carries that
-        BatchNorm-backward's sums in its epilogue (stride-1 data gradients only)."""
+        """prev: name of the block whose output is this block's input (None: the stem's pooled map) — its last BatchNorm
+        consumes dx with the ReLU mask of its output; conv1's data gradient writes dx last and carries that BatchNorm-backward's
+        sums in its epilogue."""
         B = self.bufs
         out = B[name + '/out']
         has_down = blk.downsample is not None

@@ -70,8 +70,8 @@ int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_
  *   part[0][c][row] = sum g,   part[1][c][row] = sum g * (y - mean[c]) * rstd[c],   g = dz_final * [mask > 0]
  * over the FINAL dst values (after `accumulate`): the call must be the last writer of dst.  part: [2][Cd][rows] floats with
  * rows = dbn_igemm_bn_rows(same geometry); hand it to dbn_bn_backward_t as `sums` with sums_parts = rows.  Exact-fp32 math on
- * fp32 tensors (at = 0, ns = 0); mode 0 (any stride) and mode 1 with stride 1 (the parity-class launches of strided
- * transposed convs keep the separate reduce pass). */
+ * fp32 tensors (at = 0, ns = 0); a strided transposed conv (mode 1, stride > 1) must be tap-complete (R, S >= stride: every
+ * output pixel is visited). */
 int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode,
                       int tile_hint);
 int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,

@@ -1244,7 +1244,8 @@ def test_pixel_patch_weight_gradient(case, mode_name):
 
 # N, Cin (of the forward conv = channels of dx), Cout, k, s, p, H, W, as_forward
 BNSUM_CASES = [(2, 64, 64, 3, 1, 1, 16, 12, False), (1, 256, 128, 3, 1, 1, 12, 12, False), (3, 128, 64, 1, 1, 0, 9, 7, False),
-               (2, 64, 64, 2, 2, 0, 10, 12, True), (1, 64, 128, 3, 2, 1, 18, 14, True), (2, 64, 64, 3, 1, 1, 40, 24, False)]
+               (2, 64, 64, 2, 2, 0, 10, 12, True), (1, 64, 128, 3, 2, 1, 18, 14, True), (2, 64, 64, 3, 1, 1, 40, 24, False),
+               (1, 64, 128, 3, 2, 1, 18, 14, False), (2, 128, 256, 3, 2, 1, 16, 16, False), (1, 64, 64, 3, 2, 1, 17, 13, False)]
 
 
 @pytest.mark.parametrize('case', BNSUM_CASES)
