@@ -34,9 +34,13 @@ namespace {
 // PATCH (3x3, stride 1, pad 1, 16-bit matrix math; Hd % 8 == 0, Wd % 16 == 0, Cs % 32 == 0): the M tile is an 8 x 16 PIXEL PATCH
 // and the A operand is not gathered per tap at all — see the main loop.
 // EPI = 1: the epilogue also produces the partial sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_*).
-template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0>
+// BLK = false: the source's channel count is not a multiple of 16 (the stem: Cs = 4) — the K walk then crosses taps inside a
+// k-step; forward convs on fp32 tensors only.  A compile-time fact: as a runtime flag its inner `while` put loops and branches
+// into every kernel's k-loop (and an s_waitcnt vmcnt(0) at the loop header that drained the two-tile prefetch every iteration).
+template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0, bool BLK = true>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) void igemm_f32_kernel(const IgemmParams p) {
     static_assert(EPI == 0 || (AT == 0 && MODE < 3 && !PATCH), "BatchNorm-backward sums: fp32 storage, generic loop");
+    static_assert(BLK || (AT == 0 && MODE == 0 && !PATCH && EPI == 0), "non-blocked K walk: forward conv on fp32 tensors");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     //   otherwise (stem, Cs = 4): k = (r*S + s)*Cs + ci.
     // (always, for 16-bit storage and pre-split planes — checked on the host: a compile-time fact there, which removes the
     // non-blocked walk and its branches from the k-loop)
-    const bool blocked = AT != 0 || (p.Cs & 15) == 0;
+    constexpr bool blocked = BLK;
     int kidx = A_CH * a_chunk;
     int k_ci, k_r, k_s;
     int kt_begin = 0, kt_end = qKT;
@@ -701,11 +705,19 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     issue_loads(C1{});
     offsets_of_interval();  // offsets of interval 2
     stage(0, C0{});
+    // every prologue load has landed before the loop is entered (a real S_WAITCNT, which the compiler's wait-count pass tracks):
+    // entered with interval 1's loads still pending, the loop header carried `s_waitcnt vmcnt(2) / (1) / (0)` in front of its
+    // fragment reads — the entry state merged into the back edge — and drained the two-tile prefetch in EVERY iteration.
+    // (vmcnt = 0, expcnt / lgkmcnt untouched)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     auto k_step = [&](int kt, auto PAR) {
         constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
         issue_loads(PAR);  // interval +2 into the register set this interval was staged from
+        // ... and they stay HERE: left alone the scheduler sinks them below the first MFMAs (it reuses the set's registers for the
+        // fragment reads first), which shortens the prefetch distance from two k-steps to about one
+        if constexpr (NS == 0) __builtin_amdgcn_sched_barrier(0);
         const f32x4* As = smem + buf * STAGE;
         const f32x4* Bs = As + A_IMG;
         if constexpr (KU > 1) {
@@ -757,10 +769,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
     };
-    for (int kt = kt_begin; kt < kt_end; kt += 2 * KU) {
+    // whole pairs of k-steps, then the odd one: with `if (more) k_step(C1)` INSIDE the loop there is a static path around the
+    // second step on which the first step's loads reach the loop header unstaged, and the compiler guarded the header's fragment
+    // reads (which reuse those registers) with s_waitcnt vmcnt(2) / (1) / (0) — draining the two-tile prefetch every iteration
+    int kt = kt_begin;
+    for (; kt + 2 * KU <= kt_end; kt += 2 * KU) {
         k_step(kt, C0{});
-        if (kt + KU < kt_end) k_step(kt + KU, C1{});
+        k_step(kt + KU, C1{});
     }
+    if (kt < kt_end) k_step(kt, C0{});
     }
 
     }
@@ -1158,6 +1175,15 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
         }
     }
     if (p.patch) return DBN_ERR_ARG;
+    if ((p.Cs & 15) != 0) {  // the stem (Cs = 4): K walk across taps
+        if constexpr (AT == 0) {
+            if (mode != 0 || p.bnb_part || gy != 1) return DBN_ERR_ARG;
+            hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, false, 0, false>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
+            return dbn_status();
+        } else {
+            return DBN_ERR_ARG;
+        }
+    }
     if (p.bnb_part) {  // with the sums of the BatchNorm backward that consumes dst (exact fp32 on fp32 tensors only)
         if constexpr (NS == 0 && AT == 0) {
             if (gy != 1 || !p.bnb_y || !p.bnb_mean || !p.bnb_rstd || !(p.bnb_zmask || (p.bnb_msc && p.bnb_msh))) return DBN_ERR_ARG;

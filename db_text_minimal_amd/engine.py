@@ -593,15 +593,15 @@ class Engine:
                   'bn eval ' + name)
         return sc, sh
 
-    def _prof_hbm(self, kernel, nbytes):
+    def _prof_hbm(self, kernel, nbytes, tag=''):
         """Bracket an HBM-bound launch with its ALGORITHMIC bytes (tensors read + written once); pair with self.prof.end()."""
         if self.prof:
-            self.prof.begin(kernel, 0.0, float(nbytes))
+            self.prof.begin(kernel, 0.0, float(nbytes), tag)
 
     def bn_apply(self, y, sc, sh, out_name, relu=True, res=None, rsc=None, rsh=None):
         C = y.shape[-1]
         out = self.buf(out_name, *y.shape)
-        self._prof_hbm('bn_apply_kernel', y.numel() * y.element_size() * (2 + (res is not None)))
+        self._prof_hbm('bn_apply_kernel', y.numel() * y.element_size() * (2 + (res is not None)), out_name)
         check(self.L.dbn_bn_apply_t(self.at, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), _p(res), _p(rsc), _p(rsh), out.data_ptr(),
                                     y.numel() // C, C, int(relu), self.stream), 'bn apply ' + out_name)
         if self.prof:
@@ -631,7 +631,8 @@ class Engine:
         # sums: [2][C] reductions already produced by the kernel that wrote dout
         nb = y.numel() * y.element_size()
         rd = 2 + (zmask is not None)  # tensors a pass reads: dout, y (+ the ReLU mask source)
-        self._prof_hbm('bn_bwd_reduce_kernel + bn_bwd_finalize_kernel + bn_bwd_apply_kernel', nb * ((0 if sums is not None else rd) + rd + 1 + (gout is not None) * (1 + bool(gout_acc))))
+        self._prof_hbm('bn_bwd_reduce_kernel + bn_bwd_finalize_kernel + bn_bwd_apply_kernel', nb * ((0 if sums is not None else rd) + rd + 1 + (gout is not None) * (1 + bool(gout_acc))),
+                       name + (' [sums given]' if sums is not None else ''))
         check(self.L.dbn_bn_backward_t(self.at, _p(sums), int(sums_parts), y.data_ptr(), _p(zmask), _p(msc), _p(msh), dout.data_ptr(),
                                         self.bufs[name + '/mean'].data_ptr(), self.bufs[name + '/rstd'].data_ptr(),
                                         self.views[name + '.weight'].data_ptr(), dy.data_ptr(), _p(gout), int(gout_acc),

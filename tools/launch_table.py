@@ -5,7 +5,7 @@ import torch
 import bench
 from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
 from db_text_minimal_amd.engine import KernelTimer
-math = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+math = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else 'f32'
 torch.manual_seed(42)
 m = DBTextModel().cuda().train()
 m.engine.set_conv_math(math)
@@ -22,6 +22,7 @@ rows = [(e0.elapsed_time(e1), label, tag, flops, nbytes) for label, flops, nbyte
 peak = bench.MATH[math][2]
 tot = sum(r[0] for r in rows)
 print('%d launches, %.2f ms bracketed' % (len(rows), tot))
-for ms, label, tag, flops, nbytes in sorted(rows, key=lambda r: -r[0])[:70]:
+order = rows if '--order' in sys.argv else sorted(rows, key=lambda r: -r[0])[:90]
+for ms, label, tag, flops, nbytes in order:
     rate = ('%6.1f TF/s %.2f' % (flops / ms / 1e9, flops / ms / 1e9 / peak)) if flops else (('%6.0f GB/s' % (nbytes / ms / 1e6)) if nbytes else '')
-    print('%7.3f ms  %-44s %-34s %s' % (ms, label[:44], tag[:34], rate))
+    print('%7.3f ms  %-44s %-48s %s' % (ms, label[:44], tag[:48], rate))
