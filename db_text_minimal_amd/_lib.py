@@ -82,7 +82,7 @@ SIGNATURES.update({
     'dbn_conv_bn_t': 'i' + SIGNATURES['dbn_conv_bn_f32'],
     'dbn_pyramid_conv_t': 'i' + SIGNATURES['dbn_pyramid_conv_f32'],
     'dbn_igemm_bn_rows': 'i' * 15,
-    'dbn_igemm_bnsums_t': 'ii' + 'pppp' + 'i' * 14 + 'ppppppp' + 'p',
+    'dbn_igemm_bnsums_t': 'ii' + 'pppp' + 'i' * 14 + 'ppppppp' + 'pppp' + 'p',
     'dbn_wgrad_t': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',

@@ -189,6 +189,9 @@ struct IgemmBnb {
     const void *y, *zmask;
     const float *msc, *msh, *mean, *rstd;
     float* part;
+    const void* y2;  // optional second BatchNorm over the same dz and mask tensor
+    const float *mean2, *rstd2;
+    float* part2;
 };
 
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -200,6 +203,8 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
     p.bnb_mean = bnb ? bnb->mean : nullptr; p.bnb_rstd = bnb ? bnb->rstd : nullptr;
     p.bnb_part = bnb ? bnb->part : nullptr;
+    p.bnb_y2 = bnb ? bnb->y2 : nullptr; p.bnb_mean2 = bnb ? bnb->mean2 : nullptr; p.bnb_rstd2 = bnb ? bnb->rstd2 : nullptr;
+    p.bnb_part2 = bnb ? bnb->part2 : nullptr;
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
@@ -296,6 +301,7 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
             b = *bnb;
             b.y = reinterpret_cast<const char*>(bnb->y) + (long)n0 * Hd * Wd * Cd * des;
             if (bnb->zmask) b.zmask = reinterpret_cast<const char*>(bnb->zmask) + (long)n0 * Hd * Wd * Cd * des;
+            if (bnb->y2) b.y2 = reinterpret_cast<const char*>(bnb->y2) + (long)n0 * Hd * Wd * Cd * des;
         }
         const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
                                      reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
@@ -346,14 +352,17 @@ int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int
 // BatchNorm's own output recomputed).  The sums are taken over the FINAL dst values (after `accumulate`), so the call must be
 // the last writer of dst.  part: [2][Cd][dbn_igemm_bn_rows(...)] floats.  Replaces the reduce pass of dbn_bn_backward_t (which
 // re-reads dst and y): pass `part` as its `sums`.  Exact-fp32 math on fp32 tensors (at = 0, ns = 0) only.
+// y2 / save_mean2 / save_rstd2 / part2 (optional, with zmask): a second BatchNorm that consumes the same dst under the same mask.
 int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                        int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
                        const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
-                       const float* save_rstd, float* part, void* stream) {
+                       const float* save_rstd, float* part, const void* y2, const float* save_mean2, const float* save_rstd2,
+                       float* part2, void* stream) {
     DBN_REQUIRE(at == 0 && ns == 0 && y && save_mean && save_rstd && part && (zmask || (mask_scale && mask_shift)));
+    DBN_REQUIRE(!y2 || (zmask && save_mean2 && save_rstd2 && part2));
     const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
     DBN_REQUIRE(rows > 0);
-    const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part};
+    const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part, y2, save_mean2, save_rstd2, part2};
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr, 1,
                      nullptr, rows, at, &b);
 }
@@ -475,7 +484,8 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * des;
         p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
-        p.bnb_y = p.bnb_zmask = nullptr; p.bnb_msc = p.bnb_msh = p.bnb_mean = p.bnb_rstd = nullptr; p.bnb_part = nullptr;
+        p.bnb_y = p.bnb_zmask = p.bnb_y2 = nullptr; p.bnb_msc = p.bnb_msh = p.bnb_mean = p.bnb_rstd = p.bnb_mean2 = p.bnb_rstd2 = nullptr;
+        p.bnb_part = p.bnb_part2 = nullptr;
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
         p.ksplit = 1; p.kt_per = 0; p.patch = 0;

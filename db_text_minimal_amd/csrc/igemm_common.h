@@ -82,6 +82,11 @@ struct IgemmParams {
     const void* bnb_zmask;
     const float *bnb_msc, *bnb_msh, *bnb_mean, *bnb_rstd;
     float* bnb_part;
+    // a SECOND BatchNorm consuming the same dz under the same mask tensor (a residual block with a projection shortcut: bn2 and
+    // the downsample BatchNorm, resnet.py:84-91): its input, statistics and partials (null: none; needs bnb_zmask)
+    const void* bnb_y2;
+    const float *bnb_mean2, *bnb_rstd2;
+    float* bnb_part2;
     unsigned src_bytes;
     unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)

@@ -1018,14 +1018,20 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             msc = *reinterpret_cast<const f32x4*>(p.bnb_msc + cg);
             msh = *reinterpret_cast<const f32x4*>(p.bnb_msh + cg);
         }
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-        auto sweep = [&](int h, auto ZM) {
-            constexpr bool kZ = decltype(ZM)::value;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1, s4 = s1;
+        const float* const y2b = reinterpret_cast<const float*>(p.bnb_y2);
+        f32x4 mu2 = s1, rs2 = s1;
+        if (y2b) {
+            mu2 = *reinterpret_cast<const f32x4*>(p.bnb_mean2 + cg);
+            rs2 = *reinterpret_cast<const f32x4*>(p.bnb_rstd2 + cg);
+        }
+        auto sweep = [&](int h, auto ZM, auto TWO) {
+            constexpr bool kZ = decltype(ZM)::value, k2 = decltype(TWO)::value;
             constexpr int UN = 2;  // rows in flight per thread
             static_assert((RH / RSTEP) % UN == 0, "whole groups");
 #pragma unroll 1
             for (int j0 = rq; j0 < RH; j0 += UN * RSTEP) {
-                f32x4 yv[UN], zv[UN];
+                f32x4 yv[UN], zv[UN], y2v[UN];
                 long doff[UN];
                 bool ok[UN];
 #pragma unroll
@@ -1037,6 +1043,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                     const long o = ok[u] ? doff[u] + cg : (long)cg;        // rows past M read a valid pixel, contribute nothing
                     yv[u] = *reinterpret_cast<const f32x4*>(yb + o);
                     if constexpr (kZ) zv[u] = *reinterpret_cast<const f32x4*>(zb + o);
+                    if constexpr (k2) y2v[u] = *reinterpret_cast<const f32x4*>(y2b + o);
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
@@ -1051,6 +1058,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                         const float g = (ok[u] & (m_ > 0.f)) ? dz[e] : 0.f;
                         s1[e] += g;
                         s2[e] += g * ((yv[u][e] - mu[e]) * rs[e]);
+                        if constexpr (k2) s4[e] += g * ((y2v[u][e] - mu2[e]) * rs2[e]);
                     }
                 }
             }
@@ -1065,35 +1073,37 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int j = wm * (32 * MI_H) + al * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        // read the accumulator element where it is consumed: left to itself the compiler copies ALL accumulators
-                        // out of the AGPRs right after the k-loop and keeps the copies live beside everything below
-                        float v_;
-                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(acc[h * MI_H + al][b][r]));
-                        T[j * PITCH + wn * TN + b * 32 + li] = v_ + bv[b];
+                        T[j * PITCH + wn * TN + b * 32 + li] = acc[h * MI_H + al][b][r] + bv[b];
                     }
             __syncthreads();
-            if (zb) sweep(h, std::true_type{});
-            else sweep(h, std::false_type{});
+            if (zb && y2b) sweep(h, std::true_type{}, std::true_type{});
+            else if (zb) sweep(h, std::true_type{}, std::false_type{});
+            else sweep(h, std::false_type{}, std::false_type{});
         }
+        s3 = s1;  // (the second BatchNorm's first sum is the same masked gradient sum)
         // fold the RSTEP row groups of each channel (fixed order) and write this tile's partial row
-        __syncthreads();
+        const int trow_ = p.stat_row0 + q_row_base + mt;
         float* const r1 = T;               // [RSTEP][BN]
         float* const r2 = T + RSTEP * BN;  // [RSTEP][BN]
-        *reinterpret_cast<f32x4*>(r1 + rq * BN + 4 * c4) = s1;
-        *reinterpret_cast<f32x4*>(r2 + rq * BN + 4 * c4) = s2;
-        __syncthreads();
-        const int trow_ = p.stat_row0 + q_row_base + mt;
-        for (int cl = tid; cl < BN; cl += NT) {
-            float t1 = 0.f, t2 = 0.f;
+        auto fold = [&](const f32x4& a_, const f32x4& b_, float* part) {
+            __syncthreads();
+            *reinterpret_cast<f32x4*>(r1 + rq * BN + 4 * c4) = a_;
+            *reinterpret_cast<f32x4*>(r2 + rq * BN + 4 * c4) = b_;
+            __syncthreads();
+            for (int cl = tid; cl < BN; cl += NT) {
+                float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < RSTEP; ++w) {
-                t1 += r1[w * BN + cl];
-                t2 += r2[w * BN + cl];
+                for (int w = 0; w < RSTEP; ++w) {
+                    t1 += r1[w * BN + cl];
+                    t2 += r2[w * BN + cl];
+                }
+                const long c = n0 + cl;
+                part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
+                part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
             }
-            const long c = n0 + cl;
-            p.bnb_part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
-            p.bnb_part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
-        }
+        };
+        fold(s1, s2, p.bnb_part);
+        if (y2b) fold(s3, s4, p.bnb_part2);
         return;
     }
     if constexpr (!DST_F32) {
@@ -1187,6 +1197,7 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     if (p.bnb_part) {  // with the sums of the BatchNorm backward that consumes dst (exact fp32 on fp32 tensors only)
         if constexpr (NS == 0 && AT == 0) {
             if (gy != 1 || !p.bnb_y || !p.bnb_mean || !p.bnb_rstd || !(p.bnb_zmask || (p.bnb_msc && p.bnb_msh))) return DBN_ERR_ARG;
+            if (p.bnb_y2 && !(p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2)) return DBN_ERR_ARG;
             if (mode == 0)
                 hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
             else if (mode == 1)

@@ -349,7 +349,8 @@ class Engine:
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
         at, srcp = self._src(args[0], Cs)
         if consumer is not None and self._bnb_eligible(args):
-            bn_name, y, zmask = consumer
+            bn_name, y, zmask = consumer[:3]
+            second = consumer[3] if len(consumer) > 3 else None  # (bn_name2, y2): a second BatchNorm over the same dz and mask
             assert tuple(y.shape) == (N, Hd, Wd, Cd) and (zmask is None or zmask.shape == y.shape), (what, bn_name)
             hint = args[17]
             rows = self.L.dbn_igemm_bn_rows(at, self.ns, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, hint)
@@ -357,10 +358,17 @@ class Engine:
             msc = msh = None
             if zmask is None:
                 msc, msh = self.bufs[bn_name + '/scale'], self.bufs[bn_name + '/shift']
+            y2 = mean2 = rstd2 = part2 = None
+            if second is not None:
+                assert zmask is not None and second[1].shape == y.shape
+                y2, mean2, rstd2 = second[1], self.bufs[second[0] + '/mean'], self.bufs[second[0] + '/rstd']
+                part2 = self.fbuf(second[0] + '/bnb_part', 2 * Cd * rows)
             check(self.L.dbn_igemm_bnsums_t(at, self.ns, srcp, *args[1:], y.data_ptr(), _p(zmask), _p(msc), _p(msh),
                                             self.bufs[bn_name + '/mean'].data_ptr(), self.bufs[bn_name + '/rstd'].data_ptr(),
-                                            part.data_ptr(), self.stream), what)
+                                            part.data_ptr(), _p(y2), _p(mean2), _p(rstd2), _p(part2), self.stream), what)
             self._bnb_sums[bn_name] = (part, rows)
+            if second is not None:
+                self._bnb_sums[second[0]] = (part2, rows)
             return
         ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):
@@ -1169,4 +1177,6 @@ class Engine:
         if prev is not None:
             plast = '3' if (prev + '/y3') in B else '2'
             consumer = (prev + '.bn' + plast, B[prev + '/y' + plast], B[prev + '/out'])
+            if (prev + '/yd') in B:  # the projection shortcut's BatchNorm consumes the same gradient under the same mask
+                consumer += ((prev + '.downsample.1', B[prev + '/yd']), )
         self.conv_dgrad(name + '.conv1', dy1, blk.conv1, dx, dx_acc, consumer=consumer)

@@ -1287,13 +1287,20 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
     rows = L().dbn_igemm_bn_rows(*a)
     assert rows > 0
     part = torch.full((2, Cd, rows), float('nan'), device=DEV)
+    # a second BatchNorm over the same dz and mask tensor (projection shortcut), only with a mask tensor
+    two = mask == 'tensor'
+    y2 = rnd(N, Cd, Hd, Wd, seed=21)
+    mean2, rstd2 = rnd(Cd, seed=22, scale=0.3), rnd(Cd, seed=23).abs() + 0.4
+    y2s, mean2_d, rstd2_d = nhwc(y2), mean2.to(DEV), rstd2.to(DEV)
+    part2 = torch.full((2, Cd, rows), float('nan'), device=DEV)
     dev = lambda t: t.to(DEV)
     mean_d, rstd_d, msc_d, msh_d = dev(mean), dev(rstd), dev(msc), dev(msh)
     _lib.check(L().dbn_igemm_bnsums_t(0, 0, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), N, srcs.shape[1], srcs.shape[2],
                                       srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode, accumulate, tile, ys.data_ptr(),
                                       zs.data_ptr() if mask == 'tensor' else None, None if mask == 'tensor' else msc_d.data_ptr(),
                                       None if mask == 'tensor' else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(),
-                                      part.data_ptr(), stream()), 'igemm_bnsums')
+                                      part.data_ptr(), y2s.data_ptr() if two else None, mean2_d.data_ptr() if two else None,
+                                      rstd2_d.data_ptr() if two else None, part2.data_ptr() if two else None, stream()), 'igemm_bnsums')
     torch.cuda.synchronize()
     assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
     dz = nchw(dst).double()
@@ -1308,3 +1315,6 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
     got = part.double().sum(2).cpu()
     sc = float(g.abs().sum((0, 2, 3)).max()) + 1e-9
     report('bn-backward sums %s tile %d %s acc %d' % (case, tile, mask, accumulate), got, torch.stack([s1, s2]), 2e-6 * sc, 1e-5)
+    if two:
+        xhat2 = (y2.double() - mean2.double().view(1, -1, 1, 1)) * rstd2.double().view(1, -1, 1, 1)
+        report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, (g * xhat2).sum((0, 2, 3))]), 2e-6 * sc, 1e-5)
