@@ -149,6 +149,8 @@ def main():
                     help="N>1: time the 4-bucket exchange issued under the backward pass as the headline instead of north_star's one "
                          "all-reduce after it (the other form is always timed too and reported under grad_allreduce_other); results are "
                          "bit-identical (tests/test_dp_gloo.py, tests/test_rccl_gpu.py)")
+    ap.add_argument('--no-graph', action='store_true',
+                    help='launch every kernel of the step individually instead of replaying forward + loss + backward as one hipGraph')
     ap.add_argument('--serial-steps', type=int, default=3, help='instrumented single-stream steps for the kernels[] table (median)')
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
@@ -169,6 +171,7 @@ def main():
     model.engine.set_conv_math(args.math)
     trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
     trainer.overlap_allreduce = bool(args.bucketed_allreduce)
+    trainer.use_graph = not args.no_graph and not args.bucketed_allreduce  # (the bucket announcements are host callbacks: eager only)
     img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
     eng = model.engine
 
@@ -359,6 +362,9 @@ def main():
                        'note': 'per-step figures from HIP events on the main stream at the step boundaries (rank 0); '
                                '%d of the K steps carry event brackets around their MFMA launches (roofline), which costs those steps ~2 %%' % timed_steps},
             'engine_clock': clock.result(),
+            'step_launch': ('hipGraph replay of forward + DBLoss + backward (captured after %d eager steps), gradient exchange and Adam '
+                            'launched eagerly; the %d instrumented steps of the region are eager' % (trainer.graph_warmup, timed_steps)
+                            if trainer.use_graph else 'every kernel launched individually (--no-graph)'),
             'data_parallel': dp_diag,
             'roofline': roofline,
             'roofline_serial': roofline_serial,

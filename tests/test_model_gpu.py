@@ -90,8 +90,12 @@ def test_train_steps_vs_reference_golden(golden_dir, name):
             for k in [f[len('grad/'):-len('/stats')] for f in z.files if f.startswith('grad/') and f.endswith('/stats')]:
                 if k.endswith('.bias') and ('conv.bias' in k or k.endswith(('.0.bias', '.3.bias'))):
                     continue  # conv bias ahead of train-mode BN: analytically zero, reference value is round-off noise
-                if name.startswith('r50'):  # 53 conv layers: proportionally more ReLU-mask flips than resnet18
-                    check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k], l2_rtol=0.1, sample_tol=0.5, cos_min=0.99)
+                if name.startswith('r50'):
+                    # 53 conv layers: proportionally more ReLU-mask flips than resnet18.  Measured worst cases (round 3):
+                    # cosine 0.9983, L2 6.1 % (a one-element bias), single sample 0.27 of |g|max (an 8-element sample of a bias
+                    # vector); the principled bound on the Bottleneck backward is test_distance_to_fp64_is_within_the_references_own
+                    # (HIP no further from the fp64 gradient than 1.5x the reference's own fp32 run, per tensor)
+                    check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k], l2_rtol=0.08, sample_tol=0.35, cos_min=0.997)
                 else:
                     check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
         tol = ((1e-5, 1e-2, 5e-2) if name.startswith('r50') else (1e-5, 2e-3, 2e-2))[it]
@@ -603,7 +607,7 @@ def test_bottleneck_and_deformable_backbones_vs_oracle(arch, n, size):
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         rel = float((a - b).norm() / b.norm())
         worst = min(worst, cos)
-        assert cos >= 0.99 and rel <= 0.15, (k, cos, rel)
+        assert cos >= 0.997 and rel <= 0.08, (k, cos, rel)  # (measured worst: cosine 0.9988; see also the fp64-distance test)
     print('%s: worst gradient cosine %.6f' % (arch, worst))
     if 'deformable' in arch:
         k = 'backbone.layer2.0.conv2_offset.weight'
@@ -644,7 +648,10 @@ def test_native_bf16_on_bottleneck_and_deformable_backbones(arch):
         a, b = model.engine.grad_views[k].cpu().double().flatten(), grads_o[k].double().flatten()
         cos = float(a @ b / (a.norm() * b.norm()))
         print('%s bf16 grad %s: cos %.5f' % (arch, k, cos))
-        assert cos >= 0.6, (k, cos)
+        # (measured 0.74-0.98; the reference's own bf16-autocast run reaches 0.75-0.99 on the same kind of net, see the
+        # 'refbf16_cos' entries of tests/golden/fp64_r50_2x96_bn3x02.npz — the deformable nets have no reference yardstick:
+        # torchvision is absent)
+        assert cos >= 0.7, (k, cos)
 
 
 def test_two_stream_step_is_bit_reproducible():
@@ -665,6 +672,41 @@ def test_two_stream_step_is_bit_reproducible():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_graph_captured_step_is_bit_identical_to_the_eager_step(math):
+    """DBTrainer.use_graph: forward + DBLoss + backward replayed as ONE hipGraph launch (two-stream fork / join captured with it),
+    gradient exchange and Adam outside.  Five steps over changing batches — two eager warm-up steps, the capturing step, two
+    replays — must leave parameters, BatchNorm buffers (incl. num_batches_tracked), maps and losses bit-identical to five
+    eager steps, and an eval-mode forward afterwards must see the updated weights (the host-side panel stamps are kept valid)."""
+    seed = 9
+    batches = [O.synthetic_batch(2, 96, seed=seed + i) for i in range(3)]
+    outs = []
+    for use_graph in (False, True):
+        model = make_model(seed).train()
+        model.engine.set_conv_math(math)
+        trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        trainer.use_graph = use_graph
+        rec = []
+        for it in range(5):
+            img, gts = batches[it % 3]
+            preds, losses = trainer.step(img.to(DEV), gts.to(DEV))
+            rec.append((preds.clone(), losses.clone()))
+        assert (trainer._graph is not None and trainer._graph['graph'] is not None) == use_graph
+        model.eval()
+        with torch.no_grad():
+            pe = model(batches[0][0].to(DEV)).clone()
+        torch.cuda.synchronize()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        outs.append((rec, pe, sd, model.engine.flat_grad.clone()))
+    (rec0, pe0, sd0, g0), (rec1, pe1, sd1, g1) = outs
+    for it, ((p0, l0), (p1, l1)) in enumerate(zip(rec0, rec1)):
+        assert torch.equal(p0, p1) and torch.equal(l0, l1), 'step %d differs between the eager and the graph-captured step' % it
+    assert torch.equal(pe0, pe1) and torch.equal(g0, g1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert int(sd1['backbone.bn1.num_batches_tracked']) == 5
 
 
 def test_fit_and_evaluate_epoch_loop(tmp_path):
