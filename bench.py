@@ -149,8 +149,10 @@ def main():
                     help="N>1: time the 4-bucket exchange issued under the backward pass as the headline instead of north_star's one "
                          "all-reduce after it (the other form is always timed too and reported under grad_allreduce_other); results are "
                          "bit-identical (tests/test_dp_gloo.py, tests/test_rccl_gpu.py)")
-    ap.add_argument('--no-graph', action='store_true',
-                    help='launch every kernel of the step individually instead of replaying forward + loss + backward as one hipGraph')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay forward + loss + backward as one hipGraph (DBTrainer.use_graph) instead of launching every kernel '
+                         'individually.  Measured SLOWER on ROCm 7.2 / MI355X: 33.4 vs 32.0 ms (f32), 10.76 vs 10.07 ms (bf16) — the '
+                         'eager step is GPU-bound already (the host enqueues ahead) and the graph executor adds gaps between nodes')
     ap.add_argument('--serial-steps', type=int, default=3, help='instrumented single-stream steps for the kernels[] table (median)')
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
@@ -171,7 +173,7 @@ def main():
     model.engine.set_conv_math(args.math)
     trainer = DBTrainer(model, DBLoss(alpha=1.0, beta=10.0, negative_ratio=3, reduction='mean'), FusedAdam(model, lr=0.005))
     trainer.overlap_allreduce = bool(args.bucketed_allreduce)
-    trainer.use_graph = not args.no_graph and not args.bucketed_allreduce  # (the bucket announcements are host callbacks: eager only)
+    trainer.use_graph = args.graph and not args.bucketed_allreduce  # (the bucket announcements are host callbacks: eager only)
     img, gts = synthetic(args.batch, args.size, 42 + rank, dev)
     eng = model.engine
 
@@ -364,7 +366,7 @@ def main():
             'engine_clock': clock.result(),
             'step_launch': ('hipGraph replay of forward + DBLoss + backward (captured after %d eager steps), gradient exchange and Adam '
                             'launched eagerly; the %d instrumented steps of the region are eager' % (trainer.graph_warmup, timed_steps)
-                            if trainer.use_graph else 'every kernel launched individually (--no-graph)'),
+                            if trainer.use_graph else 'every kernel launched individually (default; --graph replays a captured hipGraph: measured slower)'),
             'data_parallel': dp_diag,
             'roofline': roofline,
             'roofline_serial': roofline_serial,

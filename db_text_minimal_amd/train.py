@@ -120,6 +120,9 @@ class DBTrainer:
         # kernel launches of a step replay with their captured arguments; the two-stream fork / join is captured with them).
         # The gradient exchange and Adam stay outside the graph (bias corrections and the learning rate change every step).
         # Captured after `graph_warmup` eager steps on the same batch shape; bit-identical to the eager step (tested).
+        # OFF by default: on ROCm 7.2 / MI355X the replay is SLOWER than the eager launches (f32 33.4 vs 32.0 ms, bf16 10.76 vs
+        # 10.07 ms per step at bs16 640^2): the host already enqueues far ahead of the GPU, so there is no launch latency to
+        # remove, and the graph executor leaves larger gaps between dependent nodes than back-to-back stream launches do.
         self.use_graph = os.environ.get('DBN_STEP_GRAPH', '0') == '1'
         self.graph_warmup = 2
         self._graph = None
