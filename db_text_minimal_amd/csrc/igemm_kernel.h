@@ -751,15 +751,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                         for (int b = 0; b < NI; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
-                if (s2 == 0) {
-                    // the staging writes of tile kt+1 BETWEEN the two MFMA groups (their registers landed a k-step ago): the write
-                    // latency and the s_waitcnt lgkmcnt(0) in front of the barrier then sit under the second group's MFMAs instead
-                    // of between the last MFMA and the barrier (tools/probes/mfma_peak.hip: 0.82 -> 0.86 of peak for this loop shape)
-                    __builtin_amdgcn_sched_barrier(0);
-                    stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                    next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
-                }
+                if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
             }
         } else {
             // one 32x32x16 bf16 MFMA k-step per k-tile: lane half lh owns k = 8*lh .. 8*lh+7
@@ -774,10 +766,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             mfma_split<NS, MI, NI, AT == 2>(af, bf, acc);
             next_offsets();
         }
-        if constexpr (NS != 0) stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
-        // (exact fp32: keep the second MFMA group in front of the barrier — the compiler otherwise sinks it below, which puts the
-        // barrier and the wait for the staging writes right behind the writes again)
-        if constexpr (NS == 0) __builtin_amdgcn_sched_barrier(0);
+        stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
         __syncthreads();
     };
     // whole pairs of k-steps, then the odd one: with `if (more) k_step(C1)` INSIDE the loop there is a static path around the

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                 for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -275,13 +275,6 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 #pragma unroll
                         for (int b = 0; b < NI; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
-                if (s2 == 0) {  // staging (transposes + LDS writes) between the two MFMA groups, see step() below
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) stage(buf ^ 1, C0{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         } else {
             bf16x8 af[NSX][MI], bf[NSX][NI];
 #pragma unroll
@@ -294,7 +287,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             mfma_split<NS, MI, NI>(af, bf, acc);
         }
         if (NS > 0) offsets(kt + 2);  // independent of the MFMAs above: overlaps their execution
-        if (NS > 0 && more) stage(buf ^ 1, C0{});
+        if (more) stage(buf ^ 1, C0{});
         __syncthreads();
     }
     } else {
@@ -327,7 +320,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                 for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -335,16 +328,6 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
 #pragma unroll
                         for (int b = 0; b < NI; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
-                if (s2 == 0) {
-                    // the staging of the next k-tile (register transposes + four ds_write_b128) BETWEEN the two MFMA groups, and the
-                    // second group pinned in front of the barrier: the write latency and the lgkmcnt(0) wait of the barrier then sit
-                    // under MFMAs instead of between the last MFMA and the barrier (tools/probes/mfma_peak.hip: 0.82 -> 0.86)
-                    __builtin_amdgcn_sched_barrier(0);
-                    stage(buf ^ 1, std::integral_constant<int, (U + 1) % D>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         } else {
             bf16x8 af[NSX][MI], bf[NSX][NI];
 #pragma unroll
@@ -356,7 +339,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             }
             mfma_split<NS, MI, NI>(af, bf, acc);
         }
-        if constexpr (NS != 0) stage(buf ^ 1, std::integral_constant<int, (U + 1) % D>{});
+        stage(buf ^ 1, std::integral_constant<int, (U + 1) % D>{});
         __syncthreads();
     };
     static_assert(D <= 4, "the k-loop spells the sets out");

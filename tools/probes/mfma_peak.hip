@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k(float* out, int steps, unsigned long lo
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < steps; ++it) {
         const f32x4* As = smem + (it & 1) * 1040;
-        if (MODE == 4) {
+        if (MODE >= 4) {
             st[it & 1][0] = src[goff0];
             st[it & 1][1] = src[goff1];
             st[it & 1][2] = src[goffb];
@@ -54,22 +54,13 @@ __global__ __launch_bounds__(256) void k(float* out, int steps, unsigned long lo
                 }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int a = 0; a < ACC; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][a & 1][e], bf[s][(a >> 1) & 1][e], acc[a], 0, 0, 0);
-            if (MODE == 5 && s == 0) {  // the staging writes between the two MFMA groups (their latency under the second group)
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4* Ws = smem + ((it + 1) & 1) * 1040;
-                Ws[(tid & 3) * 130 + (tid >> 2)] = st[(it + 1) & 1][0];
-                Ws[(tid & 3) * 130 + (tid >> 2) + 64] = st[(it + 1) & 1][1];
-                Ws[520 + (tid >> 6) * 66 + (tid & 63)] = st[(it + 1) & 1][2];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (MODE == 3 || MODE == 4) {
+        if (MODE >= 3) {
             f32x4* Ws = smem + ((it + 1) & 1) * 1040;
             Ws[(tid & 3) * 130 + (tid >> 2)] = st[(it + 1) & 1][0];
             Ws[(tid & 3) * 130 + (tid >> 2) + 64] = st[(it + 1) & 1][1];
@@ -127,7 +118,7 @@ int main() {
     for (int w = 1; w <= 3; ++w) run<4, 2>("MFMA + LDS reads + barrier per k-step", w);
     for (int w = 1; w <= 4; ++w) run<2, 3>("... + staging ds_write_b128 x3", w);
     for (int w = 1; w <= 3; ++w) run<4, 3>("... + staging ds_write_b128 x3", w);
-    for (int w = 3; w <= 4; ++w) run<2, 5>("staging writes BETWEEN the two MFMA groups", w);
-    for (int w = 2; w <= 3; ++w) run<4, 5>("staging writes BETWEEN the two MFMA groups", w);
+    for (int w = 1; w <= 4; ++w) run<2, 4>("... + global loads x3 (distance 2)", w);
+    for (int w = 1; w <= 3; ++w) run<4, 4>("... + global loads x3 (distance 2)", w);
     return 0;
 }
