@@ -3,6 +3,10 @@
 #pragma once
 #include "igemm_common.h"
 
+#ifndef DBN_DBG
+#define DBN_DBG 0
+#endif
+
 namespace {
 
 // MODE 0: hs = hd*stride - pad + r (forward conv, stride 1 or 2)
@@ -296,12 +300,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) ra_[st_][u][j] = buffer_load_f32x4(rsrc, aoff[u][j]);
+            for (int j = 0; j < A_LD; ++j)
+                if (!(DBN_DBG & 1)) ra_[st_][u][j] = buffer_load_f32x4(rsrc, aoff[u][j]);
             const long adv = b_left > 0 ? b_step : 0;
             --b_left;
 #pragma unroll
             for (int j = 0; j < B_LD; ++j) {
-                if (B_FULL || b_on[j]) rb_[st_][u][j] = *bptr[j];
+                if (!(DBN_DBG & 2) && (B_FULL || b_on[j])) rb_[st_][u][j] = *bptr[j];
                 bptr[j] += adv;
             }
         }
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         f32x4 (&rb)[B_LD] = rb_[st_][u_];
         f32x4* As = smem + buf * STAGE + u_ * UNIT;
         f32x4* Bs = As + A_IMG;
+        if (DBN_DBG & 4) return;
         if constexpr (NS == 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) As[a_chunk * AS + (tid >> 2) + j * (NT / 4)] = ra[j];
@@ -738,9 +744,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-                for (int a = 0; a < MI; ++a) af[s2][a] = As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
+                for (int a = 0; a < MI; ++a) af[s2][a] = (DBN_DBG & 8) ? f32x4{(float)kt, 1.f, 2.f, 3.f} : As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-                for (int b = 0; b < NI; ++b) bf[s2][b] = Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+                for (int b = 0; b < NI; ++b) bf[s2][b] = (DBN_DBG & 8) ? f32x4{1.f, (float)kt, 2.f, 3.f} : Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                         for (int b = 0; b < NI; ++b)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
-                if (s2 == 0) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
+                if (s2 == 0 && !(DBN_DBG & 32)) next_offsets();  // address math of tile kt+2 in the shadow of the MFMAs
             }
         } else {
             // one 32x32x16 bf16 MFMA k-step per k-tile: lane half lh owns k = 8*lh .. 8*lh+7
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             next_offsets();
         }
         stage(buf ^ 1, std::integral_constant<int, buf ^ 1>{});
-        __syncthreads();
+        if (!(DBN_DBG & 16)) __syncthreads();
     };
     // whole pairs of k-steps, then the odd one: with `if (more) k_step(C1)` INSIDE the loop there is a static path around the
     // second step on which the first step's loads reach the loop header unstaged, and the compiler guarded the header's fragment
