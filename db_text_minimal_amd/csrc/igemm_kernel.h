@@ -151,6 +151,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     auto a_plane = [&](int j) { return AT == 0 ? 0 : ((tid + j * NT) >> 1) / BM; };
     auto a_on = [&](int j) { return A_FULL || tid + j * NT < A_PIECES; };  // (the last j of tiles whose piece count is not a multiple of NT)
     int a_hb[A_LD], a_wb[A_LD], a_nb[A_LD];
+    // SOFF (blocked K walk on fp32 tensors): the tap / channel-block part of a gather address is the same for every lane, so it
+    // travels in the buffer instruction's SCALAR offset (not bounds-checked) and a lane only supplies its pixel's origin — or an
+    // out-of-range offset when the tap falls into the padding.  Per load and k-step that leaves two compares and a select for the
+    // vector ALU instead of the multiply-add chain (profile by deletion: the address math cost 0.06 of the MFMA peak).  The scalar
+    // offset must not be negative: the resource's base lies `a_shift` bytes in front of the tensor.
+    constexpr bool SOFF = BLK && AT == 0 && !PATCH;
+    unsigned a_org[A_LD];  // SOFF: byte offset (from the shifted base) of this lane's piece at the origin tap
     unsigned a_pl[A_LD];  // byte offset of the piece's plane
     unsigned plane_bytes = p.plane_bytes;
     int a_n[MODE == 3 ? A_LD : 1], a_hd[MODE == 3 ? A_LD : 1], a_wd[MODE == 3 ? A_LD : 1];
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         divmod24(mm, HWd, 1.0f / (float)HWd, n, rem);
         divmod24(rem, qWd, 1.0f / (float)qWd, hd, wd);
         a_nb[j] = n * p.Hs * p.Ws * p.Cs;
+        a_org[j] = 0;
         if (MODE == 3) {
             a_n[j] = n;
             a_hd[j] = ok ? hd : -(1 << 20);
@@ -173,11 +181,24 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         } else if (MODE == 0) {
             a_hb[j] = ok ? hd * p.stride - q.pad_h : -(1 << 20);  // a far-away row can never be in range
             a_wb[j] = wd * p.stride - q.pad_w;
+            // origin: tap (0, 0) seen from the shifted base = the pixel (hd*stride, wd*stride) itself
+            if (SOFF) a_org[j] = (unsigned)(a_nb[j] + (hd * p.stride * p.Ws + wd * p.stride) * p.Cs + A_CH * a_chunk) * (unsigned)ES;
         } else {
             a_hb[j] = ok ? hd + q.pad_h : -(1 << 20);
             a_wb[j] = wd + q.pad_w;
+            // origin: tap (R-1, S-1) seen from the shifted base = the pixel (hd + pad_h, wd + pad_w) (may lie below the tensor)
+            if (SOFF) a_org[j] = (unsigned)(a_nb[j] + ((hd + q.pad_h) * p.Ws + wd + q.pad_w) * p.Cs + A_CH * a_chunk) * (unsigned)ES;
         }
     }
+    // base shift in bytes (see SOFF) and the resource over [src - shift, src + bytes + margin): origins of the transposed forms
+    // reach up to pad rows below the tensor, which must still pass the bounds check (everything stays below OOB_OFFSET)
+    auto soff_rsrc = [&](const void* base, unsigned bytes, int Ws_, int R_, int S_, int padh, int padw) {
+        const unsigned shift = (unsigned)((MODE == 0 ? padh * Ws_ + padw : (R_ - 1) * Ws_ + (S_ - 1)) * p.Cs) * (unsigned)ES;
+        const unsigned margin = (unsigned)((padh * Ws_ + padw + 1) * p.Cs) * (unsigned)ES;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base) - shift), 0, bytes + shift + margin,
+                                                 0x00020000);
+    };
+    if (SOFF && MODE != 3) rsrc = soff_rsrc(p.src, p.src_bytes, p.Ws, q.R, q.S, q.pad_h, q.pad_w);
     // K order (must match the weight panels, pack_weights_kernel):
     //   Cs % 16 == 0: k = ((cb*R + r)*S + s)*16 + cl with ci = 16*cb + cl — every k-tile is one tap of one
     //                 16-channel block and the R*S taps of a block are consecutive k-tiles, so the 9 re-reads of
@@ -193,10 +214,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         kt_begin = blockIdx.y * p.kt_per;
         kt_end = min(qKT, kt_begin + p.kt_per);
     }
+    int k_cb = 0;  // SOFF: first channel of the current 16-channel block (wave-uniform, like k_r / k_s there)
     if (blocked) {  // k-tile kt is tap (kt % RS) of channel block (kt / RS)
         const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
         kidx += 16 * kt_begin;
         k_ci = 16 * cb + A_CH * a_chunk;
+        k_cb = 16 * cb;
         k_r = tap / qS;
         k_s = tap - k_r * qS;
     } else {
@@ -207,15 +230,31 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
 
     unsigned aoff[KU][A_LD];
+    unsigned asoff[KU];  // SOFF: the scalar offset of unit u (bytes)
     int kend = (MODE < 2 && p.ksplit > 1) ? min(qK, 16 * kt_end) : qK;  // units past the end (of K, or of this split's range) gather zeros
     auto next_offsets = [&](int u = 0) {  // offsets of the current k position (unit u of the barrier interval), then advance by 16 k
+        if constexpr (SOFF) {
+            // (k_r, k_s, k_cb derive from the workgroup's k-tile range only: scalar registers)
+            const int tr = MODE == 0 ? k_r : qR - 1 - k_r, ts = MODE == 0 ? k_s : qS - 1 - k_s;
+            asoff[u] = (unsigned)((tr * gWs + ts) * p.Cs + k_cb) * (unsigned)ES;
+            const bool kv = kidx - A_CH * a_chunk < kend;  // (uniform: kidx differs between lanes by the chunk only, kend % 16 == 0 here)
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
-            const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
-            const bool v = kidx < kend && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
-            const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES + (AT == 3 ? a_pl[j] : 0u);
-            aoff[u][j] = v ? off : OOB_OFFSET;
+            for (int j = 0; j < A_LD; ++j) {
+                const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
+                const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
+                const bool v = kv && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+                aoff[u][j] = v ? a_org[j] : OOB_OFFSET;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const int hs = MODE == 0 ? a_hb[j] + k_r : a_hb[j] - k_r;
+                const int ws = MODE == 0 ? a_wb[j] + k_s : a_wb[j] - k_s;
+                const bool v = kidx < kend && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
+                const unsigned off = (unsigned)(a_nb[j] + (hs * gWs + ws) * p.Cs + k_ci) * (unsigned)ES + (AT == 3 ? a_pl[j] : 0u);
+                aoff[u][j] = v ? off : OOB_OFFSET;
+            }
+            asoff[u] = 0;
         }
         kidx += 16;
         if (blocked) {  // next tap of the same channel block; after the last tap, the next block (branch-free)
@@ -226,6 +265,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             const bool wr_ = k_r == qR;
             k_r = wr_ ? 0 : k_r;
             k_ci += wr_ ? 16 : 0;
+            k_cb += wr_ ? 16 : 0;
         } else {
             k_ci += 16;
             while (k_ci >= p.Cs) {  // stem (Cs = 4): several taps per step
@@ -237,24 +277,29 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             }
         }
     };
-    const f32x4* bptr[B_LD];
+    // weight panel: a lane's piece of a k-tile lies at a fixed offset inside the tile, the tile's offset is wave-uniform and
+    // travels as the scalar offset of the buffer load (no per-lane pointer arithmetic in the k-loop)
+    unsigned b_voff[B_LD];
     int b_lds[B_LD];
     bool b_on[B_LD];
-    auto panel_setup = [&](const float* panel) {
+    __amdgpu_buffer_rsrc_t rsrcB;
+    int b_kt = 0, b_ktmax = 0;  // next k-tile to load (clamped to the last one: loads past the end re-read it), scalar
+    const unsigned b_step_bytes = (unsigned)((NS == 0 ? 4 : 2 * NS) * p.Cd) * 16u;  // bytes per k-tile
+    auto panel_setup = [&](const float* panel, int ktiles) {
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const int idx = tid + j * NT;
             b_on[j] = B_FULL || idx < B_PIECES;
             const int c = b_on[j] ? idx / BN : 0, n = idx - (idx / BN) * BN;  // c: k-chunk (NS==0) or split*2+k8 (NS>0)
-            bptr[j] = reinterpret_cast<const f32x4*>(panel) + (long)c * p.Cd + n0 + n;
+            b_voff[j] = (unsigned)(c * p.Cd + n0 + n) * 16u;
             b_lds[j] = c * BS + n;
         }
+        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(panel), 0, (unsigned)ktiles * b_step_bytes, 0x00020000);
     };
-    const long b_step = (NS == 0 ? 4L : 2L * NS) * p.Cd;  // 16-byte pieces per k-tile
     if (MODE != 3) {
-        panel_setup(p.wpk + q_wpk_off);
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) bptr[j] += kt_begin * b_step;
+        panel_setup(p.wpk + q_wpk_off, qKT);
+        b_kt = kt_begin;
+        b_ktmax = max(kt_end - 1, kt_begin);
     }
     // MODE 3: source, tap geometry and weight panel of pyramid level g for this tile's pixel class
     auto level_setup = [&](int g) {
@@ -276,15 +321,22 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         }
         long krows = 0;  // padded-K rows of the classes packed before (ph, pw)
         for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
-        panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2));
+        panel_setup(p.seg_wpk[g] + (NS == 0 ? krows * p.Cd : krows * p.Cd * NS / 2), qKT);
+        b_kt = 0;
+        b_ktmax = max(qKT - 1, 0);
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             a_nb[j] = a_n[MODE == 3 ? j : 0] * gHs * gWs * p.Cs;
             a_hb[j] = a_hd[MODE == 3 ? j : 0] * (8 >> g) + (q.oh0 >> g) + padh;
             a_wb[j] = a_wd[MODE == 3 ? j : 0] * (8 >> g) + (q.ow0 >> g) + padw;
+            // (rows past M carry a_hd = -2^20: never valid; their origin is never used, keep it in range of the arithmetic)
+            const int hb_ = a_hd[MODE == 3 ? j : 0] < 0 ? 0 : a_hb[j];
+            if (SOFF) a_org[j] = (unsigned)(a_nb[j] + (hb_ * gWs + a_wb[j]) * p.Cs + A_CH * a_chunk) * (unsigned)ES;
         }
+        if (SOFF) rsrc = soff_rsrc(p.seg_src[g], p.seg_bytes[g], gWs, qR, qS, padh, padw);
         kidx = A_CH * a_chunk;
         k_ci = A_CH * a_chunk;
+        k_cb = 0;
         k_r = k_s = 0;
     };
 
@@ -294,21 +346,26 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
     // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
     f32x4 ra_[2][KU][A_LD], rb_[2][KU][B_LD];
-    int b_left = 0;  // weight k-tiles that remain beyond the one bptr points at
     auto issue_loads = [&](auto SET) {
         constexpr int st_ = decltype(SET)::value;
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
-                if (!(DBN_DBG & 1)) ra_[st_][u][j] = buffer_load_f32x4(rsrc, aoff[u][j]);
-            const long adv = b_left > 0 ? b_step : 0;
-            --b_left;
+                if (!(DBN_DBG & 1)) {
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff[u][j], (int)asoff[u], 0);
+                    ra_[st_][u][j] = __builtin_bit_cast(f32x4, v_);
+                }
+            const unsigned bso = (unsigned)min(b_kt, b_ktmax) * b_step_bytes;
+            ++b_kt;
 #pragma unroll
-            for (int j = 0; j < B_LD; ++j) {
-                if (!(DBN_DBG & 2) && (B_FULL || b_on[j])) rb_[st_][u][j] = *bptr[j];
-                bptr[j] += adv;
-            }
+            for (int j = 0; j < B_LD; ++j)
+                if (!(DBN_DBG & 2) && (B_FULL || b_on[j])) {
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_voff[j], (int)bso, 0);
+                    rb_[st_][u][j] = __builtin_bit_cast(f32x4, v_);
+                }
         }
     };
     auto stage_unit = [&](int buf, auto SET, auto UU) {
@@ -700,7 +757,6 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    b_left = kt_end - kt_begin - 1;
     auto offsets_of_interval = [&]() {
 #pragma unroll
         for (int u = 0; u < KU; ++u) next_offsets(u);
