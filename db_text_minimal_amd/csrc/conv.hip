@@ -106,15 +106,17 @@ int dbn_igemm_tile_config(int M, int Cd) {
     // Workgroups are handed to the 256 CUs as they free up, so a launch lasts about
     // ceil(blocks/256) tiles per CU; pick the tile that minimises tiles-per-CU x tile area / efficiency
     // (efficiency = measured steady-state MFMA utilisation of each variant).
-    // Round 2 re-measured the variants alone on the backbone's four stage shapes (tools/tile_probe.py): with the two-tile prefetch
-    // the 64x64 tile is the fastest at 80x80x128 and 40x40x256 (115 / 103 TFLOP/s against 109 / 97 for the choices below).  In
-    // the two-stream step that does not carry over: efficiencies {0.89, 0.85, 0.845, 0.83} everywhere gave +0.5 % (within noise)
-    // with the dominant kernel's in-step rate down from 0.60 to 0.56, on the layer3/4-sized grids only -0.6 % — small tiles lose
-    // more to the co-resident weight-gradient workgroups.  The table stays (DBN_TILE_EFF_R2=1 selects the re-measured one).
+    // Round 2 re-measured the variants alone on the backbone's four stage shapes (tools/tile_probe.py): the smaller tiles are the
+    // faster ones in isolation (64x64: 115 / 125 / 112 TFLOP/s at 160x160x64 / 80x80x128 / 40x40x256 against 108 / 114 / 97 for
+    // 128x64 and 103 / 95 for 128x128, round-3 kernels).  Inside the two-stream step that did not carry over in round 2 (+0.5 %,
+    // within noise); with round 3's k-loop (scalar-offset addressing, no drained prefetch) it does: efficiencies
+    // {0.89, 0.85, 0.845, 0.83} give 524 images/s against 511 for round 1's {0.89, 0.83, 0.80, 0.72} (interleaved A/B on one box,
+    // 510.9 / 524.4 / 523.9 / 510.3 / 523.9; a table favouring 64x64 even more, {0.80, 0.76, 0.86, 0.93}, measures the same).
+    // (-DDBN_EXPERIMENTS builds: DBN_TILE_EFF_R2=0 selects round 1's table, 2 the third one)
     const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 64, 64};
-    static const bool r2_eff = dbn_env_int("DBN_TILE_EFF_R2", 0) != 0;
-    const double eff_r1[4] = {0.89, 0.83, 0.80, 0.72}, eff_r2[4] = {0.89, 0.85, 0.845, 0.83};
-    const double* eff = r2_eff ? eff_r2 : eff_r1;
+    static const int r2_eff = dbn_env_int("DBN_TILE_EFF_R2", 1);
+    const double eff_r1[4] = {0.89, 0.83, 0.80, 0.72}, eff_r2[4] = {0.89, 0.85, 0.845, 0.83}, eff_r3[4] = {0.80, 0.76, 0.86, 0.93};
+    const double* eff = r2_eff == 2 ? eff_r3 : r2_eff ? eff_r2 : eff_r1;
     int best = 4;
     double best_t = 1e300;
     for (int c = 0; c < 4; ++c) {

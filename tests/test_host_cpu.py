@@ -54,7 +54,7 @@ def test_size_queries_without_gpu():
     assert L.dbn_reduce_ws_floats(512) == 1024 * 2 * 512
     # bs16 640x640 shapes: FPN conv / head convs use the 128x128 tile, Cout=64 layers 256x64
     assert L.dbn_igemm_tile_config(409600, 256) == 1
-    assert L.dbn_igemm_tile_config(409600, 64) in (2, 3)
+    assert L.dbn_igemm_tile_config(409600, 64) in (2, 3, 4)  # (round 3: the 64x64 tile, see dbn_igemm_tile_config)
     sk = L.dbn_wgrad_splitk(16, 160, 160, 64, 64, 3, 3)
     assert 1 <= sk <= 409600 // 256
 
