@@ -20,9 +20,11 @@ SIGNATURES = {
     'dbn_igemm_packed_floats': 'ii',
     'dbn_igemm_f32': 'pppp' + 'i' * 14 + 'p',
     'dbn_igemm_tile_config': 'ii',
+    'dbn_igemm_tile_config_ns': 'iii',
     'dbn_conv_bn_ws_floats': 'iiiiii',
     'dbn_pack_weights_batched': 'piip',
     'dbn_igemm_splitk_plan': 'iiii',
+    'dbn_igemm_splitk_plan_ns': 'iiiii',
     'dbn_igemm_splitk_f32': 'pppp' + 'i' * 16 + 'pp',
     'dbn_deform_im2col': 'ppp' + 'i' * 11 + 'p',
     'dbn_deform_col2im': 'ppppp' + 'i' * 11 + 'p',

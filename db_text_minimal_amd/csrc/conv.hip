@@ -102,7 +102,7 @@ int dbn_has_experiments(void) { return DBN_HAS_EXPERIMENTS; }
 // Tile configuration dbn_igemm_f32 picks for an M x Cd output (tile_hint 0):
 // 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64 — the largest tile that still yields
 // >= ~2 workgroups per CU on 256 CUs.
-int dbn_igemm_tile_config(int M, int Cd) {
+static int tile_config_for(int M, int Cd, int ns) {
     // Workgroups are handed to the 256 CUs as they free up, so a launch lasts about
     // ceil(blocks/256) tiles per CU; pick the tile that minimises tiles-per-CU x tile area / efficiency
     // (efficiency = measured steady-state MFMA utilisation of each variant).
@@ -114,7 +114,9 @@ int dbn_igemm_tile_config(int M, int Cd) {
     // 510.9 / 524.4 / 523.9 / 510.3 / 523.9; a table favouring 64x64 even more, {0.80, 0.76, 0.86, 0.93}, measures the same).
     // (-DDBN_EXPERIMENTS builds: DBN_TILE_EFF_R2=0 selects round 1's table, 2 the third one)
     const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 64, 64};
-    static const int r2_eff = dbn_env_int("DBN_TILE_EFF_R2", 1);
+    // (the 16-bit matrix modes keep round 1's table: their DMA-ring kernels lose with the small tiles — bf16 1619 -> 1565 images/s)
+    static const int r2_env = dbn_env_int("DBN_TILE_EFF_R2", 1);
+    const int r2_eff = ns == 0 ? r2_env : 0;
     const double eff_r1[4] = {0.89, 0.83, 0.80, 0.72}, eff_r2[4] = {0.89, 0.85, 0.845, 0.83}, eff_r3[4] = {0.80, 0.76, 0.86, 0.93};
     const double* eff = r2_eff == 2 ? eff_r3 : r2_eff ? eff_r2 : eff_r1;
     int best = 4;
@@ -132,6 +134,8 @@ int dbn_igemm_tile_config(int M, int Cd) {
     }
     return best;
 }
+int dbn_igemm_tile_config(int M, int Cd) { return tile_config_for(M, Cd, 0); }  // exact-fp32 choice
+int dbn_igemm_tile_config_ns(int M, int Cd, int ns) { return tile_config_for(M, Cd, ns); }
 
 static int g_patch_enabled = 1;
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
@@ -153,7 +157,7 @@ static int patch_cfg(int cfg) { return (cfg == 1 && g_patch_bn64) ? 3 : cfg; }
 // the pixel-patch kernel get a 128-row tile whatever the generic heuristic says.
 static int resolve_cfg(int M_total, int Cd, int tile_hint, int at = 0, int ns = 0, int mode = 0, int R = 0, int S = 0, int stride = 1,
                        int pad = 0, int Hs = 0, int Ws = 0, int Hd = 0, int Wd = 0, int Cs = 0, int ksplit = 1) {
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(M_total, Cd);
+    int cfg = tile_hint > 0 ? tile_hint : tile_config_for(M_total, Cd, ns);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
     if (tile_hint == 0 && !(mode == 1 && stride > 1) && patch_eligible(mode, ns, at, 3, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) cfg = 3;
     return cfg;
@@ -172,7 +176,7 @@ int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, in
 
 static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipStream_t st, int at = 0) {
     // tile choice from the total row count (for parity classes: all classes together)
-    int cfg = tile_hint > 0 ? tile_hint : dbn_igemm_tile_config(p.N * p.Hdf * p.Wdf, p.Cd);
+    int cfg = tile_hint > 0 ? tile_hint : tile_config_for(p.N * p.Hdf * p.Wdf, p.Cd, ns);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
     p.patch = patch_eligible(kmode, ns, at, cfg, p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hdf, p.Wdf, p.Cs, p.ksplit);
     // 128 x 64 tiles also where the generic loop takes 128 x 128: K is short (two to eight channel blocks), so twice the workgroups
@@ -419,9 +423,9 @@ int dbn_igemm_bf16s(const float* src, const float* wpk, const float* bias, float
 
 // Split-K plan for a conv whose output grid alone cannot fill the chip (few pixels x few channels, long reduction —
 // the coarse FPN levels' data gradients): number of K splits (1 = none) for M rows, Cd channels, K = R*S*Cs.
-int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) {
+int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns) {
     if (Cs % 16 != 0) return 1;
-    const int cfg0 = dbn_igemm_tile_config(M, Cd);
+    const int cfg0 = tile_config_for(M, Cd, ns);
     const int cfg = (cfg0 == 1 && Cd % 128 != 0) ? 3 : cfg0;
     static const int bm_of[5] = {0, 128, 256, 128, 64}, bn_of[5] = {0, 128, 64, 64, 64};
     const long tiles = (long)dbn_ceil_div(M, bm_of[cfg]) * (Cd / bn_of[cfg]);
@@ -433,6 +437,7 @@ int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) {
     if (sk > 64) sk = 64;
     return sk < 2 ? 1 : (int)sk;
 }
+int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) { return dbn_igemm_splitk_plan_ns(M, Cd, K, Cs, 0); }
 
 // dbn_igemm_f32 with the reduction split `ksplit` ways (mode 0, or mode 1 with stride 1; Cs % 16 == 0).
 // slab: ksplit * N*Hd*Wd*Cd floats of scratch.  Bit-reproducible (fixed summation order).

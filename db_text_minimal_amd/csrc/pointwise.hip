@@ -206,6 +206,48 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nb, i
     c2[c] = (float)(s2 / M);
 }
 
+// The same for MANY partials per channel (the sums produced per output tile by a data gradient's epilogue: 6400 rows at bs16
+// 160x160 with 64-row tiles): one 256-thread block per channel instead of a 32-lane team — the team's chain of 50 dependent
+// load rounds took 20-30 us per BatchNorm layer, the block takes a few.  Fixed order: thread t adds rows t, t+256, ... in fp64,
+// then a fixed tree over the threads.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(const float* __restrict__ part, int nb, int M, int C,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                   float* __restrict__ c1, float* __restrict__ c2, float gscale) {
+    __shared__ double red[2][256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    const float* p1 = part + (long)c * nb;
+    const float* p2 = part + ((long)C + c) * nb;
+    double s1 = 0.0, s2 = 0.0;
+    int b = t;
+    for (; b + 768 < nb; b += 1024) {  // eight independent loads in flight per thread
+        const float a0 = p1[b], a1 = p1[b + 256], a2 = p1[b + 512], a3 = p1[b + 768];
+        const float q0 = p2[b], q1 = p2[b + 256], q2 = p2[b + 512], q3 = p2[b + 768];
+        s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        s2 += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+    }
+    for (; b < nb; b += 256) {
+        s1 += (double)p1[b];
+        s2 += (double)p2[b];
+    }
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            red[0][t] += red[0][t + o];
+            red[1][t] += red[1][t + o];
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    s1 = red[0][0];
+    s2 = red[1][0];
+    dbeta[c] = (float)(s1 * gscale);
+    dgamma[c] = (float)(s2 * gscale);
+    c1[c] = (float)(s1 / M);
+    c2[c] = (float)(s2 / M);
+}
+
 // dy = gamma*rstd*(g - c1 - xhat*c2); optionally also emits g (the ReLU-masked dout).
 // bias_part (optional, needs 256 % (C/4) == 0): per-block column sums of dy, [C][gridDim.x] — the gradient of the bias of the
 // conv that feeds this BatchNorm (analytically zero; the reference's value is the round-off of exactly this sum), so that no
@@ -790,7 +832,10 @@ int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, 
     const long total4 = (long)M * (C / 4);
     const int grid = bn_stream_grid(total4, C);
     DBN_DISPATCH_AT(at, {
-        if (sums) {
+        if (sums && sums_parts >= 512) {
+            hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C), dim3(256), 0, st, sums, sums_parts, M, C, dgamma, dbeta, c1, c2,
+                               grad_scale);
+        } else if (sums) {
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, sums, sums_parts > 0 ? sums_parts : 1, M,
                                C, dgamma, dbeta, c1, c2, grad_scale);
         } else {

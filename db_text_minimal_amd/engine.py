@@ -337,7 +337,7 @@ class Engine:
             return False
         if self.prof is not None and self.prof.labels is None and not self.prof_fused:
             return False
-        return not (self.splitk and self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs) > 1)
+        return not (self.splitk and self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * S * Cs, Cs, self.ns) > 1)
 
     prof_fused = True
 
@@ -372,7 +372,7 @@ class Engine:
             return
         ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):
-            ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * S * Cs, Cs)
+            ks = self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * S * Cs, Cs, self.ns)
             if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
                 slab = self.scratch('_splitk_slab', ks * (N * Hd * Wd * Cd + 1088))  # slabs are padded apart (HBM channel rotation)
         check(self.L.dbn_igemm_t(at, self.ns, srcp, *args[1:], ks, _p(slab), self.stream), what)
@@ -453,7 +453,7 @@ class Engine:
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        split = self.splitk and self.L.dbn_igemm_splitk_plan(N * Ho * Wo, conv.cout, k * k * C, C) > 1
+        split = self.splitk and self.L.dbn_igemm_splitk_plan_ns(N * Ho * Wo, conv.cout, k * k * C, C, self.ns) > 1
         if not (train and self.fuse_bn_stats) or split:  # split-K convs take their statistics in a (small) separate pass
             y = self.conv_fwd(name, x, conv, out_name, version=version)
             sc, sh = self.bn_coef(bn_name, bn, y, train)
@@ -491,11 +491,11 @@ class Engine:
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0, geom=None, epi=0):
         """geom = (N, Hs, Ws, Cs, Hd, Wd, R, stride, pad) of a forward / stride-1 data-gradient call: only those can take the
         pixel-patch kernel (the last template argument of the symbol)."""
-        cfg = self.L.dbn_igemm_tile_config(M, Cd)
+        cfg = self.L.dbn_igemm_tile_config_ns(M, Cd, self.ns)
         at = 3 if self._use_planes else self.at
         if geom is not None and mode < 2:
             N, Hs, Ws, Cs, Hd, Wd, R, stride, pad = geom
-            ks = self.L.dbn_igemm_splitk_plan(N * Hd * Wd, Cd, R * R * Cs, Cs) if self.splitk else 1
+            ks = self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * R * Cs, Cs, self.ns) if self.splitk else 1
             cfg = self.L.dbn_igemm_kernel_config(at, self.ns, mode, N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, 0, ks)
         self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi), flops, 0.0, tag)
 

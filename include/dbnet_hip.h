@@ -99,6 +99,7 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
  * dbn_igemm_splitk_plan returns the split count the library would pick (1 = do not split);
  * slab: ksplit * (N*Hd*Wd*Cd + 1088) floats (the slabs are padded apart so that consecutive splits land on different HBM channels). */
 int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs);
+int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns); /* ... for matrix math ns (the plan follows the tile choice) */
 int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                          int ksplit, float* slab, void* stream);
@@ -118,6 +119,8 @@ int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, cons
 
 /* tile configuration chosen for tile_hint 0: 1=128x128, 2=256x64, 3=128x64, 4=64x64 */
 int dbn_igemm_tile_config(int M, int Cd);
+/* ... for matrix math ns (0 exact fp32, 1 / 3 the bf16 pipe: those modes keep the larger tiles) */
+int dbn_igemm_tile_config_ns(int M, int Cd, int ns);
 
 /* grad_oihw[O][I][R][S] = scale * sum_p sm[p][o] * big[pixel(p)+tap][i];
  * sm = [N,Ho,Wo,O] (output-side tensor), big = [N,H,W,Cb] (input-side, Cb >= I).

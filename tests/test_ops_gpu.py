@@ -1318,3 +1318,42 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
     if two:
         xhat2 = (y2.double() - mean2.double().view(1, -1, 1, 1)) * rstd2.double().view(1, -1, 1, 1)
         report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, (g * xhat2).sum((0, 2, 3))]), 2e-6 * sc, 1e-5)
+
+
+@pytest.mark.parametrize('C,N,H,W,parts', [(64, 2, 12, 10, 1), (64, 2, 12, 10, 37), (128, 1, 16, 16, 700), (64, 2, 24, 24, 6400), (256, 1, 8, 8, 513)])
+def test_batchnorm_backward_from_given_partial_sums(C, N, H, W, parts):
+    """dbn_bn_backward_t with `sums` = [2][C][parts] partials produced elsewhere (a data gradient's epilogue writes one row per
+    output tile: thousands of rows at bs16 160x160): the finalize step folds them — a 32-lane team per channel for few rows, a
+    256-thread block per channel from 512 rows on — and the result must equal the BatchNorm + ReLU backward of autograd."""
+    x = (rnd(N, C, H, W, seed=1) * 2 + 3).requires_grad_(True)
+    gamma = (rnd(C, seed=2) * 0.3 + 1).requires_grad_(True)
+    beta = rnd(C, seed=3).requires_grad_(True)
+    z = F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5))
+    dout = rnd(N, C, H, W, seed=7)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(z, (x, gamma, beta), dout)
+    M = N * H * W
+    xd = x.detach()
+    mean = xd.mean((0, 2, 3))
+    rstd = 1.0 / torch.sqrt(xd.var((0, 2, 3), unbiased=False) + 1e-5)
+    g = (dout * (z.detach() > 0)).double()
+    xhat = ((xd - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)).double()
+    s1, s2 = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
+    # split the two sums into `parts` random addends per channel (fp32, as a producing kernel would store them)
+    gen = torch.Generator().manual_seed(5)
+    wts = torch.rand(2, C, parts, generator=gen, dtype=torch.float64) + 0.1
+    wts = wts / wts.sum(2, keepdim=True)
+    part = (torch.stack([s1, s2]).unsqueeze(2) * wts).float()
+    resid = torch.stack([s1, s2]) - part.double().sum(2)  # keep the total exact to fp32 round-off of one addend
+    part[:, :, 0] += resid.float()
+    xs, zs, douts = nhwc(xd), nhwc(z.detach()), nhwc(dout)
+    dy = torch.empty_like(xs)
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dev = lambda t: t.contiguous().to(DEV)
+    part_d, mean_d, rstd_d, gam_d = dev(part), dev(mean), dev(rstd), dev(gamma.detach())
+    ws = reduce_ws()
+    _lib.check(L().dbn_bn_backward_t(0, part_d.data_ptr(), parts, xs.data_ptr(), zs.data_ptr(), None, None, douts.data_ptr(),
+                                     mean_d.data_ptr(), rstd_d.data_ptr(), gam_d.data_ptr(), dy.data_ptr(), None, 0, dg.data_ptr(),
+                                     db.data_ptr(), None, M, C, 1.0, ws.data_ptr(), stream()), 'bn backward from sums')
+    report('bn bwd (given sums, %d parts) dx' % parts, nchw(dy), dx_ref, 2e-5, 1e-4)
+    report('dgamma', dg.cpu(), dg_ref, 1e-4, 1e-4)
+    report('dbeta', db.cpu(), db_ref, 1e-4, 1e-4)
