@@ -357,14 +357,16 @@ int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int
 // mean / rstd, and ReLU mask either `zmask` > 0 (a saved activation of that shape) or fma(y, mask_scale, mask_shift) > 0 (the
 // BatchNorm's own output recomputed).  The sums are taken over the FINAL dst values (after `accumulate`), so the call must be
 // the last writer of dst.  part: [2][Cd][dbn_igemm_bn_rows(...)] floats.  Replaces the reduce pass of dbn_bn_backward_t (which
-// re-reads dst and y): pass `part` as its `sums`.  Exact-fp32 math on fp32 tensors (at = 0, ns = 0) only.
+// re-reads dst and y): pass `part` as its `sums`.  fp32 tensors (at = 0, any matrix math) and bf16 tensors (at = 1): in bf16
+// storage the sums are taken over the values as stored (rounded), y / zmask are bf16 like dst.
 // y2 / save_mean2 / save_rstd2 / part2 (optional, with zmask): a second BatchNorm that consumes the same dst under the same mask.
 int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                        int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
                        const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
                        const float* save_rstd, float* part, const void* y2, const float* save_mean2, const float* save_rstd2,
                        float* part2, void* stream) {
-    DBN_REQUIRE(at == 0 && ns == 0 && y && save_mean && save_rstd && part && (zmask || (mask_scale && mask_shift)));
+    DBN_REQUIRE(((at == 0 && (ns == 0 || ns == 1 || ns == 3)) || (at == 1 && ns == 1)) && y && save_mean && save_rstd && part &&
+                (zmask || (mask_scale && mask_shift)));
     DBN_REQUIRE(!y2 || (zmask && save_mean2 && save_rstd2 && part2));
     const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
     DBN_REQUIRE(rows > 0);

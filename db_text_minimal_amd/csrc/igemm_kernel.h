@@ -43,7 +43,7 @@ namespace {
 // into every kernel's k-loop (and an s_waitcnt vmcnt(0) at the loop header that drained the two-tile prefetch every iteration).
 template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0, bool BLK = true>
 __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) void igemm_f32_kernel(const IgemmParams p) {
-    static_assert(EPI == 0 || (AT == 0 && MODE < 3 && !PATCH), "BatchNorm-backward sums: fp32 storage, generic loop");
+    static_assert(EPI == 0 || ((AT == 0 || AT == 1) && MODE < 3), "BatchNorm-backward sums: fp32 or bf16 storage, no pyramid form");
     static_assert(BLK || (AT == 0 && MODE == 0 && !PATCH && EPI == 0), "non-blocked K walk: forward conv on fp32 tensors");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
     static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
@@ -86,7 +86,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // three planes: ONE patch buffer (refilled between two barriers at a channel-block boundary) keeps the workgroup at 70 KB
     // so that two fit a CU; with a second buffer it was alone on its CU (103 KB, one wave per SIMD: every LDS latency exposed)
     constexpr int P_NBUF = NSX == 1 ? 2 : 1;
-    __shared__ f32x4 smem[PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE];
+    // (EPI = 1 on fp32 storage: the row-major epilogue needs half a tile — a whole one for one accumulator block per wave — of fp32)
+    constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
+    constexpr int EPI_SMEM = (EPI == 1 && DST_F32) ? BM * BN / (4 * (MI >= 2 ? 2 : 1)) : 0;
+    __shared__ f32x4 smem[LOOP_SMEM > EPI_SMEM ? LOOP_SMEM : EPI_SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1061,7 +1064,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // second pass walks it row-major: a thread owns one channel quad, reads dz from LDS and y / mask from HBM as 16-byte pieces
     // (a row's BN*4 contiguous bytes per BN/4 lanes), accumulates its quad's two sums over the rows it visits, and stores dz with
     // 16-byte stores.  Tiles larger than the LDS panels (128x128, 256x64) take two passes (accumulator blocks a < MI/2, then the rest).
-    if constexpr (EPI == 1) {
+    if constexpr (EPI == 1 && DST_F32) {
         constexpr int PITCH = BN;                            // floats per LDS row (the b32 writes and b128 reads below are conflict-free unpadded)
         constexpr int HALVES = ((long)BM * PITCH * 4 > (long)sizeof(smem)) ? 2 : 1;
         constexpr int MI_H = MI / HALVES, RH = BM / HALVES;  // accumulator blocks / tile rows per pass
@@ -1191,6 +1194,89 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             constexpr int LPR = T_LPR, RPP = T_RPP;
             static_assert(BM % RPP == 0, "whole passes");
             const int piece = tid % LPR;
+            if constexpr (EPI == 1) {
+                // + the sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_part), taken in the same row-major sweep
+                // over the values AS STORED (rounded to the storage type: what the apply pass will read back).  A thread owns 8
+                // channels; y / the mask tensor come in as 16-byte pieces like dst goes out.
+                static_assert(AT == 1, "sums epilogue of the 16-bit path: bf16 storage (training)");
+                const unsigned short* const yb = reinterpret_cast<const unsigned short*>(p.bnb_y);
+                const unsigned short* const zb = reinterpret_cast<const unsigned short*>(p.bnb_zmask);
+                const unsigned short* const y2b = reinterpret_cast<const unsigned short*>(p.bnb_y2);
+                const int cg = n0 + piece * 8;
+                float mu[8], rs[8], msc[8], msh[8], mu2[8], rs2[8], s1[8], s2[8], s4[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    mu[e] = p.bnb_mean[cg + e];
+                    rs[e] = p.bnb_rstd[cg + e];
+                    msc[e] = zb ? 0.f : p.bnb_msc[cg + e];
+                    msh[e] = zb ? 0.f : p.bnb_msh[cg + e];
+                    mu2[e] = y2b ? p.bnb_mean2[cg + e] : 0.f;
+                    rs2[e] = y2b ? p.bnb_rstd2[cg + e] : 0.f;
+                    s1[e] = s2[e] = s4[e] = 0.f;
+                }
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                auto bf = [](const u32x4_& w, int e) { return __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xFFFF0000u) : (w[e >> 1] << 16)); };
+                auto sweep16 = [&](auto ZM, auto TWO) {
+                    constexpr bool kZ = decltype(ZM)::value, k2 = decltype(TWO)::value;
+#pragma unroll 1
+                    for (int ps = 0; ps < BM / RPP; ++ps) {
+                        const int row = ps * RPP + tid / LPR;
+                        const u32x4_ v = *reinterpret_cast<const u32x4_*>(T + row * PITCH + piece * 8);
+                        bool ok;
+                        long doff;
+                        tile_row(row, ok, doff);
+                        const long o = ok ? doff + cg : (long)cg;  // rows past M read a valid pixel, contribute nothing
+                        const u32x4_ yv = *reinterpret_cast<const u32x4_*>(yb + o);
+                        u32x4_ zv = yv, y2v = yv;
+                        if constexpr (kZ) zv = *reinterpret_cast<const u32x4_*>(zb + o);
+                        if constexpr (k2) y2v = *reinterpret_cast<const u32x4_*>(y2b + o);
+                        if (ok) *reinterpret_cast<u32x4_*>(reinterpret_cast<unsigned short*>(dstv) + doff + cg) = v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float y_ = bf(yv, e);
+                            float m_;
+                            if constexpr (kZ) m_ = bf(zv, e);
+                            else m_ = dbn_affine(y_, msc[e], msh[e]);
+                            const float g = (ok & (m_ > 0.f)) ? bf(v, e) : 0.f;
+                            s1[e] += g;
+                            s2[e] += g * ((y_ - mu[e]) * rs[e]);
+                            if constexpr (k2) s4[e] += g * ((bf(y2v, e) - mu2[e]) * rs2[e]);
+                        }
+                    }
+                };
+                if (zb && y2b) sweep16(std::true_type{}, std::true_type{});
+                else if (zb) sweep16(std::true_type{}, std::false_type{});
+                else sweep16(std::false_type{}, std::false_type{});
+                // fold the RPP row groups of each channel in fixed order, write this tile's partial row
+                static_assert(2L * RPP * BN * 4 <= (long)sizeof(smem), "reduction scratch");
+                float* const r1 = reinterpret_cast<float*>(smem);  // [RPP][BN]
+                float* const r2 = r1 + RPP * BN;                    // [RPP][BN]
+                const int rq = tid / LPR;
+                const int trow_ = p.stat_row0 + q_row_base + mt;
+                auto fold16 = [&](const float (&a_)[8], const float (&b_)[8], float* part) {
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        r1[rq * BN + piece * 8 + e] = a_[e];
+                        r2[rq * BN + piece * 8 + e] = b_[e];
+                    }
+                    __syncthreads();
+                    for (int cl = tid; cl < BN; cl += NT) {
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < RPP; ++w) {
+                            t1 += r1[w * BN + cl];
+                            t2 += r2[w * BN + cl];
+                        }
+                        const long c = n0 + cl;
+                        part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
+                        part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+                    }
+                };
+                fold16(s1, s2, p.bnb_part);
+                if (y2b) fold16(s1, s4, p.bnb_part2);
+                return;
+            }
 #pragma unroll
             for (int ps = 0; ps < BM / RPP; ++ps) {
                 const int row = ps * RPP + tid / LPR;
@@ -1237,8 +1323,21 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
+    const bool epi_ok = gy == 1 && p.bnb_y && p.bnb_mean && p.bnb_rstd && (p.bnb_zmask || (p.bnb_msc && p.bnb_msh)) &&
+                        (!p.bnb_y2 || (p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2));
     if constexpr (BM == 128 && WM == 2 && WN == 2 && NS > 0 && AT != 3) {
         if (p.patch && mode < 2) {
+            if constexpr (AT == 0 || AT == 1) {
+                if (p.bnb_part) {
+                    if (!epi_ok) return DBN_ERR_ARG;
+                    if (mode == 0)
+                        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, true, 1>), dim3(grid), dim3(256), 0, st, p);
+                    else
+                        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 1, NS, AT, true, 1>), dim3(grid), dim3(256), 0, st, p);
+                    return dbn_status();
+                }
+            }
+            if (p.bnb_part) return DBN_ERR_ARG;
             if (mode == 0)
                 hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, true>), dim3(grid), dim3(256), 0, st, p);
             else
@@ -1256,10 +1355,9 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
             return DBN_ERR_ARG;
         }
     }
-    if (p.bnb_part) {  // with the sums of the BatchNorm backward that consumes dst (exact fp32 on fp32 tensors only)
-        if constexpr (NS == 0 && AT == 0) {
-            if (gy != 1 || !p.bnb_y || !p.bnb_mean || !p.bnb_rstd || !(p.bnb_zmask || (p.bnb_msc && p.bnb_msh))) return DBN_ERR_ARG;
-            if (p.bnb_y2 && !(p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2)) return DBN_ERR_ARG;
+    if (p.bnb_part) {  // with the sums of the BatchNorm backward that consumes dst (fp32 or bf16 storage)
+        if constexpr (AT == 0 || AT == 1) {
+            if (!epi_ok) return DBN_ERR_ARG;
             if (mode == 0)
                 hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, 0, NS, AT, false, 1>), dim3(grid), dim3(WM * WN * 64), 0, st, p);
             else if (mode == 1)

@@ -40,9 +40,10 @@ def flat_layout(numels):
     return offs, total
 
 
-# rocprof names: <BM,BN,WM,WN,MODE,NS,AT,PATCH,EPI> (EPI = 1: epilogue with the sums of the consuming BatchNorm's backward)
-IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s,%d>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s,%d>',
-                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s,%d>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s,%d>'}
+# rocprof names: <BM,BN,WM,WN,MODE,NS,AT,PATCH,EPI,BLK> (EPI = 1: epilogue with the sums of the consuming BatchNorm's backward;
+# BLK = false: the stem's K walk across taps)
+IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s,%d,%s>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s,%d,%s>',
+                    3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s,%d,%s>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s,%d,%s>'}
 WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d>',
                     3: 'wgrad_f32_kernel<64,128,2,2,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d>'}
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
@@ -331,7 +332,7 @@ class Engine:
     def _bnb_eligible(self, args):
         """Can this igemm call (dbn_igemm_f32 argument list) carry the BatchNorm-backward sums of its consumer?"""
         N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode = args[4:16]
-        if not self.fuse_bn_bwd_sums or self.at != 0 or self.ns != 0 or self._use_planes:
+        if not self.fuse_bn_bwd_sums or self._use_planes or not ((self.at == 0 and self.ns in (0, 1, 3)) or (self.at == 1 and self.ns == 1)):
             return False
         if mode == 1 and stride > 1 and (R < stride or S < stride):  # a parity class without taps: pixels the launch never visits
             return False
@@ -497,7 +498,8 @@ class Engine:
             N, Hs, Ws, Cs, Hd, Wd, R, stride, pad = geom
             ks = self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * R * Cs, Cs, self.ns) if self.splitk else 1
             cfg = self.L.dbn_igemm_kernel_config(at, self.ns, mode, N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, 0, ks)
-        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi), flops, 0.0, tag)
+        blk = 'false' if (geom is not None and mode == 0 and geom[3] % 16 != 0) else 'true'
+        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, 0.0, tag)
 
     def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None, consumer=None):
         """consumer: see _igemm — the BatchNorm that will consume dx, when this call is dx's last writer."""
@@ -1066,7 +1068,7 @@ class Engine:
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0,true>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co

@@ -69,10 +69,10 @@ int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_
  * output recomputed as fma(y, mask_scale[c], mask_shift[c]) > 0.  Per output tile (row) and channel:
  *   part[0][c][row] = sum g,   part[1][c][row] = sum g * (y - mean[c]) * rstd[c],   g = dz_final * [mask > 0]
  * over the FINAL dst values (after `accumulate`): the call must be the last writer of dst.  part: [2][Cd][rows] floats with
- * rows = dbn_igemm_bn_rows(same geometry); hand it to dbn_bn_backward_t as `sums` with sums_parts = rows.  y2 / save_mean2 /
+ * rows = dbn_igemm_bn_rows(same geometry); hand it to dbn_bn_backward_t as `sums` with sums_parts = rows.  fp32 tensors
+ * (at = 0, ns = 0 / 1 / 3) and bf16 tensors (at = 1, ns = 1: sums over the stored, rounded values; y / zmask bf16).  y2 / save_mean2 /
  * save_rstd2 / part2 (all NULL, or all given together with zmask): a SECOND BatchNorm consuming the same dst under the same mask
- * (bn2 and the projection shortcut's BatchNorm of a residual block, resnet.py:84-91); part2 like part.  Exact-fp32 math on
- * fp32 tensors (at = 0, ns = 0); a strided transposed conv (mode 1, stride > 1) must be tap-complete (R, S >= stride: every
+ * (bn2 and the projection shortcut's BatchNorm of a residual block, resnet.py:84-91); part2 like part.  A strided transposed conv (mode 1, stride > 1) must be tap-complete (R, S >= stride: every
  * output pixel is visited). */
 int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode,
                       int tile_hint);

@@ -1252,69 +1252,82 @@ BNSUM_CASES = [(2, 64, 64, 3, 1, 1, 16, 12, False), (1, 256, 128, 3, 1, 1, 12, 1
 @pytest.mark.parametrize('tile', [0, 1, 2, 3, 4])
 @pytest.mark.parametrize('mask', ['self', 'tensor'])
 @pytest.mark.parametrize('accumulate', [0, 1])
-def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate):
-    """dbn_igemm_bnsums_t: a data gradient (mode 1, stride 1) or a forward-form conv (mode 0, any stride: the ConvTranspose2d
-    data gradient of the head) whose epilogue also reduces the two per-channel sums of the BatchNorm backward that consumes its
-    output (the conv -> BN -> ReLU chain of resnet.py:70-91 / basic.py:32-36 backwards): dst must equal the plain call's bit for
-    bit, and the folded partials must equal sum(g), sum(g * xhat) with g = dz * [mask > 0] evaluated in fp64 on the final dz."""
+@pytest.mark.parametrize('math', ['f32', 'bf16x3', 'bf16'])
+def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate, math):
+    """dbn_igemm_bnsums_t: a data gradient (mode 1, any stride) or a forward-form conv (mode 0: the ConvTranspose2d data gradient
+    of the head) whose epilogue also reduces the two per-channel sums of the BatchNorm backward that consumes its output (the
+    conv -> BN -> ReLU chain of resnet.py:70-91 / basic.py:32-36 backwards) — and of a second BatchNorm over the same gradient and
+    mask (projection shortcut, resnet.py:84-91).  dst must equal the plain call's bit for bit, and the folded partials must
+    equal sum(g), sum(g * xhat) with g = dz * [mask > 0] evaluated in fp64 on the final dz AS STORED.  'bf16x3': fp32 tensors,
+    split-bf16 matrix math; 'bf16': bf16 tensors (incl. the pixel-patch kernels of the 3x3 / stride-1 shapes)."""
     N, Ci, Co, k, s, p, H, W, as_forward = case
+    ns, at = {'f32': (0, 0), 'bf16x3': (3, 0), 'bf16': (1, 1)}[math]
+    kind = {'f32': 0, 'bf16x3': 3, 'bf16': 1}[math]
+    tdt = torch.bfloat16 if at == 1 else torch.float32
     if tile == 1 and (Co if as_forward else Ci) % 128 != 0:
         pytest.skip('128-wide tile needs Cd % 128 == 0')
+    if math != 'f32' and (accumulate == 1 and tile not in (0, 3)):
+        pytest.skip('16-bit math: the tile sweep runs without accumulate')
     if as_forward:  # dst = conv(src): mode 0
         src = rnd(N, Ci, H, W, seed=1)
         w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
         dzc = F.conv2d(src, w, None, s, p)
-        wpk, mode, Cd = pack(w, 0), 0, Co
+        mode, Cd, wsrc, stride_pack = 0, Co, w, 1
     else:  # dst = d(input) of conv: mode 1
         x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
         w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
         yf = F.conv2d(x, w, None, s, p)
         src = rnd(*yf.shape, seed=4)
         (dzc, ) = torch.autograd.grad(yf, x, src)
-        wpk, mode, Cd = pack(w, 1, s), 1, Ci
+        mode, Cd, wsrc, stride_pack = 1, Ci, w, s
     Hd, Wd = dzc.shape[2:]
-    srcs = nhwc(src)
+    srcs = nhwc(src).to(tdt)
+    O_, I_, R_, S_ = wsrc.shape
+    wpk = torch.empty(L().dbn_igemm_panel_floats_t(kind, O_, I_, R_, S_, mode, stride_pack, srcs.shape[3] if mode == 0 else 0), device=DEV)
+    _lib.check(L().dbn_pack_weights_t(kind, wsrc.to(DEV).data_ptr(), O_, I_, R_, S_, mode, stride_pack, srcs.shape[3] if mode == 0 else 0,
+                                      wpk.data_ptr(), stream()), 'pack')
     y = rnd(N, Cd, Hd, Wd, seed=7)
     mean, rstd = rnd(Cd, seed=8, scale=0.2), rnd(Cd, seed=9).abs() + 0.5
     msc, msh = rnd(Cd, seed=10), rnd(Cd, seed=11, scale=0.3)
     z = rnd(N, Cd, Hd, Wd, seed=12)
     old = rnd(N, Cd, Hd, Wd, seed=13)
-    ys, zs = nhwc(y), nhwc(z)
-    dst = nhwc(old).clone() if accumulate else torch.full((N, Hd, Wd, Cd), float('nan'), device=DEV)
-    plain = nhwc(old).clone() if accumulate else torch.full((N, Hd, Wd, Cd), float('nan'), device=DEV)
-    igemm(srcs, wpk, None, plain, k, s, p, mode, accumulate, tile)
-    a = (0, 0, N, srcs.shape[1], srcs.shape[2], srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode, tile)
-    rows = L().dbn_igemm_bn_rows(*a)
+    ys, zs = nhwc(y).to(tdt), nhwc(z).to(tdt)
+    y, z = nchw(ys.float()), nchw(zs.float())  # the values the kernel sees (rounded for bf16 storage)
+    fresh = lambda: nhwc(old).to(tdt).clone() if accumulate else torch.full((N, Hd, Wd, Cd), float('nan'), device=DEV, dtype=tdt)
+    dst, plain = fresh(), fresh()
+    geo = (N, srcs.shape[1], srcs.shape[2], srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode)
+    _lib.check(L().dbn_igemm_t(at, ns, srcs.data_ptr(), wpk.data_ptr(), None, plain.data_ptr(), *geo, accumulate, tile, 1, None, stream()),
+               'igemm_t')
+    rows = L().dbn_igemm_bn_rows(at, ns, *geo[:11], mode, tile)
     assert rows > 0
     part = torch.full((2, Cd, rows), float('nan'), device=DEV)
     # a second BatchNorm over the same dz and mask tensor (projection shortcut), only with a mask tensor
     two = mask == 'tensor'
-    y2 = rnd(N, Cd, Hd, Wd, seed=21)
+    y2s = nhwc(rnd(N, Cd, Hd, Wd, seed=21)).to(tdt)
+    y2 = nchw(y2s.float())
     mean2, rstd2 = rnd(Cd, seed=22, scale=0.3), rnd(Cd, seed=23).abs() + 0.4
-    y2s, mean2_d, rstd2_d = nhwc(y2), mean2.to(DEV), rstd2.to(DEV)
+    mean2_d, rstd2_d = mean2.to(DEV), rstd2.to(DEV)
     part2 = torch.full((2, Cd, rows), float('nan'), device=DEV)
     dev = lambda t: t.to(DEV)
     mean_d, rstd_d, msc_d, msh_d = dev(mean), dev(rstd), dev(msc), dev(msh)
-    _lib.check(L().dbn_igemm_bnsums_t(0, 0, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), N, srcs.shape[1], srcs.shape[2],
-                                      srcs.shape[3], Hd, Wd, Cd, k, k, s, p, mode, accumulate, tile, ys.data_ptr(),
+    _lib.check(L().dbn_igemm_bnsums_t(at, ns, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), *geo, accumulate, tile, ys.data_ptr(),
                                       zs.data_ptr() if mask == 'tensor' else None, None if mask == 'tensor' else msc_d.data_ptr(),
                                       None if mask == 'tensor' else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(),
                                       part.data_ptr(), y2s.data_ptr() if two else None, mean2_d.data_ptr() if two else None,
                                       rstd2_d.data_ptr() if two else None, part2.data_ptr() if two else None, stream()), 'igemm_bnsums')
     torch.cuda.synchronize()
     assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
-    dz = nchw(dst).double()
-    m = z.double() if mask == 'tensor' else torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1)).double()
+    dz = nchw(dst.float()).double()
+    m32 = torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1))
+    m = z.double() if mask == 'tensor' else m32.double()
     if mask == 'self':  # the kernel evaluates fmaf(y, sc, sh) in fp32: elements within round-off of zero may flip
-        m32 = torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1))
-        safe = m32.abs() > 1e-6
-        assert bool(safe.all()), 'test data has a mask value at round-off level'
+        assert bool((m32.abs() > 1e-6).all()), 'test data has a mask value at round-off level'
     g = dz * (m > 0)
     xhat = (y.double() - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
     s1, s2 = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
     got = part.double().sum(2).cpu()
     sc = float(g.abs().sum((0, 2, 3)).max()) + 1e-9
-    report('bn-backward sums %s tile %d %s acc %d' % (case, tile, mask, accumulate), got, torch.stack([s1, s2]), 2e-6 * sc, 1e-5)
+    report('bn-backward sums %s tile %d %s acc %d %s' % (case, tile, mask, accumulate, math), got, torch.stack([s1, s2]), 2e-6 * sc, 1e-5)
     if two:
         xhat2 = (y2.double() - mean2.double().view(1, -1, 1, 1)) * rstd2.double().view(1, -1, 1, 1)
         report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, (g * xhat2).sum((0, 2, 3))]), 2e-6 * sc, 1e-5)
