@@ -26,8 +26,10 @@ namespace {
 // pixel-patch kernels with three planes: two waves per SIMD (<= 256 registers; the fully unrolled nine stages had taken 257)
 // exact-fp32 16K-element tiles with the BatchNorm-backward epilogue (EPI = 1): three waves per SIMD like the plain kernel (the row
 // sweep of that epilogue peaks 1-3 registers above the 104 that three waves allow; the attribute makes the allocator fit it)
-#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) \
-    __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : 1, 8)))
+// bf16-storage pixel-patch kernels with that epilogue: four waves like the plain kernel (117 registers as written = three)
+#define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI, AT) \
+    __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : \
+                                       ((EPI) == 1 && (AT) == 1 && (PATCH) && (BN) == 64) ? 4 : 1, 8)))
 
 // AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
 // of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
@@ -42,7 +44,7 @@ namespace {
 // k-step; forward convs on fp32 tensors only.  A compile-time fact: as a runtime flag its inner `while` put loops and branches
 // into every kernel's k-loop (and an s_waitcnt vmcnt(0) at the loop header that drained the two-tile prefetch every iteration).
 template <int BM, int BN, int WM, int WN, int MODE, int NS, int AT = 0, bool PATCH = false, int EPI = 0, bool BLK = true>
-__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI) void igemm_f32_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI, AT) void igemm_f32_kernel(const IgemmParams p) {
     static_assert(EPI == 0 || ((AT == 0 || AT == 1) && MODE < 3), "BatchNorm-backward sums: fp32 or bf16 storage, no pyramid form");
     static_assert(BLK || (AT == 0 && MODE == 0 && !PATCH && EPI == 0), "non-blocked K walk: forward conv on fp32 tensors");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
@@ -1196,75 +1198,81 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             const int piece = tid % LPR;
             if constexpr (EPI == 1) {
                 // + the sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_part), taken in the same row-major sweep
-                // over the values AS STORED (rounded to the storage type: what the apply pass will read back).  A thread owns 8
-                // channels; y / the mask tensor come in as 16-byte pieces like dst goes out.
+                // over the values AS STORED (rounded to the storage type: what the apply pass will read back).  A thread owns FOUR
+                // channels here (8-byte pieces: with eight, the per-channel constants and sums alone were 70 registers and the
+                // kernel dropped from four to two waves per SIMD); y / the mask tensor come in the same way.
                 static_assert(AT == 1, "sums epilogue of the 16-bit path: bf16 storage (training)");
+                constexpr int LPR4 = BN / 4, RPP4 = NT / LPR4, PASSES = BM / RPP4;
+                static_assert(NT % LPR4 == 0 && BM % RPP4 == 0 && PASSES % 2 == 0, "whole passes");
+                const int piece4 = tid % LPR4, rq = tid / LPR4;
                 const unsigned short* const yb = reinterpret_cast<const unsigned short*>(p.bnb_y);
                 const unsigned short* const zb = reinterpret_cast<const unsigned short*>(p.bnb_zmask);
                 const unsigned short* const y2b = reinterpret_cast<const unsigned short*>(p.bnb_y2);
-                const int cg = n0 + piece * 8;
-                float mu[8], rs[8], msc[8], msh[8], mu2[8], rs2[8], s1[8], s2[8], s4[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    mu[e] = p.bnb_mean[cg + e];
-                    rs[e] = p.bnb_rstd[cg + e];
-                    msc[e] = zb ? 0.f : p.bnb_msc[cg + e];
-                    msh[e] = zb ? 0.f : p.bnb_msh[cg + e];
-                    mu2[e] = y2b ? p.bnb_mean2[cg + e] : 0.f;
-                    rs2[e] = y2b ? p.bnb_rstd2[cg + e] : 0.f;
-                    s1[e] = s2[e] = s4[e] = 0.f;
-                }
-                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                auto bf = [](const u32x4_& w, int e) { return __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xFFFF0000u) : (w[e >> 1] << 16)); };
+                const int cg = n0 + piece4 * 4;
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, s4[4] = {0.f, 0.f, 0.f, 0.f};
+                auto bf = [](const u32x2& w, int e) { return __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xFFFF0000u) : (w[e >> 1] << 16)); };
                 auto sweep16 = [&](auto ZM, auto TWO) {
                     constexpr bool kZ = decltype(ZM)::value, k2 = decltype(TWO)::value;
+                    f32x4 mu = *reinterpret_cast<const f32x4*>(p.bnb_mean + cg), rs = *reinterpret_cast<const f32x4*>(p.bnb_rstd + cg);
+                    f32x4 msc = mu, msh = mu, mu2 = mu, rs2 = mu;
+                    if constexpr (!kZ) {
+                        msc = *reinterpret_cast<const f32x4*>(p.bnb_msc + cg);
+                        msh = *reinterpret_cast<const f32x4*>(p.bnb_msh + cg);
+                    }
+                    if constexpr (k2) {
+                        mu2 = *reinterpret_cast<const f32x4*>(p.bnb_mean2 + cg);
+                        rs2 = *reinterpret_cast<const f32x4*>(p.bnb_rstd2 + cg);
+                    }
+                    constexpr int UN = 2;  // rows in flight per thread
 #pragma unroll 1
-                    for (int ps = 0; ps < BM / RPP; ++ps) {
-                        const int row = ps * RPP + tid / LPR;
-                        const u32x4_ v = *reinterpret_cast<const u32x4_*>(T + row * PITCH + piece * 8);
-                        bool ok;
-                        long doff;
-                        tile_row(row, ok, doff);
-                        const long o = ok ? doff + cg : (long)cg;  // rows past M read a valid pixel, contribute nothing
-                        const u32x4_ yv = *reinterpret_cast<const u32x4_*>(yb + o);
-                        u32x4_ zv = yv, y2v = yv;
-                        if constexpr (kZ) zv = *reinterpret_cast<const u32x4_*>(zb + o);
-                        if constexpr (k2) y2v = *reinterpret_cast<const u32x4_*>(y2b + o);
-                        if (ok) *reinterpret_cast<u32x4_*>(reinterpret_cast<unsigned short*>(dstv) + doff + cg) = v;
+                    for (int ps0 = 0; ps0 < PASSES; ps0 += UN) {
+                        u32x2 v[UN], yv[UN], zv[UN], y2v[UN];
+                        bool ok[UN];
+                        long doff[UN];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float y_ = bf(yv, e);
-                            float m_;
-                            if constexpr (kZ) m_ = bf(zv, e);
-                            else m_ = dbn_affine(y_, msc[e], msh[e]);
-                            const float g = (ok & (m_ > 0.f)) ? bf(v, e) : 0.f;
-                            s1[e] += g;
-                            s2[e] += g * ((y_ - mu[e]) * rs[e]);
-                            if constexpr (k2) s4[e] += g * ((bf(y2v, e) - mu2[e]) * rs2[e]);
+                        for (int u = 0; u < UN; ++u) {
+                            const int row = (ps0 + u) * RPP4 + rq;
+                            v[u] = *reinterpret_cast<const u32x2*>(T + row * PITCH + piece4 * 4);
+                            tile_row(row, ok[u], doff[u]);
+                            const long o = ok[u] ? doff[u] + cg : (long)cg;  // rows past M read a valid pixel, contribute nothing
+                            yv[u] = *reinterpret_cast<const u32x2*>(yb + o);
+                            if constexpr (kZ) zv[u] = *reinterpret_cast<const u32x2*>(zb + o);
+                            if constexpr (k2) y2v[u] = *reinterpret_cast<const u32x2*>(y2b + o);
+                        }
+#pragma unroll
+                        for (int u = 0; u < UN; ++u) {
+                            if (ok[u]) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(dstv) + doff[u] + cg) = v[u];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y_ = bf(yv[u], e);
+                                float m_;
+                                if constexpr (kZ) m_ = bf(zv[u], e);
+                                else m_ = dbn_affine(y_, msc[e], msh[e]);
+                                const float g = (ok[u] & (m_ > 0.f)) ? bf(v[u], e) : 0.f;
+                                s1[e] += g;
+                                s2[e] += g * ((y_ - mu[e]) * rs[e]);
+                                if constexpr (k2) s4[e] += g * ((bf(y2v[u], e) - mu2[e]) * rs2[e]);
+                            }
                         }
                     }
                 };
                 if (zb && y2b) sweep16(std::true_type{}, std::true_type{});
                 else if (zb) sweep16(std::true_type{}, std::false_type{});
                 else sweep16(std::false_type{}, std::false_type{});
-                // fold the RPP row groups of each channel in fixed order, write this tile's partial row
-                static_assert(2L * RPP * BN * 4 <= (long)sizeof(smem), "reduction scratch");
-                float* const r1 = reinterpret_cast<float*>(smem);  // [RPP][BN]
-                float* const r2 = r1 + RPP * BN;                    // [RPP][BN]
-                const int rq = tid / LPR;
+                // fold the RPP4 row groups of each channel in fixed order, write this tile's partial row
+                static_assert(2L * RPP4 * BN * 4 <= (long)sizeof(smem), "reduction scratch");
+                float* const r1 = reinterpret_cast<float*>(smem);  // [RPP4][BN]
+                float* const r2 = r1 + RPP4 * BN;                   // [RPP4][BN]
                 const int trow_ = p.stat_row0 + q_row_base + mt;
-                auto fold16 = [&](const float (&a_)[8], const float (&b_)[8], float* part) {
+                auto fold16 = [&](const float (&a_)[4], const float (&b_)[4], float* part) {
                     __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        r1[rq * BN + piece * 8 + e] = a_[e];
-                        r2[rq * BN + piece * 8 + e] = b_[e];
-                    }
+                    *reinterpret_cast<f32x4*>(r1 + rq * BN + piece4 * 4) = f32x4{a_[0], a_[1], a_[2], a_[3]};
+                    *reinterpret_cast<f32x4*>(r2 + rq * BN + piece4 * 4) = f32x4{b_[0], b_[1], b_[2], b_[3]};
                     __syncthreads();
                     for (int cl = tid; cl < BN; cl += NT) {
                         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-                        for (int w = 0; w < RPP; ++w) {
+                        for (int w = 0; w < RPP4; ++w) {
                             t1 += r1[w * BN + cl];
                             t2 += r2[w * BN + cl];
                         }
