@@ -84,7 +84,9 @@ SIGNATURES.update({
     'dbn_conv_bn_t': 'i' + SIGNATURES['dbn_conv_bn_f32'],
     'dbn_pyramid_conv_t': 'i' + SIGNATURES['dbn_pyramid_conv_f32'],
     'dbn_igemm_bn_rows': 'i' * 15,
-    'dbn_igemm_bnsums_t': 'ii' + 'pppp' + 'i' * 14 + 'ppppppp' + 'pppp' + 'p',
+    'dbn_igemm_bnsums_t': 'ii' + 'pppp' + 'i' * 14 + 'ppppppp' + 'pppp' + 'p' + 'p',
+    'dbn_igemm_bn_final_counters': 'ii',
+    'dbn_igemm_bn_final_group_floats': 'ii',
     'dbn_wgrad_t': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',
@@ -113,12 +115,18 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class BnbFinal(ctypes.Structure):
+    """dbn_bnb_final of include/dbnet_hip.h: the in-kernel finalize of a data gradient's BatchNorm-backward sums."""
+    _fields_ = [('counters', _P), ('group', _P), ('c1c2', _P), ('dgamma', _P), ('dbeta', _P), ('c1c2_2', _P), ('dgamma_2', _P),
+                ('dbeta_2', _P), ('grad_scale', _F)]
 
 
 def build(verbose=False):

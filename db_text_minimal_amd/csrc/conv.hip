@@ -6,6 +6,7 @@
 // modules/basic.py:32-36, modules/segmentation_body.py:64-77 and modules/segmentation_head.py:24-29,64-79
 // (Conv2d / ConvTranspose2d forward and their data gradients).
 #include "igemm_common.h"
+#include "../../include/dbnet_hip.h"
 
 long dbn_g_pixel_limit = 1L << 24;
 long dbn_g_byte_limit = 0xF0000000L;
@@ -198,6 +199,8 @@ struct IgemmBnb {
     const void* y2;  // optional second BatchNorm over the same dz and mask tensor
     const float *mean2, *rstd2;
     float* part2;
+    const dbn_bnb_final* fin;  // optional in-kernel finalize
+    int M_total;               // pixels of the whole call (c1 = sum / M)
 };
 
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -211,6 +214,14 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     p.bnb_part = bnb ? bnb->part : nullptr;
     p.bnb_y2 = bnb ? bnb->y2 : nullptr; p.bnb_mean2 = bnb ? bnb->mean2 : nullptr; p.bnb_rstd2 = bnb ? bnb->rstd2 : nullptr;
     p.bnb_part2 = bnb ? bnb->part2 : nullptr;
+    p.bnb_cnt = nullptr; p.bnb_grp = nullptr; p.bnb_gscale = 1.f; p.bnb_invM = 0.f;
+    for (int b_ = 0; b_ < 2; ++b_) p.bnb_c1c2[b_] = p.bnb_dgamma[b_] = p.bnb_dbeta[b_] = nullptr;
+    if (bnb && bnb->fin) {
+        const dbn_bnb_final* f = bnb->fin;
+        p.bnb_cnt = f->counters; p.bnb_grp = f->group; p.bnb_gscale = f->grad_scale; p.bnb_invM = 1.0f / (float)bnb->M_total;
+        p.bnb_c1c2[0] = f->c1c2; p.bnb_dgamma[0] = f->dgamma; p.bnb_dbeta[0] = f->dbeta;
+        p.bnb_c1c2[1] = f->c1c2_2; p.bnb_dgamma[1] = f->dgamma_2; p.bnb_dbeta[1] = f->dbeta_2;
+    }
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
     p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
@@ -364,16 +375,22 @@ int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const 
                        int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
                        const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
                        const float* save_rstd, float* part, const void* y2, const float* save_mean2, const float* save_rstd2,
-                       float* part2, void* stream) {
+                       float* part2, const dbn_bnb_final* fin, void* stream) {
     DBN_REQUIRE(((at == 0 && (ns == 0 || ns == 1 || ns == 3)) || (at == 1 && ns == 1)) && y && save_mean && save_rstd && part &&
                 (zmask || (mask_scale && mask_shift)));
     DBN_REQUIRE(!y2 || (zmask && save_mean2 && save_rstd2 && part2));
+    DBN_REQUIRE(!fin || (fin->counters && fin->group && fin->c1c2 && fin->dgamma && fin->dbeta &&
+                         (!y2 || (fin->c1c2_2 && fin->dgamma_2 && fin->dbeta_2))));
     const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
     DBN_REQUIRE(rows > 0);
-    const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part, y2, save_mean2, save_rstd2, part2};
+    const IgemmBnb b{y, zmask, mask_scale, mask_shift, save_mean, save_rstd, part, y2, save_mean2, save_rstd2, part2, fin, N * Hd * Wd};
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr, 1,
                      nullptr, rows, at, &b);
 }
+
+// sizes of the in-kernel finalize's scratch (dbn_bnb_final) for `rows` partial rows and Cd channels
+long dbn_igemm_bn_final_counters(int rows, int Cd) { return (long)(Cd / 64) * ((rows + 63) / 64 + 1); }
+long dbn_igemm_bn_final_group_floats(int rows, int Cd) { return 4L * Cd * ((rows + 63) / 64); }
 
 // floats of scratch for the fused conv + BatchNorm-statistics call
 long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride) {
@@ -495,6 +512,8 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
         p.bnb_y = p.bnb_zmask = p.bnb_y2 = nullptr; p.bnb_msc = p.bnb_msh = p.bnb_mean = p.bnb_rstd = p.bnb_mean2 = p.bnb_rstd2 = nullptr;
         p.bnb_part = p.bnb_part2 = nullptr;
+        p.bnb_cnt = nullptr; p.bnb_grp = nullptr; p.bnb_gscale = 1.f; p.bnb_invM = 0.f;
+        for (int b_ = 0; b_ < 2; ++b_) p.bnb_c1c2[b_] = p.bnb_dgamma[b_] = p.bnb_dbeta[b_] = nullptr;
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
         p.ksplit = 1; p.kt_per = 0; p.patch = 0;

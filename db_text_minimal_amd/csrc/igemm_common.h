@@ -87,6 +87,15 @@ struct IgemmParams {
     const void* bnb_y2;
     const float *bnb_mean2, *bnb_rstd2;
     float* bnb_part2;
+    // optional in-kernel finalize of those sums (null: the caller folds the partial rows itself): the last workgroup to finish
+    // in each group of 64 partial rows folds the group, the last group-folder of an output-channel tile folds the groups and
+    // writes that tile's channels of the results — fixed summation order, no float atomics (the counters are integers and are
+    // left at zero).  bnb_cnt: [Cd/BN][1 + groups] ints; bnb_grp: [2 BatchNorms][2][Cd][groups] floats; results per BatchNorm b:
+    // bnb_c1c2[b] = [2][Cd] (sum / M, sum_xhat / M: what the apply pass needs), bnb_dgamma[b], bnb_dbeta[b] (times bnb_gscale).
+    int* bnb_cnt;
+    float* bnb_grp;
+    float *bnb_c1c2[2], *bnb_dgamma[2], *bnb_dbeta[2];
+    float bnb_gscale, bnb_invM;
     unsigned src_bytes;
     unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)

@@ -1058,6 +1058,65 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
     for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
     const long dcol = n0 + wn * TN + li;
+    // EPI = 1, optional: in-kernel finalize of the BatchNorm-backward sums (IgemmParams::bnb_cnt).  Called by every thread of the
+    // workgroup after it wrote its partial row `trow_`.
+    auto bnb_finish = [&](int trow_) {
+        if constexpr (EPI == 1) {
+            if (!p.bnb_cnt) return;
+            constexpr int G = 64;
+            const int NG = (p.stat_rows + G - 1) / G, g = trow_ / G;
+            const int nbn = p.bnb_y2 ? 2 : 1;
+            int* const cnt = p.bnb_cnt + nt * (NG + 1);
+            int* const s_flag = reinterpret_cast<int*>(smem) + (sizeof(smem) / 4 - 4);  // (behind every scratch region of the epilogue)
+            __threadfence();  // this thread's partial-row writes are visible device-wide before the count goes up
+            __syncthreads();
+            if (tid == 0) {
+                const int gsize = min(G, p.stat_rows - g * G);
+                const int last = atomicAdd(cnt + 1 + g, 1) == gsize - 1;
+                if (last) cnt[1 + g] = 0;  // (nobody touches this counter again in this call)
+                *s_flag = last;
+            }
+            __syncthreads();
+            if (!*s_flag) return;
+            __threadfence();
+            // fold this group's rows for the BN channels of this tile column: item = (BatchNorm, sum, channel)
+            const int r0 = g * G, r1_ = min(p.stat_rows, r0 + G);
+            for (int it = tid; it < nbn * 2 * BN; it += NT) {
+                const int b = it / (2 * BN), ks = (it / BN) & 1, cl = it % BN;
+                const float* src = (b ? p.bnb_part2 : p.bnb_part) + ((long)ks * p.Cd + n0 + cl) * p.stat_rows;
+                double s = 0.0;
+                int r = r0;
+                for (; r + 3 < r1_; r += 4) s += ((double)src[r] + (double)src[r + 1]) + ((double)src[r + 2] + (double)src[r + 3]);
+                for (; r < r1_; ++r) s += (double)src[r];
+                p.bnb_grp[(((long)b * 2 + ks) * p.Cd + n0 + cl) * NG + g] = (float)s;
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) {
+                const int last = atomicAdd(cnt, 1) == NG - 1;
+                if (last) cnt[0] = 0;
+                *s_flag = last;
+            }
+            __syncthreads();
+            if (!*s_flag) return;
+            __threadfence();
+            for (int it = tid; it < nbn * BN; it += NT) {
+                const int b = it / BN, cl = it % BN;
+                const long c = n0 + cl;
+                const float* g1 = p.bnb_grp + (((long)b * 2 + 0) * p.Cd + c) * NG;
+                const float* g2 = p.bnb_grp + (((long)b * 2 + 1) * p.Cd + c) * NG;
+                double s1_ = 0.0, s2_ = 0.0;
+                for (int q_ = 0; q_ < NG; ++q_) {
+                    s1_ += (double)g1[q_];
+                    s2_ += (double)g2[q_];
+                }
+                p.bnb_dbeta[b][c] = (float)(s1_ * p.bnb_gscale);
+                p.bnb_dgamma[b][c] = (float)(s2_ * p.bnb_gscale);
+                p.bnb_c1c2[b][c] = (float)(s1_ * p.bnb_invM);
+                p.bnb_c1c2[b][p.Cd + c] = (float)(s2_ * p.bnb_invM);
+            }
+        }
+    };
     // ---- EPI = 1: store + the sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_part), ROW-MAJOR through LDS.
     // The accumulators hold the final dz values.  Reading y (and the mask tensor) at the accumulator layout — a lane owns one
     // column of 16 rows — is MI*NI*16 four-byte loads per lane and tensor, with every accumulator copied out of the AGPRs and
@@ -1171,6 +1230,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         };
         fold(s1, s2, p.bnb_part);
         if (y2b) fold(s3, s4, p.bnb_part2);
+        bnb_finish(trow_);
         return;
     }
     if constexpr (!DST_F32) {
@@ -1283,6 +1343,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 };
                 fold16(s1, s2, p.bnb_part);
                 if (y2b) fold16(s1, s4, p.bnb_part2);
+                bnb_finish(trow_);
                 return;
             }
 #pragma unroll

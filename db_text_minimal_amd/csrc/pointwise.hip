@@ -832,7 +832,11 @@ int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, 
     const long total4 = (long)M * (C / 4);
     const int grid = bn_stream_grid(total4, C);
     DBN_DISPATCH_AT(at, {
-        if (sums && sums_parts >= 512) {
+        if (sums && sums_parts < 0) {
+            // already finalized by the producing kernel (dbn_bnb_final): sums = [2][C] = c1, c2; dgamma / dbeta are written
+            c1 = const_cast<float*>(sums);
+            c2 = c1 + C;
+        } else if (sums && sums_parts >= 512) {
             hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C), dim3(256), 0, st, sums, sums_parts, M, C, dgamma, dbeta, c1, c2,
                                grad_scale);
         } else if (sums) {

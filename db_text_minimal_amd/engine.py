@@ -328,6 +328,7 @@ class Engine:
         return self.at, ptr
 
     fuse_bn_bwd_sums = True  # data gradients also reduce the two sums of the BatchNorm backward that consumes their output
+    bnb_finalize_in_kernel = True  # ... and fold them to the per-channel results themselves (last-arriver, fixed order)
 
     def _bnb_eligible(self, args):
         """Can this igemm call (dbn_igemm_f32 argument list) carry the BatchNorm-backward sums of its consumer?"""
@@ -364,12 +365,31 @@ class Engine:
                 assert zmask is not None and second[1].shape == y.shape
                 y2, mean2, rstd2 = second[1], self.bufs[second[0] + '/mean'], self.bufs[second[0] + '/rstd']
                 part2 = self.fbuf(second[0] + '/bnb_part', 2 * Cd * rows)
+            fin = None
+            if self.bnb_finalize_in_kernel:
+                # the data gradient's last workgroups also fold the partial rows: no finalize launch between it and the apply pass
+                G = self.grad_views
+                cnt = self.bufs.get(bn_name + '/bnb_cnt')
+                ncnt = self.L.dbn_igemm_bn_final_counters(rows, Cd)
+                if cnt is None or cnt.numel() != ncnt or cnt.device != self.flat.device:
+                    cnt = torch.zeros(ncnt, device=self.flat.device, dtype=torch.int32)  # (the kernels leave them zero)
+                    self.bufs[bn_name + '/bnb_cnt'] = cnt
+                grp = self.fbuf(bn_name + '/bnb_grp', self.L.dbn_igemm_bn_final_group_floats(rows, Cd))
+                c1c2 = self.fbuf(bn_name + '/bnb_c1c2', 2 * Cd)
+                fin = _lib.BnbFinal(cnt.data_ptr(), grp.data_ptr(), c1c2.data_ptr(), G[bn_name + '.weight'].data_ptr(),
+                                    G[bn_name + '.bias'].data_ptr(), None, None, None, self.grad_scale)
+                if second is not None:
+                    c1c2b = self.fbuf(second[0] + '/bnb_c1c2', 2 * Cd)
+                    fin.c1c2_2, fin.dgamma_2, fin.dbeta_2 = (c1c2b.data_ptr(), G[second[0] + '.weight'].data_ptr(),
+                                                             G[second[0] + '.bias'].data_ptr())
+            import ctypes
             check(self.L.dbn_igemm_bnsums_t(at, self.ns, srcp, *args[1:], y.data_ptr(), _p(zmask), _p(msc), _p(msh),
                                             self.bufs[bn_name + '/mean'].data_ptr(), self.bufs[bn_name + '/rstd'].data_ptr(),
-                                            part.data_ptr(), _p(y2), _p(mean2), _p(rstd2), _p(part2), self.stream), what)
-            self._bnb_sums[bn_name] = (part, rows)
+                                            part.data_ptr(), _p(y2), _p(mean2), _p(rstd2), _p(part2),
+                                            ctypes.byref(fin) if fin is not None else None, self.stream), what)
+            self._bnb_sums[bn_name] = (c1c2, -1) if fin is not None else (part, rows)
             if second is not None:
-                self._bnb_sums[second[0]] = (part2, rows)
+                self._bnb_sums[second[0]] = (c1c2b, -1) if fin is not None else (part2, rows)
             return
         ks, slab = 1, None
         if self.splitk and (mode == 0 or stride == 1):

@@ -76,11 +76,28 @@ int dbn_wgrad_bf16s(const float* sm, const float* big, float* slab, float* grad_
  * output pixel is visited). */
 int dbn_igemm_bn_rows(int at, int ns, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode,
                       int tile_hint);
+/* Optional in-kernel finalize of those sums (`fin` of dbn_igemm_bnsums_t; NULL: the caller hands `part` to dbn_bn_backward_t,
+ * which folds it with its own launch).  The last workgroup to finish in each group of 64 partial rows folds the group, the last
+ * group-folder of an output-channel tile folds the groups — fixed summation order, integer counters only — and writes, per
+ * BatchNorm, c1c2 = [2][Cd] (sum g / M, sum g*xhat / M with M = N*Hd*Wd: hand it to dbn_bn_backward_t as `sums` with sums_parts
+ * = -1, which then launches the apply pass only) and the parameter gradients dgamma = grad_scale * sum g*xhat, dbeta =
+ * grad_scale * sum g.  counters: dbn_igemm_bn_final_counters(rows, Cd) ints, ZERO before the first call (the kernels leave
+ * them zero); group: dbn_igemm_bn_final_group_floats(rows, Cd) floats of scratch.  The *_2 members belong to the second
+ * BatchNorm (y2). */
+typedef struct dbn_bnb_final {
+    int* counters;
+    float* group;
+    float *c1c2, *dgamma, *dbeta;
+    float *c1c2_2, *dgamma_2, *dbeta_2;
+    float grad_scale;
+} dbn_bnb_final;
+long dbn_igemm_bn_final_counters(int rows, int Cd);
+long dbn_igemm_bn_final_group_floats(int rows, int Cd);
 int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                        int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, const void* y,
                        const void* zmask, const float* mask_scale, const float* mask_shift, const float* save_mean,
                        const float* save_rstd, float* part, const void* y2, const float* save_mean2, const float* save_rstd2,
-                       float* part2, void* stream);
+                       float* part2, const dbn_bnb_final* fin, void* stream);
 
 /* Convolution whose epilogue also accumulates the train-mode BatchNorm statistics of its output (per-tile pivot,
  * sum, sum of squares; merged in fp64 by a finalize kernel): one call replaces conv + statistics pass.
@@ -354,8 +371,9 @@ int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma
 int dbn_bn_apply_t(int at, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
                    const float* res_shift, void* out, long M, int C, int relu, void* stream);
 /* The general BatchNorm backward: `sums` optional — [2*C][sums_parts] partial sums (or [2][C] with sums_parts = 1) of the masked
- * gradient and of masked gradient * xhat produced by the kernel that wrote dout (dbn_head_tail_bwd, dbn_bnrelu_maxpool_bwd_t);
- * dbias_conv optional as in dbn_bn_backward_ex */
+ * gradient and of masked gradient * xhat produced by the kernel that wrote dout (dbn_head_tail_bwd, dbn_bnrelu_maxpool_bwd_t,
+ * dbn_igemm_bnsums_t); sums_parts = -1: `sums` is the FINALIZED pair [2][C] (sum / M, sum_xhat / M) of a dbn_bnb_final, dgamma /
+ * dbeta are already written: only the apply pass runs.  dbias_conv optional as in dbn_bn_backward_ex */
 int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, const void* zmask, const float* mask_scale,
                       const float* mask_shift, const void* dout, const float* save_mean, const float* save_rstd, const float* gamma,
                       void* dy, void* gout, int gout_accumulate, float* dgamma, float* dbeta, float* dbias_conv, int M, int C,

@@ -1310,11 +1310,24 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
     part2 = torch.full((2, Cd, rows), float('nan'), device=DEV)
     dev = lambda t: t.to(DEV)
     mean_d, rstd_d, msc_d, msh_d = dev(mean), dev(rstd), dev(msc), dev(msh)
-    _lib.check(L().dbn_igemm_bnsums_t(at, ns, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), *geo, accumulate, tile, ys.data_ptr(),
-                                      zs.data_ptr() if mask == 'tensor' else None, None if mask == 'tensor' else msc_d.data_ptr(),
-                                      None if mask == 'tensor' else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(),
-                                      part.data_ptr(), y2s.data_ptr() if two else None, mean2_d.data_ptr() if two else None,
-                                      rstd2_d.data_ptr() if two else None, part2.data_ptr() if two else None, stream()), 'igemm_bnsums')
+    # the in-kernel finalize (dbn_bnb_final): per-channel results without a separate fold launch; counters must come back zero
+    import ctypes
+    cnt = torch.zeros(L().dbn_igemm_bn_final_counters(rows, Cd), device=DEV, dtype=torch.int32)
+    grp = torch.full((L().dbn_igemm_bn_final_group_floats(rows, Cd), ), float('nan'), device=DEV)
+    fo = [torch.full((n_, ), float('nan'), device=DEV) for n_ in (2 * Cd, Cd, Cd, 2 * Cd, Cd, Cd)]
+    fin = _lib.BnbFinal(cnt.data_ptr(), grp.data_ptr(), fo[0].data_ptr(), fo[1].data_ptr(), fo[2].data_ptr(),
+                        fo[3].data_ptr() if two else None, fo[4].data_ptr() if two else None, fo[5].data_ptr() if two else None, 0.5)
+    for rep in range(2):  # twice: the second call relies on the counters the first one left behind
+        if rep:
+            dst.copy_(fresh())
+        _lib.check(L().dbn_igemm_bnsums_t(at, ns, srcs.data_ptr(), wpk.data_ptr(), None, dst.data_ptr(), *geo, accumulate, tile, ys.data_ptr(),
+                                          zs.data_ptr() if mask == 'tensor' else None, None if mask == 'tensor' else msc_d.data_ptr(),
+                                          None if mask == 'tensor' else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(),
+                                          part.data_ptr(), y2s.data_ptr() if two else None, mean2_d.data_ptr() if two else None,
+                                          rstd2_d.data_ptr() if two else None, part2.data_ptr() if two else None,
+                                          ctypes.byref(fin), stream()), 'igemm_bnsums')
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0, 'the finalize left a counter behind'
     torch.cuda.synchronize()
     assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
     dz = nchw(dst.float()).double()
@@ -1328,9 +1341,16 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
     got = part.double().sum(2).cpu()
     sc = float(g.abs().sum((0, 2, 3)).max()) + 1e-9
     report('bn-backward sums %s tile %d %s acc %d %s' % (case, tile, mask, accumulate, math), got, torch.stack([s1, s2]), 2e-6 * sc, 1e-5)
+    Mtot = N * Hd * Wd
+    report('finalized c1, c2', fo[0].cpu().view(2, Cd), torch.stack([s1, s2]) / Mtot, 2e-6 * sc / Mtot, 1e-5)
+    report('finalized dgamma', fo[1].cpu(), 0.5 * s2, 2e-6 * sc, 1e-5)
+    report('finalized dbeta', fo[2].cpu(), 0.5 * s1, 2e-6 * sc, 1e-5)
     if two:
         xhat2 = (y2.double() - mean2.double().view(1, -1, 1, 1)) * rstd2.double().view(1, -1, 1, 1)
-        report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, (g * xhat2).sum((0, 2, 3))]), 2e-6 * sc, 1e-5)
+        s2b = (g * xhat2).sum((0, 2, 3))
+        report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, s2b]), 2e-6 * sc, 1e-5)
+        report('second BatchNorm finalized', torch.cat([fo[3].cpu(), fo[4].cpu(), fo[5].cpu()]),
+               torch.cat([s1 / Mtot, s2b / Mtot, 0.5 * s2b, 0.5 * s1]), 2e-6 * sc, 1e-5)
 
 
 @pytest.mark.parametrize('C,N,H,W,parts', [(64, 2, 12, 10, 1), (64, 2, 12, 10, 37), (128, 1, 16, 16, 700), (64, 2, 24, 24, 6400), (256, 1, 8, 8, 513)])
