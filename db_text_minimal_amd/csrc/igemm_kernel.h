@@ -1060,6 +1060,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     const long dcol = n0 + wn * TN + li;
     // EPI = 1, optional: in-kernel finalize of the BatchNorm-backward sums (IgemmParams::bnb_cnt).  Called by every thread of the
     // workgroup after it wrote its partial row `trow_`.
+    // Cross-workgroup hand-over WITHOUT device-scope fences: a release fence makes every wave write its L2 back (gfx950's L2s
+    // are per XCD and not coherent with each other) — measured: the data gradients 3.3x slower with a __threadfence() per tile.
+    // Instead the few floats that cross workgroups are moved with agent-scope relaxed atomics (sc1 stores / loads: they go
+    // to / come from the memory side, never a stale line of this XCD's L2), a plain s_waitcnt vmcnt(0) lets the stores complete
+    // before the (agent-scope, integer) counter goes up, and a consumer only reads after it has seen the count.
+    auto xst = [](float* ptr, float v) { __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto xld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto bnb_finish = [&](int trow_) {
         if constexpr (EPI == 1) {
             if (!p.bnb_cnt) return;
@@ -1068,17 +1075,17 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             const int nbn = p.bnb_y2 ? 2 : 1;
             int* const cnt = p.bnb_cnt + nt * (NG + 1);
             int* const s_flag = reinterpret_cast<int*>(smem) + (sizeof(smem) / 4 - 4);  // (behind every scratch region of the epilogue)
-            __threadfence();  // this thread's partial-row writes are visible device-wide before the count goes up
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial-row stores have completed
             __syncthreads();
             if (tid == 0) {
                 const int gsize = min(G, p.stat_rows - g * G);
-                const int last = atomicAdd(cnt + 1 + g, 1) == gsize - 1;
-                if (last) cnt[1 + g] = 0;  // (nobody touches this counter again in this call)
+                const int last = __hip_atomic_fetch_add(cnt + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+                if (last) __hip_atomic_store(cnt + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody touches it again in this call)
                 *s_flag = last;
             }
             __syncthreads();
             if (!*s_flag) return;
-            __threadfence();
+            asm volatile("" ::: "memory");
             // fold this group's rows for the BN channels of this tile column: item = (BatchNorm, sum, channel)
             const int r0 = g * G, r1_ = min(p.stat_rows, r0 + G);
             for (int it = tid; it < nbn * 2 * BN; it += NT) {
@@ -1086,20 +1093,20 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 const float* src = (b ? p.bnb_part2 : p.bnb_part) + ((long)ks * p.Cd + n0 + cl) * p.stat_rows;
                 double s = 0.0;
                 int r = r0;
-                for (; r + 3 < r1_; r += 4) s += ((double)src[r] + (double)src[r + 1]) + ((double)src[r + 2] + (double)src[r + 3]);
-                for (; r < r1_; ++r) s += (double)src[r];
-                p.bnb_grp[(((long)b * 2 + ks) * p.Cd + n0 + cl) * NG + g] = (float)s;
+                for (; r + 3 < r1_; r += 4) s += ((double)xld(src + r) + (double)xld(src + r + 1)) + ((double)xld(src + r + 2) + (double)xld(src + r + 3));
+                for (; r < r1_; ++r) s += (double)xld(src + r);
+                xst(p.bnb_grp + (((long)b * 2 + ks) * p.Cd + n0 + cl) * NG + g, (float)s);
             }
-            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                const int last = atomicAdd(cnt, 1) == NG - 1;
-                if (last) cnt[0] = 0;
+                const int last = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NG - 1;
+                if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *s_flag = last;
             }
             __syncthreads();
             if (!*s_flag) return;
-            __threadfence();
+            asm volatile("" ::: "memory");
             for (int it = tid; it < nbn * BN; it += NT) {
                 const int b = it / BN, cl = it % BN;
                 const long c = n0 + cl;
@@ -1107,8 +1114,8 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 const float* g2 = p.bnb_grp + (((long)b * 2 + 1) * p.Cd + c) * NG;
                 double s1_ = 0.0, s2_ = 0.0;
                 for (int q_ = 0; q_ < NG; ++q_) {
-                    s1_ += (double)g1[q_];
-                    s2_ += (double)g2[q_];
+                    s1_ += (double)xld(g1 + q_);
+                    s2_ += (double)xld(g2 + q_);
                 }
                 p.bnb_dbeta[b][c] = (float)(s1_ * p.bnb_gscale);
                 p.bnb_dgamma[b][c] = (float)(s2_ * p.bnb_gscale);
@@ -1224,8 +1231,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                     t2 += r2[w * BN + cl];
                 }
                 const long c = n0 + cl;
-                part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
-                part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+                if (p.bnb_cnt) {  // read by another workgroup of this launch: memory-side store (see bnb_finish)
+                    xst(part + (0L * p.Cd + c) * p.stat_rows + trow_, t1);
+                    xst(part + (1L * p.Cd + c) * p.stat_rows + trow_, t2);
+                } else {
+                    part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
+                    part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+                }
             }
         };
         fold(s1, s2, p.bnb_part);
@@ -1337,8 +1349,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                             t2 += r2[w * BN + cl];
                         }
                         const long c = n0 + cl;
-                        part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
-                        part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+                        if (p.bnb_cnt) {
+                            xst(part + (0L * p.Cd + c) * p.stat_rows + trow_, t1);
+                            xst(part + (1L * p.Cd + c) * p.stat_rows + trow_, t2);
+                        } else {
+                            part[(0L * p.Cd + c) * p.stat_rows + trow_] = t1;
+                            part[(1L * p.Cd + c) * p.stat_rows + trow_] = t2;
+                        }
                     }
                 };
                 fold16(s1, s2, p.bnb_part);
