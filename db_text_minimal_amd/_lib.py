@@ -27,7 +27,8 @@ SIGNATURES = {
     'dbn_igemm_splitk_plan_ns': 'iiiii',
     'dbn_igemm_splitk_f32': 'pppp' + 'i' * 16 + 'pp',
     'dbn_deform_im2col': 'ppp' + 'i' * 11 + 'p',
-    'dbn_deform_col2im': 'ppppp' + 'i' * 11 + 'p',
+    'dbn_deform_col2im': 'ppppp' + 'i' + 'p' + 'i' * 11 + 'p',
+    'dbn_deform_col2im_ws_bytes': 'i' * 8,
     'dbn_permute_weight': 'ppiiiifp',
     'dbn_binarize_u8': 'piiiifpp',
     'dbn_box_scores': 'piipiipp',
@@ -115,7 +116,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

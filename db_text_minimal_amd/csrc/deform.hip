@@ -5,8 +5,8 @@
 //   cols[m][tap][c] = bilinear(x[n, :, :, c], ho*stride - pad + r + dy, wo*stride - pad + s + dx)   (this file, HBM-bound)
 //   y[m][co]        = sum_{tap,c} cols[m][tap][c] * W[co][c][tap]                                      (igemm 1x1, MFMA)
 // and the backward is the 1x1 data/weight gradients of the GEMM (igemm / wgrad kernels) plus the adjoint of the
-// sampling: dx (scattered with float atomics: the only non-bit-reproducible kernel of the library) and
-// d(offset) (a reduction over channels).  Sampling rule = torchvision's bilinear_interpolate: a sample outside
+// sampling: dx (a scatter, accumulated in 64-bit fixed point so that it is bit-reproducible) and d(offset) (a reduction
+// over channels, likewise).  Sampling rule = torchvision's bilinear_interpolate: a sample outside
 // (-1, H) x (-1, W) is zero; each corner contributes only if its index is inside the image.
 // Offsets: channel 2k = dy, 2k+1 = dx of tap k = r*S + s, stored [M][off_stride] (off_stride >= 2*R*S).
 #include "common.h"
@@ -77,82 +77,66 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const void* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restrict__ dcols, const float* __restrict__ x,
-                                                            const float* __restrict__ offset, float* __restrict__ dx,
-                                                            float* __restrict__ doffset, DeformDims d, long teams) {
-    const int lane = threadIdx.x & 31;
-    const int RS = d.R * d.S, c4n = d.C >> 2;
-    for (long t = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5; t < teams; t += ((long)gridDim.x * blockDim.x) >> 5) {
-        const int m = (int)(t / RS), k = (int)(t - (long)m * RS);
-        int n, ho, wo;
-        const Sample sp = sample_of(d, offset, m, k, n, ho, wo);
-        const float hy = 1.f - sp.ly, hx = 1.f - sp.lx;
-        const float w00 = hy * hx, w01 = hy * sp.lx, w10 = sp.ly * hx, w11 = sp.ly * sp.lx;
-        const long base = ((long)n * d.H + sp.y0) * d.W + sp.x0;
-        const f32x4* g4 = reinterpret_cast<const f32x4*>(dcols + ((long)m * RS + k) * d.C);
-        float gy = 0.f, gx = 0.f;  // d(sample)/d(y), d(sample)/d(x) contracted with the column gradient
-        for (int c4 = lane; c4 < c4n; c4 += 32) {
-            const f32x4 g = g4[c4];
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 v00 = sp.ok[0] ? reinterpret_cast<const f32x4*>(x + base * d.C)[c4] : z;
-            const f32x4 v01 = sp.ok[1] ? reinterpret_cast<const f32x4*>(x + (base + 1) * d.C)[c4] : z;
-            const f32x4 v10 = sp.ok[2] ? reinterpret_cast<const f32x4*>(x + (base + d.W) * d.C)[c4] : z;
-            const f32x4 v11 = sp.ok[3] ? reinterpret_cast<const f32x4*>(x + (base + d.W + 1) * d.C)[c4] : z;
-            const f32x4 dvy = hx * (v10 - v00) + sp.lx * (v11 - v01);
-            const f32x4 dvx = hy * (v01 - v00) + sp.ly * (v11 - v10);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gy += g[e] * dvy[e];
-                gx += g[e] * dvx[e];
-                const int c = 4 * c4 + e;
-                if (sp.ok[0]) atomicAdd(dx + base * d.C + c, w00 * g[e]);
-                if (sp.ok[1]) atomicAdd(dx + (base + 1) * d.C + c, w01 * g[e]);
-                if (sp.ok[2]) atomicAdd(dx + (base + d.W) * d.C + c, w10 * g[e]);
-                if (sp.ok[3]) atomicAdd(dx + (base + d.W + 1) * d.C + c, w11 * g[e]);
-            }
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            gy += __shfl_xor(gy, o, 64);
-            gx += __shfl_xor(gx, o, 64);
-        }
-        if (lane == 0) {
-            doffset[(long)m * d.off_stride + 2 * k] = gy;
-            doffset[(long)m * d.off_stride + 2 * k + 1] = gx;
-        }
+// ---- adjoint of the sampling: DETERMINISTIC (round 3) ---------------------------------------------------------------------------
+// dx[n, y, x, c] receives w_corner * dcols[m, k, c] from every sample (m, k) one of whose four bilinear corners is (y, x); which
+// samples those are depends on the learned offsets.  Rounds 1-2 scattered with float atomics (the library's only kernel whose
+// summation order was not fixed).  Now every contribution is accumulated in FIXED POINT: c -> round(c * 2^k) as a 64-bit integer,
+// with 2^k chosen per call from max |dcols| (a reduction pass: absmax_kernel) so that the largest possible contribution is 2^43 —
+// integer addition is associative, so LDS and global integer atomics give the same bits in any order; the resolution is
+// 2^-43 of the largest column gradient (5e-14 relative: far below the fp32 rounding of the result).  d(offset) — a sum over
+// channels of g * d(bilinear)/d(y, x), bounded by 2 max|dcols| max|x| per term — takes the same route with its own scale.
+// The 9 taps of neighbouring output pixels land on the same few input pixels, so a workgroup owns a T x T tile of output pixels
+// of one image and one chunk of CC channels and accumulates its corner contributions in an LDS patch of the input region first
+// (tile footprint + HALO pixels for the learned offsets; ds_add_u64), flushing each touched patch element with ONE global
+// integer atomic; samples that leave the patch (|offset| > HALO) go to the global accumulator directly.
+constexpr int COL2IM_T = 8, COL2IM_HALO = 2;
+
+template <int AT>
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ x, long n4, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = dbn_ld4<AT>(x, i);
+        m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (!(m == m) || m > 3.0e38f) m = 3.0e38f;  // NaN / inf inputs: keep the scale finite (the result is garbage either way)
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
 }
 
-// Tiled adjoint of the sampling.  The 9 taps of neighbouring output pixels land on the same few input pixels, so a
-// workgroup owns a T x T tile of output pixels of one image and one chunk of 32 channels, accumulates their corner
-// contributions in an LDS patch of the input region (tile footprint + HALO pixels for the learned offsets; native
-// ds_add_f32) and flushes each patch element with ONE global atomic — 12x fewer global atomics than the scatter per
-// sample.  Samples that leave the patch (|offset| > HALO) fall back to global atomics.  d(offset) sums over channels:
-// a team reduction per (pixel, tap) and one atomic per channel chunk (doffset is zeroed by the caller).
-constexpr int COL2IM_T = 8, COL2IM_HALO = 2, COL2IM_CC = 32;
+// 2^k with (largest magnitude, rounded up to a power of two) * 2^k = 2^43
+__device__ __forceinline__ double fixed_scale(float vmax) {
+    if (!(vmax > 0.f)) return 1.0;
+    int e;
+    frexpf(vmax, &e);  // vmax < 2^e
+    return ldexp(1.0, 43 - e);
+}
+__device__ __forceinline__ unsigned long long to_fixed(float v, double scale) { return (unsigned long long)__double2ll_rn((double)v * scale); }
 
-// AT: storage type of dcols, x and offset; dx and doffset are ALWAYS fp32 (they are accumulated with float atomics: in 16-bit
-// storage the caller gives fp32 scratch and rounds once afterwards, dbn_cast_f32)
-template <int AT>
+// AT: storage type of dcols, x and offset.  dx64 / doff64: 64-bit fixed-point accumulators (zeroed by the caller).
+template <int AT, int CC>
 __global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const void* __restrict__ dcols, const void* __restrict__ x,
-                                                                  const void* __restrict__ offset, float* __restrict__ dx,
-                                                                  float* __restrict__ doffset, DeformDims d, int tiles_x, int tiles_y,
-                                                                  int PD) {
-    extern __shared__ float patch[];  // [PD][PD][CC]
-    constexpr int T = COL2IM_T, CC = COL2IM_CC;
-    const int lane = threadIdx.x & 31, team = threadIdx.x >> 5;
+                                                                  const void* __restrict__ offset, unsigned long long* __restrict__ dx64,
+                                                                  unsigned long long* __restrict__ doff64,
+                                                                  const unsigned* __restrict__ maxbits, DeformDims d, int tiles_x,
+                                                                  int tiles_y, int PD) {
+    extern __shared__ unsigned long long patch[];  // [PD][PD][CC]
+    constexpr int T = COL2IM_T, TEAM = CC, TEAMS = 256 / CC;
+    const int lane = threadIdx.x % TEAM, team = threadIdx.x / TEAM;
     const int chunk = blockIdx.y, c = chunk * CC + lane;
+    const float gmax = __builtin_bit_cast(float, maxbits[0]), xmax = __builtin_bit_cast(float, maxbits[1]);
+    const double sdx = fixed_scale(gmax), soff = fixed_scale(64.f * fmaxf(gmax, 1e-30f) * fmaxf(xmax, 1e-30f));
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, n = bid / tiles_y;
     const int oy0 = ty * T, ox0 = tx * T;                                                       // first output pixel of the tile
     const int py0 = oy0 * d.stride - d.pad - COL2IM_HALO, px0 = ox0 * d.stride - d.pad - COL2IM_HALO;  // patch origin (input coords)
-    for (int i = threadIdx.x; i < PD * PD * CC; i += blockDim.x) patch[i] = 0.f;
+    for (int i = threadIdx.x; i < PD * PD * CC; i += blockDim.x) patch[i] = 0ull;
     __syncthreads();
     const int RS = d.R * d.S;
     const bool cok = c < d.C;
-    for (int pair = team; pair < T * T * RS; pair += 8) {
+    for (int pair = team; pair < T * T * RS; pair += TEAMS) {
         const int pi = pair / RS, k = pair - pi * RS;
         const int ho = oy0 + pi / T, wo = ox0 + pi % T;
         if (ho >= d.Ho || wo >= d.Wo) continue;
@@ -170,33 +154,59 @@ __global__ __launch_bounds__(256) void deform_col2im_tiled_kernel(const void* __
             v[q] = (sp.ok[q] && cok) ? dbn_ld1<AT>(x, (((long)n * d.H + yy) * d.W + xx) * d.C + c) : 0.f;
             if (sp.ok[q] && cok) {
                 const int ry = yy - py0, rx = xx - px0;
-                const float add = wgt[q] * g;
+                const unsigned long long add = to_fixed(wgt[q] * g, sdx);
                 if ((unsigned)ry < (unsigned)PD && (unsigned)rx < (unsigned)PD)
                     atomicAdd(&patch[(ry * PD + rx) * CC + lane], add);
                 else
-                    atomicAdd(dx + (((long)n * d.H + yy) * d.W + xx) * d.C + c, add);
+                    atomicAdd(dx64 + (((long)n * d.H + yy) * d.W + xx) * d.C + c, add);
             }
         }
         float gy = g * (hx * (v[2] - v[0]) + sp.lx * (v[3] - v[1]));
         float gx = g * (hy * (v[1] - v[0]) + sp.ly * (v[3] - v[2]));
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int o = TEAM / 2; o > 0; o >>= 1) {  // fixed shuffle tree inside the team
             gy += __shfl_xor(gy, o, 64);
             gx += __shfl_xor(gx, o, 64);
         }
         if (lane == 0) {
-            atomicAdd(doffset + (long)m * d.off_stride + 2 * k, gy);
-            atomicAdd(doffset + (long)m * d.off_stride + 2 * k + 1, gx);
+            atomicAdd(doff64 + ((long)m * RS + k) * 2, to_fixed(gy, soff));
+            atomicAdd(doff64 + ((long)m * RS + k) * 2 + 1, to_fixed(gx, soff));
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < PD * PD * CC; i += blockDim.x) {
-        const float vsum = patch[i];
-        if (vsum == 0.f) continue;
+        const unsigned long long vsum = patch[i];
+        if (vsum == 0ull) continue;
         const int cc = i % CC, pix = i / CC;
         const int yy = py0 + pix / PD, xx = px0 + pix % PD;
         if ((unsigned)yy < (unsigned)d.H && (unsigned)xx < (unsigned)d.W && chunk * CC + cc < d.C)
-            atomicAdd(dx + (((long)n * d.H + yy) * d.W + xx) * d.C + chunk * CC + cc, vsum);
+            atomicAdd(dx64 + (((long)n * d.H + yy) * d.W + xx) * d.C + chunk * CC + cc, vsum);
+    }
+}
+
+// fixed point -> storage type: dx = [dx +] dx64 / 2^k,  doffset[m][0 .. 2RS) = doff64 / 2^k', the remaining channels zero
+template <int AT>
+__global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict__ dx64, const unsigned long long* __restrict__ doff64,
+                                            const unsigned* __restrict__ maxbits, void* __restrict__ dx, void* __restrict__ doffset,
+                                            long ndx4, long M, int RS2, int off_stride, int accumulate) {
+    const float gmax = __builtin_bit_cast(float, maxbits[0]), xmax = __builtin_bit_cast(float, maxbits[1]);
+    const double idx = 1.0 / fixed_scale(gmax), ioff = 1.0 / fixed_scale(64.f * fmaxf(gmax, 1e-30f) * fmaxf(xmax, 1e-30f));
+    const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    for (long i = t0; i < ndx4; i += stride) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)((double)(long long)dx64[4 * i + e] * idx);
+        if (accumulate) v += dbn_ld4<AT>(dx, i);
+        dbn_st4<AT>(dx, i, v);
+    }
+    const long noff4 = M * (off_stride / 4);
+    for (long i = t0; i < noff4; i += stride) {
+        const long m = i / (off_stride / 4);
+        const int ch = (int)(i - m * (off_stride / 4)) * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ch + e < RS2 ? (float)((double)(long long)doff64[m * RS2 + ch + e] * ioff) : 0.f;
+        dbn_st4<AT>(doffset, i, v);
     }
 }
 
@@ -257,37 +267,46 @@ int dbn_cast_f32(int at, const float* src, void* dst, long n, void* stream) {
     return dbn_status();
 }
 
-// adjoint of the sampling: dx[N,H,W,C] += scatter(dcols) (float atomics; the caller initialises dx),
-// doffset[N*Ho*Wo][off_stride]: channels 0..2RS-1 written, the rest set to zero
-// dcols / x / offset in the activation type `at`; dx and doffset are fp32 in every mode (float atomics) — 16-bit callers pass
-// fp32 scratch and round with dbn_cast_f32
-int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, float* dx, float* doffset, int N, int H, int W,
-                        int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
+// Scratch of dbn_deform_col2im_t: two maxima + the 64-bit fixed-point accumulators of dx and of the 2*R*S offset channels
+long dbn_deform_col2im_ws_bytes(int N, int H, int W, int C, int Ho, int Wo, int R, int S) {
+    return 16L + 8L * ((long)N * H * W * C + (long)N * Ho * Wo * 2 * R * S);
+}
+
+// adjoint of the sampling, deterministic (fixed-point accumulation, see above): dx[N,H,W,C] = [dx +] scatter(dcols),
+// doffset[N*Ho*Wo][off_stride]: channels 0 .. 2RS-1 written, the rest set to zero.  dcols / x / offset / dx / doffset in the
+// activation type `at`; ws: dbn_deform_col2im_ws_bytes(...) bytes.  accumulate = 1: dx holds a gradient already (it is added).
+int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, void* dx, void* doffset, int accumulate, void* ws,
+                        int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
     const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
-    DBN_REQUIRE(dcols && x && offset && dx && doffset && dims_ok(d));
+    DBN_REQUIRE(dcols && x && offset && dx && doffset && ws && dims_ok(d) && R == S && off_stride % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    static const int tiled = dbn_env_int("DBN_COL2IM_TILED", 1);  // (0: per-sample scatter; -DDBN_EXPERIMENTS builds only)
-    const int PD = (COL2IM_T - 1) * stride + R + 2 * COL2IM_HALO;  // patch edge; R == S for every DCN layer of the reference
-    const size_t lds = (size_t)PD * PD * COL2IM_CC * sizeof(float);
-    if (tiled && R == S && lds <= 64 * 1024) {
-        if (hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess) return dbn_status();
-        const int tiles_x = dbn_ceil_div(Wo, COL2IM_T), tiles_y = dbn_ceil_div(Ho, COL2IM_T);
-        DBN_DISPATCH_AT(at, hipLaunchKernelGGL(deform_col2im_tiled_kernel<AT>, dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, COL2IM_CC)),
-                                               dim3(256), lds, st, dcols, x, offset, dx, doffset, d, tiles_x, tiles_y, PD));
-        return dbn_status();
-    }
-    DBN_REQUIRE(at == 0);  // the per-sample scatter below exists for fp32 tensors only
-    if (off_stride > 2 * R * S &&
-        hipMemsetAsync(doffset, 0, (size_t)N * Ho * Wo * off_stride * sizeof(float), st) != hipSuccess)
-        return dbn_status();
-    const long teams = (long)N * Ho * Wo * R * S;
-    hipLaunchKernelGGL(deform_col2im_kernel, dim3(dbn_grid(teams * 32, 256, 1 << 16)), dim3(256), 0, st, (const float*)dcols,
-                       (const float*)x, (const float*)offset, dx, doffset, d, teams);
+    const long M = (long)N * Ho * Wo, ndx = (long)N * H * W * C, ncols = M * R * S * C;
+    if (hipMemsetAsync(ws, 0, (size_t)dbn_deform_col2im_ws_bytes(N, H, W, C, Ho, Wo, R, S), st) != hipSuccess) return dbn_status();
+    unsigned* maxbits = reinterpret_cast<unsigned*>(ws);
+    unsigned long long* dx64 = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 16);
+    unsigned long long* doff64 = dx64 + ndx;
+    const int PD = (COL2IM_T - 1) * stride + R + 2 * COL2IM_HALO;  // patch edge
+    const int tiles_x = dbn_ceil_div(Wo, COL2IM_T), tiles_y = dbn_ceil_div(Ho, COL2IM_T);
+    // channels per workgroup: 32, or 16 where the 64-bit patch of a stride-2 layer would not fit 64 KB
+    const bool cc32 = (size_t)PD * PD * 32 * 8 <= 64 * 1024;
+    DBN_REQUIRE(cc32 || (size_t)PD * PD * 16 * 8 <= 64 * 1024);
+    DBN_DISPATCH_AT(at, {
+        hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(ncols / 4, 256, 2048)), dim3(256), 0, st, dcols, ncols / 4, maxbits);
+        hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(ndx / 4, 256, 2048)), dim3(256), 0, st, x, ndx / 4, maxbits + 1);
+        if (cc32)
+            hipLaunchKernelGGL((deform_col2im_tiled_kernel<AT, 32>), dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, 32)), dim3(256),
+                               (size_t)PD * PD * 32 * 8, st, dcols, x, offset, dx64, doff64, maxbits, d, tiles_x, tiles_y, PD);
+        else
+            hipLaunchKernelGGL((deform_col2im_tiled_kernel<AT, 16>), dim3(N * tiles_y * tiles_x, dbn_ceil_div(C, 16)), dim3(256),
+                               (size_t)PD * PD * 16 * 8, st, dcols, x, offset, dx64, doff64, maxbits, d, tiles_x, tiles_y, PD);
+        hipLaunchKernelGGL(deform_col2im_finish_kernel<AT>, dim3(dbn_grid(ndx / 4)), dim3(256), 0, st, dx64, doff64, maxbits, dx, doffset,
+                           ndx / 4, M, 2 * R * S, off_stride, accumulate);
+    });
     return dbn_status();
 }
-int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
-                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
-    return dbn_deform_col2im_t(0, dcols, x, offset, dx, doffset, N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride, stream);
+int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int accumulate, void* ws, int N,
+                      int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
+    return dbn_deform_col2im_t(0, dcols, x, offset, dx, doffset, accumulate, ws, N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride, stream);
 }
 
 // to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T] (OIHW -> GEMM column order); 0: the inverse

@@ -860,16 +860,11 @@ class Engine:
         dcols = self.buf(name + '/dcols', *cols.shape)
         self.conv_dgrad(name + '.conv2', dy, vconv, dcols, False, version=ver2)
         doff = self.buf(name + '/doffset', N, Ho, Wo, 64)
-        # the adjoint of the sampling accumulates with float atomics: fp32 targets in every mode (16-bit storage: fp32 scratch,
-        # rounded once afterwards)
-        dx32 = dx if self.at == 0 else self.scratch('_dcn_dx32', dx.numel())[:dx.numel()].view(dx.shape)
-        doff32 = doff if self.at == 0 else self.scratch('_dcn_doff32', doff.numel())[:doff.numel()].view(doff.shape)
-        dx32.zero_()
-        check(self.L.dbn_deform_col2im_t(self.at, dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx32.data_ptr(), doff32.data_ptr(), N, H,
-                                         W, C, Ho, Wo, conv.k, conv.k, conv.stride, conv.padding, 64, self.stream), 'deform_col2im')
-        if self.at != 0:
-            check(self.L.dbn_cast_f32(self.at, dx32.data_ptr(), dx.data_ptr(), dx.numel(), self.stream), 'cast dx')
-            check(self.L.dbn_cast_f32(self.at, doff32.data_ptr(), doff.data_ptr(), doff.numel(), self.stream), 'cast doffset')
+        # the adjoint of the sampling accumulates in 64-bit fixed point (deterministic, any storage type)
+        ws = self.scratch('_dcn_col2im_ws', self.L.dbn_deform_col2im_ws_bytes(N, H, W, C, Ho, Wo, conv.k, conv.k) // 4 + 1)
+        check(self.L.dbn_deform_col2im_t(self.at, dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx.data_ptr(), doff.data_ptr(), 0,
+                                         ws.data_ptr(), N, H, W, C, Ho, Wo, conv.k, conv.k, conv.stride, conv.padding, 64, self.stream),
+              'deform_col2im')
         voc, ver = self._offset_conv(name + '.conv2_offset', oc)
         tg = self.fbuf(name + '/dw_offset', 64, C, oc.k, oc.k)
         self.wgrad(name + '.conv2_offset', doff, x, 64, C, oc.k, oc.stride, oc.padding, tg)

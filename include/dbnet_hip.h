@@ -279,10 +279,13 @@ int dbn_wall_clock_khz(void);
  * off_stride >= 2*R*S lets the offsets live in the 64-channel output of the (zero-padded) offset conv. */
 int dbn_deform_im2col(const float* x, const float* offset, float* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
                       int stride, int pad, int off_stride, void* stream);
-/* dx += adjoint of the sampling applied to dcols (float atomics: summation order not fixed); doffset is written
- * (channels >= 2*R*S zeroed). */
-int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int N, int H, int W, int C,
-                      int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
+/* dx = [dx +] adjoint of the sampling applied to dcols; doffset is written (channels >= 2*R*S zeroed).  DETERMINISTIC since
+ * round 3: every contribution is accumulated in 64-bit fixed point (scale from max |dcols| of the call: resolution 2^-43 of the
+ * largest column gradient), so LDS / global integer atomics give the same bits in any order.  ws: dbn_deform_col2im_ws_bytes(...)
+ * bytes of scratch; accumulate = 1 adds to the gradient dx already holds; off_stride % 4 == 0. */
+long dbn_deform_col2im_ws_bytes(int N, int H, int W, int C, int Ho, int Wo, int R, int S);
+int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int accumulate, void* ws, int N,
+                      int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
 /* to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T]; 0: dst[O][C][T] = scale * src[O][T][C] */
 int dbn_permute_weight(const float* src, float* dst, int O, int C, int T, int to_ohwi, float scale, void* stream);
 
@@ -357,12 +360,11 @@ int dbn_wgrad_tile_config(int O, int J);
 int dbn_wgrad_phase_t(int phase, int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo,
                       int O, int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream);
 
-/* deformable conv (resnet.py:54-65,111-124) on typed tensors; dx / doffset of the adjoint are fp32 in every mode (float atomics):
- * 16-bit callers accumulate into fp32 scratch and round once with dbn_cast_f32 */
+/* deformable conv (resnet.py:54-65,111-124) on typed tensors: dcols, x, offset, dx and doffset all in the activation type `at` */
 int dbn_deform_im2col_t(int at, const void* x, const void* offset, void* cols, int N, int H, int W, int C, int Ho, int Wo, int R, int S,
                         int stride, int pad, int off_stride, void* stream);
-int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, float* dx, float* doffset, int N, int H, int W,
-                        int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
+int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, void* dx, void* doffset, int accumulate, void* ws,
+                        int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
 int dbn_cast_f32(int at, const float* src, void* dst, long n, void* stream);
 
 int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,

@@ -675,6 +675,35 @@ def test_two_stream_step_is_bit_reproducible():
 
 
 @pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_deformable_backbone_step_is_bit_reproducible(math):
+    """The deformable convs' sampling adjoint accumulates in 64-bit fixed point since round 3 (rounds 1-2: float atomics, the
+    library's only kernel whose summation order was not fixed): a train step of the DCN backbone (resnet.py:54-65,111-124) with
+    NON-ZERO learned offsets gives bit-identical gradients, parameters and maps from run to run."""
+    seed = 13
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    sd = O.new_state(seed, 'deformable_resnet18')
+    g = torch.Generator().manual_seed(1)
+    for k in sd:  # the reference initialises conv2_offset to zero (resnet.py:204-208): give it something to sample off-grid
+        if 'conv2_offset' in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (0.05 if k.endswith('weight') else 0.7)
+    outs = []
+    for _ in range(3):
+        model = make_model(seed, 'deformable_resnet18')
+        model.load_state_dict(sd)
+        model = model.train()
+        model.engine.set_conv_math(math)
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        for _ in range(2):
+            preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+        torch.cuda.synchronize()
+        outs.append((model.engine.flat_grad.clone(), model.engine.flat.clone(), preds.clone(), losses.clone()))
+    assert float(outs[0][0].abs().max()) > 0 and torch.isfinite(outs[0][0]).all()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
 def test_graph_captured_step_is_bit_identical_to_the_eager_step(math):
     """DBTrainer.use_graph: forward + DBLoss + backward replayed as ONE hipGraph launch (two-stream fork / join captured with it),
     gradient exchange and Adam outside.  Five steps over changing batches — two eager warm-up steps, the capturing step, two

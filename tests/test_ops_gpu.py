@@ -614,10 +614,19 @@ def test_deformable_conv(case, zero_offsets):
     dys = nhwc(dy)
     dcols = torch.full((N, Ho, Wo, 9 * C), float('nan'), device=DEV)
     igemm(dys, pack(wp.cpu(), 1), None, dcols, 1, 1, 0, 1)
-    dx = torch.zeros(N, H, W, C, device=DEV)
-    doffs = torch.full((N, Ho, Wo, OS), float('nan'), device=DEV)
-    _lib.check(L().dbn_deform_col2im(dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx.data_ptr(), doffs.data_ptr(), *dims,
-                                     stream()), 'deform_col2im')
+    ws = torch.empty(L().dbn_deform_col2im_ws_bytes(N, H, W, C, Ho, Wo, 3, 3), device=DEV, dtype=torch.uint8)
+    runs = []
+    for rep in range(3):  # the adjoint accumulates in 64-bit fixed point: bit-identical from run to run, whatever the offsets
+        dx = torch.full((N, H, W, C), float('nan'), device=DEV)
+        doffs = torch.full((N, Ho, Wo, OS), float('nan'), device=DEV)
+        _lib.check(L().dbn_deform_col2im(dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx.data_ptr(), doffs.data_ptr(), 0,
+                                         ws.data_ptr(), *dims, stream()), 'deform_col2im')
+        runs.append((dx.clone(), doffs.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:]), 'col2im is not bit-reproducible'
+    dx1 = torch.ones(N, H, W, C, device=DEV)  # accumulate form
+    _lib.check(L().dbn_deform_col2im(dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx1.data_ptr(), doffs.data_ptr(), 1,
+                                     ws.data_ptr(), *dims, stream()), 'deform_col2im acc')
+    report('deform conv dx (accumulate)', nchw(dx1), dx_ref + 1, 1e-4, 1e-4)
     report('deform conv dx', nchw(dx), dx_ref, 1e-4, 1e-4)
     report('deform conv doffset', nchw(doffs[..., :18].contiguous()), doff_ref, 2e-4 * float(doff_ref.abs().max()) + 1e-5, 1e-4)
     assert float(doffs[..., 18:].abs().max()) == 0.0
