@@ -195,10 +195,13 @@ long dbn_wgrad_slab_floats(int N, int Ho, int Wo, int O, int Cb, int R, int S) {
 
 // -1: read DBN_WGRAD_DMA on first use; 0: defaults (fp32 tensors: register-transposing kernel; bf16 tensors: LDS-DMA + transposing
 // reads); 1: LDS-DMA kernel for exact-fp32 math on fp32 tensors; 2: register-transposing kernel for bf16 tensors too
+// 3: as 0 with the general (per-pixel) gather addressing also where the k-tiles are whole row segments (A/B measurements, tests)
 static int g_wgrad_variant = -1;
+static int g_wgrad_row16 = 1;
 int dbn_set_wgrad_variant(int v) {
-    DBN_REQUIRE(v == 0 || v == 2 || (v == 1 && DBN_HAS_EXPERIMENTS));  // 1: the LDS-DMA kernel exists in -DDBN_EXPERIMENTS builds only
-    g_wgrad_variant = v;
+    DBN_REQUIRE(v == 0 || v == 2 || v == 3 || (v == 1 && DBN_HAS_EXPERIMENTS));  // 1: the LDS-DMA kernel exists in -DDBN_EXPERIMENTS builds only
+    g_wgrad_variant = v == 3 ? 0 : v;
+    g_wgrad_row16 = v == 3 ? 0 : 1;
     return DBN_OK;
 }
 
@@ -275,6 +278,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         p.rcp_Wo = 1.0f / (float)Wo;
         p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * es + 2 * sm_plane);
         p.big_bytes = (unsigned)((long)n * H * W * Cb * es + 2 * big_plane);
+        p.row16 = g_wgrad_row16;
         p.sm_plane_bytes = (unsigned)sm_plane;
         p.big_plane_bytes = (unsigned)big_plane;
         const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);

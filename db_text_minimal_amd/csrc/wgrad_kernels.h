@@ -12,7 +12,12 @@ struct WgradParams {
     float rcp_HWo, rcp_Wo;
     unsigned sm_bytes, big_bytes;
     unsigned sm_plane_bytes, big_plane_bytes;  // AT = 3: distance of the three bf16 planes of each operand
+    int row16;                                 // 0 switches the scalar-offset addressing of whole-row k-tiles off (measurements)
 };
+
+#ifndef DBN_DBG
+#define DBN_DBG 0
+#endif
 
 namespace {
 
@@ -33,10 +38,17 @@ __host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { retu
 
 // AT = 1 (bf16 activations and gradients in HBM, NS = 1): the staging threads fetch their 4 pixels x 4 channels as four
 // 8-byte loads and transpose the 16-bit values with two bit operations per output word — no conversion.
-template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
+// ROW = 1 (host: Wo % 16 == 0, so pixel splits and k-tiles are whole sixteenths of output rows): the 16 pixels of a k-tile lie in
+// ONE output row, its position (n, oh, ow0) is workgroup-uniform and moves with scalar instructions; each load is a loop-
+// invariant per-thread byte offset + a scalar offset (the s-offset of the buffer instruction), and what is left for the vector
+// unit per k-tile is the padding test of the gather (14 instructions instead of ~60: profile by deletion had put the address
+// math at a fifth of the kernel's time, tools/wgrad_deletion_probe.py).  The hardware does not range-check the scalar offset,
+// hence the k-tile index is clamped to the last one of the split (the prefetch runs D tiles past the end).
+template <int BM, int BN, int WM, int WN, int NS, int AT = 0, int ROW = 0>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
     // AT = 3 (NS = 3): both operands are pre-split fp32 tensors (three bf16 planes each, dbn_split3): as AT = 1, three times.
     static_assert(AT == 0 || (AT == 1 && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
+    static_assert(!ROW || AT == 0, "scalar-offset addressing is built for fp32 storage");
     constexpr unsigned ES = AT == 0 ? 4u : 2u;
     constexpr int NP = AT == 3 ? 3 : 1;
     constexpr int NT = WM * WN * 64;
@@ -67,7 +79,10 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int KT = (pend - pbeg + 15) / 16;
 
     const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.sm), 0, p.sm_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.big), 0, p.big_bytes, 0x00020000);
+    // ROW: taps reach `pad` rows / columns before a pixel: the per-thread offsets are made non-negative by moving the base back
+    const unsigned row_shift = ROW ? (unsigned)((p.pad * p.W + p.pad) * p.Cb) * ES : 0u;
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.big) - row_shift), 0, p.big_bytes + row_shift, 0x00020000);
 
     // staging roles (wave-uniform): threads [0,BM) transpose the A panel (sm: 16 pixels x BM channels),
     // threads [NT-BN,NT) the B panel (gathered big: 16 pixels x BN (tap,channel) columns).
@@ -112,7 +127,54 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         divmod24(pbeg + 4 * s_g, HWo, p.rcp_HWo, w_n, rem);
         divmod24(rem, p.Wo, p.rcp_Wo, w_oh, w_ow);
     }
+    // ROW: loop-invariant offsets, column of each of the 4 pixels relative to the k-tile's first input column, scalar position
+    unsigned vcon[4] = {OOB_OFFSET, OOB_OFFSET, OOB_OFFSET, OOB_OFFSET};
+    int ccol[4] = {0, 0, 0, 0};
+    int s_n = 0, s_oh = 0, s_ow = 0;
+    unsigned soff = 0;
+    if constexpr (ROW) {
+        const bool live = KT > 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (is_a) {
+                vcon[i] = live ? (unsigned)((4 * s_g + i) * p.O + o0 + 4 * s_c) * ES : OOB_OFFSET;
+                woff[i] = vcon[i];
+            } else if (is_b) {
+                ccol[i] = (4 * s_g + i) * p.stride + ts;
+                vcon[i] = (live && j_ok) ? row_shift + (unsigned)((tr * p.W + ccol[i]) * p.Cb + ci) * ES : OOB_OFFSET;
+            }
+        }
+        int rem, q0, q1, q2;
+        divmod24(pbeg, HWo, p.rcp_HWo, q0, rem);
+        divmod24(rem, p.Wo, p.rcp_Wo, q1, q2);
+        s_n = __builtin_amdgcn_readfirstlane(q0);
+        s_oh = __builtin_amdgcn_readfirstlane(q1);
+        s_ow = __builtin_amdgcn_readfirstlane(q2);
+    }
     auto offsets = [&](int kt) {
+        if (DBN_DBG & 2) return;
+        if constexpr (ROW) {
+            if (is_a) {
+                soff = (unsigned)((pbeg + 16 * max(0, min(kt, KT - 1))) * p.O) * ES;
+            } else if (is_b) {
+                const int ihb = s_oh * p.stride, iwb = s_ow * p.stride;
+                soff = (unsigned)(((s_n * p.H + ihb) * p.W + iwb) * p.Cb) * ES;
+                const bool rok = (unsigned)(ihb + tr) < (unsigned)p.H;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) woff[i] = (rok && (unsigned)(iwb + ccol[i]) < (unsigned)p.W) ? vcon[i] : OOB_OFFSET;
+                if (kt + 1 < KT) {  // (scalar) next k-tile of the split; the last one is re-read by the prefetch past the end
+                    s_ow += 16;
+                    if (s_ow == p.Wo) {
+                        s_ow = 0;
+                        if (++s_oh == p.Ho) {
+                            s_oh = 0;
+                            ++s_n;
+                        }
+                    }
+                }
+            }
+            return;
+        }
         const int pp0 = pbeg + kt * 16 + 4 * s_g;
         if (is_a) {
 #pragma unroll
@@ -149,6 +211,16 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     auto issue_loads = [&](auto SET) {
         f32x4 (&rr)[4] = rr_[decltype(SET)::value];
         u32x2 (&rh)[NP][4] = rh_[decltype(SET)::value];
+        if constexpr (ROW) {
+            const __amdgpu_buffer_rsrc_t rs = is_a ? rs_sm : rs_big;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (!(DBN_DBG & 1)) {
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    rr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)woff[i], (int)soff, 0));
+                }
+            return;
+        }
         if constexpr (D > 1) {
             // ONE code path for both roles (descriptor and plane distance picked by the wave-uniform role; threads without a role
             // load from out-of-range offsets): with the loads inside role branches the compiler's wait counts at the merge point
@@ -156,7 +228,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             const __amdgpu_buffer_rsrc_t rs = is_a ? rs_sm : rs_big;
             if constexpr (AT == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rr[i] = buffer_load_f32x4(rs, woff[i]);
+                for (int i = 0; i < 4; ++i)
+                    if (!(DBN_DBG & 1)) rr[i] = buffer_load_f32x4(rs, woff[i]);
             } else {
                 const unsigned pl = is_a ? p.sm_plane_bytes : p.big_plane_bytes;
 #pragma unroll
@@ -196,7 +269,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     auto stage = [&](int buf, auto SET) {
         f32x4 (&rr)[4] = rr_[decltype(SET)::value];
         u32x2 (&rh)[NP][4] = rh_[decltype(SET)::value];
-        if (is_a || is_b) {
+        if ((is_a || is_b) && !(DBN_DBG & 4)) {
             f32x4* dst = smem + buf * STAGE + lds_base;
             if constexpr (NS == 0) {
 #pragma unroll
@@ -899,17 +972,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS == 3 ? 3
 }
 
 // launch the register-transposing kernel for tile (bm, bn)
+template <int NS, int AT, int ROW>
+int launch_wgrad_tiles_row(const WgradParams& p, int bm, int bn, dim3 grid, hipStream_t st) {
+    if (bn == 192)
+        hipLaunchKernelGGL((wgrad_f32_kernel<64, 192, 2, 2, NS, AT, ROW>), grid, dim3(256), 0, st, p);
+    else if (bm == 128 && bn == 128)
+        hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS, AT, ROW>), grid, dim3(256), 0, st, p);
+    else if (bn == 128)
+        hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS, AT, ROW>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS, AT, ROW>), grid, dim3(256), 0, st, p);
+    return dbn_status();
+}
+// (scalar-offset addressing where every k-tile lies in one output row: fp32 storage, Wo % 16 == 0, whole-k-tile splits)
 template <int NS, int AT>
 int launch_wgrad_tiles(const WgradParams& p, int bm, int bn, dim3 grid, hipStream_t st) {
-    if (bn == 192)
-        hipLaunchKernelGGL((wgrad_f32_kernel<64, 192, 2, 2, NS, AT>), grid, dim3(256), 0, st, p);
-    else if (bm == 128 && bn == 128)
-        hipLaunchKernelGGL((wgrad_f32_kernel<128, 128, 2, 2, NS, AT>), grid, dim3(256), 0, st, p);
-    else if (bn == 128)
-        hipLaunchKernelGGL((wgrad_f32_kernel<64, 128, 2, 2, NS, AT>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS, AT>), grid, dim3(256), 0, st, p);
-    return dbn_status();
+    if constexpr (AT == 0)
+        if (p.Wo % 16 == 0 && p.pchunk % 16 == 0 && p.row16) return launch_wgrad_tiles_row<NS, AT, 1>(p, bm, bn, grid, st);
+    return launch_wgrad_tiles_row<NS, AT, 0>(p, bm, bn, grid, st);
 }
 
 }  // namespace
