@@ -278,7 +278,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         p.rcp_Wo = 1.0f / (float)Wo;
         p.sm_bytes = (unsigned)((long)n * Ho * Wo * O * es + 2 * sm_plane);
         p.big_bytes = (unsigned)((long)n * H * W * Cb * es + 2 * big_plane);
-        p.row16 = g_wgrad_row16;
+        p.row_tw = g_wgrad_row16 ? wgrad_row_tw(Ho, Wo) : 0;
         p.sm_plane_bytes = (unsigned)sm_plane;
         p.big_plane_bytes = (unsigned)big_plane;
         const int splitk = wgrad_splitk_one(n, Ho, Wo, O, Cb, R, S);

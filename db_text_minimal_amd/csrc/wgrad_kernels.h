@@ -12,8 +12,11 @@ struct WgradParams {
     float rcp_HWo, rcp_Wo;
     unsigned sm_bytes, big_bytes;
     unsigned sm_plane_bytes, big_plane_bytes;  // AT = 3: distance of the three bf16 planes of each operand
-    int row16;                                 // 0 switches the scalar-offset addressing of whole-row k-tiles off (measurements)
+    int row_tw;                                // ROW addressing: width of the 16-pixel blocks (16, 8, 4); 0 = general gather
 };
+
+// Width TW of the TW x 16/TW pixel blocks the reduction can be cut into (0: none — odd sizes keep the general gather)
+static inline int wgrad_row_tw(int Ho, int Wo) { return Wo % 16 == 0 ? 16 : (Wo % 8 == 0 && Ho % 2 == 0) ? 8 : (Wo % 4 == 0 && Ho % 4 == 0) ? 4 : 0; }
 
 #ifndef DBN_DBG
 #define DBN_DBG 0
@@ -38,12 +41,14 @@ __host__ __device__ __forceinline__ int tile_pos_to_index(int pos, int B) { retu
 
 // AT = 1 (bf16 activations and gradients in HBM, NS = 1): the staging threads fetch their 4 pixels x 4 channels as four
 // 8-byte loads and transpose the 16-bit values with two bit operations per output word — no conversion.
-// ROW = 1 (host: Wo % 16 == 0, so pixel splits and k-tiles are whole sixteenths of output rows): the 16 pixels of a k-tile lie in
-// ONE output row, its position (n, oh, ow0) is workgroup-uniform and moves with scalar instructions; each load is a loop-
-// invariant per-thread byte offset + a scalar offset (the s-offset of the buffer instruction), and what is left for the vector
-// unit per k-tile is the padding test of the gather (14 instructions instead of ~60: profile by deletion had put the address
-// math at a fifth of the kernel's time, tools/wgrad_deletion_probe.py).  The hardware does not range-check the scalar offset,
-// hence the k-tile index is clamped to the last one of the split (the prefetch runs D tiles past the end).
+// ROW = 1 (host: p.row_tw = TW in {16, 8, 4} with TW | Wo and TH = 16 / TW | Ho): the reduction runs over the pixels in blocks of
+// TW x TH (any order of a sum is a weight gradient; the order is fixed, so the result stays deterministic) — a k-tile is one such
+// block, its position (n, oh0, ow0) is workgroup-uniform and moves with scalar instructions; each load is a loop-invariant
+// per-thread byte offset + a scalar offset (the s-offset of the buffer instruction), and what is left for the vector unit per
+// k-tile is the padding test of the gather (14 instructions instead of ~60: profile by deletion had put the address math at a
+// fifth of the kernel's time, tools/wgrad_deletion_probe.py).  The hardware does not range-check the scalar offset, hence the
+// scalar position stops at the last k-tile of the split (the prefetch runs D tiles past the end and re-reads it).
+// TW = 16 visits the pixels in the order of the general gather (ROW = 0): bit-identical results.
 template <int BM, int BN, int WM, int WN, int NS, int AT = 0, int ROW = 0>
 __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParams p) {
     // AT = 3 (NS = 3): both operands are pre-split fp32 tensors (three bf16 planes each, dbn_split3): as AT = 1, three times.
@@ -127,49 +132,56 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         divmod24(pbeg + 4 * s_g, HWo, p.rcp_HWo, w_n, rem);
         divmod24(rem, p.Wo, p.rcp_Wo, w_oh, w_ow);
     }
-    // ROW: loop-invariant offsets, column of each of the 4 pixels relative to the k-tile's first input column, scalar position
+    // ROW: loop-invariant offsets; input row / columns of this thread's 4 pixels relative to the block's first input pixel;
+    // scalar position of the block
     unsigned vcon[4] = {OOB_OFFSET, OOB_OFFSET, OOB_OFFSET, OOB_OFFSET};
     int ccol[4] = {0, 0, 0, 0};
+    int crow = 0;
     int s_n = 0, s_oh = 0, s_ow = 0;
     unsigned soff = 0;
+    const int TW = ROW ? p.row_tw : 16, TH = 16 / TW;
     if constexpr (ROW) {
         const bool live = KT > 0;
+        const int qy = (4 * s_g) / TW;  // (TW >= 4: the 4 pixels of a thread share a row of the block)
+        crow = qy * p.stride + tr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const int qx = (4 * s_g + i) & (TW - 1);
             if (is_a) {
-                vcon[i] = live ? (unsigned)((4 * s_g + i) * p.O + o0 + 4 * s_c) * ES : OOB_OFFSET;
+                vcon[i] = live ? (unsigned)((qy * p.Wo + qx) * p.O + o0 + 4 * s_c) * ES : OOB_OFFSET;
                 woff[i] = vcon[i];
             } else if (is_b) {
-                ccol[i] = (4 * s_g + i) * p.stride + ts;
-                vcon[i] = (live && j_ok) ? row_shift + (unsigned)((tr * p.W + ccol[i]) * p.Cb + ci) * ES : OOB_OFFSET;
+                ccol[i] = qx * p.stride + ts;
+                vcon[i] = (live && j_ok) ? row_shift + (unsigned)((crow * p.W + ccol[i]) * p.Cb + ci) * ES : OOB_OFFSET;
             }
         }
-        int rem, q0, q1, q2;
-        divmod24(pbeg, HWo, p.rcp_HWo, q0, rem);
-        divmod24(rem, p.Wo, p.rcp_Wo, q1, q2);
-        s_n = __builtin_amdgcn_readfirstlane(q0);
-        s_oh = __builtin_amdgcn_readfirstlane(q1);
-        s_ow = __builtin_amdgcn_readfirstlane(q2);
+        const int bw = p.Wo / TW, bh = p.Ho / TH;
+        const int t0 = __builtin_amdgcn_readfirstlane(pbeg >> 4);
+        const int r0 = t0 / bw;
+        s_ow = (t0 - r0 * bw) * TW;
+        s_n = r0 / bh;
+        s_oh = (r0 - s_n * bh) * TH;
     }
     auto offsets = [&](int kt) {
         if (DBN_DBG & 2) return;
         if constexpr (ROW) {
             if (is_a) {
-                soff = (unsigned)((pbeg + 16 * max(0, min(kt, KT - 1))) * p.O) * ES;
+                soff = (unsigned)(((s_n * p.Ho + s_oh) * p.Wo + s_ow) * p.O) * ES;
             } else if (is_b) {
                 const int ihb = s_oh * p.stride, iwb = s_ow * p.stride;
                 soff = (unsigned)(((s_n * p.H + ihb) * p.W + iwb) * p.Cb) * ES;
-                const bool rok = (unsigned)(ihb + tr) < (unsigned)p.H;
+                const bool rok = (unsigned)(ihb + crow) < (unsigned)p.H;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) woff[i] = (rok && (unsigned)(iwb + ccol[i]) < (unsigned)p.W) ? vcon[i] : OOB_OFFSET;
-                if (kt + 1 < KT) {  // (scalar) next k-tile of the split; the last one is re-read by the prefetch past the end
-                    s_ow += 16;
-                    if (s_ow == p.Wo) {
-                        s_ow = 0;
-                        if (++s_oh == p.Ho) {
-                            s_oh = 0;
-                            ++s_n;
-                        }
+            }
+            if (kt + 1 < KT) {  // (scalar) next block of the split; the last one is re-read by the prefetch past the end
+                s_ow += TW;
+                if (s_ow == p.Wo) {
+                    s_ow = 0;
+                    s_oh += TH;
+                    if (s_oh == p.Ho) {
+                        s_oh = 0;
+                        ++s_n;
                     }
                 }
             }
@@ -984,11 +996,11 @@ int launch_wgrad_tiles_row(const WgradParams& p, int bm, int bn, dim3 grid, hipS
         hipLaunchKernelGGL((wgrad_f32_kernel<64, 64, 2, 2, NS, AT, ROW>), grid, dim3(256), 0, st, p);
     return dbn_status();
 }
-// (scalar-offset addressing where every k-tile lies in one output row: fp32 storage, Wo % 16 == 0, whole-k-tile splits)
+// (scalar-offset addressing over TW x 16/TW pixel blocks: fp32 storage, p.row_tw chosen by wgrad_row_tw(), whole-k-tile splits)
 template <int NS, int AT>
 int launch_wgrad_tiles(const WgradParams& p, int bm, int bn, dim3 grid, hipStream_t st) {
     if constexpr (AT == 0)
-        if (p.Wo % 16 == 0 && p.pchunk % 16 == 0 && p.row16) return launch_wgrad_tiles_row<NS, AT, 1>(p, bm, bn, grid, st);
+        if (p.row_tw && p.pchunk % 16 == 0) return launch_wgrad_tiles_row<NS, AT, 1>(p, bm, bn, grid, st);
     return launch_wgrad_tiles_row<NS, AT, 0>(p, bm, bn, grid, st);
 }
 
