@@ -325,11 +325,12 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     // (a prefetch distance of two k-tiles, which helps the igemm kernel, costs this kernel its occupancy — every thread
     // holds a 4x4 block per set for the register transpose: 64 -> 130 VGPRs, 100 -> 72 TFLOP/s measured — so it stays at one)
     using C0 = std::integral_constant<int, 0>;
+    constexpr bool AHEAD = NS > 0;  // (measured for ROW && NS == 0 too: 3-12 % slower than offsets right before the loads)
     if constexpr (D == 1) {
     if (KT > 0) {
         offsets(0);
         issue_loads(C0{});
-        if (NS > 0) offsets(1);
+        if (AHEAD) offsets(1);
         stage(0, C0{});
     }
     __syncthreads();
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
         const int buf = kt & 1;
         const bool more = kt + 1 < KT;
         if (more) {
-            if (NS == 0) offsets(kt + 1);
+            if (!AHEAD) offsets(kt + 1);
             issue_loads(C0{});
         }
         const f32x4* As = smem + buf * STAGE;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
             }
             mfma_split<NS, MI, NI>(af, bf, acc);
         }
-        if (NS > 0) offsets(kt + 2);  // independent of the MFMAs above: overlaps their execution
+        if (AHEAD) offsets(kt + 2);  // independent of the MFMAs above: overlaps their execution
         if (more) stage(buf ^ 1, C0{});
         __syncthreads();
     }
@@ -412,6 +413,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
                     for (int a = 0; a < MI; ++a)
 #pragma unroll
                         for (int b = 0; b < NI; ++b)
+                            // (scheduling barriers loads | MFMAs | staging measured: 0.71 -> 0.66 of peak on 64 x 192 — the
+                            // compiler's interleaving of the staging moves with the MFMAs is the better schedule)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], bf[s2][b][e], acc[a][b], 0, 0, 0);
         } else {
             bf16x8 af[NSX][MI], bf[NSX][NI];
