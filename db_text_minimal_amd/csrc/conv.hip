@@ -207,7 +207,7 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
                          hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
                          long plane_bytes, const IgemmBnb* bnb = nullptr) {
-    IgemmParams p;
+    IgemmParams p{};
     p.bnb_y = bnb ? bnb->y : nullptr; p.bnb_zmask = bnb ? bnb->zmask : nullptr;
     p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
     p.bnb_mean = bnb ? bnb->mean : nullptr; p.bnb_rstd = bnb ? bnb->rstd : nullptr;
@@ -498,7 +498,7 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
     int row0 = 0;
     for (int n0 = 0; n0 < N; n0 += nmax) {
         const int n = std::min(nmax, N - n0);
-        IgemmParams p;
+        IgemmParams p{};
         for (int g = 0; g < 4; ++g) {
             p.seg_src[g] = srcs[g] + (long)n0 * (H >> g) * (W >> g) * Cs * es;
             p.seg_wpk[g] = wpks[g];
