@@ -230,9 +230,12 @@ int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb) {
     return dbn_wgrad_tile_config(O, J) + (wgrad_uses_tr(at, ns, Cb) ? 16 : 0);
 }
 // ... with the layer geometry: + 32 when the launch is wgrad_patch_kernel<ns, at> (3x3 / stride 1 on the bf16 matrix pipe)
+// ... + 64 when wgrad_f32_kernel runs with block-wise k-tiles and scalar-offset addressing (its last template argument, ROW = 1)
 int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int stride, int pad, int Ho, int Wo, int H, int W) {
     if (wgrad_uses_patch(at, ns, O, Cb, R, S, stride, pad, Ho, Wo, H, W)) return dbn_wgrad_tile_config(O, R * S * Cb) + 32;
-    return dbn_wgrad_kernel_config(at, ns, O, R * S * Cb, Cb);
+    const int cfg = dbn_wgrad_kernel_config(at, ns, O, R * S * Cb, Cb);
+    const bool dma = g_wgrad_variant == 1 && ns == 0 && at == 0;
+    return cfg + ((cfg & 16) == 0 && at == 0 && !dma && g_wgrad_row16 && wgrad_row_tw(Ho, Wo) ? 64 : 0);
 }
 
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

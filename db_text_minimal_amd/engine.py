@@ -44,8 +44,8 @@ def flat_layout(numels):
 # BLK = false: the stem's K walk across taps)
 IGEMM_TILE_NAMES = {1: 'igemm_f32_kernel<128,128,2,2,%d,%d,%d,%s,%d,%s>', 2: 'igemm_f32_kernel<256,64,4,1,%d,%d,%d,%s,%d,%s>',
                     3: 'igemm_f32_kernel<128,64,2,2,%d,%d,%d,%s,%d,%s>', 4: 'igemm_f32_kernel<64,64,2,2,%d,%d,%d,%s,%d,%s>'}
-WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d>',
-                    3: 'wgrad_f32_kernel<64,128,2,2,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d>'}
+WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d,%d>', 2: 'wgrad_f32_kernel<128,128,2,2,%d,%d,%d>',
+                    3: 'wgrad_f32_kernel<64,128,2,2,%d,%d,%d>', 4: 'wgrad_f32_kernel<64,64,2,2,%d,%d,%d>'}
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
@@ -548,11 +548,11 @@ class Engine:
                 pad, self.grad_scale, self.stream)
         if self.prof:  # bracket the matrix kernel alone (its rocprofv3 symbol), then the slab reduction
             cfg = self.L.dbn_wgrad_kernel_config_hw(at, self.ns, O, Cb, k, k, stride, pad, Ho, Wo, H, W)
-            wname = WGRAD_TILE_NAMES[cfg & 15] % (self.ns, at)
+            wname = WGRAD_TILE_NAMES[cfg & 15] % (self.ns, at, (cfg >> 6) & 1)  # <BM,BN,WM,WN,NS,AT,ROW>
             if cfg & 32:  # 3x3 / stride 1 in the 16-bit matrix modes: pixel-patch kernel
                 wname = 'wgrad_patch_kernel<%d,%d>' % (self.ns, at)
             elif cfg & 16:  # bf16 tensors: LDS-DMA + transposing LDS reads
-                wname = 'wgrad_tr_kernel<' + wname.split('<')[1].rsplit(',', 2)[0] + '>'
+                wname = 'wgrad_tr_kernel<' + wname.split('<')[1].rsplit(',', 3)[0] + '>'
             self.prof.begin(wname,
                             2.0 * N * Ho * Wo * O * I * k * k, 0.0, 'wgrad ' + name)
             check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)

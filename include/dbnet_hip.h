@@ -341,11 +341,14 @@ int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, fl
 /* weight-gradient kernel selection (same results up to the summation order inside a split): 0 = defaults — fp32 tensors: the
  * register-transposing kernel; bf16 tensors: LDS-DMA panels + transposing LDS reads (wgrad_tr_kernel); 1 = LDS-DMA kernel for
  * exact-fp32 math on fp32 tensors (pixel-major LDS image, three-stage ring); 2 = the register-transposing kernel also where the
- * defaults take wgrad_tr_kernel or wgrad_patch_kernel (3x3 / stride-1 layers in the 16-bit matrix modes) */
+ * defaults take wgrad_tr_kernel or wgrad_patch_kernel (3x3 / stride-1 layers in the 16-bit matrix modes); 3 = the defaults with
+ * the general per-pixel gather also where the block-wise k-tiles apply (measurements, tests) */
 int dbn_set_wgrad_variant(int variant);
 /* tile variant as dbn_wgrad_tile_config, + 16 when the matrix kernel is wgrad_tr_kernel<BM,BN,2,2> (its rocprofv3 symbol) */
 int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb);
-/* ... with the layer geometry: + 32 when the matrix kernel is wgrad_patch_kernel<ns, at> (3x3 / stride 1, 16-bit matrix modes) */
+/* ... with the layer geometry: + 32 when the matrix kernel is wgrad_patch_kernel<ns, at> (3x3 / stride 1, 16-bit matrix modes);
+ * + 64 when wgrad_f32_kernel<BM,BN,2,2,ns,at,ROW> runs with ROW = 1: fp32 tensors whose output map tiles into 16x1, 8x2 or 4x4 pixel
+ * blocks — the reduction then walks such blocks with scalar-offset addressing (same sum; 16x1 blocks: bit-identical to ROW = 0) */
 int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int stride, int pad, int Ho, int Wo, int H, int W);
 /* 0: route 3x3 / stride-1 convolutions of the 16-bit matrix modes through the generic gather loop instead of the pixel-patch
    form (A/B and test hook; returns the previous setting) */
