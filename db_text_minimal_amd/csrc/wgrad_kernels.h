@@ -79,7 +79,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const int split = work / ntiles, tile_ = work - split * ntiles;
     const int ot = tile_ / njt, jt = tile_ - ot * njt;
     const int o0 = ot * BM, j0 = jt * BN;
-    const int pbeg = split * p.pchunk;
+    // (DBN_DBG bit 8: every split reads the FIRST pixel range — the same work with all gathers served from L2)
+    const int pbeg = (DBN_DBG & 8) ? 0 : split * p.pchunk;
     const int pend = min(p.P, pbeg + p.pchunk);
     const int KT = (pend - pbeg + 15) / 16;
 
