@@ -106,7 +106,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     const bool j_ok = is_b && jj < p.J;
     const int tap = j_ok ? jj / p.Cb : 0;
     const int ci = j_ok ? jj - tap * p.Cb : 0;
-    const int tr = tap / p.S - p.pad, ts = tap % p.S - p.pad;
+    // (DBN_DBG bit 16: every tap of a row reads the centre tap's pixel — same instructions, a third of the distinct lines)
+    const int tr = tap / p.S - p.pad, ts = (DBN_DBG & 16) ? 0 : tap % p.S - p.pad;
     const int HWo = p.Ho * p.Wo;
     const int ld = is_a ? AS : BS;
     const int lds_base = (is_a ? 0 : A_IMG) + s_c;
@@ -119,7 +120,9 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_f32_kernel(const WgradParam
     // the head convs' weight gradients 1.084 -> 1.045 ms, all weight gradients 0.648 -> 0.663 of peak, step +0.4 %), one for
     // 128 x 128 (152 registers = an occupancy step: 0.256 -> 0.279 ms).  Round 1's attempt at two had lost 28 % — with the loads
     // inside role branches the compiler drained every set each k-step (see issue_loads).
-    constexpr int D = AT == 3 ? 1 : NS == 0 ? (BM == 64 ? 2 : 1) : (AT == 0 ? 3 : 4);
+    // ROW (round 3): the scalar-offset addressing frees the registers of the address walk — two sets fit 128 x 128 at 149 registers
+    // (three waves per SIMD): 0.80 -> 0.84 at 80 x 80, no change at 40 x 40; three / four sets on the 64-row tiles +0..2 %: not taken
+    constexpr int D = AT == 3 ? 1 : NS == 0 ? ((BM == 64 || ROW) ? 2 : 1) : (AT == 0 ? 3 : 4);
     f32x4 rr_[D][4];        // AT = 0: 4 pixels x 4 fp32 channels
     u32x2 rh_[D][NP][4];    // AT = 1 / 3: per plane 4 pixels x 4 bf16 channels
     unsigned woff[4] = {OOB_OFFSET, OOB_OFFSET, OOB_OFFSET, OOB_OFFSET};

@@ -12,7 +12,7 @@ shapes = [('64->64 3x3 @160  <64,192>', 16, 160, 64, 64, 3), ('256->64 3x3 @160 
           ('128->128 3x3 @80 <128,128>', 16, 80, 128, 128, 3), ('256->256 3x3 @40 <128,128>', 16, 40, 256, 256, 3)]
 libs = sorted(glob.glob(os.path.join(ROOT, 'tools', 'probes', 'dbg', 'libwdbg_*.so')), key=lambda p: int(p.split('_')[-1][:-3]))
 libs.append(os.path.join(ROOT, 'db_text_minimal_amd', 'libdbnet_hip.so'))
-names = {-1: 'product library', 8: 'every split reads the first pixel range (L2-resident)', 201: 'sched barriers: loads | MFMA | staging', 202: 'sched barriers: loads | MFMA | last 3 MFMA + staging', 0: 'baseline', 1: '-loads', 2: '-address math', 3: '-loads,-math', 4: '-staging', 7: 'MFMA + LDS reads only'}
+names = {-1: 'product library', 301: 'prefetch distance 1', 302: 'prefetch distance 2', 303: 'prefetch distance 3', 304: 'prefetch distance 4', 16: 'the three taps of a row read the same pixel (L1 re-use)', 8: 'every split reads the first pixel range (L2-resident)', 201: 'sched barriers: loads | MFMA | staging', 202: 'sched barriers: loads | MFMA | last 3 MFMA + staging', 0: 'baseline', 1: '-loads', 2: '-address math', 3: '-loads,-math', 4: '-staging', 7: 'MFMA + LDS reads only'}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 st = torch.cuda.current_stream().cuda_stream
 for what, N, H, Ci, Co, k in shapes:
