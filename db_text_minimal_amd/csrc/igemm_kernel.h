@@ -1375,6 +1375,17 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             return;
         }
     }
+    if (DBN_DBG & 64) {  // (profile by deletion: no output stores — one element per lane keeps the accumulators alive)
+        float s_ = 0.f;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_ += acc[a][b][r];
+        if (s_ == 12345.678f) st_dst(dcol, s_);
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < MI; ++a)
         for_rows(a, [&](int r, bool ok, long doff) {
