@@ -92,6 +92,7 @@ SIGNATURES.update({
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
+    'dbn_set_convt_kernel': 'i',
     'dbn_wgrad_kernel_config': 'iiiii',
     'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',

@@ -138,6 +138,24 @@ static int tile_config_for(int M, int Cd, int ns) {
 int dbn_igemm_tile_config(int M, int Cd) { return tile_config_for(M, Cd, 0); }  // exact-fp32 choice
 int dbn_igemm_tile_config_ns(int M, int Cd, int ns) { return tile_config_for(M, Cd, ns); }
 
+// ConvTranspose2d(2x2, stride 2) forward in exact fp32: the dedicated kernel of convt_f32.hip (input tile resident in LDS, the four
+// parity classes walked inside the workgroup) instead of the general parity-class launch
+static int g_convt_enabled = 1;
+int dbn_set_convt_kernel(int on) {  // test / A-B hook: 0 routes the layer through igemm_f32_kernel MODE 2 again
+    const int old = g_convt_enabled;
+    g_convt_enabled = on != 0;
+    return old;
+}
+static bool convt_eligible(int mode, int ns, int at, int tile_hint, int R, int S, int stride, int pad, int Hs, int Ws, int Hd, int Wd, int Cs,
+                           int Cd, int accumulate, int ksplit) {
+    return g_convt_enabled && mode == 1 && ns == 0 && at == 0 && tile_hint == 0 && R == 2 && S == 2 && stride == 2 && pad == 0 && Hd == 2 * Hs &&
+           Wd == 2 * Ws && (Cs == 16 || Cs == 32 || Cs == 48 || Cs == 64) && Cd % 64 == 0 && !accumulate && ksplit <= 1;
+    // (+ per launch: convt_launch_ok)
+}
+
+// ... and the output of one launch (n images) below 4 GB: the kernel addresses rows with 32-bit byte offsets
+static bool convt_launch_ok(int n, int Hd, int Wd, int Cd) { return (long)n * Hd * Wd * Cd * 4 < (1L << 32); }
+
 static int g_patch_enabled = 1;
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
 int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
@@ -172,6 +190,8 @@ int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, in
     const int cfg = resolve_cfg(N * Hd * Wd, Cd, tile_hint, at, ns, kmode >= 2 ? 1 : kmode, R, S, kmode == 2 && stride == 1 ? 2 : stride, pad, Hs,
                                 Ws, Hd, Wd, Cs, ksplit);
     if (patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) return patch_cfg(cfg) + 16;
+    // + 32: the launch is convt2x2_f32_kernel<Cs> (a non-accumulating transposed 2x2 / stride-2 conv in exact fp32)
+    if (kmode == 2 && convt_eligible(1, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, 0, ksplit)) return cfg + 32;
     return cfg;
 }
 
@@ -206,7 +226,7 @@ struct IgemmBnb {
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
                          hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
-                         long plane_bytes, const IgemmBnb* bnb = nullptr) {
+                         long plane_bytes, const IgemmBnb* bnb = nullptr, int tile_hint = -1) {
     IgemmParams p{};
     p.bnb_y = bnb ? bnb->y : nullptr; p.bnb_zmask = bnb ? bnb->zmask : nullptr;
     p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
@@ -271,6 +291,12 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     }
     *rows_out = 0;
     if (covered == 0) return DBN_OK;
+    if (!bnb && convt_eligible(mode, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, accumulate, ksplit) &&
+        convt_launch_ok(N, Hd, Wd, Cd)) {
+        const int rc = dbn_launch_convt_f32(p, st);
+        *rows_out = p.launch_rows;
+        return rc;
+    }
     const int rc = igemm_dispatch(p, 2, ns, cfg, st, at);
     *rows_out = p.launch_rows;
     return rc;
@@ -323,7 +349,7 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
         const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
                                      reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
                                      pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes,
-                                     bnb ? &b : nullptr);
+                                     bnb ? &b : nullptr, tile_hint);
         if (rc) return rc;
         row0 += rows;
     }
@@ -345,14 +371,19 @@ int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* 
 }
 
 // Rows of BatchNorm partials a conv with this output shape produces (see dbn_conv_bn_f32); follows igemm_run's chunking
+// (conv_bn: the call is a dbn_conv_bn_t — no BatchNorm-backward sums — with this `accumulate`: it may take the ConvT kernel)
 static int bn_tile_rows(int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int mode, int stride, int tile_hint, int at, int ns, int R,
-                        int S, int pad) {
+                        int S, int pad, bool conv_bn = false, int accumulate = 0) {
     const int nmax = chunk_images(N, (long)Hd * Wd, (long)Hs * Ws * Cs * dbn_esize(at), (long)Hd * Wd * Cd);
     if (nmax < 1) return 0;
+    const bool convt = conv_bn && convt_eligible(mode, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, accumulate, 1);
     const int cfg = resolve_cfg((int)std::min<long>((long)N * Hd * Wd, 0x7FFFFFFF), Cd, tile_hint, at, ns, mode, R, S, stride, pad, Hs, Ws,
                                 Hd, Wd, Cs, 1);
     int rows = 0;
-    for (int n0 = 0; n0 < N; n0 += nmax) rows += bn_tile_rows_one(std::min(nmax, N - n0), Hd, Wd, mode, stride, cfg);
+    for (int n0 = 0; n0 < N; n0 += nmax) {
+        const int n = std::min(nmax, N - n0);
+        rows += (convt && convt_launch_ok(n, Hd, Wd, Cd)) ? dbn_convt_f32_rows(n * Hs * Ws) : bn_tile_rows_one(n, Hd, Wd, mode, stride, cfg);
+    }
     return rows;
 }
 
@@ -411,7 +442,7 @@ int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, 
                   const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                   float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
-    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad);
+    const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad, true, accumulate);
     DBN_REQUIRE(rows > 0);
     // (16-bit storage: the statistics are those of the fp32 accumulators, i.e. of the values BEFORE they are rounded for storage)
     const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,

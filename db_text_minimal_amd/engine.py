@@ -501,13 +501,23 @@ class Engine:
         wpk = self.pack(name, ct.weight, 1, 2)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
-            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 2)
+            self._prof_convT(N, H, W, C, ct.cout, name)
         sc, sh = self._conv_bn_call('convT+bn ' + name, bn_name, bn, y,
                                     (x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W, ct.cout, 2,
                                      2, 2, 0, 1), 1, 2)
         if self.prof:
             self.prof.end()
         return y, sc, sh
+
+    def _prof_convT(self, N, H, W, C, Co, name):
+        """label of a ConvTranspose2d(2x2, stride 2) forward: convt2x2_f32_kernel<Cin> (convt_f32.hip) in exact fp32, else the
+        parity-class launch of the implicit-GEMM kernel"""
+        flops = 2.0 * N * H * W * C * Co * 4
+        at = 3 if self._use_planes else self.at
+        if self.L.dbn_igemm_kernel_config(at, self.ns, 2, N, H, W, C, 2 * H, 2 * W, Co, 2, 2, 2, 0, 0, 1) & 32:
+            self.prof.begin('convt2x2_f32_kernel<%d>' % C, flops, 0.0, 'convT fwd ' + name)
+        else:
+            self._prof_igemm(N * 4 * H * W, Co, flops, 'convT fwd ' + name, 2)
 
     def _prof_igemm(self, M, Cd, flops, tag='', mode=0, geom=None, epi=0):
         """geom = (N, Hs, Ws, Cs, Hd, Wd, R, stride, pad) of a forward / stride-1 data-gradient call: only those can take the
@@ -575,7 +585,7 @@ class Engine:
         wpk = self.pack(name, ct.weight, 1, 2)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
-            self._prof_igemm(N * 4 * H * W, ct.cout, 2.0 * N * H * W * C * ct.cout * 4, 'convT fwd ' + name, 2)
+            self._prof_convT(N, H, W, C, ct.cout, name)
         self._igemm('igemm convT fwd ' + name, x.data_ptr(), wpk.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, C, 2 * H, 2 * W,
                     ct.cout, 2, 2, 2, 0, 1, 0, 0)
         if self.prof:

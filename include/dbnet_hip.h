@@ -344,6 +344,11 @@ int dbn_wgrad_t(int at, int ns, const void* sm, const void* big, float* slab, fl
  * defaults take wgrad_tr_kernel or wgrad_patch_kernel (3x3 / stride-1 layers in the 16-bit matrix modes); 3 = the defaults with
  * the general per-pixel gather also where the block-wise k-tiles apply (measurements, tests) */
 int dbn_set_wgrad_variant(int variant);
+/* ConvTranspose2d(2x2, stride 2, padding 0) forward in exact fp32 (dbn_igemm_f32 / dbn_conv_bn_f32 with mode 1, stride 2, R = S = 2,
+ * Cs in {16, 32, 48, 64}, no accumulate, tile_hint 0) runs as convt2x2_f32_kernel<Cs>: the input tile stays in LDS and the four output
+ * parity classes are walked inside the workgroup.  0 routes these calls through the general parity-class launch again (tests, A/B);
+ * returns the previous setting. */
+int dbn_set_convt_kernel(int on);
 /* tile variant as dbn_wgrad_tile_config, + 16 when the matrix kernel is wgrad_tr_kernel<BM,BN,2,2> (its rocprofv3 symbol) */
 int dbn_wgrad_kernel_config(int at, int ns, int O, int J, int Cb);
 /* ... with the layer geometry: + 32 when the matrix kernel is wgrad_patch_kernel<ns, at> (3x3 / stride 1, 16-bit matrix modes);

@@ -143,6 +143,55 @@ def test_conv_transpose(shape):
     report('convT wgrad', g.cpu(), dw_ref, 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('with_bn', [0, 1])
+@pytest.mark.parametrize('shape', [(2, 64, 64, 8, 6), (3, 64, 128, 20, 13), (1, 16, 64, 5, 7), (2, 32, 64, 16, 16), (1, 48, 192, 9, 11),
+                                   (16, 64, 64, 40, 40)])
+def test_conv_transpose_2x2_kernel(shape, with_bn):
+    """ConvTranspose2d(2x2, stride 2) forward in exact fp32 runs as convt2x2_f32_kernel (input tile resident in LDS, the four parity
+    classes walked inside the workgroup): equals F.conv_transpose2d and — the same products summed in the same order — is
+    BIT-IDENTICAL to the general parity-class launch (dbn_set_convt_kernel(0)); with the fused BatchNorm statistics (one partial
+    row per workgroup over its 4 x 128 output pixels) the coefficients / running statistics equal F.batch_norm's.  Ragged tiles
+    (pixels % 128 != 0), several channel tiles, every supported Cin."""
+    N, Ci, Co, H, W = shape
+    x = rnd(N, Ci, H, W, seed=1) * 2 + 0.3
+    w = rnd(Ci, Co, 2, 2, seed=2, scale=0.1)
+    b = rnd(Co, seed=3) * 2
+    ref = F.conv_transpose2d(x, w, b, 2)
+    xs, wp, bd = nhwc(x), pack(w, 1, 2), b.to(DEV)
+    d = lambda t: t.clone().to(DEV)
+    gamma, beta = rnd(Co, seed=4) * 0.3 + 1, rnd(Co, seed=5)
+    rm, rv = rnd(Co, seed=6), rnd(Co, seed=7).abs() + 0.5
+    outs = []
+    for on in (1, 0):
+        old = L().dbn_set_convt_kernel(on)
+        try:
+            y = torch.full((N, 2 * H, 2 * W, Co), float('nan'), device=DEV)
+            if with_bn:
+                g_, b_, rm_, rv_ = d(gamma), d(beta), d(rm), d(rv)
+                sc, sh, mu, rs = (torch.full((Co, ), float('nan'), device=DEV) for _ in range(4))
+                ws = torch.empty(L().dbn_conv_bn_ws_floats(N, 2 * H, 2 * W, Co, 1, 2), device=DEV)
+                _lib.check(L().dbn_conv_bn_f32(xs.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, Ci, 2 * H, 2 * W, Co, 2, 2,
+                                               2, 0, 1, 0, 0, 0, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                               sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'conv_bn')
+                outs.append((y, sc, sh, mu, rs, rm_, rv_))
+            else:
+                igemm(xs, wp, bd, y, 2, 2, 0, 1)
+                outs.append((y, ))
+        finally:
+            L().dbn_set_convt_kernel(old)
+    report('convT 2x2 kernel', nchw(outs[0][0]), ref, 1e-4, 1e-4)
+    assert torch.equal(outs[0][0], outs[1][0])
+    if with_bn:
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        z_ref = F.batch_norm(ref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+        y, sc, sh, mu, rs, rm_, rv_ = outs[0]
+        report('convT+bn running_mean', rm_.cpu(), rm_ref, 1e-5, 1e-5)
+        report('convT+bn running_var', rv_.cpu(), rv_ref, 1e-5, 2e-5)
+        report('convT+bn normalised output', nchw(y) * sc.cpu().view(1, Co, 1, 1) + sh.cpu().view(1, Co, 1, 1), z_ref, 2e-5, 1e-4)
+        for nm, a, g in zip(('scale', 'shift', 'mean', 'rstd'), outs[0][1:5], outs[1][1:5]):  # other partial rows, same statistics
+            report('convT+bn %s vs general launch' % nm, a.cpu(), g.cpu(), 2e-6 * float(g.abs().max()) + 1e-7, 1e-5)
+
+
 @pytest.mark.parametrize('C,N,H,W', [(64, 2, 12, 10), (128, 1, 7, 5), (256, 2, 6, 6), (512, 3, 2, 2), (64, 4, 48, 48)])
 def test_batchnorm_train(C, N, H, W):
     x = (rnd(N, C, H, W, seed=1) * 2 + 3).requires_grad_(True)

@@ -38,3 +38,20 @@ for tag, src, wp, dst, k, s, p, flops in cases:
                 ts.append(e0.elapsed_time(e1))
             ts.sort()
             print('   tile %d  %-48s %6.1f us  %6.1f TFLOP/s  %.3f of peak' % (tile, names.get(bits, str(bits)), ts[2] * 1e3, flops / ts[2] / 1e9, flops / ts[2] / 1e9 / 157.3))
+
+# the dedicated kernel (convt_f32.hip) of the product library against the general launch
+from db_text_minimal_amd import _lib
+Lp = _lib.lib()
+tag, src, wp, dst, k, s, p, flops = cases[0]
+for on in (1, 0):
+    old = Lp.dbn_set_convt_kernel(on)
+    call = lambda: Lp.dbn_igemm_f32(src.data_ptr(), wp.data_ptr(), None, dst.data_ptr(), N, 160, 160, 64, 320, 320, 64, 2, 2, 2, 0, 1, 0, 0, st)
+    for _ in range(3):
+        call()
+    ts = []
+    for _ in range(9):
+        e0.record(); call(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    Lp.dbn_set_convt_kernel(old)
+    print('   product library, %-40s %6.1f us  %6.1f TFLOP/s  %.3f of peak' % ('convt2x2_f32_kernel' if on else 'general parity-class launch', ts[3] * 1e3, flops / ts[3] / 1e9, flops / ts[3] / 1e9 / 157.3))
