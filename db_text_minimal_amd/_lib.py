@@ -93,6 +93,7 @@ SIGNATURES.update({
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
     'dbn_set_convt_kernel': 'i',
+    'dbn_igemm_splitk_slab_floats': 'iiiii',
     'dbn_wgrad_kernel_config': 'iiiii',
     'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',
@@ -117,7 +118,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

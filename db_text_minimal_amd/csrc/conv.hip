@@ -490,13 +490,16 @@ int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns) {
 int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs) { return dbn_igemm_splitk_plan_ns(M, Cd, K, Cs, 0); }
 
 // dbn_igemm_f32 with the reduction split `ksplit` ways (mode 0, or mode 1 with stride 1; Cs % 16 == 0).
-// slab: ksplit * N*Hd*Wd*Cd floats of scratch.  Bit-reproducible (fixed summation order).
+// slab: dbn_igemm_splitk_slab_floats(ksplit, N, Hd, Wd, Cd) = ksplit * (N*Hd*Wd*Cd + 1088) floats of scratch (the slabs lie 1088 floats
+// further apart than their size: HBM channel rotation).  Bit-reproducible (fixed summation order).
 int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                          int ksplit, float* slab, void* stream) {
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream,
                      nullptr, ksplit, slab);
 }
+
+long dbn_igemm_splitk_slab_floats(int ksplit, int N, int Hd, int Wd, int Cd) { return (long)ksplit * ((long)N * Hd * Wd * Cd + 1088); }
 
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 

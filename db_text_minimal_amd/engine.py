@@ -395,7 +395,7 @@ class Engine:
         if self.splitk and (mode == 0 or stride == 1):
             ks = self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * S * Cs, Cs, self.ns)
             if ks > 1:  # few output tiles, long reduction: split K over workgroup rows, fixed-order slab sum
-                slab = self.scratch('_splitk_slab', ks * (N * Hd * Wd * Cd + 1088))  # slabs are padded apart (HBM channel rotation)
+                slab = self.scratch('_splitk_slab', self.L.dbn_igemm_splitk_slab_floats(ks, N, Hd, Wd, Cd))  # (slabs are padded apart: HBM channel rotation)
         check(self.L.dbn_igemm_t(at, self.ns, srcp, *args[1:], ks, _p(slab), self.stream), what)
 
     batched_repack = True

@@ -114,7 +114,9 @@ int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float
  * `ksplit` workgroup rows each reduce a contiguous range of k-tiles into their own slab, a second kernel sums the
  * slabs in fixed order and applies bias / accumulate.  mode 0, or mode 1 with stride 1; Cs % 16 == 0.
  * dbn_igemm_splitk_plan returns the split count the library would pick (1 = do not split);
- * slab: ksplit * (N*Hd*Wd*Cd + 1088) floats (the slabs are padded apart so that consecutive splits land on different HBM channels). */
+ * slab: dbn_igemm_splitk_slab_floats(...) = ksplit * (N*Hd*Wd*Cd + 1088) floats (the slabs are padded apart so that consecutive splits
+ * land on different HBM channels). */
+long dbn_igemm_splitk_slab_floats(int ksplit, int N, int Hd, int Wd, int Cd);
 int dbn_igemm_splitk_plan(int M, int Cd, int K, int Cs);
 int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns); /* ... for matrix math ns (the plan follows the tile choice) */
 int dbn_igemm_splitk_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,

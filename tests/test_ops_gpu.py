@@ -653,7 +653,7 @@ def test_conv_splitk(case, ksplit, ns):
     dst = nhwc(base)
     Nn, Hs, Ws, Cs = src.shape
     _, Hd, Wd, _ = dst.shape
-    slab = torch.full((ksplit * (dst.numel() + 1088), ), float('nan'), device=DEV)
+    slab = torch.full((L().dbn_igemm_splitk_slab_floats(ksplit, dst.shape[0], dst.shape[1], dst.shape[2], dst.shape[3]), ), float('nan'), device=DEV)
     _lib.check(L().dbn_igemm_splitk_f32(src.data_ptr(), wpk.data_ptr(), None if bias is None else bias.data_ptr(), dst.data_ptr(), Nn, Hs,
                                         Ws, Cs, Hd, Wd, Cd, k, k, s, p, mode, 1, 0, ns, ksplit, slab.data_ptr(), stream()), 'splitk')
     report('splitk conv %s ks=%d' % (case, ksplit), nchw(dst), base + ref.detach(), 1e-4, 1e-4)
