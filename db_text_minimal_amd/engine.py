@@ -279,6 +279,8 @@ class Engine:
     def pack(self, name, w, mode, stride=1, version=None, cs=0):
         """Weight panels of `w` for (mode, stride), cached until `w` changes.  `version` replaces w._version for tensors
         that are rewritten through raw pointers (the FPN's combined weights).  cs: channels of the source tensor (mode 0)."""
+        if self._repack_pending and name != self.STEM:  # (first use of a panel the side stream is still rebuilding)
+            self._join_repack()
         ns = self.kind
         key = (name, mode, stride, ns)
         ent = self.packs.get(key)
@@ -399,6 +401,17 @@ class Engine:
         check(self.L.dbn_igemm_t(at, self.ns, srcp, *args[1:], ks, _p(slab), self.stream), what)
 
     batched_repack = True
+    # ... and that launch (HBM-bound, 0.13 ms) runs on the side stream beside the stem conv, whose own panel is packed lazily on
+    # the main stream; the main stream waits for it after the stem (forward() -> _join_repack)
+    overlap_repack = True
+    _repack_pending = False
+    STEM = 'backbone.conv1'
+
+    def _join_repack(self):
+        if self._repack_pending:
+            assert not self._in_side
+            self.join_side()
+            self._repack_pending = False
 
     def repack_params(self):
         """After an optimizer step every weight panel is stale.  Instead of ~80 dbn_pack_weights launches sprinkled over the
@@ -406,9 +419,10 @@ class Engine:
         if not self.batched_repack:
             return
         ns = self.kind
+        beside = self.overlap_repack and self.overlap_wgrad
         stale = []
         for key, (w, cs) in self.pack_src.items():
-            if key[3] != ns:
+            if key[3] != ns or (beside and key[0] == self.STEM):
                 continue
             ent = self.packs.get(key)
             stamp = (w._version, self.param_epoch, w.data_ptr())
@@ -431,7 +445,12 @@ class Engine:
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self._pack_jobs = (sig, host.to(self.flat.device), len(stale))
         _, table, n = self._pack_jobs
-        check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
+        if beside:
+            with self.side_stream():
+                check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
+            self._repack_pending = True
+        else:
+            check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
         for key, _, out, stamp, _ in stale:
             self.packs[key] = (out, stamp)
 
@@ -726,6 +745,7 @@ class Engine:
               'maxpool fwd')
         if self.prof:
             self.prof.end()
+        self._join_repack()
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
 
