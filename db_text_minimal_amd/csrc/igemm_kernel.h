@@ -72,7 +72,18 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // in native bf16; 51 KB of LDS and a second register set of 4 units cost occupancy, and the barrier was not what bounds them —
     // the instruction stream per unit is).  Every path runs with one unit per barrier.
     constexpr int KU = 1;
-    constexpr int UNIT = A_IMG + B_IMG;
+#ifndef DBN_DIRECTB
+#define DBN_DIRECTB 1
+#endif
+    // DIRECTB (exact fp32 on fp32 tensors; round 3): the weight panel's pieces are fetched in MFMA-fragment order straight into
+    // registers — lane (li, lh) of wave column wn needs chunk 2*s2 + lh of column wn*TN + b*32 + li: 16 contiguous bytes of the packed
+    // panel, a half-wave 512 — one k-tile ahead: no LDS image, no ds_write / ds_read for B, half the LDS footprint (64 x 64 tile:
+    // 8.4 KB).  The two waves of a wave column fetch the same pieces (the second from L1).  Same products in the same order.
+    // Measured (interleaved A/B on one box, -DDBN_DIRECTB=0 is the staged form): the kernels alone within 1 % either way, the
+    // two-stream step +0.6 ... +0.9 % (538.2 / 541.8 against 534.8 / 536.9 images/s) — the smaller footprint co-resides better with
+    // the weight-gradient stream's workgroups.
+    constexpr bool DIRECTB = DBN_DIRECTB && NS == 0 && AT == 0 && !PATCH;
+    constexpr int UNIT = A_IMG + (DIRECTB ? 0 : B_IMG);
     constexpr int STAGE = KU * UNIT;
     constexpr int NSX = NS > 0 ? NS : 1;
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
@@ -285,6 +296,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // weight panel: a lane's piece of a k-tile lies at a fixed offset inside the tile, the tile's offset is wave-uniform and
     // travels as the scalar offset of the buffer load (no per-lane pointer arithmetic in the k-loop)
     unsigned b_voff[B_LD];
+    unsigned bf_voff[2][NI];  // DIRECTB
     int b_lds[B_LD];
     bool b_on[B_LD];
     __amdgpu_buffer_rsrc_t rsrcB;
@@ -299,6 +311,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             b_voff[j] = (unsigned)(c * p.Cd + n0 + n) * 16u;
             b_lds[j] = c * BS + n;
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bf_voff[s2][b] = (unsigned)((2 * s2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
         rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(panel), 0, (unsigned)ktiles * b_step_bytes, 0x00020000);
     };
     if (MODE != 3) {
@@ -351,6 +367,20 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
     // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
     f32x4 ra_[2][KU][A_LD], rb_[2][KU][B_LD];
+    f32x4 rbf_[2][2][NI];  // DIRECTB: B fragments of the current and the next k-tile
+    auto issue_b_frag = [&](auto SET) {  // the NEXT weight k-tile (clamped) into fragment set SET
+        constexpr int st_ = decltype(SET)::value;
+        const unsigned bso = (unsigned)min(b_kt, b_ktmax) * b_step_bytes;
+        ++b_kt;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bf_voff[s2][b], (int)bso, 0);
+                rbf_[st_][s2][b] = __builtin_bit_cast(f32x4, v_);
+            }
+    };
     auto issue_loads = [&](auto SET) {
         constexpr int st_ = decltype(SET)::value;
 #pragma unroll
@@ -362,6 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                     const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff[u][j], (int)asoff[u], 0);
                     ra_[st_][u][j] = __builtin_bit_cast(f32x4, v_);
                 }
+            if constexpr (DIRECTB) continue;
             const unsigned bso = (unsigned)min(b_kt, b_ktmax) * b_step_bytes;
             ++b_kt;
 #pragma unroll
@@ -401,9 +432,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                     reinterpret_cast<u32x2*>(As + (t * 2 + (a_chunk >> 1)) * AS + row)[a_chunk & 1] = sp[t];
             }
         }
+        if constexpr (!DIRECTB) {
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            if (B_FULL || b_on[j]) Bs[b_lds[j]] = rb[j];
+            for (int j = 0; j < B_LD; ++j)
+                if (B_FULL || b_on[j]) Bs[b_lds[j]] = rb[j];
+        }
     };
     auto stage = [&](int buf, auto SET) {
         stage_unit(buf, SET, std::integral_constant<int, 0>{});
@@ -767,6 +800,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         for (int u = 0; u < KU; ++u) next_offsets(u);
     };
     offsets_of_interval();
+    if constexpr (DIRECTB) issue_b_frag(C0{});  // weight k-tile 0
     issue_loads(C0{});
     offsets_of_interval();  // offsets of interval 1
     issue_loads(C1{});
@@ -781,6 +815,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 
     auto k_step = [&](int kt, auto PAR) {
         constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
+        if constexpr (DIRECTB) issue_b_frag(std::integral_constant<int, buf ^ 1>{});  // weight k-tile +1 (older than the A loads below: its wait leaves them in flight)
         issue_loads(PAR);  // interval +2 into the register set this interval was staged from
         // ... and they stay HERE: left alone the scheduler sinks them below the first MFMAs (it reuses the set's registers for the
         // fragment reads first), which shortens the prefetch distance from two k-steps to about one
@@ -807,7 +842,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                 for (int a = 0; a < MI; ++a) af[s2][a] = (DBN_DBG & 8) ? f32x4{(float)kt, 1.f, 2.f, 3.f} : As[(2 * s2 + lh) * AS + wm * TM + a * 32 + li];
 #pragma unroll
-                for (int b = 0; b < NI; ++b) bf[s2][b] = (DBN_DBG & 8) ? f32x4{1.f, (float)kt, 2.f, 3.f} : Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+                for (int b = 0; b < NI; ++b) {
+                    if constexpr (DIRECTB) bf[s2][b] = rbf_[buf][s2][b];
+                    else bf[s2][b] = (DBN_DBG & 8) ? f32x4{1.f, (float)kt, 2.f, 3.f} : Bs[(2 * s2 + lh) * BS + wn * TN + b * 32 + li];
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
