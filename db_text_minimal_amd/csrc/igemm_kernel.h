@@ -89,7 +89,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
     // 16-bit storage (AT != 0): LDS-DMA ring (see the main loop): stages of DMA_SU units, unpadded images [plane][k/8][row]
     constexpr int DMA_SU = 2;
-    constexpr int DMA_UNIT = NP * 2 * BM + NSX * 2 * BN;  // 16-byte slots of one unit
+#ifndef DBN_DIRECTB16
+#define DBN_DIRECTB16 1
+#endif
+    // DB16 (stored 16-bit operands, generic ring, not the pyramid form; round 3): the weight fragments come straight from the packed
+    // panel into registers, one stage ahead (as DIRECTB for fp32) — the ring carries the A panel only: half the DMA instructions and
+    // their scalar bookkeeping, no fragment reads for B, a ring half the size.  bf16 step 1624 -> 1683 images/s (interleaved A/B on
+    // one box; -DDBN_DIRECTB16=0 builds the ring with both panels)
+    constexpr bool DB16 = DBN_DIRECTB16 && AT != 0 && AT != 3 && MODE != 3 && !PATCH;
+    constexpr int DMA_UNIT = NP * 2 * BM + (DB16 ? 0 : NSX * 2 * BN);  // 16-byte slots of one unit
     constexpr int DMA_STAGE = DMA_SU * DMA_UNIT;
     constexpr int DMA_NSTG = DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
     // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
@@ -102,7 +110,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // (EPI = 1 on fp32 storage: the row-major epilogue needs half a tile — a whole one for one accumulator block per wave — of fp32)
     constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
     constexpr int EPI_SMEM = (EPI == 1 && DST_F32) ? BM * BN / (4 * (MI >= 2 ? 2 : 1)) : 0;
-    __shared__ f32x4 smem[LOOP_SMEM > EPI_SMEM ? LOOP_SMEM : EPI_SMEM];
+    // (16-bit destinations: the output tile is staged through LDS, BM rows of BN + 8 elements)
+    constexpr int OUT_SMEM = DST_F32 ? 0 : (BM * (BN + 8) * 2 + 15) / 16;
+    constexpr int SMEM_A = LOOP_SMEM > EPI_SMEM ? LOOP_SMEM : EPI_SMEM;
+    // (+ one slot: the in-kernel finalize of the BatchNorm sums keeps its flag in the last 16 bytes, behind every scratch region)
+    __shared__ f32x4 smem[(SMEM_A > OUT_SMEM ? SMEM_A : OUT_SMEM) + 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // handles ~one 128-byte line per clock whatever the lanes take from it (tools/probes/gather_rate.hip: 71 clocks per instruction
     // with 64 lines, 35 with 32), and the gather, not the MFMA, bounds these kernels.  The A image is therefore row-major
     // [plane][row][2 slices]; the fragment reads (stride 32 B) pay a 2-way bank conflict for it.
-    constexpr int A_I = NP * (BM / 32), B_I = NSX * 2 * (BN / 64), U_I = A_I + B_I;
+    constexpr int A_I = NP * (BM / 32), B_I = DB16 ? 0 : NSX * 2 * (BN / 64), U_I = A_I + B_I;
     static_assert(BM % 64 == 0 && BN % 64 == 0 && (DMA_SU * U_I) % NW == 0, "DMA instructions are dealt evenly to the waves");
     constexpr int PW = DMA_SU * U_I / NW;
     // Dealing: a wave's slot i of a stage has a COMPILE-TIME kind (A panel / weight panel) and, where a unit has at least one
@@ -626,7 +638,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     constexpr bool A_PER_UNIT = A_I % NW == 0, B_PER_UNIT = B_I % NW == 0;
     constexpr int RA = A_PER_UNIT ? A_I / NW : A_I / 2, RB = B_PER_UNIT ? B_I / NW : B_I / 2;
     constexpr int PA = A_PER_UNIT ? DMA_SU * RA : RA;
-    static_assert(PA + (B_PER_UNIT ? DMA_SU * RB : RB) == PW, "slot count");
+    static_assert(PA + (DB16 ? 0 : (B_PER_UNIT ? DMA_SU * RB : RB)) == PW, "slot count");
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int uw = wave_u >> 1;  // the unit of a slot dealt per stage
     int i_lds[PW];       // slot of the instruction's destination inside its UNIT (16-byte units)
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         const bool isA = i < PA;
         // index of the instruction inside its unit
         const int r = isA ? (A_PER_UNIT ? wave_u * RA + i % RA : (wave_u & 1) * RA + i)
-                          : (B_PER_UNIT ? wave_u * RB + (i - PA) % RB : (wave_u & 1) * RB + (i - PA));
+                          : (B_PER_UNIT ? wave_u * RB + (i - PA) % (RB > 0 ? RB : 1) : (wave_u & 1) * RB + (i - PA));
         const int c = r & 1, gp = r >> 1;
         const int g = isA ? r % (BM / 32) : gp % (BN / 64), plane = isA ? r / (BM / 32) : gp / (BN / 64);
         i_plane[i] = plane;
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         for (int i = 0; i < PW; ++i) {
             const bool isA = i < PA;  // compile-time after unrolling, like `fixed` and `uc`
             const bool fixed = isA ? A_PER_UNIT : B_PER_UNIT;
-            const int uc = isA ? i / RA : (i - PA) / RB;  // the unit of a per-unit slot
+            const int uc = isA ? i / RA : (i - PA) / (RB > 0 ? RB : 1);  // the unit of a per-unit slot
             const int u = fixed ? uc : uw;
             const bool v_u = fixed ? uv[uc] : (uw ? uv[DMA_SU - 1] : uv[0]);
             const int tr = fixed ? ur[uc] : (uw ? ur[DMA_SU - 1] : ur[0]), ts = fixed ? us[uc] : (uw ? us[DMA_SU - 1] : us[0]);
@@ -757,6 +769,87 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         }
     };
     static_assert(DMA_SU == 2, "issue_stage selects between two units");
+    if constexpr (DB16) {
+        // B fragments of a stage's two units: lane (li, lh) of wave column wn takes slice t*2 + lh of column wn*TN + b*32 + li
+        constexpr int NB = DMA_SU * NSX * NI;  // register loads per stage and wave
+        unsigned bvo[NSX][NI];
+#pragma unroll
+        for (int t = 0; t < NSX; ++t)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bvo[t][b] = (unsigned)((t * 2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
+        f32x4 rbB[2][DMA_SU][NSX][NI];
+        int bkt = kt_begin;  // weight k-tile of the next unit to fetch (clamped: units past the end multiply zeros of A)
+        const int bkt_max = max(kt_end - 1, kt_begin);
+        auto issue_bs = [&](auto SET) {
+            constexpr int st__ = decltype(SET)::value;
+#pragma unroll
+            for (int u = 0; u < DMA_SU; ++u) {
+                const unsigned so = (unsigned)min(bkt, bkt_max) * bstep_bytes;
+                ++bkt;
+#pragma unroll
+                for (int t = 0; t < NSX; ++t)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bvo[t][b], (int)so, 0);
+                        rbB[st__][u][t][b] = __builtin_bit_cast(f32x4, v_);
+                    }
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // prologue: the first DMA_NSTG - 1 stages of A, then the first B set (no dummy register loads: the compiler deletes loads
+        // whose results are overwritten, and the counted waits below must match what is really in flight)
+#pragma unroll
+        for (int s_ = 0; s_ < DMA_NSTG - 1; ++s_) issue_stage(s_);
+        asm volatile("" ::: "memory");
+        issue_bs(S0{});
+        asm volatile("" ::: "memory");
+        int slot = 0;
+        // EARLY = min(stage index, DMA_NSTG - 2): younger than stage st_'s DMA are the (DMA_NSTG - 2) later A stages and the B sets
+        // issued since — one after the prologue, one more per iteration until the steady state of DMA_NSTG - 1
+        auto body = [&](auto PARITY, auto EARLY) {
+            constexpr int par = decltype(PARITY)::value, early = decltype(EARLY)::value;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((DMA_NSTG - 2) * PW + NB * (1 + early)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int fill = slot == 0 ? DMA_NSTG - 1 : slot - 1;
+            issue_stage(fill);
+            // the counted wait assumes the register loads are YOUNGER than this iteration's DMA instructions (vmcnt retires in order)
+            asm volatile("" ::: "memory");
+            issue_bs(std::integral_constant<int, par ^ 1>{});
+            asm volatile("" ::: "memory");
+            const f32x4* Sg = smem + slot * DMA_STAGE;
+#pragma unroll
+            for (int u = 0; u < DMA_SU; ++u) {
+                const f32x4* As = Sg + u * DMA_UNIT;
+                bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+                for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                    for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * BM + wm * TM + a * 32 + li) * 2 + lh]);
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, rbB[par][u][t][b]);
+                }
+                mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+            }
+            slot = slot + 1 == DMA_NSTG ? 0 : slot + 1;
+        };
+        static_assert(DMA_NSTG == 4, "the peeled iterations below spell the early counts out");
+        using E0 = std::integral_constant<int, 0>;
+        using E1 = std::integral_constant<int, 1>;
+        using E2 = std::integral_constant<int, 2>;
+        int st_ = 0;
+        if (nstages > 0) body(S0{}, E0{});
+        if (nstages > 1) body(S1{}, E1{});
+        for (st_ = 2; st_ + 2 <= nstages; st_ += 2) {
+            body(S0{}, E2{});
+            body(S1{}, E2{});
+        }
+        if (st_ < nstages) body(S0{}, E2{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
 #pragma unroll
     for (int s_ = 0; s_ < DMA_NSTG - 1; ++s_) issue_stage(s_);
     int slot = 0;
@@ -786,6 +879,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-filled stages issued past the end
     __syncthreads();
+    }
     } else {
     for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
     if (MODE == 3) {

@@ -898,6 +898,36 @@ def pack_t(w, mode, stride, kind, cs=0):
     return out
 
 
+@pytest.mark.parametrize('case', [(8, 200, 64, 256, 1, 1, 0, 0), (8, 200, 64, 256, 1, 1, 0, 1), (8, 200, 128, 128, 3, 2, 1, 1), (8, 50, 2304, 256, 1, 1, 0, 1),
+                                  (8, 100, 128, 64, 3, 1, 1, 1), (2, 24, 2048, 512, 1, 1, 0, 0), (8, 25, 4608, 512, 1, 1, 0, 0)])
+def test_16bit_generic_loop_on_long_launches(case):
+    """The 16-bit generic loop keeps several A stages (LDS-DMA) and a weight-fragment set (register loads) in flight behind COUNTED
+    vmcnt waits; a count that does not match what is really outstanding reads a stage before it has landed — a race that only long
+    launches lose (configs[3] shapes: resnet50 / deformable at 800 x 800; the first version of the register-fragment form passed
+    every small-shape test and failed here).  bf16 storage, against F.conv2d / conv_transpose2d on the same rounded operands; three
+    runs must agree bit for bit."""
+    N, H, Cs, Cd, k, s, p, mode = case
+    x = (rnd(N, Cs, H, H, seed=1)).to(torch.bfloat16)
+    if mode == 0:
+        w = (rnd(Cd, Cs, k, k, seed=2, scale=(1.0 / (Cs * k * k))**0.5)).to(torch.bfloat16)
+        ref = F.conv2d(x.float(), w.float(), None, s, p)
+    else:
+        w = (rnd(Cs, Cd, k, k, seed=2, scale=(1.0 / (Cs * k * k))**0.5)).to(torch.bfloat16)
+        ref = F.conv_transpose2d(x.float(), w.float(), None, s, p, output_padding=s - 1 if s > 1 else 0)
+    Hd = ref.shape[2]
+    xs = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = pack_t(w.float(), mode, s, 1, Cs if mode == 0 else 0)
+    outs = []
+    for _ in range(3):
+        y = torch.full((N, Hd, Hd, Cd), float('nan'), device=DEV, dtype=torch.bfloat16)
+        igemm_t(xs, wp, None, y, k, s, p, mode)
+        outs.append(y)
+    got = outs[0].float().permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    report('16-bit generic loop %s' % (case, ), got, ref, 2.0**-7 * scale, 2.0**-7)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('tile', [0, 1, 2, 4])
 def test_convolutions_on_16bit_storage(dtype, tile):
