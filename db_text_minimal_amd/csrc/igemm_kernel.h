@@ -108,7 +108,15 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // so that two fit a CU; with a second buffer it was alone on its CU (103 KB, one wave per SIMD: every LDS latency exposed)
     constexpr int P_NBUF = NSX == 1 ? 2 : 1;
     // (EPI = 1 on fp32 storage: the row-major epilogue needs half a tile — a whole one for one accumulator block per wave — of fp32)
-    constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + P_NSTG * P_BSTAGE : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
+#ifndef DBN_DIRECTBP
+#define DBN_DIRECTBP 1
+#endif
+    // DBP (pixel-patch kernels of the three-plane bf16x3 mode; round 3): the weight fragments straight into registers, one stage (two
+    // taps) ahead — no weight ring, and the only barriers left are the two around a patch refill (one channel block = 18 units
+    // between them).  Measured (interleaved A/B on one box): bf16x3 714 -> 732 images/s; the single-plane kernels (bf16 storage,
+    // two patch buffers, ten barriers per block that also pace the ring) lose with it: 1644 -> 1620 — they keep the ring.
+    constexpr bool DBP = DBN_DIRECTBP && PATCH && NS == 3;
+    constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + (DBP ? 0 : P_NSTG * P_BSTAGE) : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
     constexpr int EPI_SMEM = (EPI == 1 && DST_F32) ? BM * BN / (4 * (MI >= 2 ? 2 : 1)) : 0;
     // (16-bit destinations: the output tile is staged through LDS, BM rows of BN + 8 elements)
     constexpr int OUT_SMEM = DST_F32 ? 0 : (BM * (BN + 8) * 2 + 15) / 16;
@@ -554,6 +562,88 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     const int q4 = li >> 2;
     const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1)) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
 
+    if constexpr (DBP) {
+        unsigned bvo[NSX][NI];
+#pragma unroll
+        for (int t = 0; t < NSX; ++t)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bvo[t][b] = (unsigned)((t * 2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
+        // fragment sets: stage st of a channel block uses set (st == 0 ? 2 : st & 1) — nine stages per block, so plain parity would
+        // hand stage 8 and the next block's stage 0 the same set
+        f32x4 rbP[3][2][NSX][NI];
+        auto issue_bp = [&](auto SET) {  // the next two weight k-tiles (one stage) into set SET
+            constexpr int st__ = decltype(SET)::value;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kt = g_kt + u;
+                const unsigned so = (unsigned)min(kt, qKT - 1) * bstep_bytes;  // (past the end: the last tile again — its A units are zeros... see below)
+#pragma unroll
+                for (int t = 0; t < NSX; ++t)
+#pragma unroll
+                    for (int b = 0; b < NI; ++b) {
+                        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)(kt < qKT ? bvo[t][b] : OOB_OFFSET), (int)so, 0);
+                        rbP[st__][u][t][b] = __builtin_bit_cast(f32x4, v_);
+                    }
+            }
+            g_kt += 2;
+        };
+        load_patch(0);
+        issue_bp(std::integral_constant<int, 2>{});
+        store_patch(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int cb = 0; cb < ncb; ++cb) {
+            const f32x4* const P = patch + (P_NBUF == 2 ? (cb & 1) : 0) * P_PATCH;
+            load_patch(cb + 1);
+            auto stage_p = [&](auto ST) {
+                constexpr int st = decltype(ST)::value;
+                constexpr int cur = st == 0 ? 2 : (st & 1), nxt = st == 8 ? 2 : ((st + 1) & 1);
+                issue_bp(std::integral_constant<int, nxt>{});
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int ui = 2 * st + u, h = ui / 9, tap = ui - h * 9;
+                    const int tr = MODE == 0 ? tap / 3 : 2 - tap / 3, ts = MODE == 0 ? tap % 3 : 2 - tap % 3;
+                    bf16x8 af[NSX][MI], bf[NSX][NI];
+#pragma unroll
+                    for (int t = 0; t < NSX; ++t) {
+#pragma unroll
+                        for (int a = 0; a < MI; ++a)
+                            af[t][a] = __builtin_bit_cast(bf16x8, P[(t * 4 + 2 * h) * PPX + a_pix + (2 * a + tr) * PROW + ts]);
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, rbP[cur][u][t][b]);
+                    }
+                    mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
+                }
+            };
+            stage_p(std::integral_constant<int, 0>{});
+            stage_p(std::integral_constant<int, 1>{});
+            stage_p(std::integral_constant<int, 2>{});
+            stage_p(std::integral_constant<int, 3>{});
+            stage_p(std::integral_constant<int, 4>{});
+            stage_p(std::integral_constant<int, 5>{});
+            stage_p(std::integral_constant<int, 6>{});
+            stage_p(std::integral_constant<int, 7>{});
+            stage_p(std::integral_constant<int, 8>{});
+            if (cb + 1 < ncb) {
+                if constexpr (P_NBUF == 1) {  // one buffer: everyone must be done reading it
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                // (two buffers: the other one was last read in block cb - 1, and every wave has passed the barrier that ended it)
+                store_patch(P_NBUF == 2 ? ((cb + 1) & 1) : 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
     load_patch(0);
 #pragma unroll
     for (int s_ = 0; s_ < P_NSTG - 1; ++s_) issue_b(s_);
@@ -611,6 +701,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }
     } else if constexpr (AT != 0) {
     // ---- stored 16-bit operands: LDS-DMA ring ------------------------------------------------------------------------------
     // One 32x32x16 MFMA per accumulator and unit is 32 cycles; a register-staged loop with a prefetch distance of one unit kept the
