@@ -82,7 +82,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // Measured (interleaved A/B on one box, -DDBN_DIRECTB=0 is the staged form): the kernels alone within 1 % either way, the
     // two-stream step +0.6 ... +0.9 % (538.2 / 541.8 against 534.8 / 536.9 images/s) — the smaller footprint co-resides better with
     // the weight-gradient stream's workgroups.
-    constexpr bool DIRECTB = DBN_DIRECTB && NS == 0 && AT == 0 && !PATCH;
+// (also for the bf16 matrix modes on fp32 tensors — fragment = slice lh of plane t of the pre-split panel: bf16x3 739 -> 749 images/s)
+#ifndef DBN_DIRECTB_NS
+#define DBN_DIRECTB_NS 1
+#endif
+    constexpr bool DIRECTB = DBN_DIRECTB && (NS == 0 || DBN_DIRECTB_NS) && AT == 0 && !PATCH;
+    constexpr int NF = NS == 0 ? 2 : NS;  // B fragments (16 bytes each) per accumulator column block and k-tile
     constexpr int UNIT = A_IMG + (DIRECTB ? 0 : B_IMG);
     constexpr int STAGE = KU * UNIT;
     constexpr int NSX = NS > 0 ? NS : 1;
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // weight panel: a lane's piece of a k-tile lies at a fixed offset inside the tile, the tile's offset is wave-uniform and
     // travels as the scalar offset of the buffer load (no per-lane pointer arithmetic in the k-loop)
     unsigned b_voff[B_LD];
-    unsigned bf_voff[2][NI];  // DIRECTB
+    unsigned bf_voff[NF][NI];  // DIRECTB
     int b_lds[B_LD];
     bool b_on[B_LD];
     __amdgpu_buffer_rsrc_t rsrcB;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             b_lds[j] = c * BS + n;
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < NF; ++s2)  // (NS == 0: chunk 2*s2 + lh of the k-tile; NS > 0: slice lh of plane s2)
 #pragma unroll
             for (int b = 0; b < NI; ++b) bf_voff[s2][b] = (unsigned)((2 * s2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
         rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(panel), 0, (unsigned)ktiles * b_step_bytes, 0x00020000);
@@ -387,13 +392,13 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // offsets and re-read the last weight tile): with a conditional issue the compiler merges the "issued" and "not issued"
     // paths and waits vmcnt(0) before staging — i.e. also for the set that was just issued — which defeats the distance of two.
     f32x4 ra_[2][KU][A_LD], rb_[2][KU][B_LD];
-    f32x4 rbf_[2][2][NI];  // DIRECTB: B fragments of the current and the next k-tile
+    f32x4 rbf_[2][NF][NI];  // DIRECTB: B fragments of the current and the next k-tile
     auto issue_b_frag = [&](auto SET) {  // the NEXT weight k-tile (clamped) into fragment set SET
         constexpr int st_ = decltype(SET)::value;
         const unsigned bso = (unsigned)min(b_kt, b_ktmax) * b_step_bytes;
         ++b_kt;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < NF; ++s2)
 #pragma unroll
             for (int b = 0; b < NI; ++b) {
                 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -1051,7 +1056,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                 for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * 2 + lh) * AS + wm * TM + a * 32 + li]);
 #pragma unroll
-                for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+                for (int b = 0; b < NI; ++b) {
+                    if constexpr (DIRECTB) bf[t][b] = __builtin_bit_cast(bf16x8, rbf_[buf][t][b]);
+                    else bf[t][b] = __builtin_bit_cast(bf16x8, Bs[(t * 2 + lh) * BS + wn * TN + b * 32 + li]);
+                }
             }
             mfma_split<NS, MI, NI, AT == 2>(af, bf, acc);
             next_offsets();
