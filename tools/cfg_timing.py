@@ -1,5 +1,6 @@
-"""GPU: wall time per train step of a BASELINE config shape that is not the bench headline (parity cases).
-usage: python tools/cfg_timing.py <backbone> <batch> <size> <math> [steps]"""
+"""GPU: wall time per train step — or, with `eval` as the sixth argument, per inference forward (BASELINE configs[4]: fp16, 32 x 1280^2) —
+of a BASELINE config shape that is not the bench headline (parity cases).
+usage: python tools/cfg_timing.py <backbone> <batch> <size> <math> [steps] [eval]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +10,22 @@ import bench
 arch, n, size, math_ = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 torch.manual_seed(0)
+if len(sys.argv) > 6 and sys.argv[6] == 'eval':
+    m = DBTextModel(arch).cuda().eval()
+    m.engine.set_conv_math(math_)
+    img, _ = bench.synthetic(n, size, 42, torch.device('cuda'))
+    with torch.no_grad():
+        for _ in range(3):
+            out = m(img)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = m(img)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print('%s bs%d %dx%d %s eval: %.2f ms/forward, %.1f images/s, out %s, peak mem %.1f GB' %
+          (arch, n, size, size, math_, dt * 1e3, n / dt, tuple(out.shape), torch.cuda.max_memory_allocated() / 2**30))
+    sys.exit(0)
 m = DBTextModel(arch).cuda().train()
 m.engine.set_conv_math(math_)
 tr = DBTrainer(m, DBLoss(), FusedAdam(m))
