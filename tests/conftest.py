@@ -49,7 +49,7 @@ def pytest_collection_finish(session):
                        out=out, log=out + '.log')
     # ... and it runs to completion BEFORE the first test: two processes time-slicing one GPU perturb more than timing — under
     # that contention a few launches per thousand of otherwise bit-reproducible kernels return different bits (measured round 3:
-    # dbn_head_tail_bwd 15 of 400 calls beside a second training process, 0 of 400 alone), which is what made the bit-identity
+    # dbn_head_tail_bwd 20 of 600 calls beside a second process training in bf16, 0 of 600 alone or beside an f32 one), which is what made the bit-identity
     # tests of this suite flaky while the child was still training.
     try:
         _RCCL_CHILD['proc'].wait(timeout=900)
