@@ -6,8 +6,10 @@ fp32, synthetic data (BASELINE.json `metric`, configs[1]; the path of SURVEY.md 
 
 A step is one iteration of the reference's loop (train.py:160-172): forward, DBLoss,
 backward, [one RCCL all-reduce of the flat gradients when N > 1], Adam — all HIP kernels of
-libdbnet_hip.so.  Inputs are resident in HBM before the timed region.  One process per GPU
-(launched by torch.distributed.run for N > 1); rank 0 prints ONE JSON line.
+libdbnet_hip.so.  Inputs are resident in HBM before the timed region.  One process per GPU: with --gpus N > 1 and no
+torch.distributed.run environment (WORLD_SIZE unset) this script starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` itself as a fresh child process (before anything here touches the GPU), forwards rank 0's ONE JSON line and exits
+with the child's code; fewer than N visible GPUs -> exit code 2.  Launched BY torch.distributed.run it is one of the N ranks.
 
 Extra objects on the JSON line:
   roofline      the dominant kernel (the MFMA kernel — implicit-GEMM conv or weight gradient — with the largest share
@@ -15,11 +17,15 @@ Extra objects on the JSON line:
                 region, vs the MFMA peak of the conv math in use (157.3 TFLOP/s for exact fp32)
   kernels       the same figure for every igemm tile variant, the weight-gradient kernels and the
                 HBM-bound DB-head kernels (instrumented extra step after the timed region)
+  roofline_hbm  the DB-head group (head tail forward / backward, DBLoss forward / backward) against the HBM peak: on the
+                fused kernels' own bytes and on SURVEY section 8d's unfused-algorithmic 84 B/px
   cpu_baseline  the CPU oracle (oracle/dbnet_oracle.py, plain PyTorch fp32) timed on this host
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -131,6 +137,93 @@ class ClockProbe:
                 'how': 's_memtime / s_memrealtime over 200 us, one wave on its own stream at the start of every timed step'}
 
 
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed.run environment: start the N ranks as a FRESH child process (never an exec:
+    this process may not have touched the GPU yet, and must not need to), forward rank 0's JSON line, return the child's code.
+    The reference is single-device (src/train.py:96-98): the whole launcher is this build's."""
+    if args.backend == 'nccl':
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < args.gpus:
+            print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, have), file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), DBN_BENCH_SELF_LAUNCHED='1')
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in res.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    if res.returncode == 0 and not lines:
+        print('bench.py: the %d-rank child printed no JSON line' % args.gpus, file=sys.stderr)
+        return 3
+    return res.returncode
+
+
+def dry_run(args):
+    """--dry: the launch / rendezvous / exchange plumbing of an N-rank run without a GPU (tests/test_host_cpu.py runs it with
+    --backend gloo): every rank joins the process group, sums a flat gradient buffer of the real size with ONE all-reduce per
+    step, rank 0 prints a line with the contract's keys, value null and "dry": true.  Nothing is measured."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    from db_text_minimal_amd.train import allreduce_flat_grads
+    flat = torch.full((12269378, ), float(rank + 1))  # the live gradient elements of ResNet18-FPN-DBHead (49.08 MB)
+    for _ in range(args.steps):
+        flat.fill_(float(rank + 1))
+        scale = allreduce_flat_grads(flat, world)
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    ok = abs(float(flat[0]) * scale - (world + 1) / 2.0) < 1e-6  # mean over the ranks of (rank + 1)
+    if rank == 0:
+        print(json.dumps({'metric': 'train images/sec @640x640 bs=16/GPU', 'value': None, 'unit': 'images/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'dry': True, 'scaling': 'weak',
+                          'config': {'parallelism': 'dp%d' % world, 'global_batch': world * args.batch},
+                          'data_parallel': {'world_seen': seen, 'backend': args.backend, 'allreduce_mean_ok': bool(ok),
+                                            'launched_by': launched_by()}}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 4
+
+
+def launched_by():
+    if os.environ.get('DBN_BENCH_SELF_LAUNCHED') == '1':
+        return 'bench.py --gpus N (self-launched torch.distributed.run child)'
+    return 'torch.distributed.run (external)' if 'WORLD_SIZE' in os.environ else 'single process'
+
+
+def hbm_group(summ, px, steps):
+    """The DB-head group of BASELINE's metric ("DB-head GB/s vs HBM peak"): head tail forward / backward (+ its fold launches),
+    DBLoss forward (+ finalize) / backward, from a KernelTimer summary over `steps` instrumented steps.  `achieved` is on the
+    bytes these FUSED kernels move (the head tail also applies BatchNorm + ReLU to both 64-channel ConvT outputs and evaluates
+    the last ConvT: 2 x 64 channels per quarter-resolution pixel on top of the maps); `achieved_unfused` is on SURVEY 8d's
+    unfused-algorithmic 84 B per full-resolution pixel (20 epilogue fwd + 28 loss fwd + 36 loss/epilogue bwd; reference
+    segmentation_head.py:106-108, losses.py:18-40,62-64,77-78) so that the figure stays comparable across fusion choices."""
+    labels = [k for k in summ if k.startswith(('head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))]
+    if len(labels) < 4:
+        return None
+    ms = sum(summ[k]['ms'] for k in labels) / steps
+    own = sum(summ[k]['bytes'] for k in labels) / steps
+    unfused = 84.0 * px
+    a, u = own / (ms * 1e-3) / 1e9, unfused / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernels': sorted(labels), 'ms_per_step': round(ms, 4), 'achieved': round(a, 1), 'peak': PEAK_HBM_GBS,
+            'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4), 'bytes_per_step': round(own),
+            'achieved_unfused': round(u, 1), 'frac_unfused': round(u / PEAK_HBM_GBS, 4), 'bytes_per_step_unfused': round(unfused),
+            'per_kernel': {k: {'ms': round(summ[k]['ms'] / steps, 4), 'GBps': round(summ[k]['bytes'] / (summ[k]['ms'] * 1e-3) / 1e9, 1),
+                               'frac': round(summ[k]['bytes'] / (summ[k]['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for k in sorted(labels)}}
+
+
 def main():
     import warnings
     warnings.filterwarnings('ignore', message=r'.*barrier\(\).*')  # keep rank 0's stdout/stderr to the one JSON line
@@ -156,14 +249,23 @@ def main():
     ap.add_argument('--serial-steps', type=int, default=3, help='instrumented single-stream steps for the kernels[] table (median)')
     ap.add_argument('--no-alt-modes', action='store_true',
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (nccl = RCCL; gloo only with --dry)')
+    ap.add_argument('--dry', action='store_true', help='launch / rendezvous / exchange plumbing only, no GPU work (CPU test of --gpus N)')
     args = ap.parse_args()
+    if args.backend != 'nccl' and not args.dry:
+        raise SystemExit('--backend gloo is for --dry runs: the step itself has no CPU path')
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:  # nothing has touched the GPU yet
+        raise SystemExit(self_launch(args))
+    if args.dry:
+        raise SystemExit(dry_run(args))
 
     from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
     from db_text_minimal_amd.engine import KernelTimer
     from db_text_minimal_amd.train import init_distributed
 
     rank, local, world = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # (--gpus N > 1 without WORLD_SIZE was self-launched above: a mismatch here is a wrong external launch)
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
@@ -187,7 +289,8 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel'))
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
+                                'head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
     clock = ClockProbe(dev, args.steps)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -198,7 +301,7 @@ def main():
         step_ev[it].record()
         clock.sample()
         eng.prof = timer if it % TIMED_EVERY == 0 else None
-        preds, losses = trainer.step(img, gts)
+        preds, losses = trainer.step(img, gts, resident=True)  # (the same resident tensors every step: --graph skips its input copy)
     step_ev[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
@@ -218,12 +321,12 @@ def main():
         v = sorted(a.elapsed_time(b) for a, b in events)
         return round(v[len(v) // 2], 4) if v else None
 
-    dp_diag = None
+    dp_diag = {'world_seen': dist.get_world_size() if dist.is_initialized() else 1, 'launched_by': launched_by()}
     if world > 1:
         form = 'bucketed' if trainer.overlap_allreduce else 'single'
-        dp_diag = {'form': form, 'allreduce_exposed_ms': exposed_ms(trainer.exchange_events),
+        dp_diag.update({'form': form, 'allreduce_exposed_ms': exposed_ms(trainer.exchange_events),
                    'how': 'HIP events on the main stream after the last backward kernel was enqueued and after the exchange was '
-                          'joined: the time the step waits for the collective(s); median over the timed steps'}
+                          'joined: the time the step waits for the collective(s); median over the timed steps'})
         # the other form, same number of steps, same bracket
         trainer.overlap_allreduce = not trainer.overlap_allreduce
         trainer.exchange_events = []
@@ -281,15 +384,23 @@ def main():
                          'weight-gradient stream, so their durations (here and in the rocprofv3 trace of this command) include that '
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
 
-    # HBM traffic of that kernel from the committed PMC passes (profiles/, tools/pmc_traffic.py), per launch
-    for tag in ('r03', 'r02', 'r01'):  # newest committed PMC summary that knows this kernel (tools/profile_round.sh)
+    # HBM traffic of that kernel: the PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass, separate
+    # for FETCH_SIZE and WRITE_SIZE: tools/profile_round.sh), so the figure comes from the newest committed pass — and ONLY while
+    # it still describes these kernels: the summary records the sha256 of csrc/ it was taken on (tools/pmc_traffic.py); when the
+    # sources have changed since, or the kernel is not in it, the line says `traffic: null, traffic_stale: true` instead.
+    from db_text_minimal_amd._lib import source_stamp
+    roofline['traffic_stale'] = True
+    for tag in ('r04', 'r03'):
         try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))['kernels'].get(dname)
-        except (OSError, ValueError, KeyError):
-            tr = None
-        if tr:
+            prof = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))
+        except (OSError, ValueError):
+            continue
+        tr = prof.get('kernels', {}).get(dname)
+        if tr and prof.get('csrc_stamp') == source_stamp():
             roofline['traffic'] = tr['hbm_bytes_per_launch']
-            roofline['traffic_unit'] = ('bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, profiles/%s_pmc_traffic.json)' % tag)
+            roofline['traffic_stale'] = False
+            roofline['traffic_unit'] = ('bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC passes of this source tree: '
+                                        'profiles/%s_pmc_traffic.json, csrc stamp %s)' % (tag, prof['csrc_stamp']))
             break
 
     kernels = []
@@ -370,6 +481,9 @@ def main():
             'data_parallel': dp_diag,
             'roofline': roofline,
             'roofline_serial': roofline_serial,
+            # BASELINE metric, second half ("DB-head GB/s vs HBM peak"): in the timed region / with the streams serialised
+            'roofline_hbm': hbm_group(summ, args.batch * args.size * args.size, timed_steps),
+            'roofline_hbm_serial': hbm_group(serial_summ, args.batch * args.size * args.size, 1),
             # whole-step rates: on the dense convolution count of SURVEY §8d (an EFFECTIVE rate: the structured FPN kernels
             # skip ~0.77 TFLOP/step of it) and on the FLOPs the MFMA kernels actually execute (sum over the instrumented step)
             'step_tflops': round(TRAIN_GFLOP_PER_IMAGE * (args.size / 640.0)**2 * args.batch / ms, 2),

@@ -143,6 +143,19 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def source_stamp():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, sorted by name): recorded beside profile summaries
+    (tools/pmc_traffic.py) so that bench.py can tell whether a committed per-kernel figure still describes these kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith(('.hip', '.h')) or name == 'Makefile':
+            h.update(name.encode())
+            with open(os.path.join(CSRC, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -1082,7 +1082,9 @@ class Engine:
         self.conv_wgrad('backbone.conv1', dy0, B['x4w' if self.at != 0 else 'x4'], bb.conv1)
         self.join_side()
         self.saved_generation = -1
+        self.backwards_since_clear += 1  # FusedAdam.step refuses gradients that a second backward pass overwrote
 
+    backwards_since_clear = 0
     fpn_structured = True  # FPN output conv per upsample level (forward and backward) instead of over the concat
     fpn_one_launch = True  # forward: the four levels in one launch (dbn_pyramid_conv_f32) instead of four accumulating ones
     fpn_exact = False  # set by forward(): the levels are exact 1, 1/2, 1/4, 1/8 sizes, so the structured path applies

@@ -27,12 +27,14 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         """Every backward pass OVERWRITES the engine's flat gradient buffer completely, so there is nothing to clear there —
-        and no accumulation either: `step()` consumes the gradients of the LAST backward only (gradient accumulation over
-        several backward passes and in-place edits of `p.grad` such as clip_grad_norm_ are not supported by the fused path;
-        use torch.optim.Adam over `model.parameters()` for those).  On the autograd surface the parameters' `.grad` views are
-        dropped here so they do not keep accumulating across iterations."""
+        and no accumulation either: `step()` consumes the gradients of ONE backward pass.  Gradient accumulation (a second
+        backward pass without a zero_grad() / step() in between, which torch.optim.Adam would sum) is refused by step() with a
+        RuntimeError instead of silently dropping the first pass; use torch.optim.Adam over `model.parameters()` for that.
+        On the autograd surface the parameters' `.grad` views are dropped here so they do not keep accumulating across
+        iterations."""
         for _, p in self.engine.live_params:
             p.grad = None
+        self.engine.backwards_since_clear = 0
         return None
 
     def _ensure_state(self):
@@ -49,6 +51,11 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError('closures are not supported')
         self._ensure_state()
         eng = self.engine
+        if eng.backwards_since_clear > 1:
+            raise RuntimeError('FusedAdam.step(): %d backward passes ran since the last zero_grad()/step(); the flat gradient buffer '
+                               'holds only the last one (no gradient accumulation on the fused path — use torch.optim.Adam over '
+                               'model.parameters())' % eng.backwards_since_clear)
+        eng.backwards_since_clear = 0
         g = self.param_groups[0]
         self.step_count += 1
         check(_lib.lib().dbn_adam_step(eng.flat.data_ptr(), eng.flat_grad.data_ptr(), self.exp_avg.data_ptr(),

@@ -210,9 +210,12 @@ class DBTrainer:
             eng.prof.end()
         return losses, dpreds
 
-    def step(self, img, gts):
+    def step(self, img, gts=None, resident=False):
         """One training iteration.  img [N,3,H,W], gts [4,N,H,W] (or the reference's batch dict
-        as `img`, with gts=None).  Returns (preds, losses[5]) as device tensors; no host sync."""
+        as `img`, with gts=None).  Returns (preds, losses[5]) as device tensors; no host sync.
+        `resident=True` (hipGraph step only) is the caller's promise that `img` / `gts` are the very tensors of the previous
+        call, unmodified (bench.py's synthetic batch): the copy into the graph's static inputs is skipped.  Nothing is
+        inferred from object identity — a new batch is always copied."""
         if isinstance(img, dict):
             batch = img
             img, gts = batch['img'], stack_gts(batch)
@@ -224,7 +227,7 @@ class DBTrainer:
             self._warm_arena_then_sync(img, gts)
         distributed = dist.is_available() and dist.is_initialized()
         if self.use_graph and eng.prof is None and not (distributed and self.overlap_allreduce):
-            got = self._graph_step(img, gts)
+            got = self._graph_step(img, gts, resident)
             if got is not None:
                 preds, losses = got
                 self.optimizer.zero_grad()
@@ -256,11 +259,14 @@ class DBTrainer:
         self.optimizer.step(grad_scale=scale)
         return preds, losses
 
-    def _graph_step(self, img, gts):
+    def _graph_step(self, img, gts, resident=False):
         """forward + loss + backward through a captured hipGraph; None while still warming up (the caller takes the eager path).
-        The graph reads the batch from its own static buffers: a new batch is copied in first (183 MB at bs16 640^2, ~0.1 ms);
-        the same unmodified tensors handed over again (bench.py's resident synthetic batch) are not copied twice.  The
-        returned preds / losses are the graph's static output tensors: they are overwritten by the next step."""
+        The graph reads the batch from its own static buffers: every batch is copied in first (183 MB at bs16 640^2, ~0.1 ms)
+        unless the caller declares it `resident` (see step()).  Round 3 inferred "same batch" from (id, _version, data_ptr) of the
+        arguments: a freed temporary's object slot and allocator block are reused by the next batch's tensor, so that key
+        collided and the graph replayed on the PREVIOUS batch (advisor finding) — identity is no longer consulted.
+        `preds` is the graph's static output tensor (overwritten by the next step, like the engine's arena in the eager step);
+        the five losses are returned as a fresh 5-float copy, so a caller may keep summing them across steps (fit())."""
         eng = self.model.engine
         img = img.contiguous().float()
         key = (tuple(img.shape), tuple(gts.shape), eng.math_mode, eng.overlap_wgrad, eng.fuse_bn_bwd_sums)
@@ -285,18 +291,17 @@ class DBTrainer:
             G['nbt_delta'] = {k: v - nbt0.get(k, 0) for k, v in eng.nbt_pending.items() if v != nbt0.get(k, 0)}
             eng.nbt_pending, eng.generation = nbt0, gen0
             G['graph'], G['preds'], G['losses'] = g, preds, losses
-        # a resident batch (the same tensor objects, unmodified since the last step — bench.py's synthetic batch) is not copied again
-        src = (id(img), img._version, img.data_ptr(), id(gts), gts._version, gts.data_ptr())
-        if src != G['src']:
+        if not (resident and G['src']):
             G['img'].copy_(img)
             G['gts'].copy_(gts)
-            G['src'] = src
+            G['src'] = True
         G['graph'].replay()
         eng.generation += 1
         for k, v in G['nbt_delta'].items():
             eng.nbt_pending[k] = eng.nbt_pending.get(k, 0) + v
         eng.saved_generation = -1  # (the graph contains the backward pass: the saved activations are consumed)
-        return G['preds'], G['losses']
+        eng.backwards_since_clear += 1
+        return G['preds'], G['losses'].clone()
 
     def _exchange_event(self, start=None):
         """HIP events on the main stream before / after the gradient exchange (when `exchange_events` is a list): the elapsed
@@ -424,7 +429,7 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
                 scheduler.step()
             if running is not None:
                 running.update_device(preds[:, 0, :, :], batch['prob_map'], batch['supervision_mask'], thresh)
-            train_sum = losses[4] if train_sum is None else train_sum + losses[4]  # device-side sums: no per-step host sync
+            train_sum = losses[4].clone() if train_sum is None else train_sum + losses[4]  # device-side sums: no per-step host sync
         score = running.get_scores()[0] if (train_sum is not None and running is not None) else {}
         train_loss = float(train_sum) if train_sum is not None else float('nan')
         test_loss, test_score = float('nan'), {}

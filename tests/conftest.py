@@ -30,6 +30,8 @@ def pytest_collection_finish(session):
     torch.distributed.run.  A process that has already initialised the GPU must not exec another program on this pool, so
     the child is started here — after collection (only when that test is among the selected items) and before any test of
     this session has touched the GPU — and the test only collects its verdict."""
+    if session.config.option.collectonly:  # listing tests must not start a GPU training process
+        return
     if not any(item.fspath.basename == 'test_rccl_gpu.py' for item in session.items):
         return
     try:
@@ -38,6 +40,9 @@ def pytest_collection_finish(session):
             return
     except Exception:
         return
+    # the invariant this hook relies on, checked instead of assumed: importing the test modules (collection) made no GPU call
+    assert not torch.cuda.is_initialized(), ('a test module initialised the GPU at import time: the RCCL child must be started '
+                                             'from a process that has not touched the GPU (tests/conftest.py)')
     out = os.path.join(tempfile.mkdtemp(prefix='dbn_rccl_'), 'verdict.json')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     env.pop('DBN_FORCE_DIST', None)
@@ -54,14 +59,13 @@ def pytest_collection_finish(session):
     try:
         _RCCL_CHILD['proc'].wait(timeout=900)
     except subprocess.TimeoutExpired:
-        pass
+        # a child that is still training would run BESIDE the tests (exactly the co-tenancy described above): end its process
+        # group now and let the RCCL test report the timeout as a failure
+        _kill_child(_RCCL_CHILD['proc'])
+        _RCCL_CHILD['timed_out'] = True
 
 
-def pytest_sessionfinish(session, exitstatus):
-    """Do not leave the child behind (-x, Ctrl-C, or a session that never reached the RCCL test)."""
-    proc = _RCCL_CHILD.get('proc')
-    if proc is None or proc.poll() is not None:
-        return
+def _kill_child(proc):
     import signal
     try:
         os.killpg(proc.pid, signal.SIGTERM)  # exactly the process group started above
@@ -72,6 +76,14 @@ def pytest_sessionfinish(session, exitstatus):
             proc.wait(timeout=10)
         except Exception:
             pass
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Do not leave the child behind (-x, Ctrl-C, or a session that never reached the RCCL test)."""
+    proc = _RCCL_CHILD.get('proc')
+    if proc is None or proc.poll() is not None:
+        return
+    _kill_child(proc)
 
 
 @pytest.fixture(scope='session')

@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -151,3 +152,38 @@ def test_kernel_selection_logic_without_gpu():
         assert cfg(1, 1, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 == 0
     finally:
         L.dbn_set_patch_conv(1)
+
+
+def _run_bench(*argv, env_drop=('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus N` with no torch.distributed.run environment (how the driver may invoke it) must produce an N-rank
+    run or fail — round 3 silently ran one rank and printed n_gpus: 1.  The dry run (no GPU work, gloo) exercises exactly the
+    self-launch: a fresh `torch.distributed.run --nproc-per-node 2` child, the rendezvous on 127.0.0.1, ONE all-reduce of a
+    49 MB flat buffer per step through train.allreduce_flat_grads, rank 0's single JSON line forwarded with the child's code."""
+    import json
+    r = _run_bench('--gpus', '2', '--steps', '2', '--warmup', '0', '--dry', '--backend', 'gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line on stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['config']['global_batch'] == 32
+    dp = line['data_parallel']
+    assert dp['world_seen'] == 2 and dp['allreduce_mean_ok'] and 'self-launched' in dp['launched_by']
+
+
+def test_bench_refuses_more_gpus_than_visible_and_wrong_world_size():
+    """No silent fallback to fewer ranks: this container has no GPU, so --gpus 2 (RCCL) must exit with code 2 before anything is
+    launched; an external launch whose WORLD_SIZE disagrees with --gpus must fail as well."""
+    r = _run_bench('--gpus', '2', '--steps', '1', '--warmup', '0')
+    assert r.returncode == 2 and 'GPU(s) visible' in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not r.stdout.strip()
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry', '--backend', 'gloo'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)

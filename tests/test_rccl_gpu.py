@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 def test_nccl_step_is_bit_identical_to_the_single_process_step(rccl_child):
     if not rccl_child:
         pytest.skip('the RCCL child process was not started (tests/conftest.py: needs a visible GPU)')
+    assert not rccl_child.get('timed_out'), ('the RCCL child did not finish within 900 s and was terminated (tests/conftest.py):\n'
+                                             + open(rccl_child['log']).read()[-3000:])
     rc = rccl_child['proc'].wait(timeout=800)
     log = open(rccl_child['log']).read()[-3000:]
     assert rc == 0, 'torch.distributed.run failed (rc %d):\n%s' % (rc, log)

@@ -4,7 +4,9 @@ gfx950).  Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM
 and FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced reads on gfx950 -> x2
 (confirmed here on head_tail_fwd_kernel: 2 x 409 684 KiB = 839 MB = its 838.9 MB of input).
 usage: pmc_traffic.py fetch.db write.db out.json"""
-import json, sqlite3, sys
+import json, os, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from db_text_minimal_amd._lib import source_stamp  # (hashes csrc/: no GPU, no library load)
 
 def load(db, counter):
     c = sqlite3.connect(db)
@@ -21,6 +23,7 @@ for k in sorted(set(f) & set(w)):
     rd, wr = 2.0 * f[k][0] * 1024, w[k][0] * 1024
     res[name] = {'launches_sampled': f[k][1], 'hbm_read_bytes_per_launch': round(rd), 'hbm_write_bytes_per_launch': round(wr),
                  'hbm_bytes_per_launch': round(rd + wr)}
-json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1',
+json.dump({'csrc_stamp': source_stamp(),  # bench.py quotes these figures only while csrc/ still hashes to this
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1',
            'corrections': 'KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read under-count)', 'kernels': res}, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(res, indent=1)[:1500])
