@@ -49,6 +49,32 @@ WGRAD_TILE_NAMES = {1: 'wgrad_f32_kernel<64,192,2,2,%d,%d,%d>', 2: 'wgrad_f32_ke
 ACT_DTYPES = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
 
 
+# Debug aid (tests/test_model_gpu.py::test_results_do_not_depend_on_uninitialised_memory): what every buffer the engine allocates
+# holds BEFORE its first kernel writes it.  '' = whatever the allocator returns (default); 'nan' = NaN / 0xFF bytes; 'rand' =
+# finite noise that differs per allocation.  A path that never reads memory it has not written gives the same bits in all three;
+# a stale-memory read shows up as a difference (or a NaN) instead of as a once-in-a-while run-to-run mismatch.
+POISON = os.environ.get('DBN_POISON', '')
+_poison_count = [0]
+
+
+def device_empty(shape, device, dtype=torch.float32):
+    t = torch.empty(shape, device=device, dtype=dtype)
+    if POISON and t.numel():
+        if POISON == 'nan':
+            t.view(torch.uint8).fill_(0xFF) if not t.is_floating_point() else t.fill_(float('nan'))
+        elif POISON == 'rand':
+            _poison_count[0] += 1
+            g = torch.Generator(device=t.device).manual_seed(1000 + _poison_count[0])
+            if t.is_floating_point():
+                t.copy_((torch.rand(t.shape, device=t.device, generator=g) * 2000.0 - 1000.0).to(t.dtype))
+            else:
+                t.view(torch.uint8).copy_(torch.randint(0, 255, (t.numel() * t.element_size(), ), device=t.device, generator=g,
+                                                        dtype=torch.uint8).view(t.view(torch.uint8).shape))
+        else:
+            raise ValueError('DBN_POISON: nan | rand')
+    return t
+
+
 class KernelTimer:
     """HIP-event bracket around selected launches (events are recorded on the stream the
     kernels are launched on).  `labels`: None = time everything, else a tuple of label prefixes."""
@@ -220,7 +246,7 @@ class Engine:
         t = self.bufs.get(name)
         dev = self.flat.device
         if t is None or tuple(t.shape) != tuple(shape) or t.device != dev or t.dtype != dtype:
-            t = torch.empty(shape, device=dev, dtype=dtype)
+            t = device_empty(shape, dev, dtype)
             self.bufs[name] = t
             self._by_ptr[t.data_ptr()] = t
         return t
@@ -234,7 +260,7 @@ class Engine:
             name += '#side'
         t = self.bufs.get(name)
         if t is None or t.numel() < numel or t.device != self.flat.device:
-            t = torch.empty(int(numel), device=self.flat.device, dtype=torch.float32)
+            t = device_empty(int(numel), self.flat.device)
             self.bufs[name] = t
         return t
 
@@ -292,7 +318,7 @@ class Engine:
         if version is None:  # a parameter (not a derived tensor): remembered for the one-launch repack of later steps
             self.pack_src[key] = (w, cs if cs else (I + 3) // 4 * 4)
         n = self.L.dbn_igemm_panel_floats_t(ns, O, I, R, S, mode, stride, cs)
-        out = ent[0] if ent is not None else torch.empty(n, device=w.device, dtype=torch.float32)
+        out = ent[0] if ent is not None else device_empty(n, w.device)
         check(self.L.dbn_pack_weights_t(ns, w.data_ptr(), O, I, R, S, mode, stride, cs, out.data_ptr(), self.stream), 'pack_weights')
         self.packs[key] = (out, stamp)
         return out
@@ -814,7 +840,7 @@ class Engine:
         (yb_, sb_, hb_), (yt_, st_, ht_) = z1['binarize'], z1['thresh']
         Hh, Wh = yb_.shape[1], yb_.shape[2]
         resample = (2 * Hh, 2 * Wh) != (H, W)  # only when H or W is not a multiple of 32 (models.py:43-46)
-        out = torch.empty((N, ch, H, W), device=x.device, dtype=torch.float32)
+        out = device_empty((N, ch, H, W), x.device)
         head_out = self.fbuf('head/out', N, ch, 2 * Hh, 2 * Wh) if resample else out
         b6, t6 = head.binarize[6], head.thresh[6]
         if self.prof:  # reads 2 x 64ch at half resolution, writes `ch` full-resolution maps
@@ -854,7 +880,7 @@ class Engine:
         stamp = (w._version, self.param_epoch, w.data_ptr())
         ent = self.packs.get((name, 'ohwi'))
         if ent is None or ent[1] != stamp:
-            wp = ent[0] if ent is not None else torch.empty(conv.cout, conv.k * conv.k * conv.cin, 1, 1, device=w.device)
+            wp = ent[0] if ent is not None else device_empty((conv.cout, conv.k * conv.k * conv.cin, 1, 1), w.device)
             check(self.L.dbn_permute_weight(w.data_ptr(), wp.data_ptr(), conv.cout, conv.cin, conv.k * conv.k, 1, 1.0, self.stream),
                   'permute_weight')
             self.packs[(name, 'ohwi')] = (wp, stamp)
@@ -1096,7 +1122,7 @@ class Engine:
         stamp = (w._version, self.param_epoch, w.data_ptr())
         ent = self.packs.get((name, 'combined'))
         if ent is None or ent[1] != stamp:
-            wds = ent[0] if ent is not None else [torch.empty(Cg, Co, (1 << g) + 2, (1 << g) + 2, device=w.device) for g in range(4)]
+            wds = ent[0] if ent is not None else [device_empty((Cg, Co, (1 << g) + 2, (1 << g) + 2), w.device) for g in range(4)]
             for g in range(4):
                 check(self.L.dbn_fpn_combine_weights(w.data_ptr(), Co, w.shape[1], g, Cg, wds[g].data_ptr(), self.stream),
                       'fpn_combine_weights')

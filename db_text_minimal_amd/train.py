@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import engine as engine_mod
 from ._lib import check
 from .optim import FusedAdam
 
@@ -188,8 +189,8 @@ class DBTrainer:
             self._ws = None
         need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if per_pixel else L.dbn_db_loss_ws_bytes()) // 4 + 1
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, device=dev)
-        losses = torch.empty(5, device=dev)
+            self._ws = engine_mod.device_empty(need, dev)
+        losses = engine_mod.device_empty(5, dev)
         fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
         eng = self.model.engine
         if eng.prof:  # reads the 3 maps and the 4 targets once

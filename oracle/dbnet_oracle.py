@@ -206,8 +206,9 @@ def synthetic_batch(n, size, seed=0, img_scale=1.0):
     """Inputs of SURVEY.md §8c(2): img ~ N(0,1)·scale; binary masks like the real
     loader (data_loaders.py:158-165); gts stacked in train.py:163-166 order."""
     g = torch.Generator().manual_seed(seed)
-    img = torch.randn(n, 3, size, size, generator=g) * img_scale
-    u = torch.rand(4, n, size, size, generator=g)
+    h, w = (size, size) if isinstance(size, int) else size  # (h, w): the inference CLIs resize without padding (utils.py:160-175)
+    img = torch.randn(n, 3, h, w, generator=g) * img_scale
+    u = torch.rand(4, n, h, w, generator=g)
     prob_gt = (u[0] > 0.9).float()
     sup_mask = (u[1] > 0.05).float()
     thresh_gt = 0.3 + 0.4 * u[2]

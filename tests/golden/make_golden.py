@@ -160,6 +160,37 @@ def case_fp64(name, n, size, seed, arch='resnet18', bn3_gain=None):
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
+def case_odd(name, n, h, w, seed):
+    """A size that is NOT a multiple of 32: the FPN's size-based nearest upsampling (segmentation_body.py:64-76) and the final
+    F.interpolate(bilinear, align_corners=True) of models.py:43-46 are real resamples (the inference CLIs resize without padding,
+    utils.py:160-175).  The reference's eval forward (+ DBLoss single value) and one train step: full maps, losses, gradients,
+    running statistics."""
+    print('==', name)
+    img, gts = O.synthetic_batch(n, (h, w), seed=seed + 100)
+    out = {'meta': np.array([n, h, w, seed])}
+    m = make_ref(seed).eval()
+    with torch.no_grad():
+        pe = m(img)
+        assert pe.shape == (n, 2, h, w)
+        out['eval_preds'] = pe.numpy()
+        out['eval_loss'] = np.array(float(DBLoss()(pe, gts)))
+    m = make_ref(seed).train()
+    preds = m(img)
+    assert preds.shape == (n, 3, h, w)
+    losses = DBLoss()(preds, gts)
+    losses[4].backward()
+    out['preds'] = preds.detach().numpy()
+    out['losses'] = np.array([float(v) for v in losses])
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            summarize('grad/' + k, p.grad, out)
+    for k, v in m.state_dict().items():
+        if 'running' in k:
+            summarize('post/' + k, v, out, full_below=600)
+    print('  losses', out['losses'], 'eval loss', out['eval_loss'])
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
 def case_eval(name, n, size, seed):
     print('==', name)
     m = make_ref(seed).eval()
@@ -303,6 +334,9 @@ if __name__ == '__main__':
     if '--only-kats' in sys.argv:
         case_loss_kats()
         sys.exit(0)
+    if '--only-odd' in sys.argv:
+        case_odd('odd_1x96x70', 1, 96, 70, seed=8)
+        sys.exit(0)
     if '--only-fp64' in sys.argv:
         case_fp64('fp64_2x128', 2, 128, seed=2)
         case_fp64('fp64_r50_2x96', 2, 96, seed=12, arch='resnet50')
@@ -322,6 +356,7 @@ if __name__ == '__main__':
     case_train('train_2x128', 2, 128, seed=2, steps=3)
     case_train('train_2x96_scaled', 2, 96, seed=4, img_scale=60.0, steps=1)
     case_eval('eval_2x128', 2, 128, seed=2)
+    case_odd('odd_1x96x70', 1, 96, 70, seed=8)
     case_dp('dp_2x1x128', 128, seed=6)
     check_oracle('resnet50')
     case_train('r50_train_1x128', 1, 128, seed=11, steps=2, arch='resnet50')

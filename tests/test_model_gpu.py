@@ -227,7 +227,7 @@ _DEAD_BIAS = ('conv.bias', '.0.bias', '.3.bias')
 # (golden, backbone, precision mode): the reference's own distance from fp64 at that precision is the yardstick
 _FP64_CASES = [('fp64_2x128', 'resnet18', 'f32'), ('fp64_r50_2x96', 'resnet50', 'f32'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'f32'),
                ('fp64_2x128', 'resnet18', 'bf16x3'), ('fp64_2x128', 'resnet18', 'bf16'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'bf16'),
-               ('fp64_r50_2x96', 'resnet50', 'bf16')]
+               ('fp64_r50_2x96', 'resnet50', 'bf16'), ('fp64_2x128', 'resnet18', 'bf16c')]
 
 
 @pytest.mark.parametrize('case,arch,math', _FP64_CASES)
@@ -257,7 +257,7 @@ def test_distance_to_fp64_is_within_the_references_own(golden_dir, case, arch, m
                 sd[k] = sd[k] * gain
     _, l64, g64 = O.loss_and_grads(O.to_dtype(sd, torch.float64), img.double(), gts.double())
     assert np.allclose(l64, z['losses_f64'], rtol=1e-10)
-    bf16 = math == 'bf16'
+    bf16 = math in ('bf16', 'bf16c')  # (bf16c: fp32 tensors, operands rounded to bf16 when staged — same yardstick)
     ref_tag, dist_tag = ('bf16ac', 'refbf16_dist/') if bf16 else ('f32', 'ref32_dist/')
     f_t, f_m = (2.0, 1.5) if bf16 else (1.5, 1.2)
     model = make_model(seed, arch)
@@ -386,39 +386,35 @@ def test_full_size_bs16_properties():
     assert float(losses[4]) < l0, 'loss did not decrease over 4 Adam steps on a fixed batch'
 
 
-@pytest.mark.parametrize('math,map_tol,loss_tol,cos_min', [('bf16x3', (1e-3, 1e-2), 1e-5, 0.999), ('bf16c', (6e-2, 6e-2), 3e-2, 0.75),
-                                                           ('bf16', (8e-2, 8e-2), 4e-2, 0.70)])
-def test_split_bf16_conv_math_modes(math, map_tol, loss_tol, cos_min):
-    """Reduced-precision modes of the path (engine.set_conv_math).  'bf16x3' (three-way exact operand split, fp32 accumulate)
-    must meet the SAME north_star tolerance as the native fp32 path.  'bf16' is the NATIVE bf16 mode of BASELINE
-    configs[2]/[3]: activations, gradients and weight panels stored in bf16 in HBM, fp32 accumulators / BatchNorm statistics /
-    loss sums / master weights; 'bf16c' is the compute-only variant (fp32 tensors, operands rounded when staged).  Their
-    stated bounds: 6e-2 (8e-2 with bf16 storage) abs on P,T (B = sigmoid(50(P-T)) is not compared per pixel: the k = 50
-    step amplifies a 2^-9 relative error of P-T by 12.5), 3 % (4 %) on the losses, gradient cosine >= 0.75 (0.70)
-    (bf16 noise flips many ReLU masks and the step function concentrates the gradient on few pixels)."""
+def test_split_bf16_conv_math_modes():
+    """'bf16x3' (three-way exact operand split on the bf16 matrix pipe, fp32 accumulate) must meet the SAME north_star tolerance
+    as the exact-fp32 path (1e-3 abs / 1e-2 rel on all three maps, losses 1e-5, gradient cosine >= 0.999 against the oracle).
+    The 16-bit modes ('bf16', 'bf16c') are NOT judged by absolute bounds any more (round 3 had cosine >= 0.70 / maps 8e-2 here,
+    which only hid regressions): test_distance_to_fp64_is_within_the_references_own holds them to the reference's own distance
+    from fp64 under bf16 autocast, per tensor; here only the storage contract of the native mode is checked."""
     seed, n, size = 11, 2, 128
     img, gts = O.synthetic_batch(n, size, seed=seed)
     sd = O.new_state(seed)
     model = make_model(seed).train()
-    model.engine.set_conv_math(math)
+    model.engine.set_conv_math('bf16x3')
     tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = tr.step(img.to(DEV), gts.to(DEV))
     assert preds.dtype == torch.float32
-    if math == 'bf16':
-        assert model.engine.bufs['fpn/z'].dtype == torch.bfloat16 and model.engine.bufs['backbone.layer1.0/dy1'].dtype == torch.bfloat16
-        assert model.engine.flat.dtype == torch.float32 and model.engine.flat_grad.dtype == torch.float32
     preds_o, losses_o, grads_o = O.loss_and_grads(sd, img, gts)
-    chans = 3 if math == 'bf16x3' else 2
-    report(math + ' maps', preds[:, :chans].cpu(), preds_o[:, :chans], *map_tol)
-    report(math + ' losses', losses.cpu().double(), torch.tensor(losses_o).double(), loss_tol, loss_tol if math != 'bf16x3' else 1e-5)
-    worst = 1.0
+    report('bf16x3 maps', preds.cpu(), preds_o, 1e-3, 1e-2)
+    report('bf16x3 losses', losses.cpu().double(), torch.tensor(losses_o).double(), 1e-5, 1e-5)
     for k in ('backbone.conv1.weight', 'backbone.layer2.0.conv1.weight', 'segmentation_body.conv.0.weight',
               'segmentation_head.binarize.3.weight', 'segmentation_head.thresh.0.weight', 'backbone.layer4.1.bn2.weight'):
         a, b = model.engine.grad_views[k].cpu().double().flatten(), grads_o[k].double().flatten()
         cos = float(a @ b / (a.norm() * b.norm()))
-        print('%s grad %s: cos %.6f, |g| ratio %.5f' % (math, k, cos, float(a.norm() / b.norm())))
-        worst = min(worst, cos)
-    assert worst >= cos_min, worst
+        print('bf16x3 grad %s: cos %.6f, |g| ratio %.5f' % (k, cos, float(a.norm() / b.norm())))
+        assert cos >= 0.999, (k, cos)
+    m2 = make_model(seed).train()
+    m2.engine.set_conv_math('bf16')  # native storage: 16-bit activations and gradients, fp32 maps / parameters / gradients of parameters
+    p2, _ = DBTrainer(m2, DBLoss(), FusedAdam(m2, lr=0.005)).step(img.to(DEV), gts.to(DEV))
+    assert p2.dtype == torch.float32
+    assert m2.engine.bufs['fpn/z'].dtype == torch.bfloat16 and m2.engine.bufs['backbone.layer1.0/dy1'].dtype == torch.bfloat16
+    assert m2.engine.flat.dtype == torch.float32 and m2.engine.flat_grad.dtype == torch.float32
 
 
 def test_native_bf16_training_and_fp16_inference_full_size():
@@ -483,30 +479,43 @@ def test_native_bf16_training_and_fp16_inference_full_size():
 
 
 def test_cfg5_inference_1280_bs32_vs_oracle():
-    """BASELINE configs[4] shape: eval-mode forward at 32x3x1280x1280, in fp32 and on the native fp16 inference path.  In eval mode images are independent (running-stat BN), so two of the 32 images are
-    checked per pixel against the CPU oracle; the prob map goes to the host exactly as postprocess.py consumes it."""
+    """BASELINE configs[4] shape: eval-mode forward at 32x3x1280x1280, in fp32 and on the native fp16 inference path.  In eval mode
+    images are independent (running-stat BN), so two of the 32 images are checked per pixel against the CPU oracle; the prob map
+    goes to the host exactly as postprocess.py consumes it.  The running statistics are CALIBRATED first (one momentum-1 train pass
+    of the oracle over the two checked images, as in test_native_bf16_training_and_fp16_inference_full_size): with the procedurally
+    filled statistics eval activations grow to ~1e3 and saturated logits make a max-error bound meaningless — round 3 asserted
+    the mean only; now mean AND max are bounded in fp16 (stated bound of the fp16 path: mean <= 4e-3, max <= 6e-2)."""
     seed = 4
     g = torch.Generator().manual_seed(123)
     img = torch.randn(32, 3, 1280, 1280, generator=g)
-    model = make_model(seed).eval()
+    sd = O.new_state(seed)
+    O.BN_MOMENTUM = 1.0
+    try:
+        with torch.no_grad():
+            O.forward(sd, img[[0, 31]], training=True, update_stats=True)
+    finally:
+        O.BN_MOMENTUM = 0.1
+    model = make_model(seed)
+    model.load_state_dict(sd)
+    model.eval()
     with torch.no_grad():
         preds = model(img.to(DEV))
         assert preds.shape == (32, 2, 1280, 1280)
         prob = preds[:, 0, :, :].cpu().numpy()  # postprocess.py:33-34,61-62: pred[:, 0], .cpu().numpy()
-        ref = O.forward(O.new_state(seed), img[[0, 31]], training=False)
+        ref = O.forward(sd, img[[0, 31]], training=False)
     assert prob.dtype == np.float32 and np.isfinite(prob).all()
     report('cfg5 image 0', preds[0].cpu(), ref[0], MAP_ATOL, MAP_RTOL)
     report('cfg5 image 31', preds[31].cpu(), ref[1], MAP_ATOL, MAP_RTOL)
-    # configs[4] in its own dtype: the native fp16 inference path (fp16 activations and weight panels, fp32 accumulate).
-    # the procedurally filled running statistics let eval-mode activations grow to ~1e3, where a 2^-11 relative operand error
-    # moves saturated logits: only the mean error is meaningful here (calibrated statistics: test_native_bf16_..._full_size)
+    # configs[4] in its own dtype: the native fp16 inference path (fp16 activations and weight panels, fp32 accumulate)
     model.engine.set_conv_math('fp16')
     with torch.no_grad():
         preds_f16 = model(img.to(DEV))
     assert preds_f16.dtype == torch.float32 and model.engine.bufs['fpn/z'].dtype == torch.float16
-    err = (preds_f16[31].cpu() - ref[1]).abs()
-    print('cfg5 fp16 inference: mean abs err %.3e, max %.3e' % (float(err.mean()), float(err.max())))
-    assert torch.isfinite(preds_f16).all() and float(err.mean()) < 1e-2
+    assert torch.isfinite(preds_f16).all()
+    for i, j in ((0, 0), (31, 1)):
+        err = (preds_f16[i].cpu() - ref[j]).abs()
+        print('cfg5 fp16 inference image %d: mean abs err %.3e, max %.3e' % (i, float(err.mean()), float(err.max())))
+        assert float(err.mean()) <= 4e-3 and float(err.max()) <= 6e-2
 
 
 def test_checkpoint_roundtrip_and_lr_schedulers(tmp_path):
@@ -535,6 +544,38 @@ def test_checkpoint_roundtrip_and_lr_schedulers(tmp_path):
         a, b = model(img.to(DEV)), m2(img.to(DEV))
     assert torch.equal(a, b)
     assert int(sd['backbone.bn1.num_batches_tracked']) == 1
+
+
+def test_odd_size_vs_reference_golden(golden_dir):
+    """1x3x96x70 against the REFERENCE's own output (tests/golden/odd_1x96x70.npz, make_golden.case_odd): H, W not multiples of 32,
+    so the FPN's size-based nearest upsampling (segmentation_body.py:64-76) and the final bilinear(align_corners=True) resample
+    (models.py:43-46) are real resamples — dbn_nearest_up_*, dbn_bilinear_fwd/bwd.  Eval maps + loss, train maps, losses,
+    gradients, running statistics."""
+    z = np.load(os.path.join(golden_dir, 'odd_1x96x70.npz'))
+    n, h, w, seed = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, (h, w), seed=seed + 100)
+    model = make_model(seed).eval()
+    with torch.no_grad():
+        pe = model(img.to(DEV))
+        val = DBLoss()(pe, gts.to(DEV))
+    assert pe.shape == (n, 2, h, w)
+    report('odd-size eval maps vs reference', pe.cpu(), torch.from_numpy(z['eval_preds']), MAP_ATOL, MAP_RTOL)
+    report('odd-size eval loss vs reference', val.cpu().double().view(1), torch.from_numpy(z['eval_loss']).view(1), 1e-4, 1e-3)
+    model = make_model(seed).train()
+    trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = trainer.step(img.to(DEV), gts.to(DEV))
+    assert preds.shape == (n, 3, h, w)
+    report('odd-size train maps vs reference', preds.cpu(), torch.from_numpy(z['preds']), MAP_ATOL, MAP_RTOL)
+    report('odd-size P,T (tight)', preds[:, :2].cpu(), torch.from_numpy(z['preds'][:, :2]), 1e-4, 1e-3)
+    report('odd-size losses vs reference', losses.cpu().double(), torch.from_numpy(z['losses']), 1e-5, 1e-5)
+    for k in [f[len('grad/'):-len('/stats')] for f in z.files if f.startswith('grad/') and f.endswith('/stats')]:
+        if k.endswith('.bias') and ('conv.bias' in k or k.endswith(('.0.bias', '.3.bias'))):
+            continue  # conv bias ahead of train-mode BN: analytically zero, reference value is round-off noise
+        check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k])
+    sd = model.state_dict()
+    for f in z.files:
+        if f.startswith('post/') and f.endswith('/stats'):
+            check_summary(z, f[:-len('/stats')], sd[f[len('post/'):-len('/stats')]], 1e-4, 1e-3)
 
 
 @pytest.mark.parametrize('n,h,w', [(1, 96, 70), (2, 70, 90), (1, 33, 47)])
@@ -743,25 +784,11 @@ def test_graph_captured_step_is_bit_identical_to_the_eager_step(math):
         return None
 
     eager = run(False)
-    # Round 3 met GPUs of this pool on which about one run in five of THIS test (either mode, with or without that round's kernels)
-    # differs from the others, and GPUs on which none of hundreds does: a transient is told from a defect of the
-    # captured step by repetition — a defect differs every time.
-    why = []
-    for attempt in range(3):
-        graph = run(True)
-        w = same(eager, graph)
-        if w is None:
-            break
-        why.append(w)
-        eager2 = run(False)
-        if same(eager, eager2) is not None:  # the eager reference itself did not reproduce: take the fresh one
-            why.append('(the eager run itself did not reproduce)')
-            eager = eager2
-    else:
-        raise AssertionError('three graph-captured runs in a row differ from the eager step: %s' % why)
-    if why:
-        import warnings
-        warnings.warn('graph-captured step: %d transient mismatch(es) before a bit-identical run: %s' % (len(why), why))
+    graph = run(True)
+    # one run each, hard fail (round 3 retried up to three times and downgraded mismatches to a warning; the graph's input copy was
+    # then skipped on an (id, _version, data_ptr) key that a freed temporary's successor can reproduce — train.DBTrainer._graph_step)
+    assert same(eager, graph) is None, same(eager, graph)
+    assert same(eager, run(False)) is None, 'the eager step did not reproduce itself'
     assert int(graph[2]['backbone.bn1.num_batches_tracked']) == 5
 
 
@@ -804,3 +831,63 @@ def test_fit_and_evaluate_epoch_loop(tmp_path):
         p = O.forward(sd, b['img'], training=False)
         ref += float(O.db_loss(p, torch.stack([b['prob_map'], b['supervision_mask'], b['thresh_map'], b['text_area_map']])))
     assert abs(ref / len(test_loader) - l1) < 2e-3 * max(1.0, abs(l1))
+
+
+@pytest.mark.parametrize('math,arch,n,size', [('f32', 'resnet18', 2, 96), ('bf16', 'resnet18', 2, 96), ('bf16x3', 'resnet18', 1, 64),
+                                              ('f32', 'resnet18', 1, (96, 70)), ('f32', 'deformable_resnet18', 1, 64),
+                                              ('bf16', 'resnet50', 1, 64)])
+def test_results_do_not_depend_on_uninitialised_memory(math, arch, n, size):
+    """Every buffer the engine allocates (activations, gradients, weight panels, slabs, partial rows, scratch) comes from
+    torch.empty: recycled allocator blocks holding whatever the previous owner left.  A kernel that reads an element no kernel of
+    this step has written — a partial row of a tile that does not exist, a panel's padding, a slab gap — makes the step depend on
+    that history, which shows as a once-in-a-while run-to-run mismatch on some boxes (round 3's unexplained transients).  Here the
+    history is made explicit: three training steps with all fresh buffers pre-filled with NaN, with finite noise (different per
+    buffer), and left as allocated must produce the same bits (train.py:160-172 is the sequence)."""
+    from db_text_minimal_amd import engine as engine_mod
+    seed = 13
+    img, gts = O.synthetic_batch(n, size, seed=seed)
+    img, gts = img.to(DEV), gts.to(DEV)
+    sd = O.new_state(seed, arch)
+
+    def run(poison):
+        engine_mod.POISON = poison
+        try:
+            model = DBTextModel() if arch == 'resnet18' else DBTextModel(arch)
+            model.load_state_dict(sd)
+            model = model.to(DEV).train()
+            model.engine.set_conv_math(math)
+            tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+            for _ in range(3):
+                preds, losses = tr.step(img, gts)
+            torch.cuda.synchronize()
+            return preds.clone(), losses.clone(), model.engine.flat_grad.clone(), model.engine.flat.clone()
+        finally:
+            engine_mod.POISON = ''
+
+    base = run('')
+    assert torch.isfinite(base[2]).all() and torch.isfinite(base[0]).all()
+    for poison in ('nan', 'rand', 'rand'):
+        got = run(poison)
+        for name, a, b in zip(('preds', 'losses', 'gradients', 'parameters'), base, got):
+            bad = int((a != b).sum()) if a.shape == b.shape else -1
+            assert torch.equal(a, b), ('%s differ (%d elements) with fresh buffers pre-filled by %r: the step reads memory it has not '
+                                       'written' % (name, bad, poison))
+
+
+def test_fused_adam_refuses_gradient_accumulation():
+    """torch.optim.Adam would SUM the gradients of two backward passes without a zero_grad() in between; the fused path's flat
+    gradient buffer holds only the last pass — FusedAdam.step() raises instead of silently applying half of the accumulation."""
+    seed = 3
+    img, gts = O.synthetic_batch(1, 64, seed=seed)
+    model = make_model(seed).train()
+    opt = FusedAdam(model, lr=0.005)
+    crit = DBLoss()
+    for _ in range(2):
+        crit(model(img.to(DEV)), gts.to(DEV))[4].backward()
+    with pytest.raises(RuntimeError, match='backward passes'):
+        opt.step()
+    opt.zero_grad()
+    crit(model(img.to(DEV)), gts.to(DEV))[4].backward()
+    opt.step()  # one pass since zero_grad(): fine
+    crit(model(img.to(DEV)), gts.to(DEV))[4].backward()
+    opt.step()  # step() also clears the count (the reference calls zero_grad() first anyway, train.py:169-172)

@@ -106,6 +106,37 @@ def test_oracle_eval_matches_reference(golden_dir):
     assert abs(float(val) - float(z['loss'])) < 1e-6
 
 
+def test_oracle_odd_size_matches_reference(golden_dir):
+    """1x3x96x70 — not a multiple of 32: the FPN's size-based nearest upsampling and the final bilinear(align_corners=True)
+    resample are real resamples (models.py:43-46, segmentation_body.py:64-76).  Eval forward + loss and one train step's maps,
+    losses, gradients and running statistics of the oracle against the reference's own (make_golden.case_odd)."""
+    z = np.load(os.path.join(golden_dir, 'odd_1x96x70.npz'))
+    n, h, w, seed = (int(v) for v in z['meta'])
+    img, gts = O.synthetic_batch(n, (h, w), seed=seed + 100)
+    with torch.no_grad():
+        pe = O.forward(O.new_state(seed), img, training=False)
+        val = O.db_loss(pe, gts)
+    assert pe.shape == (n, 2, h, w) and np.abs(pe.numpy() - z['eval_preds']).max() < 1e-6
+    assert abs(float(val) - float(z['eval_loss'])) < 1e-5 * abs(float(z['eval_loss']))
+    sd = O.new_state(seed)
+    preds, losses, grads = O.loss_and_grads(sd, img, gts)
+    assert preds.shape == (n, 3, h, w) and np.abs(preds.numpy() - z['preds']).max() < 1e-6
+    assert np.allclose(losses, z['losses'], rtol=1e-5, atol=1e-7)
+    for f in z.files:
+        if f.startswith('grad/') and f.endswith('/stats'):
+            k = f[5:-6]
+            a = grads[k].double().reshape(-1).numpy()
+            st = z[f]
+            assert abs(np.sqrt((a * a).sum()) - st[2]) <= 1e-5 * st[2] + 1e-12, k
+            key = 'grad/' + k + ('/full' if 'grad/' + k + '/full' in z.files else '/sample')
+            got = a if key.endswith('full') else a[sample_idx(a.size)]
+            assert np.abs(got - z[key].reshape(-1)).max() <= 1e-5 * max(abs(st[3]), abs(st[4])) + 1e-12, k
+        if f.startswith('post/') and f.endswith('/stats'):
+            k = f[5:-6]
+            a = sd[k].double().reshape(-1).numpy()
+            assert abs(np.sqrt((a * a).sum()) - z[f][2]) <= 1e-5 * z[f][2] + 1e-9, k
+
+
 @pytest.mark.parametrize('tag', ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta',
                                  'reduction_none', 'reduction_sum'])
 def test_oracle_loss_known_answers(golden_dir, tag):
