@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdbnet_hip.so')
+# DBN_LIB_PATH: a test vehicle built from the same sources (make RACE=1 -> libdbnet_hip_race.so, csrc/common.h); the default is the product
+LIB_PATH = os.environ.get('DBN_LIB_PATH') or os.path.join(_HERE, 'libdbnet_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float

@@ -21,6 +21,36 @@ static inline constexpr int dbn_env_int(const char*, int dflt) { return dflt; }
 static inline constexpr double dbn_env_double(const char*, double dflt) { return dflt; }
 #endif
 
+// -DDBN_RACE=1 (make RACE=1 -> ../libdbnet_hip_race.so; never the product library): every workgroup barrier — __syncthreads()
+// and the raw s_barrier of the LDS-DMA rings — and every cross-workgroup counter increment (DBN_RACE_JITTER) is preceded AND
+// followed by a delay of 0..7 x 512 cycles hashed from (wave, workgroup, source line).  Correct kernels return the same bits as the
+// product build; a missing barrier, a counted wait that is one short, or a hand-over that relies on arrival order turns from a
+// once-per-thousand transient into a wrong result on (nearly) every launch.  tools/probes/repro.hip and the -m gpu suite run
+// against this library through DBN_LIB_PATH (profiles/r04_repro.md).
+#ifndef DBN_RACE
+#define DBN_RACE 0
+#endif
+#if DBN_RACE
+__device__ __forceinline__ void dbn_race_jitter(unsigned site) {
+    unsigned h = (threadIdx.x >> 6) * 2654435761u + blockIdx.x * 40503u + site * 2246822519u;
+    h ^= h >> 15;
+    h *= 2654435761u;
+    h ^= h >> 13;
+    const unsigned n = __builtin_amdgcn_readfirstlane(h & 7u);
+    for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+}
+__device__ __forceinline__ void dbn_race_raw_barrier(unsigned site) {
+    dbn_race_jitter(site);
+    __builtin_amdgcn_s_barrier();
+    dbn_race_jitter(site + 7919u);
+}
+#define __syncthreads() (dbn_race_jitter(__LINE__), (__syncthreads)(), dbn_race_jitter(__LINE__ + 7919u))
+#define __builtin_amdgcn_s_barrier() dbn_race_raw_barrier(__LINE__)
+#define DBN_RACE_JITTER() dbn_race_jitter(__LINE__ + 104729u)
+#else
+#define DBN_RACE_JITTER() ((void)0)
+#endif
+
 #define DBN_OK 0
 #define DBN_ERR_ARG 1
 

@@ -1308,6 +1308,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             int* const s_flag = reinterpret_cast<int*>(smem) + (sizeof(smem) / 4 - 4);  // (behind every scratch region of the epilogue)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial-row stores have completed
             __syncthreads();
+            DBN_RACE_JITTER();
             if (tid == 0) {
                 const int gsize = min(G, p.stat_rows - g * G);
                 const int last = __hip_atomic_fetch_add(cnt + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
@@ -1330,6 +1331,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            DBN_RACE_JITTER();
             if (tid == 0) {
                 const int last = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NG - 1;
                 if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

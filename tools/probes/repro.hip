@@ -1,0 +1,258 @@
+// Standalone bit-reproducibility probe (no torch, no Python): the three kernels round 3's review named as suspects of the
+// timing-dependent transients, each launched ITERS times on fixed inputs through the C ABI of libdbnet_hip.so (include/dbnet_hip.h),
+// every output hashed on the device after every launch with an order-independent 64-bit integer hash:
+//
+//   head_tail_bwd      dbn_head_tail_bwd_t at 16 x 320 x 320 x 64 (fp32 and bf16 storage): DPP quad broadcasts, 49 KB LDS reduction
+//   dgrad_bnsums_f32   dbn_igemm_bnsums_t, 3x3 64->64 stride-1 data gradient at 16 x 160^2 with the in-kernel finalize (dbn_bnb_final:
+//                      the fence-free cross-workgroup hand-over, igemm_kernel.h bnb_finish) — dst, partial rows, c1c2, dgamma, dbeta
+//   dgrad_bnsums_bf16  the same on bf16 tensors (16-bit epilogue through LDS)
+//   dgrad_s2_bnsums    stride-2 3x3 128->64 parity-class data gradient with the sums epilogue + finalize
+//   conv_ring_bf16     dbn_igemm_t at = ns = 1, 3x3 stride 2 64->128 at 16 x 160^2: the generic 16-bit LDS-DMA ring (counted vmcnt waits)
+//   conv_patch_bf16    dbn_igemm_t at = ns = 1, 3x3 stride 1 64->64 at 16 x 160^2: the pixel-patch kernel + weight ring
+//
+// Prints one line per case: launches, distinct hashes, launches that differ from the first.  Exit code 1 if any case is not
+// bit-reproducible.  Build + run (GPU box):
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/probes/repro.hip -o tools/probes/repro -L db_text_minimal_amd -ldbnet_hip \
+//         -Wl,-rpath,'$ORIGIN/../../db_text_minimal_amd'     (or -l:libdbnet_hip_race.so for the make RACE=1 flavour)
+//   tools/probes/repro [iters=1000] [stress=0|1]     stress = 1: a second stream runs a bf16 MFMA + LDS-heavy conv beside every case
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dbnet_hip.h"
+
+#define HIPCHECK(x)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (x);                                                                     \
+        if (e_ != hipSuccess) {                                                                  \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+            exit(2);                                                                             \
+        }                                                                                        \
+    } while (0)
+#define DBN(x)                                                              \
+    do {                                                                    \
+        int rc_ = (x);                                                      \
+        if (rc_ != 0) {                                                     \
+            fprintf(stderr, "%s:%d %s -> %d\n", __FILE__, __LINE__, #x, rc_); \
+            exit(2);                                                        \
+        }                                                                   \
+    } while (0)
+
+// order-independent hash of a word array: sum over i of mix(word_i, i) in 64-bit integers (integer addition commutes)
+__global__ void hash_kernel(const uint32_t* __restrict__ w, long n, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned long long v = ((unsigned long long)w[i] + 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long)i + 1ull);
+        v ^= v >> 29;
+        s += v * 0xBF58476D1CE4E5B9ull;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// deterministic pseudo-random fill: fp32 in [-scale, scale] (+ bias), or bf16 pairs
+__global__ void fill_f32(float* p, long n, unsigned seed, float scale, float bias) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed * 40503u;
+        h ^= h >> 16; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale + bias;
+    }
+}
+__global__ void fill_bf16(unsigned short* p, long n, unsigned seed, float scale, float bias) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed * 40503u;
+        h ^= h >> 16; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        const float v = ((h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale + bias;
+        p[i] = (unsigned short)(__builtin_bit_cast(unsigned, v) >> 16);
+    }
+}
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+static Buf alloc(size_t bytes, int poison = 0xFF) {
+    Buf b;
+    b.bytes = bytes;
+    HIPCHECK(hipMalloc(&b.p, bytes));
+    HIPCHECK(hipMemset(b.p, poison, bytes));
+    return b;
+}
+static Buf f32(long n, unsigned seed, float scale = 1.f, float bias = 0.f) {
+    Buf b = alloc(n * 4);
+    fill_f32<<<2048, 256>>>((float*)b.p, n, seed, scale, bias);
+    return b;
+}
+static Buf b16(long n, unsigned seed, float scale = 1.f, float bias = 0.f) {
+    Buf b = alloc(n * 2);
+    fill_bf16<<<2048, 256>>>((unsigned short*)b.p, n, seed, scale, bias);
+    return b;
+}
+static Buf act(int at, long n, unsigned seed, float scale = 1.f, float bias = 0.f) { return at ? b16(n, seed, scale, bias) : f32(n, seed, scale, bias); }
+
+static unsigned long long* g_hash;
+static unsigned long long hash_of(const std::vector<Buf>& outs, hipStream_t st) {
+    HIPCHECK(hipMemsetAsync(g_hash, 0, 8, st));
+    for (const Buf& b : outs) hash_kernel<<<1024, 256, 0, st>>>((const uint32_t*)b.p, (long)(b.bytes / 4), g_hash);
+    unsigned long long h;
+    HIPCHECK(hipMemcpyAsync(&h, g_hash, 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return h;
+}
+
+struct Result {
+    std::string name;
+    int launches, distinct, differ;
+};
+static std::vector<Result> g_results;
+
+template <class Launch>
+static void run_case(const char* name, int iters, const std::vector<Buf>& outs, hipStream_t st, Launch launch) {
+    std::map<unsigned long long, int> seen;
+    unsigned long long first = 0;
+    int differ = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (const Buf& b : outs) HIPCHECK(hipMemsetAsync(b.p, (it & 1) ? 0xFF : 0x7F, b.bytes, st));  // outputs start from two different poisons
+        launch();
+        const unsigned long long h = hash_of(outs, st);
+        if (it == 0) first = h;
+        differ += h != first;
+        seen[h]++;
+    }
+    printf("%-22s launches %5d  distinct results %3d  launches differing from the first %5d\n", name, iters, (int)seen.size(), differ);
+    fflush(stdout);
+    g_results.push_back({name, iters, (int)seen.size(), differ});
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 1000;
+    const int stress = argc > 2 ? atoi(argv[2]) : 0;
+    hipStream_t st, st2;
+    HIPCHECK(hipStreamCreate(&st));
+    HIPCHECK(hipStreamCreate(&st2));
+    HIPCHECK(hipMalloc((void**)&g_hash, 8));
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs; %d launches per case; co-running bf16 stress stream: %s\n", prop.gcnArchName, prop.multiProcessorCount, iters,
+           stress ? "yes" : "no");
+
+    // ---- stress companion: a bf16 pixel-patch conv (MFMA + LDS-DMA ring, 70 KB LDS) looping on a second stream
+    const int N = 16, H = 160, W = 160;
+    Buf sx = b16((long)N * H * W * 64, 901, 1.f), sy = alloc((size_t)N * H * W * 64 * 2);
+    Buf sw = f32(64L * 64 * 9, 902, 0.05f);
+    Buf swp = alloc((size_t)dbn_igemm_panel_floats_t(1, 64, 64, 3, 3, 0, 1, 64) * 4);
+    DBN(dbn_pack_weights_t(1, (const float*)sw.p, 64, 64, 3, 3, 0, 1, 64, (float*)swp.p, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    auto stress_burst = [&]() {
+        if (!stress) return;
+        for (int i = 0; i < 3; ++i)
+            DBN(dbn_igemm_t(1, 1, sx.p, (const float*)swp.p, nullptr, sy.p, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 0, 0, 1, nullptr, st2));
+    };
+
+    // ---- head_tail_bwd, fp32 and bf16 storage ------------------------------------------------------------------------------
+    for (int at = 0; at < 2; ++at) {
+        const int Hq = 320, Wq = 320;
+        const long nq = (long)N * Hq * Wq, px = (long)N * 4 * Hq * Wq;
+        Buf xb = act(at, nq * 64, 11, 1.f), xt = act(at, nq * 64, 12, 1.f);
+        Buf wb = f32(256, 13, 0.2f), wt = f32(256, 14, 0.2f);
+        Buf preds = f32(px * 3, 15, 0.49f, 0.5f), dpreds = f32(px * 3, 16, 1e-3f);
+        Buf scb = f32(64, 17, 0.5f, 1.f), shb = f32(64, 18, 0.3f), sct = f32(64, 19, 0.5f, 1.f), sht = f32(64, 20, 0.3f);
+        Buf mub = f32(64, 21, 0.2f), rsb = f32(64, 22, 0.3f, 1.f), mut = f32(64, 23, 0.2f), rst = f32(64, 24, 0.3f, 1.f);
+        Buf sums = alloc(4 * 64 * 4), dxb = alloc((size_t)nq * 64 * (at ? 2 : 4)), dxt = alloc((size_t)nq * 64 * (at ? 2 : 4));
+        Buf dwb = alloc(256 * 4), dbb = alloc(4), dwt = alloc(256 * 4), dbt = alloc(4);
+        Buf ws = alloc((size_t)dbn_head_tail_bwd_ws_floats() * 4);
+        HIPCHECK(hipDeviceSynchronize());
+        run_case(at ? "head_tail_bwd bf16" : "head_tail_bwd f32", iters, {sums, dxb, dxt, dwb, dbb, dwt, dbt}, st, [&]() {
+            stress_burst();
+            DBN(dbn_head_tail_bwd_t(at, xb.p, xt.p, (const float*)wb.p, (const float*)wt.p, (const float*)preds.p, (const float*)dpreds.p,
+                                    (const float*)scb.p, (const float*)shb.p, (const float*)sct.p, (const float*)sht.p, (const float*)mub.p,
+                                    (const float*)rsb.p, (const float*)mut.p, (const float*)rst.p, (float*)sums.p, dxb.p, dxt.p, (float*)dwb.p,
+                                    (float*)dbb.p, (float*)dwt.p, (float*)dbt.p, N, Hq, Wq, 3, 50.f, 1.f, (float*)ws.p, st));
+        });
+        HIPCHECK(hipDeviceSynchronize());
+        for (Buf* b : {&xb, &xt, &wb, &wt, &preds, &dpreds, &scb, &shb, &sct, &sht, &mub, &rsb, &mut, &rst, &sums, &dxb, &dxt, &dwb, &dbb, &dwt, &dbt, &ws})
+            HIPCHECK(hipFree(b->p));
+    }
+
+    // ---- data gradients with the BatchNorm-backward sums epilogue and the in-kernel finalize --------------------------------
+    struct DG {
+        const char* name;
+        int at, ns, Ci, Co, stride, Hs;  // conv Ci -> Co (3x3, pad 1) whose data gradient is taken; Hs = conv OUTPUT size
+    };
+    const DG dgs[] = {{"dgrad_bnsums_f32", 0, 0, 64, 64, 1, 160}, {"dgrad_bnsums_bf16", 1, 1, 64, 64, 1, 160},
+                      {"dgrad_s2_bnsums_f32", 0, 0, 64, 128, 2, 80}, {"dgrad_s2_bnsums_bf16", 1, 1, 64, 128, 2, 80}};
+    for (const DG& c : dgs) {
+        const int kind = c.at ? 1 : 0, Hd = c.Hs * c.stride, Wd = Hd, Cd = c.Ci, Cs = c.Co, Hs = c.Hs;
+        const long nd = (long)N * Hd * Wd * Cd, ns_ = (long)N * Hs * Hs * Cs;
+        Buf dy = act(c.at, ns_, 31, 1.f);
+        Buf w = f32((long)c.Co * c.Ci * 9, 32, 0.05f);
+        Buf wp = alloc((size_t)dbn_igemm_panel_floats_t(kind, c.Co, c.Ci, 3, 3, 1, c.stride, 0) * 4);
+        DBN(dbn_pack_weights_t(kind, (const float*)w.p, c.Co, c.Ci, 3, 3, 1, c.stride, 0, (float*)wp.p, st));
+        Buf y = act(c.at, nd, 33, 1.f), msc = f32(Cd, 34, 0.5f, 1.f), msh = f32(Cd, 35, 0.3f), mu = f32(Cd, 36, 0.2f), rs = f32(Cd, 37, 0.3f, 1.f);
+        const int rows = dbn_igemm_bn_rows(c.at, c.ns, N, Hs, Hs, Cs, Hd, Wd, Cd, 3, 3, c.stride, 1, 1, 0);
+        if (rows <= 0) {
+            fprintf(stderr, "%s: dbn_igemm_bn_rows = %d\n", c.name, rows);
+            return 2;
+        }
+        Buf dst = alloc((size_t)nd * (c.at ? 2 : 4)), part = alloc((size_t)2 * Cd * rows * 4);
+        Buf cnt = alloc((size_t)dbn_igemm_bn_final_counters(rows, Cd) * 4, 0), grp = alloc((size_t)dbn_igemm_bn_final_group_floats(rows, Cd) * 4);
+        Buf c1c2 = alloc(2 * Cd * 4), dga = alloc(Cd * 4), dbe = alloc(Cd * 4);
+        dbn_bnb_final fin;
+        memset(&fin, 0, sizeof(fin));
+        fin.counters = (int*)cnt.p;
+        fin.group = (float*)grp.p;
+        fin.c1c2 = (float*)c1c2.p;
+        fin.dgamma = (float*)dga.p;
+        fin.dbeta = (float*)dbe.p;
+        fin.grad_scale = 1.f;
+        HIPCHECK(hipDeviceSynchronize());
+        run_case(c.name, iters, {dst, part, c1c2, dga, dbe}, st, [&]() {
+            stress_burst();
+            DBN(dbn_igemm_bnsums_t(c.at, c.ns, dy.p, (const float*)wp.p, nullptr, dst.p, N, Hs, Hs, Cs, Hd, Wd, Cd, 3, 3, c.stride, 1, 1, 0, 0, y.p,
+                                   nullptr, (const float*)msc.p, (const float*)msh.p, (const float*)mu.p, (const float*)rs.p, (float*)part.p,
+                                   nullptr, nullptr, nullptr, nullptr, &fin, st));
+        });
+        // the counters must have come back to zero after every launch
+        std::vector<int> hc(cnt.bytes / 4);
+        HIPCHECK(hipMemcpy(hc.data(), cnt.p, cnt.bytes, hipMemcpyDeviceToHost));
+        long left = 0;
+        for (int v : hc) left += v != 0;
+        if (left) {
+            printf("%-22s %ld finalize counters left non-zero\n", c.name, left);
+            g_results.back().differ += 1;
+        }
+        for (Buf* b : {&dy, &w, &wp, &y, &msc, &msh, &mu, &rs, &dst, &part, &cnt, &grp, &c1c2, &dga, &dbe}) HIPCHECK(hipFree(b->p));
+    }
+
+    // ---- 16-bit convolutions: the generic LDS-DMA ring and the pixel-patch kernel -------------------------------------------
+    struct CV {
+        const char* name;
+        int Ci, Co, stride, R;
+    };
+    const CV cvs[] = {{"conv_ring_bf16 s2", 64, 128, 2, 3}, {"conv_ring_bf16 1x1", 64, 256, 1, 1}, {"conv_patch_bf16", 64, 64, 1, 3}};
+    for (const CV& c : cvs) {
+        const int Hs = 160, Hd = Hs / c.stride, pad = c.R / 2;
+        Buf x = b16((long)N * Hs * Hs * c.Ci, 41, 1.f), w = f32((long)c.Co * c.Ci * c.R * c.R, 42, 0.05f), bias = f32(c.Co, 43, 0.1f);
+        Buf wp = alloc((size_t)dbn_igemm_panel_floats_t(1, c.Co, c.Ci, c.R, c.R, 0, 1, c.Ci) * 4);
+        DBN(dbn_pack_weights_t(1, (const float*)w.p, c.Co, c.Ci, c.R, c.R, 0, 1, c.Ci, (float*)wp.p, st));
+        Buf dst = alloc((size_t)N * Hd * Hd * c.Co * 2);
+        HIPCHECK(hipDeviceSynchronize());
+        run_case(c.name, iters, {dst}, st, [&]() {
+            stress_burst();
+            DBN(dbn_igemm_t(1, 1, x.p, (const float*)wp.p, (const float*)bias.p, dst.p, N, Hs, Hs, c.Ci, Hd, Hd, c.Co, c.R, c.R, c.stride, pad, 0, 0, 0, 1,
+                            nullptr, st));
+        });
+        for (Buf* b : {&x, &w, &bias, &wp, &dst}) HIPCHECK(hipFree(b->p));
+    }
+    HIPCHECK(hipDeviceSynchronize());
+    int bad = 0;
+    for (const Result& r : g_results) bad += r.distinct != 1 || r.differ != 0;
+    printf("%s: %d of %d cases bit-reproducible over %d launches each\n", bad ? "FAIL" : "OK", (int)g_results.size() - bad, (int)g_results.size(), iters);
+    return bad ? 1 : 0;
+}
