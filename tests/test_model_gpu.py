@@ -560,7 +560,12 @@ def test_odd_size_vs_reference_golden(golden_dir):
         val = DBLoss()(pe, gts.to(DEV))
     assert pe.shape == (n, 2, h, w)
     report('odd-size eval maps vs reference', pe.cpu(), torch.from_numpy(z['eval_preds']), MAP_ATOL, MAP_RTOL)
-    report('odd-size eval loss vs reference', val.cpu().double().view(1), torch.from_numpy(z['eval_loss']).view(1), 1e-4, 1e-3)
+    # the eval loss of a net with procedurally filled running statistics is ill-conditioned (saturated maps: BCE takes log of
+    # values near 0, the loss is ~19): 1e-4 on the maps moves it by 1e-3 relative.  Two checks instead of one loose one: the loss
+    # kernel on OUR maps against the oracle's DBLoss on the same maps (tight), and the end-to-end value against the reference's.
+    report('odd-size eval loss, HIP DBLoss vs oracle DBLoss on the HIP maps', val.cpu().double().view(1),
+           O.db_loss(pe.cpu(), gts).double().view(1), 1e-5, 1e-5)
+    report('odd-size eval loss vs reference', val.cpu().double().view(1), torch.from_numpy(z['eval_loss']).view(1), 1e-4, 5e-3)
     model = make_model(seed).train()
     trainer = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = trainer.step(img.to(DEV), gts.to(DEV))

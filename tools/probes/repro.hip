@@ -125,7 +125,7 @@ static void run_case(const char* name, int iters, const std::vector<Buf>& outs, 
         differ += h != first;
         seen[h]++;
     }
-    printf("%-22s launches %5d  distinct results %3d  launches differing from the first %5d\n", name, iters, (int)seen.size(), differ);
+    printf("%-22s launches %5d  distinct results %3d  launches differing from the first %5d  hash %016llx\n", name, iters, (int)seen.size(), differ, first);
     fflush(stdout);
     g_results.push_back({name, iters, (int)seen.size(), differ});
 }
