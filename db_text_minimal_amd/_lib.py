@@ -91,6 +91,8 @@ SIGNATURES.update({
     'dbn_igemm_bn_final_group_floats': 'ii',
     'dbn_wgrad_t': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
     'dbn_wgrad_phase_t': 'iii' + 'pppp' + 'i' * 12 + 'f' + 'p',
+    'dbn_wgrad_reduce_describe': 'ii' + 'pppp' + 'i' * 12 + 'f' + 'p',
+    'dbn_wgrad_reduce_many': 'ppiiip',
     'dbn_wgrad_tile_config': 'ii',
     'dbn_set_wgrad_variant': 'i',
     'dbn_set_convt_kernel': 'i',
@@ -125,6 +127,12 @@ _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class WgradReduceJob(ctypes.Structure):
+    """dbn_wgrad_reduce_job of include/dbnet_hip.h: one layer's slab reduction, for dbn_wgrad_reduce_many."""
+    _fields_ = ([('slab', _P), ('grad', _P)] + [(f, _I) for f in ('splitk', 'O', 'J', 'Jp', 'BM', 'BN', 'Cb', 'I', 'RS', 'G', 'natural', 'blocks')]
+                + [('scale', _F), ('smem_bytes', _I)])
 
 
 class BnbFinal(ctypes.Structure):

@@ -340,9 +340,100 @@ __device__ __forceinline__ void stv(float* p, f32x4 v) {
 
 
 
+struct DbLossFinal {
+    // arguments of the finalize step, run by the LAST workgroup of db_loss_fwd_kernel
+    long px;
+    int CH;
+    float alpha, beta, negative_ratio, eps;
+    int bce_sum;
+    float* losses;
+    float* coef;
+    unsigned* counter;  // arrival counter (zero on entry, left zero)
+};
+
+// losses[5] = prob, thresh, binary, prob+beta*thresh, total;  coef[8] for the backward:
+//   0: c_bce = (sum_pos + n_neg)/(n_pos+n_neg+eps)/px   1: 1/(sum_A+eps)
+//   2: dice U   3: dice I   4: has_pos flag (n_pos + n_neg > 0 ... always 1; kept for clarity)
+__device__ __forceinline__ void db_loss_finish(const double (&s)[NSUM], const DbLossFinal& f) {
+    // losses.py:25-28 — int() truncations
+    const long n_pos = (long)(float)s[S_POS];
+    const long n_neg_expect = (long)((double)n_pos * (double)f.negative_ratio);
+    const long n_neg_cur = (long)(float)s[S_NEG];
+    const long n_neg = n_neg_expect < n_neg_cur ? n_neg_expect : n_neg_cur;
+    // reduction='mean' (default) / 'sum': F.binary_cross_entropy returns ONE scalar over all pixels (losses.py:30)
+    const double bce_div = f.bce_sum ? 1.0 : (double)f.px;
+    const float bce = (float)(s[S_BCE] / bce_div);
+    // positive_loss.sum() = bce*sum_pos; topk(bce*negative, n_neg).sum() = bce*n_neg for binary maps
+    const float denom = (float)((double)(n_pos + n_neg) + (double)f.eps);
+    const float num_w = (float)s[S_POS] + (float)n_neg;
+    const float prob = bce * num_w / denom;
+    const float thr = (float)s[S_L1] / ((float)s[S_A] + f.eps);
+    const float pt = prob + f.beta * thr;
+    float* losses = f.losses;
+    float* coef = f.coef;
+    losses[0] = prob;
+    losses[1] = thr;
+    coef[0] = num_w / denom / (float)bce_div;
+    coef[1] = 1.f / ((float)s[S_A] + f.eps);
+    if (f.CH == 3) {
+        const float U = (float)s[S_BM] + (float)s[S_POS] + f.eps;
+        const float I = (float)s[S_BGM];
+        const float binl = 1.f - 2.f * I / U;
+        losses[2] = binl;
+        losses[3] = pt;
+        losses[4] = f.alpha * binl + pt;
+        coef[2] = U;
+        coef[3] = I;
+    } else {
+        losses[2] = 0.f;
+        losses[3] = pt;
+        losses[4] = pt;
+        coef[2] = 1.f;
+        coef[3] = 0.f;
+    }
+}
+
+// one 256-thread block: 32 lanes fold each of the NSUM (<= 8) partial columns in a fixed order, thread 0 finishes.
+// The partials were written by other workgroups of THIS launch: agent-scope loads (never a stale line of this CU's L1).
+__device__ __forceinline__ void db_loss_fold_and_finish(const double* __restrict__ part, int nb, const DbLossFinal& f, double* sums) {
+    {
+        const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+        double t = 0.0;
+        if (k < NSUM)
+            for (int b = l32; b < nb; b += 32)
+                t += __hip_atomic_load(part + (long)b * NSUM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (l32 == 0 && k < 8) sums[k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double s[NSUM];
+    for (int k = 0; k < NSUM; ++k) s[k] = sums[k];
+    db_loss_finish(s, f);
+}
+
+// BCE term (t - 1) * max(log1p(-x), -100) - t * max(log(x), -100)  (ATen binary_cross_entropy; losses.py:30).
+// The targets of the reference's loader are binary (data_loaders.py:158-165), so ONE logarithm per pixel suffices: of x where t = 1,
+// of 1 - x where t = 0 — v_log_f32 (1 ulp) instead of two libm calls (~100 VALU instructions per pixel: the kernel had been as
+// much VALU- as HBM-bound, 40 us for 183 MB).  log1p(u) is evaluated as log(w) * u / (w - 1) with w = fl(1 + u) (the rounding
+// error of w cancels in the quotient; w == 1 -> u).  A pixel with a fractional target takes the two-logarithm form.
+__device__ __forceinline__ float bce_term(float x, float t) {
+    if (t == 1.f || t == 0.f) {
+        const bool pos = t == 1.f;
+        const float u = -x, w = pos ? x : 1.f + u;
+        float l = __logf(w);
+        if (!pos) l = (w == 1.f) ? u : l * (u * __builtin_amdgcn_rcpf(w - 1.f));
+        return -fmaxf(l, -100.f);
+    }
+    const float lp = fmaxf(logf(x), -100.f);
+    const float lq = fmaxf(log1pf(-x), -100.f);
+    return (t - 1.f) * lq - t * lp;
+}
+
 template <int V>
 __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float* __restrict__ gts, int N, long HW, int CH,
-                                   double* __restrict__ part) {
+                                   double* __restrict__ part, DbLossFinal fin) {
     const long total4 = (long)N * HW / V;
     const long NHW = (long)N * HW;
     float s[NSUM];
@@ -368,9 +459,7 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
         for (int e = 0; e < V; ++e) {
             s[S_POS] += G[e] * M[e];
             s[S_NEG] += (1.f - G[e]) * M[e];
-            const float lp = fmaxf(logf(P[e]), -100.f);
-            const float lq = fmaxf(log1pf(-P[e]), -100.f);
-            s[S_BCE] += (G[e] - 1.f) * lq - G[e] * lp;
+            s[S_BCE] += bce_term(P[e], G[e]);
             s[S_L1] += fabsf(T[e] - Tg[e]) * A[e];
             s[S_A] += A[e];
             s[S_BGM] += B[e] * G[e] * M[e];
@@ -387,7 +476,8 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
     }
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) ds[k] += (double)s[k];
-    __shared__ double red[4][NSUM];
+    __shared__ double red[4][8];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) {
@@ -398,65 +488,24 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
     if (threadIdx.x < NSUM) {
         double t = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
-        part[(long)blockIdx.x * NSUM + threadIdx.x] = t;
+        double* dst = part + (long)blockIdx.x * NSUM + threadIdx.x;
+        __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // read by the last workgroup: memory-side store
     }
-}
-
-// losses[5] = prob, thresh, binary, prob+beta*thresh, total;  coef[8] for the backward:
-//   0: c_bce = (sum_pos + n_neg)/(n_pos+n_neg+eps)/px   1: 1/(sum_A+eps)
-//   2: dice U   3: dice I   4: has_pos flag (n_pos + n_neg > 0 ... always 1; kept for clarity)
-__global__ void db_loss_finalize_kernel(const double* __restrict__ part, int nb, long px, int CH, float alpha, float beta,
-                                        float negative_ratio, float eps, int bce_sum, float* __restrict__ losses,
-                                        float* __restrict__ coef) {
-    // one 256-thread block: 32 lanes fold each of the NSUM (<= 8) partial columns, thread 0 finishes
-    __shared__ double sums[8];
-    {
-        const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-        double t = 0.0;
-        if (k < NSUM)
-            for (int b = l32; b < nb; b += 32) t += part[(long)b * NSUM + k];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        if (l32 == 0) sums[k] = t;
+    // In-kernel finalize: the workgroup that arrives last folds every workgroup's row (fixed order) and writes the five losses and
+    // the backward's coefficients — the separate one-block finalize launch (10 us of a 50 us bracket) is gone.  Hand-over as in
+    // igemm_kernel.h bnb_finish: 8-byte agent-scope (sc1) stores drained by s_waitcnt before the agent-scope counter goes up,
+    // agent-scope loads on the reading side; the counter is left at zero for the next call.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DBN_RACE_JITTER();
+    if (threadIdx.x == 0) {
+        const int last = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (last) __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double s[NSUM];
-    for (int k = 0; k < NSUM; ++k) s[k] = sums[k];
-    // losses.py:25-28 — int() truncations
-    const long n_pos = (long)(float)s[S_POS];
-    const long n_neg_expect = (long)((double)n_pos * (double)negative_ratio);
-    const long n_neg_cur = (long)(float)s[S_NEG];
-    const long n_neg = n_neg_expect < n_neg_cur ? n_neg_expect : n_neg_cur;
-    // reduction='mean' (default) / 'sum': F.binary_cross_entropy returns ONE scalar over all pixels (losses.py:30)
-    const double bce_div = bce_sum ? 1.0 : (double)px;
-    const float bce = (float)(s[S_BCE] / bce_div);
-    // positive_loss.sum() = bce*sum_pos; topk(bce*negative, n_neg).sum() = bce*n_neg for binary maps
-    const float denom = (float)((double)(n_pos + n_neg) + (double)eps);
-    const float num_w = (float)s[S_POS] + (float)n_neg;
-    const float prob = bce * num_w / denom;
-    const float thr = (float)s[S_L1] / ((float)s[S_A] + eps);
-    const float pt = prob + beta * thr;
-    losses[0] = prob;
-    losses[1] = thr;
-    coef[0] = num_w / denom / (float)bce_div;
-    coef[1] = 1.f / ((float)s[S_A] + eps);
-    if (CH == 3) {
-        const float U = (float)s[S_BM] + (float)s[S_POS] + eps;
-        const float I = (float)s[S_BGM];
-        const float binl = 1.f - 2.f * I / U;
-        losses[2] = binl;
-        losses[3] = pt;
-        losses[4] = alpha * binl + pt;
-        coef[2] = U;
-        coef[3] = I;
-    } else {
-        losses[2] = 0.f;
-        losses[3] = pt;
-        losses[4] = pt;
-        coef[2] = 1.f;
-        coef[3] = 0.f;
-    }
+    if (!s_last) return;
+    db_loss_fold_and_finish(part, (int)gridDim.x, fin, &red[0][0]);
 }
 
 // gout[5]: upstream grads of the 5 returned losses (device); dpreds planes like preds.
@@ -770,10 +819,12 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
                                grad_scale, ws, stream);
 }
 
-int dbn_db_loss_ws_bytes() { return 1024 * NSUM * (int)sizeof(double); }
+// [1024][NSUM] partial sums (doubles) + the arrival counter of the in-kernel finalize (ZERO before the first call; left zero)
+static const long DB_LOSS_PART_BYTES = 1024L * NSUM * 8;
+int dbn_db_loss_ws_bytes() { return (int)DB_LOSS_PART_BYTES + 64; }
 
 // workspace of the per-pixel OHEM path: sums partials | pos partials | select partials | state | hist | v[N*H*W]
-static const long OHEM_OFF_POS = 1024L * NSUM * 8, OHEM_OFF_SEL = OHEM_OFF_POS + 1024L * 8, OHEM_OFF_ST = OHEM_OFF_SEL + 2048L * 8,
+static const long OHEM_OFF_POS = DB_LOSS_PART_BYTES + 64, OHEM_OFF_SEL = OHEM_OFF_POS + 1024L * 8, OHEM_OFF_ST = OHEM_OFF_SEL + 2048L * 8,
                   OHEM_OFF_HIST = OHEM_OFF_ST + 64, OHEM_OFF_V = OHEM_OFF_HIST + 3L * OHEM_BINS * 4;
 long dbn_db_loss_ohem_ws_bytes(int N, int H, int W) { return OHEM_OFF_V + (long)N * H * W * 4; }
 
@@ -785,12 +836,12 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     const bool vec = HW % 4 == 0;
     const int nb = dbn_grid((long)N * HW / (vec ? 4 : 1), 256, 1024);
     char* base = (char*)ws;
+    DbLossFinal fin = {(long)N * HW, channels, alpha, beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef,
+                       (unsigned*)(base + DB_LOSS_PART_BYTES)};
     if (vec)
-        hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
+        hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     else
-        hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws);
-    hipLaunchKernelGGL(db_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, (long)N * HW, channels, alpha,
-                       beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef);
+        hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     if (per_pixel != 1) return dbn_status();
     double* part_pos = (double*)(base + OHEM_OFF_POS);
     double* part_sel = (double*)(base + OHEM_OFF_SEL);

@@ -49,13 +49,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
 // Layers with few output elements and hundreds of pixel splits (64-channel layers at 160^2: 3 tiles x 340 splits) are
 // latency-bound on the chain of split loads: G thread groups share the splits (group g takes splits g, g+G, ...), their
 // fp64 partial sums are combined through LDS in group order — fixed summation order, bit-reproducible.
-__global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
-                                                              int BN, int Cb, int I, int RS, int G, float* __restrict__ grad,
-                                                              float scale, int natural) {
-    extern __shared__ double dsm[];  // [G][items][4] partial sums (G > 1), then the [64][RS] float staging image
+__device__ __forceinline__ void wgrad_reduce64_body(double* dsm, int o, int iy, const float* __restrict__ slab, int splitk, int O, int J,
+                                                    int Jp, int BM, int BN, int Cb, int I, int RS, int G, float* __restrict__ grad,
+                                                    float scale, int natural) {
     const int items = RS * 16;
     float* stage = reinterpret_cast<float*>(dsm + (G > 1 ? (size_t)G * items * 4 : 0));
-    const int o = blockIdx.x, i0 = blockIdx.y * 64;
+    const int i0 = iy * 64;
     const int om = o % BM;
     const int prow = natural ? o : (o / BM) * BM + (om & 3) * (BM / 4) + (om >> 2);  // inverse of tile_pos_to_index
     const long total4 = wgrad_slab_stride(O, Jp) >> 2;
@@ -106,6 +105,39 @@ __global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __res
     const int n = min(64, I - i0) * RS;  // channels >= I are padding of the activation tensor
     float* dst = grad + ((long)o * I + i0) * RS;
     for (int k = threadIdx.x; k < n; k += nthr) dst[k] = stage[k];
+}
+
+__global__ __launch_bounds__(1024) void wgrad_reduce64_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM,
+                                                              int BN, int Cb, int I, int RS, int G, float* __restrict__ grad,
+                                                              float scale, int natural) {
+    extern __shared__ double dsm[];  // [G][items][4] partial sums (G > 1), then the [64][RS] float staging image
+    wgrad_reduce64_body(dsm, blockIdx.x, blockIdx.y, slab, splitk, O, J, Jp, BM, BN, Cb, I, RS, G, grad, scale, natural);
+}
+
+// The slab reductions of MANY layers in one launch (dbn_wgrad_reduce_many): the side stream of a training step otherwise carries one
+// small reduction behind every weight-gradient kernel — 34 launches of 5-40 us that each hold the stream's next matrix kernel back
+// until their last workgroup has drained (0.46 ms of work, 4.6 ms in flight at bs16 640^2).  Workgroup b looks its job up in the
+// prefix table `first` (jobs' first workgroup; n_jobs + 1 entries) and runs wgrad_reduce64_kernel's body on it: same sums, same order.
+struct WgradReduceJob {  // == dbn_wgrad_reduce_job (include/dbnet_hip.h)
+    const float* slab;
+    float* grad;
+    int splitk, O, J, Jp, BM, BN, Cb, I, RS, G, natural, blocks;
+    float scale;
+    int smem_bytes;
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce64_many_kernel(const WgradReduceJob* __restrict__ jobs, const int* __restrict__ first,
+                                                                   int n_jobs) {
+    extern __shared__ double dsm[];
+    int lo = 0, hi = n_jobs - 1;  // the last job whose first workgroup is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const WgradReduceJob j = jobs[lo];
+    const int local = blockIdx.x - first[lo], ny = j.Cb / 64;
+    wgrad_reduce64_body(dsm, local / ny, local % ny, j.slab, j.splitk, j.O, j.J, j.Jp, j.BM, j.BN, j.Cb, j.I, j.RS, j.G, j.grad, j.scale,
+                        j.natural);
 }
 
 }  // namespace
@@ -238,8 +270,20 @@ int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int 
     return cfg + ((cfg & 16) == 0 && at == 0 && !dma && g_wgrad_row16 && wgrad_row_tw(Ho, Wo) ? 64 : 0);
 }
 
+// thread groups sharing the splits of wgrad_reduce64_kernel (>= 4 splits each), its block size and dynamic LDS
+static void wgrad_reduce64_plan(int RS, int splits_total, int& G, int& threads, size_t& smem) {
+    const int items = RS * 16;
+    G = std::min(1024 / items, splits_total / 4);
+    if (G < 1) G = 1;
+    if (G > 32) G = 32;
+    if (const int e = dbn_env_int("DBN_REDUCE_G", 0)) G = std::max(1, std::min(e, 1024 / items > 0 ? 1024 / items : 1));  // experiments
+    threads = std::min(1024, (items * G + 63) / 64 * 64);
+    smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)RS * 64 * sizeof(float);
+}
+
 static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,
-                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0, int phases = 3) {
+                     int Cb, int I, int R, int S, int stride, int pad, float scale, int ns, void* stream, int at = 0, int phases = 3,
+                     WgradReduceJob* reduce_job = nullptr) {
     DBN_REQUIRE(sm_ && big_ && slab && grad_oihw && (ns == 0 || ns == 1 || ns == 3) && phases >= 1 && phases <= 3);
     DBN_REQUIRE(at == 0 || (at == 1 && ns == 1) || (at == 3 && ns == 3));
     DBN_REQUIRE(O % 64 == 0 && Cb % 4 == 0 && I <= Cb && I > 0);
@@ -308,14 +352,19 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         splits_total += splitk;
     }
     if (!(phases & 2)) return DBN_OK;
+    if (reduce_job) {  // (dbn_wgrad_reduce_job: describe the reduction instead of launching it)
+        if (!(Cb % 64 == 0 && R * S * 64 * 4 <= 32 * 1024)) return DBN_ERR_ARG;
+        int G, threads;
+        size_t smem;
+        wgrad_reduce64_plan(R * S, splits_total, G, threads, smem);
+        *reduce_job = WgradReduceJob{slab, grad_oihw, splits_total, O, J, Jp, bm, bn, Cb, I, R * S, G, natural ? 1 : 0, O * (Cb / 64), scale,
+                                     (int)smem};
+        return DBN_OK;
+    }
     if (Cb % 64 == 0 && R * S * 64 * 4 <= 32 * 1024) {
-        const int items = R * S * 16;
-        int G = std::min(1024 / items, splits_total / 4);  // thread groups sharing the splits (>= 4 splits each)
-        if (G < 1) G = 1;
-        if (G > 32) G = 32;
-        if (const int e = dbn_env_int("DBN_REDUCE_G", 0)) G = std::max(1, std::min(e, 1024 / items > 0 ? 1024 / items : 1));  // experiments
-        const int threads = std::min(1024, (items * G + 63) / 64 * 64);
-        const size_t smem = (G > 1 ? (size_t)G * items * 4 * sizeof(double) : 0) + (size_t)R * S * 64 * sizeof(float);
+        int G, threads;
+        size_t smem;
+        wgrad_reduce64_plan(R * S, splits_total, G, threads, smem);
         hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,
                            R * S, G, grad_oihw, scale, natural ? 1 : 0);
     } else
@@ -336,6 +385,25 @@ int dbn_wgrad_phase_t(int phase, int at, int ns, const void* sm, const void* big
                       int O, int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* stream) {
     DBN_REQUIRE(phase == 1 || phase == 2);
     return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, stream, at, phase);
+}
+
+// Phase 2 of a dbn_wgrad_phase_t call DESCRIBED instead of launched: fills `job` (host memory, dbn_wgrad_reduce_job) for
+// dbn_wgrad_reduce_many.  Only layers whose activation tensor has a multiple of 64 channels (every layer but the stem) have this
+// form: DBN_ERR_ARG otherwise (the caller then runs phase 2 as its own launch).
+int dbn_wgrad_reduce_describe(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O,
+                              int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* job) {
+    DBN_REQUIRE(job);
+    return wgrad_run(sm, big, slab, grad_oihw, N, Ho, Wo, O, H, W, Cb, I, R, S, stride, pad, scale, ns, nullptr, at, 2,
+                     reinterpret_cast<WgradReduceJob*>(job));
+}
+// One launch for the slab reductions of n_jobs layers.  jobs: DEVICE array of n_jobs dbn_wgrad_reduce_job records (as filled by
+// dbn_wgrad_reduce_describe); first: DEVICE array of n_jobs + 1 ints, first[i] = sum of jobs[0..i-1].blocks; max_smem: the largest
+// smem_bytes of the jobs.  Same sums in the same order as the per-layer launches: bit-identical gradients.
+int dbn_wgrad_reduce_many(const void* jobs, const int* first, int n_jobs, int total_blocks, int max_smem, void* stream) {
+    DBN_REQUIRE(jobs && first && n_jobs > 0 && total_blocks > 0 && max_smem > 0 && max_smem <= 64 * 1024);
+    hipLaunchKernelGGL(wgrad_reduce64_many_kernel, dim3(total_blocks), dim3(1024), (size_t)max_smem, (hipStream_t)stream,
+                       reinterpret_cast<const WgradReduceJob*>(jobs), first, n_jobs);
+    return dbn_status();
 }
 
 int dbn_wgrad_f32(const float* sm, const float* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O, int H, int W,

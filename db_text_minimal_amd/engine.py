@@ -138,6 +138,9 @@ class Engine:
         self.nbt_pending = {}
         self._bias_done = set()
         self._bnb_sums = {}     # bn name -> (partials [2][C][rows], rows) produced by the data gradient that wrote its dout
+        self._reduce_pending = []    # deferred slab reductions of this backward pass: (key, job record)
+        self._reduce_job_cache = {}  # (layer, phase-2 arguments) -> dbn_wgrad_reduce_job
+        self._reduce_tables = {}     # tuple of keys -> device job table of one grouped launch
         self._by_ptr = {}       # data_ptr -> activation buffer (to find the pre-split planes of an operand)
         self._plane_cache = {}  # data_ptr -> (planes, generation)
         # 'bf16x3' mode, optional (DBN_PRESPLIT=1 / engine.presplit): MFMA operands read from pre-split bf16 planes (made once per
@@ -197,6 +200,7 @@ class Engine:
         self.flat, self.flat_grad, self.offsets = flat, grad, offs
         self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
         self._by_ptr, self._plane_cache = {}, {}
+        self._reduce_pending, self._reduce_job_cache, self._reduce_tables = [], {}, {}
         self.param_epoch += 1
 
     def flush_counters(self):
@@ -226,6 +230,7 @@ class Engine:
         if at != self.at:  # other storage type: every activation buffer and weight panel is stale
             self.bufs, self.packs, self.pack_src, self._pack_jobs = {}, {}, {}, None
             self._by_ptr, self._plane_cache = {}, {}
+            self._reduce_pending, self._reduce_job_cache, self._reduce_tables = [], {}, {}
             self.saved_generation = -1
         self.ns, self.at = ns, at
         self.math_mode = mode
@@ -592,10 +597,18 @@ class Engine:
         if self.prof:
             self.prof.end()
 
-    def wgrad(self, name, sm, big, O, I, k, stride, pad, gview):
+    # Slab reductions of the weight gradients: ONE grouped launch per gradient stage (dbn_wgrad_reduce_many) instead of one small
+    # launch behind every matrix kernel.  Each layer then keeps its own slab scratch (the reductions run later: ~1.7 GB at bs16 640^2).
+    defer_wgrad_reduce = True
+
+    def wgrad(self, name, sm, big, O, I, k, stride, pad, gview, defer=False):
+        """defer: the gradient is only needed by the optimizer / the gradient exchange, so its slab reduction may wait for
+        flush_wgrad_reduces() (conv_wgrad, convT_bwd); False: a kernel of this pass reads gview next (FPN level scatter, DCN)."""
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
-        slab = self.scratch('_wgrad_slab', self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
+        defer = defer and self.defer_wgrad_reduce and self.prof is None and Cb % 64 == 0
+        slab = self.scratch('_wgrad_slab/' + name if defer else '_wgrad_slab',
+                            self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
         at, smp, bigp = self.at, sm.data_ptr(), big.data_ptr()
         if self._use_planes and sm.dtype == torch.float32 and big.dtype == torch.float32:
             at, smp, bigp = 3, self._planes(sm).data_ptr(), self._planes(big).data_ptr()
@@ -615,13 +628,44 @@ class Engine:
             self.prof.begin('wgrad_reduce_kernel', 0.0, 0.0, 'wgrad reduce ' + name)
             check(self.L.dbn_wgrad_phase_t(2, *args), 'wgrad reduce ' + name)
             self.prof.end()
+        elif defer:
+            check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)
+            key = (name, args[:-1])
+            job = self._reduce_job_cache.get(key)
+            if job is None:
+                import ctypes
+                job = _lib.WgradReduceJob()
+                check(self.L.dbn_wgrad_reduce_describe(*args[:-1], ctypes.byref(job)), 'wgrad reduce describe ' + name)
+                self._reduce_job_cache[key] = job
+            self._reduce_pending.append((key, job))
         else:
             check(self.L.dbn_wgrad_t(*args), 'wgrad ' + name)
+
+    def flush_wgrad_reduces(self):
+        """The deferred slab reductions as ONE launch on the side stream (behind the matrix kernels that filled the slabs)."""
+        if not self._reduce_pending:
+            return
+        pending, self._reduce_pending = self._reduce_pending, []
+        sig = tuple(k for k, _ in pending)
+        ent = self._reduce_tables.get(sig)
+        if ent is None:
+            import ctypes
+            arr = (_lib.WgradReduceJob * len(pending))(*[j for _, j in pending])
+            first = [0]
+            for _, j in pending:
+                first.append(first[-1] + j.blocks)
+            dev = self.flat.device
+            ent = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), torch.tensor(first, dtype=torch.int32, device=dev),
+                   len(pending), first[-1], max(j.smem_bytes for _, j in pending))
+            self._reduce_tables[sig] = ent
+        table, first, n, blocks, smem = ent
+        with self.side_stream():
+            check(self.L.dbn_wgrad_reduce_many(table.data_ptr(), first.data_ptr(), n, blocks, smem, self.stream), 'wgrad_reduce_many')
 
     def conv_wgrad(self, name, dy, x, conv):
         self._presplit(dy, x)
         with self.side_stream():
-            self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'])
+            self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True)
             if conv.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
@@ -651,7 +695,7 @@ class Engine:
             self.prof.end()
         self._presplit(x, dy)
         with self.side_stream():
-            self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'])
+            self.wgrad(name, x, dy, Ci, Co, 2, 2, 0, self.grad_views[name + '.weight'], defer=True)
             if ct.bias is not None and name + '.bias' not in self._bias_done:
                 self.col_sum(dy, self.grad_views[name + '.bias'])
 
@@ -1069,6 +1113,7 @@ class Engine:
         self.up_bwd(dp4pre, dP['reduce_conv_c5'], 0, True)
         cbr_bwd('reduce_conv_c4', fpn.reduce_conv_c4, c4, dp4pre, dc4, False)
         cbr_bwd('reduce_conv_c5', fpn.reduce_conv_c5, c5, dP['reduce_conv_c5'], dc5, False)
+        self.flush_wgrad_reduces()  # FPN + head (one grouped launch per gradient stage: train.GRAD_STAGES)
         if self.grad_ready_hook is not None:  # every FPN / head gradient kernel has been enqueued
             with self.side_stream():  # announced from the side stream (it has waited for the main one): main is not stalled
                 self.grad_ready_hook('segmentation')
@@ -1089,6 +1134,8 @@ class Engine:
                     dx, acc = dpool, False
                 prev = 'backbone.layer%d.%d' % ((li, bi - 1) if bi > 0 else (li - 1, lastb[li - 1])) if (bi > 0 or li > 1) else None
                 self._block_bwd(name, layer[bi], xin, dout, dx, acc, prev=prev)
+            if li >= 3:
+                self.flush_wgrad_reduces()
             if self.grad_ready_hook is not None and li >= 3:
                 with self.side_stream():
                     self.grad_ready_hook('layer%d' % li)
@@ -1106,6 +1153,7 @@ class Engine:
             self.prof.end()
         dy0 = self.bn_backward('backbone.bn1', y0, None, dz, 'stem/dy', sums=parts, sums_parts=nparts)
         self.conv_wgrad('backbone.conv1', dy0, B['x4w' if self.at != 0 else 'x4'], bb.conv1)
+        self.flush_wgrad_reduces()
         self.join_side()
         self.saved_generation = -1
         self.backwards_since_clear += 1  # FusedAdam.step refuses gradients that a second backward pass overwrote

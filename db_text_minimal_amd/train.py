@@ -190,6 +190,7 @@ class DBTrainer:
         need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if per_pixel else L.dbn_db_loss_ws_bytes()) // 4 + 1
         if self._ws is None or self._ws.numel() < need:
             self._ws = engine_mod.device_empty(need, dev)
+            self._ws[:L.dbn_db_loss_ws_bytes() // 4].zero_()  # the arrival counter of the in-kernel finalize starts at zero (left zero)
         losses = engine_mod.device_empty(5, dev)
         fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
         eng = self.model.engine

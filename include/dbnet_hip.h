@@ -232,7 +232,10 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
                       const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
                       float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
 
-/* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W] */
+/* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W].
+ * One launch: the workgroup that finishes last folds every workgroup's partial sums (fixed order) and writes losses[5] and
+ * coef[8].  ws: dbn_db_loss_ws_bytes() bytes, ZERO-FILLED by the caller before the first call (it ends with the arrival counter
+ * of that hand-over, which every call leaves at zero); not shared between calls that may run concurrently. */
 int dbn_db_loss_ws_bytes(void);
 int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                     float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
@@ -245,7 +248,8 @@ int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int 
 
 /* DBLoss(reduction='none') — true per-pixel OHEM (losses.py:30-39 with a per-pixel BCE): the n_neg largest
  * negative losses are found by a 3-pass radix select on device (no sort, no host sync).  `ws` holds
- * dbn_db_loss_ohem_ws_bytes(N,H,W) bytes and must stay untouched between _fwd and _bwd. */
+ * dbn_db_loss_ohem_ws_bytes(N,H,W) bytes (the first dbn_db_loss_ws_bytes() of them zero-filled before the first call, as above)
+ * and must stay untouched between _fwd and _bwd. */
 long dbn_db_loss_ohem_ws_bytes(int N, int H, int W);
 int dbn_db_loss_ohem_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                          float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
@@ -364,6 +368,21 @@ int dbn_set_patch_conv(int on);
    (kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid) — the template arguments of its rocprofv3 symbol */
 int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,
                             int pad, int tile_hint, int ksplit);
+/* The slab reductions (phase 2) of many dbn_wgrad_phase_t calls in ONE launch.  dbn_wgrad_reduce_describe takes phase 2's
+ * arguments and fills a host-side job record instead of launching (DBN_ERR_ARG for layers without the 64-channel reduction form:
+ * the stem); the caller uploads the records and the prefix table of their `blocks` and calls dbn_wgrad_reduce_many.  Same sums
+ * in the same order as the per-layer launches.  (A training step's side stream otherwise carries one small reduction behind
+ * every weight-gradient kernel; conv / ConvTranspose weight gradients of resnet.py:70-91, basic.py:32-36, segmentation_head.py:24-29.) */
+typedef struct dbn_wgrad_reduce_job {
+    const float* slab;
+    float* grad;
+    int splitk, O, J, Jp, BM, BN, Cb, I, RS, G, natural, blocks;
+    float scale;
+    int smem_bytes;
+} dbn_wgrad_reduce_job;
+int dbn_wgrad_reduce_describe(int at, int ns, const void* sm, const void* big, float* slab, float* grad_oihw, int N, int Ho, int Wo, int O,
+                              int H, int W, int Cb, int I, int R, int S, int stride, int pad, float scale, void* job);
+int dbn_wgrad_reduce_many(const void* jobs, const int* first, int n_jobs, int total_blocks, int max_smem, void* stream);
 /* tile variant of the weight-gradient kernel for O output channels, J = R*S*Cb columns: 1 = 64x192, 2 = 128x128, 3 = 64x128, 4 = 64x64 */
 int dbn_wgrad_tile_config(int O, int J);
 /* dbn_wgrad_t in two calls: phase 1 = matrix kernels (-> slabs), phase 2 = slab reduction (-> grad_oihw) */

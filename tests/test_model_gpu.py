@@ -896,3 +896,27 @@ def test_fused_adam_refuses_gradient_accumulation():
     opt.step()  # one pass since zero_grad(): fine
     crit(model(img.to(DEV)), gts.to(DEV))[4].backward()
     opt.step()  # step() also clears the count (the reference calls zero_grad() first anyway, train.py:169-172)
+
+
+@pytest.mark.parametrize('math,arch', [('f32', 'resnet18'), ('bf16', 'resnet18'), ('f32', 'resnet50')])
+def test_grouped_slab_reduction_is_bit_identical_to_per_layer_launches(math, arch):
+    """engine.defer_wgrad_reduce: the weight gradients' slab reductions run as one grouped launch per gradient stage
+    (dbn_wgrad_reduce_many over a device job table) instead of one small launch behind every matrix kernel.  Same sums in the same
+    order: after two training steps gradients and parameters must equal the per-layer form bit for bit — also through the
+    bucketed-exchange hook points, which flush the pending reductions before a bucket is announced."""
+    seed = 6
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    img, gts = img.to(DEV), gts.to(DEV)
+    outs = []
+    for defer in (False, True):
+        model = make_model(seed, arch).train()
+        model.engine.set_conv_math(math)
+        model.engine.defer_wgrad_reduce = defer
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        for _ in range(2):
+            tr.step(img, gts)
+        torch.cuda.synchronize()
+        assert bool(model.engine._reduce_tables) == defer and not model.engine._reduce_pending
+        outs.append((model.engine.flat_grad.clone(), model.engine.flat.clone()))
+    assert float(outs[0][0].abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
