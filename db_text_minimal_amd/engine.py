@@ -599,7 +599,7 @@ class Engine:
 
     # Slab reductions of the weight gradients: ONE grouped launch per gradient stage (dbn_wgrad_reduce_many) instead of one small
     # launch behind every matrix kernel.  Each layer then keeps its own slab scratch (the reductions run later: ~1.7 GB at bs16 640^2).
-    defer_wgrad_reduce = True
+    defer_wgrad_reduce = os.environ.get('DBN_DEFER_REDUCE', '1') == '1'  # (0: the per-layer launches, for A/B runs)
 
     def wgrad(self, name, sm, big, O, I, k, stride, pad, gview, defer=False):
         """defer: the gradient is only needed by the optimizer / the gradient exchange, so its slab reduction may wait for
