@@ -156,21 +156,25 @@ static bool convt_eligible(int mode, int ns, int at, int tile_hint, int R, int S
 // ... and the output of one launch (n images) below 4 GB: the kernel addresses rows with 32-bit byte offsets
 static bool convt_launch_ok(int n, int Hd, int Wd, int Cd) { return (long)n * Hd * Wd * Cd * 4 < (1L << 32); }
 
-static int g_patch_enabled = 1;
+static int g_patch_enabled = 1;  // 0: never; 1: every eligible launch; 2: the 16-bit matrix modes only (exact fp32 takes the gather loop)
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
 int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
     const int old = g_patch_enabled;
-    g_patch_enabled = on != 0;
+    g_patch_enabled = (on == 2) ? 2 : (on != 0);
     return old;
 }
 // pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
 // partial rows of a launch are the same N*H*W/128 either way); kmode: kernel MODE
+// Exact fp32 (ns = 0, round 4): the same form with 16-channel blocks on v_mfma_f32_32x32x2_f32, 128 x 64 tiles whatever the generic
+// heuristic picked (its choice for these layers is the 64 x 64 gather tile) — unless the caller names another tile.
 static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int stride, int pad, int Hs, int Ws, int Hd, int Wd, int Cs,
-                           int ksplit) {
-    return g_patch_enabled && (kmode == 0 || kmode == 1) && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && R == 3 && S == 3 && stride == 1 &&
-           pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 && Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
+                           int ksplit, int tile_hint = 0) {
+    const bool geom = (kmode == 0 || kmode == 1) && R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 &&
+                      Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
+    if (ns == 0) return g_patch_enabled == 1 && at == 0 && geom && (tile_hint == 0 || tile_hint == 3);
+    return g_patch_enabled && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && geom;
 }
-static int patch_cfg(int cfg) { return (cfg == 1 && g_patch_bn64) ? 3 : cfg; }
+static int patch_cfg(int cfg, int ns = 1) { return (ns == 0 || (cfg == 1 && g_patch_bn64)) ? 3 : cfg; }
 
 // Tile configuration of a dbn_igemm / dbn_conv_bn call (`mode`, `stride` as the caller passes them).  The convolutions that can take
 // the pixel-patch kernel get a 128-row tile whatever the generic heuristic says.
@@ -178,7 +182,8 @@ static int resolve_cfg(int M_total, int Cd, int tile_hint, int at = 0, int ns = 
                        int pad = 0, int Hs = 0, int Ws = 0, int Hd = 0, int Wd = 0, int Cs = 0, int ksplit = 1) {
     int cfg = tile_hint > 0 ? tile_hint : tile_config_for(M_total, Cd, ns);
     if (cfg == 1 && Cd % 128 != 0) cfg = 3;
-    if (tile_hint == 0 && !(mode == 1 && stride > 1) && patch_eligible(mode, ns, at, 3, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) cfg = 3;
+    if (tile_hint == 0 && !(mode == 1 && stride > 1) && Cd % 64 == 0 && patch_eligible(mode, ns, at, 3, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit))
+        cfg = 3;
     return cfg;
 }
 
@@ -189,7 +194,7 @@ int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, in
                             int pad, int tile_hint, int ksplit) {
     const int cfg = resolve_cfg(N * Hd * Wd, Cd, tile_hint, at, ns, kmode >= 2 ? 1 : kmode, R, S, kmode == 2 && stride == 1 ? 2 : stride, pad, Hs,
                                 Ws, Hd, Wd, Cs, ksplit);
-    if (patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit)) return patch_cfg(cfg) + 16;
+    if (Cd % 64 == 0 && patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit, tile_hint)) return patch_cfg(cfg, ns) + 16;
     // + 32: the launch is convt2x2_f32_kernel<Cs> (a non-accumulating transposed 2x2 / stride-2 conv in exact fp32)
     if (kmode == 2 && convt_eligible(1, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, 0, ksplit)) return cfg + 32;
     return cfg;
@@ -199,11 +204,11 @@ static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipS
     // tile choice from the total row count (for parity classes: all classes together)
     int cfg = tile_hint > 0 ? tile_hint : tile_config_for(p.N * p.Hdf * p.Wdf, p.Cd, ns);
     if (cfg == 1 && p.Cd % 128 != 0) cfg = 3;
-    p.patch = patch_eligible(kmode, ns, at, cfg, p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hdf, p.Wdf, p.Cs, p.ksplit);
+    p.patch = p.Cd % 64 == 0 && patch_eligible(kmode, ns, at, cfg, p.R, p.S, p.stride, p.pad, p.Hs, p.Ws, p.Hdf, p.Wdf, p.Cs, p.ksplit, tile_hint);
     // 128 x 64 tiles also where the generic loop takes 128 x 128: K is short (two to eight channel blocks), so twice the workgroups
     // hide the prologue / epilogue better than the wider tile saves weight traffic (measured: 120.8 GFLOP launch 509 -> ~270 us;
     // step +1-3 %); the BatchNorm partial rows depend on BM only.  DBN_PATCH_BN64=0 keeps the generic choice.
-    if (p.patch) cfg = patch_cfg(cfg);
+    if (p.patch) cfg = patch_cfg(cfg, ns);
     return launch_igemm(p, cfg, kmode, ns, st, at);
 }
 

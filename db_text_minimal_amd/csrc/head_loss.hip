@@ -393,23 +393,30 @@ __device__ __forceinline__ void db_loss_finish(const double (&s)[NSUM], const Db
     }
 }
 
-// one 256-thread block: 32 lanes fold each of the NSUM (<= 8) partial columns in a fixed order, thread 0 finishes.
-// The partials were written by other workgroups of THIS launch: agent-scope loads (never a stale line of this CU's L1).
-__device__ __forceinline__ void db_loss_fold_and_finish(const double* __restrict__ part, int nb, const DbLossFinal& f, double* sums) {
-    {
-        const int k = threadIdx.x >> 5, l32 = threadIdx.x & 31;
-        double t = 0.0;
-        if (k < NSUM)
-            for (int b = l32; b < nb; b += 32)
-                t += __hip_atomic_load(part + (long)b * NSUM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The last workgroup (256 threads) folds every workgroup's row in a FIXED order and thread 0 finishes.  The partials were written
+// by other workgroups of THIS launch: agent-scope loads (never a stale line of this CU's L1).  All of a thread's loads are issued
+// before the first is used — a 32-lane team walking its column with one dependent load per trip took 30 us of a 50 us kernel.
+__device__ __forceinline__ void db_loss_fold_and_finish(const double* __restrict__ part, int nb, const DbLossFinal& f, double* red /* [4][8] */) {
+    constexpr int PER = 4;  // rows per thread: nb <= 1024 = 256 * PER
+    double v[PER][NSUM];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        if (l32 == 0 && k < 8) sums[k] = t;
+    for (int i = 0; i < PER; ++i) {
+        const int b = threadIdx.x + i * 256;
+#pragma unroll
+        for (int k = 0; k < NSUM; ++k)
+            v[i][k] = b < nb ? __hip_atomic_load(part + (long)b * NSUM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // (red was read by the partial-row store above)
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+        const double w = dbn_wave_sum_d((v[0][k] + v[1][k]) + (v[2][k] + v[3][k]));
+        if (lane == 0) red[wave * 8 + k] = w;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
     double s[NSUM];
-    for (int k = 0; k < NSUM; ++k) s[k] = sums[k];
+    for (int k = 0; k < NSUM; ++k) s[k] = (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k]);
     db_loss_finish(s, f);
 }
 

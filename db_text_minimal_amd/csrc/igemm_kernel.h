@@ -48,7 +48,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     static_assert(EPI == 0 || ((AT == 0 || AT == 1) && MODE < 3), "BatchNorm-backward sums: fp32 or bf16 storage, no pyramid form");
     static_assert(BLK || (AT == 0 && MODE == 0 && !PATCH && EPI == 0), "non-blocked K walk: forward conv on fp32 tensors");
     static_assert(AT == 0 || ((AT == 1 || AT == 2) && NS == 1) || (AT == 3 && NS == 3), "storage type / matrix math combination");
-    static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && NS > 0 && AT != 3), "patch form");
+    static_assert(!PATCH || (BM == 128 && WM == 2 && WN == 2 && MODE < 2 && (NS > 0 || AT == 0) && AT != 3), "patch form");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // between them).  Measured (interleaved A/B on one box): bf16x3 714 -> 732 images/s; the single-plane kernels (bf16 storage,
     // two patch buffers, ten barriers per block that also pace the ring) lose with it: 1644 -> 1620 — they keep the ring.
     constexpr bool DBP = DBN_DIRECTBP && PATCH && NS == 3;
-    constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + (DBP ? 0 : P_NSTG * P_BSTAGE) : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
+    constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + ((DBP || NS == 0) ? 0 : P_NSTG * P_BSTAGE) : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
     constexpr int EPI_SMEM = (EPI == 1 && DST_F32) ? BM * BN / (4 * (MI >= 2 ? 2 : 1)) : 0;
     // (16-bit destinations: the output tile is staged through LDS, BM rows of BN + 8 elements)
     constexpr int OUT_SMEM = DST_F32 ? 0 : (BM * (BN + 8) * 2 + 15) / 16;
@@ -493,7 +493,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // {0-3,12-15,20-27}, {4-11,16-19,28-31}) reads 16 consecutive pixels of one patch row — conflict-free for every tap.
     // The weight panels stream through a ring of DMA stages as in the generic 16-bit loop below.
     constexpr int PPX = 180, PROW = 18;
-    constexpr int CHUNKS = AT == 0 ? 8 : 4;           // 16-byte pieces per pixel of a 32-channel block
+    // exact fp32 (NS == 0, round 4): the channel block is ONE k-step wide — 16 channels = four 16-byte chunks per pixel, image
+    // [chunk][patch pixel][4 f32]; the fragment of lane (li, lh) for MFMA group s2 is chunk 2*s2 + lh of its pixel, as in the gather loop
+    constexpr int CB = NS == 0 ? 16 : 32;             // channels per block
+    constexpr int CHUNKS = NS == 0 ? 4 : AT == 0 ? 8 : 4;  // 16-byte pieces per pixel of a channel block
     constexpr int PL = (PPX * CHUNKS + NT - 1) / NT;  // pieces per thread
     constexpr int B_I = NSX * 2 * (BN / 64);          // DMA instructions per unit
     static_assert((2 * B_I) % 4 == 0 && NT == 256, "weight DMA is dealt evenly to four waves");
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         const bool v = on && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
         poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * (unsigned)ES + (unsigned)chunk * 16u : OOB_OFFSET;
         // fp32 source: chunk = 4 channels = one 8-byte half of slice chunk >> 1 (slot in 8-byte units); 16-bit: chunk = slice
-        pslot[j] = !on ? -1 : AT == 0 ? ((chunk >> 1) * PPX + pix) * 2 + (chunk & 1) : chunk * PPX + pix;
+        pslot[j] = !on ? -1 : NS == 0 ? chunk * PPX + pix : AT == 0 ? ((chunk >> 1) * PPX + pix) * 2 + (chunk & 1) : chunk * PPX + pix;
     }
     f32x4 pr[PL];
-    const int ncb = p.Cs >> 5;
+    const int ncb = p.Cs / CB;
     auto load_patch = [&](int cb) {  // (cb == ncb: the loads are issued all the same, so that the counted waits stay constant)
-        const unsigned add = (unsigned)(cb * 32 * ES);
+        const unsigned add = (unsigned)(cb * CB * ES);
 #pragma unroll
         for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
     };
@@ -528,7 +531,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
             if (pslot[j] < 0) continue;
-            if constexpr (AT == 0) {
+            if constexpr (NS == 0) {
+                P[pslot[j]] = pr[j];
+            } else if constexpr (AT == 0) {
                 u32x2 sp[NSX];
                 split4<NS>(pr[j], sp);
 #pragma unroll
@@ -567,7 +572,95 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     const int q4 = li >> 2;
     const int a_pix = (2 * wm * MI + (__builtin_popcount(q4) & 1)) * PROW + (q4 >> 1) * 4 + (li & 3) + lh * PPX;
 
-    if constexpr (DBP) {
+    if constexpr (NS == 0) {
+        // ---- exact fp32 (v_mfma_f32_32x32x2_f32) over the pixel patch.  A 3x3 / stride-1 conv re-reads every input pixel nine times;
+        // the gather loop fetches each of them from L1 / L2 again (nine 16-byte gathers per row and channel block, each with its
+        // padding test and staging write, one barrier per k-step).  Here a channel block's 10 x 18 patch is fetched ONCE (three
+        // 16-byte loads per thread), and the nine k-steps of the block read their A fragments at LDS offsets of the same image:
+        // per k-step a wave issues MI * 2 fragment reads, 2 * NI weight-fragment loads (contiguous, straight into registers as in the
+        // gather loop) and MI * NI * 8 MFMAs — no address arithmetic, no staging write, no barrier; one barrier per NINE k-steps.
+        // Same products in the same k order per accumulator as the gather form: bit-identical results.
+        unsigned bvo[2][NI];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) bvo[s2][b] = (unsigned)((2 * s2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
+        const unsigned bstep32 = (unsigned)(4 * p.Cd) * 16u;  // bytes per k-tile of the fp32 panel
+        const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk + q_wpk_off), 0,
+                                                                               (unsigned)qKT * bstep32, 0x00020000);
+        int w_kt = 0;  // next weight k-tile (clamped to the last one: the fetches past the end re-read it and are never used)
+        f32x4 rw[3][2][NI];  // three fragment sets: k-step g uses set g % 3 (nine k-steps per block: tap % 3), fetched two k-steps ahead
+        auto issue_w = [&](auto SET) {
+            constexpr int st_ = decltype(SET)::value;
+            const unsigned so = (unsigned)min(w_kt, qKT - 1) * bstep32;
+            ++w_kt;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) {
+                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                    const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, (int)bvo[s2][b], (int)so, 0);
+                    rw[st_][s2][b] = __builtin_bit_cast(f32x4, v_);
+                }
+        };
+        load_patch(0);
+        issue_w(std::integral_constant<int, 0>{});
+        issue_w(std::integral_constant<int, 1>{});
+        store_patch(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // two channel blocks per trip (Cs % 32 == 0, checked on the host), so that the patch buffer of a block is a compile-time
+        // LDS offset of its fragment reads
+        auto block = [&](int cb, auto ODD) {
+            constexpr int odd = decltype(ODD)::value;
+            const f32x4* const P = patch + odd * P_PATCH;
+            load_patch(cb + 1);  // (past the last block: out-of-range offsets, zeros, never stored)
+            auto tap_step = [&](auto TAP) {
+                constexpr int tap = decltype(TAP)::value;
+                constexpr int cur = tap % 3;
+                constexpr int tr = MODE == 0 ? tap / 3 : 2 - tap / 3, ts = MODE == 0 ? tap % 3 : 2 - tap % 3;
+                issue_w(std::integral_constant<int, (tap + 2) % 3>{});  // the weight fragments of the k-step after the next
+                __builtin_amdgcn_sched_barrier(0);  // (left alone the loads sink down to one MFMA group before their use)
+                f32x4 af[2][MI];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int a = 0; a < MI; ++a) af[s2][a] = P[2 * s2 * PPX + a_pix + (2 * a + tr) * PROW + ts];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int a = 0; a < MI; ++a)
+#pragma unroll
+                            for (int b = 0; b < NI; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2][a][e], rw[cur][s2][b][e], acc[a][b], 0, 0, 0);
+            };
+            tap_step(std::integral_constant<int, 0>{});
+            tap_step(std::integral_constant<int, 1>{});
+            tap_step(std::integral_constant<int, 2>{});
+            tap_step(std::integral_constant<int, 3>{});
+            tap_step(std::integral_constant<int, 4>{});
+            tap_step(std::integral_constant<int, 5>{});
+            tap_step(std::integral_constant<int, 6>{});
+            tap_step(std::integral_constant<int, 7>{});
+            tap_step(std::integral_constant<int, 8>{});
+            if (cb + 1 < ncb) {
+                // the other buffer was last read in block cb - 1, and every wave has passed the barrier that ended it
+                store_patch(odd ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+        for (int cb = 0; cb < ncb; cb += 2) {
+            block(cb, std::integral_constant<int, 0>{});
+            block(cb + 1, std::integral_constant<int, 1>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if constexpr (DBP) {
         unsigned bvo[NSX][NI];
 #pragma unroll
         for (int t = 0; t < NSX; ++t)
@@ -1655,7 +1748,7 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
     const bool epi_ok = gy == 1 && p.bnb_y && p.bnb_mean && p.bnb_rstd && (p.bnb_zmask || (p.bnb_msc && p.bnb_msh)) &&
                         (!p.bnb_y2 || (p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2));
-    if constexpr (BM == 128 && WM == 2 && WN == 2 && NS > 0 && AT != 3) {
+    if constexpr (BM == 128 && WM == 2 && WN == 2 && (NS > 0 || BN == 64) && AT != 3) {  // (exact fp32: the 128 x 64 tile only)
         if (p.patch && mode < 2) {
             if constexpr (AT == 0 || AT == 1) {
                 if (p.bnb_part) {

@@ -1151,14 +1151,16 @@ def test_weight_gradient_lds_dma_variant(case):
     report('wgrad variants agree', g.cpu(), g0.cpu(), 1e-5 * float(gref.abs().max()), 1e-5)
 
 
-@pytest.mark.parametrize('mode_name', ['bf16x3', 'bf16c', 'bf16', 'fp16'])
-@pytest.mark.parametrize('Co,tile', [(64, 3), (128, 1), (128, 3)])
+@pytest.mark.parametrize('mode_name', ['f32', 'bf16x3', 'bf16c', 'bf16', 'fp16'])
+@pytest.mark.parametrize('Co,tile', [(64, 3), (128, 1), (128, 3), (64, 0), (128, 0)])
 def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
-    """3x3 / stride-1 convolutions and their data gradients in the 16-bit matrix modes run in the pixel-patch form (the input patch
-    of an 8 x 16 output tile staged in LDS once per 32-channel block, taps as LDS offsets).  Same k order, same MFMA sequence per
-    accumulator as the generic gather loop: the results are BIT-IDENTICAL to it (dbn_set_patch_conv(0)), including the fused
-    bias, the accumulate form and, through it, everything the generic loop is tested against."""
-    ns, dtype = {'bf16x3': (3, torch.float32), 'bf16c': (1, torch.float32), 'bf16': (1, torch.bfloat16), 'fp16': (1, torch.float16)}[mode_name]
+    """3x3 / stride-1 convolutions and their data gradients run in the pixel-patch form (the input patch of an 8 x 16 output tile
+    staged in LDS once per channel block — 32 channels in the 16-bit matrix modes, 16 in exact fp32 (round 4) — taps as LDS
+    offsets).  Same k order, same MFMA sequence per accumulator as the generic gather loop: the results are BIT-IDENTICAL to it
+    (dbn_set_patch_conv(0)), including the fused bias, the accumulate form and, through it, everything the generic loop is tested
+    against.  tile 0: the library's own choice (exact fp32: the 128 x 64 patch kernel against the 64 x 64 gather tile)."""
+    ns, dtype = {'f32': (0, torch.float32), 'bf16x3': (3, torch.float32), 'bf16c': (1, torch.float32), 'bf16': (1, torch.bfloat16),
+                 'fp16': (1, torch.float16)}[mode_name]
     kind = 2 if dtype == torch.float16 else ns
     N, Ci, H, W = 2, 128, 24, 48   # four 32-channel blocks, 3 x 3 patches per image
     x = nhwc(rnd(N, Ci, H, W, seed=11)).to(dtype)
@@ -1176,7 +1178,10 @@ def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
         return y, d
 
     try:
-        assert L().dbn_set_patch_conv(1) in (0, 1)
+        assert L().dbn_set_patch_conv(1) in (0, 1, 2)
+        if tile in (0, 3):  # (exact fp32 has the 128 x 64 patch kernel only; 128 x 128 stays on the gather loop)
+            cfg = L().dbn_igemm_kernel_config(AT_OF[dtype], ns, 0, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, tile, 1)
+            assert cfg & 16, 'the patch kernel was not selected (config %d)' % cfg
         y1, d1 = run()
         L().dbn_set_patch_conv(0)
         y0, d0 = run()
@@ -1188,21 +1193,23 @@ def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
     # and against fp64: on the operands as stored for 16-bit storage; bf16x3 is fp32-accurate on fp32 operands
     wq = w.to(dtype).double() if dtype != torch.float32 else w.double()
     ref = F.conv2d(nchw(x.double()), wq, b.double().cpu(), 1, 1)
-    tol = {'bf16x3': 2e-6, 'bf16c': 2e-2, 'bf16': 2e-2, 'fp16': 3e-3}[mode_name]
+    tol = {'f32': 2e-6, 'bf16x3': 2e-6, 'bf16c': 2e-2, 'bf16': 2e-2, 'fp16': 3e-3}[mode_name]
     err = float((nchw(y1.double()) - ref).abs().max()) / float(ref.abs().max())
     assert err < tol, err
 
 
-@pytest.mark.parametrize('mode_name', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('mode_name', ['f32', 'bf16', 'bf16x3'])
 def test_pixel_patch_convolution_is_race_free_at_full_size(mode_name):
     """The pixel-patch kernels pipeline LDS-DMA weight stages and register-staged patches across raw barriers (counted vmcnt,
     lgkmcnt(0) before each barrier).  A missing wait does not show on small grids — every workgroup alone on its CU — but did at
     the benchmark's size (several workgroups per CU, thousands of tiles): repeat full-size launches (16 x 160 x 160, both 128-row
     tiles, forward and data gradient) and require every run to equal the generic gather form bit for bit."""
-    ns, dtype = {'bf16x3': (3, torch.float32), 'bf16': (1, torch.bfloat16)}[mode_name]
+    ns, dtype = {'f32': (0, torch.float32), 'bf16x3': (3, torch.float32), 'bf16': (1, torch.bfloat16)}[mode_name]
     N, H, W = 16, 160, 160
     g = torch.Generator(device=DEV).manual_seed(3)
     for (Ci, Co, tile, mode) in ((64, 256, 1, 1), (256, 64, 3, 0), (128, 128, 1, 1), (128, 128, 1, 0)):
+        if ns == 0:
+            tile = 3  # (the exact-fp32 patch kernel exists for the 128 x 64 tile)
         w = rnd(Co, Ci, 3, 3, seed=2, scale=0.05)
         cin, cout = (Ci, Co) if mode == 0 else (Co, Ci)
         x = torch.randn(N, H, W, cin, device=DEV, generator=g).to(dtype)
