@@ -156,6 +156,14 @@ static bool convt_eligible(int mode, int ns, int at, int tile_hint, int R, int S
 // ... and the output of one launch (n images) below 4 GB: the kernel addresses rows with 32-bit byte offsets
 static bool convt_launch_ok(int n, int Hd, int Wd, int Cd) { return (long)n * Hd * Wd * Cd * 4 < (1L << 32); }
 
+int dbn_g_stagger = 0;
+// permille of the nominal first-round stagger of the exact-fp32 implicit-GEMM launches (igemm_kernel.h); 0 = off.  Returns the old value.
+int dbn_set_stagger(int permille) {
+    const int old = dbn_g_stagger;
+    dbn_g_stagger = permille < 0 ? 0 : permille;
+    return old;
+}
+
 static int g_patch_enabled = 1;  // 0: never; 1: every eligible launch; 2: the 16-bit matrix modes only (exact fp32 takes the gather loop)
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
 int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again

@@ -102,6 +102,9 @@ struct IgemmParams {
     int tile_end[MAX_CLASSES], row_base[MAX_CLASSES], wpk_off[MAX_CLASSES];
     // split-K (MODE 0/1, Cs % 16 == 0): workgroup row blockIdx.y reduces k-tiles [y*kt_per, (y+1)*kt_per) into slab y of dst
     int ksplit, kt_per;
+    // First-round stagger (see igemm_f32_kernel): workgroups with blockIdx.x < stagger_blocks wait (their wave slot) * stagger_units
+    // * 1024 clocks before they start, so that the workgroups sharing a CU run out of phase.  0: off.
+    int stagger_units, stagger_blocks;
     int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
     int patch;          // host only: use the pixel-patch form (3x3, stride 1; see igemm_dispatch)
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
@@ -110,6 +113,9 @@ struct IgemmParams {
     unsigned seg_bytes[4];
     unsigned seg_plane_bytes[4];  // AT = 3
 };
+
+// permille of the nominal first-round stagger (0 = off): dbn_set_stagger
+extern "C" int dbn_g_stagger;
 
 namespace {
 

@@ -134,6 +134,18 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    // First-round stagger.  Every workgroup of a launch takes the same time, and the first 256 x (workgroups per CU) of them start
+    // together: the workgroups sharing a CU then run in LOCKSTEP for the whole launch — all in their prologue (index arithmetic, first
+    // loads: no MFMA) at the same time, all in their epilogue at the same time — and the matrix pipe idles through every such phase
+    // (profile by deletion: ~4 us per 128 x 64 tile exposed whatever K is: 0.79 of peak at K = 576 with every load deleted, 0.94 at
+    // K = 2304).  Delaying the first-round workgroup in wave slot j by j / slots of a tile time puts the residents of a CU out of phase;
+    // later workgroups inherit the offsets because each starts when its predecessor in the slot ends.
+    if (p.stagger_units > 0 && (int)blockIdx.x < p.stagger_blocks) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;  // HW_REG_HW_ID.WAVE_ID: this wave's slot on its SIMD
+        const unsigned n = __builtin_amdgcn_readfirstlane(slot * (unsigned)p.stagger_units);
+        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
+    }
+
     int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
     IgemmClass q;
     int q_row_base = 0, q_wpk_off = 0;
@@ -1745,6 +1757,19 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     if (p.stat_rows <= 0) p.stat_rows = rows;  // a chunked call sets the total itself
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
+    p.stagger_units = p.stagger_blocks = 0;
+    if (dbn_g_stagger > 0 && NS == 0 && AT == 0 && mode < 2 && p.ksplit <= 1) {
+        // exact fp32: a k-step is MI * NI * 8 MFMAs of 64 clocks per wave; the residents of a SIMD share its matrix pipe, so one slot
+        // step = one workgroup's own loop time.  Only when the grid is more than one round of residents (otherwise nothing repeats).
+        constexpr int MI_ = BM / WM / 32, NI_ = BN / WN / 32;
+        const int slots = (BM * BN <= 4096) ? 7 : (BM * BN <= 8192) ? 4 : 3;  // resident workgroups per CU of these instantiations
+        const long kt = ((long)p.R * p.S * p.Cs + 15) / 16;
+        const long units = kt * MI_ * NI_ * 8 * 64 / 1024 * dbn_g_stagger / 1000;
+        if (grid > 256 * slots && units > 0) {
+            p.stagger_units = (int)std::min<long>(units, 4096);
+            p.stagger_blocks = 256 * slots;
+        }
+    }
     const int gy = (mode < 2 && p.ksplit > 1) ? p.ksplit : 1;
     const bool epi_ok = gy == 1 && p.bnb_y && p.bnb_mean && p.bnb_rstd && (p.bnb_zmask || (p.bnb_msc && p.bnb_msh)) &&
                         (!p.bnb_y2 || (p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2));
