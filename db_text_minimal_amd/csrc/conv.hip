@@ -156,6 +156,15 @@ static bool convt_eligible(int mode, int ns, int at, int tile_hint, int R, int S
 // ... and the output of one launch (n images) below 4 GB: the kernel addresses rows with 32-bit byte offsets
 static bool convt_launch_ok(int n, int Hd, int Wd, int Cd) { return (long)n * Hd * Wd * Cd * 4 < (1L << 32); }
 
+unsigned long long* dbn_g_trace = nullptr;
+long dbn_g_trace_blocks = 0;
+// -DDBN_TRACE=1 builds: the next exact-fp32 implicit-GEMM launches of at most `max_blocks` workgroups write [grid][8] timestamps to buf
+// (see IgemmParams::trace); null switches it off.  Product builds accept the call and ignore it.
+int dbn_set_trace(void* buf, long max_blocks) {
+    dbn_g_trace = reinterpret_cast<unsigned long long*>(buf);
+    dbn_g_trace_blocks = max_blocks;
+    return DBN_TRACE;
+}
 int dbn_g_stagger = 0;
 // permille of the nominal first-round stagger of the exact-fp32 implicit-GEMM launches (igemm_kernel.h); 0 = off.  Returns the old value.
 int dbn_set_stagger(int permille) {

@@ -397,21 +397,21 @@ __device__ __forceinline__ void db_loss_finish(const double (&s)[NSUM], const Db
 // by other workgroups of THIS launch: agent-scope loads (never a stale line of this CU's L1).  All of a thread's loads are issued
 // before the first is used — a 32-lane team walking its column with one dependent load per trip took 30 us of a 50 us kernel.
 __device__ __forceinline__ void db_loss_fold_and_finish(const double* __restrict__ part, int nb, const DbLossFinal& f, double* red /* [4][8] */) {
-    constexpr int PER = 4;  // rows per thread: nb <= 1024 = 256 * PER
+    constexpr int PER = 4;  // rows per thread of the first four waves: nb <= 1024 = 256 * PER
     double v[PER][NSUM];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int b = threadIdx.x + i * 256;
 #pragma unroll
         for (int k = 0; k < NSUM; ++k)
-            v[i][k] = b < nb ? __hip_atomic_load(part + (long)b * NSUM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            v[i][k] = (b < nb && threadIdx.x < 256) ? __hip_atomic_load(part + (long)b * NSUM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();  // (red was read by the partial-row store above)
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) {
         const double w = dbn_wave_sum_d((v[0][k] + v[1][k]) + (v[2][k] + v[3][k]));
-        if (lane == 0) red[wave * 8 + k] = w;
+        if (lane == 0 && wave < 4) red[wave * 8 + k] = w;
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -483,7 +483,7 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
     }
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) ds[k] += (double)s[k];
-    __shared__ double red[4][8];
+    __shared__ double red[8][8];  // (up to eight waves)
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -841,14 +841,15 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     const long HW = (long)H * W;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = HW % 4 == 0;
-    const int nb = dbn_grid((long)N * HW / (vec ? 4 : 1), 256, 1024);
+    // 512-thread workgroups (eight waves per SIMD at 1024 workgroups: twice the loads in flight of the 256-thread form)
+    const int nb = dbn_grid((long)N * HW / (vec ? 4 : 1), 512, 1024);
     char* base = (char*)ws;
     DbLossFinal fin = {(long)N * HW, channels, alpha, beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef,
                        (unsigned*)(base + DB_LOSS_PART_BYTES)};
     if (vec)
-        hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
+        hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(512), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     else
-        hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
+        hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(512), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     if (per_pixel != 1) return dbn_status();
     double* part_pos = (double*)(base + OHEM_OFF_POS);
     double* part_sel = (double*)(base + OHEM_OFF_SEL);

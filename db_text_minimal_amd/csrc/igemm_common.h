@@ -105,6 +105,9 @@ struct IgemmParams {
     // First-round stagger (see igemm_f32_kernel): workgroups with blockIdx.x < stagger_blocks wait (their wave slot) * stagger_units
     // * 1024 clocks before they start, so that the workgroups sharing a CU run out of phase.  0: off.
     int stagger_units, stagger_blocks;
+    // -DDBN_TRACE=1 builds (make TRACE=1, tools/trace_probe.py): [gridDim.x][8] timestamps (s_memrealtime, 100 MHz) written by thread 0 —
+    // 0 entry, 1 main loop entered, 2 main loop done, 3 epilogue done, 7 HW_ID; null otherwise
+    unsigned long long* trace;
     int launch_rows;    // host only: M-tiles of this launch (set by launch_igemm_ns)
     int patch;          // host only: use the pixel-patch form (3x3, stride 1; see igemm_dispatch)
     // MODE 3 only (pyramid conv): level g source [N, Hdf>>g, Wdf>>g, Cs] and its stride-2^g transposed-conv panels
@@ -116,6 +119,19 @@ struct IgemmParams {
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger
 extern "C" int dbn_g_stagger;
+extern "C" unsigned long long* dbn_g_trace;
+extern "C" long dbn_g_trace_blocks;
+#ifndef DBN_TRACE
+#define DBN_TRACE 0
+#endif
+#if DBN_TRACE
+#define DBN_TRACE_MARK(i)                                                                                      \
+    do {                                                                                                       \
+        if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DBN_TRACE_MARK(i) ((void)0)
+#endif
 
 namespace {
 

@@ -140,6 +140,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // (profile by deletion: ~4 us per 128 x 64 tile exposed whatever K is: 0.79 of peak at K = 576 with every load deleted, 0.94 at
     // K = 2304).  Delaying the first-round workgroup in wave slot j by j / slots of a tile time puts the residents of a CU out of phase;
     // later workgroups inherit the offsets because each starts when its predecessor in the slot ends.
+    DBN_TRACE_MARK(0);
+#if DBN_TRACE
+    if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
+#endif
     if (p.stagger_units > 0 && (int)blockIdx.x < p.stagger_blocks) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;  // HW_REG_HW_ID.WAVE_ID: this wave's slot on its SIMD
         const unsigned n = __builtin_amdgcn_readfirstlane(slot * (unsigned)p.stagger_units);
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        DBN_TRACE_MARK(1);
         // two channel blocks per trip (Cs % 32 == 0, checked on the host), so that the patch buffer of a block is a compile-time
         // LDS offset of its fragment reads
         auto block = [&](int cb, auto ODD) {
@@ -670,6 +675,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             block(cb, std::integral_constant<int, 0>{});
             block(cb + 1, std::integral_constant<int, 1>{});
         }
+        DBN_TRACE_MARK(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else if constexpr (DBP) {
@@ -1107,6 +1113,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // (vmcnt = 0, expcnt / lgkmcnt untouched)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    if (NS == 0 && MODE != 3) DBN_TRACE_MARK(1);
 
     auto k_step = [&](int kt, auto PAR) {
         constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
@@ -1181,6 +1188,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         k_step(kt + KU, C1{});
     }
     if (kt < kt_end) k_step(kt, C0{});
+    if (NS == 0 && MODE != 3) DBN_TRACE_MARK(2);
     }
 
     }
@@ -1580,6 +1588,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         };
         fold(s1, s2, p.bnb_part);
         if (y2b) fold(s3, s4, p.bnb_part2);
+        DBN_TRACE_MARK(3);
         bnb_finish(trow_);
         return;
     }
@@ -1732,6 +1741,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 for (int b = 0; b < NI; ++b) st_dst(dcol + doff + b * 32, acc[a][b][r] + bv[b]);
             }
         });
+    DBN_TRACE_MARK(3);
+#if DBN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and once more when this thread's output stores have completed
+    DBN_TRACE_MARK(4);
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int AT = 0>
@@ -1758,6 +1772,7 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
     p.stagger_units = p.stagger_blocks = 0;
+    p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;
     if (dbn_g_stagger > 0 && NS == 0 && AT == 0 && mode < 2 && p.ksplit <= 1) {
         // exact fp32: a k-step is MI * NI * 8 MFMAs of 64 clocks per wave; the residents of a SIMD share its matrix pipe, so one slot
         // step = one workgroup's own loop time.  Only when the grid is more than one round of residents (otherwise nothing repeats).

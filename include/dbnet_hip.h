@@ -367,6 +367,9 @@ int dbn_set_patch_conv(int on);
 /* First-round stagger of the exact-fp32 implicit-GEMM launches (workgroups sharing a CU start out of phase so that their prologues /
  * epilogues overlap other workgroups' MFMA loops), in permille of the nominal delay; 0 = off.  Returns the previous setting. */
 int dbn_set_stagger(int permille);
+/* Diagnostic builds only (make TRACE=1: per-workgroup phase timestamps of the exact-fp32 implicit-GEMM kernels, tools/trace_probe.py);
+ * the product library ignores the buffer and returns 0. */
+int dbn_set_trace(void* buf, long max_blocks);
 /* what one (unchunked) dbn_igemm_t call launches: tile configuration as dbn_igemm_tile_config, + 16 for the pixel-patch kernel
    (kmode: 0 forward, 1 stride-1 data gradient, 2 parity classes, 3 pyramid) — the template arguments of its rocprofv3 symbol */
 int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride,

@@ -25,26 +25,28 @@ shapes = ((16, 160, 64, 64, 'layer1 / FPN smooth p2'), (16, 80, 128, 128, 'layer
 for (N, H, Ci, Co, what) in shapes:
     w = rnd(Co, Ci, 3, 3, seed=1, scale=0.05)
     flops = 2.0 * N * H * H * Ci * Co * 9
-  for stg in STAGGERS:
-    L().dbn_set_stagger(stg)
-    for mode in (0, 1):
-        cin, cout = (Ci, Co) if mode == 0 else (Co, Ci)
-        x = torch.randn(N, H, H, cin, device=DEV)
-        y = torch.empty(N, H, H, cout, device=DEV)
-        wp = pack(w, mode)
-        res = {}
-        try:
-            L().dbn_set_patch_conv(1)
-            cfgp = L().dbn_igemm_kernel_config(0, 0, mode, N, H, H, cin, H, H, cout, 3, 3, 1, 1, 0, 1)
-            res['patch'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode))
-            yp = y.clone()
-            L().dbn_set_patch_conv(2)
-            cfgg = L().dbn_igemm_kernel_config(0, 0, mode, N, H, H, cin, H, H, cout, 3, 3, 1, 1, 0, 1)
-            res['gather(auto)'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode))
-            same = torch.equal(y, yp)
-            res['gather 128x64'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode, tile=3))
-        finally:
-            L().dbn_set_patch_conv(1)
-        print('stagger %4d %-24s %3d->%3d @%3d mode %d: %s   [patch cfg %d, gather cfg %d, bit-identical %s]' % (
-            stg, what, cin, cout, H, mode, '  '.join('%s %6.1f us %5.1f TF/s (%.3f)' % (k, v * 1e3, flops / v / 1e9, flops / v / 1e9 / 157.3) for k, v in res.items()),
-            cfgp, cfgg, same))
+    for stg in STAGGERS:
+        L().dbn_set_stagger(stg)
+        for mode in (0, 1):
+            cin, cout = (Ci, Co) if mode == 0 else (Co, Ci)
+            x = torch.randn(N, H, H, cin, device=DEV)
+            y = torch.empty(N, H, H, cout, device=DEV)
+            wp = pack(w, mode)
+            res = {}
+            try:
+                L().dbn_set_patch_conv(1)
+                cfgp = L().dbn_igemm_kernel_config(0, 0, mode, N, H, H, cin, H, H, cout, 3, 3, 1, 1, 0, 1)
+                res['patch'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode))
+                yp = y.clone()
+                L().dbn_set_patch_conv(2)
+                cfgg = L().dbn_igemm_kernel_config(0, 0, mode, N, H, H, cin, H, H, cout, 3, 3, 1, 1, 0, 1)
+                res['gather(auto)'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode))
+                same = torch.equal(y, yp)
+                res['gather 128x64'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode, tile=3))
+            finally:
+                L().dbn_set_patch_conv(1)
+            print('stagger %4d %-24s %3d->%3d @%3d mode %d: %s   [patch cfg %d, gather cfg %d, bit-identical %s]' % (
+                stg, what, cin, cout, H, mode,
+                '  '.join('%s %6.1f us %5.1f TF/s (%.3f)' % (k, v * 1e3, flops / v / 1e9, flops / v / 1e9 / 157.3) for k, v in res.items()),
+                cfgp, cfgg, same))
+L().dbn_set_stagger(0)
