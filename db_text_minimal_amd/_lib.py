@@ -101,6 +101,7 @@ SIGNATURES.update({
     'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',
     'dbn_set_stagger': 'i',
+    'dbn_set_phase_priority': 'i',
     'dbn_set_trace': 'pl',
     'dbn_igemm_kernel_config': 'i' * 16,
     'dbn_split3': 'pplp',

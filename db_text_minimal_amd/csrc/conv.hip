@@ -165,6 +165,13 @@ int dbn_set_trace(void* buf, long max_blocks) {
     dbn_g_trace_blocks = max_blocks;
     return DBN_TRACE;
 }
+int dbn_g_phase_prio = 0;
+// 1: implicit-GEMM workgroups run their prologue and epilogue at raised wave priority (igemm_kernel.h); returns the old setting
+int dbn_set_phase_priority(int on) {
+    const int old = dbn_g_phase_prio;
+    dbn_g_phase_prio = on != 0;
+    return old;
+}
 int dbn_g_stagger = 0;
 // permille of the nominal first-round stagger of the exact-fp32 implicit-GEMM launches (igemm_kernel.h); 0 = off.  Returns the old value.
 int dbn_set_stagger(int permille) {

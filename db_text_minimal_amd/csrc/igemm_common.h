@@ -105,6 +105,7 @@ struct IgemmParams {
     // First-round stagger (see igemm_f32_kernel): workgroups with blockIdx.x < stagger_blocks wait (their wave slot) * stagger_units
     // * 1024 clocks before they start, so that the workgroups sharing a CU run out of phase.  0: off.
     int stagger_units, stagger_blocks;
+    int phase_prio;  // 1: the prologue and the epilogue run at raised wave priority (s_setprio), the main loop at the default
     // -DDBN_TRACE=1 builds (make TRACE=1, tools/trace_probe.py): [gridDim.x][8] timestamps (s_memrealtime, 100 MHz) written by thread 0 —
     // 0 entry, 1 main loop entered, 2 main loop done, 3 epilogue done, 7 HW_ID; null otherwise
     unsigned long long* trace;
@@ -119,6 +120,7 @@ struct IgemmParams {
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger
 extern "C" int dbn_g_stagger;
+extern "C" int dbn_g_phase_prio;
 extern "C" unsigned long long* dbn_g_trace;
 extern "C" long dbn_g_trace_blocks;
 #ifndef DBN_TRACE

@@ -140,6 +140,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // (profile by deletion: ~4 us per 128 x 64 tile exposed whatever K is: 0.79 of peak at K = 576 with every load deleted, 0.94 at
     // K = 2304).  Delaying the first-round workgroup in wave slot j by j / slots of a tile time puts the residents of a CU out of phase;
     // later workgroups inherit the offsets because each starts when its predecessor in the slot ends.
+    // Phase priority.  Per-workgroup timestamps (make TRACE=1, tools/trace_probe.py) show what a tile's fixed cost is: with six other
+    // workgroups of the CU inside their MFMA loops, a workgroup's prologue (index arithmetic, first loads, first barrier: ~2 us on an
+    // idle CU) takes ~14 us and its epilogue ~5 us of a 68 us lifetime at K = 576 — its scalar / vector instructions wait behind the
+    // residents' MFMAs for issue — and for that long its four waves feed no MFMA.  Raised wave priority for exactly these phases gets
+    // a workgroup into (and out of) its loop sooner; the loop itself runs at the default priority.
+    if (p.phase_prio) __builtin_amdgcn_s_setprio(3);
     DBN_TRACE_MARK(0);
 #if DBN_TRACE
     if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         DBN_TRACE_MARK(1);
+        if (p.phase_prio) __builtin_amdgcn_s_setprio(0);
         // two channel blocks per trip (Cs % 32 == 0, checked on the host), so that the patch buffer of a block is a compile-time
         // LDS offset of its fragment reads
         auto block = [&](int cb, auto ODD) {
@@ -676,6 +683,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             block(cb + 1, std::integral_constant<int, 1>{});
         }
         DBN_TRACE_MARK(2);
+        if (p.phase_prio) __builtin_amdgcn_s_setprio(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else if constexpr (DBP) {
@@ -1114,6 +1122,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (NS == 0 && MODE != 3) DBN_TRACE_MARK(1);
+    if (p.phase_prio) __builtin_amdgcn_s_setprio(0);
 
     auto k_step = [&](int kt, auto PAR) {
         constexpr int buf = decltype(PAR)::value;  // parity of the interval: LDS buffer and register set of its tiles
@@ -1189,6 +1198,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
     if (kt < kt_end) k_step(kt, C0{});
     if (NS == 0 && MODE != 3) DBN_TRACE_MARK(2);
+    if (p.phase_prio && level + 1 == (MODE == 3 ? 4 : 1)) __builtin_amdgcn_s_setprio(3);
     }
 
     }
@@ -1772,6 +1782,7 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
     p.stagger_units = p.stagger_blocks = 0;
+    p.phase_prio = dbn_g_phase_prio;
     p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;
     if (dbn_g_stagger > 0 && NS == 0 && AT == 0 && mode < 2 && p.ksplit <= 1) {
         // exact fp32: a k-step is MI * NI * 8 MFMAs of 64 clocks per wave; the residents of a SIMD share its matrix pipe, so one slot

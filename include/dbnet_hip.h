@@ -367,6 +367,9 @@ int dbn_set_patch_conv(int on);
 /* First-round stagger of the exact-fp32 implicit-GEMM launches (workgroups sharing a CU start out of phase so that their prologues /
  * epilogues overlap other workgroups' MFMA loops), in permille of the nominal delay; 0 = off.  Returns the previous setting. */
 int dbn_set_stagger(int permille);
+/* 1: the implicit-GEMM workgroups run their prologue and epilogue at raised wave priority (s_setprio), so that they do not wait behind
+ * the MFMA loops of the other workgroups on their CU; 0: everything at the default priority.  Returns the previous setting. */
+int dbn_set_phase_priority(int on);
 /* Diagnostic builds only (make TRACE=1: per-workgroup phase timestamps of the exact-fp32 implicit-GEMM kernels, tools/trace_probe.py);
  * the product library ignores the buffer and returns 0. */
 int dbn_set_trace(void* buf, long max_blocks);

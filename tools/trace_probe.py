@@ -13,6 +13,9 @@ patch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 stagger = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 L().dbn_set_patch_conv(1 if patch else 2)
 L().dbn_set_stagger(stagger)
+prio = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+L().dbn_set_phase_priority(prio)
+print('phase priority', prio)
 for (N, H, Ci, Co, what) in ((16, 160, 64, 64, '64->64 @160 (K = 576)'), (16, 160, 256, 64, '256->64 @160 (K = 2304)')):
     w = rnd(Co, Ci, 3, 3, seed=1, scale=0.05)
     x = torch.randn(N, H, H, Ci, device=DEV)
