@@ -27,9 +27,12 @@ namespace {
 // exact-fp32 16K-element tiles with the BatchNorm-backward epilogue (EPI = 1): three waves per SIMD like the plain kernel (the row
 // sweep of that epilogue peaks 1-3 registers above the 104 that three waves allow; the attribute makes the allocator fit it)
 // bf16-storage pixel-patch kernels with that epilogue: four waves like the plain kernel (117 registers as written = three)
+// exact-fp32 64 x 64 tiles without that epilogue: seven waves per SIMD as before round 4 (the buffer-store epilogue's row offsets peak
+// two registers above the 72 that seven waves allow)
 #define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI, AT) \
     __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : \
-                                       ((EPI) == 1 && (AT) == 1 && (PATCH) && (BN) == 64) ? 4 : 1, 8)))
+                                       ((EPI) == 1 && (AT) == 1 && (PATCH) && (BN) == 64) ? 4 : \
+                                       ((EPI) == 0 && (NS) == 0 && (AT) == 0 && (BM) * (BN) == 4096 && (MODE) < 2) ? 7 : 1, 8)))
 
 // AT (activation storage type of src and dst): 0 fp32; 1 bf16 / 2 fp16 need NS = 1 — the gather then fetches 16-byte pieces
 // of EIGHT stored 16-bit channels that go to LDS unchanged (no conversion, the LDS image of the NS = 1 path is exactly the
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     constexpr int MI = TM / 32, NI = TN / 32;
     constexpr int ES = AT == 0 ? 4 : 2;            // bytes per stored source element
     constexpr bool DST_F32 = AT == 0 || AT == 3;
+#ifndef DBN_BUFST
+#define DBN_BUFST 1
+#endif
+    constexpr bool BUFST = DBN_BUFST && DST_F32 && MODE < 2;  // plain epilogue through raw buffer stores (see the end of the kernel)
     constexpr int NP = AT == 3 ? 3 : 1;            // 16-bit planes of the source
     constexpr int A_SH = AT == 0 ? 2 : 1;          // pieces per row and plane = 1 << A_SH (4 x 4 fp32 channels, or 2 x 8 16-bit channels)
     constexpr int A_CH = AT == 0 ? 4 : 8;          // channels per 16-byte piece
@@ -1743,6 +1750,43 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         if (s_ == 12345.678f) st_dst(dcol, s_);
         return;
     }
+    if constexpr (BUFST) {
+        // fp32 destination whose tile rows are a linear walk (MODE 0 / 1) or the pixel patch: raw BUFFER stores.  A row's byte offset is
+        // a per-lane base + a wave-uniform multiple of the row pitch (one v_add per row); rows past M fall outside the resource's range
+        // and are dropped by the hardware — no compare / saveexec / 64-bit address arithmetic / branch per row.  The predicated form
+        // below is ~40 instructions per row; per-workgroup timestamps (tools/trace_probe.py) showed that a workgroup's instructions
+        // outside its MFMAs are NOT hidden by the other residents of the CU — every one of them costs matrix time (the epilogue was
+        // 750 of a 64 x 64 tile-wave's ~3100 instructions at K = 576).
+        const __amdgpu_buffer_rsrc_t rsrcD =
+            __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (unsigned)((long)(PATCH ? p.N * p.Hdf * p.Wdf : qM) * p.Cd * 4), 0x00020000);
+        const unsigned pitch = (unsigned)p.Cd * 4u;
+        const unsigned colb = (unsigned)(n0 + wn * TN + li) * 4u;
+#pragma unroll
+        for (int a = 0; a < MI; ++a) {
+            if constexpr (PATCH) {
+                // row (r, lh) of block a is pixel y = ph0 + 2 (wm MI + a) + parity(popcount(r >> 2) + lh), x = pw0 + 4 (r >> 2) + (r & 3)
+                const unsigned row0 = (unsigned)((pn * p.Hdf + ph0 + 2 * (wm * MI + a)) * p.Wdf + pw0);
+                const unsigned base0 = (row0 + (unsigned)(lh ? p.Wdf : 0)) * pitch + colb;  // parity(popcount) == 0 -> y offset lh
+                const unsigned base1 = (row0 + (unsigned)(lh ? 0 : p.Wdf)) * pitch + colb;  // parity == 1 -> y offset 1 - lh
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = ((__builtin_popcount(r >> 2) & 1) ? base1 : base0) + (unsigned)((r >> 2) * 4 + (r & 3)) * pitch;
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv[b]), rsrcD, (int)off, 0, 0);
+                }
+            } else {
+                const unsigned base = (unsigned)(m0 + wm * TM + a * 32 + 4 * lh) * pitch + colb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = base + (unsigned)((r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+                    for (int b = 0; b < NI; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv[b]), rsrcD, (int)off + b * 128, 0, 0);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int a = 0; a < MI; ++a)
         for_rows(a, [&](int r, bool ok, long doff) {
@@ -1751,6 +1795,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 for (int b = 0; b < NI; ++b) st_dst(dcol + doff + b * 32, acc[a][b][r] + bv[b]);
             }
         });
+    }
     DBN_TRACE_MARK(3);
 #if DBN_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and once more when this thread's output stores have completed
