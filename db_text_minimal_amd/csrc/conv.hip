@@ -180,11 +180,11 @@ int dbn_set_stagger(int permille) {
     return old;
 }
 
-static int g_patch_enabled = 1;  // 0: never; 1: every eligible launch; 2: the 16-bit matrix modes only (exact fp32 takes the gather loop)
+static int g_patch_enabled = 1;  // 0: never; 1: default; 2: the 16-bit matrix modes only (exact fp32 takes the gather loop); 3: exact fp32 on every eligible launch
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
 int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
     const int old = g_patch_enabled;
-    g_patch_enabled = (on == 2) ? 2 : (on != 0);
+    g_patch_enabled = (on == 2 || on == 3) ? on : (on != 0);
     return old;
 }
 // pixel-patch form: 3x3 / stride 1 / pad 1 on the bf16 matrix pipe, whole 8 x 16 patches, 128-row tiles (the BatchNorm
@@ -195,7 +195,13 @@ static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int
                            int ksplit, int tile_hint = 0) {
     const bool geom = (kmode == 0 || kmode == 1) && R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 &&
                       Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
-    if (ns == 0) return g_patch_enabled == 1 && at == 0 && geom && (tile_hint == 0 || tile_hint == 3);
+    // exact fp32: an explicit 128 x 64 request (tile_hint 3) always takes it; the library's own choice (tile_hint 0) only where it was
+    // measured faster than the 64 x 64 gather tile — the long-K forward convs (the head's 256 -> 64 at 160^2: 886 vs 925-933 us alone;
+    // at K = 576 its heavier prologue / epilogue make it a tie or a loss: 64 -> 64 at 160^2 286-300 vs 277-293 us, and the whole step
+    // 538-540 vs 543-545 images/s with every eligible layer on it; dbn_set_patch_conv(3) selects that for A/B runs)
+    if (ns == 0)
+        return (g_patch_enabled == 1 || g_patch_enabled == 3) && at == 0 && geom &&
+               (tile_hint == 3 || (tile_hint == 0 && (g_patch_enabled == 3 || (kmode == 0 && Cs >= 256))));
     return g_patch_enabled && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && geom;
 }
 static int patch_cfg(int cfg, int ns = 1) { return (ns == 0 || (cfg == 1 && g_patch_bn64)) ? 3 : cfg; }

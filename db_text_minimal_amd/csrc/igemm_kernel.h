@@ -1321,7 +1321,35 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
         for (int a = 0; a < MI; ++a)
         {
-            if constexpr (MODE < 2) {
+            if constexpr (BUFST) {
+                // fp32 destination, linear rows or the pixel patch: raw buffer loads at the store loop's offsets (rows past M are out of
+                // range and read as 0), four rows in flight
+                const __amdgpu_buffer_rsrc_t rsrcA =
+                    __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (unsigned)((long)(PATCH ? p.N * p.Hdf * p.Wdf : qM) * p.Cd * 4), 0x00020000);
+                const unsigned pitch = (unsigned)p.Cd * 4u, colb = (unsigned)(n0 + wn * TN + li) * 4u;
+                const unsigned row0 = PATCH ? (unsigned)((pn * p.Hdf + ph0 + 2 * (wm * MI + a)) * p.Wdf + pw0) : (unsigned)(m0 + wm * TM + a * 32 + 4 * lh);
+                const unsigned base0 = (row0 + (unsigned)((PATCH && lh) ? p.Wdf : 0)) * pitch + colb;
+                const unsigned base1 = PATCH ? (row0 + (unsigned)(lh ? 0 : p.Wdf)) * pitch + colb : base0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float old[4][NI];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;
+                        const unsigned off = PATCH ? ((__builtin_popcount(r >> 2) & 1) ? base1 : base0) + (unsigned)((r >> 2) * 4 + (r & 3)) * pitch
+                                                   : base0 + (unsigned)((r & 3) + 8 * (r >> 2)) * pitch;
+#pragma unroll
+                        for (int b = 0; b < NI; ++b)
+                            old[i][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, (int)off + b * 128, 0, 0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int b = 0; b < NI; ++b) acc[a][b][4 * g + i] += old[i][b];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (MODE < 2) {
                 // unpredicated loads (rows past M read a valid pixel and add 0), issued four rows (4 x NI loads) at a time
                 // before their adds: left alone, the scheduler put each load right before its use with a full wait — 64
                 // dependent round trips per tile; whole blocks in flight would cost an occupancy step in registers
@@ -1773,7 +1801,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                     const unsigned off = ((__builtin_popcount(r >> 2) & 1) ? base1 : base0) + (unsigned)((r >> 2) * 4 + (r & 3)) * pitch;
 #pragma unroll
                     for (int b = 0; b < NI; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv[b]), rsrcD, (int)off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[a][b][r] + bv[b]), rsrcD, (int)off + b * 128, 0, 0);
                 }
             } else {
                 const unsigned base = (unsigned)(m0 + wm * TM + a * 32 + 4 * lh) * pitch + colb;

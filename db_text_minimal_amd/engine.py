@@ -121,8 +121,8 @@ class Engine:
     def __init__(self, model):
         self.model = model
         self.L = _lib.lib()
-        if os.environ.get('DBN_PATCH_F32', '1') == '0':  # A/B runs: exact fp32 on the gather loop (the 16-bit modes keep their patch kernels)
-            self.L.dbn_set_patch_conv(2)
+        if 'DBN_PATCH_F32' in os.environ:  # A/B runs: 0 exact fp32 on the gather loop everywhere, 1 on the pixel-patch kernel wherever eligible
+            self.L.dbn_set_patch_conv(2 if os.environ['DBN_PATCH_F32'] == '0' else 3)
         if 'DBN_PHASE_PRIO' in os.environ:  # A/B runs
             self.L.dbn_set_phase_priority(int(os.environ['DBN_PHASE_PRIO']))
         if 'DBN_STAGGER' in os.environ:  # A/B runs (permille of the nominal first-round stagger of the fp32 convs)

@@ -130,9 +130,11 @@ def test_kernel_selection_logic_without_gpu():
     kernels, and that the tile configuration reported for a call is the one its BatchNorm partial rows are sized for."""
     L = _lib.lib()
     cfg = lambda at, ns, kmode, N, H, W, Cs, Cd, R, s, p: L.dbn_igemm_kernel_config(at, ns, kmode, N, H, W, Cs, H // s, W // s, Cd, R, R, s, p, 0, 1)
-    # 3x3 / stride 1 on whole 8 x 16 patches of 32-channel blocks takes the pixel-patch form: the 16-bit matrix modes, and (round 4)
-    # exact fp32 with 128 x 64 tiles
-    for at, ns in ((0, 0), (0, 3), (0, 1), (1, 1), (2, 1)):
+    # 3x3 / stride 1 on whole 8 x 16 patches of 32-channel blocks takes the pixel-patch form in the 16-bit matrix modes; exact fp32
+    # (round 4, 128 x 64 tiles) by default only for the long-K forward convs, on request (tile 3 / dbn_set_patch_conv(3)) everywhere
+    assert cfg(0, 0, 0, 16, 160, 160, 64, 64, 3, 1, 1) == 4 and cfg(0, 0, 0, 16, 160, 160, 256, 64, 3, 1, 1) == 19
+    assert L.dbn_igemm_kernel_config(0, 0, 0, 16, 160, 160, 64, 160, 160, 64, 3, 3, 1, 1, 3, 1) == 19
+    for at, ns in ((0, 3), (0, 1), (1, 1), (2, 1)):
         c = cfg(at, ns, 0, 16, 160, 160, 64, 64, 3, 1, 1)
         assert c & 16 and (c & 15) == 3, (at, ns, c)                    # 128 x 64 patch tiles
         assert cfg(at, ns, 1, 16, 80, 80, 128, 128, 3, 1, 1) & 16        # data gradient too
@@ -152,7 +154,9 @@ def test_kernel_selection_logic_without_gpu():
         assert L.dbn_set_patch_conv(0) == 1
         assert cfg(1, 1, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 == 0 and cfg(0, 0, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 == 0
         assert L.dbn_set_patch_conv(2) == 0  # 2: the 16-bit matrix modes only
-        assert cfg(1, 1, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 and cfg(0, 0, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 == 0
+        assert cfg(1, 1, 0, 16, 160, 160, 64, 64, 3, 1, 1) & 16 and cfg(0, 0, 0, 16, 160, 160, 256, 64, 3, 1, 1) & 16 == 0
+        assert L.dbn_set_patch_conv(3) == 2  # 3: exact fp32 on every eligible launch
+        assert cfg(0, 0, 0, 16, 160, 160, 64, 64, 3, 1, 1) == 19
     finally:
         L.dbn_set_patch_conv(1)
 

@@ -34,7 +34,7 @@ for (N, H, Ci, Co, what) in shapes:
             wp = pack(w, mode)
             res = {}
             try:
-                L().dbn_set_patch_conv(1)
+                L().dbn_set_patch_conv(3)
                 cfgp = L().dbn_igemm_kernel_config(0, 0, mode, N, H, H, cin, H, H, cout, 3, 3, 1, 1, 0, 1)
                 res['patch'] = timed(lambda: igemm(x, wp, None, y, 3, 1, 1, mode))
                 yp = y.clone()

@@ -11,7 +11,7 @@ from gpu_util import L, rnd, DEV, igemm, pack
 
 patch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 stagger = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-L().dbn_set_patch_conv(1 if patch else 2)
+L().dbn_set_patch_conv(3 if patch else 2)
 L().dbn_set_stagger(stagger)
 prio = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 L().dbn_set_phase_priority(prio)
