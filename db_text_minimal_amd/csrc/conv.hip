@@ -195,13 +195,12 @@ static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int
                            int ksplit, int tile_hint = 0) {
     const bool geom = (kmode == 0 || kmode == 1) && R == 3 && S == 3 && stride == 1 && pad == 1 && Hs == Hd && Ws == Wd && Hd % 8 == 0 &&
                       Wd % 16 == 0 && Cs % 32 == 0 && ksplit <= 1;
-    // exact fp32: an explicit 128 x 64 request (tile_hint 3) always takes it; the library's own choice (tile_hint 0) only where it was
-    // measured faster than the 64 x 64 gather tile — the long-K forward convs (the head's 256 -> 64 at 160^2: 886 vs 925-933 us alone;
-    // at K = 576 its heavier prologue / epilogue make it a tie or a loss: 64 -> 64 at 160^2 286-300 vs 277-293 us, and the whole step
-    // 538-540 vs 543-545 images/s with every eligible layer on it; dbn_set_patch_conv(3) selects that for A/B runs)
-    if (ns == 0)
-        return (g_patch_enabled == 1 || g_patch_enabled == 3) && at == 0 && geom &&
-               (tile_hint == 3 || (tile_hint == 0 && (g_patch_enabled == 3 || (kmode == 0 && Cs >= 256))));
+    // exact fp32: an explicit 128 x 64 request (tile_hint 3) takes it, and dbn_set_patch_conv(3) makes it the library's own choice
+    // (tile_hint 0).  NOT the default: alone it wins only on the long-K forward convs (the head's 256 -> 64 at 160^2: 871-892 us against
+    // 907-933 for the 64 x 64 gather tile; at K = 576 its heavier prologue / epilogue make it a tie or a loss: 64 -> 64 at 160^2
+    // 286-300 vs 277-293 us), and inside the two-stream step neither choice moved the result (every eligible layer: 538-540 vs
+    // 543-545 images/s; the head's forward convs only: 543.2 vs 542.6, within the run-to-run spread) — profiles/r04_fp32_patch.txt
+    if (ns == 0) return (g_patch_enabled == 1 || g_patch_enabled == 3) && at == 0 && geom && (tile_hint == 3 || (tile_hint == 0 && g_patch_enabled == 3));
     return g_patch_enabled && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && geom;
 }
 static int patch_cfg(int cfg, int ns = 1) { return (ns == 0 || (cfg == 1 && g_patch_bn64)) ? 3 : cfg; }

@@ -91,17 +91,27 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(const void* __restri
 // integer atomic; samples that leave the patch (|offset| > HALO) go to the global accumulator directly.
 constexpr int COL2IM_T = 8, COL2IM_HALO = 2;
 
+// Non-finite inputs: the old float atomics carried a NaN / Inf in dcols into dx; a fixed-point sum cannot (to_fixed(NaN) is 0).
+// absmax therefore reports a NaN bit pattern (which orders above every finite value in atomicMax) as soon as ONE element is not
+// finite, and the finish kernel then writes NaN to the whole of dx / doffset — a diverged step stays visible downstream.
+// Resolution: every addend is rounded to 2^-43 of the GLOBAL max |dcols| (doffset: of 64 max|dcols| max|x|), so one outlier sets
+// the absolute error floor of every element: |error| <= (#addends) * 2^-44 * max|dcols| — e.g. 1e6 * 6e-14 = 6e-8 per addend with
+// a 1e6 outlier, against fp32 gradients of O(1e-3 .. 1) (tests/test_ops_gpu.py::test_deformable_col2im_non_finite_and_outliers).
+constexpr unsigned DEFORM_NONFINITE = 0x7FC00000u;
 template <int AT>
 __global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ x, long n4, unsigned* __restrict__ out) {
     float m = 0.f;
+    bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 v = dbn_ld4<AT>(x, i);
-        m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
+        const float a = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        bad |= !(fabsf(v[0]) <= 3.0e38f) | !(fabsf(v[1]) <= 3.0e38f) | !(fabsf(v[2]) <= 3.0e38f) | !(fabsf(v[3]) <= 3.0e38f);  // (fmaxf drops a NaN)
+        m = fmaxf(a, m);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (!(m == m) || m > 3.0e38f) m = 3.0e38f;  // NaN / inf inputs: keep the scale finite (the result is garbage either way)
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
+    const bool any_bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, any_bad ? DEFORM_NONFINITE : __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
 }
 
 // 2^k with (largest magnitude, rounded up to a power of two) * 2^k = 2^43
@@ -190,12 +200,14 @@ __global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict
                                             const unsigned* __restrict__ maxbits, void* __restrict__ dx, void* __restrict__ doffset,
                                             long ndx4, long M, int RS2, int off_stride, int accumulate) {
     const float gmax = __builtin_bit_cast(float, maxbits[0]), xmax = __builtin_bit_cast(float, maxbits[1]);
+    const bool bad_g = maxbits[0] == DEFORM_NONFINITE, bad_x = maxbits[1] == DEFORM_NONFINITE;  // a non-finite dcols / x element (absmax_kernel)
+    const float nan_ = __builtin_bit_cast(float, DEFORM_NONFINITE);
     const double idx = 1.0 / fixed_scale(gmax), ioff = 1.0 / fixed_scale(64.f * fmaxf(gmax, 1e-30f) * fmaxf(xmax, 1e-30f));
     const long stride = (long)gridDim.x * blockDim.x, t0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
     for (long i = t0; i < ndx4; i += stride) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)((double)(long long)dx64[4 * i + e] * idx);
+        for (int e = 0; e < 4; ++e) v[e] = bad_g ? nan_ : (float)((double)(long long)dx64[4 * i + e] * idx);
         if (accumulate) v += dbn_ld4<AT>(dx, i);
         dbn_st4<AT>(dx, i, v);
     }
@@ -205,7 +217,7 @@ __global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict
         const int ch = (int)(i - m * (off_stride / 4)) * 4;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ch + e < RS2 ? (float)((double)(long long)doff64[m * RS2 + ch + e] * ioff) : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ch + e < RS2 ? ((bad_g || bad_x) ? nan_ : (float)((double)(long long)doff64[m * RS2 + ch + e] * ioff)) : 0.f;
         dbn_st4<AT>(doffset, i, v);
     }
 }
