@@ -289,7 +289,7 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'winograd_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
                                 'head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
     clock = ClockProbe(dev, args.steps)

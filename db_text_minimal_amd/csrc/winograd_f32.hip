@@ -1,0 +1,279 @@
+// 3x3 / stride-1 / pad-1 forward convolution in exact-fp32 arithmetic through the Winograd transform F(2x2, 3x3):
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2 x 2 output tile, 4 x 4 input window d, 3 x 3 filter g
+// 16 element-wise "points" per tile instead of 36 multiply-adds per output pair: 2.25x fewer MFMA FLOPs than the direct
+// convolution (the convolutions of /root/reference/src/modules/resnet.py:70-91 (BasicBlock), segmentation_body.py:55-61 (FPN smooth
+// convs) and segmentation_head.py:24-25,64-68 (the head's 256 -> 64 convs) are all 3x3 / stride 1 / pad 1).
+//
+// Mapping onto v_mfma_f32_32x32x2_f32: a workgroup owns an 8 x 16 patch of output pixels of one image = 4 x 8 = 32 tiles, and 64
+// output channels.  For point (i, j) the products are a GEMM  M_ij[32 tiles][64 cout] = V_ij[32 tiles][Cin] x U_ij[Cin][64 cout]:
+// the 32 tiles are exactly one MFMA row block.  Wave i of the workgroup owns the four points (i, 0..3): 4 x 2 accumulator blocks
+// (128 AGPRs).  Per 16-channel block the 10 x 18 input patch is brought to LDS once (the pixel-patch staging of igemm_kernel.h),
+// every lane forms its V fragments on the fly — V_ij = sum of FOUR patch pixels with signs (B^T has two non-zeros per row: four
+// ds_read_b128 + 12 vector instructions per fragment) — and the pre-transformed weights U = G g G^T come straight from a packed
+// panel into registers (dbn_winograd_pack).  The epilogue applies A^T . A: along j inside each wave (registers), along i across the
+// four waves (through LDS), adds the bias, optionally produces the train-mode BatchNorm tile statistics (same partial-row format as
+// the implicit-GEMM kernels: bn_finalize_tiles_kernel folds them), and stores with raw buffer stores.
+// Arithmetic is fp32 throughout (no reduced precision); the result differs from the direct convolution by fp32 rounding of a
+// different summation (max relative error ~1e-6 of the output scale), not bit for bit.
+#include "igemm_common.h"
+
+namespace {
+
+constexpr int W_PPX = 180, W_PROW = 18;  // 10 x 18 patch pixels
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void winograd_f32_kernel(const IgemmParams p) {
+    // LDS: loop = two patch buffers [4 chunks][180 px] f32x4 (23 KB); epilogue = the cross-wave exchange [4 waves][2 dx][2 b][16][64]
+    // floats (64 KB) + the statistics scratch
+    constexpr int P_PATCH = 4 * W_PPX;
+    constexpr int X_FLOATS = 4 * 2 * 2 * 16 * 64;
+    __shared__ f32x4 smem[X_FLOATS / 4 + (64 + 2 * 4 * 64) / 4 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
+    const int ntn = p.Cd >> 6;
+    const int mt = tile / ntn, nt = tile - mt * ntn, n0 = nt * 64;
+    const int tw = p.Wdf >> 4, tpi = (p.Hdf >> 3) * tw;
+    const int pn = mt / tpi, t_ = mt - pn * tpi, ty_ = t_ / tw;
+    const int ph0 = ty_ * 8, pw0 = (t_ - ty_ * tw) * 16;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
+
+    // ---- patch staging: 180 pixels x 4 chunks of 16 bytes per channel block, three pieces per thread
+    constexpr int PL = (W_PPX * 4 + 255) / 256;
+    unsigned poff[PL];
+    int pslot[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+        const int idx = tid + j * 256;
+        const bool on = idx < W_PPX * 4;
+        const int chunk = idx & 3, pix = on ? idx >> 2 : 0;
+        const int py = pix / W_PROW, px = pix - py * W_PROW;
+        const int hs = ph0 - 1 + py, ws = pw0 - 1 + px;
+        const bool v = on && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * 4u + (unsigned)chunk * 16u : OOB_OFFSET;
+        pslot[j] = on ? chunk * W_PPX + pix : -1;
+    }
+    f32x4 pr[PL];
+    const int ncb = p.Cs >> 4;
+    auto load_patch = [&](int cb) {
+        const unsigned add = (unsigned)(cb * 64);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
+    };
+    auto store_patch = [&](int buf) {
+        f32x4* const P = smem + buf * P_PATCH;
+#pragma unroll
+        for (int j = 0; j < PL; ++j)
+            if (pslot[j] >= 0) P[pslot[j]] = pr[j];
+    };
+
+    // ---- this wave's row of the input transform: B^T row i = wave has two non-zeros: V = d[a1] + sa * d[a2]
+    //      i = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+    const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sa = wave == 1 ? 1.f : -1.f;
+    // MFMA row = tile (ty, tx) = (li >> 3, li & 7): its 4 x 4 input window starts at patch pixel (2 ty, 2 tx); chunk 2*s2 + lh
+    const int vbase = (2 * (li >> 3)) * W_PROW + 2 * (li & 7) + lh * W_PPX;
+    const int row1 = vbase + a1 * W_PROW, row2 = vbase + a2 * W_PROW;
+
+    // ---- weight fragments: panel [cb][16 points][4 chunks][Cd][4]; lane (li, lh): chunk 2*s2 + lh, column n0 + 32 b + li
+    const __amdgpu_buffer_rsrc_t rsrcW =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)((long)p.Cs * 16 * p.Cd * 4), 0x00020000);
+    unsigned wvo[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) wvo[s2][b] = (unsigned)((2 * s2 + lh) * p.Cd + n0 + b * 32 + li) * 16u;
+    const unsigned point_bytes = (unsigned)(4 * p.Cd) * 16u;  // one point of one channel block
+    int w_next = 0;  // next (channel block, point) to fetch: g = cb * 4 + j; clamped at the end (the surplus fetch is never used)
+    const int w_last = ncb * 4 - 1;
+    f32x4 rw[2][2][2];
+    auto issue_w = [&](auto SET) {
+        constexpr int st_ = decltype(SET)::value;
+        const int g = min(w_next, w_last);
+        ++w_next;
+        const unsigned so = (unsigned)((g >> 2) * 16 + 4 * wave + (g & 3)) * point_bytes;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, (int)wvo[s2][b], (int)so, 0);
+                rw[st_][s2][b] = __builtin_bit_cast(f32x4, v_);
+            }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+
+    load_patch(0);
+    issue_w(std::integral_constant<int, 0>{});
+    store_patch(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int cb = 0; cb < ncb; ++cb) {
+        const f32x4* const P = smem + (cb & 1) * P_PATCH;
+        load_patch(cb + 1);  // (past the last block: out-of-range offsets, zeros, never stored)
+        auto point = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int cur = j & 1;  // four points per block: the sets alternate cleanly across blocks
+            issue_w(std::integral_constant<int, cur ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+            constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
+            constexpr bool plus = j == 1;
+            f32x4 v[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f32x4 x11 = P[2 * s2 * W_PPX + row1 + b1], x12 = P[2 * s2 * W_PPX + row1 + b2];
+                const f32x4 x21 = P[2 * s2 * W_PPX + row2 + b1], x22 = P[2 * s2 * W_PPX + row2 + b2];
+                const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[cur][s2][b][e], acc[j][b], 0, 0, 0);
+        };
+        point(std::integral_constant<int, 0>{});
+        point(std::integral_constant<int, 1>{});
+        point(std::integral_constant<int, 2>{});
+        point(std::integral_constant<int, 3>{});
+        if (cb + 1 < ncb) {
+            // the other buffer was last read in block cb - 1, and every wave has passed the barrier that ended it
+            store_patch((cb + 1) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with the patches: the region becomes the exchange buffer
+
+    // ---- output transform.  Along j (this wave holds M_i0 .. M_i3): T_i[dx] = A^T row dx: dx 0: M0 + M1 + M2;  dx 1: M1 - M2 - M3
+    float* const X = reinterpret_cast<float*>(smem);  // [(i*2 + dx)*2 + b][r][lane]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0_ = acc[0][b][r], m1_ = acc[1][b][r], m2_ = acc[2][b][r], m3_ = acc[3][b][r];
+            X[(((wave * 2 + 0) * 2 + b) * 16 + r) * 64 + lane] = (m0_ + m1_) + m2_;
+            X[(((wave * 2 + 1) * 2 + b) * 16 + r) * 64 + lane] = (m1_ - m2_) - m3_;
+        }
+    __syncthreads();
+    // along i, across the waves: wave w produces the output pixel (dy, dx) = (w >> 1, w & 1) of every tile:
+    //   dy 0: T_0 + T_1 + T_2;  dy 1: T_1 - T_2 - T_3
+    const int dy = wave >> 1, dx = wave & 1;
+    float y[2][16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float bias = p.bias ? p.bias[n0 + b * 32 + li] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            auto T = [&](int i) { return X[(((i * 2 + dx) * 2 + b) * 16 + r) * 64 + lane]; };
+            const float t1 = T(1), t2 = T(2);
+            y[b][r] = (dy == 0 ? (T(0) + t1) + t2 : (t1 - t2) - T(3)) + bias;
+        }
+    }
+    // ---- optional BatchNorm statistics of this 128-pixel tile (pivot, sum, sum of squares per channel; igemm_kernel.h's format)
+    if (p.stats) {
+        float* const piv = reinterpret_cast<float*>(smem) + X_FLOATS;  // [64]
+        float* const r1 = piv + 64;                                    // [4][64]
+        float* const r2 = r1 + 4 * 64;                                 // [4][64]
+        if (wave == 0 && lh == 0) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) piv[b * 32 + li] = y[b][0];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float pv = piv[b * 32 + li];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = y[b][r] - pv;
+                s1 += d;
+                s2 += d * d;
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                r1[wave * 64 + b * 32 + li] = s1;
+                r2[wave * 64 + b * 32 + li] = s2;
+            }
+        }
+        __syncthreads();
+        const int trow = p.stat_row0 + mt;
+        if (tid < 64) {
+            const float s1 = (r1[tid] + r1[64 + tid]) + (r1[128 + tid] + r1[192 + tid]);
+            const float s2 = (r2[tid] + r2[64 + tid]) + (r2[128 + tid] + r2[192 + tid]);
+            const long c = n0 + tid;
+            p.stats[(0L * p.Cd + c) * p.stat_rows + trow] = piv[tid];
+            p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
+            p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
+        }
+        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = 128.f;
+    }
+    // ---- stores: tile t = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (ph0 + 2 (t >> 3) + dy, pw0 + 2 (t & 7) + dx), channel n0 + 32 b + li
+    const __amdgpu_buffer_rsrc_t rsrcD =
+        __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4), 0x00020000);
+    const unsigned pitch = (unsigned)p.Cd * 4u;
+    // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
+    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[b][r]), rsrcD, (int)off + b * 128, 0, 0);
+    }
+}
+
+// U = G g G^T per (output, input) channel pair, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; panel [I/16][16 points][4 chunks][O][4]
+__global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, int Cs, float* __restrict__ out) {
+    const long total = (long)Cs * O;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % O), ci = (int)(idx / O);
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g[r][s] = ci < I ? w[(((long)o * I + ci) * 3 + r) * 3 + s] : 0.f;
+        float t[4][3];  // G g
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = g[0][s];
+            t[1][s] = 0.5f * ((g[0][s] + g[1][s]) + g[2][s]);
+            t[2][s] = 0.5f * ((g[0][s] - g[1][s]) + g[2][s]);
+            t[3][s] = g[2][s];
+        }
+        const int cb = ci >> 4, c4 = (ci >> 2) & 3, e = ci & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u[4] = {t[i][0], 0.5f * ((t[i][0] + t[i][1]) + t[i][2]), 0.5f * ((t[i][0] - t[i][1]) + t[i][2]), t[i][2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[((((long)cb * 16 + 4 * i + j) * 4 + c4) * O + o) * 4 + e] = u[j];
+        }
+    }
+}
+
+}  // namespace
+
+int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
+    const int grid = p.N * (p.Hdf >> 3) * (p.Wdf >> 4) * (p.Cd >> 6);
+    if (grid <= 0) return DBN_OK;
+    hipLaunchKernelGGL(winograd_f32_kernel, dim3(grid), dim3(256), 0, st, p);
+    return dbn_status();
+}
+
+int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(winograd_pack_kernel, dim3(dbn_grid((long)Cs * O)), dim3(256), 0, st, w, O, I, Cs, out);
+    return dbn_status();
+}

@@ -492,11 +492,62 @@ class Engine:
             self.packs[key] = (out, stamp)
 
     # ------------------------------------------------------------------ kernels
+    # 3x3 / stride-1 / pad-1 FORWARD convolutions of the exact-fp32 path through Winograd F(2x2, 3x3) (csrc/winograd_f32.hip): fp32
+    # arithmetic, 2.25x fewer matrix FLOPs; the result equals the direct convolution up to fp32 rounding (another summation order).
+    winograd = os.environ.get('DBN_WINOGRAD', '0') == '1'
+
+    def _winograd_ok(self, x, conv):
+        N, H, W, C = x.shape
+        return (self.winograd and self.ns == 0 and self.at == 0 and x.dtype == torch.float32 and conv.k == 3 and conv.stride == 1 and
+                conv.padding == 1 and bool(self.L.dbn_winograd_eligible(N, H, W, C, conv.cout)))
+
+    def _winograd_panel(self, name, w, cs):
+        """G g G^T of every filter, re-made when the parameter changed (one small launch per layer and step)."""
+        key = (name, 'winograd', cs)
+        ent = self.packs.get(key)
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        if ent is not None and ent[1] == stamp:
+            return ent[0]
+        O, I = w.shape[0], w.shape[1]
+        out = ent[0] if ent is not None else device_empty(self.L.dbn_winograd_panel_floats(O, cs), w.device)
+        check(self.L.dbn_winograd_pack(w.data_ptr(), O, I, cs, out.data_ptr(), self.stream), 'winograd pack ' + name)
+        self.packs[key] = (out, stamp)
+        return out
+
+    def _winograd_conv(self, name, x, conv, y, bn=None, bn_name=None):
+        N, H, W, C = x.shape
+        up = self._winograd_panel(name, conv.weight, C)
+        if self.prof:
+            # FLOPs the MFMA pipe EXECUTES: 16 products per 2 x 2 output tile and channel pair (the direct form's 36 are what
+            # `step_tflops` counts): the roofline fraction of this kernel is matrix-pipe utilisation, not an effective rate
+            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 0.0, 'fwd ' + name)
+        if bn is None:
+            check(self.L.dbn_winograd_conv_bn_f32(x.data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, conv.cout, None, None,
+                                                  0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
+            sc = sh = None
+        else:
+            Co = conv.cout
+            sc, sh = self.fbuf(bn_name + '/scale', Co), self.fbuf(bn_name + '/shift', Co)
+            mu, rs = self.fbuf(bn_name + '/mean', Co), self.fbuf(bn_name + '/rstd', Co)
+            ws = self.scratch('_conv_bn_ws', self.L.dbn_winograd_ws_floats(N, H, W, Co))
+            check(self.L.dbn_winograd_conv_bn_f32(x.data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Co, bn.weight.data_ptr(),
+                                                  bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
+                                                  bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                                                  ws.data_ptr(), self.stream), 'winograd+bn ' + name)
+            self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
+        if self.prof:
+            self.prof.end()
+        return sc, sh
+
     def conv_fwd(self, name, x, conv, out_name, version=None):
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
+        if version is None and self._winograd_ok(x, conv):
+            y = self.buf(out_name, N, Ho, Wo, conv.cout)
+            self._winograd_conv(name, x, conv, y)
+            return y
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
@@ -536,6 +587,10 @@ class Engine:
             sc, sh = self.bn_coef(bn_name, bn, y, train)
             return y, sc, sh
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
+        if version is None and self._winograd_ok(x, conv):
+            y = self.buf(out_name, N, Ho, Wo, conv.cout)
+            sc, sh = self._winograd_conv(name, x, conv, y, bn, bn_name)
+            return y, sc, sh
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:

@@ -232,6 +232,21 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
                       const float* bn_rstd_t, float* bn_sums, float* dxb, float* dxt, float* dw_b, float* dbias_b, float* dw_t,
                       float* dbias_t, int N, int Hq, int Wq, int channels, float kstep, float grad_scale, float* ws, void* stream);
 
+/* ---- 3x3 / stride 1 / pad 1 forward convolution through the Winograd transform F(2x2, 3x3), fp32 arithmetic (2.25x fewer matrix
+ * FLOPs than the direct form; BasicBlock convs resnet.py:70-91, FPN smooth convs segmentation_body.py:55-61, the head's 256 -> 64
+ * convs segmentation_head.py:24-25,64-68).  fp32 NHWC tensors with H % 8 == 0, W % 16 == 0, Cs % 16 == 0 channels in the source
+ * tensor (I <= Cs of them real), Cd % 64 == 0 (dbn_winograd_eligible).  upanel: the filters transformed once per parameter update
+ * (dbn_winograd_pack; dbn_winograd_panel_floats(O, Cs) floats).  gamma non-NULL: the train-mode BatchNorm that follows is folded
+ * in exactly as in dbn_conv_bn_f32 (ws: dbn_winograd_ws_floats floats).  Same result as the direct convolution up to fp32 rounding
+ * of a different summation order (not bit for bit). */
+int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd);
+long dbn_winograd_panel_floats(int O, int Cs);
+int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, float* out, void* stream);
+long dbn_winograd_ws_floats(int N, int H, int W, int Cd);
+int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                             const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                             float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
+
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W].
  * One launch: the workgroup that finishes last folds every workgroup's partial sums (fixed order) and writes losses[5] and
  * coef[8].  ws: dbn_db_loss_ws_bytes() bytes, ZERO-FILLED by the caller before the first call (it ends with the arrival counter

@@ -1568,3 +1568,58 @@ def test_batchnorm_backward_from_given_partial_sums(C, N, H, W, parts):
     report('bn bwd (given sums, %d parts) dx' % parts, nchw(dy), dx_ref, 2e-5, 1e-4)
     report('dgamma', dg.cpu(), dg_ref, 1e-4, 1e-4)
     report('dbeta', db.cpu(), db_ref, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('N,Ci,Cs,Co,H,W', [(2, 64, 64, 64, 16, 32), (1, 128, 128, 128, 8, 16), (2, 32, 32, 64, 24, 16), (1, 20, 32, 192, 8, 48),
+                                            (3, 256, 256, 64, 16, 16)])
+@pytest.mark.parametrize('with_bn', [False, True])
+def test_winograd_conv3x3(N, Ci, Cs, Co, H, W, with_bn):
+    """dbn_winograd_conv_bn_f32: 3x3 / stride 1 / pad 1 forward convolution through Winograd F(2x2, 3x3) in fp32 (the BasicBlock, FPN
+    smooth and head convs of resnet.py:70-91, segmentation_body.py:55-61, segmentation_head.py:24-25) against F.conv2d in fp64, with
+    the bias and — with_bn — the folded train-mode BatchNorm statistics (scale / shift / saved mean / rstd / running statistics)
+    against F.batch_norm.  fp32 arithmetic with another summation order than the direct form: tolerance 2e-6 of the output scale
+    per element (the direct kernels' own fp32 rounding is ~3e-7 at K = 2304).  Cs > Ci: the source tensor carries padding channels."""
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(2.0 / (Ci * 9))**0.5)
+    b = rnd(Co, seed=3) * 0.1
+    xs = torch.zeros(N, H, W, Cs, device=DEV)
+    xs[..., :Ci] = nhwc(x)
+    up = torch.full((L().dbn_winograd_panel_floats(Co, Cs), ), float('nan'), device=DEV)
+    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Co, Ci, Cs, up.data_ptr(), stream()), 'winograd pack')
+    assert L().dbn_winograd_eligible(N, H, W, Cs, Co)
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    bd = b.to(DEV)
+    if not with_bn:
+        _lib.check(L().dbn_winograd_conv_bn_f32(xs.data_ptr(), up.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, Cs, Co, None, None, 0.0, 0.0,
+                                                None, None, None, None, None, None, None, stream()), 'winograd')
+    else:
+        gamma, beta = (rnd(Co, seed=4) * 0.3 + 1).to(DEV), rnd(Co, seed=5).to(DEV)
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        sc, sh, mu, rs = (torch.full((Co, ), float('nan'), device=DEV) for _ in range(4))
+        ws = torch.full((L().dbn_winograd_ws_floats(N, H, W, Co), ), float('nan'), device=DEV)
+        _lib.check(L().dbn_winograd_conv_bn_f32(xs.data_ptr(), up.data_ptr(), bd.data_ptr(), y.data_ptr(), N, H, W, Cs, Co, gamma.data_ptr(),
+                                                beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                                mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'winograd+bn')
+        mean = ref.mean((0, 2, 3))
+        var = ref.var((0, 2, 3), unbiased=False)
+        report('winograd BN mean', mu.cpu(), mean, 1e-5, 1e-5)
+        report('winograd BN rstd', rs.cpu(), 1.0 / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+        report('winograd BN scale', sc.cpu(), gamma.cpu().double() / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+        report('winograd BN shift', sh.cpu(), beta.cpu().double() - mean * gamma.cpu().double() / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+        n = N * H * W
+        report('winograd BN running mean', rm.cpu(), 0.1 * mean, 1e-6, 1e-5)
+        report('winograd BN running var', rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), 1e-6, 1e-4)
+    scale = float(ref.abs().max())
+    report('winograd conv3x3', nchw(y), ref, 2e-6 * scale, 2e-6)
+    # bit-reproducible from run to run, and against the direct kernel to fp32 rounding
+    y2 = torch.full_like(y, float('nan'))
+    _lib.check(L().dbn_winograd_conv_bn_f32(xs.data_ptr(), up.data_ptr(), bd.data_ptr(), y2.data_ptr(), N, H, W, Cs, Co, None, None, 0.0, 0.0,
+                                            None, None, None, None, None, None, None, stream()), 'winograd')
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    yd = torch.full_like(y, float('nan'))
+    wfull = torch.zeros(Co, Cs, 3, 3)
+    wfull[:, :Ci] = w
+    igemm(xs, pack(wfull, 0), bd, yd, 3, 1, 1, 0)
+    report('winograd vs the direct kernel', y.cpu(), yd.cpu(), 3e-6 * scale, 3e-6)
