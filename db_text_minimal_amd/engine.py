@@ -494,7 +494,7 @@ class Engine:
     # ------------------------------------------------------------------ kernels
     # 3x3 / stride-1 / pad-1 FORWARD convolutions of the exact-fp32 path through Winograd F(2x2, 3x3) (csrc/winograd_f32.hip): fp32
     # arithmetic, 2.25x fewer matrix FLOPs; the result equals the direct convolution up to fp32 rounding (another summation order).
-    winograd = os.environ.get('DBN_WINOGRAD', '0') == '1'
+    winograd = os.environ.get('DBN_WINOGRAD', '1') == '1'
 
     def _winograd_ok(self, x, conv):
         N, H, W, C = x.shape
