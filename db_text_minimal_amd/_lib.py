@@ -103,7 +103,9 @@ SIGNATURES.update({
     'dbn_set_stagger': 'i',
     'dbn_winograd_eligible': 'iiiii',
     'dbn_winograd_panel_floats': 'ii',
-    'dbn_winograd_pack': 'piiipp',
+    'dbn_winograd_pack': 'piiiipp',
+    'dbn_winograd_rows': 'iii',
+    'dbn_winograd_dgrad_bnsums_f32': 'ppp' + 'iiiiii' + 'pppp' + 'ppp' + 'pppp' + 'p' + 'p',
     'dbn_winograd_ws_floats': 'iiii',
     'dbn_winograd_conv_bn_f32': 'pppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_set_phase_priority': 'i',

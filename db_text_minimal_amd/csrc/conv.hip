@@ -497,10 +497,14 @@ int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd) {
            (long)N * H * W * std::max(Cs, Cd) * 4 < dbn_g_byte_limit && (long)N * H * W < dbn_g_pixel_limit;
 }
 long dbn_winograd_panel_floats(int O, int Cs) { return (long)Cs * 16 * O; }
-int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, float* out, void* stream) {
-    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && I <= Cs && Cs % 16 == 0 && O % 64 == 0);
-    return dbn_launch_winograd_pack(w_oihw, O, I, Cs, out, (hipStream_t)stream);
+// dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT of
+// the conv with weights w [I][O][3][3] (w's own output channels are this conv's I input channels, its input channels the O outputs):
+// the same kernel then maps dy (Cs >= I channels) to dx (O channels) — filters rotated by 180 degrees, channel roles swapped.
+int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, int dgrad, float* out, void* stream) {
+    DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && I <= Cs && Cs % 16 == 0 && O % 64 == 0 && (dgrad == 0 || dgrad == 1));
+    return dbn_launch_winograd_pack(w_oihw, O, I, Cs, dgrad, out, (hipStream_t)stream);
 }
+int dbn_winograd_rows(int N, int H, int W) { return N * (H / 8) * (W / 16); }
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * ((long)N * (H / 8) * (W / 16)); }
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
@@ -518,6 +522,37 @@ int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float*
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
+}
+
+// The data gradient of a 3x3 / stride-1 / pad-1 conv through the same kernel (upanel from dbn_winograd_pack(..., dgrad = 1)): dx [N,H,W,Cd]
+// = [dx +] conv(dy [N,H,W,Cs]).  y non-NULL: the epilogue also produces the two per-channel sums of the BatchNorm backward that consumes
+// dx — arguments and semantics of dbn_igemm_bnsums_t (part: [2][Cd][dbn_winograd_rows(N,H,W)] floats; fin: optional in-kernel finalize,
+// counters dbn_igemm_bn_final_counters(rows, Cd) ints as there).
+int dbn_winograd_dgrad_bnsums_f32(const float* dy, const float* upanel, float* dx, int N, int H, int W, int Cs, int Cd, int accumulate,
+                                  const void* y, const void* zmask, const float* mask_scale, const float* mask_shift,
+                                  const float* save_mean, const float* save_rstd, float* part, const void* y2, const float* save_mean2,
+                                  const float* save_rstd2, float* part2, const dbn_bnb_final* fin, void* stream) {
+    DBN_REQUIRE(dy && upanel && dx && dbn_winograd_eligible(N, H, W, Cs, Cd));
+    DBN_REQUIRE(!y || (save_mean && save_rstd && part && (zmask || (mask_scale && mask_shift))));
+    DBN_REQUIRE(!y2 || (y && zmask && save_mean2 && save_rstd2 && part2));
+    DBN_REQUIRE(!fin || (y && fin->counters && fin->group && fin->c1c2 && fin->dgamma && fin->dbeta &&
+                         (!y2 || (fin->c1c2_2 && fin->dgamma_2 && fin->dbeta_2))));
+    IgemmParams p{};
+    p.src = dy; p.wpk = upanel; p.bias = nullptr; p.dst = dx;
+    p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
+    p.accumulate = accumulate;
+    p.src_bytes = (unsigned)((long)N * H * W * Cs * 4);
+    p.stat_rows = dbn_winograd_rows(N, H, W); p.stat_row0 = 0;
+    if (y) {
+        p.bnb_y = y; p.bnb_zmask = zmask; p.bnb_msc = mask_scale; p.bnb_msh = mask_shift; p.bnb_mean = save_mean; p.bnb_rstd = save_rstd;
+        p.bnb_part = part; p.bnb_y2 = y2; p.bnb_mean2 = save_mean2; p.bnb_rstd2 = save_rstd2; p.bnb_part2 = part2;
+        if (fin) {
+            p.bnb_cnt = fin->counters; p.bnb_grp = fin->group; p.bnb_gscale = fin->grad_scale; p.bnb_invM = 1.0f / (float)((long)N * H * W);
+            p.bnb_c1c2[0] = fin->c1c2; p.bnb_dgamma[0] = fin->dgamma; p.bnb_dbeta[0] = fin->dbeta;
+            p.bnb_c1c2[1] = fin->c1c2_2; p.bnb_dgamma[1] = fin->dgamma_2; p.bnb_dbeta[1] = fin->dbeta_2;
+        }
+    }
+    return dbn_launch_winograd_f32(p, (hipStream_t)stream);
 }
 
 int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // floats (64 KB) + the statistics scratch
     constexpr int P_PATCH = 4 * W_PPX;
     constexpr int X_FLOATS = 4 * 2 * 2 * 16 * 64;
-    __shared__ f32x4 smem[X_FLOATS / 4 + (64 + 2 * 4 * 64) / 4 + 1];
+    __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 2];  // + the statistics / sums scratch [<= 3][4][64] floats and a flag
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
@@ -183,6 +183,161 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             y[b][r] = (dy == 0 ? (T(0) + t1) + t2 : (t1 - t2) - T(3)) + bias;
         }
     }
+    // destination offsets: tile t = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (ph0 + 2 (t >> 3) + dy, pw0 + 2 (t & 7) + dx), channel n0 + 32 b + li
+    const unsigned dst_bytes = (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4);
+    const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, dst_bytes, 0x00020000);
+    const unsigned pitch = (unsigned)p.Cd * 4u;
+    // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
+    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+    auto row_off = [&](int r) { return base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch; };
+    auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); };
+    if (p.accumulate) {  // (data gradients that add into an existing gradient: the sums below see the final values)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float old[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) old[i][b] = ldf(rsrcD, row_off(4 * g + i) + b * 128);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y[b][4 * g + i] += old[i][b];
+        }
+    }
+    // ---- optional: the two per-channel sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_*; igemm_kernel.h EPI = 1):
+    //      g = dz * [mask > 0],  part[0][c][row] = sum g,  part[1][c][row] = sum g * (ybn - mean[c]) * rstd[c]  over this 128-pixel tile
+    if (p.bnb_part) {
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y), 0, dst_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_zmask ? p.bnb_zmask : p.bnb_y), 0, dst_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y2 ? p.bnb_y2 : p.bnb_y), 0, dst_bytes, 0x00020000);
+        const bool zm = p.bnb_zmask != nullptr, two = p.bnb_y2 != nullptr;
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, s4[2] = {0.f, 0.f};
+        float mu[2], rsd[2], msc[2], msh[2], mu2[2], rs2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = n0 + b * 32 + li;
+            mu[b] = p.bnb_mean[c];
+            rsd[b] = p.bnb_rstd[c];
+            msc[b] = zm ? 0.f : p.bnb_msc[c];
+            msh[b] = zm ? 0.f : p.bnb_msh[c];
+            mu2[b] = two ? p.bnb_mean2[c] : 0.f;
+            rs2[b] = two ? p.bnb_rstd2[c] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float yv[4][2], zv[4][2], y2v[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const unsigned off = row_off(4 * g + i) + b * 128;
+                    yv[i][b] = ldf(rsY, off);
+                    zv[i][b] = zm ? ldf(rsZ, off) : 0.f;
+                    y2v[i][b] = two ? ldf(rsY2, off) : 0.f;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float m_ = zm ? zv[i][b] : dbn_affine(yv[i][b], msc[b], msh[b]);
+                    const float gq = m_ > 0.f ? y[b][4 * g + i] : 0.f;
+                    s1[b] += gq;
+                    s2[b] += gq * ((yv[i][b] - mu[b]) * rsd[b]);
+                    s4[b] += gq * ((y2v[i][b] - mu2[b]) * rs2[b]);
+                }
+        }
+        float* const red = reinterpret_cast<float*>(smem) + X_FLOATS;  // [3][4 waves][64]
+        __syncthreads();  // (the exchange buffer X has been read by everyone; red lies behind it, but keep the phases apart)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32, 64), t2 = s2[b] + __shfl_xor(s2[b], 32, 64), t4 = s4[b] + __shfl_xor(s4[b], 32, 64);
+            if (lh == 0) {
+                red[(0 * 4 + wave) * 64 + b * 32 + li] = t1;
+                red[(1 * 4 + wave) * 64 + b * 32 + li] = t2;
+                red[(2 * 4 + wave) * 64 + b * 32 + li] = t4;
+            }
+        }
+        __syncthreads();
+        const int trow = p.stat_row0 + mt;
+        if (tid < 64) {
+            auto fold4 = [&](int k) { return (red[(k * 4 + 0) * 64 + tid] + red[(k * 4 + 1) * 64 + tid]) + (red[(k * 4 + 2) * 64 + tid] + red[(k * 4 + 3) * 64 + tid]); };
+            const float t1 = fold4(0), t2 = fold4(1), t4 = fold4(2);
+            const long c = n0 + tid;
+            // (read by another workgroup of this launch when the in-kernel finalize is on: memory-side stores)
+            auto put = [&](float* part, int k, float v) {
+                float* dstp = part + ((long)k * p.Cd + c) * p.stat_rows + trow;
+                if (p.bnb_cnt) __hip_atomic_store(dstp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dstp = v;
+            };
+            put(p.bnb_part, 0, t1);
+            put(p.bnb_part, 1, t2);
+            if (two) {
+                put(p.bnb_part2, 0, t1);
+                put(p.bnb_part2, 1, t4);
+            }
+        }
+        if (p.bnb_cnt) {
+            // in-kernel finalize, as igemm_kernel.h bnb_finish (BN = 64 columns per workgroup): the last workgroup of each group of
+            // 64 partial rows folds the group, the last group-folder of this column tile folds the groups — fixed order, integer counters
+            constexpr int G = 64;
+            const int NG = (p.stat_rows + G - 1) / G, gq = trow / G;
+            const int nbn = two ? 2 : 1;
+            int* const cnt = p.bnb_cnt + nt * (NG + 1);
+            int* const s_flag = reinterpret_cast<int*>(red + 3 * 4 * 64);
+            auto xld = [](const float* ptr) { return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            DBN_RACE_JITTER();
+            if (tid == 0) {
+                const int gsize = min(G, p.stat_rows - gq * G);
+                const int last = __hip_atomic_fetch_add(cnt + 1 + gq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+                if (last) __hip_atomic_store(cnt + 1 + gq, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_flag = last;
+            }
+            __syncthreads();
+            if (*s_flag) {
+                const int r0 = gq * G, r1_ = min(p.stat_rows, r0 + G);
+                for (int it = tid; it < nbn * 2 * 64; it += 256) {
+                    const int bq = it / 128, ks = (it / 64) & 1, cl = it % 64;
+                    const float* src = (bq ? p.bnb_part2 : p.bnb_part) + ((long)ks * p.Cd + n0 + cl) * p.stat_rows;
+                    double sd = 0.0;
+                    int r = r0;
+                    for (; r + 3 < r1_; r += 4) sd += ((double)xld(src + r) + (double)xld(src + r + 1)) + ((double)xld(src + r + 2) + (double)xld(src + r + 3));
+                    for (; r < r1_; ++r) sd += (double)xld(src + r);
+                    __hip_atomic_store(p.bnb_grp + (((long)bq * 2 + ks) * p.Cd + n0 + cl) * NG + gq, (float)sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                DBN_RACE_JITTER();
+                if (tid == 0) {
+                    const int last = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NG - 1;
+                    if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *s_flag = last;
+                }
+                __syncthreads();
+                if (*s_flag) {
+                    for (int it = tid; it < nbn * 64; it += 256) {
+                        const int bq = it / 64, cl = it % 64;
+                        const long c = n0 + cl;
+                        const float* g1 = p.bnb_grp + (((long)bq * 2 + 0) * p.Cd + c) * NG;
+                        const float* g2 = p.bnb_grp + (((long)bq * 2 + 1) * p.Cd + c) * NG;
+                        double a1_ = 0.0, a2_ = 0.0;
+                        for (int q_ = 0; q_ < NG; ++q_) {
+                            a1_ += (double)xld(g1 + q_);
+                            a2_ += (double)xld(g2 + q_);
+                        }
+                        p.bnb_dbeta[bq][c] = (float)(a1_ * p.bnb_gscale);
+                        p.bnb_dgamma[bq][c] = (float)(a2_ * p.bnb_gscale);
+                        p.bnb_c1c2[bq][c] = (float)(a1_ * p.bnb_invM);
+                        p.bnb_c1c2[bq][p.Cd + c] = (float)(a2_ * p.bnb_invM);
+                    }
+                }
+            }
+        }
+    }
     // ---- optional BatchNorm statistics of this 128-pixel tile (pivot, sum, sum of squares per channel; igemm_kernel.h's format)
     if (p.stats) {
         float* const piv = reinterpret_cast<float*>(smem) + X_FLOATS;  // [64]
@@ -222,22 +377,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = 128.f;
     }
-    // ---- stores: tile t = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (ph0 + 2 (t >> 3) + dy, pw0 + 2 (t & 7) + dx), channel n0 + 32 b + li
-    const __amdgpu_buffer_rsrc_t rsrcD =
-        __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4), 0x00020000);
-    const unsigned pitch = (unsigned)p.Cd * 4u;
-    // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
-    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+    // ---- stores
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const unsigned off = base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch;
+        const unsigned off = row_off(r);
 #pragma unroll
         for (int b = 0; b < 2; ++b) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[b][r]), rsrcD, (int)off + b * 128, 0, 0);
     }
 }
 
 // U = G g G^T per (output, input) channel pair, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; panel [I/16][16 points][4 chunks][O][4]
-__global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, int Cs, float* __restrict__ out) {
+// dgrad = 1: the panel of the DATA GRADIENT of the conv with weights w [Ow][Iw][3][3] — itself a 3x3 / stride-1 / pad-1 convolution of
+// dy (Ow channels) with the filters rotated by 180 degrees and the channel roles swapped: g'[o' = iw][c' = ow][r][s] = w[ow][iw][2-r][2-s];
+// then O = Iw output and I = Ow input channels
+__global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, int Cs, int dgrad, float* __restrict__ out) {
     const long total = (long)Cs * O;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int o = (int)(idx % O), ci = (int)(idx / O);
@@ -245,7 +398,8 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, 
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) g[r][s] = ci < I ? w[(((long)o * I + ci) * 3 + r) * 3 + s] : 0.f;
+            for (int s = 0; s < 3; ++s)
+                g[r][s] = ci >= I ? 0.f : dgrad ? w[(((long)ci * O + o) * 3 + (2 - r)) * 3 + (2 - s)] : w[(((long)o * I + ci) * 3 + r) * 3 + s];
         float t[4][3];  // G g
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -273,7 +427,7 @@ int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
     return dbn_status();
 }
 
-int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(winograd_pack_kernel, dim3(dbn_grid((long)Cs * O)), dim3(256), 0, st, w, O, I, Cs, out);
+int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, int dgrad, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(winograd_pack_kernel, dim3(dbn_grid((long)Cs * O)), dim3(256), 0, st, w, O, I, Cs, dgrad, out);
     return dbn_status();
 }

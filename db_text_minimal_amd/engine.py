@@ -501,16 +501,17 @@ class Engine:
         return (self.winograd and self.ns == 0 and self.at == 0 and x.dtype == torch.float32 and conv.k == 3 and conv.stride == 1 and
                 conv.padding == 1 and bool(self.L.dbn_winograd_eligible(N, H, W, C, conv.cout)))
 
-    def _winograd_panel(self, name, w, cs):
-        """G g G^T of every filter, re-made when the parameter changed (one small launch per layer and step)."""
-        key = (name, 'winograd', cs)
+    def _winograd_panel(self, name, w, cs, dgrad=0):
+        """G g G^T of every filter (dgrad: of the rotated / transposed filters of the data gradient), re-made when the parameter
+        changed (one small launch per layer and step)."""
+        key = (name, 'winograd', cs, dgrad)
         ent = self.packs.get(key)
         stamp = (w._version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
-        O, I = w.shape[0], w.shape[1]
+        O, I = (w.shape[1], w.shape[0]) if dgrad else (w.shape[0], w.shape[1])  # channels out of / into THIS conv
         out = ent[0] if ent is not None else device_empty(self.L.dbn_winograd_panel_floats(O, cs), w.device)
-        check(self.L.dbn_winograd_pack(w.data_ptr(), O, I, cs, out.data_ptr(), self.stream), 'winograd pack ' + name)
+        check(self.L.dbn_winograd_pack(w.data_ptr(), O, I, cs, dgrad, out.data_ptr(), self.stream), 'winograd pack ' + name)
         self.packs[key] = (out, stamp)
         return out
 
@@ -642,10 +643,68 @@ class Engine:
         blk = 'false' if (geom is not None and mode == 0 and geom[3] % 16 != 0) else 'true'
         self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, 0.0, tag)
 
+    def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer):
+        """The data gradient of a 3x3 / stride-1 / pad-1 conv through the Winograd kernel (the rotated / transposed filters), with the
+        BatchNorm-backward sums of its consumer in the epilogue exactly as _igemm arranges them for the implicit-GEMM kernels."""
+        import ctypes
+        N, H, W, O = dy.shape
+        Cd = dx.shape[3]
+        up = self._winograd_panel(name, conv.weight, O, dgrad=1)
+        L = self.L
+        rows = L.dbn_winograd_rows(N, H, W)
+        a = dict(y=None, zmask=None, msc=None, msh=None, mean=None, rstd=None, part=None, y2=None, mean2=None, rstd2=None, part2=None)
+        fin = None
+        if consumer is not None:
+            bn_name, y, zmask = consumer[:3]
+            second = consumer[3] if len(consumer) > 3 else None
+            assert tuple(y.shape) == (N, H, W, Cd) and (zmask is None or zmask.shape == y.shape), (name, bn_name)
+            a.update(y=y, zmask=zmask, mean=self.bufs[bn_name + '/mean'], rstd=self.bufs[bn_name + '/rstd'],
+                     part=self.fbuf(bn_name + '/bnb_part', 2 * Cd * rows))
+            if zmask is None:
+                a.update(msc=self.bufs[bn_name + '/scale'], msh=self.bufs[bn_name + '/shift'])
+            if second is not None:
+                assert zmask is not None and second[1].shape == y.shape
+                a.update(y2=second[1], mean2=self.bufs[second[0] + '/mean'], rstd2=self.bufs[second[0] + '/rstd'],
+                         part2=self.fbuf(second[0] + '/bnb_part', 2 * Cd * rows))
+            if self.bnb_finalize_in_kernel:
+                G = self.grad_views
+                cnt = self.bufs.get(bn_name + '/bnb_cnt')
+                ncnt = L.dbn_igemm_bn_final_counters(rows, Cd)
+                if cnt is None or cnt.numel() != ncnt or cnt.device != self.flat.device:
+                    cnt = torch.zeros(ncnt, device=self.flat.device, dtype=torch.int32)  # (the kernels leave them zero)
+                    self.bufs[bn_name + '/bnb_cnt'] = cnt
+                grp = self.fbuf(bn_name + '/bnb_grp', L.dbn_igemm_bn_final_group_floats(rows, Cd))
+                c1c2 = self.fbuf(bn_name + '/bnb_c1c2', 2 * Cd)
+                fin = _lib.BnbFinal(cnt.data_ptr(), grp.data_ptr(), c1c2.data_ptr(), G[bn_name + '.weight'].data_ptr(),
+                                    G[bn_name + '.bias'].data_ptr(), None, None, None, self.grad_scale)
+                if second is not None:
+                    c1c2b = self.fbuf(second[0] + '/bnb_c1c2', 2 * Cd)
+                    fin.c1c2_2, fin.dgamma_2, fin.dbeta_2 = (c1c2b.data_ptr(), G[second[0] + '.weight'].data_ptr(),
+                                                             G[second[0] + '.bias'].data_ptr())
+        if self.prof:  # (FLOPs the MFMA pipe executes: see _winograd_conv)
+            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * O * Cd * 4, 0.0, 'dgrad ' + name)
+        check(L.dbn_winograd_dgrad_bnsums_f32(dy.data_ptr(), up.data_ptr(), dx.data_ptr(), N, H, W, O, Cd, int(accumulate), _p(a['y']),
+                                              _p(a['zmask']), _p(a['msc']), _p(a['msh']), _p(a['mean']), _p(a['rstd']), _p(a['part']),
+                                              _p(a['y2']), _p(a['mean2']), _p(a['rstd2']), _p(a['part2']),
+                                              ctypes.byref(fin) if fin is not None else None, self.stream), 'winograd dgrad ' + name)
+        if self.prof:
+            self.prof.end()
+        if consumer is not None:
+            self._bnb_sums[consumer[0]] = (c1c2, -1) if fin is not None else (a['part'], rows)
+            if len(consumer) > 3 and consumer[3] is not None:
+                self._bnb_sums[consumer[3][0]] = (c1c2b, -1) if fin is not None else (a['part2'], rows)
+
     def conv_dgrad(self, name, dy, conv, dx, accumulate, version=None, consumer=None):
         """consumer: see _igemm — the BatchNorm that will consume dx, when this call is dx's last writer."""
         N, Ho, Wo, O = dy.shape
         _, H, W, I = dx.shape
+        if (version is None and self.winograd and self.ns == 0 and self.at == 0 and conv.k == 3 and conv.stride == 1 and conv.padding == 1
+                and (Ho, Wo) == (H, W) and dy.dtype == torch.float32 and I == conv.cin and O == conv.cout
+                and bool(self.L.dbn_winograd_eligible(N, H, W, O, I))):
+            if consumer is not None and not (self.fuse_bn_bwd_sums and not (self.prof is not None and self.prof.labels is None and not self.prof_fused)):
+                consumer = None
+            self._winograd_dgrad(name, dy, conv, dx, accumulate, consumer)
+            return
         wpk = self.pack(name, conv.weight, 1, conv.stride, version=version)
         args = (dy.data_ptr(), wpk.data_ptr(), None, dx.data_ptr(), N, Ho, Wo, O, H, W, I, conv.k, conv.k, conv.stride, conv.padding, 1,
                 int(accumulate), 0)

@@ -241,7 +241,18 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
  * of a different summation order (not bit for bit). */
 int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd);
 long dbn_winograd_panel_floats(int O, int Cs);
-int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, float* out, void* stream);
+/* dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT
+ * of the conv with weights w [I][O][3][3] (filters rotated by 180 degrees, channel roles swapped): maps dy (Cs >= I channels) to dx (O). */
+int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, int dgrad, float* out, void* stream);
+int dbn_winograd_rows(int N, int H, int W);
+/* The data gradient through the same kernel: dx [N,H,W,Cd] = [dx +] conv(dy [N,H,W,Cs]) with the dgrad = 1 panel.  y non-NULL: the
+ * epilogue also produces the two per-channel sums of the BatchNorm backward that consumes dx — arguments and semantics of
+ * dbn_igemm_bnsums_t, part = [2][Cd][dbn_winograd_rows(N,H,W)] floats, fin = optional in-kernel finalize (counters sized by
+ * dbn_igemm_bn_final_counters(rows, Cd)). */
+int dbn_winograd_dgrad_bnsums_f32(const float* dy, const float* upanel, float* dx, int N, int H, int W, int Cs, int Cd, int accumulate,
+                                  const void* y, const void* zmask, const float* mask_scale, const float* mask_shift,
+                                  const float* save_mean, const float* save_rstd, float* part, const void* y2, const float* save_mean2,
+                                  const float* save_rstd2, float* part2, const dbn_bnb_final* fin, void* stream);
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd);
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,

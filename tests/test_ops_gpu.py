@@ -1585,7 +1585,7 @@ def test_winograd_conv3x3(N, Ci, Cs, Co, H, W, with_bn):
     xs = torch.zeros(N, H, W, Cs, device=DEV)
     xs[..., :Ci] = nhwc(x)
     up = torch.full((L().dbn_winograd_panel_floats(Co, Cs), ), float('nan'), device=DEV)
-    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Co, Ci, Cs, up.data_ptr(), stream()), 'winograd pack')
+    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Co, Ci, Cs, 0, up.data_ptr(), stream()), 'winograd pack')
     assert L().dbn_winograd_eligible(N, H, W, Cs, Co)
     y = torch.full((N, H, W, Co), float('nan'), device=DEV)
     ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
@@ -1623,3 +1623,83 @@ def test_winograd_conv3x3(N, Ci, Cs, Co, H, W, with_bn):
     wfull[:, :Ci] = w
     igemm(xs, pack(wfull, 0), bd, yd, 3, 1, 1, 0)
     report('winograd vs the direct kernel', y.cpu(), yd.cpu(), 3e-6 * scale, 3e-6)
+
+
+@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 128, 64, 8, 16), (2, 64, 256, 8, 32)])
+@pytest.mark.parametrize('mask,accumulate', [('self', 0), ('tensor', 1), ('none', 1)])
+def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
+    """dbn_winograd_dgrad_bnsums_f32: the data gradient of a 3x3 / stride-1 / pad-1 conv (Ci -> Co) through the Winograd kernel with
+    the rotated / transposed filter panel, [+ accumulate], and in its epilogue the two sums of the BatchNorm backward that consumes dx
+    (mask recomputed from the BatchNorm's own output, or a mask tensor with a SECOND BatchNorm over the same gradient) plus the
+    in-kernel finalize — against autograd in fp64 (conv -> BN -> ReLU chain of resnet.py:70-91; same contract as
+    test_batchnorm_backward_sums_in_the_data_gradient for the implicit-GEMM kernels)."""
+    import ctypes
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(2.0 / (Ci * 9))**0.5)
+    yf = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dyt = rnd(N, Co, H, W, seed=4)
+    (dx_ref, ) = torch.autograd.grad(yf, x, dyt.double())
+    old = rnd(N, Ci, H, W, seed=13)
+    if accumulate:
+        dx_ref = dx_ref + old.double()
+    dys = nhwc(dyt)
+    up = torch.full((L().dbn_winograd_panel_floats(Ci, Co), ), float('nan'), device=DEV)
+    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Ci, Co, Co, 1, up.data_ptr(), stream()), 'winograd pack (dgrad)')
+    dx = nhwc(old).clone() if accumulate else torch.full((N, H, W, Ci), float('nan'), device=DEV)
+    ybn = rnd(N, Ci, H, W, seed=7)
+    mean, rstd = rnd(Ci, seed=8, scale=0.2), rnd(Ci, seed=9).abs() + 0.5
+    msc, msh = rnd(Ci, seed=10), rnd(Ci, seed=11, scale=0.3)
+    z = rnd(N, Ci, H, W, seed=12)
+    y2 = rnd(N, Ci, H, W, seed=21)
+    mean2, rstd2 = rnd(Ci, seed=22, scale=0.3), rnd(Ci, seed=23).abs() + 0.4
+    rows = L().dbn_winograd_rows(N, H, W)
+    d = lambda t: t.contiguous().to(DEV)
+    ys, zs, y2s = nhwc(ybn), nhwc(z), nhwc(y2)
+    mean_d, rstd_d, msc_d, msh_d, mean2_d, rstd2_d = d(mean), d(rstd), d(msc), d(msh), d(mean2), d(rstd2)
+    two = mask == 'tensor'
+    part = torch.full((2, Ci, rows), float('nan'), device=DEV)
+    part2 = torch.full((2, Ci, rows), float('nan'), device=DEV)
+    cnt = torch.zeros(L().dbn_igemm_bn_final_counters(rows, Ci), device=DEV, dtype=torch.int32)
+    grp = torch.full((L().dbn_igemm_bn_final_group_floats(rows, Ci), ), float('nan'), device=DEV)
+    fo = [torch.full((n_, ), float('nan'), device=DEV) for n_ in (2 * Ci, Ci, Ci, 2 * Ci, Ci, Ci)]
+    fin = _lib.BnbFinal(cnt.data_ptr(), grp.data_ptr(), fo[0].data_ptr(), fo[1].data_ptr(), fo[2].data_ptr(),
+                        fo[3].data_ptr() if two else None, fo[4].data_ptr() if two else None, fo[5].data_ptr() if two else None, 0.5)
+    for rep in range(2):  # twice: the second call relies on the counters the first one left behind
+        if rep and accumulate:
+            dx.copy_(nhwc(old))
+        if mask == 'none':
+            _lib.check(L().dbn_winograd_dgrad_bnsums_f32(dys.data_ptr(), up.data_ptr(), dx.data_ptr(), N, H, W, Co, Ci, accumulate, None, None,
+                                                         None, None, None, None, None, None, None, None, None, None, stream()), 'winograd dgrad')
+        else:
+            _lib.check(L().dbn_winograd_dgrad_bnsums_f32(dys.data_ptr(), up.data_ptr(), dx.data_ptr(), N, H, W, Co, Ci, accumulate, ys.data_ptr(),
+                                                         zs.data_ptr() if two else None, None if two else msc_d.data_ptr(),
+                                                         None if two else msh_d.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(), part.data_ptr(),
+                                                         y2s.data_ptr() if two else None, mean2_d.data_ptr() if two else None,
+                                                         rstd2_d.data_ptr() if two else None, part2.data_ptr() if two else None,
+                                                         ctypes.byref(fin), stream()), 'winograd dgrad + sums')
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0, 'the finalize left a counter behind'
+    scale = float(dx_ref.abs().max())
+    report('winograd dgrad', nchw(dx), dx_ref, 3e-6 * scale, 3e-6)
+    if mask == 'none':
+        return
+    dz = nchw(dx).double()  # the sums are over the kernel's own final values
+    m32 = torch.addcmul(msh.view(1, -1, 1, 1), ybn, msc.view(1, -1, 1, 1))
+    m = z.double() if two else m32.double()
+    if not two:
+        assert bool((m32.abs() > 1e-6).all()), 'test data has a mask value at round-off level'
+    g = dz * (m > 0)
+    xhat = (ybn.double() - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
+    s1, s2 = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
+    sc = float(g.abs().sum((0, 2, 3)).max()) + 1e-9
+    report('winograd bn-backward sums', part.double().sum(2).cpu(), torch.stack([s1, s2]), 2e-6 * sc, 1e-5)
+    Mtot = N * H * W
+    report('finalized c1, c2', fo[0].cpu().view(2, Ci), torch.stack([s1, s2]) / Mtot, 2e-6 * sc / Mtot, 1e-5)
+    report('finalized dgamma', fo[1].cpu(), 0.5 * s2, 2e-6 * sc, 1e-5)
+    report('finalized dbeta', fo[2].cpu(), 0.5 * s1, 2e-6 * sc, 1e-5)
+    if two:
+        xhat2 = (y2.double() - mean2.double().view(1, -1, 1, 1)) * rstd2.double().view(1, -1, 1, 1)
+        s2b = (g * xhat2).sum((0, 2, 3))
+        report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, s2b]), 2e-6 * sc, 1e-5)
+        report('second BatchNorm finalized', torch.cat([fo[3].cpu(), fo[4].cpu(), fo[5].cpu()]),
+               torch.cat([s1 / Mtot, s2b / Mtot, 0.5 * s2b, 0.5 * s1]), 2e-6 * sc, 1e-5)

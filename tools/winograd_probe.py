@@ -29,7 +29,7 @@ for (N, H, Ci, Co, what) in ((16, 160, 64, 64, 'layer1 / smooth_p2'), (16, 160, 
     rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
     sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
     up = torch.empty(L().dbn_winograd_panel_floats(Co, Ci), device=DEV)
-    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Co, Ci, Ci, up.data_ptr(), stream()), 'pack')
+    _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Co, Ci, Ci, 0, up.data_ptr(), stream()), 'pack')
     wsw = torch.empty(L().dbn_winograd_ws_floats(N, H, H, Co), device=DEV)
     wp = pack(w, 0)
     wsd = torch.empty(L().dbn_conv_bn_ws_floats(N, H, H, Co, 0, 1), device=DEV)
