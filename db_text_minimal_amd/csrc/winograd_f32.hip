@@ -168,10 +168,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             X[(((wave * 2 + 0) * 2 + b) * 16 + r) * 64 + lane] = (m0_ + m1_) + m2_;
             X[(((wave * 2 + 1) * 2 + b) * 16 + r) * 64 + lane] = (m1_ - m2_) - m3_;
         }
+    // (the accumulators are dead from here on: their registers take the epilogue's global loads, ALL issued before the exchange
+    // barrier so that their latency hides behind it and the LDS reads below — in groups of four rows behind scheduling fences they
+    // were four exposed round trips per tile: the head's accumulating data gradient with sums took 728 us against 558 us without)
+    const int dy = wave >> 1, dx = wave & 1;
+    // destination offsets: tile t = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (ph0 + 2 (t >> 3) + dy, pw0 + 2 (t & 7) + dx), channel n0 + 32 b + li
+    const unsigned dst_bytes = (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4);
+    const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, dst_bytes, 0x00020000);
+    const unsigned pitch = (unsigned)p.Cd * 4u;
+    // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
+    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+    auto row_off = [&](int r) { return base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch; };
+    auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); };
+    const bool sums = p.bnb_part != nullptr, zm = p.bnb_zmask != nullptr, two = p.bnb_y2 != nullptr;
+    float oldv[2][16], yv[2][16], zv[2][16], y2v[2][16];
+    if (p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) oldv[b][r] = ldf(rsrcD, row_off(r) + b * 128);
+    }
+    if (sums) {
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y), 0, dst_bytes, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) yv[b][r] = ldf(rsY, row_off(r) + b * 128);
+        if (zm) {
+            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_zmask), 0, dst_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) zv[b][r] = ldf(rsZ, row_off(r) + b * 128);
+        }
+        if (two) {
+            const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y2), 0, dst_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y2v[b][r] = ldf(rsY2, row_off(r) + b * 128);
+        }
+    }
     __syncthreads();
     // along i, across the waves: wave w produces the output pixel (dy, dx) = (w >> 1, w & 1) of every tile:
     //   dy 0: T_0 + T_1 + T_2;  dy 1: T_1 - T_2 - T_3
-    const int dy = wave >> 1, dx = wave & 1;
     float y[2][16];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -183,71 +223,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             y[b][r] = (dy == 0 ? (T(0) + t1) + t2 : (t1 - t2) - T(3)) + bias;
         }
     }
-    // destination offsets: tile t = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (ph0 + 2 (t >> 3) + dy, pw0 + 2 (t & 7) + dx), channel n0 + 32 b + li
-    const unsigned dst_bytes = (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4);
-    const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, dst_bytes, 0x00020000);
-    const unsigned pitch = (unsigned)p.Cd * 4u;
-    // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
-    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
-    auto row_off = [&](int r) { return base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch; };
-    auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); };
     if (p.accumulate) {  // (data gradients that add into an existing gradient: the sums below see the final values)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float old[4][2];
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) old[i][b] = ldf(rsrcD, row_off(4 * g + i) + b * 128);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) y[b][4 * g + i] += old[i][b];
-        }
+            for (int r = 0; r < 16; ++r) y[b][r] += oldv[b][r];
     }
     // ---- optional: the two per-channel sums of the BatchNorm backward that consumes dst (IgemmParams::bnb_*; igemm_kernel.h EPI = 1):
     //      g = dz * [mask > 0],  part[0][c][row] = sum g,  part[1][c][row] = sum g * (ybn - mean[c]) * rstd[c]  over this 128-pixel tile
-    if (p.bnb_part) {
-        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y), 0, dst_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_zmask ? p.bnb_zmask : p.bnb_y), 0, dst_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.bnb_y2 ? p.bnb_y2 : p.bnb_y), 0, dst_bytes, 0x00020000);
-        const bool zm = p.bnb_zmask != nullptr, two = p.bnb_y2 != nullptr;
+    if (sums) {
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, s4[2] = {0.f, 0.f};
-        float mu[2], rsd[2], msc[2], msh[2], mu2[2], rs2[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int c = n0 + b * 32 + li;
-            mu[b] = p.bnb_mean[c];
-            rsd[b] = p.bnb_rstd[c];
-            msc[b] = zm ? 0.f : p.bnb_msc[c];
-            msh[b] = zm ? 0.f : p.bnb_msh[c];
-            mu2[b] = two ? p.bnb_mean2[c] : 0.f;
-            rs2[b] = two ? p.bnb_rstd2[c] : 0.f;
-        }
+            const float mu = p.bnb_mean[c], rsd = p.bnb_rstd[c];
+            const float msc = zm ? 0.f : p.bnb_msc[c], msh = zm ? 0.f : p.bnb_msh[c];
+            const float mu2 = two ? p.bnb_mean2[c] : 0.f, rs2 = two ? p.bnb_rstd2[c] : 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float yv[4][2], zv[4][2], y2v[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const unsigned off = row_off(4 * g + i) + b * 128;
-                    yv[i][b] = ldf(rsY, off);
-                    zv[i][b] = zm ? ldf(rsZ, off) : 0.f;
-                    y2v[i][b] = two ? ldf(rsY2, off) : 0.f;
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float m_ = zm ? zv[i][b] : dbn_affine(yv[i][b], msc[b], msh[b]);
-                    const float gq = m_ > 0.f ? y[b][4 * g + i] : 0.f;
-                    s1[b] += gq;
-                    s2[b] += gq * ((yv[i][b] - mu[b]) * rsd[b]);
-                    s4[b] += gq * ((y2v[i][b] - mu2[b]) * rs2[b]);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float m_ = zm ? zv[b][r] : dbn_affine(yv[b][r], msc, msh);
+                const float gq = m_ > 0.f ? y[b][r] : 0.f;
+                s1[b] += gq;
+                s2[b] += gq * ((yv[b][r] - mu) * rsd);
+                if (two) s4[b] += gq * ((y2v[b][r] - mu2) * rs2);
+            }
         }
         float* const red = reinterpret_cast<float*>(smem) + X_FLOATS;  // [3][4 waves][64]
         __syncthreads();  // (the exchange buffer X has been read by everyone; red lies behind it, but keep the phases apart)

@@ -1646,9 +1646,11 @@ def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
     up = torch.full((L().dbn_winograd_panel_floats(Ci, Co), ), float('nan'), device=DEV)
     _lib.check(L().dbn_winograd_pack(w.to(DEV).data_ptr(), Ci, Co, Co, 1, up.data_ptr(), stream()), 'winograd pack (dgrad)')
     dx = nhwc(old).clone() if accumulate else torch.full((N, H, W, Ci), float('nan'), device=DEV)
-    ybn = rnd(N, Ci, H, W, seed=7)
+    # (values on a 2^-6 grid: fma(y, sc, sh) is then exact in fp32, so the recomputed ReLU mask cannot differ from the fp64 one by round-off)
+    grid = lambda t: torch.round(t * 64) / 64
+    ybn = grid(rnd(N, Ci, H, W, seed=7))
     mean, rstd = rnd(Ci, seed=8, scale=0.2), rnd(Ci, seed=9).abs() + 0.5
-    msc, msh = rnd(Ci, seed=10), rnd(Ci, seed=11, scale=0.3)
+    msc, msh = grid(rnd(Ci, seed=10)), grid(rnd(Ci, seed=11, scale=0.3)) + 1.0 / 128
     z = rnd(N, Ci, H, W, seed=12)
     y2 = rnd(N, Ci, H, W, seed=21)
     mean2, rstd2 = rnd(Ci, seed=22, scale=0.3), rnd(Ci, seed=23).abs() + 0.4
@@ -1686,8 +1688,6 @@ def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
     dz = nchw(dx).double()  # the sums are over the kernel's own final values
     m32 = torch.addcmul(msh.view(1, -1, 1, 1), ybn, msc.view(1, -1, 1, 1))
     m = z.double() if two else m32.double()
-    if not two:
-        assert bool((m32.abs() > 1e-6).all()), 'test data has a mask value at round-off level'
     g = dz * (m > 0)
     xhat = (ybn.double() - mean.double().view(1, -1, 1, 1)) * rstd.double().view(1, -1, 1, 1)
     s1, s2 = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
