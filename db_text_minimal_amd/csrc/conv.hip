@@ -492,9 +492,12 @@ int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, 
 // channels), Cd % 64 == 0, tensors below 3.75 GB; upanel from dbn_winograd_pack (dbn_winograd_panel_floats floats: the filters
 // transformed once per parameter update).  gamma != NULL: the train-mode BatchNorm that follows is folded in as in dbn_conv_bn_t
 // (ws: dbn_winograd_ws_floats floats).  Not bit-identical to the direct convolution (another fp32 summation: ~1e-6 relative).
+// (any map size runs: right / bottom patches may be ragged — their pixels past the map are masked — but the kernel only pays when most
+// of the 8 x 16 patches are real: >= 3/4 of the patch area, e.g. 40 x 40 maps (40 x 48 computed) yes, 20 x 20 (24 x 32) no)
 int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd) {
-    return N > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 16 == 0 && Cs > 0 && Cs % 16 == 0 && Cd > 0 && Cd % 64 == 0 &&
-           (long)N * H * W * std::max(Cs, Cd) * 4 < dbn_g_byte_limit && (long)N * H * W < dbn_g_pixel_limit;
+    if (!(N > 0 && H > 0 && W > 0 && Cs > 0 && Cs % 16 == 0 && Cd > 0 && Cd % 64 == 0)) return 0;
+    const long Hp = (H + 7) / 8 * 8, Wp = (W + 15) / 16 * 16;
+    return 4L * H * W >= 3L * Hp * Wp && (long)N * H * W * std::max(Cs, Cd) * 4 < dbn_g_byte_limit && (long)N * Hp * Wp < dbn_g_pixel_limit;
 }
 long dbn_winograd_panel_floats(int O, int Cs) { return (long)Cs * 16 * O; }
 // dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT of
@@ -504,8 +507,8 @@ int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, int dgrad, floa
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && I <= Cs && Cs % 16 == 0 && O % 64 == 0 && (dgrad == 0 || dgrad == 1));
     return dbn_launch_winograd_pack(w_oihw, O, I, Cs, dgrad, out, (hipStream_t)stream);
 }
-int dbn_winograd_rows(int N, int H, int W) { return N * (H / 8) * (W / 16); }
-long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * ((long)N * (H / 8) * (W / 16)); }
+int dbn_winograd_rows(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16); }
+long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * dbn_winograd_rows(N, H, W); }
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                              float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
@@ -515,7 +518,7 @@ int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float*
     p.src = src; p.wpk = upanel; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
     p.src_bytes = (unsigned)((long)N * H * W * Cs * 4);
-    const int rows = N * (H / 8) * (W / 16);
+    const int rows = dbn_winograd_rows(N, H, W);
     p.stats = gamma ? ws : nullptr; p.stat_rows = rows; p.stat_row0 = 0;
     const int rc = dbn_launch_winograd_f32(p, (hipStream_t)stream);
     if (rc || !gamma) return rc;

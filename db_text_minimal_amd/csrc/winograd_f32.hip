@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
     const int ntn = p.Cd >> 6;
     const int mt = tile / ntn, nt = tile - mt * ntn, n0 = nt * 64;
-    const int tw = p.Wdf >> 4, tpi = (p.Hdf >> 3) * tw;
+    const int tw = (p.Wdf + 15) >> 4, tpi = ((p.Hdf + 7) >> 3) * tw;  // (ragged right / bottom patches: pixels past the map are masked)
     const int pn = mt / tpi, t_ = mt - pn * tpi, ty_ = t_ / tw;
     const int ph0 = ty_ * 8, pw0 = (t_ - ty_ * tw) * 16;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
@@ -178,7 +178,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned pitch = (unsigned)p.Cd * 4u;
     // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
     const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
-    auto row_off = [&](int r) { return base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch; };
+    // pixels past the map's right / bottom edge (maps whose size is not a multiple of the 8 x 16 patch): out-of-range offsets — loads
+    // read 0, stores are dropped — and bit r of `vmask` keeps them out of the statistics
+    unsigned vmask = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        vmask |= (unsigned)((ph0 + 2 * (r >> 2) + dy < p.Hdf) && (pw0 + 2 * ((r & 3) + 4 * lh) + dx < p.Wdf)) << r;
+    auto row_off = [&](int r) { return ((vmask >> r) & 1u) ? base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch : OOB_OFFSET; };
     auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); };
     const bool sums = p.bnb_part != nullptr, zm = p.bnb_zmask != nullptr, two = p.bnb_y2 != nullptr;
     float oldv[2][16], yv[2][16], zv[2][16], y2v[2][16];
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float m_ = zm ? zv[b][r] : dbn_affine(yv[b][r], msc, msh);
-                const float gq = m_ > 0.f ? y[b][r] : 0.f;
+                const float gq = (m_ > 0.f && ((vmask >> r) & 1u)) ? y[b][r] : 0.f;
                 s1[b] += gq;
                 s2[b] += gq * ((yv[b][r] - mu) * rsd);
                 if (two) s4[b] += gq * ((y2v[b][r] - mu2) * rs2);
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float d = y[b][r] - pv;
+                const float d = ((vmask >> r) & 1u) ? y[b][r] - pv : 0.f;
                 s1 += d;
                 s2 += d * d;
             }
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
             p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
         }
-        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = 128.f;
+        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)(min(8, p.Hdf - ph0) * min(16, p.Wdf - pw0));
     }
     // ---- stores
 #pragma unroll
@@ -420,7 +426,7 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, 
 }  // namespace
 
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
-    const int grid = p.N * (p.Hdf >> 3) * (p.Wdf >> 4) * (p.Cd >> 6);
+    const int grid = p.N * ((p.Hdf + 7) >> 3) * ((p.Wdf + 15) >> 4) * (p.Cd >> 6);
     if (grid <= 0) return DBN_OK;
     hipLaunchKernelGGL(winograd_f32_kernel, dim3(grid), dim3(256), 0, st, p);
     return dbn_status();

@@ -501,12 +501,12 @@ class Engine:
         return (self.winograd and self.ns == 0 and self.at == 0 and x.dtype == torch.float32 and conv.k == 3 and conv.stride == 1 and
                 conv.padding == 1 and bool(self.L.dbn_winograd_eligible(N, H, W, C, conv.cout)))
 
-    def _winograd_panel(self, name, w, cs, dgrad=0):
+    def _winograd_panel(self, name, w, cs, dgrad=0, version=None):
         """G g G^T of every filter (dgrad: of the rotated / transposed filters of the data gradient), re-made when the parameter
-        changed (one small launch per layer and step)."""
+        changed (one small launch per layer and step).  version: as in pack() — stamp of a derived tensor rewritten through raw pointers."""
         key = (name, 'winograd', cs, dgrad)
         ent = self.packs.get(key)
-        stamp = (w._version, self.param_epoch, w.data_ptr())
+        stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
         if ent is not None and ent[1] == stamp:
             return ent[0]
         O, I = (w.shape[1], w.shape[0]) if dgrad else (w.shape[0], w.shape[1])  # channels out of / into THIS conv
@@ -643,13 +643,15 @@ class Engine:
         blk = 'false' if (geom is not None and mode == 0 and geom[3] % 16 != 0) else 'true'
         self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, 0.0, tag)
 
-    def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer):
+    def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer, panel=None):
         """The data gradient of a 3x3 / stride-1 / pad-1 conv through the Winograd kernel (the rotated / transposed filters), with the
-        BatchNorm-backward sums of its consumer in the epilogue exactly as _igemm arranges them for the implicit-GEMM kernels."""
+        BatchNorm-backward sums of its consumer in the epilogue exactly as _igemm arranges them for the implicit-GEMM kernels.
+        panel: a ready Winograd panel mapping dy's channels to dx's (the FPN output conv's level-0 gradient: a forward-form conv
+        with the combined weights)."""
         import ctypes
         N, H, W, O = dy.shape
         Cd = dx.shape[3]
-        up = self._winograd_panel(name, conv.weight, O, dgrad=1)
+        up = panel if panel is not None else self._winograd_panel(name, conv.weight, O, dgrad=1)
         L = self.L
         rows = L.dbn_winograd_rows(N, H, W)
         a = dict(y=None, zmask=None, msc=None, msh=None, mean=None, rstd=None, part=None, y2=None, mean2=None, rstd2=None, part2=None)
@@ -1369,11 +1371,17 @@ class Engine:
             # coarser levels are completed by the nearest-upsample adjoints later
             bn_ = 'segmentation_body.%s.bn' % nm
             consumer = (bn_, self.bufs[nm + '/y'], None) if (g == 0 and self._bnb_eligible(args)) else None
-            if self.prof:
-                self._prof_igemm(N * Hg * Wg, Cg, flops, 'dgrad %s level %d' % (name, g), 0, epi=int(consumer is not None))
-            self._igemm('igemm fpn dgrad', *args, consumer=consumer)
-            if self.prof:
-                self.prof.end()
+            if (g == 0 and self.winograd and self.ns == 0 and self.at == 0 and dy.dtype == torch.float32
+                    and bool(self.L.dbn_winograd_eligible(N, H, W, Co, Cg))):
+                # level 0 is a plain 3x3 / stride-1 / pad-1 conv of dy with the (combined == original) weights [Cg][Co][3][3]
+                up = self._winograd_panel('%s#g0' % name, wds[0], Co, dgrad=0, version=wver)
+                self._winograd_dgrad('%s level 0' % name, dy, None, d, False, consumer, panel=up)
+            else:
+                if self.prof:
+                    self._prof_igemm(N * Hg * Wg, Cg, flops, 'dgrad %s level %d' % (name, g), 0, epi=int(consumer is not None))
+                self._igemm('igemm fpn dgrad', *args, consumer=consumer)
+                if self.prof:
+                    self.prof.end()
             dP[nm] = d
             t = self.fbuf('%s#t%d' % (name, g), Cg, Co, k, k)
             self._presplit(z, dy)

@@ -234,7 +234,8 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
 
 /* ---- 3x3 / stride 1 / pad 1 forward convolution through the Winograd transform F(2x2, 3x3), fp32 arithmetic (2.25x fewer matrix
  * FLOPs than the direct form; BasicBlock convs resnet.py:70-91, FPN smooth convs segmentation_body.py:55-61, the head's 256 -> 64
- * convs segmentation_head.py:24-25,64-68).  fp32 NHWC tensors with H % 8 == 0, W % 16 == 0, Cs % 16 == 0 channels in the source
+ * convs segmentation_head.py:24-25,64-68).  fp32 NHWC tensors of any H x W (worked in 8 x 16 pixel patches; ragged edges are masked;
+ * dbn_winograd_eligible says yes when >= 3/4 of the patch area is real), Cs % 16 == 0 channels in the source
  * tensor (I <= Cs of them real), Cd % 64 == 0 (dbn_winograd_eligible).  upanel: the filters transformed once per parameter update
  * (dbn_winograd_pack; dbn_winograd_panel_floats(O, Cs) floats).  gamma non-NULL: the train-mode BatchNorm that follows is folded
  * in exactly as in dbn_conv_bn_f32 (ws: dbn_winograd_ws_floats floats).  Same result as the direct convolution up to fp32 rounding
