@@ -109,32 +109,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
 
+    DBN_TRACE_MARK(0);
+#if DBN_TRACE
+    unsigned long long tr_bar = 0, tr_t = 0;
+#endif
     load_patch(0);
     issue_w(std::integral_constant<int, 0>{});
     store_patch(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    DBN_TRACE_MARK(1);
     for (int cb = 0; cb < ncb; ++cb) {
         const f32x4* const P = smem + (cb & 1) * P_PATCH;
         load_patch(cb + 1);  // (past the last block: out-of-range offsets, zeros, never stored)
+        // Per point (i, j): V = (d[a1][b1] +- d[a1][b2]) + sa * (d[a2][b1] +- d[a2][b2]) — four LDS reads, twelve vector instructions per
+        // chunk.  A wave issues in order, so its own vector work does not overlap its MFMAs: the LDS reads of point j + 1 are issued
+        // BEFORE the sixteen MFMAs of point j (their latency passes under them), the arithmetic follows after.  (Measured and not kept:
+        // forming all four points' V at the start of a block from the shared row combination — 16 reads + 44 vector instructions per
+        // block instead of 32 + 96, and 3-8 % SLOWER: one long vector phase per block overlaps the other resident wave's MFMAs worse
+        // than four short ones.)
+        f32x4 xr[2][2][4];  // [set][s2][x11, x12, x21, x22]
+        auto vreads = [&](auto J, auto SET) {
+            constexpr int j = decltype(J)::value, st_ = decltype(SET)::value;
+            // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+            constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                xr[st_][s2][0] = P[2 * s2 * W_PPX + row1 + b1];
+                xr[st_][s2][1] = P[2 * s2 * W_PPX + row1 + b2];
+                xr[st_][s2][2] = P[2 * s2 * W_PPX + row2 + b1];
+                xr[st_][s2][3] = P[2 * s2 * W_PPX + row2 + b2];
+            }
+        };
         auto point = [&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int cur = j & 1;  // four points per block: the sets alternate cleanly across blocks
             issue_w(std::integral_constant<int, cur ^ 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
-            constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
             constexpr bool plus = j == 1;
             f32x4 v[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x4 x11 = P[2 * s2 * W_PPX + row1 + b1], x12 = P[2 * s2 * W_PPX + row1 + b2];
-                const f32x4 x21 = P[2 * s2 * W_PPX + row2 + b1], x22 = P[2 * s2 * W_PPX + row2 + b2];
-                const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
+                const f32x4 t1 = plus ? xr[cur][s2][0] + xr[cur][s2][1] : xr[cur][s2][0] - xr[cur][s2][1];
+                const f32x4 t2 = plus ? xr[cur][s2][2] + xr[cur][s2][3] : xr[cur][s2][2] - xr[cur][s2][3];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
             }
+            if constexpr (j < 3) vreads(std::integral_constant<int, (j + 1) & 3>{}, std::integral_constant<int, cur ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -143,18 +165,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int b = 0; b < 2; ++b)
                         acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[cur][s2][b][e], acc[j][b], 0, 0, 0);
         };
+        vreads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         point(std::integral_constant<int, 0>{});
         point(std::integral_constant<int, 1>{});
         point(std::integral_constant<int, 2>{});
         point(std::integral_constant<int, 3>{});
         if (cb + 1 < ncb) {
             // the other buffer was last read in block cb - 1, and every wave has passed the barrier that ended it
+#if DBN_TRACE
+            tr_t = __builtin_amdgcn_s_memrealtime();
+#endif
             store_patch((cb + 1) & 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#if DBN_TRACE
+            tr_bar += __builtin_amdgcn_s_memrealtime() - tr_t;
+#endif
         }
     }
+    DBN_TRACE_MARK(2);
+#if DBN_TRACE
+    if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 8 + 5] = tr_bar;  // ticks spent from "MFMAs issued" to "past the barrier"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with the patches: the region becomes the exchange buffer
 
@@ -389,6 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int b = 0; b < 2; ++b) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[b][r]), rsrcD, (int)off + b * 128, 0, 0);
     }
+    DBN_TRACE_MARK(3);
 }
 
 // U = G g G^T per (output, input) channel pair, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; panel [I/16][16 points][4 chunks][O][4]
@@ -428,6 +462,7 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, 
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
     const int grid = p.N * ((p.Hdf + 7) >> 3) * ((p.Wdf + 15) >> 4) * (p.Cd >> 6);
     if (grid <= 0) return DBN_OK;
+    p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;
     hipLaunchKernelGGL(winograd_f32_kernel, dim3(grid), dim3(256), 0, st, p);
     return dbn_status();
 }
