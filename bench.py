@@ -38,6 +38,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
+WINOGRAD = 'winograd_f32_kernel'  # its bracketed FLOPs are the EXECUTED ones (engine._winograd_conv)
 TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem dgrad (dense convolution count)
 # what the matrix pipe computes per conv math mode: dtype of the JSON line, wording of the workload, MFMA peak that bounds it
 # (bf16x3 evaluates six bf16 products per fp32 product: its roofline is the bf16 peak / 6)
@@ -383,6 +384,12 @@ def main():
                 'note': ('measured in the timed region; the backward-pass launches of this kernel share the CUs with the concurrent '
                          'weight-gradient stream, so their durations (here and in the rocprofv3 trace of this command) include that '
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
+    if dname == WINOGRAD:
+        # F(2x2,3x3): the matrix pipe executes 16 products per 2 x 2 output tile and channel pair where the direct convolution has 36.
+        # `achieved` / `frac` are on the EXECUTED FLOPs (matrix-pipe utilisation, <= 1 by construction); the figure on the direct
+        # convolution's algorithmic 2*M*N*K count is 9/4 of it and is what the step-level TFLOP/s use.
+        roofline.update(flops_counted='executed by the MFMA pipe (Winograd F(2x2,3x3): 4/9 of the direct convolution\'s 2*M*N*K)',
+                        achieved_algorithmic=round(achieved * 2.25, 2), frac_algorithmic=round(achieved * 2.25 / peak_mfma, 4))
 
     # HBM traffic of that kernel: the PMC counters cannot be collected inside this run (rocprofv3 --pmc is its own pass, separate
     # for FETCH_SIZE and WRITE_SIZE: tools/profile_round.sh), so the figure comes from the newest committed pass — and ONLY while
@@ -409,6 +416,7 @@ def main():
         a = serial['flops'] / (serial['ms'] * 1e-3) / 1e12
         roofline_serial = {'kernel': dname, 'achieved': round(a, 2), 'peak': round(peak_mfma, 1), 'unit': 'TFLOP/s',
                            'frac': round(a / peak_mfma, 4), 'launches': serial['launches'],
+                           **({'achieved_algorithmic': round(a * 2.25, 2), 'frac_algorithmic': round(a * 2.25 / peak_mfma, 4)} if dname == WINOGRAD else {}),
                            'avg_launch_ms': round(serial['ms'] / serial['launches'], 4),
                            'how': 'median of %d extra steps outside the timed region, every launch bracketed by HIP events, single stream' % len(serial_runs)}
     else:
@@ -421,6 +429,8 @@ def main():
                 a = v['flops'] / (v['ms'] * 1e-3) / 1e12
                 ent.update(bound='mfma', achieved=round(a, 2), peak=round(peak_mfma, 1), unit='TFLOP/s',
                            frac=round(a / peak_mfma, 4))
+                if name == WINOGRAD:
+                    ent.update(frac_algorithmic=round(a * 2.25 / peak_mfma, 4))
             elif v['bytes'] > 0:
                 a = v['bytes'] / (v['ms'] * 1e-3) / 1e9
                 ent.update(bound='hbm', achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
