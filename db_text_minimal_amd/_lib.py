@@ -105,6 +105,7 @@ SIGNATURES.update({
     'dbn_winograd_panel_floats': 'ii',
     'dbn_winograd_pack': 'piiiipp',
     'dbn_winograd_rows': 'iii',
+    'dbn_winograd_pack_batched': 'pip',
     'dbn_winograd_dgrad_bnsums_f32': 'ppp' + 'iiiiii' + 'pppp' + 'ppp' + 'pppp' + 'p' + 'p',
     'dbn_winograd_ws_floats': 'iiii',
     'dbn_winograd_conv_bn_f32': 'pppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',

@@ -507,6 +507,11 @@ int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, int dgrad, floa
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && I <= Cs && Cs % 16 == 0 && O % 64 == 0 && (dgrad == 0 || dgrad == 1));
     return dbn_launch_winograd_pack(w_oihw, O, I, Cs, dgrad, out, (hipStream_t)stream);
 }
+// n dbn_winograd_pack calls in one launch.  jobs: DEVICE array of n records { const float* w; float* out; int O, I, Cs, dgrad; } (32 bytes)
+int dbn_winograd_pack_batched(const void* jobs, int n, void* stream) {
+    DBN_REQUIRE(jobs && n > 0);
+    return dbn_launch_winograd_pack_many(jobs, n, (hipStream_t)stream);
+}
 int dbn_winograd_rows(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16); }
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * dbn_winograd_rows(N, H, W); }
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,

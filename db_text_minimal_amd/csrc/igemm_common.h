@@ -255,7 +255,8 @@ static inline int chunk_images(int N, long px_rows, long src_bytes_per_image, lo
 // launchers of the kernel translation units.  cfg: 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64; mode: kernel MODE 0..3
 int dbn_launch_convt_f32(IgemmParams& p, hipStream_t st);  // convt_f32.hip
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st);                                       // winograd_f32.hip
-int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, int dgrad, float* out, hipStream_t st);  // winograd_f32.hip
+int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, int dgrad, float* out, hipStream_t st);
+int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st);  // winograd_f32.hip
 int dbn_convt_f32_rows(int M);
 int dbn_launch_igemm_f32(IgemmParams& p, int cfg, int mode, hipStream_t st);                    // conv_f32.hip: exact fp32 (ns 0, at 0)
 int dbn_launch_igemm_x(IgemmParams& p, int cfg, int mode, int ns, int at, hipStream_t st);      // conv_x3.hip: fp32 tensors, bf16 math

@@ -457,7 +457,47 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int O, int I, 
     }
 }
 
+// every panel of a model in one launch: blockIdx.y = job
+struct WinoPackJob {
+    const float* w;
+    float* out;
+    int O, I, Cs, dgrad;
+};
+__global__ void winograd_pack_many_kernel(const WinoPackJob* __restrict__ jobs) {
+    const WinoPackJob j = jobs[blockIdx.y];
+    const long total = (long)j.Cs * j.O;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % j.O), ci = (int)(idx / j.O);
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                g[r][s] = ci >= j.I ? 0.f : j.dgrad ? j.w[(((long)ci * j.O + o) * 3 + (2 - r)) * 3 + (2 - s)] : j.w[(((long)o * j.I + ci) * 3 + r) * 3 + s];
+        float t[4][3];  // G g
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = g[0][s];
+            t[1][s] = 0.5f * ((g[0][s] + g[1][s]) + g[2][s]);
+            t[2][s] = 0.5f * ((g[0][s] - g[1][s]) + g[2][s]);
+            t[3][s] = g[2][s];
+        }
+        const int cb = ci >> 4, c4 = (ci >> 2) & 3, e = ci & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float u[4] = {t[i][0], 0.5f * ((t[i][0] + t[i][1]) + t[i][2]), 0.5f * ((t[i][0] - t[i][1]) + t[i][2]), t[i][2]};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) j.out[((((long)cb * 16 + 4 * i + jj) * 4 + c4) * j.O + o) * 4 + e] = u[jj];
+        }
+    }
+}
+
 }  // namespace
+
+int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st) {
+    hipLaunchKernelGGL(winograd_pack_many_kernel, dim3(16, n), dim3(256), 0, st, reinterpret_cast<const WinoPackJob*>(jobs));
+    return dbn_status();
+}
 
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
     const int grid = p.N * ((p.Hdf + 7) >> 3) * ((p.Wdf + 15) >> 4) * (p.Cd >> 6);

@@ -145,6 +145,8 @@ class Engine:
         self._bias_done = set()
         self._bnb_sums = {}     # bn name -> (partials [2][C][rows], rows) produced by the data gradient that wrote its dout
         self._reduce_pending = []    # deferred slab reductions of this backward pass: (key, job record)
+        self._wino_src = {}          # Winograd panel key -> (parameter, panel, O, I, cs, dgrad)
+        self._wino_jobs = None
         self._reduce_job_cache = {}  # (layer, phase-2 arguments) -> dbn_wgrad_reduce_job
         self._reduce_tables = {}     # tuple of keys -> device job table of one grouped launch
         self._by_ptr = {}       # data_ptr -> activation buffer (to find the pre-split planes of an operand)
@@ -173,6 +175,7 @@ class Engine:
         self.side_priority = None  # HIP stream priority of the side stream (None: default)
         self._side = None
         self._side_used = False
+        self._slab_free = [None, None]  # per slab scratch: event of the reduction that last read it
 
     # ------------------------------------------------------------------ memory
     @property
@@ -307,7 +310,15 @@ class Engine:
         finally:
             self._in_side = False
 
+    def _side_waits_for_reductions(self):
+        """Before a gradient bucket is announced from the side stream its reductions (third stream) must have been ordered in."""
+        if self._side2_used and self._in_side:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side2)
+
     def join_side(self):
+        if self._side2_used:  # the reduction stream (see reduce_stream) joins first
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side2)
+            self._side2_used = False
         if self._side_used:
             torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
             self._side_used = False
@@ -490,6 +501,33 @@ class Engine:
             check(self.L.dbn_pack_weights_batched(table.data_ptr(), n, ns, self.stream), 'pack_weights_batched')
         for key, _, out, stamp, _ in stale:
             self.packs[key] = (out, stamp)
+        self._repack_winograd(beside)
+
+    def _repack_winograd(self, beside):
+        """The Winograd panels (G g G^T of every 3x3 / stride-1 filter, forward and data-gradient form) of all layers in ONE launch
+        after the optimizer step — 31 launches of ~10 us sprinkled over the step otherwise (0.34 ms in the round-4 trace)."""
+        items = [(k, v) for k, v in self._wino_src.items() if k in self.packs]
+        if len(items) < 4:
+            return
+        sig = tuple((k, v[0].data_ptr(), v[1].data_ptr()) for k, v in items)
+        if self._wino_jobs is None or self._wino_jobs[0] != sig:
+            import ctypes
+
+            class Job(ctypes.Structure):
+                _fields_ = [('w', ctypes.c_void_p), ('out', ctypes.c_void_p)] + [(f, ctypes.c_int) for f in ('O', 'I', 'Cs', 'dgrad')]
+            arr = (Job * len(items))()
+            for i, (_, (w, out, O, I, cs, dgrad)) in enumerate(items):
+                arr[i] = Job(w.data_ptr(), out.data_ptr(), O, I, cs, dgrad)
+            self._wino_jobs = (sig, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.flat.device), len(items))
+        _, table, n = self._wino_jobs
+        if beside:
+            with self.side_stream():
+                check(self.L.dbn_winograd_pack_batched(table.data_ptr(), n, self.stream), 'winograd_pack_batched')
+            self._repack_pending = True
+        else:
+            check(self.L.dbn_winograd_pack_batched(table.data_ptr(), n, self.stream), 'winograd_pack_batched')
+        for k, (w, out, *_r) in items:
+            self.packs[k] = (out, (w._version, self.param_epoch, w.data_ptr()))
 
     # ------------------------------------------------------------------ kernels
     # 3x3 / stride-1 / pad-1 FORWARD convolutions of the exact-fp32 path through Winograd F(2x2, 3x3) (csrc/winograd_f32.hip): fp32
@@ -504,6 +542,8 @@ class Engine:
     def _winograd_panel(self, name, w, cs, dgrad=0, version=None):
         """G g G^T of every filter (dgrad: of the rotated / transposed filters of the data gradient), re-made when the parameter
         changed (one small launch per layer and step).  version: as in pack() — stamp of a derived tensor rewritten through raw pointers."""
+        if self._repack_pending:  # (first use of a panel the side stream is still rebuilding)
+            self._join_repack()
         key = (name, 'winograd', cs, dgrad)
         ent = self.packs.get(key)
         stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
@@ -511,6 +551,8 @@ class Engine:
             return ent[0]
         O, I = (w.shape[1], w.shape[0]) if dgrad else (w.shape[0], w.shape[1])  # channels out of / into THIS conv
         out = ent[0] if ent is not None else device_empty(self.L.dbn_winograd_panel_floats(O, cs), w.device)
+        if version is None:  # a parameter: remembered for the one-launch refresh after the optimizer step (repack_params)
+            self._wino_src[key] = (w, out, O, I, cs, dgrad)
         check(self.L.dbn_winograd_pack(w.data_ptr(), O, I, cs, dgrad, out.data_ptr(), self.stream), 'winograd pack ' + name)
         self.packs[key] = (out, stamp)
         return out
@@ -732,8 +774,10 @@ class Engine:
         flush_wgrad_reduces() (conv_wgrad, convT_bwd); False: a kernel of this pass reads gview next (FPN level scatter, DCN)."""
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
+        # reductions on their own stream (see reduce_stream): only for gradients no kernel of this pass reads, on the side stream
+        async_reduce = defer and self.reduce_stream and self._in_side and self.prof is None and not self.defer_wgrad_reduce
         defer = defer and self.defer_wgrad_reduce and self.prof is None and Cb % 64 == 0
-        slab = self.scratch('_wgrad_slab/' + name if defer else '_wgrad_slab',
+        slab = self.scratch('_wgrad_slab/' + name if defer else ('_wgrad_slab@%d' % self._slab_k if async_reduce else '_wgrad_slab'),
                             self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
         at, smp, bigp = self.at, sm.data_ptr(), big.data_ptr()
         if self._use_planes and sm.dtype == torch.float32 and big.dtype == torch.float32:
@@ -764,8 +808,36 @@ class Engine:
                 check(self.L.dbn_wgrad_reduce_describe(*args[:-1], ctypes.byref(job)), 'wgrad reduce describe ' + name)
                 self._reduce_job_cache[key] = job
             self._reduce_pending.append((key, job))
+        elif async_reduce:
+            side = torch.cuda.current_stream(self.flat.device)
+            free = self._slab_free[self._slab_k]
+            if free is not None:  # this slab's previous reduction (two weight gradients ago) has read it
+                side.wait_event(free)
+            check(self.L.dbn_wgrad_phase_t(1, *args), 'wgrad ' + name)
+            filled = torch.cuda.Event()
+            filled.record(side)
+            if self._side2 is None or self._side2.device != self.flat.device:
+                self._side2 = torch.cuda.Stream(device=self.flat.device)
+            self._side2.wait_event(filled)
+            with torch.cuda.stream(self._side2):
+                check(self.L.dbn_wgrad_phase_t(2, *args[:-1], self._side2.cuda_stream), 'wgrad reduce ' + name)
+                done = torch.cuda.Event()
+                done.record(self._side2)
+            self._slab_free[self._slab_k] = done
+            self._slab_k ^= 1
+            self._side2_used = True
         else:
             check(self.L.dbn_wgrad_t(*args), 'wgrad ' + name)
+
+    # The slab reduction of a weight gradient (34 launches of 5-260 us per step, latency-bound: 0.46 ms alone) used to sit BETWEEN the
+    # matrix kernels of the side stream; since the Winograd convs shortened the main stream, the side stream is what the step's end
+    # waits for (round 4 trace: wgrad_reduce64 1.4 ms in flight, 0.9 ms of it with nothing else running).  The reductions of gradients
+    # that only the optimizer reads now run on a THIRD stream behind their matrix kernel, over two alternating slab scratches (both
+    # stay in the Infinity Cache — per-layer slabs did not, see defer_wgrad_reduce); the next matrix kernel starts at once.
+    reduce_stream = os.environ.get('DBN_REDUCE_STREAM', '1') == '1'
+    _side2 = None
+    _side2_used = False
+    _slab_k = 0
 
     def flush_wgrad_reduces(self):
         """The deferred slab reductions as ONE launch on the side stream (behind the matrix kernels that filled the slabs)."""
@@ -1142,6 +1214,7 @@ class Engine:
         B = self.bufs
         self._bias_done = set()
         self._bnb_sums = {}
+        self._slab_free = [None, None]  # (the previous pass's reductions were joined: no event of it is waited for again)
         out = self.saved_out  # head output before the (optional) final resample
         dpreds = dpreds.contiguous()
         assert dpreds.shape == (N, 3, H, W)
@@ -1242,6 +1315,7 @@ class Engine:
         self.flush_wgrad_reduces()  # FPN + head (one grouped launch per gradient stage: train.GRAD_STAGES)
         if self.grad_ready_hook is not None:  # every FPN / head gradient kernel has been enqueued
             with self.side_stream():  # announced from the side stream (it has waited for the main one): main is not stalled
+                self._side_waits_for_reductions()
                 self.grad_ready_hook('segmentation')
         # backbone, deepest stage first; dC[...] already holds the FPN contribution
         bb = m.backbone
@@ -1264,6 +1338,7 @@ class Engine:
                 self.flush_wgrad_reduces()
             if self.grad_ready_hook is not None and li >= 3:
                 with self.side_stream():
+                    self._side_waits_for_reductions()
                     self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)

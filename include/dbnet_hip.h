@@ -245,6 +245,9 @@ long dbn_winograd_panel_floats(int O, int Cs);
 /* dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT
  * of the conv with weights w [I][O][3][3] (filters rotated by 180 degrees, channel roles swapped): maps dy (Cs >= I channels) to dx (O). */
 int dbn_winograd_pack(const float* w_oihw, int O, int I, int Cs, int dgrad, float* out, void* stream);
+/* n dbn_winograd_pack calls in one launch (after an optimizer step every panel is stale).  jobs: DEVICE array of n records
+ *   struct { const float* w; float* out; int O, I, Cs, dgrad; }   (32 bytes) */
+int dbn_winograd_pack_batched(const void* jobs, int n, void* stream);
 int dbn_winograd_rows(int N, int H, int W);
 /* The data gradient through the same kernel: dx [N,H,W,Cd] = [dx +] conv(dy [N,H,W,Cs]) with the dgrad = 1 panel.  y non-NULL: the
  * epilogue also produces the two per-channel sums of the BatchNorm backward that consumes dx — arguments and semantics of
