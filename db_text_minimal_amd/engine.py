@@ -775,7 +775,8 @@ class Engine:
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
         # reductions on their own stream (see reduce_stream): only for gradients no kernel of this pass reads, on the side stream
-        async_reduce = defer and self.reduce_stream and self._in_side and self.prof is None and not self.defer_wgrad_reduce
+        async_reduce = (defer and self.reduce_stream and self._in_side and self.prof is None and not self.defer_wgrad_reduce
+                        and not torch.cuda.is_current_stream_capturing())
         defer = defer and self.defer_wgrad_reduce and self.prof is None and Cb % 64 == 0
         slab = self.scratch('_wgrad_slab/' + name if defer else ('_wgrad_slab@%d' % self._slab_k if async_reduce else '_wgrad_slab'),
                             self.L.dbn_wgrad_slab_floats_hw(N, Ho, Wo, O, H, W, Cb, k, k, 4 if self.at == 0 else 2))
@@ -829,12 +830,15 @@ class Engine:
         else:
             check(self.L.dbn_wgrad_t(*args), 'wgrad ' + name)
 
-    # The slab reduction of a weight gradient (34 launches of 5-260 us per step, latency-bound: 0.46 ms alone) used to sit BETWEEN the
-    # matrix kernels of the side stream; since the Winograd convs shortened the main stream, the side stream is what the step's end
-    # waits for (round 4 trace: wgrad_reduce64 1.4 ms in flight, 0.9 ms of it with nothing else running).  The reductions of gradients
-    # that only the optimizer reads now run on a THIRD stream behind their matrix kernel, over two alternating slab scratches (both
-    # stay in the Infinity Cache — per-layer slabs did not, see defer_wgrad_reduce); the next matrix kernel starts at once.
-    reduce_stream = os.environ.get('DBN_REDUCE_STREAM', '1') == '1'
+    # The slab reduction of a weight gradient (34 launches of 5-260 us per step, latency-bound: 0.46 ms alone) sits BETWEEN the matrix
+    # kernels of the side stream, and since the Winograd convs shortened the main stream the side stream is what the step's end waits
+    # for (round-4 trace: wgrad_reduce64 1.4 ms in flight, 0.9 ms of it with nothing else running).  reduce_stream = True runs the
+    # reductions of gradients that only the optimizer reads on a THIRD stream behind their matrix kernel, over two alternating slab
+    # scratches (both stay in the Infinity Cache).  Built, bit-identical, measured on one box and OFF: f32 614.7 -> 606.7 images/s,
+    # bf16 1600 -> 1390-1470 (three extra event / wait calls per weight gradient on the host, and the reductions now compete with the
+    # NEXT matrix kernel instead of running in its shadow at the end); not used under hipGraph capture (cross-stream events created
+    # inside a capture crashed capture_end on ROCm 7.2).
+    reduce_stream = os.environ.get('DBN_REDUCE_STREAM', '0') == '1'
     _side2 = None
     _side2_used = False
     _slab_k = 0
