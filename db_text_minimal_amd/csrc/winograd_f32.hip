@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int b = 0; b < 2; ++b) wvo[s2][b] = (unsigned)((2 * s2 + lh) * p.Cd + n0 + b * 32 + li) * 16u;
     const unsigned point_bytes = (unsigned)(4 * p.Cd) * 16u;  // one point of one channel block
     int w_next = 0;  // next (channel block, point) to fetch: g = cb * 4 + j; clamped at the end (the surplus fetch is never used)
-    const int w_last = ncb * 4 - 1;
-    f32x4 rw[2][2][2];
+    const int w_last = ncb * 4 - 1;  // (the two surplus fetches at the end re-read the last one and are never used)
+    f32x4 rw[4][2][2];  // one fragment set per point of a block, fetched TWO points ahead (one point = 16 MFMAs ~ 0.4-1.2 us: an L2 hit under load takes about as long)
     auto issue_w = [&](auto SET) {
         constexpr int st_ = decltype(SET)::value;
         const int g = min(w_next, w_last);
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     load_patch(0);
     issue_w(std::integral_constant<int, 0>{});
+    issue_w(std::integral_constant<int, 1>{});
     store_patch(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -124,48 +125,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const f32x4* const P = smem + (cb & 1) * P_PATCH;
         load_patch(cb + 1);  // (past the last block: out-of-range offsets, zeros, never stored)
         // Per point (i, j): V = (d[a1][b1] +- d[a1][b2]) + sa * (d[a2][b1] +- d[a2][b2]) — four LDS reads, twelve vector instructions per
-        // chunk.  A wave issues in order, so its own vector work does not overlap its MFMAs: the LDS reads of point j + 1 are issued
-        // BEFORE the sixteen MFMAs of point j (their latency passes under them), the arithmetic follows after.  (Measured and not kept:
-        // forming all four points' V at the start of a block from the shared row combination — 16 reads + 44 vector instructions per
-        // block instead of 32 + 96, and 3-8 % SLOWER: one long vector phase per block overlaps the other resident wave's MFMAs worse
-        // than four short ones.)
-        f32x4 xr[2][2][4];  // [set][s2][x11, x12, x21, x22]
-        auto vreads = [&](auto J, auto SET) {
-            constexpr int j = decltype(J)::value, st_ = decltype(SET)::value;
-            // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
-            constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                xr[st_][s2][0] = P[2 * s2 * W_PPX + row1 + b1];
-                xr[st_][s2][1] = P[2 * s2 * W_PPX + row1 + b2];
-                xr[st_][s2][2] = P[2 * s2 * W_PPX + row2 + b1];
-                xr[st_][s2][3] = P[2 * s2 * W_PPX + row2 + b2];
-            }
-        };
+        // chunk.  (Measured and not kept: forming all four points' V at the start of a block from the shared row combination — 16 reads
+        // + 44 vector instructions per block instead of 32 + 96 — 3-8 % SLOWER: one long vector phase per block overlaps the other
+        // resident wave's MFMAs worse than four short ones; issuing the next point's LDS reads ahead of the current point's MFMAs:
+        // neutral, and its 32 registers are better spent on the weight fragments' prefetch distance.)
         auto point = [&](auto J) {
             constexpr int j = decltype(J)::value;
-            constexpr int cur = j & 1;  // four points per block: the sets alternate cleanly across blocks
-            issue_w(std::integral_constant<int, cur ^ 1>{});
+            issue_w(std::integral_constant<int, (j + 2) & 3>{});  // the weight fragments of the point after the next (set = point index)
+            __builtin_amdgcn_sched_barrier(0);
+            // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
+            constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
             constexpr bool plus = j == 1;
             f32x4 v[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x4 t1 = plus ? xr[cur][s2][0] + xr[cur][s2][1] : xr[cur][s2][0] - xr[cur][s2][1];
-                const f32x4 t2 = plus ? xr[cur][s2][2] + xr[cur][s2][3] : xr[cur][s2][2] - xr[cur][s2][3];
+                const f32x4 x11 = P[2 * s2 * W_PPX + row1 + b1], x12 = P[2 * s2 * W_PPX + row1 + b2];
+                const f32x4 x21 = P[2 * s2 * W_PPX + row2 + b1], x22 = P[2 * s2 * W_PPX + row2 + b2];
+                const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
             }
-            if constexpr (j < 3) vreads(std::integral_constant<int, (j + 1) & 3>{}, std::integral_constant<int, cur ^ 1>{});
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[cur][s2][b][e], acc[j][b], 0, 0, 0);
+                        acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[j][s2][b][e], acc[j][b], 0, 0, 0);
         };
-        vreads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         point(std::integral_constant<int, 0>{});
         point(std::integral_constant<int, 1>{});
         point(std::integral_constant<int, 2>{});
