@@ -497,7 +497,10 @@ int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, 
 int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd) {
     if (!(N > 0 && H > 0 && W > 0 && Cs > 0 && Cs % 16 == 0 && Cd > 0 && Cd % 64 == 0)) return 0;
     const long Hp = (H + 7) / 8 * 8, Wp = (W + 15) / 16 * 16;
-    return 4L * H * W >= 3L * Hp * Wp && (long)N * H * W * std::max(Cs, Cd) * 4 < dbn_g_byte_limit && (long)N * Hp * Wp < dbn_g_pixel_limit;
+    // small maps (the band of 32 consecutive tiles fits the LDS patch) run in the consecutive-tile form: no ragged patches at all
+    const long tiles = (long)((H + 1) / 2) * ((W + 1) / 2);
+    const bool pays = dbn_winograd_linear(H, W) ? 5 * tiles >= 3 * ((tiles + 31) / 32 * 32) : 4L * H * W >= 3L * Hp * Wp;  // (>= 60 % / 75 % real work)
+    return pays && (long)N * H * W * std::max(Cs, Cd) * 4 < dbn_g_byte_limit && (long)N * Hp * Wp < dbn_g_pixel_limit;
 }
 long dbn_winograd_panel_floats(int O, int Cs) { return (long)Cs * 16 * O; }
 // dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT of
@@ -512,7 +515,6 @@ int dbn_winograd_pack_batched(const void* jobs, int n, void* stream) {
     DBN_REQUIRE(jobs && n > 0);
     return dbn_launch_winograd_pack_many(jobs, n, (hipStream_t)stream);
 }
-int dbn_winograd_rows(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16); }
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * dbn_winograd_rows(N, H, W); }
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,

@@ -256,7 +256,9 @@ static inline int chunk_images(int N, long px_rows, long src_bytes_per_image, lo
 int dbn_launch_convt_f32(IgemmParams& p, hipStream_t st);  // convt_f32.hip
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st);                                       // winograd_f32.hip
 int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, int dgrad, float* out, hipStream_t st);
-int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st);  // winograd_f32.hip
+int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st);
+int dbn_winograd_linear(int H, int W);  // winograd_f32.hip: the map runs in the consecutive-tile (LIN) form
+extern "C" int dbn_winograd_rows(int N, int H, int W);  // winograd_f32.hip
 int dbn_convt_f32_rows(int M);
 int dbn_launch_igemm_f32(IgemmParams& p, int cfg, int mode, hipStream_t st);                    // conv_f32.hip: exact fp32 (ns 0, at 0)
 int dbn_launch_igemm_x(IgemmParams& p, int cfg, int mode, int ns, int at, hipStream_t st);      // conv_x3.hip: fp32 tensors, bf16 math

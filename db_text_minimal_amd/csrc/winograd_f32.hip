@@ -16,41 +16,75 @@
 // Arithmetic is fp32 throughout (no reduced precision); the result differs from the direct convolution by fp32 rounding of a
 // different summation (max relative error ~1e-6 of the output scale), not bit for bit.
 #include "igemm_common.h"
+#include <algorithm>
 
 namespace {
 
 constexpr int W_PPX = 180, W_PROW = 18;  // 10 x 18 patch pixels
 
+// LIN = false: a workgroup's 32 tiles are the 4 x 8 tiles of an 8 x 16-pixel patch (large maps).  LIN = true (maps up to ~50 pixels wide:
+// layer3 / layer4 of the 640^2 benchmark, 40 x 40 and 20 x 20): the 32 tiles are CONSECUTIVE tiles of one image in row-major order over
+// its ceil(H/2) x ceil(W/2) tile grid — no ragged patches (a 20 x 20 map is 52 % of its 8 x 16 patches, but 100 / 128 of its tile
+// groups) — and the LDS patch is the band of pixel rows those tiles touch, full width (+ the one-pixel halo).
+constexpr int W_LIN_PPX = 448;  // most patch pixels of the LIN form (dbn_winograd_eligible checks the map against it)
+template <bool LIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void winograd_f32_kernel(const IgemmParams p) {
-    // LDS: loop = two patch buffers [4 chunks][180 px] f32x4 (23 KB); epilogue = the cross-wave exchange [4 waves][2 dx][2 b][16][64]
-    // floats (64 KB) + the statistics scratch
-    constexpr int P_PATCH = 4 * W_PPX;
+    // LDS: loop = two patch buffers [4 chunks][patch pixels] f32x4 (23 KB; LIN: up to 57 KB); epilogue = the cross-wave exchange
+    // [4 waves][2 dx][2 b][16][64] floats (64 KB) + the statistics scratch
+    constexpr int PPX_MAX = LIN ? W_LIN_PPX : W_PPX;
+    constexpr int P_PATCH = 4 * PPX_MAX;
     constexpr int X_FLOATS = 4 * 2 * 2 * 16 * 64;
-    __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 2];  // + the statistics / sums scratch [<= 3][4][64] floats and a flag
+    static_assert(2 * P_PATCH <= X_FLOATS / 4, "the patch buffers live inside the exchange region");
+    __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 4];  // + the statistics / sums scratch [<= 3][4][64] floats, a flag, 8 counts
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int tile = dbn_xcd_remap(blockIdx.x, gridDim.x);
     const int ntn = p.Cd >> 6;
     const int mt = tile / ntn, nt = tile - mt * ntn, n0 = nt * 64;
-    const int tw = (p.Wdf + 15) >> 4, tpi = ((p.Hdf + 7) >> 3) * tw;  // (ragged right / bottom patches: pixels past the map are masked)
-    const int pn = mt / tpi, t_ = mt - pn * tpi, ty_ = t_ / tw;
-    const int ph0 = ty_ * 8, pw0 = (t_ - ty_ * tw) * 16;
+    // patch geometry: image pn; the patch's first pixel row / column in the image (hs0, ws0: the halo starts one pixel before the
+    // first output pixel), its row pitch `prow` and pixel count `ppx` (= the LDS stride between the four 16-byte chunks of a block)
+    int pn, ph0 = 0, pw0 = 0, hs0, ws0, prow, ppx, t0 = 0, TWl = 1, ntiles = 0;
+    if constexpr (LIN) {
+        TWl = (p.Wdf + 1) >> 1;
+        ntiles = ((p.Hdf + 1) >> 1) * TWl;
+        const int groups = (ntiles + 31) >> 5;
+        pn = mt / groups;
+        t0 = (mt - pn * groups) << 5;
+        const int tr0 = t0 / TWl, tr1 = min(t0 + 31, ntiles - 1) / TWl;  // first / last tile row of this group
+        hs0 = 2 * tr0 - 1;
+        ws0 = -1;
+        prow = 2 * TWl + 2;
+        ppx = (2 * (tr1 - tr0 + 1) + 2) * prow;
+    } else {
+        const int tw = (p.Wdf + 15) >> 4, tpi = ((p.Hdf + 7) >> 3) * tw;  // (ragged right / bottom patches: pixels past the map are masked)
+        pn = mt / tpi;
+        const int t_ = mt - pn * tpi, ty_ = t_ / tw;
+        ph0 = ty_ * 8;
+        pw0 = (t_ - ty_ * tw) * 16;
+        hs0 = ph0 - 1;
+        ws0 = pw0 - 1;
+        prow = W_PROW;
+        ppx = W_PPX;
+    }
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.src), 0, p.src_bytes, 0x00020000);
 
-    // ---- patch staging: 180 pixels x 4 chunks of 16 bytes per channel block, three pieces per thread
-    constexpr int PL = (W_PPX * 4 + 255) / 256;
+    // ---- patch staging: patch pixels x 4 chunks of 16 bytes per channel block, PL pieces per thread
+    constexpr int PL = (PPX_MAX * 4 + 255) / 256;
     unsigned poff[PL];
     int pslot[PL];
+    const float rprow = 1.0f / (float)prow;
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
         const int idx = tid + j * 256;
-        const bool on = idx < W_PPX * 4;
+        const bool on = idx < ppx * 4;
         const int chunk = idx & 3, pix = on ? idx >> 2 : 0;
-        const int py = pix / W_PROW, px = pix - py * W_PROW;
-        const int hs = ph0 - 1 + py, ws = pw0 - 1 + px;
+        int py, px;
+        if constexpr (LIN) divmod24(pix, prow, rprow, py, px);
+        else { py = pix / W_PROW; px = pix - py * W_PROW; }
+        const int hs = hs0 + py, ws = ws0 + px;
         const bool v = on && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
         poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * 4u + (unsigned)chunk * 16u : OOB_OFFSET;
-        pslot[j] = on ? chunk * W_PPX + pix : -1;
+        pslot[j] = on ? chunk * ppx + pix : -1;
     }
     f32x4 pr[PL];
     const int ncb = p.Cs >> 4;
@@ -70,9 +104,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     //      i = 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
     const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sa = wave == 1 ? 1.f : -1.f;
-    // MFMA row = tile (ty, tx) = (li >> 3, li & 7): its 4 x 4 input window starts at patch pixel (2 ty, 2 tx); chunk 2*s2 + lh
-    const int vbase = (2 * (li >> 3)) * W_PROW + 2 * (li & 7) + lh * W_PPX;
-    const int row1 = vbase + a1 * W_PROW, row2 = vbase + a2 * W_PROW;
+    // MFMA row li = tile (ty, tx) — patch form: (li >> 3, li & 7); LIN: tile t0 + li of the image's grid (past the last tile: tile 0 of
+    // the band, masked in the epilogue) — whose 4 x 4 input window starts at patch pixel (2 ty, 2 tx); chunk 2*s2 + lh
+    int lty = li >> 3, ltx = li & 7;
+    if constexpr (LIN) {
+        const int t = t0 + li < ntiles ? t0 + li : t0;
+        divmod24(t, TWl, 1.0f / (float)TWl, lty, ltx);
+        lty -= t0 / TWl;
+    }
+    const int vbase = 2 * lty * prow + 2 * ltx + lh * ppx;
+    const int row1 = vbase + a1 * prow, row2 = vbase + a2 * prow;
+    const int ppx2 = 2 * ppx;  // chunk 2*s2 + lh: s2 = 1 lies two chunk planes further
 
     // ---- weight fragments: panel [cb][16 points][4 chunks][Cd][4]; lane (li, lh): chunk 2*s2 + lh, column n0 + 32 b + li
     const __amdgpu_buffer_rsrc_t rsrcW =
@@ -139,8 +181,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f32x4 v[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x4 x11 = P[2 * s2 * W_PPX + row1 + b1], x12 = P[2 * s2 * W_PPX + row1 + b2];
-                const f32x4 x21 = P[2 * s2 * W_PPX + row2 + b1], x22 = P[2 * s2 * W_PPX + row2 + b2];
+                const f32x4 x11 = P[s2 * ppx2 + row1 + b1], x12 = P[s2 * ppx2 + row1 + b2];
+                const f32x4 x21 = P[s2 * ppx2 + row2 + b1], x22 = P[s2 * ppx2 + row2 + b2];
                 const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
@@ -197,14 +239,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, dst_bytes, 0x00020000);
     const unsigned pitch = (unsigned)p.Cd * 4u;
     // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
-    const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
-    // pixels past the map's right / bottom edge (maps whose size is not a multiple of the 8 x 16 patch): out-of-range offsets — loads
-    // read 0, stores are dropped — and bit r of `vmask` keeps them out of the statistics
+    // byte offset of row r's pixel (tile (r & 3) + 8 (r >> 2) + 4 lh of the workgroup's 32), or OOB_OFFSET past the map: loads read 0,
+    // stores are dropped, and bit r of `vmask` keeps the pixel out of the statistics
     unsigned vmask = 0;
+    unsigned roff[16];
+    if constexpr (LIN) {
+        const float rTW = 1.0f / (float)TWl;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        vmask |= (unsigned)((ph0 + 2 * (r >> 2) + dy < p.Hdf) && (pw0 + 2 * ((r & 3) + 4 * lh) + dx < p.Wdf)) << r;
-    auto row_off = [&](int r) { return ((vmask >> r) & 1u) ? base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch : OOB_OFFSET; };
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int ty, tx;
+            divmod24(min(t, ntiles - 1), TWl, rTW, ty, tx);
+            const int yy = 2 * ty + dy, xx = 2 * tx + dx;
+            const bool ok = t < ntiles && yy < p.Hdf && xx < p.Wdf;
+            vmask |= (unsigned)ok << r;
+            roff[r] = ok ? (unsigned)((pn * p.Hdf + yy) * p.Wdf + xx) * pitch + (unsigned)(n0 + li) * 4u : OOB_OFFSET;
+        }
+    } else {
+        // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
+        const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (ph0 + 2 * (r >> 2) + dy < p.Hdf) && (pw0 + 2 * ((r & 3) + 4 * lh) + dx < p.Wdf);
+            vmask |= (unsigned)ok << r;
+            roff[r] = ok ? base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch : OOB_OFFSET;
+        }
+    }
+    auto row_off = [&](int r) { return roff[r]; };
     auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0)); };
     const bool sums = p.bnb_part != nullptr, zm = p.bnb_zmask != nullptr, two = p.bnb_y2 != nullptr;
     float oldv[2][16], yv[2][16], zv[2][16], y2v[2][16];
@@ -400,7 +461,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
             p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
         }
-        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)(min(8, p.Hdf - ph0) * min(16, p.Wdf - pw0));
+        if (nt == 0) {  // the number of real pixels of this tile group: every wave holds one (dy, dx) of each tile — lanes 0 and 32 its two halves
+            int* const cntp = reinterpret_cast<int*>(r2 + 4 * 64);
+            __syncthreads();
+            if (li == 0) cntp[wave * 2 + lh] = __builtin_popcount(vmask);
+            __syncthreads();
+            if (tid == 0) {
+                int c_ = 0;
+                for (int k = 0; k < 8; ++k) c_ += cntp[k];
+                p.stats[3L * p.Cd * p.stat_rows + trow] = (float)c_;
+            }
+        }
     }
     // ---- stores
 #pragma unroll
@@ -486,11 +557,24 @@ int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st) {
     return dbn_status();
 }
 
+// LIN form (consecutive tiles, full-width band) for maps whose band fits the LDS patch: 32 tiles span at most (31 + TW) / TW + 1 tile rows
+int dbn_winograd_linear(int H, int W) {
+    const int TW = (W + 1) / 2, TH = (H + 1) / 2;
+    const int tile_rows = std::min(TH, (31 + TW - 1) / TW + 1);
+    return (2 * tile_rows + 2) * (2 * TW + 2) <= W_LIN_PPX;
+}
+extern "C" int dbn_winograd_rows(int N, int H, int W) {
+    if (dbn_winograd_linear(H, W)) return N * ((((H + 1) / 2) * ((W + 1) / 2) + 31) / 32);
+    return N * ((H + 7) / 8) * ((W + 15) / 16);
+}
+
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
-    const int grid = p.N * ((p.Hdf + 7) >> 3) * ((p.Wdf + 15) >> 4) * (p.Cd >> 6);
+    const bool lin = dbn_winograd_linear(p.Hdf, p.Wdf);
+    const int grid = dbn_winograd_rows(p.N, p.Hdf, p.Wdf) * (p.Cd >> 6);
     if (grid <= 0) return DBN_OK;
     p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;
-    hipLaunchKernelGGL(winograd_f32_kernel, dim3(grid), dim3(256), 0, st, p);
+    if (lin) hipLaunchKernelGGL(winograd_f32_kernel<true>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(winograd_f32_kernel<false>, dim3(grid), dim3(256), 0, st, p);
     return dbn_status();
 }
 

@@ -1571,14 +1571,15 @@ def test_batchnorm_backward_from_given_partial_sums(C, N, H, W, parts):
 
 
 @pytest.mark.parametrize('N,Ci,Cs,Co,H,W', [(2, 64, 64, 64, 16, 32), (1, 128, 128, 128, 8, 16), (2, 32, 32, 64, 24, 16), (1, 20, 32, 192, 8, 48),
-                                            (3, 256, 256, 64, 16, 16), (1, 64, 64, 64, 40, 40), (2, 32, 32, 64, 14, 30), (1, 32, 32, 64, 13, 30)])
+                                            (3, 256, 256, 64, 16, 16), (1, 64, 64, 64, 40, 40), (2, 32, 32, 64, 14, 30), (1, 32, 32, 64, 13, 30),
+                                            (2, 64, 64, 64, 20, 20), (1, 32, 32, 64, 25, 25), (2, 32, 32, 64, 8, 96), (1, 64, 64, 128, 50, 50)])
 @pytest.mark.parametrize('with_bn', [False, True])
 def test_winograd_conv3x3(N, Ci, Cs, Co, H, W, with_bn):
     """dbn_winograd_conv_bn_f32: 3x3 / stride 1 / pad 1 forward convolution through Winograd F(2x2, 3x3) in fp32 (the BasicBlock, FPN
     smooth and head convs of resnet.py:70-91, segmentation_body.py:55-61, segmentation_head.py:24-25) against F.conv2d in fp64, with
     the bias and — with_bn — the folded train-mode BatchNorm statistics (scale / shift / saved mean / rstd / running statistics)
-    against F.batch_norm.  Map sizes that are not multiples of the 8 x 16 patch (40 x 40: layer3; odd sizes) run with masked ragged
-    patches.  fp32 arithmetic with another summation order than the direct form: tolerance 2e-6 of the output scale
+    against F.batch_norm.  Small maps (40 x 40: layer3, 20 x 20: layer4, odd sizes) run in the consecutive-tile form, wide maps whose
+    size is not a multiple of the 8 x 16 patch with masked ragged patches.  fp32 arithmetic with another summation order than the direct form: tolerance 2e-6 of the output scale
     per element (the direct kernels' own fp32 rounding is ~3e-7 at K = 2304).  Cs > Ci: the source tensor carries padding channels."""
     x = rnd(N, Ci, H, W, seed=1)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=(2.0 / (Ci * 9))**0.5)
@@ -1626,7 +1627,8 @@ def test_winograd_conv3x3(N, Ci, Cs, Co, H, W, with_bn):
     report('winograd vs the direct kernel', y.cpu(), yd.cpu(), 3e-6 * scale, 3e-6)
 
 
-@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 128, 64, 8, 16), (2, 64, 256, 8, 32), (1, 64, 64, 40, 40), (2, 64, 64, 13, 30)])
+@pytest.mark.parametrize('N,Ci,Co,H,W', [(2, 64, 64, 16, 32), (1, 128, 64, 8, 16), (2, 64, 256, 8, 32), (1, 64, 64, 40, 40), (2, 64, 64, 13, 30),
+                                         (3, 64, 64, 20, 20), (1, 64, 128, 25, 25)])
 @pytest.mark.parametrize('mask,accumulate', [('self', 0), ('tensor', 1), ('none', 1)])
 def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
     """dbn_winograd_dgrad_bnsums_f32: the data gradient of a 3x3 / stride-1 / pad-1 conv (Ci -> Co) through the Winograd kernel with

@@ -21,7 +21,7 @@ def timed(fn):
 
 
 for (N, H, Ci, Co, what) in ((16, 160, 64, 64, 'layer1 / smooth_p2'), (16, 160, 256, 64, 'head 256->64'), (16, 80, 128, 128, 'layer2'),
-                             (16, 80, 64, 64, 'smooth_p3'), (16, 160, 64, 256, '(dgrad-shaped) 64->256')):
+                             (16, 80, 64, 64, 'smooth_p3'), (16, 160, 64, 256, '(dgrad-shaped) 64->256'), (16, 40, 256, 256, 'layer3'), (16, 20, 512, 512, 'layer4')):
     w = rnd(Co, Ci, 3, 3, seed=1, scale=0.05)
     x = torch.randn(N, H, H, Ci, device=DEV)
     y = torch.empty(N, H, H, Co, device=DEV)
