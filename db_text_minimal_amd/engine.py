@@ -145,6 +145,7 @@ class Engine:
         self._bias_done = set()
         self._bnb_sums = {}     # bn name -> (partials [2][C][rows], rows) produced by the data gradient that wrote its dout
         self._reduce_pending = []    # deferred slab reductions of this backward pass: (key, job record)
+        self._wgrad_fifo = []        # weight gradients queued for a late launch (late_wgrad)
         self._wino_src = {}          # Winograd panel key -> (parameter, panel, O, I, cs, dgrad)
         self._wino_jobs = None
         self._reduce_job_cache = {}  # (layer, phase-2 arguments) -> dbn_wgrad_reduce_job
@@ -845,6 +846,7 @@ class Engine:
 
     def flush_wgrad_reduces(self):
         """The deferred slab reductions as ONE launch on the side stream (behind the matrix kernels that filled the slabs)."""
+        self._flush_wgrads()  # (every weight gradient of the stage is issued before its gradients are announced / joined)
         if not self._reduce_pending:
             return
         pending, self._reduce_pending = self._reduce_pending, []
@@ -864,12 +866,33 @@ class Engine:
         with self.side_stream():
             check(self.L.dbn_wgrad_reduce_many(table.data_ptr(), first.data_ptr(), n, blocks, smem, self.stream), 'wgrad_reduce_many')
 
+    # Weight gradients enqueued LATE: conv_wgrad() only queues the launch; it is issued on the side stream right before the next
+    # BatchNorm backward of the main stream (or at the end of the pass).  The side stream waits for everything the main stream has
+    # enqueued by then — i.e. also for this layer's data gradient — so the weight gradient runs beside the HBM-bound BatchNorm pass
+    # and the next layer's data gradient instead of beside its own layer's data gradient (two MFMA kernels side by side are zero-sum,
+    # an MFMA kernel beside an HBM-bound one hides it).  Round 3 measured this as a loss (538 -> 532 images/s) when the data
+    # gradients were the longer kernels; with the Winograd data gradients the main stream's BatchNorm passes had become exposed
+    # (1.28 ms of bn_bwd_apply with no MFMA kernel in flight, round-4 trace).
+    late_wgrad = os.environ.get('DBN_LATE_WGRAD', '1') == '1'
+
+    def _flush_wgrads(self):
+        if self._wgrad_fifo:
+            fifo, self._wgrad_fifo = self._wgrad_fifo, []
+            for fn in fifo:
+                fn()
+
     def conv_wgrad(self, name, dy, x, conv):
         self._presplit(dy, x)
-        with self.side_stream():
-            self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True)
-            if conv.bias is not None and name + '.bias' not in self._bias_done:
-                self.col_sum(dy, self.grad_views[name + '.bias'])
+
+        def launch():
+            with self.side_stream():
+                self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True)
+                if conv.bias is not None and name + '.bias' not in self._bias_done:
+                    self.col_sum(dy, self.grad_views[name + '.bias'])
+        if self.late_wgrad and self.overlap_wgrad and not self._in_side and self.prof is None:
+            self._wgrad_fifo.append(launch)
+        else:
+            launch()
 
     def convT_fwd(self, name, x, ct, out_name):
         N, H, W, C = x.shape
@@ -945,6 +968,7 @@ class Engine:
         """mask: None (no ReLU), 'self' (ReLU directly on this BN's output: recomputed from y with the
         forward's scale/shift, nothing extra is read), or a tensor (saved activation whose sign gates).
         conv_bias: name of the bias parameter of the conv that produced y (its gradient = column sums of dy)."""
+        self._flush_wgrads()  # (late_wgrad: the queued weight gradients start beside this HBM-bound pass)
         C = y.shape[-1]
         M = y.numel() // C
         dy = self.buf(dy_name, *y.shape)

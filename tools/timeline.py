@@ -16,7 +16,7 @@ rows = c.execute(q).fetchall()
 t0, t1 = rows[0][1], max(r[2] for r in rows)
 lo = t0 + skip * (t1 - t0)  # skip warm-up / set-up
 rows = [r for r in rows if r[1] >= lo]
-is_mfma = lambda n: ('igemm_f32_kernel' in n) or ('convt2x2_f32_kernel' in n) or ('wgrad_f32_kernel' in n) or ('wgrad_tr_kernel' in n) or ('wgrad_patch_kernel' in n)
+is_mfma = lambda n: ('igemm_f32_kernel' in n) or ('winograd_f32_kernel' in n) or ('convt2x2_f32_kernel' in n) or ('wgrad_f32_kernel' in n) or ('wgrad_tr_kernel' in n) or ('wgrad_patch_kernel' in n)
 ev = []
 for r in rows:
     k = 1 if is_mfma(r[0]) else 0
