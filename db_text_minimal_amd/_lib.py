@@ -108,6 +108,9 @@ SIGNATURES.update({
     'dbn_winograd_pack_batched': 'pip',
     'dbn_winograd_dgrad_bnsums_f32': 'ppp' + 'iiiiii' + 'pppp' + 'ppp' + 'pppp' + 'p' + 'p',
     'dbn_winograd_ws_floats': 'iiii',
+    'dbn_winograd_wgrad_eligible': 'iiiiii',
+    'dbn_winograd_wgrad_slab_floats': 'iiiii',
+    'dbn_winograd_wgrad_f32': 'ipppp' + 'iiiiii' + 'fp',
     'dbn_winograd_conv_bn_f32': 'pppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_set_phase_priority': 'i',
     'dbn_set_trace': 'pl',
@@ -132,7 +135,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_winograd_panel_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

@@ -769,12 +769,29 @@ class Engine:
     # the 256 MB Infinity Cache — f32 545.6 -> 542.1 images/s, bf16 1667 -> 1340-1420 (profiles/r04_ab_grouped_reduce.txt).  The long
     # in-flight time of the small reductions costs nothing: they run beside MFMA kernels on a stream that is not the critical path.
     defer_wgrad_reduce = os.environ.get('DBN_DEFER_REDUCE', '0') == '1'
+    winograd_wgrad = os.environ.get('DBN_WINOGRAD_WGRAD', '1') == '1'  # (A/B switch; off: the direct kernels of wgrad_kernels.h)
 
     def wgrad(self, name, sm, big, O, I, k, stride, pad, gview, defer=False):
         """defer: the gradient is only needed by the optimizer / the gradient exchange, so its slab reduction may wait for
         flush_wgrad_reduces() (conv_wgrad, convT_bwd); False: a kernel of this pass reads gview next (FPN level scatter, DCN)."""
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
+        if (self.winograd_wgrad and self.at == 0 and self.ns == 0 and (k, stride, pad) == (3, 1, 1) and (Ho, Wo) == (H, W)
+                and sm.dtype == torch.float32 and big.dtype == torch.float32
+                and self.L.dbn_winograd_wgrad_eligible(N, H, W, O, Cb, I)):
+            # 3x3 / stride 1 in exact fp32: Winograd F(2x2,3x3) over the tiles (csrc/winograd_wgrad_f32.hip), 2.25x fewer matrix FLOPs
+            slab = self.scratch('_wgrad_slab', self.L.dbn_winograd_wgrad_slab_floats(N, H, W, O, Cb))
+            wargs = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, H, W, O, Cb, I, self.grad_scale, self.stream)
+            if self.prof:  # (FLOPs the matrix pipe executes: 16 products per tile and channel pair; see _winograd_conv)
+                self.prof.begin('winograd_wgrad_f32_kernel', 2.0 * N * ((H + 1) // 2) * ((W + 1) // 2) * 16 * O * Cb, 0.0, 'wgrad ' + name)
+                check(self.L.dbn_winograd_wgrad_f32(1, *wargs), 'winograd wgrad ' + name)
+                self.prof.end()
+                self.prof.begin('wgrad_reduce_kernel', 0.0, 0.0, 'wgrad reduce ' + name)
+                check(self.L.dbn_winograd_wgrad_f32(2, *wargs), 'winograd wgrad reduce ' + name)
+                self.prof.end()
+            else:
+                check(self.L.dbn_winograd_wgrad_f32(3, *wargs), 'winograd wgrad ' + name)
+            return
         # reductions on their own stream (see reduce_stream): only for gradients no kernel of this pass reads, on the side stream
         async_reduce = (defer and self.reduce_stream and self._in_side and self.prof is None and not self.defer_wgrad_reduce
                         and not torch.cuda.is_current_stream_capturing())
@@ -872,8 +889,11 @@ class Engine:
     # and the next layer's data gradient instead of beside its own layer's data gradient (two MFMA kernels side by side are zero-sum,
     # an MFMA kernel beside an HBM-bound one hides it).  Round 3 measured this as a loss (538 -> 532 images/s) when the data
     # gradients were the longer kernels; with the Winograd data gradients the main stream's BatchNorm passes had become exposed
-    # (1.28 ms of bn_bwd_apply with no MFMA kernel in flight, round-4 trace).
-    late_wgrad = os.environ.get('DBN_LATE_WGRAD', '1') == '1'
+    # (1.28 ms of bn_bwd_apply with no MFMA kernel in flight, round-4 trace).  Measured on one box, interleaved: exact fp32 629 vs
+    # 633 images/s (off is better: default off there); bf16 1620-1630 vs 1430-1500 (on is better, and equal to the round-3 tree on the
+    # same box — the bf16 step with immediate launches is bimodal from process to process, 1170 / 1445 / 1670 images/s for the SAME
+    # library, profiles/r04_late_wgrad.txt — the late order has only shown the fast mode): default on for the 16-bit storage modes.
+    late_wgrad = os.environ.get('DBN_LATE_WGRAD', '')  # '' = in the 16-bit storage modes only (measured, see above); '0' / '1' force
 
     def _flush_wgrads(self):
         if self._wgrad_fifo:
@@ -889,7 +909,8 @@ class Engine:
                 self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True)
                 if conv.bias is not None and name + '.bias' not in self._bias_done:
                     self.col_sum(dy, self.grad_views[name + '.bias'])
-        if self.late_wgrad and self.overlap_wgrad and not self._in_side and self.prof is None:
+        late = self.late_wgrad == '1' or (self.late_wgrad == '' and self.at != 0)
+        if late and self.overlap_wgrad and not self._in_side and self.prof is None:
             self._wgrad_fifo.append(launch)
         else:
             launch()

@@ -262,6 +262,16 @@ int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float*
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                              float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
 
+/* Weight gradient of a 3x3 / stride-1 / pad-1 conv through the Winograd transform F(2x2,3x3) in exact-fp32 arithmetic
+ * (csrc/winograd_wgrad_f32.hip; replaces torch.autograd's conv weight gradient for resnet.py:70-91, segmentation_body.py:55-61,
+ * segmentation_head.py:24-25,64-68).  x [N][H][W][Cb] (channels >= I are zero padding), dy [N][H][W][O], grad [O][I][3][3] =
+ * scale * dW (overwritten).  slab: dbn_winograd_wgrad_slab_floats floats of scratch.  phases: 1 = matrix kernel (-> slab),
+ * 2 = slab reduction + G^T . G (-> grad), 3 = both.  Deterministic (fixed-order fp64 reduction, no atomics). */
+int dbn_winograd_wgrad_eligible(int N, int H, int W, int O, int Cb, int I);
+long dbn_winograd_wgrad_slab_floats(int N, int H, int W, int O, int Cb);
+int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, float* slab, float* grad, int N, int H, int W, int O, int Cb, int I,
+                           float scale, void* stream);
+
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W].
  * One launch: the workgroup that finishes last folds every workgroup's partial sums (fixed order) and writes losses[5] and
  * coef[8].  ws: dbn_db_loss_ws_bytes() bytes, ZERO-FILLED by the caller before the first call (it ends with the arrival counter

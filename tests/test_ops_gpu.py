@@ -1706,3 +1706,35 @@ def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
         report('second BatchNorm sums', part2.double().sum(2).cpu(), torch.stack([s1, s2b]), 2e-6 * sc, 1e-5)
         report('second BatchNorm finalized', torch.cat([fo[3].cpu(), fo[4].cpu(), fo[5].cpu()]),
                torch.cat([s1 / Mtot, s2b / Mtot, 0.5 * s2b, 0.5 * s1]), 2e-6 * sc, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,Ci,Cs,Co,H,W', [(2, 64, 64, 64, 16, 32), (1, 64, 64, 128, 20, 20), (2, 128, 128, 64, 9, 29), (1, 40, 64, 64, 8, 16),
+                                            (3, 256, 256, 64, 24, 40), (1, 128, 128, 128, 40, 40), (5, 64, 64, 64, 13, 30), (2, 64, 64, 64, 64, 64)])
+def test_winograd_weight_gradient(N, Ci, Cs, Co, H, W):
+    """dbn_winograd_wgrad_f32: weight gradient of a 3x3 / stride 1 / pad 1 conv through Winograd F(2x2, 3x3) over the tiles in fp32
+    (torch.autograd's conv weight gradient of resnet.py:70-91, segmentation_body.py:55-61, segmentation_head.py:24-25) against
+    autograd in fp64: ragged maps (zero-filled patch edges), odd sizes, padding channels (Cs > Ci), several channel blocks, scale.
+    Tolerance 4e-6 of the gradient's scale per element (the direct kernel's own fp32 rounding is ~1e-6 here); bit-reproducible
+    from run to run; against the direct kernel to fp32 rounding."""
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, 1, 1)
+    dy = rnd(*y.shape, seed=4)
+    (ref, ) = torch.autograd.grad(y, w, dy.double())
+    xs, dys = nhwc(pad_c(x, Cs)), nhwc(dy)
+    assert L().dbn_winograd_wgrad_eligible(N, H, W, Co, Cs, Ci)
+    slab = torch.full((L().dbn_winograd_wgrad_slab_floats(N, H, W, Co, Cs), ), float('nan'), device=DEV)
+    g = torch.full((Co, Ci, 3, 3), float('nan'), device=DEV)
+    args = (dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, H, W, Co, Cs, Ci)
+    _lib.check(L().dbn_winograd_wgrad_f32(3, *args, 0.5, stream()), 'winograd wgrad')
+    scale = float(ref.abs().max())
+    report('winograd wgrad', g.cpu(), 0.5 * ref, 4e-6 * 0.5 * scale, 4e-6)
+    g2 = torch.full_like(g, float('nan'))
+    slab.fill_(float('nan'))
+    _lib.check(L().dbn_winograd_wgrad_f32(1, *args[:3], g2.data_ptr(), *args[4:], 0.5, stream()), 'winograd wgrad phase 1')
+    _lib.check(L().dbn_winograd_wgrad_f32(2, *args[:3], g2.data_ptr(), *args[4:], 0.5, stream()), 'winograd wgrad phase 2')
+    torch.cuda.synchronize()
+    assert torch.equal(g, g2)
+    gd = wgrad(dys, xs, Co, Ci, 3, 1, 1, scale=0.5)
+    report('winograd wgrad vs the direct kernel', g.cpu(), gd.cpu(), 5e-6 * 0.5 * scale, 5e-6)
