@@ -38,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
-WINOGRAD = 'winograd_f32_kernel'  # its bracketed FLOPs are the EXECUTED ones (engine._winograd_conv)
+WINOGRAD = ('winograd_f32_kernel', 'winograd_wgrad_f32_kernel')  # their bracketed FLOPs are the EXECUTED ones (engine._winograd_conv, engine.wgrad)
 TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem dgrad (dense convolution count)
 # what the matrix pipe computes per conv math mode: dtype of the JSON line, wording of the workload, MFMA peak that bounds it
 # (bf16x3 evaluates six bf16 products per fp32 product: its roofline is the bf16 peak / 6)
@@ -290,23 +290,45 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'winograd_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'winograd_f32_kernel', 'winograd_wgrad_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
                                 'head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
     clock = ClockProbe(dev, args.steps)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     trainer.exchange_events = [] if world > 1 else None
+    # The cyclic garbage collector stays out of the timed region: a generation-2 pass of this process (torch + the model's object
+    # graph) stalls the enqueueing thread for 70-90 ms — measured on a fresh box as ONE timed step of 98-117 ms against 23 ms
+    # (cProfile: the whole stall inside one dict lookup), i.e. 15 % off a 20-step figure, and whether it falls inside the region
+    # depends on the allocation history (first process after a fresh checkout compiles its .pyc files and shifts it in).
+    # Nothing in a step creates reference cycles; the collector runs again right after the region.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
+    host_ms = []
+    cprof = None
     for it in range(args.steps):
+        th = time.perf_counter()
         step_ev[it].record()
         clock.sample()
         eng.prof = timer if it % TIMED_EVERY == 0 else None
+        if it == 0 and os.environ.get('DBN_BENCH_CPROFILE'):  # debugging aid: host profile of the first timed step
+            import cProfile
+            cprof = cProfile.Profile()
+            cprof.enable()
         preds, losses = trainer.step(img, gts, resident=True)  # (the same resident tensors every step: --graph skips its input copy)
+        if cprof is not None and it == 0:
+            cprof.disable()
+        host_ms.append(round((time.perf_counter() - th) * 1e3, 2))
     step_ev[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     eng.prof = None
+    if cprof is not None and rank == 0:
+        import pstats
+        pstats.Stats(cprof, stream=sys.stderr).sort_stats('tottime').print_stats(14)
     timed_steps = len(range(0, args.steps, TIMED_EVERY))
     per_step = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     if dist.is_initialized():
@@ -384,7 +406,7 @@ def main():
                 'note': ('measured in the timed region; the backward-pass launches of this kernel share the CUs with the concurrent '
                          'weight-gradient stream, so their durations (here and in the rocprofv3 trace of this command) include that '
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
-    if dname == WINOGRAD:
+    if dname in WINOGRAD:
         # F(2x2,3x3): the matrix pipe executes 16 products per 2 x 2 output tile and channel pair where the direct convolution has 36.
         # `achieved` / `frac` are on the EXECUTED FLOPs (matrix-pipe utilisation, <= 1 by construction); the figure on the direct
         # convolution's algorithmic 2*M*N*K count is 9/4 of it and is what the step-level TFLOP/s use.
@@ -416,7 +438,7 @@ def main():
         a = serial['flops'] / (serial['ms'] * 1e-3) / 1e12
         roofline_serial = {'kernel': dname, 'achieved': round(a, 2), 'peak': round(peak_mfma, 1), 'unit': 'TFLOP/s',
                            'frac': round(a / peak_mfma, 4), 'launches': serial['launches'],
-                           **({'achieved_algorithmic': round(a * 2.25, 2), 'frac_algorithmic': round(a * 2.25 / peak_mfma, 4)} if dname == WINOGRAD else {}),
+                           **({'achieved_algorithmic': round(a * 2.25, 2), 'frac_algorithmic': round(a * 2.25 / peak_mfma, 4)} if dname in WINOGRAD else {}),
                            'avg_launch_ms': round(serial['ms'] / serial['launches'], 4),
                            'how': 'median of %d extra steps outside the timed region, every launch bracketed by HIP events, single stream' % len(serial_runs)}
     else:
@@ -429,7 +451,7 @@ def main():
                 a = v['flops'] / (v['ms'] * 1e-3) / 1e12
                 ent.update(bound='mfma', achieved=round(a, 2), peak=round(peak_mfma, 1), unit='TFLOP/s',
                            frac=round(a / peak_mfma, 4))
-                if name == WINOGRAD:
+                if name in WINOGRAD:
                     ent.update(frac_algorithmic=round(a * 2.25 / peak_mfma, 4))
             elif v['bytes'] > 0:
                 a = v['bytes'] / (v['ms'] * 1e-3) / 1e9
@@ -437,13 +459,13 @@ def main():
             kernels.append(ent)
 
     if rank == 0:  # the weight gradient as a whole (every tile variant + the slab reductions), serial
-        wg = [v for k, v in serial_summ.items() if k.startswith(('wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel'))]
+        wg = [v for k, v in serial_summ.items() if k.startswith(('wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel', 'winograd_wgrad_f32_kernel'))]
         red = serial_summ.get('wgrad_reduce_kernel')
         if wg:
             ms_w = sum(v['ms'] for v in wg) + (red['ms'] if red else 0.0)
             fl_w = sum(v['flops'] for v in wg)
             a = fl_w / (ms_w * 1e-3) / 1e12
-            kernels.append({'kernel': 'weight gradient: every wgrad_f32_kernel / wgrad_tr_kernel / wgrad_patch_kernel variant + wgrad_reduce_kernel', 'launches': sum(v['launches'] for v in wg),
+            kernels.append({'kernel': 'weight gradient: every wgrad_f32_kernel / wgrad_tr_kernel / wgrad_patch_kernel / winograd_wgrad_f32_kernel launch + wgrad_reduce_kernel (FLOPs as executed)', 'launches': sum(v['launches'] for v in wg),
                             'ms_per_step': round(ms_w, 3), 'bound': 'mfma', 'achieved': round(a, 2), 'peak': round(peak_mfma, 1),
                             'unit': 'TFLOP/s', 'frac': round(a / peak_mfma, 4)})
     alt = {}
@@ -481,6 +503,7 @@ def main():
             'timing': {'value_from': 'wall time of the K steps between two barrier+synchronize brackets, max over ranks (driver contract)',
                        'ms_per_step_median': round(per_step[len(per_step) // 2], 3), 'ms_per_step_min': round(per_step[0], 3),
                        'ms_per_step_max': round(per_step[-1], 3), 'ms_per_step_in_order': [round(step_ev[i].elapsed_time(step_ev[i + 1]), 2) for i in range(args.steps)],
+                       'host_enqueue_ms_in_order': host_ms,
                        'instrumented_steps_in_region': timed_steps,
                        'note': 'per-step figures from HIP events on the main stream at the step boundaries (rank 0); '
                                '%d of the K steps carry event brackets around their MFMA launches (roofline), which costs those steps ~2 %%' % timed_steps},
