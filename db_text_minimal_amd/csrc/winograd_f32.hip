@@ -17,6 +17,9 @@
 // different summation (max relative error ~1e-6 of the output scale), not bit for bit.
 #include "igemm_common.h"
 #include <algorithm>
+#ifndef DBN_WINO_EXP
+#define DBN_WINO_EXP 0
+#endif
 
 namespace {
 
@@ -132,6 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int st_ = decltype(SET)::value;
         const int g = min(w_next, w_last);
         ++w_next;
+#if DBN_WINO_EXP == 1  // (timing experiment, wrong results: the weight fragments of the first channel block only — no L2 weight traffic)
+        if (w_next > 4) return;
+#endif
         const unsigned so = (unsigned)((g >> 2) * 16 + 4 * wave + (g & 3)) * point_bytes;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -179,6 +185,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
             constexpr bool plus = j == 1;
             f32x4 v[2];
+#if DBN_WINO_EXP == 2  // (timing experiment, wrong results: no LDS reads / transform arithmetic in the loop)
+            v[0] = pr[0];
+            v[1] = pr[1 % PL];
+#else
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const f32x4 x11 = P[s2 * ppx2 + row1 + b1], x12 = P[s2 * ppx2 + row1 + b2];
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
             }
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll

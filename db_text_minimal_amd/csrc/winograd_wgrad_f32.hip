@@ -15,6 +15,9 @@
 // reduction kernel adds the slabs in fp64 in a fixed order and applies G^T . G (deterministic, no atomics).
 #include "igemm_common.h"
 #include <algorithm>
+#ifndef DBN_WWG_EXP
+#define DBN_WWG_EXP 0  // timing experiments (wrong results): 1 = the first patch only (no staging / barriers in the loop), 2 = no LDS reads / transforms
+#endif
 
 namespace {
 
@@ -115,19 +118,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1) load_group(g + 1);
+        if (g + 1 < g1 && DBN_WWG_EXP != 1) load_group(g + 1);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int xo = (2 * (s >> 2) * WG_XROW + 4 * (s & 3)) * 32, yo = (2 * (s >> 2) * WG_YROW + 4 * (s & 3)) * 64;
             f32x2 R[4];
+#if DBN_WWG_EXP == 2
+            for (int q = 0; q < 4; ++q) { R[q][0] = rx[q][0]; R[q][1] = rx[q][1]; }
+            const float d00 = ry[0][0], d01 = ry[0][1], d10 = ry[1][0], d11 = ry[1][1];
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x2 u1 = Xr1[xo + q * 32], u2 = Xr2[xo + q * 32];
                 R[q][0] = fmaf(sa, u2[0], u1[0]);  // (sa = +-1: exact)
                 R[q][1] = fmaf(sa, u2[1], u1[1]);
             }
-            const f32x2 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
             const float d00 = Yb[yo], d01 = Yb[yo + 64], d10 = Yb[yo + WG_YROW * 64], d11 = Yb[yo + WG_YROW * 64 + 64];
+#endif
+            const f32x2 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
             const float r0 = fmaf(c1, d10, c0 * d00), r1 = fmaf(c1, d11, c0 * d01);
             const float D[4] = {r0, r0 + r1, r0 - r1, -r1};
 #pragma unroll
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[j], V[j][h], acc[j][h], 0, 0, 0);
         }
-        if (g + 1 < g1) {
+        if (g + 1 < g1 && DBN_WWG_EXP != 1) {
             __syncthreads();  // every wave has read this patch
             store_group();
             __syncthreads();
