@@ -109,8 +109,10 @@ SIGNATURES.update({
     'dbn_winograd_dgrad_bnsums_f32': 'ppp' + 'iiiiii' + 'pppp' + 'ppp' + 'pppp' + 'p' + 'p',
     'dbn_winograd_ws_floats': 'iiii',
     'dbn_winograd_wgrad_eligible': 'iiiiii',
+    'dbn_winograd_wgrad_linear': 'ii',
     'dbn_winograd_wgrad_slab_floats': 'iiiii',
-    'dbn_winograd_wgrad_f32': 'ipppp' + 'iiiiii' + 'fp',
+    'dbn_winograd_wgrad_f32': 'ipppppp' + 'iiiiii' + 'fp',
+    'dbn_winograd_conv_bn_act_f32': 'pppppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_winograd_conv_bn_f32': 'pppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_set_phase_priority': 'i',
     'dbn_set_trace': 'pl',

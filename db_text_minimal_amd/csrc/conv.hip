@@ -516,12 +516,17 @@ int dbn_winograd_pack_batched(const void* jobs, int n, void* stream) {
     return dbn_launch_winograd_pack_many(jobs, n, (hipStream_t)stream);
 }
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * dbn_winograd_rows(N, H, W); }
-int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
-                             const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
-                             float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
-    DBN_REQUIRE(src && upanel && dst && dbn_winograd_eligible(N, H, W, Cs, Cd));
+// ... _act_: the conv's input is relu(src * in_scale[c] + in_shift[c]) ([Cs] floats each; NULL, NULL: src itself) — src is the INPUT of
+// the BatchNorm + ReLU in front of the conv (basic.py:32-36 / resnet.py:77-80), applied while the patch is staged with bn_apply's own
+// arithmetic, so that activation tensor is never written or re-read (bit-identical to bn_apply followed by dbn_winograd_conv_bn_f32).
+int dbn_winograd_conv_bn_act_f32(const float* src, const float* in_scale, const float* in_shift, const float* upanel, const float* bias,
+                                 float* dst, int N, int H, int W, int Cs, int Cd, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean,
+                                 float* save_rstd, float* ws, void* stream) {
+    DBN_REQUIRE(src && upanel && dst && dbn_winograd_eligible(N, H, W, Cs, Cd) && !in_scale == !in_shift);
     DBN_REQUIRE(!gamma || (beta && scale && shift && save_mean && save_rstd && ws));
     IgemmParams p{};
+    p.in_scale = in_scale; p.in_shift = in_shift;
     p.src = src; p.wpk = upanel; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
     p.src_bytes = (unsigned)((long)N * H * W * Cs * 4);
@@ -532,6 +537,13 @@ int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float*
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
+}
+
+int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
+                             const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                             float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_winograd_conv_bn_act_f32(src, nullptr, nullptr, upanel, bias, dst, N, H, W, Cs, Cd, gamma, beta, eps, momentum, run_mean, run_var,
+                                        scale, shift, save_mean, save_rstd, ws, stream);
 }
 
 // The data gradient of a 3x3 / stride-1 / pad-1 conv through the same kernel (upanel from dbn_winograd_pack(..., dgrad = 1)): dx [N,H,W,Cd]

@@ -116,6 +116,9 @@ struct IgemmParams {
     const float* seg_wpk[4];
     unsigned seg_bytes[4];
     unsigned seg_plane_bytes[4];  // AT = 3
+    // winograd_f32_kernel only: src is the INPUT of a BatchNorm + ReLU whose output the conv consumes; relu(fma(src, in_scale[c],
+    // in_shift[c])) is applied while the patch is staged (the activation tensor is never written; same arithmetic as bn_apply_kernel)
+    const float *in_scale, *in_shift;
 };
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger

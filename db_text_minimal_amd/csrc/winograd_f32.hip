@@ -91,13 +91,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     f32x4 pr[PL];
     const int ncb = p.Cs >> 4;
+    // apply-on-load (IgemmParams::in_scale): this thread's pieces are chunk tid & 3 of every pixel = channels 16 cb + 4 (tid & 3) .. + 3
+    // (the coefficients wait in LDS behind the two patch buffers — Cs <= 512 — until the epilogue takes the region over)
+    const bool act = p.in_scale != nullptr;
+    f32x4* const ACT = smem + 2 * P_PATCH;  // [Cs / 4] scale, [Cs / 4] shift
+    static_assert(2 * P_PATCH + 2 * 128 <= X_FLOATS / 4, "room for the apply-on-load coefficients of 512 channels");
+    if (act) {
+        for (int i = tid; i < (p.Cs >> 2); i += 256) {
+            ACT[i] = reinterpret_cast<const f32x4*>(p.in_scale)[i];
+            ACT[(p.Cs >> 2) + i] = reinterpret_cast<const f32x4*>(p.in_shift)[i];
+        }
+    }
     auto load_patch = [&](int cb) {
         const unsigned add = (unsigned)(cb * 64);
 #pragma unroll
         for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
     };
-    auto store_patch = [&](int buf) {
+    auto store_patch = [&](int buf, int cb) {
         f32x4* const P = smem + buf * P_PATCH;
+        if (act) {  // (pixels outside the map are the conv's zero padding of the ACTIVATION: they stay zero)
+            const f32x4 asc = ACT[cb * 4 + (tid & 3)], ash = ACT[(p.Cs >> 2) + cb * 4 + (tid & 3)];
+#pragma unroll
+            for (int j = 0; j < PL; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pr[j][e] = poff[j] == OOB_OFFSET ? 0.f : dbn_affine_relu(pr[j][e], asc[e], ash[e]);
+        }
 #pragma unroll
         for (int j = 0; j < PL; ++j)
             if (pslot[j] >= 0) P[pslot[j]] = pr[j];
@@ -164,7 +182,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_patch(0);
     issue_w(std::integral_constant<int, 0>{});
     issue_w(std::integral_constant<int, 1>{});
-    store_patch(0);
+    if (act) __syncthreads();  // (the coefficients are in LDS)
+    store_patch(0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #if DBN_TRACE
             tr_t = __builtin_amdgcn_s_memrealtime();
 #endif
-            store_patch((cb + 1) & 1);
+            store_patch((cb + 1) & 1, cb + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

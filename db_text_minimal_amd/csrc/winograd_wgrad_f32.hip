@@ -22,7 +22,6 @@
 namespace {
 
 constexpr int WG_XPX = 180, WG_XROW = 18, WG_YPX = 128, WG_YROW = 16;
-constexpr int WG_XCH = WG_XPX * 16, WG_YCH = WG_YPX * 16;  // 16-byte chunks of the two patches (64 channels = 16 chunks per pixel)
 
 struct WinoWgradParams {
     const float* x;   // [N][H][W][Cx]
@@ -33,10 +32,21 @@ struct WinoWgradParams {
     int tw, gpi, groups;    // patches per patch row, per image, in all
     int nsplit;
     unsigned x_bytes, dy_bytes;
+    const float *x_scale, *x_shift;  // optional: x is the input of a BatchNorm + ReLU; relu(fma(x, x_scale[c], x_shift[c])) is applied on load
 };
 
+// LIN = false: a workgroup's 32 tiles per k-group are the 4 x 8 tiles of an 8 x 16-pixel patch (large maps; ragged edges zero-filled).
+// LIN = true (maps up to 40 pixels wide: layer3 / layer4 of the 640^2 benchmark): the 32 tiles are CONSECUTIVE tiles of one image in
+// row-major order over its ceil(H/2) x ceil(W/2) tile grid — a 20 x 20 map fills 52 % of its 8 x 16 patches but 100 / 128 of its tile
+// groups — and the LDS holds the band of pixel rows those tiles touch, full width (x: + the one-pixel halo).  The band is too large
+// for a register prefetch beside the 128 accumulators: it is loaded and stored between the two barriers of a group.
+constexpr int WL_XPX = 336, WL_YPX = 240;  // most band pixels of x / dY in the LIN form (dbn_winograd_wgrad_linear checks the map)
+template <bool LIN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void winograd_wgrad_f32_kernel(const WinoWgradParams p) {
-    __shared__ f32x4 smem[WG_XCH + WG_YCH];  // x patch [180 px][64 ch] (45 KB), dY patch [128 px][64 ch] (32 KB)
+    constexpr int XPX = LIN ? WL_XPX : WG_XPX, YPX = LIN ? WL_YPX : WG_YPX;
+    constexpr int XCH = XPX * 16, YCH = YPX * 16;
+    constexpr int NXP = (XCH + 511) / 512, NYP = (YCH + 511) / 512;  // staging pieces per thread
+    __shared__ f32x4 smem[XCH + YCH];  // x [pixels][64 ch], dY [pixels][64 ch]: 45 + 32 KB (patch form), 84 + 60 KB (LIN)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int irow = wave & 3, oh = wave >> 2;
@@ -47,47 +57,125 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int g0 = (int)((long)split * p.groups / p.nsplit), g1 = (int)((long)(split + 1) * p.groups / p.nsplit);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    // geometry of the LDS images: row pitch of the x image (with halo) and of the dY image, in pixels
+    const int TW = (p.W + 1) >> 1, TI = ((p.H + 1) >> 1) * TW;  // (LIN) tile grid of one image
+    const int prow = LIN ? 2 * TW + 2 : WG_XROW, yrow = LIN ? 2 * TW : WG_YROW;
+    const float rTW = 1.0f / (float)TW;
 
-    // ---- staging pieces: chunk idx = tid + 512 j of the x patch (j < 6; pixel idx >> 4, 16-byte chunk idx & 15), of the dY patch (j < 4)
-    unsigned xrel[6], yrel[4];
-    int xpos[6];  // py | px << 8, or -1 past the patch
+    // ---- staging pieces: 16-byte chunk idx = tid + 512 j of the x image (pixel idx >> 4, chunk idx & 15), of the dY image
+    unsigned xrel[NXP], yrel[NYP];
+    int xpos[NXP], ypos[NYP];  // py | px << 8, or -1 past the image
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NXP; ++j) {
         const int idx = tid + j * 512, pix = idx >> 4, ch = idx & 15;
-        const int py = pix / WG_XROW, px = pix - py * WG_XROW;
+        int py, px;
+        if constexpr (LIN) divmod24(pix, prow, 1.0f / (float)prow, py, px);
+        else { py = pix / WG_XROW; px = pix - py * WG_XROW; }
         xrel[j] = (unsigned)((py * p.W + px) * p.Cx + ch * 4) * 4u;
-        xpos[j] = idx < WG_XCH ? (py | (px << 8)) : -1;
+        xpos[j] = idx < XCH ? (py | (px << 8)) : -1;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NYP; ++j) {
         const int idx = tid + j * 512, pix = idx >> 4, ch = idx & 15;
-        yrel[j] = (unsigned)(((pix >> 4) * p.W + (pix & 15)) * p.Cy + ch * 4) * 4u;
+        int py, px;
+        if constexpr (LIN) divmod24(pix, yrow, 1.0f / (float)yrow, py, px);
+        else { py = pix >> 4; px = pix & 15; }
+        yrel[j] = (unsigned)((py * p.W + px) * p.Cy + ch * 4) * 4u;
+        ypos[j] = idx < YCH ? (py | (px << 8)) : -1;
     }
-    f32x4 rx[6], ry[4];
-    auto load_group = [&](int g) {  // (uniform g)
-        const int n = g / p.gpi, t = g - n * p.gpi, ty = t / p.tw, tx = t - ty * p.tw;
-        const int ph0 = ty * 8, pw0 = tx * 16;
-        const unsigned bx = (unsigned)(((n * p.H + ph0 - 1) * p.W + pw0 - 1) * p.Cx + ib * 64) * 4u;  // (may wrap: only in-map pieces use it)
-        const unsigned by = (unsigned)(((n * p.H + ph0) * p.W + pw0) * p.Cy + ob * 64) * 4u;
+    f32x4 rx[NXP], ry[LIN ? 1 : NYP];
+    // apply-on-load: this thread's x pieces are chunk tid & 15 of every pixel = channels 64 ib + 4 (tid & 15) .. + 3 throughout
+    // (patch form: held in registers; LIN — registers are short, and its staging does not overlap the matrix phase anyway — re-read per group)
+    const bool act = p.x_scale != nullptr;
+    f32x4 asc_ = {0.f, 0.f, 0.f, 0.f}, ash_ = {0.f, 0.f, 0.f, 0.f};
+    if (act && !LIN) {
+        asc_ = *reinterpret_cast<const f32x4*>(p.x_scale + ib * 64 + (tid & 15) * 4);
+        ash_ = *reinterpret_cast<const f32x4*>(p.x_shift + ib * 64 + (tid & 15) * 4);
+    }
+    unsigned xvalid = 0;  // bit j: piece j of the staged x image lies inside the map (outside: the conv's zero padding of the activation)
+    int t0 = 0, tr0 = 0;  // (LIN) first tile of the current group, its tile row
+    // origin of group g's LDS images in the tensors: image, first pixel row / column of the x image (hs0, ws0: one before the first
+    // output pixel), rows of the x image that belong to the group (LIN: the band; patch form: all 10)
+    auto geometry = [&](int g, int& n, int& hs0, int& ws0, int& xrows) {
+        n = g / p.gpi;
+        const int t = g - n * p.gpi;
+        if constexpr (LIN) {
+            const int tfirst = t * 32, tlast = min(tfirst + 31, TI - 1);
+            const int r0_ = tfirst / TW, r1_ = tlast / TW;
+            hs0 = 2 * r0_ - 1;
+            ws0 = -1;
+            xrows = 2 * (r1_ - r0_ + 1) + 2;
+        } else {
+            const int ty = t / p.tw, tx = t - ty * p.tw;
+            hs0 = ty * 8 - 1;
+            ws0 = tx * 16 - 1;
+            xrows = 10;
+        }
+    };
+    auto load_x = [&](int g) {  // (uniform g)
+        int n, hs0, ws0, xrows;
+        geometry(g, n, hs0, ws0, xrows);
+        const unsigned bx = (unsigned)(((n * p.H + hs0) * p.W + ws0) * p.Cx + ib * 64) * 4u;  // (may wrap: only in-map pieces use it)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < NXP; ++j) {
             const int py = xpos[j] & 255, px = xpos[j] >> 8;
-            const bool v = xpos[j] >= 0 && (unsigned)(ph0 - 1 + py) < (unsigned)p.H && (unsigned)(pw0 - 1 + px) < (unsigned)p.W;
+            const bool v = xpos[j] >= 0 && py < xrows && (unsigned)(hs0 + py) < (unsigned)p.H && (unsigned)(ws0 + px) < (unsigned)p.W;
             rx[j] = buffer_load_f32x4(rsX, v ? bx + xrel[j] : OOB_OFFSET);
+            xvalid = (xvalid & ~(1u << j)) | ((unsigned)v << j);
+        }
+    };
+    auto store_x = [&](int xrows) {
+        if (act) {
+            const f32x4 asc = LIN ? *reinterpret_cast<const f32x4*>(p.x_scale + ib * 64 + (tid & 15) * 4) : asc_;
+            const f32x4 ash = LIN ? *reinterpret_cast<const f32x4*>(p.x_shift + ib * 64 + (tid & 15) * 4) : ash_;
+#pragma unroll
+            for (int j = 0; j < NXP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rx[j][e] = ((xvalid >> j) & 1u) ? dbn_affine_relu(rx[j][e], asc[e], ash[e]) : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pix = (tid + j * 512) >> 4;
-            const bool v = ph0 + (pix >> 4) < p.H && pw0 + (pix & 15) < p.W;
-            ry[j] = buffer_load_f32x4(rsY, v ? by + yrel[j] : OOB_OFFSET);
+        for (int j = 0; j < NXP; ++j)
+            if (xpos[j] >= 0 && (xpos[j] & 255) < xrows) smem[tid + j * 512] = rx[j];
+    };
+    auto y_piece = [&](int j, int n, int hs0, int ws0, int xrows) {  // dY image: the x image without its halo
+        const int py = ypos[j] & 255, px = ypos[j] >> 8;
+        const unsigned by = (unsigned)(((n * p.H + hs0 + 1) * p.W + ws0 + 1) * p.Cy + ob * 64) * 4u;
+        const bool v = ypos[j] >= 0 && py < xrows - 2 && hs0 + 1 + py < p.H && ws0 + 1 + px < p.W;
+        return buffer_load_f32x4(rsY, v ? by + yrel[j] : OOB_OFFSET);
+    };
+    auto load_group = [&](int g) {  // patch form: both images into registers (stored after the compute phase of the previous group)
+        int n, hs0, ws0, xrows;
+        geometry(g, n, hs0, ws0, xrows);
+        load_x(g);
+        if constexpr (!LIN) {
+#pragma unroll
+            for (int j = 0; j < NYP; ++j) ry[j] = y_piece(j, n, hs0, ws0, xrows);
         }
     };
     auto store_group = [&]() {
+        store_x(10);
+        if constexpr (!LIN) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-            if (xpos[j] >= 0) smem[tid + j * 512] = rx[j];
+            for (int j = 0; j < NYP; ++j) smem[XCH + tid + j * 512] = ry[j];
+        }
+    };
+    auto stage_lin = [&](int g) {  // LIN: load and store between the group's two barriers; dY in batches of four pieces (registers)
+        int n, hs0, ws0, xrows;
+        geometry(g, n, hs0, ws0, xrows);
+        load_x(g);
+        f32x4 q[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) smem[WG_XCH + tid + j * 512] = ry[j];
+        for (int h = 0; h < NYP; h += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (h + j < NYP) q[j] = y_piece(h + j, n, hs0, ws0, xrows);
+            if (h == 0) store_x(xrows);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (h + j < NYP && ypos[h + j] >= 0 && (ypos[h + j] & 255) < xrows - 2) smem[XCH + tid + (h + j) * 512] = q[j];
+        }
+        t0 = (g - n * p.gpi) * 32;
+        tr0 = t0 / TW;
     };
 
     // ---- this wave's rows of the two transforms
@@ -97,12 +185,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float sa = irow == 1 ? 1.f : -1.f;
     const float c0 = irow == 3 ? 0.f : 1.f, c1 = irow == 0 ? 0.f : (irow == 1 ? 1.f : -1.f);
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    // lane (li, lh): tile 2 s + lh of k-step s = tile (s >> 2, 2 (s & 3) + lh) of the patch's 4 x 8; x channels 2 li, 2 li + 1 (-> the
-    // two 32-wide halves of I: even / odd channels), dY channel 32 oh + li
-    const f32x2* const X2 = reinterpret_cast<const f32x2*>(smem) + (2 * lh) * 32 + li;
-    const f32x2* const Xr1 = X2 + a1 * WG_XROW * 32;
-    const f32x2* const Xr2 = X2 + a2 * WG_XROW * 32;
-    const float* const Yb = reinterpret_cast<const float*>(smem + WG_XCH) + (2 * lh) * 64 + oh * 32 + li;
+    // lane (li, lh): tile 2 s + lh of k-step s — patch form: tile (s >> 2, 2 (s & 3) + lh) of the patch's 4 x 8; LIN: tile t0 + 2 s + lh of
+    // the image's grid (past the last tile: dY operand zero) —; x channels 2 li, 2 li + 1 (-> the two 32-wide halves of I: even / odd
+    // channels), dY channel 32 oh + li
+    const f32x2* const X2 = reinterpret_cast<const f32x2*>(smem) + (LIN ? 0 : (2 * lh) * 32) + li;
+    const f32x2* const Xr1 = X2 + a1 * prow * 32;
+    const f32x2* const Xr2 = X2 + a2 * prow * 32;
+    const float* const Yb = reinterpret_cast<const float*>(smem + XCH) + (LIN ? 0 : (2 * lh) * 64) + oh * 32 + li;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -112,20 +201,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][h][r] = 0.f;
 
-    if (g0 < g1) {
-        load_group(g0);
-        store_group();
+    if constexpr (!LIN) {
+        if (g0 < g1) {
+            load_group(g0);
+            store_group();
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1 && DBN_WWG_EXP != 1) load_group(g + 1);
+        if constexpr (LIN) {
+            if (g > g0) __syncthreads();  // every wave has read the previous band
+            stage_lin(g);
+            __syncthreads();
+        } else {
+            if (g + 1 < g1 && DBN_WWG_EXP != 1) load_group(g + 1);
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int xo = (2 * (s >> 2) * WG_XROW + 4 * (s & 3)) * 32, yo = (2 * (s >> 2) * WG_YROW + 4 * (s & 3)) * 64;
+            int xo, yo;
+            float c0s = c0, c1s = c1;
+            if constexpr (LIN) {
+                const int t = t0 + 2 * s + lh;
+                const bool ok = t < TI;
+                int ty, tx;
+                divmod24(ok ? t : t0, TW, rTW, ty, tx);
+                ty -= tr0;
+                xo = (2 * ty * prow + 2 * tx) * 32;
+                yo = (2 * ty * yrow + 2 * tx) * 64;
+                c0s = ok ? c0 : 0.f;
+                c1s = ok ? c1 : 0.f;
+            } else {
+                xo = (2 * (s >> 2) * WG_XROW + 4 * (s & 3)) * 32;
+                yo = (2 * (s >> 2) * WG_YROW + 4 * (s & 3)) * 64;
+            }
             f32x2 R[4];
 #if DBN_WWG_EXP == 2
             for (int q = 0; q < 4; ++q) { R[q][0] = rx[q][0]; R[q][1] = rx[q][1]; }
-            const float d00 = ry[0][0], d01 = ry[0][1], d10 = ry[1][0], d11 = ry[1][1];
+            const float d00 = rx[0][0], d01 = rx[0][1], d10 = rx[1][0], d11 = rx[1][1];
 #else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -133,20 +245,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 R[q][0] = fmaf(sa, u2[0], u1[0]);  // (sa = +-1: exact)
                 R[q][1] = fmaf(sa, u2[1], u1[1]);
             }
-            const float d00 = Yb[yo], d01 = Yb[yo + 64], d10 = Yb[yo + WG_YROW * 64], d11 = Yb[yo + WG_YROW * 64 + 64];
+            const float d00 = Yb[yo], d01 = Yb[yo + 64], d10 = Yb[yo + yrow * 64], d11 = Yb[yo + yrow * 64 + 64];
 #endif
             const f32x2 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
-            const float r0 = fmaf(c1, d10, c0 * d00), r1 = fmaf(c1, d11, c0 * d01);
+            const float r0 = fmaf(c1s, d10, c0s * d00), r1 = fmaf(c1s, d11, c0s * d01);
             const float D[4] = {r0, r0 + r1, r0 - r1, -r1};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[j], V[j][h], acc[j][h], 0, 0, 0);
         }
-        if (g + 1 < g1 && DBN_WWG_EXP != 1) {
-            __syncthreads();  // every wave has read this patch
-            store_group();
-            __syncthreads();
+        if constexpr (!LIN) {
+            if (g + 1 < g1 && DBN_WWG_EXP != 1) {
+                __syncthreads();  // every wave has read this patch
+                store_group();
+                __syncthreads();
+            }
         }
     }
     // ---- partial sums -> slab [split][sub][point][o][i]: accumulator row (r & 3) + 8 (r >> 2) + 4 lh = output channel within this wave's
@@ -203,6 +317,31 @@ int wwg_splits(int groups, int nsub) {
     return std::min(ns, groups);
 }
 
+// LIN form (consecutive tiles, full-width band): 32 tiles span at most (30 + TW) / TW + 1 tile rows; the band must fit the LDS images
+bool wwg_linear_fits(int H, int W) {
+    const int TW = (W + 1) / 2, TH = (H + 1) / 2;
+    const int R = std::min(TH, (30 + TW) / TW + 1);
+    return (2 * R + 2) * (2 * TW + 2) <= WL_XPX && 2 * R * 2 * TW <= WL_YPX;
+}
+// share of real tiles among the tile slots of the two forms
+double wwg_fill(int H, int W, bool lin) {
+    if (lin) {
+        const long TI = (long)((H + 1) / 2) * ((W + 1) / 2);
+        return (double)TI / (double)((TI + 31) / 32 * 32);
+    }
+    return (double)H * W / ((double)((H + 7) / 8 * 8) * ((W + 15) / 16 * 16));
+}
+bool wwg_linear(int H, int W) {
+    static const int env = dbn_env_int("DBN_WWG_LIN", 1);  // 0: patch form everywhere (A/B runs)
+    // the band is staged without prefetch (~4 us per group unhidden): measured 16 x 20 x 20 x 512 -> 512: 246 -> 222 us, but 16 x 40 x 40 x
+    // 256 -> 256 (83 % patch fill): 160 -> 188 us — only where the patch form wastes much more
+    return env && wwg_linear_fits(H, W) && wwg_fill(H, W, true) > wwg_fill(H, W, false) + 0.2;
+}
+int wwg_groups(int N, int H, int W) {
+    if (wwg_linear(H, W)) return N * (int)(((long)((H + 1) / 2) * ((W + 1) / 2) + 31) / 32);
+    return N * ((H + 7) / 8) * ((W + 15) / 16);
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,23 +351,27 @@ int dbn_winograd_wgrad_eligible(int N, int H, int W, int O, int Cb, int I) {
     if (N < 1 || H < 1 || W < 1 || O % 64 || Cb % 64 || I < 1 || I > Cb) return 0;
     const long px = (long)N * H * W;
     if (px * std::max(O, Cb) * 4 >= dbn_g_byte_limit) return 0;
-    const long Hp = (H + 7) / 8 * 8, Wp = (W + 15) / 16 * 16;
-    return 2L * H * W >= Hp * Wp;  // at least half of the patches' tiles are real (the transform's 2.25x pays from 45 %)
+    return wwg_fill(H, W, wwg_linear(H, W)) >= 0.5;  // at least half of the tile slots are real (the transform's 2.25x pays from 45 %)
 }
+// 1: the layer runs in the consecutive-tile form (winograd_wgrad_f32_kernel<true> in a trace)
+int dbn_winograd_wgrad_linear(int H, int W) { return wwg_linear(H, W); }
 long dbn_winograd_wgrad_slab_floats(int N, int H, int W, int O, int Cb) {
-    const int groups = N * ((H + 7) / 8) * ((W + 15) / 16), nsub = (O / 64) * (Cb / 64);
-    return (long)wwg_splits(groups, nsub) * nsub * 16 * 4096;
+    const int nsub = (O / 64) * (Cb / 64);
+    return (long)wwg_splits(wwg_groups(N, H, W), nsub) * nsub * 16 * 4096;
 }
 // dg [O][I][3][3] = scale * the weight gradient of the conv with input x [N][H][W][Cb] (channels >= I: padding) and output gradient
-// dy [N][H][W][O].  phases: 1 = the matrix kernel (-> slab), 2 = the reduction (slab -> grad), 3 = both.
-int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, float* slab, float* grad, int N, int H, int W, int O, int Cb, int I,
-                           float scale, void* stream) {
-    DBN_REQUIRE(dy && x && slab && grad && phases >= 1 && phases <= 3);
+// dy [N][H][W][O].  x_scale / x_shift non-NULL ([Cb] each): the conv's input is relu(x * x_scale[c] + x_shift[c]) — x is the input of the
+// BatchNorm + ReLU in front of the conv, whose output was never written (see dbn_winograd_conv_bn_act_f32).  phases: 1 = the matrix kernel (-> slab), 2 = the reduction (slab -> grad), 3 = both.
+int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, const float* x_scale, const float* x_shift, float* slab, float* grad,
+                           int N, int H, int W, int O, int Cb, int I, float scale, void* stream) {
+    DBN_REQUIRE(dy && x && slab && grad && phases >= 1 && phases <= 3 && !x_scale == !x_shift);
     DBN_REQUIRE(dbn_winograd_wgrad_eligible(N, H, W, O, Cb, I));
     WinoWgradParams p;
     p.x = x;
     p.dy = dy;
     p.slab = slab;
+    p.x_scale = x_scale;
+    p.x_shift = x_shift;
     p.N = N;
     p.H = H;
     p.W = W;
@@ -236,14 +379,19 @@ int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, float* s
     p.Cy = O;
     p.nob = O / 64;
     p.nib = Cb / 64;
+    const bool lin = wwg_linear(H, W);
     p.tw = (W + 15) / 16;
-    p.gpi = ((H + 7) / 8) * p.tw;
-    p.groups = N * p.gpi;
+    p.groups = wwg_groups(N, H, W);
+    p.gpi = p.groups / N;
     p.nsplit = wwg_splits(p.groups, p.nob * p.nib);
     p.x_bytes = (unsigned)((long)N * H * W * Cb * 4);
     p.dy_bytes = (unsigned)((long)N * H * W * O * 4);
     hipStream_t st = (hipStream_t)stream;
-    if (phases & 1) hipLaunchKernelGGL(winograd_wgrad_f32_kernel, dim3(p.nsplit * p.nob * p.nib), dim3(512), 0, st, p);
+    if (phases & 1) {
+        const dim3 grid(p.nsplit * p.nob * p.nib);
+        if (lin) hipLaunchKernelGGL(winograd_wgrad_f32_kernel<true>, grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(winograd_wgrad_f32_kernel<false>, grid, dim3(512), 0, st, p);
+    }
     if (phases & 2)
         hipLaunchKernelGGL(winograd_wgrad_reduce_kernel, dim3(O, p.nib), dim3(1024), 0, st, slab, p.nsplit, p.nob * p.nib, p.nib, I, grad, scale);
     return dbn_status();

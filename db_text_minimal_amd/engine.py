@@ -558,40 +558,44 @@ class Engine:
         self.packs[key] = (out, stamp)
         return out
 
-    def _winograd_conv(self, name, x, conv, y, bn=None, bn_name=None):
+    def _winograd_conv(self, name, x, conv, y, bn=None, bn_name=None, x_act=None):
+        """x_act = (scale, shift): the conv's input is relu(x * scale + shift), applied while the kernel stages its patches (x is the
+        INPUT of the BatchNorm + ReLU in front of the conv; apply_on_load)."""
         N, H, W, C = x.shape
         up = self._winograd_panel(name, conv.weight, C)
+        asc, ash = (x_act[0].data_ptr(), x_act[1].data_ptr()) if x_act is not None else (None, None)
         if self.prof:
             # FLOPs the MFMA pipe EXECUTES: 16 products per 2 x 2 output tile and channel pair (the direct form's 36 are what
             # `step_tflops` counts): the roofline fraction of this kernel is matrix-pipe utilisation, not an effective rate
             self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 0.0, 'fwd ' + name)
         if bn is None:
-            check(self.L.dbn_winograd_conv_bn_f32(x.data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, conv.cout, None, None,
-                                                  0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
+            check(self.L.dbn_winograd_conv_bn_act_f32(x.data_ptr(), asc, ash, up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, conv.cout,
+                                                      None, None, 0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
             sc = sh = None
         else:
             Co = conv.cout
             sc, sh = self.fbuf(bn_name + '/scale', Co), self.fbuf(bn_name + '/shift', Co)
             mu, rs = self.fbuf(bn_name + '/mean', Co), self.fbuf(bn_name + '/rstd', Co)
             ws = self.scratch('_conv_bn_ws', self.L.dbn_winograd_ws_floats(N, H, W, Co))
-            check(self.L.dbn_winograd_conv_bn_f32(x.data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Co, bn.weight.data_ptr(),
-                                                  bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(),
-                                                  bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(),
-                                                  ws.data_ptr(), self.stream), 'winograd+bn ' + name)
+            check(self.L.dbn_winograd_conv_bn_act_f32(x.data_ptr(), asc, ash, up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Co,
+                                                      bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
+                                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                                      mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), 'winograd+bn ' + name)
             self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
         if self.prof:
             self.prof.end()
         return sc, sh
 
-    def conv_fwd(self, name, x, conv, out_name, version=None):
+    def conv_fwd(self, name, x, conv, out_name, version=None, x_act=None):
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
         if version is None and self._winograd_ok(x, conv):
             y = self.buf(out_name, N, Ho, Wo, conv.cout)
-            self._winograd_conv(name, x, conv, y)
+            self._winograd_conv(name, x, conv, y, x_act=x_act)
             return y
+        assert x_act is None, name  # (only the Winograd kernel applies an activation on load: lazy_act() checks before it defers)
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
@@ -620,21 +624,23 @@ class Engine:
         self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
         return sc, sh
 
-    def conv_bn(self, name, x, conv, out_name, bn_name, bn, train, version=None):
+    def conv_bn(self, name, x, conv, out_name, bn_name, bn, train, version=None, x_act=None):
         """conv -> BatchNorm coefficients.  Train mode: one fused call (statistics in the conv epilogue)."""
         N, H, W, C = x.shape
         k, s, p = conv.k, conv.stride, conv.padding
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        wino = version is None and self._winograd_ok(x, conv)
         split = self.splitk and self.L.dbn_igemm_splitk_plan_ns(N * Ho * Wo, conv.cout, k * k * C, C, self.ns) > 1
         if not (train and self.fuse_bn_stats) or split:  # split-K convs take their statistics in a (small) separate pass
-            y = self.conv_fwd(name, x, conv, out_name, version=version)
+            y = self.conv_fwd(name, x, conv, out_name, version=version, x_act=x_act)
             sc, sh = self.bn_coef(bn_name, bn, y, train)
             return y, sc, sh
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
-        if version is None and self._winograd_ok(x, conv):
+        if wino:
             y = self.buf(out_name, N, Ho, Wo, conv.cout)
-            sc, sh = self._winograd_conv(name, x, conv, y, bn, bn_name)
+            sc, sh = self._winograd_conv(name, x, conv, y, bn, bn_name, x_act=x_act)
             return y, sc, sh
+        assert x_act is None, name
         wpk = self.pack(name, conv.weight, 0, version=version, cs=C)
         y = self.buf(out_name, N, Ho, Wo, conv.cout)
         if self.prof:
@@ -771,7 +777,7 @@ class Engine:
     defer_wgrad_reduce = os.environ.get('DBN_DEFER_REDUCE', '0') == '1'
     winograd_wgrad = os.environ.get('DBN_WINOGRAD_WGRAD', '1') == '1'  # (A/B switch; off: the direct kernels of wgrad_kernels.h)
 
-    def wgrad(self, name, sm, big, O, I, k, stride, pad, gview, defer=False):
+    def wgrad(self, name, sm, big, O, I, k, stride, pad, gview, defer=False, big_act=None):
         """defer: the gradient is only needed by the optimizer / the gradient exchange, so its slab reduction may wait for
         flush_wgrad_reduces() (conv_wgrad, convT_bwd); False: a kernel of this pass reads gview next (FPN level scatter, DCN)."""
         N, Ho, Wo, _ = sm.shape
@@ -781,7 +787,8 @@ class Engine:
                 and self.L.dbn_winograd_wgrad_eligible(N, H, W, O, Cb, I)):
             # 3x3 / stride 1 in exact fp32: Winograd F(2x2,3x3) over the tiles (csrc/winograd_wgrad_f32.hip), 2.25x fewer matrix FLOPs
             slab = self.scratch('_wgrad_slab', self.L.dbn_winograd_wgrad_slab_floats(N, H, W, O, Cb))
-            wargs = (sm.data_ptr(), big.data_ptr(), slab.data_ptr(), gview.data_ptr(), N, H, W, O, Cb, I, self.grad_scale, self.stream)
+            asc, ash = (big_act[0].data_ptr(), big_act[1].data_ptr()) if big_act is not None else (None, None)
+            wargs = (sm.data_ptr(), big.data_ptr(), asc, ash, slab.data_ptr(), gview.data_ptr(), N, H, W, O, Cb, I, self.grad_scale, self.stream)
             if self.prof:  # (FLOPs the matrix pipe executes: 16 products per tile and channel pair; see _winograd_conv)
                 self.prof.begin('winograd_wgrad_f32_kernel', 2.0 * N * ((H + 1) // 2) * ((W + 1) // 2) * 16 * O * Cb, 0.0, 'wgrad ' + name)
                 check(self.L.dbn_winograd_wgrad_f32(1, *wargs), 'winograd wgrad ' + name)
@@ -792,6 +799,7 @@ class Engine:
             else:
                 check(self.L.dbn_winograd_wgrad_f32(3, *wargs), 'winograd wgrad ' + name)
             return
+        assert big_act is None, name  # (lazy_act() defers an activation only where this branch is taken)
         # reductions on their own stream (see reduce_stream): only for gradients no kernel of this pass reads, on the side stream
         async_reduce = (defer and self.reduce_stream and self._in_side and self.prof is None and not self.defer_wgrad_reduce
                         and not torch.cuda.is_current_stream_capturing())
@@ -901,12 +909,13 @@ class Engine:
             for fn in fifo:
                 fn()
 
-    def conv_wgrad(self, name, dy, x, conv):
+    def conv_wgrad(self, name, dy, x, conv, x_act=None):
         self._presplit(dy, x)
 
         def launch():
             with self.side_stream():
-                self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True)
+                self.wgrad(name, dy, x, conv.cout, conv.cin, conv.k, conv.stride, conv.padding, self.grad_views[name + '.weight'], defer=True,
+                           big_act=x_act)
                 if conv.bias is not None and name + '.bias' not in self._bias_done:
                     self.col_sum(dy, self.grad_views[name + '.bias'])
         late = self.late_wgrad == '1' or (self.late_wgrad == '' and self.at != 0)
@@ -982,6 +991,25 @@ class Engine:
         if self.prof:
             self.prof.end()
         return out
+
+    # Apply-on-load BatchNorm + ReLU (basic.py:32-36, resnet.py:77-80): where every consumer of relu(bn(y)) is a Winograd conv (forward and
+    # weight gradient) the activation tensor is never written — the kernels apply relu(fma(y, scale, shift)) while they stage their
+    # patches, with bn_apply's own arithmetic (bit-identical results).  Exact-fp32 mode only (the 16-bit kernels bring their tiles to
+    # LDS by DMA: nothing passes through registers).  The BatchNorm backward takes its ReLU mask from y already (mask 'self').
+    apply_on_load = os.environ.get('DBN_APPLY_ON_LOAD', '1') == '1'
+
+    def lazy_act(self, y, convs, train):
+        """True when relu(bn(y)) may stay unwritten: every conv in `convs` (all read it as their input) runs as a Winograd conv forward
+        and — in training — takes its weight gradient through the Winograd kernel too."""
+        if not (self.apply_on_load and self.winograd and self.at == 0 and self.ns == 0 and not self._use_planes):
+            return False
+        N, H, W, C = y.shape
+        for conv in convs:
+            if getattr(conv, 'with_dcn', False) or not self._winograd_ok(y, conv):
+                return False
+            if train and not (self.winograd_wgrad and self.L.dbn_winograd_wgrad_eligible(N, H, W, conv.cout, C, conv.cin)):
+                return False
+        return True
 
     bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
 
@@ -1106,13 +1134,18 @@ class Engine:
             for i, t in enumerate(zs):
                 self.up_fwd(t, None, cat, coff=64 * i)
             fy, s_, h_ = self.conv_bn(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
-        f = self.bn_apply(fy, s_, h_, 'fpn/z')
         head = m.segmentation_head
+        f_act = None
+        if self.lazy_act(fy, (head.binarize[0], head.thresh[0]), train):
+            self.bufs.pop('fpn/z', None)  # (never written: the two head convs and their weight gradients read fpn/y through its BatchNorm's coefficients)
+            f, f_act = fy, (s_, h_)
+        else:
+            f = self.bn_apply(fy, s_, h_, 'fpn/z')
         z1 = {}
         def branch(br):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train)
+            ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train, x_act=f_act)
             za = self.bn_apply(ya, s_, h_, br + '/z0')
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
@@ -1237,8 +1270,12 @@ class Engine:
     def _block_fwd(self, name, blk, x, train):
         """BasicBlock (resnet.py:70-91) or Bottleneck (resnet.py:135-159)."""
         y1, s1, h1 = self.conv_bn(name + '.conv1', x, blk.conv1, name + '/y1', name + '.bn1', blk.bn1, train)
-        z1 = self.bn_apply(y1, s1, h1, name + '/z1')
-        y2, s2, h2 = self._conv2_bn(name, blk, z1, train)
+        if not getattr(blk, 'with_dcn', False) and self.lazy_act(y1, (blk.conv2, ), train):
+            self.bufs.pop(name + '/z1', None)  # (never written: conv2 and its weight gradient read y1 through bn1's coefficients)
+            y2, s2, h2 = self.conv_bn(name + '.conv2', y1, blk.conv2, name + '/y2', name + '.bn2', blk.bn2, train, x_act=(s1, h1))
+        else:
+            z1 = self.bn_apply(y1, s1, h1, name + '/z1')
+            y2, s2, h2 = self._conv2_bn(name, blk, z1, train)
         if hasattr(blk, 'conv3'):
             z2 = self.bn_apply(y2, s2, h2, name + '/z2')
             ylast, s2, h2 = self.conv_bn(name + '.conv3', z2, blk.conv3, name + '/y3', name + '.bn3', blk.bn3, train)
@@ -1293,7 +1330,9 @@ class Engine:
                                   self.grad_scale, ws.data_ptr(), st), 'head_tail_bwd')
         if self.prof:
             self.prof.end()
-        f = B['fpn/z']
+        f, f_act = B.get('fpn/z'), None
+        if f is None:  # apply-on-load (see forward)
+            f, f_act = B['fpn/y'], (B['segmentation_body.conv.1/scale'], B['segmentation_body.conv.1/shift'])
         df = self.buf('fpn/dz', *f.shape)
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
@@ -1308,7 +1347,7 @@ class Engine:
             self.convT_bwd(hp + '3', dy1, B[br + '/z0'], seq[3], dz0, consumer=(hp + '1', B[br + '/y0'], None))
             dy0 = self.bn_backward(hp + '1', B[br + '/y0'], 'self', dz0, br + '/dy0',
                                    conv_bias=hp + '0.bias' if seq[0].bias is not None else None)
-            self.conv_wgrad(hp + '0', dy0, f, seq[0])
+            self.conv_wgrad(hp + '0', dy0, f, seq[0], x_act=f_act)
             # (the second branch's data gradient is the last writer of df: it carries the sums of the FPN output BatchNorm)
             self.conv_dgrad(hp + '0', dy0, seq[0], df, accumulate=(i > 0),
                             consumer=(pre + 'conv.1', B['fpn/y'], None) if i > 0 else None)
@@ -1541,9 +1580,15 @@ class Engine:
             dy2 = self.bn_backward(name + '.bn2', B[name + '/y2'], 'self', dz2, name + '/dy2')
         else:
             dy2 = dyl
-        z1 = B[name + '/z1']
-        dz1 = self.buf(name + '/dz1', *z1.shape)
-        self._conv2_bwd(name, blk, dy2, z1, dz1)
+        z1 = B.get(name + '/z1')
+        if z1 is None:  # apply-on-load: conv2 read y1 through bn1's coefficients (see _block_fwd)
+            y1 = B[name + '/y1']
+            dz1 = self.buf(name + '/dz1', *y1.shape)
+            self.conv_wgrad(name + '.conv2', dy2, y1, blk.conv2, x_act=(B[name + '.bn1/scale'], B[name + '.bn1/shift']))
+            self.conv_dgrad(name + '.conv2', dy2, blk.conv2, dz1, False, consumer=(name + '.bn1', y1, None))
+        else:
+            dz1 = self.buf(name + '/dz1', *z1.shape)
+            self._conv2_bwd(name, blk, dy2, z1, dz1)
         dy1 = self.bn_backward(name + '.bn1', B[name + '/y1'], 'self', dz1, name + '/dy1')
         self.conv_wgrad(name + '.conv1', dy1, xin, blk.conv1)
         if has_down:

@@ -258,6 +258,13 @@ int dbn_winograd_dgrad_bnsums_f32(const float* dy, const float* upanel, float* d
                                   const float* save_mean, const float* save_rstd, float* part, const void* y2, const float* save_mean2,
                                   const float* save_rstd2, float* part2, const dbn_bnb_final* fin, void* stream);
 long dbn_winograd_ws_floats(int N, int H, int W, int Cd);
+/* ... with the BatchNorm + ReLU in FRONT of the conv applied on load (basic.py:32-36, resnet.py:77-80): the conv's input is
+ * relu(src * in_scale[c] + in_shift[c]) ([Cs] floats each, the coefficients of dbn_bn_apply; both NULL: src itself).  src is that
+ * BatchNorm's input; its output tensor is never written.  Bit-identical to dbn_bn_apply followed by dbn_winograd_conv_bn_f32. */
+int dbn_winograd_conv_bn_act_f32(const float* src, const float* in_scale, const float* in_shift, const float* upanel, const float* bias,
+                                 float* dst, int N, int H, int W, int Cs, int Cd, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean,
+                                 float* save_rstd, float* ws, void* stream);
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                              float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
@@ -266,11 +273,13 @@ int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float*
  * (csrc/winograd_wgrad_f32.hip; replaces torch.autograd's conv weight gradient for resnet.py:70-91, segmentation_body.py:55-61,
  * segmentation_head.py:24-25,64-68).  x [N][H][W][Cb] (channels >= I are zero padding), dy [N][H][W][O], grad [O][I][3][3] =
  * scale * dW (overwritten).  slab: dbn_winograd_wgrad_slab_floats floats of scratch.  phases: 1 = matrix kernel (-> slab),
- * 2 = slab reduction + G^T . G (-> grad), 3 = both.  Deterministic (fixed-order fp64 reduction, no atomics). */
+ * 2 = slab reduction + G^T . G (-> grad), 3 = both.  Deterministic (fixed-order fp64 reduction, no atomics).  x_scale / x_shift
+ * non-NULL ([Cb] each): the conv's input is relu(x * x_scale[c] + x_shift[c]), applied on load (see dbn_winograd_conv_bn_act_f32). */
 int dbn_winograd_wgrad_eligible(int N, int H, int W, int O, int Cb, int I);
+int dbn_winograd_wgrad_linear(int H, int W); /* 1: small map, consecutive-tile form (kernel <true> in a trace) */
 long dbn_winograd_wgrad_slab_floats(int N, int H, int W, int O, int Cb);
-int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, float* slab, float* grad, int N, int H, int W, int O, int Cb, int I,
-                           float scale, void* stream);
+int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, const float* x_scale, const float* x_shift, float* slab, float* grad,
+                           int N, int H, int W, int O, int Cb, int I, float scale, void* stream);
 
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W].
  * One launch: the workgroup that finishes last folds every workgroup's partial sums (fixed order) and writes losses[5] and

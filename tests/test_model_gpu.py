@@ -925,3 +925,36 @@ def test_grouped_slab_reduction_is_bit_identical_to_per_layer_launches(math, arc
         outs.append((model.engine.flat_grad.clone(), model.engine.flat.clone()))
     assert float(outs[0][0].abs().max()) > 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size,train', [((160, 160), True), ((96, 70), True), ((128, 160), False)])
+def test_apply_on_load_batchnorm_relu_is_bit_identical(size, train):
+    """engine.apply_on_load (exact-fp32 mode): the BatchNorm + ReLU in front of a Winograd conv (bn1 of every BasicBlock,
+    resnet.py:77-80; the FPN output's BatchNorm, segmentation_body.py:60-61 -> segmentation_head.py:24-25,64-68) is applied while the
+    conv and its weight-gradient kernel stage their patches — the activation tensor ('/z1', 'fpn/z') is never written.  Same
+    arithmetic as bn_apply: predictions, losses, gradients and parameters after two steps must equal the materialised form bit for bit
+    (odd sizes: ragged patches and the consecutive-tile form of the small maps)."""
+    seed = 9
+    img, gts = O.synthetic_batch(2, size, seed=seed)
+    img, gts = img.to(DEV), gts.to(DEV)
+    outs = []
+    for on in (False, True):
+        model = make_model(seed, 'resnet18')
+        model.engine.apply_on_load = on
+        if train:
+            model.train()
+            tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+            for _ in range(2):
+                preds, losses = tr.step(img, gts)
+            torch.cuda.synchronize()
+            outs.append((preds.clone(), losses.clone(), model.engine.flat_grad.clone(), model.engine.flat.clone()))
+        else:
+            model.eval()
+            with torch.no_grad():
+                outs.append((model(img).clone(), ))
+        written = sorted(k for k in model.engine.bufs if k.endswith('/z1') or k == 'fpn/z')
+        # (off: the 8 blocks' z1 and fpn/z exist; on: none of the maps the Winograd kernels take — the smallest maps of a small input stay direct)
+        assert (len(written) == 9) if not on else ('backbone.layer1.0/z1' not in written and 'fpn/z' not in written), written
+    for a, b in zip(*outs):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b)

@@ -1710,7 +1710,9 @@ def test_winograd_dgrad_with_bn_sums(N, Ci, Co, H, W, mask, accumulate):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('N,Ci,Cs,Co,H,W', [(2, 64, 64, 64, 16, 32), (1, 64, 64, 128, 20, 20), (2, 128, 128, 64, 9, 29), (1, 40, 64, 64, 8, 16),
-                                            (3, 256, 256, 64, 24, 40), (1, 128, 128, 128, 40, 40), (5, 64, 64, 64, 13, 30), (2, 64, 64, 64, 64, 64)])
+                                            (3, 256, 256, 64, 24, 40), (1, 128, 128, 128, 40, 40), (5, 64, 64, 64, 13, 30), (2, 64, 64, 64, 64, 64),
+                                            # consecutive-tile form (small maps): layer4 / layer3 shapes, odd sizes, one partial group
+                                            (3, 64, 64, 64, 20, 20), (2, 128, 128, 64, 25, 25), (4, 64, 64, 128, 13, 13), (1, 64, 64, 64, 10, 9), (2, 64, 64, 64, 40, 36)])
 def test_winograd_weight_gradient(N, Ci, Cs, Co, H, W):
     """dbn_winograd_wgrad_f32: weight gradient of a 3x3 / stride 1 / pad 1 conv through Winograd F(2x2, 3x3) over the tiles in fp32
     (torch.autograd's conv weight gradient of resnet.py:70-91, segmentation_body.py:55-61, segmentation_head.py:24-25) against
@@ -1726,15 +1728,57 @@ def test_winograd_weight_gradient(N, Ci, Cs, Co, H, W):
     assert L().dbn_winograd_wgrad_eligible(N, H, W, Co, Cs, Ci)
     slab = torch.full((L().dbn_winograd_wgrad_slab_floats(N, H, W, Co, Cs), ), float('nan'), device=DEV)
     g = torch.full((Co, Ci, 3, 3), float('nan'), device=DEV)
-    args = (dys.data_ptr(), xs.data_ptr(), slab.data_ptr(), g.data_ptr(), N, H, W, Co, Cs, Ci)
+    args = (dys.data_ptr(), xs.data_ptr(), None, None, slab.data_ptr(), g.data_ptr(), N, H, W, Co, Cs, Ci)
     _lib.check(L().dbn_winograd_wgrad_f32(3, *args, 0.5, stream()), 'winograd wgrad')
     scale = float(ref.abs().max())
     report('winograd wgrad', g.cpu(), 0.5 * ref, 4e-6 * 0.5 * scale, 4e-6)
     g2 = torch.full_like(g, float('nan'))
     slab.fill_(float('nan'))
-    _lib.check(L().dbn_winograd_wgrad_f32(1, *args[:3], g2.data_ptr(), *args[4:], 0.5, stream()), 'winograd wgrad phase 1')
-    _lib.check(L().dbn_winograd_wgrad_f32(2, *args[:3], g2.data_ptr(), *args[4:], 0.5, stream()), 'winograd wgrad phase 2')
+    _lib.check(L().dbn_winograd_wgrad_f32(1, *args[:5], g2.data_ptr(), *args[6:], 0.5, stream()), 'winograd wgrad phase 1')
+    _lib.check(L().dbn_winograd_wgrad_f32(2, *args[:5], g2.data_ptr(), *args[6:], 0.5, stream()), 'winograd wgrad phase 2')
     torch.cuda.synchronize()
     assert torch.equal(g, g2)
     gd = wgrad(dys, xs, Co, Ci, 3, 1, 1, scale=0.5)
     report('winograd wgrad vs the direct kernel', g.cpu(), gd.cpu(), 5e-6 * 0.5 * scale, 5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,C,Co,H,W', [(2, 64, 64, 16, 32), (1, 128, 64, 20, 20), (2, 64, 128, 13, 30), (1, 256, 64, 40, 40), (3, 64, 64, 25, 25)])
+def test_winograd_apply_on_load_equals_bn_apply_then_conv(N, C, Co, H, W):
+    """dbn_winograd_conv_bn_act_f32 / dbn_winograd_wgrad_f32(x_scale, x_shift): the BatchNorm + ReLU in front of the conv applied while
+    the kernels stage their patches (basic.py:32-36) against dbn_bn_apply followed by the same kernels on the written activation —
+    bit for bit (the same fma + max), forward with folded BatchNorm statistics and weight gradient, patch and consecutive-tile
+    forms, ragged maps (pixels outside the map are zero padding of the ACTIVATION, not relu(shift))."""
+    y = rnd(N, H, W, C, seed=1).to(DEV)
+    sc, sh = (rnd(C, seed=2) * 0.5 + 1).to(DEV), rnd(C, seed=3).to(DEV)
+    z = torch.full_like(y, float('nan'))
+    _lib.check(L().dbn_bn_apply_t(0, y.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, None, None, z.data_ptr(), N * H * W, C, 1, stream()), 'bn apply')
+    w = rnd(Co, C, 3, 3, seed=4, scale=(2.0 / (C * 9))**0.5).to(DEV)
+    up = torch.empty(L().dbn_winograd_panel_floats(Co, C), device=DEV)
+    _lib.check(L().dbn_winograd_pack(w.data_ptr(), Co, C, C, 0, up.data_ptr(), stream()), 'pack')
+    assert L().dbn_winograd_eligible(N, H, W, C, Co)
+    res = []
+    for src, a, b in ((z, None, None), (y, sc.data_ptr(), sh.data_ptr())):
+        out = torch.full((N, H, W, Co), float('nan'), device=DEV)
+        gamma, beta = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        o4 = [torch.full((Co, ), float('nan'), device=DEV) for _ in range(4)]
+        ws = torch.empty(L().dbn_winograd_ws_floats(N, H, W, Co), device=DEV)
+        _lib.check(L().dbn_winograd_conv_bn_act_f32(src.data_ptr(), a, b, up.data_ptr(), None, out.data_ptr(), N, H, W, C, Co, gamma.data_ptr(),
+                                                    beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), *[t.data_ptr() for t in o4],
+                                                    ws.data_ptr(), stream()), 'winograd act')
+        res.append([out] + o4 + [rm, rv])
+    if L().dbn_winograd_wgrad_eligible(N, H, W, Co, C, C):
+        dy = rnd(N, H, W, Co, seed=5).to(DEV)
+        for i, (src, a, b) in enumerate(((z, None, None), (y, sc.data_ptr(), sh.data_ptr()))):
+            slab = torch.empty(L().dbn_winograd_wgrad_slab_floats(N, H, W, Co, C), device=DEV)
+            g = torch.full((Co, C, 3, 3), float('nan'), device=DEV)
+            _lib.check(L().dbn_winograd_wgrad_f32(3, dy.data_ptr(), src.data_ptr(), a, b, slab.data_ptr(), g.data_ptr(), N, H, W, Co, C, C, 1.0,
+                                                  stream()), 'winograd wgrad act')
+            res[i].append(g)
+    torch.cuda.synchronize()
+    assert len(res[0]) == len(res[1])
+    for t0, t1 in zip(*res):
+        assert bool(torch.isfinite(t0).all()) and torch.equal(t0, t1)
+    # and the activation really matters (relu(shift) != 0 at the padding would show here)
+    assert float((z - y).abs().max()) > 0.1

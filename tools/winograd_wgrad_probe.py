@@ -26,7 +26,7 @@ for (N, H, Ci, Co, what) in ((16, 160, 64, 64, 'layer1 / smooth_p2'), (16, 160, 
     dy = torch.randn(N, H, H, Co, device=DEV)
     g = torch.empty(Co, Ci, 3, 3, device=DEV)
     slab = torch.empty(L().dbn_winograd_wgrad_slab_floats(N, H, H, Co, Ci), device=DEV)
-    a = (dy.data_ptr(), x.data_ptr(), slab.data_ptr(), g.data_ptr(), N, H, H, Co, Ci, Ci, 1.0, stream())
+    a = (dy.data_ptr(), x.data_ptr(), None, None, slab.data_ptr(), g.data_ptr(), N, H, H, Co, Ci, Ci, 1.0, stream())
     t1 = timed(lambda: _lib.check(L().dbn_winograd_wgrad_f32(1, *a), 'w1'))
     t2 = timed(lambda: _lib.check(L().dbn_winograd_wgrad_f32(2, *a), 'w2'))
     gw = g.clone()
