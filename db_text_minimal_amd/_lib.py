@@ -85,6 +85,7 @@ SIGNATURES.update({
     'dbn_igemm_t': 'ii' + 'pppp' + 'i' * 14 + 'i' + 'p' + 'p',
     'dbn_conv_bn_t': 'i' + SIGNATURES['dbn_conv_bn_f32'],
     'dbn_pyramid_conv_t': 'i' + SIGNATURES['dbn_pyramid_conv_f32'],
+    'dbn_pyramid_conv_from_t': 'ii' + SIGNATURES['dbn_pyramid_conv_f32'],
     'dbn_igemm_bn_rows': 'i' * 15,
     'dbn_igemm_bnsums_t': 'ii' + 'pppp' + 'i' * 14 + 'ppppppp' + 'pppp' + 'p' + 'p',
     'dbn_igemm_bn_final_counters': 'ii',

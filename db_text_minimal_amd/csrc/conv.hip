@@ -635,10 +635,15 @@ static int pyramid_rows_one(int n, int H, int W) { return 64 * dbn_ceil_div((lon
 
 long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * N * pyramid_rows_one(1, H, W); }
 
-int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,
-                       const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
-                       int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
-                       float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+// first_level = 1 (exact fp32 only): dst already holds level 0's part of the sum (the plain 3x3 conv of s0, bias included — e.g. from
+// dbn_winograd_conv_bn_f32); the launch adds levels 1-3 to it (s0, w0, bias are not read).
+int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
+                            const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,
+                            int Cd, int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum,
+                            float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws,
+                            void* stream) {
+    DBN_REQUIRE(first_level == 0 || (first_level == 1 && at == 0 && ns == 0));
+    if (first_level) { s0 = s1; w0 = w1; bias = nullptr; }
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1) || (at == 3 && ns == 3));
     const int es = dbn_esize(at), des = dst_esize(at);
@@ -667,7 +672,8 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
         p.plane_bytes = p.seg_plane_bytes[0];
         p.src = p.seg_src[0]; p.wpk = w0; p.bias = bias; p.dst = (char*)dst + (long)n0 * H * W * Cd * des;
         p.N = n; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W;
-        p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = 0; p.ncls = 64;
+        p.R = 3; p.S = 3; p.stride = 8; p.pad = 1; p.accumulate = first_level ? 1 : 0; p.ncls = 64;
+        p.first_level = first_level;
         p.bnb_y = p.bnb_zmask = p.bnb_y2 = nullptr; p.bnb_msc = p.bnb_msh = p.bnb_mean = p.bnb_rstd = p.bnb_mean2 = p.bnb_rstd2 = nullptr;
         p.bnb_part = p.bnb_part2 = nullptr;
         p.bnb_cnt = nullptr; p.bnb_grp = nullptr; p.bnb_gscale = 1.f; p.bnb_invM = 0.f;
@@ -684,6 +690,14 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows_total >= 2048 ? 1024 : 256), 0, st, ws, rows_total, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
+}
+
+int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,
+                       const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
+                       int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                       float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
+    return dbn_pyramid_conv_from_t(0, at, s0, s1, s2, s3, w0, w1, w2, w3, bias, dst, N, H, W, Cs, Cd, tile_hint, ns, gamma, beta, eps, momentum,
+                                   run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream);
 }
 
 int dbn_pyramid_conv_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* w0, const float* w1,

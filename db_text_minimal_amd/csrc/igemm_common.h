@@ -119,6 +119,7 @@ struct IgemmParams {
     // winograd_f32_kernel only: src is the INPUT of a BatchNorm + ReLU whose output the conv consumes; relu(fma(src, in_scale[c],
     // in_shift[c])) is applied while the patch is staged (the activation tensor is never written; same arithmetic as bn_apply_kernel)
     const float *in_scale, *in_shift;
+    int first_level;  // MODE 3, exact-fp32 loop only: levels [first_level, 4) (the finer ones are in dst already: accumulate = 1)
 };
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger

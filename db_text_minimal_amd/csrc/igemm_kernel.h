@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     __syncthreads();
     }
     } else {
-    for (int level = 0; level < (MODE == 3 ? 4 : 1); ++level) {
+    for (int level = (MODE == 3 ? p.first_level : 0); level < (MODE == 3 ? 4 : 1); ++level) {
     if (MODE == 3) {
         level_setup(level);
         kt_end = qKT;

@@ -997,6 +997,11 @@ class Engine:
     # patches, with bn_apply's own arithmetic (bit-identical results).  Exact-fp32 mode only (the 16-bit kernels bring their tiles to
     # LDS by DMA: nothing passes through registers).  The BatchNorm backward takes its ReLU mask from y already (mask 'self').
     apply_on_load = os.environ.get('DBN_APPLY_ON_LOAD', '1') == '1'
+    # The FPN output conv's level 0 (a plain 3x3 conv of p2, 53 % of the pyramid's FLOPs) through the Winograd kernel, levels 1-3 added by
+    # the pyramid launch (dbn_pyramid_conv_from_t): built, same results to fp32 rounding, measured on one box in interleaved runs and OFF
+    # — 704.2 / 704.9 / 703.9 images/s without, 703.7 / 702.5 / 703.4 with: the 64 -> 256 Winograd launch re-stages every patch four times
+    # (one workgroup per 64 output channels) and the second launch re-reads the 164 MB output it accumulates into.
+    fpn_level0_winograd = os.environ.get('DBN_FPN_LV0_WINOGRAD', '0') == '1'
 
     def lazy_act(self, y, convs, train):
         """True when relu(bn(y)) may stay unwritten: every conv in `convs` (all read it as their input) runs as a Winograd conv forward
@@ -1476,7 +1481,20 @@ class Engine:
         if self.fpn_one_launch and Co % 128 == 0 and Cg % 16 == 0:
             # all four levels in one launch: one accumulator per output tile, no read-modify-write of y
             wpk = [self.pack('%s#f%d' % (name, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
-            flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs))
+            # exact fp32: level 0 — a plain 3x3 conv of p2 with the first Cg input channels' filters, 53 % of the pyramid's FLOPs — goes
+            # through the Winograd kernel (2.25x fewer matrix FLOPs) and the pyramid launch adds levels 1-3 onto it
+            lv0 = _VirtualConv(Cg, Co, 3, 1, 1, wds[0], conv.bias)
+            first = int(self.fpn_level0_winograd and not self._use_planes and wds[0].shape[1] == Cg and self._winograd_ok(zs[0], lv0))
+            if first:
+                # (wds[0][ci][co][u][v] = W[co][ci][2-u][2-v]: its data-gradient panel is the forward conv of W's first Cg input channels)
+                up = self._winograd_panel(name + '#lv0', wds[0], Cg, dgrad=1, version=wver)
+                if self.prof:
+                    self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * Co * Cg * 4, 0.0, 'fwd %s level 0' % name)
+                check(self.L.dbn_winograd_conv_bn_f32(zs[0].data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, Cg, Co, None, None,
+                                                      0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
+                if self.prof:
+                    self.prof.end()
+            flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs) if g >= first)
             if self.prof:
                 self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0,true>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
@@ -1493,8 +1511,8 @@ class Engine:
             pat, zp = self.at, [z.data_ptr() for z in zs]
             if self._use_planes and Cg % 16 == 0:
                 pat, zp = 3, [self._planes(z).data_ptr() for z in zs]
-            check(self.L.dbn_pyramid_conv_t(pat, *zp, *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
-                                              N, H, W, Cg, Co, 0, self.ns, *bnargs, self.stream), 'pyramid_conv')
+            check(self.L.dbn_pyramid_conv_from_t(first, pat, *zp, *[w_.data_ptr() for w_ in wpk], _p(conv.bias), y.data_ptr(),
+                                                   N, H, W, Cg, Co, 0, self.ns, *bnargs, self.stream), 'pyramid_conv')
             if self.prof:
                 self.prof.end()
             if not fused:
