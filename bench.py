@@ -424,7 +424,13 @@ def main():
             prof = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))
         except (OSError, ValueError):
             continue
-        tr = prof.get('kernels', {}).get(dname)
+        ks = prof.get('kernels', {})
+        tr = ks.get(dname)
+        if tr is None:  # a label that covers several template instances of one kernel (winograd_f32_kernel<false> / <true>): launch-weighted mean
+            inst = [v for k, v in ks.items() if k.startswith(dname + '<')]
+            n = sum(v['launches_sampled'] for v in inst)
+            if n:
+                tr = {'hbm_bytes_per_launch': int(sum(v['hbm_bytes_per_launch'] * v['launches_sampled'] for v in inst) / n)}
         if tr and prof.get('csrc_stamp') == source_stamp():
             roofline['traffic'] = tr['hbm_bytes_per_launch']
             roofline['traffic_stale'] = False

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(1024) void winograd_wgrad_reduce_kernel(const float
 }
 
 int wwg_splits(int groups, int nsub) {
-    static const int per_cu = dbn_env_int("DBN_WWG_PER_CU", 1);  // workgroups per CU the launch aims at (one is resident: 8 waves x 256 registers)
-    int ns = std::max(1, 256 * per_cu / nsub);
+    static const int wgs = dbn_env_int("DBN_WWG_WGS", 256);  // workgroups the launch aims at (one is resident per CU: 8 waves x 256 registers)
+    int ns = std::max(1, wgs / nsub);
     return std::min(ns, groups);
 }
 

@@ -504,6 +504,41 @@ class Engine:
             self.packs[key] = (out, stamp)
         self._repack_winograd(beside)
 
+    def _repack_fpn(self):
+        """The pyramid conv's combined weights (4 launches) and every panel derived from them — forward, data-gradient, Winograd
+        forms: 9 pack launches — on the SIDE stream beside layer1 (called once the stem's repack join is behind: the side stream is
+        idle until the first lateral conv, and the main stream joins it again before the pyramid conv), instead of lazily in front of
+        their first use on the MAIN stream: there they sat on the critical path, and the data-gradient panels' pack, a small grid, took
+        0.44 ms beside the weight-gradient stream (round-4 trace: 0.6 ms of the 22.7 ms step).  (Together with the other panels right
+        after the optimizer step was measured first: 700 -> 692 images/s — the first conv behind the stem then waits for all of it.)"""
+        src = self._fpn_src
+        beside = self.overlap_repack and self.overlap_wgrad
+        on = self.fpn_repack_early == '1' or (self.fpn_repack_early == '' and self.at != 0)
+        if not on or src is None or not beside or self._in_side:
+            return
+        name, conv, Cg = src
+        ent = self.packs.get((name, 'combined'))
+        w = conv.weight
+        if ent is None or ent[1] == (w._version, self.param_epoch, w.data_ptr()):
+            return
+        derived = [k for k in self.packs if isinstance(k[0], str) and k[0].startswith(name + '#')]
+
+        def run():
+            wds, wver = self._fpn_combined_weights(name, conv, Cg)
+            for k in derived:
+                g = int(k[0][-1])  # '#f<g>' forward / '#g<g>' data-gradient panels of level g, '#lv0' / '#g0': level 0
+                if k[1] == 'winograd':
+                    self._winograd_panel(k[0], wds[g], k[2], dgrad=k[3], version=wver)
+                elif k[3] == self.kind:
+                    self.pack(k[0], wds[g], k[1], k[2], version=wver)
+        with self.side_stream():
+            run()
+
+    # measured on one box, interleaved: exact fp32 702.9-704.7 images/s without vs 698.0-701.9 with (the step there is bound by the two
+    # streams' total work, not by the main stream's chain); bf16 1600 / 1613 without vs 1628 / 1622 with: '' = in the 16-bit modes only
+    fpn_repack_early = os.environ.get('DBN_FPN_REPACK_EARLY', '')
+    _fpn_src = None
+
     def _repack_winograd(self, beside):
         """The Winograd panels (G g G^T of every 3x3 / stride-1 filter, forward and data-gradient form) of all layers in ONE launch
         after the optimizer step — 31 launches of ~10 us sprinkled over the step otherwise (0.34 ms in the round-4 trace)."""
@@ -1096,6 +1131,7 @@ class Engine:
         if self.prof:
             self.prof.end()
         self._join_repack()
+        self._repack_fpn()
         fpn = m.segmentation_body
         pre = 'segmentation_body.'
 
@@ -1461,6 +1497,7 @@ class Engine:
         """Wd_g[ci][co][u][v] = sum of the 3x3 taps of W[co][64g+ci] that land on offset (u,v) of level g's (f+2)^2 footprint."""
         w = conv.weight
         Co = w.shape[0]
+        self._fpn_src = (name, conv, Cg)
         stamp = (w._version, self.param_epoch, w.data_ptr())
         ent = self.packs.get((name, 'combined'))
         if ent is None or ent[1] != stamp:
