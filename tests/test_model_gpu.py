@@ -958,3 +958,27 @@ def test_apply_on_load_batchnorm_relu_is_bit_identical(size, train):
         assert (len(written) == 9) if not on else ('backbone.layer1.0/z1' not in written and 'fpn/z' not in written), written
     for a, b in zip(*outs):
         assert float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_pyramid_conv_on_a_winograd_level_0():
+    """engine.fpn_level0_winograd (opt-in): the FPN output conv's level 0 — the plain 3x3 conv of p2 (segmentation_body.py:55-61,82-87) —
+    through the Winograd kernel, levels 1-3 added onto it by dbn_pyramid_conv_from_t(first_level = 1), against the one-launch pyramid
+    conv: same sum in another order — predictions and losses to 2e-5, every gradient tensor to 1e-4 of its scale after one step."""
+    seed = 11
+    img, gts = O.synthetic_batch(2, 160, seed=seed)
+    img, gts = img.to(DEV), gts.to(DEV)
+    outs = []
+    for on in (False, True):
+        model = make_model(seed, 'resnet18').train()
+        model.engine.fpn_level0_winograd = on
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        preds, losses = tr.step(img, gts)
+        torch.cuda.synchronize()
+        assert (('segmentation_body.conv.0#lv0', 'winograd', 64, 1) in model.engine.packs) == on
+        outs.append((preds.clone(), losses.clone(), {k: v.clone() for k, v in model.engine.grad_views.items()}))
+    (p0, l0, g0), (p1, l1, g1) = outs
+    assert float((p0 - p1).abs().max()) <= 2e-5 and float((l0 - l1).abs().max()) <= 2e-5 * float(l0.abs().max())
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * scale + 1e-9, k
