@@ -250,15 +250,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with the patches: the region becomes the exchange buffer
 
+#if DBN_WINO_EXP == 3  // (timing experiment, wrong results: no exchange, no statistics — what would an epilogue that stays in registers cost?)
+    {
+        const unsigned pitch_ = (unsigned)p.Cd * 4u;
+        const __amdgpu_buffer_rsrc_t rsrcD_ = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (unsigned)((long)p.N * p.Hdf * p.Wdf * p.Cd * 4), 0x00020000);
+        const unsigned base_ = (unsigned)((pn * p.Hdf + ph0 + (wave >> 1)) * p.Wdf + pw0 + (wave & 1) + 8 * lh) * pitch_ + (unsigned)(n0 + li) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float v_ = ((acc[0][b][r] + acc[1][b][r]) + acc[2][b][r]) - acc[3][b][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v_), rsrcD_, (int)(base_ + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch_) + b * 128, 0, 0);
+            }
+        return;
+    }
+#endif
     // ---- output transform.  Along j (this wave holds M_i0 .. M_i3): T_i[dx] = A^T row dx: dx 0: M0 + M1 + M2;  dx 1: M1 - M2 - M3
-    float* const X = reinterpret_cast<float*>(smem);  // [(i*2 + dx)*2 + b][r][lane]
+    // Exchange layout: [(i*2 + dx)*2 + b][lane][4 groups of four rows], 16-byte accesses; the group index is XOR-swizzled with bits 1-2
+    // of the lane so that the eight lanes of one LDS cycle (64 bytes apart) hit eight different 16-byte bank groups.  (First form:
+    // [..][r][lane] with 64 four-byte writes and 96 four-byte reads per lane.)
+    f32x4* const X = smem;
+    const int xsw = (lane >> 1) & 3;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0_ = acc[0][b][r], m1_ = acc[1][b][r], m2_ = acc[2][b][r], m3_ = acc[3][b][r];
-            X[(((wave * 2 + 0) * 2 + b) * 16 + r) * 64 + lane] = (m0_ + m1_) + m2_;
-            X[(((wave * 2 + 1) * 2 + b) * 16 + r) * 64 + lane] = (m1_ - m2_) - m3_;
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4 t0_, t1_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rb + e;
+                const float m0_ = acc[0][b][r], m1_ = acc[1][b][r], m2_ = acc[2][b][r], m3_ = acc[3][b][r];
+                t0_[e] = (m0_ + m1_) + m2_;
+                t1_[e] = (m1_ - m2_) - m3_;
+            }
+            X[(((wave * 2 + 0) * 2 + b) * 64 + lane) * 4 + (rb ^ xsw)] = t0_;
+            X[(((wave * 2 + 1) * 2 + b) * 64 + lane) * 4 + (rb ^ xsw)] = t1_;
         }
     // (the accumulators are dead from here on: their registers take the epilogue's global loads, ALL issued before the exchange
     // barrier so that their latency hides behind it and the LDS reads below — in groups of four rows behind scheduling fences they
@@ -334,10 +360,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int b = 0; b < 2; ++b) {
         const float bias = p.bias ? p.bias[n0 + b * 32 + li] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            auto T = [&](int i) { return X[(((i * 2 + dx) * 2 + b) * 16 + r) * 64 + lane]; };
-            const float t1 = T(1), t2 = T(2);
-            y[b][r] = (dy == 0 ? (T(0) + t1) + t2 : (t1 - t2) - T(3)) + bias;
+        for (int rb = 0; rb < 4; ++rb) {
+            auto T = [&](int i) { return X[(((i * 2 + dx) * 2 + b) * 64 + lane) * 4 + (rb ^ xsw)]; };
+            const f32x4 t1 = T(1), t2 = T(2), t03 = T(dy == 0 ? 0 : 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[b][4 * rb + e] = (dy == 0 ? (t03[e] + t1[e]) + t2[e] : (t1[e] - t2[e]) - t03[e]) + bias;
         }
     }
     if (p.accumulate) {  // (data gradients that add into an existing gradient: the sums below see the final values)
