@@ -46,7 +46,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int XPX = LIN ? WL_XPX : WG_XPX, YPX = LIN ? WL_YPX : WG_YPX;
     constexpr int XCH = XPX * 16, YCH = YPX * 16;
     constexpr int NXP = (XCH + 511) / 512, NYP = (YCH + 511) / 512;  // staging pieces per thread
-    __shared__ f32x4 smem[XCH + YCH];  // x [pixels][64 ch], dY [pixels][64 ch]: 45 + 32 KB (patch form), 84 + 60 KB (LIN)
+    // x [pixels][64 ch], dY [pixels][64 ch]: 45 + 32 KB, TWICE in the patch form (patch g + 1 is stored while patch g is multiplied: one
+    // barrier per patch; 154 of the CU's 160 KB — one workgroup is resident per CU anyway); LIN: 84 + 60 KB, once
+    constexpr int NBUF = LIN ? 1 : 2;
+    __shared__ f32x4 smem[NBUF * (XCH + YCH)];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int irow = wave & 3, oh = wave >> 2;
@@ -124,7 +127,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             xvalid = (xvalid & ~(1u << j)) | ((unsigned)v << j);
         }
     };
+    int sbuf = 0;  // (patch form) LDS image the next store_group() fills
     auto store_x = [&](int xrows) {
+        f32x4* const dstX = smem + sbuf * (XCH + YCH);
         if (act) {
             const f32x4 asc = LIN ? *reinterpret_cast<const f32x4*>(p.x_scale + ib * 64 + (tid & 15) * 4) : asc_;
             const f32x4 ash = LIN ? *reinterpret_cast<const f32x4*>(p.x_shift + ib * 64 + (tid & 15) * 4) : ash_;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int j = 0; j < NXP; ++j)
-            if (xpos[j] >= 0 && (xpos[j] & 255) < xrows) smem[tid + j * 512] = rx[j];
+            if (xpos[j] >= 0 && (xpos[j] & 255) < xrows) dstX[tid + j * 512] = rx[j];
     };
     auto y_piece = [&](int j, int n, int hs0, int ws0, int xrows) {  // dY image: the x image without its halo
         const int py = ypos[j] & 255, px = ypos[j] >> 8;
@@ -156,8 +161,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         store_x(10);
         if constexpr (!LIN) {
 #pragma unroll
-            for (int j = 0; j < NYP; ++j) smem[XCH + tid + j * 512] = ry[j];
+            for (int j = 0; j < NYP; ++j) smem[sbuf * (XCH + YCH) + XCH + tid + j * 512] = ry[j];
         }
+        sbuf ^= 1;
     };
     auto stage_lin = [&](int g) {  // LIN: load and store between the group's two barriers; dY in batches of four pieces (registers)
         int n, hs0, ws0, xrows;
@@ -205,17 +211,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (g0 < g1) {
             load_group(g0);
             store_group();
+            if (g0 + 1 < g1) load_group(g0 + 1);
         }
         __syncthreads();
     }
     for (int g = g0; g < g1; ++g) {
+        int cbuf = 0;  // LDS image this patch is multiplied from
         if constexpr (LIN) {
             if (g > g0) __syncthreads();  // every wave has read the previous band
             stage_lin(g);
             __syncthreads();
         } else {
-            if (g + 1 < g1 && DBN_WWG_EXP != 1) load_group(g + 1);
+            // patch g + 1 (in registers since the previous iteration) goes to the OTHER image — every wave left it at the barrier that
+            // ended iteration g - 1 — and patch g + 2 starts its way from memory; both overlap this patch's matrix phase
+            cbuf = (g - g0) & 1;
+            if (DBN_WWG_EXP != 1) {
+                if (g + 1 < g1) store_group();
+                if (g + 2 < g1) load_group(g + 2);
+            }
         }
+        const int xoff2 = cbuf * (XCH + YCH) * 2, yoff4 = cbuf * (XCH + YCH) * 4;  // offsets of the image in float2 / float units
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             int xo, yo;
@@ -235,32 +250,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 yo = (2 * (s >> 2) * WG_YROW + 4 * (s & 3)) * 64;
             }
             f32x2 R[4];
-#if DBN_WWG_EXP == 2
+#if DBN_WWG_EXP == 2 || DBN_WWG_EXP == 6  // (6: the vector instructions on register operands, no LDS reads)
             for (int q = 0; q < 4; ++q) { R[q][0] = rx[q][0]; R[q][1] = rx[q][1]; }
             const float d00 = rx[0][0], d01 = rx[0][1], d10 = rx[1][0], d11 = rx[1][1];
+#if DBN_WWG_EXP == 6
+            for (int q = 0; q < 4; ++q) { R[q][0] = fmaf(sa, rx[q][1], R[q][0]); R[q][1] = fmaf(sa, rx[q][2], R[q][1]); }
+#endif
 #else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x2 u1 = Xr1[xo + q * 32], u2 = Xr2[xo + q * 32];
+                const f32x2 u1 = Xr1[xoff2 + xo + q * 32], u2 = Xr2[xoff2 + xo + q * 32];
+#if DBN_WWG_EXP == 5
+                R[q][0] = u1[0];
+                R[q][1] = u2[1];
+#else
                 R[q][0] = fmaf(sa, u2[0], u1[0]);  // (sa = +-1: exact)
                 R[q][1] = fmaf(sa, u2[1], u1[1]);
-            }
-            const float d00 = Yb[yo], d01 = Yb[yo + 64], d10 = Yb[yo + yrow * 64], d11 = Yb[yo + yrow * 64 + 64];
 #endif
+            }
+            const float* const Yc = Yb + yoff4;
+            const float d00 = Yc[yo], d01 = Yc[yo + 64], d10 = Yc[yo + yrow * 64], d11 = Yc[yo + yrow * 64 + 64];
+#endif
+#if DBN_WWG_EXP == 2 || DBN_WWG_EXP == 5  // (5: the LDS reads, no transform arithmetic)
+            const f32x2 V[4] = {R[0], R[1], R[2], R[3]};
+            const float D[4] = {d00, d01, d10, d11};
+#else
             const f32x2 V[4] = {R[0] - R[2], R[1] + R[2], R[2] - R[1], R[1] - R[3]};
             const float r0 = fmaf(c1s, d10, c0s * d00), r1 = fmaf(c1s, d11, c0s * d01);
             const float D[4] = {r0, r0 + r1, r0 - r1, -r1};
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(D[j], V[j][h], acc[j][h], 0, 0, 0);
         }
         if constexpr (!LIN) {
-            if (g + 1 < g1 && DBN_WWG_EXP != 1) {
-                __syncthreads();  // every wave has read this patch
-                store_group();
-                __syncthreads();
-            }
+            if (g + 1 < g1 && DBN_WWG_EXP != 1) __syncthreads();  // patch g + 1 is in LDS, and every wave has read patch g
         }
     }
     // ---- partial sums -> slab [split][sub][point][o][i]: accumulator row (r & 3) + 8 (r >> 2) + 4 lh = output channel within this wave's
