@@ -1033,10 +1033,12 @@ class Engine:
     # LDS by DMA: nothing passes through registers).  The BatchNorm backward takes its ReLU mask from y already (mask 'self').
     apply_on_load = os.environ.get('DBN_APPLY_ON_LOAD', '1') == '1'
     # The FPN output conv's level 0 (a plain 3x3 conv of p2, 53 % of the pyramid's FLOPs) through the Winograd kernel, levels 1-3 added by
-    # the pyramid launch (dbn_pyramid_conv_from_t): built, same results to fp32 rounding, measured on one box in interleaved runs and OFF
-    # — 704.2 / 704.9 / 703.9 images/s without, 703.7 / 702.5 / 703.4 with: the 64 -> 256 Winograd launch re-stages every patch four times
-    # (one workgroup per 64 output channels) and the second launch re-reads the 164 MB output it accumulates into.
-    fpn_level0_winograd = os.environ.get('DBN_FPN_LV0_WINOGRAD', '0') == '1'
+    # the pyramid launch (dbn_pyramid_conv_from_t): same results to fp32 rounding (test_pyramid_conv_on_a_winograd_level_0), measured
+    # on one box in interleaved runs: 702.6 / 703.8 / 703.2 images/s without, 709.6 / 708.0 / 708.6 with (+0.8 %: the 64 -> 256 Winograd
+    # launch re-stages every patch four times and the second launch re-reads the 164 MB output it accumulates into, which eats most of the
+    # 2.25x).  (A first measurement had shown "no difference": a wrong shape check had kept the switch from taking effect — the test
+    # found it.)
+    fpn_level0_winograd = os.environ.get('DBN_FPN_LV0_WINOGRAD', '1') == '1'
 
     def lazy_act(self, y, convs, train):
         """True when relu(bn(y)) may stay unwritten: every conv in `convs` (all read it as their input) runs as a Winograd conv forward
@@ -1521,7 +1523,7 @@ class Engine:
             # exact fp32: level 0 — a plain 3x3 conv of p2 with the first Cg input channels' filters, 53 % of the pyramid's FLOPs — goes
             # through the Winograd kernel (2.25x fewer matrix FLOPs) and the pyramid launch adds levels 1-3 onto it
             lv0 = _VirtualConv(Cg, Co, 3, 1, 1, wds[0], conv.bias)
-            first = int(self.fpn_level0_winograd and not self._use_planes and wds[0].shape[1] == Cg and self._winograd_ok(zs[0], lv0))
+            first = int(self.fpn_level0_winograd and not self._use_planes and wds[0].shape[0] == Cg and self._winograd_ok(zs[0], lv0))
             if first:
                 # (wds[0][ci][co][u][v] = W[co][ci][2-u][2-v]: its data-gradient panel is the forward conv of W's first Cg input channels)
                 up = self._winograd_panel(name + '#lv0', wds[0], Cg, dgrad=1, version=wver)
