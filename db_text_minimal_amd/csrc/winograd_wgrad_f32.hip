@@ -15,6 +15,9 @@
 // reduction kernel adds the slabs in fp64 in a fixed order and applies G^T . G (deterministic, no atomics).
 #include "igemm_common.h"
 #include <algorithm>
+#ifndef DBN_WWG_PIPE
+#define DBN_WWG_PIPE 1  // 0: the k-steps in the compiler's order (A/B builds)
+#endif
 #ifndef DBN_WWG_EXP
 #define DBN_WWG_EXP 0  // timing experiments (wrong results): 1 = the first patch only (no staging / barriers in the loop), 2 = no LDS reads / transforms
 #endif
@@ -231,6 +234,65 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         const int xoff2 = cbuf * (XCH + YCH) * 2, yoff4 = cbuf * (XCH + YCH) * 4;  // offsets of the image in float2 / float units
+#if DBN_WWG_PIPE
+        if constexpr (!LIN) {
+            // k-steps in a two-stage software pipeline: the LDS reads of step s + 1 go out BEFORE the eight MFMAs of step s, its operands
+            // are formed AFTER they are issued (while they run) — the compiler's order is reads -> wait -> ~40 vector instructions ->
+            // 8 MFMAs per step, a latency chain the second resident wave of the SIMD only partly covers (-DDBN_WWG_EXP=5/6).
+            f32x2 U1[4], U2[4], V[4];
+            float dd[4], D[4];
+            auto fetch = [&](int s_) {
+                const int xo = xoff2 + (2 * (s_ >> 2) * WG_XROW + 4 * (s_ & 3)) * 32, yo = yoff4 + (2 * (s_ >> 2) * WG_YROW + 4 * (s_ & 3)) * 64;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    U1[q] = Xr1[xo + q * 32];
+                    U2[q] = Xr2[xo + q * 32];
+                }
+                dd[0] = Yb[yo];
+                dd[1] = Yb[yo + 64];
+                dd[2] = Yb[yo + WG_YROW * 64];
+                dd[3] = Yb[yo + WG_YROW * 64 + 64];
+            };
+            auto form = [&]() {
+                f32x2 R[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    R[q][0] = fmaf(sa, U2[q][0], U1[q][0]);  // (sa = +-1: exact)
+                    R[q][1] = fmaf(sa, U2[q][1], U1[q][1]);
+                }
+                V[0] = R[0] - R[2];
+                V[1] = R[1] + R[2];
+                V[2] = R[2] - R[1];
+                V[3] = R[1] - R[3];
+                const float r0 = fmaf(c1, dd[2], c0 * dd[0]), r1 = fmaf(c1, dd[3], c0 * dd[1]);
+                D[0] = r0;
+                D[1] = r0 + r1;
+                D[2] = r0 - r1;
+                D[3] = -r1;
+            };
+            fetch(0);
+            form();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                f32x2 Vc[4];
+                float Dc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Vc[j] = V[j];
+                    Dc[j] = D[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < 16) fetch(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[j][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(Dc[j], Vc[j][h], acc[j][h], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < 16) form();
+            }
+        } else
+#endif
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             int xo, yo;
