@@ -17,6 +17,9 @@
 // different summation (max relative error ~1e-6 of the output scale), not bit for bit.
 #include "igemm_common.h"
 #include <algorithm>
+#ifndef DBN_WINO_BATCH
+#define DBN_WINO_BATCH 0  // 1: each point's vector instructions fenced into one batch in front of its MFMAs (measured: 64->64 189 -> 191 us, 256->64 575 -> 593, the LIN form 173 -> 193 with two spills: the LDS latency in front of the batch is then exposed)
+#endif
 #ifndef DBN_WINO_EXP
 #define DBN_WINO_EXP 0
 #endif
@@ -217,6 +220,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
             }
 #endif
+            // (DBN_WINO_BATCH: the point's 24 vector instructions fenced into ONE batch in front of its 16 MFMAs — a vector instruction
+            // between two MFMAs costs ~13 clocks of the fp32 matrix pipe, in a batch ~5 — measured slower here, see the define)
+#if DBN_WINO_BATCH
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -224,6 +232,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
                         acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[j][s2][b][e], acc[j][b], 0, 0, 0);
+#if DBN_WINO_BATCH
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         point(std::integral_constant<int, 0>{});
         point(std::integral_constant<int, 1>{});
