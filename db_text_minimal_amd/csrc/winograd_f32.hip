@@ -170,13 +170,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
     };
 
+    // (not zeroed: the first MFMA of every accumulator — channel block 0 — takes the constant 0 as its addend.  128 v_mov per wave
+    // otherwise, and a vector instruction costs fp32-MFMA time on this chip whichever wave issues it: DESIGN 7.12)
     f32x16 acc[4][2];
+    if constexpr (LIN) {  // (the LIN form has no registers to spare for the peeled first block: 68 spills — it zeroes its accumulators)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[j][b][r] = 0.f;
+    }
 
     DBN_TRACE_MARK(0);
 #if DBN_TRACE
@@ -199,8 +203,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // + 44 vector instructions per block instead of 32 + 96 — 3-8 % SLOWER: one long vector phase per block overlaps the other
         // resident wave's MFMAs worse than four short ones; issuing the next point's LDS reads ahead of the current point's MFMAs:
         // neutral, and its 32 registers are better spent on the weight fragments' prefetch distance.)
-        auto point = [&](auto J) {
+        auto point = [&](auto J, auto FIRST) {
             constexpr int j = decltype(J)::value;
+            constexpr bool first = decltype(FIRST)::value;  // channel block 0: the accumulators start here
             issue_w(std::integral_constant<int, (j + 2) & 3>{});  // the weight fragments of the point after the next (set = point index)
             __builtin_amdgcn_sched_barrier(0);
             // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
@@ -231,15 +236,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[j][s2][b][e], acc[j][b], 0, 0, 0);
+                    {
+                        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[s2][e], rw[j][s2][b][e], (first && s2 == 0 && e == 0) ? zero16 : acc[j][b], 0, 0, 0);
+                    }
 #if DBN_WINO_BATCH
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
-        point(std::integral_constant<int, 0>{});
-        point(std::integral_constant<int, 1>{});
-        point(std::integral_constant<int, 2>{});
-        point(std::integral_constant<int, 3>{});
+        if (!LIN && cb == 0) {
+            point(std::integral_constant<int, 0>{}, std::true_type{});
+            point(std::integral_constant<int, 1>{}, std::true_type{});
+            point(std::integral_constant<int, 2>{}, std::true_type{});
+            point(std::integral_constant<int, 3>{}, std::true_type{});
+        } else {
+            point(std::integral_constant<int, 0>{}, std::false_type{});
+            point(std::integral_constant<int, 1>{}, std::false_type{});
+            point(std::integral_constant<int, 2>{}, std::false_type{});
+            point(std::integral_constant<int, 3>{}, std::false_type{});
+        }
         if (cb + 1 < ncb) {
             // the other buffer was last read in block cb - 1, and every wave has passed the barrier that ended it
 #if DBN_TRACE
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // stores are dropped, and bit r of `vmask` keeps the pixel out of the statistics
     unsigned vmask = 0;
     unsigned roff[16];
+    bool allv = false;  // (uniform) every pixel of this workgroup's tiles lies inside the map: no per-pixel validity arithmetic below
     if constexpr (LIN) {
         const float rTW = 1.0f / (float)TWl;
 #pragma unroll
@@ -325,11 +341,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else {
         // t >> 3 = r >> 2 (rows of tiles), t & 7 = (r & 3) + 4 lh
         const unsigned base = (unsigned)((pn * p.Hdf + ph0 + dy) * p.Wdf + pw0 + dx + 8 * lh) * pitch + (unsigned)(n0 + li) * 4u;
+        allv = ph0 + 8 <= p.Hdf && pw0 + 16 <= p.Wdf;
+        if (allv) {  // a whole patch (every patch of a map whose sides are multiples of 8 / 16): one add per row, scalar row offsets
+            vmask = 0xFFFFu;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = (ph0 + 2 * (r >> 2) + dy < p.Hdf) && (pw0 + 2 * ((r & 3) + 4 * lh) + dx < p.Wdf);
-            vmask |= (unsigned)ok << r;
-            roff[r] = ok ? base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch : OOB_OFFSET;
+            for (int r = 0; r < 16; ++r) roff[r] = base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = (ph0 + 2 * (r >> 2) + dy < p.Hdf) && (pw0 + 2 * ((r & 3) + 4 * lh) + dx < p.Wdf);
+                vmask |= (unsigned)ok << r;
+                roff[r] = ok ? base + (unsigned)(2 * (r >> 2) * p.Wdf + 2 * (r & 3)) * pitch : OOB_OFFSET;
+            }
         }
     }
     auto row_off = [&](int r) { return roff[r]; };
@@ -369,13 +392,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float y[2][16];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const float bias = p.bias ? p.bias[n0 + b * 32 + li] : 0.f;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             auto T = [&](int i) { return X[(((i * 2 + dx) * 2 + b) * 64 + lane) * 4 + (rb ^ xsw)]; };
             const f32x4 t1 = T(1), t2 = T(2), t03 = T(dy == 0 ? 0 : 3);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[b][4 * rb + e] = (dy == 0 ? (t03[e] + t1[e]) + t2[e] : (t1[e] - t2[e]) - t03[e]) + bias;
+            for (int e = 0; e < 4; ++e) y[b][4 * rb + e] = dy == 0 ? (t03[e] + t1[e]) + t2[e] : (t1[e] - t2[e]) - t03[e];
+        }
+    }
+    if (p.bias) {  // (the convs in front of a BatchNorm have none: 32 vector instructions saved)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float bias = p.bias[n0 + b * 32 + li];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[b][r] += bias;
         }
     }
     if (p.accumulate) {  // (data gradients that add into an existing gradient: the sums below see the final values)
@@ -394,13 +424,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float mu = p.bnb_mean[c], rsd = p.bnb_rstd[c];
             const float msc = zm ? 0.f : p.bnb_msc[c], msh = zm ? 0.f : p.bnb_msh[c];
             const float mu2 = two ? p.bnb_mean2[c] : 0.f, rs2 = two ? p.bnb_rstd2[c] : 0.f;
+            if (allv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m_ = zm ? zv[b][r] : dbn_affine(yv[b][r], msc, msh);
-                const float gq = (m_ > 0.f && ((vmask >> r) & 1u)) ? y[b][r] : 0.f;
-                s1[b] += gq;
-                s2[b] += gq * ((yv[b][r] - mu) * rsd);
-                if (two) s4[b] += gq * ((y2v[b][r] - mu2) * rs2);
+                for (int r = 0; r < 16; ++r) {
+                    const float m_ = zm ? zv[b][r] : dbn_affine(yv[b][r], msc, msh);
+                    const float gq = m_ > 0.f ? y[b][r] : 0.f;
+                    s1[b] += gq;
+                    s2[b] += gq * ((yv[b][r] - mu) * rsd);
+                    if (two) s4[b] += gq * ((y2v[b][r] - mu2) * rs2);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m_ = zm ? zv[b][r] : dbn_affine(yv[b][r], msc, msh);
+                    const float gq = (m_ > 0.f && ((vmask >> r) & 1u)) ? y[b][r] : 0.f;
+                    s1[b] += gq;
+                    s2[b] += gq * ((yv[b][r] - mu) * rsd);
+                    if (two) s4[b] += gq * ((y2v[b][r] - mu2) * rs2);
+                }
             }
         }
         float* const red = reinterpret_cast<float*>(smem) + X_FLOATS;  // [3][4 waves][64]
@@ -506,11 +547,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int b = 0; b < 2; ++b) {
             const float pv = piv[b * 32 + li];
             float s1 = 0.f, s2 = 0.f;
+            if (allv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = ((vmask >> r) & 1u) ? y[b][r] - pv : 0.f;
-                s1 += d;
-                s2 += d * d;
+                for (int r = 0; r < 16; ++r) {
+                    const float d = y[b][r] - pv;
+                    s1 += d;
+                    s2 += d * d;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = ((vmask >> r) & 1u) ? y[b][r] - pv : 0.f;
+                    s1 += d;
+                    s2 += d * d;
+                }
             }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
