@@ -98,6 +98,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asc_ = *reinterpret_cast<const f32x4*>(p.x_scale + ib * 64 + (tid & 15) * 4);
         ash_ = *reinterpret_cast<const f32x4*>(p.x_shift + ib * 64 + (tid & 15) * 4);
     }
+    unsigned xstatic = 0;  // bit j: piece j exists (idx < the image's chunks)
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) xstatic |= (unsigned)(xpos[j] >= 0) << j;
     unsigned xvalid = 0;  // bit j: piece j of the staged x image lies inside the map (outside: the conv's zero padding of the activation)
     int t0 = 0, tr0 = 0;  // (LIN) first tile of the current group, its tile row
     // origin of group g's LDS images in the tensors: image, first pixel row / column of the x image (hs0, ws0: one before the first
@@ -122,6 +125,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int n, hs0, ws0, xrows;
         geometry(g, n, hs0, ws0, xrows);
         const unsigned bx = (unsigned)(((n * p.H + hs0) * p.W + ws0) * p.Cx + ib * 64) * 4u;  // (may wrap: only in-map pieces use it)
+        // (uniform) the whole 10 x 18 window lies inside the map — 72 % of the patches of a 160 x 160 map: one add per piece instead of
+        // six compares / selects (a vector instruction costs fp32-MFMA time; the pieces past the image keep OOB_OFFSET in xrel0)
+        if (!LIN && hs0 >= 0 && hs0 + 10 <= p.H && ws0 >= 0 && ws0 + WG_XROW <= p.W) {
+#pragma unroll
+            for (int j = 0; j < NXP; ++j) rx[j] = buffer_load_f32x4(rsX, xpos[j] >= 0 ? bx + xrel[j] : OOB_OFFSET);
+            xvalid = xstatic;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
             const int py = xpos[j] & 255, px = xpos[j] >> 8;
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto y_piece = [&](int j, int n, int hs0, int ws0, int xrows) {  // dY image: the x image without its halo
         const int py = ypos[j] & 255, px = ypos[j] >> 8;
         const unsigned by = (unsigned)(((n * p.H + hs0 + 1) * p.W + ws0 + 1) * p.Cy + ob * 64) * 4u;
+        if (!LIN && hs0 + 9 <= p.H && ws0 + 17 <= p.W) return buffer_load_f32x4(rsY, by + yrel[j]);  // (uniform) a whole 8 x 16 patch
         const bool v = ypos[j] >= 0 && py < xrows - 2 && hs0 + 1 + py < p.H && ws0 + 1 + px < p.W;
         return buffer_load_f32x4(rsY, v ? by + yrel[j] : OOB_OFFSET);
     };
