@@ -137,47 +137,81 @@ __global__ void pack_many_kernel(const PackJob* __restrict__ jobs, int NS) {
             Sp = taps_of_class(j.S, s0, j.f);
         }
         const int K = Rp * Sp * j.Cs, Kpad = (K + 15) / 16 * 16;
-        const long total = (long)Kpad * j.Cd;
         constexpr int G = BF16 ? 8 : 4;  // k-values per 16-byte group of the panel
-        for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-            const int e = (int)(idx % G);
-            const long qd = idx / G;
-            const int cd = (int)(qd % j.Cd);
-            const int kg = (int)(qd / j.Cd);
-            const int k = G * kg + e;
-            float v = 0.f;
-            if (k < K) {
-                int tap, cs;
-                if ((j.Cs & 15) == 0) {
-                    const int blk = k >> 4;
-                    tap = blk % (Rp * Sp);
-                    cs = (blk / (Rp * Sp)) * 16 + (k & 15);
-                } else {
-                    tap = k / j.Cs;
-                    cs = k - tap * j.Cs;
-                }
+        // one thread per (k-group, output column): its G values are one 16-byte store (per plane), and the tap / channel arithmetic —
+        // integer divisions by run-time values — is done once per group instead of once per element (the first form, one element
+        // per thread-iteration with 64-bit index arithmetic, took 0.29 ms for the model's 80 panels; on the side stream beside the stem conv, so
+        // the step did not move: fp32 718.6 vs 718.9, bf16 1627 vs 1620 images/s interleaved on one box)
+        const int total = (Kpad / G) * j.Cd;
+        const int RSp = Rp * Sp;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+            const int kg = q / j.Cd, cd = q - kg * j.Cd;
+            const int k0 = G * kg;
+            float v[G];
+            if ((j.Cs & 15) == 0) {  // 16-channel blocks: the group's G <= 8 values share one (tap, 16-channel block)
+                const int blk = k0 >> 4;
+                const int cb = blk / RSp, tap = blk - cb * RSp;
                 const int rp = tap / Sp, sp = tap - rp * Sp;
                 const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
-                if (j.mode == 0) {
-                    if (cs < j.I) v = w[(((long)cd * j.I + cs) * j.R + r) * j.S + sx];
-                } else {
-                    v = w[(((long)cs * j.I + cd) * j.R + r) * j.S + sx];
+                const int cs0 = cb * 16 + (k0 & 15);
+#pragma unroll
+                for (int e = 0; e < G; ++e) {
+                    const int cs = cs0 + e;
+                    float t = 0.f;
+                    if (k0 + e < K) {
+                        if (j.mode == 0) {
+                            if (cs < j.I) t = w[(((long)cd * j.I + cs) * j.R + r) * j.S + sx];
+                        } else {
+                            t = w[(((long)cs * j.I + cd) * j.R + r) * j.S + sx];
+                        }
+                    }
+                    v[e] = t;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < G; ++e) {
+                    const int k = k0 + e;
+                    float t = 0.f;
+                    if (k < K) {
+                        const int tap = k / j.Cs, cs = k - tap * j.Cs;
+                        const int rp = tap / Sp, sp = tap - rp * Sp;
+                        const int r = r0 + rstep * rp, sx = s0 + rstep * sp;
+                        if (j.mode == 0) {
+                            if (cs < j.I) t = w[(((long)cd * j.I + cs) * j.R + r) * j.S + sx];
+                        } else {
+                            t = w[(((long)cs * j.I + cd) * j.R + r) * j.S + sx];
+                        }
+                    }
+                    v[e] = t;
                 }
             }
             if constexpr (BF16 == 2) {  // fp16 panels (one plane)
                 unsigned short* out = reinterpret_cast<unsigned short*>(j.out) + krow0 * j.Cd;
                 const int kt = kg >> 1, k8 = kg & 1;
-                out[(((long)kt * 2 + k8) * j.Cd + cd) * 8 + e] = (unsigned short)f16_bits(v);
+                unsigned short h[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (unsigned short)f16_bits(v[e]);
+                f32x4 pk;
+                __builtin_memcpy(&pk, h, 16);
+                *reinterpret_cast<f32x4*>(out + (((long)kt * 2 + k8) * j.Cd + cd) * 8) = pk;
             } else if constexpr (BF16 == 1) {
                 unsigned short* out = reinterpret_cast<unsigned short*>(j.out) + krow0 * j.Cd * NS;
                 const int kt = kg >> 1, k8 = kg & 1;
                 for (int t = 0; t < NS; ++t) {
-                    const unsigned bits = bf16_bits_rne(v);
-                    out[((((long)kt * NS + t) * 2 + k8) * j.Cd + cd) * 8 + e] = (unsigned short)bits;
-                    v -= bf16_bits_to_f32(bits);
+                    unsigned short h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned bits = bf16_bits_rne(v[e]);
+                        h[e] = (unsigned short)bits;
+                        v[e] -= bf16_bits_to_f32(bits);
+                    }
+                    f32x4 pk;
+                    __builtin_memcpy(&pk, h, 16);
+                    *reinterpret_cast<f32x4*>(out + ((((long)kt * NS + t) * 2 + k8) * j.Cd + cd) * 8) = pk;
                 }
             } else {
-                reinterpret_cast<float*>(j.out)[krow0 * j.Cd + idx] = v;
+                f32x4 pk = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(j.out) + krow0 * j.Cd + (long)q * 4) = pk;
             }
         }
         krow0 += Kpad;
