@@ -20,6 +20,9 @@ Extra objects on the JSON line:
   roofline_hbm  the DB-head group (head tail forward / backward, DBLoss forward / backward) against the HBM peak: on the
                 fused kernels' own bytes and on SURVEY section 8d's unfused-algorithmic 84 B/px
   cpu_baseline  the CPU oracle (oracle/dbnet_oracle.py, plain PyTorch fp32) timed on this host
+  parity        BEFORE the timed region: one step of the benchmarked configuration on the inputs of tests/golden/cfg2_16x640.npz
+                (the reference's own train step at 16x3x640x640) — distances of the three maps and the five losses from the
+                reference's numbers; the run exits non-zero above the north_star tolerance
 """
 import argparse
 import json
@@ -102,10 +105,60 @@ def cpu_baseline(max_seconds=30.0, n16_budget_s=60.0):
         t0 = time.time()
         O.train_step(sd, opt, img16, gts16)
         t16 = time.time() - t0
-        out['n16'] = {'value': round(16 / t16, 4), 'unit': 'images/s', 'seconds': round(t16, 2),
+        out['n16'] = {'value': round(16 / t16, 4), 'skipped': False, 'unit': 'images/s', 'seconds': round(t16, 2),
                       'sample': 'one train step of the CPU oracle at 16x3x640x640 fp32 (the benchmarked batch), no warm-up'}
     else:
-        out['n16'] = {'value': None, 'skipped': 'predicted %.0f s per step on this host (> %.0f s budget)' % (predicted, n16_budget_s)}
+        out['n16'] = {'value': None, 'skipped': True,
+                      'why': 'predicted %.0f s per step on this host (> %.0f s budget)' % (predicted, n16_budget_s)}
+    return out
+
+
+def parity_gate(dev, math):
+    """The benchmarked configuration against the REFERENCE's own numbers, in the same run, before the timed region:
+    tests/golden/cfg2_16x640.npz holds the reference's train step at 16x3x640x640 (/root/reference/src/train.py:160-172 run by
+    tests/golden/make_golden.py --only-cfg2: strided 4096-point samples and L2 norms of the three maps, the five losses).  Its
+    inputs are regenerated from seeds (tests/golden/fixture_inputs.py: procedural weights seed 16, synthetic batch seed 116 — no
+    oracle import, fixtures only), ONE step of the HIP path runs on them, and the line carries the distances.  north_star
+    tolerance on the maps: 1e-3 abs + 1e-2 rel; losses 1e-5 (abs + rel) in the fp32-accurate modes.  The 16-bit modes are held
+    to their own yardstick in tests/test_model_gpu.py (test_distance_to_fp64...); here they only report."""
+    import importlib.util
+    import numpy as np
+    from db_text_minimal_amd import DBLoss, DBTextModel, DBTrainer, FusedAdam
+    gdir = os.path.join(ROOT, 'tests', 'golden')
+    spec = importlib.util.spec_from_file_location('fixture_inputs', os.path.join(gdir, 'fixture_inputs.py'))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    z = np.load(os.path.join(gdir, 'cfg2_16x640.npz'))
+    n, size, seed, _ = (int(v) for v in z['meta'])
+    model = DBTextModel()
+    model.load_state_dict(fx.procedural_fill({k: v.clone() for k, v in model.state_dict().items()}, seed))
+    model = model.to(dev).train()
+    model.engine.set_conv_math(math)
+    img, gts = fx.synthetic_batch(n, size, seed=seed + 100)
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    preds, losses = tr.step(img.to(dev), gts.to(dev))
+    torch.cuda.synchronize()
+    maps_err, maps_worst, l2_rel = 0.0, 0.0, 0.0
+    for c, nm in enumerate('PTB'):
+        a = preds[:, c].detach().double().cpu().reshape(-1)
+        ref = torch.from_numpy(z['preds_%s/sample' % nm]).double()
+        got = a[torch.from_numpy(fx.sample_idx(a.numel(), ref.numel()))]
+        err = (got - ref).abs()
+        maps_err = max(maps_err, float(err.max()))
+        maps_worst = max(maps_worst, float((err / (1e-3 + 1e-2 * ref.abs())).max()))
+        l2_rel = max(l2_rel, abs(float(a.pow(2).sum().sqrt()) - float(z['preds_%s/stats' % nm][2])) / float(z['preds_%s/stats' % nm][2]))
+    lref = torch.from_numpy(z['losses'][0]).double()
+    lerr = (losses.detach().double().cpu() - lref).abs()
+    loss_worst = float((lerr / (1e-5 + 1e-5 * lref.abs())).max())
+    exact = math in ('f32', 'bf16x3')
+    ok = bool(maps_worst <= 1.0 and (loss_worst <= 1.0 or not exact))
+    out = {'golden': 'cfg2_16x640 (the reference\'s train step at 16x3x640x640, tests/golden/make_golden.py --only-cfg2)',
+           'maps_max_err': float('%.3e' % maps_err), 'maps_tol': '1e-3 abs + 1e-2 rel on 3 x 4096 strided samples (north_star)',
+           'maps_worst_err_over_tol': round(maps_worst, 4), 'maps_l2_rel_err': float('%.3e' % l2_rel),
+           'loss_max_err': float('%.3e' % float(lerr.max())), 'loss_tol': '1e-5 abs + 1e-5 rel on the five losses' if exact else 'reported only (16-bit storage)',
+           'conv_math': math, 'ok': ok}
+    del tr, model, preds, losses
+    torch.cuda.empty_cache()
     return out
 
 
@@ -252,6 +305,7 @@ def main():
                     help='skip timing the other conv-math modes (reported under alt_modes; never part of `value`)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (nccl = RCCL; gloo only with --dry)')
     ap.add_argument('--dry', action='store_true', help='launch / rendezvous / exchange plumbing only, no GPU work (CPU test of --gpus N)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the cfg2_16x640 parity gate that runs before the timed region')
     args = ap.parse_args()
     if args.backend != 'nccl' and not args.dry:
         raise SystemExit('--backend gloo is for --dry runs: the step itself has no CPU path')
@@ -270,6 +324,14 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+
+    # parity gate: the benchmarked configuration vs the reference's golden, on this GPU, in this run, before anything is timed
+    parity = None
+    if rank == 0 and not args.no_parity and (args.batch, args.size) == (16, 640):
+        parity = parity_gate(dev, args.math)
+        if not parity['ok']:
+            print(json.dumps({'metric': 'train images/sec @640x640 bs=16/GPU', 'value': None, 'parity': parity}), flush=True)
+            raise SystemExit('parity gate failed: the HIP path does not reproduce the reference golden cfg2_16x640')
 
     torch.manual_seed(42)  # utils.setup_determinism(42): same initial weights on every rank
     model = DBTextModel().to(dev).train()
@@ -533,6 +595,7 @@ def main():
             'conv_math': args.math,
             'alt_modes': alt,
             'final_total_loss': round(final_loss, 5),
+            'parity': parity,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             line['cpu_baseline'] = cpu_baseline()

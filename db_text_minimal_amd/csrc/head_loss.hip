@@ -826,7 +826,10 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
                                grad_scale, ws, stream);
 }
 
-// [1024][NSUM] partial sums (doubles) + the arrival counter of the in-kernel finalize (ZERO before the first call; left zero)
+// [1024][NSUM] partial sums (doubles) + the arrival counter of the in-kernel finalize.  The caller's workspace needs NO
+// initialisation: the counter is cleared on the stream in front of every launch (a 4-byte hipMemsetAsync, graph-capturable), so an
+// uninitialised workspace, one shared with another call, or a counter left non-zero by an aborted launch cannot keep a later call
+// from finding its last workgroup (round-4 advisor finding: the old contract was "zero before the first call" and failed silently).
 static const long DB_LOSS_PART_BYTES = 1024L * NSUM * 8;
 int dbn_db_loss_ws_bytes() { return (int)DB_LOSS_PART_BYTES + 64; }
 
@@ -846,6 +849,7 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     char* base = (char*)ws;
     DbLossFinal fin = {(long)N * HW, channels, alpha, beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef,
                        (unsigned*)(base + DB_LOSS_PART_BYTES)};
+    if (hipMemsetAsync(fin.counter, 0, sizeof(unsigned), st) != hipSuccess) return dbn_status();
     if (vec)
         hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(512), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     else

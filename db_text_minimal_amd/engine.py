@@ -266,6 +266,14 @@ class Engine:
             self._by_ptr[t.data_ptr()] = t
         return t
 
+    def _drop_buf(self, name):
+        """Forget an activation buffer (apply-on-load: the tensor is never written) — including the pointer-keyed views of it, which
+        would otherwise keep the old allocation alive across train / eval alternations that disagree on lazy_act()."""
+        t = self.bufs.pop(name, None)
+        if t is not None:
+            self._by_ptr.pop(t.data_ptr(), None)
+            self._plane_cache.pop(t.data_ptr(), None)
+
     def fbuf(self, name, *shape):
         """Persistent fp32 buffer (coefficients, statistics, maps, parameter-shaped temporaries)."""
         return self.buf(name, *shape, dtype=torch.float32)
@@ -1180,7 +1188,7 @@ class Engine:
         head = m.segmentation_head
         f_act = None
         if self.lazy_act(fy, (head.binarize[0], head.thresh[0]), train):
-            self.bufs.pop('fpn/z', None)  # (never written: the two head convs and their weight gradients read fpn/y through its BatchNorm's coefficients)
+            self._drop_buf('fpn/z')  # (never written: the two head convs and their weight gradients read fpn/y through its BatchNorm's coefficients)
             f, f_act = fy, (s_, h_)
         else:
             f = self.bn_apply(fy, s_, h_, 'fpn/z')
@@ -1314,7 +1322,7 @@ class Engine:
         """BasicBlock (resnet.py:70-91) or Bottleneck (resnet.py:135-159)."""
         y1, s1, h1 = self.conv_bn(name + '.conv1', x, blk.conv1, name + '/y1', name + '.bn1', blk.bn1, train)
         if not getattr(blk, 'with_dcn', False) and self.lazy_act(y1, (blk.conv2, ), train):
-            self.bufs.pop(name + '/z1', None)  # (never written: conv2 and its weight gradient read y1 through bn1's coefficients)
+            self._drop_buf(name + '/z1')  # (never written: conv2 and its weight gradient read y1 through bn1's coefficients)
             y2, s2, h2 = self.conv_bn(name + '.conv2', y1, blk.conv2, name + '/y2', name + '.bn2', blk.bn2, train, x_act=(s1, h1))
         else:
             z1 = self.bn_apply(y1, s1, h1, name + '/z1')
@@ -1343,6 +1351,8 @@ class Engine:
         B = self.bufs
         self._bias_done = set()
         self._bnb_sums = {}
+        # (a pass that raised between queueing and flushing must not leave launches holding the PREVIOUS batch's tensors behind)
+        self._wgrad_fifo, self._reduce_pending = [], []
         self._slab_free = [None, None]  # (the previous pass's reductions were joined: no event of it is waited for again)
         out = self.saved_out  # head output before the (optional) final resample
         dpreds = dpreds.contiguous()

@@ -34,11 +34,10 @@ class _DBLossFunction(torch.autograd.Function):
         coef = torch.zeros(8, device=preds.device, dtype=torch.float32)
         if per_pixel == 1:
             ws = torch.empty(L.dbn_db_loss_ohem_ws_bytes(N, H, W) // 4 + 1, device=preds.device, dtype=torch.float32)
-            ws[:L.dbn_db_loss_ws_bytes() // 4].zero_()  # (the arrival counter of the in-kernel finalize must start at zero)
             check(L.dbn_db_loss_ohem_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
                                          losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_ohem_fwd')
         else:
-            ws = torch.zeros(L.dbn_db_loss_ws_bytes() // 4, device=preds.device, dtype=torch.float32)  # (zero arrival counter)
+            ws = torch.empty(L.dbn_db_loss_ws_bytes() // 4, device=preds.device, dtype=torch.float32)  # (scratch: the library clears its counter)
             fwd = L.dbn_db_loss_sum_fwd if per_pixel == 2 else L.dbn_db_loss_fwd
             check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, alpha, beta, float(negative_ratio), eps,
                       losses.data_ptr(), coef.data_ptr(), ws.data_ptr(), st), 'db_loss_fwd')

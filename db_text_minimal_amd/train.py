@@ -190,7 +190,6 @@ class DBTrainer:
         need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if per_pixel else L.dbn_db_loss_ws_bytes()) // 4 + 1
         if self._ws is None or self._ws.numel() < need:
             self._ws = engine_mod.device_empty(need, dev)
-            self._ws[:L.dbn_db_loss_ws_bytes() // 4].zero_()  # the arrival counter of the in-kernel finalize starts at zero (left zero)
         losses = engine_mod.device_empty(5, dev)
         fwd = L.dbn_db_loss_ohem_fwd if per_pixel else (L.dbn_db_loss_sum_fwd if reduction == 'sum' else L.dbn_db_loss_fwd)
         eng = self.model.engine
@@ -229,10 +228,10 @@ class DBTrainer:
             self._warm_arena_then_sync(img, gts)
         distributed = dist.is_available() and dist.is_initialized()
         if self.use_graph and eng.prof is None and not (distributed and self.overlap_allreduce):
+            self.optimizer.zero_grad()  # (before the backward pass, as on the eager path: the replay below counts as ONE pass)
             got = self._graph_step(img, gts, resident)
             if got is not None:
                 preds, losses = got
-                self.optimizer.zero_grad()
                 ev = self._exchange_event()
                 scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
                 self._exchange_event(ev)
@@ -292,6 +291,7 @@ class DBTrainer:
             # capture ran the host side of one step without executing it: undo its bookkeeping, replay() redoes it per launch
             G['nbt_delta'] = {k: v - nbt0.get(k, 0) for k, v in eng.nbt_pending.items() if v != nbt0.get(k, 0)}
             eng.nbt_pending, eng.generation = nbt0, gen0
+            eng.backwards_since_clear -= 1  # (the captured backward() counted itself without running: the replay below is the pass)
             G['graph'], G['preds'], G['losses'] = g, preds, losses
         if not (resident and G['src']):
             G['img'].copy_(img)

@@ -283,8 +283,8 @@ int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, const fl
 
 /* ---- DBLoss (losses.py:18-40,48-66,75-82,105-139); preds [N,3|2,H,W], gts [4,N,H,W].
  * One launch: the workgroup that finishes last folds every workgroup's partial sums (fixed order) and writes losses[5] and
- * coef[8].  ws: dbn_db_loss_ws_bytes() bytes, ZERO-FILLED by the caller before the first call (it ends with the arrival counter
- * of that hand-over, which every call leaves at zero); not shared between calls that may run concurrently. */
+ * coef[8].  ws: dbn_db_loss_ws_bytes() bytes of scratch, no initialisation required (it ends with the arrival counter of that
+ * hand-over, which the library clears on `stream` in front of every launch); not shared between calls that may run concurrently. */
 int dbn_db_loss_ws_bytes(void);
 int dbn_db_loss_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                     float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
@@ -297,8 +297,7 @@ int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int 
 
 /* DBLoss(reduction='none') — true per-pixel OHEM (losses.py:30-39 with a per-pixel BCE): the n_neg largest
  * negative losses are found by a 3-pass radix select on device (no sort, no host sync).  `ws` holds
- * dbn_db_loss_ohem_ws_bytes(N,H,W) bytes (the first dbn_db_loss_ws_bytes() of them zero-filled before the first call, as above)
- * and must stay untouched between _fwd and _bwd. */
+ * dbn_db_loss_ohem_ws_bytes(N,H,W) bytes (no initialisation required, as above) and must stay untouched between _fwd and _bwd. */
 long dbn_db_loss_ohem_ws_bytes(int N, int H, int W);
 int dbn_db_loss_ohem_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                          float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);

@@ -226,6 +226,7 @@ _DEAD_BIAS = ('conv.bias', '.0.bias', '.3.bias')
 
 # (golden, backbone, precision mode): the reference's own distance from fp64 at that precision is the yardstick
 _FP64_CASES = [('fp64_2x128', 'resnet18', 'f32'), ('fp64_r50_2x96', 'resnet50', 'f32'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'f32'),
+               ('fp64_2x128', 'resnet18', 'f32-direct'), ('fp64_r50_2x96', 'resnet50', 'f32-direct'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'f32-direct'),
                ('fp64_2x128', 'resnet18', 'bf16x3'), ('fp64_2x128', 'resnet18', 'bf16'), ('fp64_r50_2x96_bn3x02', 'resnet50', 'bf16'),
                ('fp64_r50_2x96', 'resnet50', 'bf16'), ('fp64_2x128', 'resnet18', 'bf16c')]
 
@@ -239,7 +240,8 @@ def test_distance_to_fp64_is_within_the_references_own(golden_dir, case, arch, m
     tests/test_oracle_golden.py).  Yardstick: how far the REFERENCE ITSELF is from that ground truth — in fp32 for the
     'f32' / 'bf16x3' modes, under torch.autocast('cpu', bfloat16) for the native 'bf16' mode (tests/golden/make_golden.py
     case_fp64).  Required of the HIP path:
-      per parameter tensor  |g_hip - g64| <= F_t * |g_ref - g64| + 2e-5 |g64|       (F_t = 2.0; round 3: 1.5 for fp32 — see below)
+      per parameter tensor  |g_hip - g64| <= F_t * |g_ref - g64| + 2e-5 |g64|       (F_t = 1.5 fp32 — 2.0 only for the <= 64-element
+                            tensors of the Winograd configuration, see below —, 2.0 bf16)
       whole model           |g_hip - g64| <= F_m * |g_ref - g64|                     (F_m = 1.2 fp32, 1.5 bf16)
       maps (strided sample) mean |map_hip - map64| <= 1.5 * reference's + 1e-6; P,T max likewise (+2e-5)
       losses                max_i |l_hip - l64| <= F_l * max_i |l_ref - l64| + 1e-5  (F_l = 1.5 fp32; 3.0 bf16: five scalars of a
@@ -259,14 +261,22 @@ def test_distance_to_fp64_is_within_the_references_own(golden_dir, case, arch, m
     assert np.allclose(l64, z['losses_f64'], rtol=1e-10)
     bf16 = math in ('bf16', 'bf16c')  # (bf16c: fp32 tensors, operands rounded to bf16 when staged — same yardstick)
     ref_tag, dist_tag = ('bf16ac', 'refbf16_dist/') if bf16 else ('f32', 'ref32_dist/')
-    # fp32, round 4: the 3x3 / stride-1 convs run through Winograd F(2x2,3x3) — fp32 arithmetic whose rounding error constant is about
-    # twice the direct sum's.  Whole-model distances stay BELOW the reference's own (measured 0.74x on the unconditioned resnet50,
-    # 0.8-1.0x elsewhere); single small tensors reach 1.65x (a 64-element BatchNorm bias), so the per-tensor factor is 2.0 as for bf16.
-    f_t, f_m = (2.0, 1.5) if bf16 else (2.0, 1.2)
+    # fp32: the 3x3 / stride-1 convs of the default path run through Winograd F(2x2,3x3) — fp32 arithmetic whose rounding error constant
+    # is about twice the direct sum's.  Whole-model distances stay BELOW the reference's own (measured 0.74x on the unconditioned
+    # resnet50, 0.8-1.0x elsewhere); ONE small tensor reaches 1.65x (a 64-element BatchNorm bias of the unconditioned resnet50).  Round 4
+    # had widened the per-tensor factor to 2.0 for every tensor of the fp32 mode (advisor finding); it is 1.5 again, as in round 3 —
+    # for every tensor of the direct configuration ('f32-direct': Winograd off, the exact k-ordered fmaf chain) and for every tensor
+    # of more than 64 elements of the default (Winograd) configuration; only its <= 64-element tensors keep 2.0.
+    direct = math == 'f32-direct'
+    math = 'f32' if direct else math
+    wino = math == 'f32' and not direct
+    f_t, f_m = (2.0, 1.5) if bf16 else (1.5, 1.2)
     model = make_model(seed, arch)
     model.load_state_dict(sd)
     model = model.train()
     model.engine.set_conv_math(math)
+    if direct:
+        model.engine.winograd = model.engine.winograd_wgrad = False
     tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
     preds, losses = tr.step(img.to(DEV), gts.to(DEV))
     # losses
@@ -292,7 +302,8 @@ def test_distance_to_fp64_is_within_the_references_own(golden_dir, case, arch, m
         ratio = d_hip / (d_ref + 2e-5 * nrm)
         if ratio > worst:
             worst, worst_k = ratio, k
-        if d_hip > f_t * d_ref + 2e-5 * nrm:
+        f_k = 2.0 if (wino and g.numel() <= 64) else f_t
+        if d_hip > f_k * d_ref + 2e-5 * nrm:
             bad.append((k, d_hip, d_ref, nrm))
     print('fp64 check: worst d_hip/d_ref %.3f (%s); whole-model |g_hip-g64| %.4e vs reference %.4e (ratio %.3f)' %
           (worst, worst_k, tot_h**0.5, tot_r**0.5, (tot_h / tot_r)**0.5))
@@ -581,7 +592,10 @@ def test_odd_size_vs_reference_golden(golden_dir):
             continue  # conv bias ahead of train-mode BN: analytically zero, reference value is round-off noise
         # ONE image of 96x70: the maps behind layer2..4 have 108 / 35 / 12 pixels, so a single ReLU-mask flip moves a
         # per-channel gradient element by up to ~5 % of the tensor's largest (measured 5.1 % on layer2.0.bn2.bias, cosine 0.9998)
-        check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k], sample_tol=0.10)
+        # — the default 5 % everywhere else, 7 % (the measured 5.1 % + margin; round 4: 10 % for every tensor) on the per-channel
+        # BatchNorm tensors of those three stages
+        small_map_bn = k.startswith(('backbone.layer2', 'backbone.layer3', 'backbone.layer4')) and ('.bn' in k or 'downsample.1' in k)
+        check_grad_summary(z, 'grad/' + k, model.engine.grad_views[k], sample_tol=0.07 if small_map_bn else 0.05)
     sd = model.state_dict()
     for f in z.files:
         if f.startswith('post/') and f.endswith('/stats'):

@@ -244,3 +244,25 @@ def test_deform_conv_oracle_properties():
     w = torch.randn(3, 2, 3, 3, generator=g, dtype=torch.double, requires_grad=True)
     off = (torch.rand(1, 18, 5, 6, generator=g, dtype=torch.double) * 1.6 - 0.8 + 0.013).requires_grad_(True)
     assert torch.autograd.gradcheck(lambda a, b, c: O.deform_conv2d(a, b, c, 1, 1), (x, off, w), eps=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize('arch', sorted(O.ARCHS))
+def test_fixture_inputs_equal_the_oracles_generators(golden_dir, arch):
+    """tests/golden/fixture_inputs.py regenerates a fixture's inputs (procedural weights, synthetic batch) without importing the
+    oracle — bench.py's parity gate uses it before its timed region.  Its copy of the generators must equal the oracle's (the
+    ones make_golden.py applied to the reference) bit for bit, for every architecture's key set."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fixture_inputs', os.path.join(golden_dir, 'fixture_inputs.py'))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    ref = O.new_state(16, arch)
+    mine = {k: torch.zeros_like(v) for k, v in ref.items()}
+    fx.procedural_fill(mine, 16)
+    kinds = {k: kind for k, _, kind in O.state_spec(arch)}
+    for k, v in ref.items():
+        assert fx.kind_of(k, mine) == kinds[k], k
+        assert torch.equal(v, mine[k]), k
+    for (n, size, seed, scale) in ((2, 32, 116, 1.0), (1, (24, 40), 5, 3.0)):
+        a, b = O.synthetic_batch(n, size, seed=seed, img_scale=scale), fx.synthetic_batch(n, size, seed=seed, img_scale=scale)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (fx.sample_idx(10**6, 4096) == sample_idx(10**6, 4096)).all()
