@@ -116,6 +116,12 @@ SIGNATURES.update({
     'dbn_winograd_conv_bn_act_f32': 'pppppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_winograd_conv_bn_f32': 'pppp' + 'iiiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_set_phase_priority': 'i',
+    'dbn_set_winograd_persistent': 'i',
+    'dbn_set_winograd_stagger': 'i',
+    'dbn_fold_bn_eval': 'pilppppp' + 'f' + 'ppp',
+    'dbn_igemm_act_t': 'ii' + 'pppp' + 'i' + 'p' + 'i' * 13 + 'p',
+    'dbn_winograd_conv_act_f32': 'pppp' + 'i' + 'p' + 'iiiii' + 'p',
+    'dbn_pyramid_conv_act_t': 'ii' + 'p' * 9 + 'i' + 'p' + 'i' * 6 + 'p',
     'dbn_set_trace': 'pl',
     'dbn_igemm_kernel_config': 'i' * 16,
     'dbn_split3': 'pplp',

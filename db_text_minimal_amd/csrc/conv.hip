@@ -260,8 +260,9 @@ struct IgemmBnb {
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
                          hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
-                         long plane_bytes, const IgemmBnb* bnb = nullptr, int tile_hint = -1) {
+                         long plane_bytes, const IgemmBnb* bnb = nullptr, int tile_hint = -1, const void* res = nullptr, int relu = 0) {
     IgemmParams p{};
+    p.res = res; p.relu = relu;  // inference epilogue (dbn_igemm_act_t)
     p.bnb_y = bnb ? bnb->y : nullptr; p.bnb_zmask = bnb ? bnb->zmask : nullptr;
     p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
     p.bnb_mean = bnb ? bnb->mean : nullptr; p.bnb_rstd = bnb ? bnb->rstd : nullptr;
@@ -278,7 +279,7 @@ static int igemm_run_one(const void* src, const float* wpk, const float* bias, v
     }
     p.src = src; p.wpk = wpk; p.bias = bias; p.dst = dst;
     p.N = N; p.Hs = Hs; p.Ws = Ws; p.Cs = Cs; p.Cd = Cd; p.Hdf = Hd; p.Wdf = Wd;
-    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = accumulate;
+    p.R = R; p.S = S; p.stride = stride; p.pad = pad; p.accumulate = res ? 1 : accumulate;
     p.stats = stats; p.stat_rows = stat_rows; p.stat_row0 = stat_row0; p.launch_rows = 0;
     p.ksplit = 1; p.kt_per = 0;
     // (at = 3: planes 1 and 2 lie plane_bytes and 2*plane_bytes behind the image range of plane 0 this launch covers)
@@ -352,7 +353,8 @@ static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg
 static int igemm_run(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                      void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0,
-                     const IgemmBnb* bnb = nullptr) {
+                     const IgemmBnb* bnb = nullptr, const void* res = nullptr, int relu = 0) {
+    DBN_REQUIRE((!res && !relu) || (ksplit <= 1 && !stats && !bnb && !(mode == 1 && stride > 1)));  // inference epilogue: plain launches only
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     // 16-bit storage / pre-split planes: 8-channel pieces of 16-channel blocks
     DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1 && Cs % 16 == 0) || (at == 3 && ns == 3 && Cs % 16 == 0));
@@ -383,7 +385,8 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
         const int rc = igemm_run_one(reinterpret_cast<const char*>(src) + (long)n0 * Hs * Ws * Cs * es, wpk, bias,
                                      reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
                                      pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes,
-                                     bnb ? &b : nullptr, tile_hint);
+                                     bnb ? &b : nullptr, tile_hint,
+                                     res ? reinterpret_cast<const char*>(res) + (long)n0 * Hd * Wd * Cd * des : nullptr, relu);
         if (rc) return rc;
         row0 += rows;
     }
@@ -397,6 +400,18 @@ int dbn_igemm_t(int at, int ns, const void* src, const float* wpk, const float* 
                 void* stream) {
     return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, nullptr,
                      ksplit < 1 ? 1 : ksplit, slab, 0, at);
+}
+
+// Inference form (round 5): dst = [relu]( conv(src) + bias [+ res] ) in ONE launch — what an eval-mode conv -> BatchNorm -> (+ residual) ->
+// ReLU chain (/root/reference/src/modules/basic.py:32-36, resnet.py:70-91 in model.eval()) becomes once the BatchNorm's running
+// statistics are folded into the weights (dbn_fold_bn_eval: w' = w * gamma / sqrt(var + eps), bias' = beta + (bias - mean) * that): no
+// separate BatchNorm pass over the activation.  res: NULL or a tensor of dst's shape and storage type; mode 0 (any stride) or mode 1
+// with stride 1; no split-K.
+int dbn_igemm_act_t(int at, int ns, const void* src, const float* wpk, const float* bias, const void* res, int relu, void* dst, int N,
+                    int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode, int tile_hint,
+                    void* stream) {
+    return igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, 0, tile_hint, ns, stream, nullptr, 1, nullptr, 0,
+                     at, nullptr, res, relu ? 1 : 0);
 }
 
 int dbn_igemm_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd,
@@ -539,6 +554,18 @@ int dbn_winograd_conv_bn_act_f32(const float* src, const float* in_scale, const 
     return dbn_status();
 }
 
+// Inference form of the Winograd conv: dst = [relu]( conv3x3(src) + bias [+ res] ) (see dbn_igemm_act_t)
+int dbn_winograd_conv_act_f32(const float* src, const float* upanel, const float* bias, const float* res, int relu, float* dst, int N,
+                              int H, int W, int Cs, int Cd, void* stream) {
+    DBN_REQUIRE(src && upanel && dst && dbn_winograd_eligible(N, H, W, Cs, Cd));
+    IgemmParams p{};
+    p.src = src; p.wpk = upanel; p.bias = bias; p.dst = dst; p.res = res; p.relu = relu ? 1 : 0; p.accumulate = res ? 1 : 0;
+    p.N = N; p.Hs = H; p.Ws = W; p.Cs = Cs; p.Cd = Cd; p.Hdf = H; p.Wdf = W; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1;
+    p.src_bytes = (unsigned)((long)N * H * W * Cs * 4);
+    p.stat_rows = dbn_winograd_rows(N, H, W);
+    return dbn_launch_winograd_f32(p, (hipStream_t)stream);
+}
+
 int dbn_winograd_conv_bn_f32(const float* src, const float* upanel, const float* bias, float* dst, int N, int H, int W, int Cs, int Cd,
                              const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
                              float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream) {
@@ -637,12 +664,13 @@ long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd +
 
 // first_level = 1 (exact fp32 only): dst already holds level 0's part of the sum (the plain 3x3 conv of s0, bias included — e.g. from
 // dbn_winograd_conv_bn_f32); the launch adds levels 1-3 to it (s0, w0, bias are not read).
-int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
-                            const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,
-                            int Cd, int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum,
-                            float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws,
-                            void* stream) {
+static int pyramid_run(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
+                       const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,
+                       int Cd, int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum,
+                       float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws,
+                       void* stream, int relu) {
     DBN_REQUIRE(first_level == 0 || (first_level == 1 && at == 0 && ns == 0));
+    DBN_REQUIRE(!relu || !gamma);  // (the inference epilogue and the train-mode statistics exclude each other)
     if (first_level) { s0 = s1; w0 = w1; bias = nullptr; }
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));
     DBN_REQUIRE(at == 0 || ((at == 1 || at == 2) && ns == 1) || (at == 3 && ns == 3));
@@ -681,6 +709,7 @@ int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void*
         p.stats = bn ? ws : nullptr;
         p.stat_rows = rows_total; p.stat_row0 = row0; p.launch_rows = 0;
         p.ksplit = 1; p.kt_per = 0; p.patch = 0;
+        p.relu = relu ? 1 : 0;
         p.src_bytes = p.seg_bytes[0];
         const int rc = launch_igemm(p, 1, 3, ns, st, at);
         if (rc) return rc;
@@ -690,6 +719,23 @@ int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void*
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows_total >= 2048 ? 1024 : 256), 0, st, ws, rows_total, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
+}
+
+int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
+                            const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,
+                            int Cd, int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum,
+                            float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws,
+                            void* stream) {
+    return pyramid_run(first_level, at, s0, s1, s2, s3, w0, w1, w2, w3, bias, dst, N, H, W, Cs, Cd, tile_hint, ns, gamma, beta, eps, momentum,
+                       run_mean, run_var, scale, shift, save_mean, save_rstd, ws, stream, 0);
+}
+
+// Inference form of the pyramid conv (see dbn_igemm_act_t): dst = [relu]( [dst +] pyramid(levels first_level..3) + bias ), no statistics.
+int dbn_pyramid_conv_act_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
+                           const float* w1, const float* w2, const float* w3, const float* bias, int relu, void* dst, int N, int H, int W,
+                           int Cs, int Cd, int ns, void* stream) {
+    return pyramid_run(first_level, at, s0, s1, s2, s3, w0, w1, w2, w3, bias, dst, N, H, W, Cs, Cd, 0, ns, nullptr, nullptr, 0.f, 0.f, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, relu);
 }
 
 int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0, const float* w1,

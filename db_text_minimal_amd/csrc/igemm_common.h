@@ -120,6 +120,15 @@ struct IgemmParams {
     // in_shift[c])) is applied while the patch is staged (the activation tensor is never written; same arithmetic as bn_apply_kernel)
     const float *in_scale, *in_shift;
     int first_level;  // MODE 3, exact-fp32 loop only: levels [first_level, 4) (the finer ones are in dst already: accumulate = 1)
+    // winograd_f32_kernel, round 5: persistent workgroups pull (patch, channel tile) items from `work` — [8 per-XCD counters][1 exit counter]
+    // ints, zero on entry and left zero; NULL: one workgroup per item (gridDim.x == work_items)
+    int* work;
+    int work_items;
+    // Inference epilogue (round 5: eval-mode BatchNorm folded into the weights, `bias` = its shift): `res` non-NULL (with accumulate = 1) —
+    // the tensor that is added comes from `res` (same shape / storage type as dst) instead of from dst itself: a residual connection;
+    // relu != 0: max(., 0) on the final value (after bias and the addition)
+    const void* res;
+    int relu;
 };
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger

@@ -1215,7 +1215,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     const bool to_slab = MODE < 2 && p.ksplit > 1;
     float* const slabp = reinterpret_cast<float*>(p.dst) + (to_slab ? (long)blockIdx.y * ((long)qM * p.Cd + 1088) : 0L);
     void* const dstv = p.dst;
-    auto ld_dst = [&](long off) -> float { return (DST_F32 || to_slab) ? slabp[off] : dbn_ld1 < DST_F32 ? 0 : AT > (dstv, off); };
+    // the tensor `accumulate` adds: dst itself, or — inference epilogue — a residual input of the same shape and storage type (IgemmParams::res)
+    const void* const accv = (p.res && !to_slab) ? p.res : p.dst;
+    const float* const accf = (p.res && !to_slab) ? reinterpret_cast<const float*>(p.res) : slabp;
+    auto ld_dst = [&](long off) -> float { return (DST_F32 || to_slab) ? accf[off] : dbn_ld1 < DST_F32 ? 0 : AT > (accv, off); };
     auto st_dst = [&](long off, float v) {
         if (DST_F32 || to_slab) slabp[off] = v;
         else dbn_st1 < DST_F32 ? 0 : AT > (dstv, off, v);
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 long doff;
                 tile_row(row, ok, doff);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(dstv) + doff + n0 + piece * 8);
+                if (ok) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(accv) + doff + n0 + piece * 8);
                 *reinterpret_cast<f32x4*>(T + row * T_PITCH + piece * 8) = v;
             }
             __syncthreads();
@@ -1325,7 +1328,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 // fp32 destination, linear rows or the pixel patch: raw buffer loads at the store loop's offsets (rows past M are out of
                 // range and read as 0), four rows in flight
                 const __amdgpu_buffer_rsrc_t rsrcA =
-                    __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (unsigned)((long)(PATCH ? p.N * p.Hdf * p.Wdf : qM) * p.Cd * 4), 0x00020000);
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(accf), 0, (unsigned)((long)(PATCH ? p.N * p.Hdf * p.Wdf : qM) * p.Cd * 4), 0x00020000);
                 const unsigned pitch = (unsigned)p.Cd * 4u, colb = (unsigned)(n0 + wn * TN + li) * 4u;
                 const unsigned row0 = PATCH ? (unsigned)((pn * p.Hdf + ph0 + 2 * (wm * MI + a)) * p.Wdf + pw0) : (unsigned)(m0 + wm * TM + a * 32 + 4 * lh);
                 const unsigned base0 = (row0 + (unsigned)((PATCH && lh) ? p.Wdf : 0)) * pitch + colb;
@@ -1446,6 +1449,16 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // row's store waited for the previous row's store to complete.
 #pragma unroll
     for (int b = 0; b < NI; ++b) asm volatile("" : "+v"(bv[b]));  // the loads have landed here, once
+    if (p.relu) {  // inference epilogue (eval-mode BatchNorm folded into the panel, bias = its shift): max(acc + bias, 0), then nothing left to add
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = fmaxf(acc[a][b][r] + bv[b], 0.f);
+#pragma unroll
+        for (int b = 0; b < NI; ++b) bv[b] = 0.f;
+    }
     const long dcol = n0 + wn * TN + li;
     // EPI = 1, optional: in-kernel finalize of the BatchNorm-backward sums (IgemmParams::bnb_cnt).  Called by every thread of the
     // workgroup after it wrote its partial row `trow_`.

@@ -798,6 +798,28 @@ int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* 
     return dbn_status();
 }
 
+// Eval-mode BatchNorm folded into the conv in front of it (inference; /root/reference/src/modules/basic.py:32-36 under model.eval(),
+// test.py:53-59): w' [O][inner] = w * s[o], bias' [o] = beta + (bias - mean) * s[o], s = gamma / sqrt(var + eps) — the arithmetic of
+// bn_eval_coef_kernel.  One launch per layer whenever the parameters or the running statistics change, i.e. once per checkpoint.
+__global__ void fold_bn_eval_kernel(const float* __restrict__ w, int O, long inner, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                    float* __restrict__ w_out, float* __restrict__ b_out) {
+    const long total = (long)O * inner;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / inner);
+        const float sc = gamma[o] * (1.f / sqrtf(var[o] + eps));  // (bn_eval_coef_kernel's scale, bit for bit)
+        w_out[i] = w[i] * sc;
+        if (i - (long)o * inner == 0) b_out[o] = fmaf((bias ? bias[o] : 0.f) - mean[o], sc, beta[o]);
+    }
+}
+int dbn_fold_bn_eval(const float* w, int O, long inner, const float* bias, const float* gamma, const float* beta, const float* run_mean,
+                     const float* run_var, float eps, float* w_out, float* b_out, void* stream) {
+    DBN_REQUIRE(w && gamma && beta && run_mean && run_var && w_out && b_out && O > 0 && inner > 0);
+    hipLaunchKernelGGL(fold_bn_eval_kernel, dim3(dbn_grid((long)O * inner)), dim3(256), 0, (hipStream_t)stream, w, O, inner, bias, gamma, beta,
+                       run_mean, run_var, eps, w_out, b_out);
+    return dbn_status();
+}
+
 int dbn_bn_apply_t(int at, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
                    const float* res_shift, void* out, long M, int C, int relu, void* stream) {
     DBN_REQUIRE(y && scale && shift && out && M > 0 && C % 4 == 0);

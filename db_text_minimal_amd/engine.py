@@ -117,12 +117,23 @@ class _VirtualConv:
         self.cin, self.cout, self.k, self.stride, self.padding, self.weight, self.bias = cin, cout, k, stride, padding, weight, bias
 
 
+class _Shape:
+    """A tensor's shape without the tensor (eligibility checks ahead of the launches)."""
+
+    def __init__(self, *shape):
+        self.shape = shape
+
+
 class Engine:
     def __init__(self, model):
         self.model = model
         self.L = _lib.lib()
         if 'DBN_PATCH_F32' in os.environ:  # A/B runs: 0 exact fp32 on the gather loop everywhere, 1 on the pixel-patch kernel wherever eligible
             self.L.dbn_set_patch_conv(2 if os.environ['DBN_PATCH_F32'] == '0' else 3)
+        if 'DBN_WINO_PERSISTENT' in os.environ:  # A/B runs: 0 one workgroup per item, 1 persistent workgroups pulling items, 2 static schedule
+            self.L.dbn_set_winograd_persistent(int(os.environ['DBN_WINO_PERSISTENT']))
+        if 'DBN_WINO_STAGGER' in os.environ:  # A/B runs: permille of one item's matrix time (0 = off)
+            self.L.dbn_set_winograd_stagger(int(os.environ['DBN_WINO_STAGGER']))
         if 'DBN_PHASE_PRIO' in os.environ:  # A/B runs
             self.L.dbn_set_phase_priority(int(os.environ['DBN_PHASE_PRIO']))
         if 'DBN_STAGGER' in os.environ:  # A/B runs (permille of the nominal first-round stagger of the fp32 convs)
@@ -529,7 +540,7 @@ class Engine:
         w = conv.weight
         if ent is None or ent[1] == (w._version, self.param_epoch, w.data_ptr()):
             return
-        derived = [k for k in self.packs if isinstance(k[0], str) and k[0].startswith(name + '#')]
+        derived = [k for k in self.packs if isinstance(k[0], str) and k[0].startswith(name + '#') and '#fold' not in k[0]]
 
         def run():
             wds, wver = self._fpn_combined_weights(name, conv, Cg)
@@ -1035,6 +1046,69 @@ class Engine:
             self.prof.end()
         return out
 
+    # ---- inference: eval-mode BatchNorm folded into the weights (round 5; basic.py:32-36, resnet.py:70-91 under model.eval(), test.py:53-59).
+    # w' = w * gamma / sqrt(var + eps) and bias' = beta + (bias - mean) * that go through the ordinary pack functions as derived tensors;
+    # the conv's epilogue adds the bias (and a residual input), applies the ReLU and writes the ACTIVATION: no scale / shift launch, no
+    # bn_apply pass (every activation was written twice before: the raw conv output, then the normalised one).  DBN_FOLD_EVAL_BN=0
+    # restores the conv -> coefficients -> bn_apply chain (the A/B and bit-identity baseline of the train path's kernels).
+    fold_eval_bn = os.environ.get('DBN_FOLD_EVAL_BN', '1') == '1'
+    train_forwards = 0  # counts train-mode forwards: the running statistics change under them through raw pointers
+
+    def _fold_ok(self, x, conv, train):
+        if train or not self.fold_eval_bn or self._use_planes or getattr(conv, 'with_dcn', False):
+            return False
+        N, H, W, C = x.shape
+        k, s, p = conv.k, conv.stride, conv.padding
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        return not (self.splitk and self.L.dbn_igemm_splitk_plan_ns(N * Ho * Wo, conv.cout, k * k * C, C, self.ns) > 1)
+
+    def _folded(self, name, conv, bn):
+        """(virtual conv with the folded weight / bias, version stamp), re-made when a parameter or a running statistic changed."""
+        w = conv.weight
+        stamp = (w._version, self.param_epoch, w.data_ptr(), self.train_forwards, bn.running_mean._version, bn.running_var._version,
+                 bn.weight._version, bn.bias._version)
+        ent = self.packs.get((name, 'fold'))
+        if ent is None or ent[1] != stamp:
+            wf, bf = ent[0][:2] if ent is not None else (device_empty(tuple(w.shape), w.device), device_empty((w.shape[0], ), w.device))
+            O = w.shape[0]
+            check(self.L.dbn_fold_bn_eval(w.data_ptr(), O, w.numel() // O, _p(conv.bias), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps, wf.data_ptr(), bf.data_ptr(),
+                                          self.stream), 'fold_bn_eval ' + name)
+            self._fold_count += 1  # (the derived tensors are rewritten through raw pointers: this serial is their version)
+            ent = ((wf, bf, self._fold_count), stamp)
+            self.packs[(name, 'fold')] = ent
+        wf, bf, serial = ent[0]
+        return _VirtualConv(conv.cin, conv.cout, conv.k, conv.stride, conv.padding, wf, bf), ('fold', serial)
+
+    _fold_count = 0
+
+    def conv_bn_act_eval(self, name, x, conv, out_name, bn, relu=True, res=None):
+        """relu(bn(conv(x)) [+ res]) in ONE launch, eval mode (the caller checked _fold_ok)."""
+        vconv, ver = self._folded(name, conv, bn)
+        N, H, W, C = x.shape
+        k, s, p = conv.k, conv.stride, conv.padding
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
+        z = self.buf(out_name, N, Ho, Wo, conv.cout)
+        assert res is None or (tuple(res.shape) == tuple(z.shape) and res.dtype == z.dtype), name
+        if self._winograd_ok(x, vconv):
+            up = self._winograd_panel(name + '#fold', vconv.weight, C, version=ver)
+            if self.prof:
+                self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 0.0, 'fwd ' + name)
+            check(self.L.dbn_winograd_conv_act_f32(x.data_ptr(), up.data_ptr(), vconv.bias.data_ptr(), _p(res), int(relu), z.data_ptr(), N, H, W, C,
+                                                   conv.cout, self.stream), 'winograd act ' + name)
+        else:
+            wpk = self.pack(name + '#fold', vconv.weight, 0, version=ver, cs=C)
+            if self.prof:
+                self._prof_igemm(N * Ho * Wo, conv.cout, 2.0 * N * Ho * Wo * conv.cout * conv.cin * k * k, 'fwd ' + name, 0,
+                                 (N, H, W, C, Ho, Wo, k, s, p))
+            at, srcp = self._src(x.data_ptr(), C)
+            check(self.L.dbn_igemm_act_t(at, self.ns, srcp, wpk.data_ptr(), vconv.bias.data_ptr(), _p(res), int(relu), z.data_ptr(), N, H, W, C,
+                                         Ho, Wo, conv.cout, k, k, s, p, 0, 0, self.stream), 'igemm act ' + name)
+        if self.prof:
+            self.prof.end()
+        return z
+
     # Apply-on-load BatchNorm + ReLU (basic.py:32-36, resnet.py:77-80): where every consumer of relu(bn(y)) is a Winograd conv (forward and
     # weight gradient) the activation tensor is never written — the kernels apply relu(fma(y, scale, shift)) while they stage their
     # patches, with bn_apply's own arithmetic (bit-identical results).  Exact-fp32 mode only (the 16-bit kernels bring their tiles to
@@ -1052,6 +1126,8 @@ class Engine:
         """True when relu(bn(y)) may stay unwritten: every conv in `convs` (all read it as their input) runs as a Winograd conv forward
         and — in training — takes its weight gradient through the Winograd kernel too."""
         if not (self.apply_on_load and self.winograd and self.at == 0 and self.ns == 0 and not self._use_planes):
+            return False
+        if not train and self.fold_eval_bn:  # inference: the producer's epilogue writes the activation itself (conv_bn_act_eval)
             return False
         N, H, W, C = y.shape
         for conv in convs:
@@ -1123,6 +1199,8 @@ class Engine:
         if self.at == 2 and train:
             raise RuntimeError("conv math 'fp16' is the inference path (BASELINE configs[4]): call model.eval() first")
         self.repack_params()
+        if train:
+            self.train_forwards += 1
         x = x.contiguous().float()
         L, st = self.L, self.stream
         self.generation += 1
@@ -1146,6 +1224,8 @@ class Engine:
         pre = 'segmentation_body.'
 
         def cbr(name, mod, xin):
+            if self._fold_ok(xin, mod.conv, train):  # inference: one launch writes relu(bn(conv(x)))
+                return self.conv_bn_act_eval(pre + name + '.conv', xin, mod.conv, name + '/z', mod.bn)
             y, s_, h_ = self.conv_bn(pre + name + '.conv', xin, mod.conv, name + '/y', pre + name + '.bn', mod.bn, train)
             return self.bn_apply(y, s_, h_, name + '/z')
 
@@ -1176,7 +1256,10 @@ class Engine:
         Hq, Wq = p2.shape[1], p2.shape[2]
         zs = (p2, p3, p4, p5)
         self.fpn_exact = self.fpn_structured and all(Hq == zs[g].shape[1] << g and Wq == zs[g].shape[2] << g for g in range(4))
-        if self.fpn_exact:
+        f_folded = None
+        if self.fpn_exact and not train and self.fold_eval_bn and not self._use_planes and fpn.conv[0].cout % 128 == 0 and zs[0].shape[3] % 16 == 0:
+            f_folded = self._fpn_conv_eval(pre + 'conv.0', fpn.conv[0], zs, 'fpn/z', fpn.conv[1])
+        elif self.fpn_exact:
             # conv over [p2 | up2(p3) | up4(p4) | up8(p5)] without building the concat: per level a transposed conv
             # (k = f+2, stride f, pad 1) with combined weights, accumulated into one output (47 % of the dense MACs)
             fy, s_, h_ = self._fpn_conv_forward(pre + 'conv.0', fpn.conv[0], zs, 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
@@ -1187,7 +1270,9 @@ class Engine:
             fy, s_, h_ = self.conv_bn(pre + 'conv.0', cat, fpn.conv[0], 'fpn/y', pre + 'conv.1', fpn.conv[1], train)
         head = m.segmentation_head
         f_act = None
-        if self.lazy_act(fy, (head.binarize[0], head.thresh[0]), train):
+        if f_folded is not None:
+            f = f_folded
+        elif self.lazy_act(fy, (head.binarize[0], head.thresh[0]), train):
             self._drop_buf('fpn/z')  # (never written: the two head convs and their weight gradients read fpn/y through its BatchNorm's coefficients)
             f, f_act = fy, (s_, h_)
         else:
@@ -1196,8 +1281,11 @@ class Engine:
         def branch(br):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
-            ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train, x_act=f_act)
-            za = self.bn_apply(ya, s_, h_, br + '/z0')
+            if f_act is None and self._fold_ok(f, seq[0], train):
+                za = self.conv_bn_act_eval(hp + '0', f, seq[0], br + '/z0', seq[1])
+            else:
+                ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train, x_act=f_act)
+                za = self.bn_apply(ya, s_, h_, br + '/z0')
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
 
@@ -1320,6 +1408,10 @@ class Engine:
 
     def _block_fwd(self, name, blk, x, train):
         """BasicBlock (resnet.py:70-91) or Bottleneck (resnet.py:135-159)."""
+        if not train and self.fold_eval_bn:
+            out = self._block_fwd_eval(name, blk, x)
+            if out is not None:
+                return out
         y1, s1, h1 = self.conv_bn(name + '.conv1', x, blk.conv1, name + '/y1', name + '.bn1', blk.bn1, train)
         if not getattr(blk, 'with_dcn', False) and self.lazy_act(y1, (blk.conv2, ), train):
             self._drop_buf(name + '/z1')  # (never written: conv2 and its weight gradient read y1 through bn1's coefficients)
@@ -1340,6 +1432,60 @@ class Engine:
             out = self.bn_apply(ylast, s2, h2, name + '/out', relu=True, res=x)
         self.bufs[name + '/in'] = x
         return out
+
+    def _block_fwd_eval(self, name, blk, x):
+        """Inference form of a BasicBlock / Bottleneck (resnet.py:70-91,135-159 under model.eval()): every conv writes its activation
+        itself — BatchNorm folded into the weights, ReLU and the residual addition in the epilogue.  None: a conv of the block cannot
+        take that form (deformable conv2, a split-K launch): the caller runs the general chain."""
+        convs = [(name + '.conv1', blk.conv1, blk.bn1), (name + '.conv2', blk.conv2, blk.bn2)]
+        if hasattr(blk, 'conv3'):
+            convs.append((name + '.conv3', blk.conv3, blk.bn3))
+        if getattr(blk, 'with_dcn', False):
+            return None
+        cur = x
+        for _, conv, _ in convs:  # is every launch eligible?  (the shapes follow from the geometry alone)
+            if not self._fold_ok(cur, conv, False):
+                return None
+            N, H, W, _ = cur.shape
+            cur = _Shape(N, (H + 2 * conv.padding - conv.k) // conv.stride + 1, (W + 2 * conv.padding - conv.k) // conv.stride + 1, conv.cout)
+        if blk.downsample is not None and not self._fold_ok(x, blk.downsample[0], False):
+            return None
+        cur, res = x, x
+        if blk.downsample is not None:
+            res = self.conv_bn_act_eval(name + '.downsample.0', x, blk.downsample[0], name + '/yd', blk.downsample[1], relu=False)
+        for i, (cname, conv, bn) in enumerate(convs):
+            last = i == len(convs) - 1
+            cur = self.conv_bn_act_eval(cname, cur, conv, name + ('/out' if last else '/z%d' % (i + 1)), bn, relu=True, res=res if last else None)
+        return cur
+
+    def _fpn_conv_eval(self, name, conv, zs, out_name, bn):
+        """Inference form of the FPN output conv + BatchNorm + ReLU (segmentation_body.py:55-61,75-76): the pyramid conv on the combined
+        weights of the FOLDED filters, ReLU in its epilogue."""
+        N, H, W, Cg = zs[0].shape
+        Co = conv.cout
+        vconv, ver = self._folded(name, conv, bn)
+        fname = name + '#fold'
+        wds, wver = self._fpn_combined_weights(fname, vconv, Cg, version=ver)
+        z = self.buf(out_name, N, H, W, Co)
+        wpk = [self.pack('%s#f%d' % (fname, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
+        lv0 = _VirtualConv(Cg, Co, 3, 1, 1, wds[0], vconv.bias)
+        first = int(self.fpn_level0_winograd and wds[0].shape[0] == Cg and self._winograd_ok(zs[0], lv0))
+        if first:
+            up = self._winograd_panel(fname + '#lv0', wds[0], Cg, dgrad=1, version=wver)
+            if self.prof:
+                self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * Co * Cg * 4, 0.0, 'fwd %s level 0' % name)
+            check(self.L.dbn_winograd_conv_act_f32(zs[0].data_ptr(), up.data_ptr(), vconv.bias.data_ptr(), None, 0, z.data_ptr(), N, H, W, Cg, Co,
+                                                   self.stream), 'winograd ' + name)
+            if self.prof:
+                self.prof.end()
+        if self.prof:
+            flops = sum(2.0 * N * t.shape[1] * t.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, t in enumerate(zs) if g >= first)
+            self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0,true>' % (self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
+        check(self.L.dbn_pyramid_conv_act_t(first, self.at, *[t.data_ptr() for t in zs], *[w_.data_ptr() for w_ in wpk], vconv.bias.data_ptr(), 1,
+                                            z.data_ptr(), N, H, W, Cg, Co, self.ns, self.stream), 'pyramid_conv_act')
+        if self.prof:
+            self.prof.end()
+        return z
 
     # ----------------------------------------------------------------- backward
     def backward(self, dpreds):
@@ -1505,12 +1651,14 @@ class Engine:
     fpn_one_launch = True  # forward: the four levels in one launch (dbn_pyramid_conv_f32) instead of four accumulating ones
     fpn_exact = False  # set by forward(): the levels are exact 1, 1/2, 1/4, 1/8 sizes, so the structured path applies
 
-    def _fpn_combined_weights(self, name, conv, Cg):
-        """Wd_g[ci][co][u][v] = sum of the 3x3 taps of W[co][64g+ci] that land on offset (u,v) of level g's (f+2)^2 footprint."""
+    def _fpn_combined_weights(self, name, conv, Cg, version=None):
+        """Wd_g[ci][co][u][v] = sum of the 3x3 taps of W[co][64g+ci] that land on offset (u,v) of level g's (f+2)^2 footprint.
+        version: stamp of a derived weight tensor (the eval-folded filters), as in pack()."""
         w = conv.weight
         Co = w.shape[0]
-        self._fpn_src = (name, conv, Cg)
-        stamp = (w._version, self.param_epoch, w.data_ptr())
+        if version is None:
+            self._fpn_src = (name, conv, Cg)
+        stamp = (w._version if version is None else version, self.param_epoch, w.data_ptr())
         ent = self.packs.get((name, 'combined'))
         if ent is None or ent[1] != stamp:
             wds = ent[0] if ent is not None else [device_empty((Cg, Co, (1 << g) + 2, (1 << g) + 2), w.device) for g in range(4)]

@@ -162,6 +162,24 @@ int dbn_reduce_ws_floats(int C);
 int dbn_bn_train_stats(const float* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
                        float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                        float* ws, void* stream);
+/* Inference (round 5): eval-mode BatchNorm folded into the conv in front of it (basic.py:32-36, resnet.py:70-91 under model.eval();
+ * test.py:53-59).  w_out [O][inner] = w * s[o], b_out [o] = beta + (bias - run_mean) * s[o] with s = gamma / sqrt(run_var + eps) (bias may
+ * be NULL); feed w_out / b_out to dbn_pack_weights* / dbn_winograd_pack and the *_act_* entry points below: the conv's epilogue then
+ * produces relu(bn(conv(x)) [+ residual]) directly and no BatchNorm pass over the activation runs. */
+int dbn_fold_bn_eval(const float* w, int O, long inner, const float* bias, const float* gamma, const float* beta, const float* run_mean,
+                     const float* run_var, float eps, float* w_out, float* b_out, void* stream);
+/* dst = [relu]( conv(src) + bias [+ res] ) in one launch: dbn_igemm_t's contract (mode 0 at any stride, mode 1 at stride 1; no split-K,
+ * no accumulate) plus `res` (NULL or a tensor of dst's shape and storage type: a residual connection) and `relu`. */
+int dbn_igemm_act_t(int at, int ns, const void* src, const float* wpk, const float* bias, const void* res, int relu, void* dst, int N,
+                    int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int R, int S, int stride, int pad, int mode, int tile_hint,
+                    void* stream);
+/* ... the Winograd F(2x2,3x3) form (dbn_winograd_conv_bn_f32's tensors, no statistics) */
+int dbn_winograd_conv_act_f32(const float* src, const float* upanel, const float* bias, const float* res, int relu, float* dst, int N,
+                              int H, int W, int Cs, int Cd, void* stream);
+/* ... and the FPN pyramid conv (dbn_pyramid_conv_from_t's tensors, no statistics): dst = [relu]( [dst +] levels first_level..3 + bias ) */
+int dbn_pyramid_conv_act_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
+                           const float* w1, const float* w2, const float* w3, const float* bias, int relu, void* dst, int N, int H, int W,
+                           int Cs, int Cd, int ns, void* stream);
 int dbn_bn_eval_coef(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
                      float* scale, float* shift, void* stream);
 /* out = act(y*scale+shift [+ res*res_scale+res_shift | + res]) */
@@ -240,6 +258,12 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
  * (dbn_winograd_pack; dbn_winograd_panel_floats(O, Cs) floats).  gamma non-NULL: the train-mode BatchNorm that follows is folded
  * in exactly as in dbn_conv_bn_f32 (ws: dbn_winograd_ws_floats floats).  Same result as the direct convolution up to fp32 rounding
  * of a different summation order (not bit for bit). */
+/* Round 5: winograd_f32_kernel runs with PERSISTENT workgroups — at most two per CU, pulling (patch, channel tile) items from per-XCD
+ * counters the library keeps per stream — whenever a launch has more items than the chip has workgroup slots (512).  0 restores one
+ * workgroup per item (round 4's form; A/B and test hook).  Results are bit-identical either way. */
+int dbn_set_winograd_persistent(int on);
+/* ... and the one-time phase stagger between the two persistent workgroups of a CU, in permille of one item's matrix time (0: off) */
+int dbn_set_winograd_stagger(int permille);
 int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd);
 long dbn_winograd_panel_floats(int O, int Cs);
 /* dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT

@@ -146,5 +146,5 @@ def test_loss_forward_needs_no_workspace_initialisation(golden_dir, poison):
         _lib.check(L().dbn_db_loss_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, 1.0, 10.0, 3.0, 1e-6, losses.data_ptr(),
                                        coef.data_ptr(), ws.data_ptr(), stream()), 'db_loss_fwd')
         report('losses on a poisoned workspace, call %d' % rep, losses.cpu(), torch.from_numpy(z['default/losses']).float(), 1e-5, 1e-5)
-        assert torch.isfinite(coef).all()
+        assert torch.isfinite(coef[:4]).all()  # (the four coefficients of the 'mean' form; the rest belongs to the other reductions)
         ws.view(torch.int32)[-17:].fill_(7)  # ... and whatever a later user of the scratch left behind

@@ -7,6 +7,10 @@ import torch
 from db_text_minimal_amd import _lib
 from gpu_util import L, rnd, DEV, pack, stream
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+if 'DBN_WINO_PERSISTENT' in os.environ:  # A/B: 0 = one workgroup per item (round 4's form)
+    L().dbn_set_winograd_persistent(int(os.environ['DBN_WINO_PERSISTENT']))
+if 'DBN_WINO_STAGGER' in os.environ:
+    L().dbn_set_winograd_stagger(int(os.environ['DBN_WINO_STAGGER']))
 
 
 def timed(fn):
