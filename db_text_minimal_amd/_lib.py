@@ -118,6 +118,7 @@ SIGNATURES.update({
     'dbn_set_phase_priority': 'i',
     'dbn_set_winograd_persistent': 'i',
     'dbn_set_winograd_stagger': 'i',
+    'dbn_set_winograd_blocks_per_barrier': 'i',
     'dbn_fold_bn_eval': 'pilppppp' + 'f' + 'ppp',
     'dbn_igemm_act_t': 'ii' + 'pppp' + 'i' + 'p' + 'i' * 13 + 'p',
     'dbn_winograd_conv_act_f32': 'pppp' + 'i' + 'p' + 'iiiii' + 'p',

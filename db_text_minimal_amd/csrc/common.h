@@ -145,6 +145,28 @@ __device__ __forceinline__ f32x4 dbn_ld4(const void* __restrict__ p, long i4) {
     }
 }
 
+// Q consecutive channel quads per item with ONE 16-byte access: Q = 1 for fp32 (dbn_ld4), Q = 2 for the 16-bit types (eight elements:
+// the 8-byte accesses of dbn_ld4<1|2> reach 0.54-0.70x the rate of 16-byte ones, MI355X_MICROARCH.md; round 5)
+template <int AT>
+struct dbn_quads { static constexpr int Q = AT == 0 ? 1 : 2; };
+template <int AT>
+__device__ __forceinline__ void dbn_ldq(const void* __restrict__ p, long i, f32x4 (&v)[dbn_quads<AT>::Q]) {
+    if constexpr (AT == 0) {
+        v[0] = reinterpret_cast<const f32x4*>(p)[i];
+    } else if constexpr (AT == 1) {
+        typedef unsigned dbn_u32x4_ __attribute__((ext_vector_type(4)));
+        const dbn_u32x4_ w = reinterpret_cast<const dbn_u32x4_*>(p)[i];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            v[q] = f32x4{__builtin_bit_cast(float, w[2 * q] << 16), __builtin_bit_cast(float, w[2 * q] & 0xFFFF0000u),
+                         __builtin_bit_cast(float, w[2 * q + 1] << 16), __builtin_bit_cast(float, w[2 * q + 1] & 0xFFFF0000u)};
+    } else {
+        typedef _Float16 dbn_f16x8_ __attribute__((ext_vector_type(8)));
+        const dbn_f16x8_ w = reinterpret_cast<const dbn_f16x8_*>(p)[i];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v[q] = f32x4{(float)w[4 * q], (float)w[4 * q + 1], (float)w[4 * q + 2], (float)w[4 * q + 3]};
+    }
+}
 template <int AT>
 __device__ __forceinline__ void dbn_st4(void* __restrict__ p, long i4, f32x4 v) {
     if constexpr (AT == 0) {
@@ -154,6 +176,30 @@ __device__ __forceinline__ void dbn_st4(void* __restrict__ p, long i4, f32x4 v) 
         reinterpret_cast<dbn_u32x2*>(p)[i4] = dbn_u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
     } else {
         reinterpret_cast<dbn_f16x4*>(p)[i4] = dbn_f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+}
+template <int AT>
+__device__ __forceinline__ void dbn_stq(void* __restrict__ p, long i, const f32x4 (&v)[dbn_quads<AT>::Q]) {
+    if constexpr (AT == 0) {
+        reinterpret_cast<f32x4*>(p)[i] = v[0];
+    } else if constexpr (AT == 1) {
+        typedef unsigned dbn_u32x4_ __attribute__((ext_vector_type(4)));
+        dbn_u32x4_ w;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const dbn_bf16x2 lo = {(__bf16)v[q][0], (__bf16)v[q][1]}, hi = {(__bf16)v[q][2], (__bf16)v[q][3]};
+            w[2 * q] = __builtin_bit_cast(unsigned, lo);
+            w[2 * q + 1] = __builtin_bit_cast(unsigned, hi);
+        }
+        reinterpret_cast<dbn_u32x4_*>(p)[i] = w;
+    } else {
+        typedef _Float16 dbn_f16x8_ __attribute__((ext_vector_type(8)));
+        dbn_f16x8_ w;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[4 * q + e] = (_Float16)v[q][e];
+        reinterpret_cast<dbn_f16x8_*>(p)[i] = w;
     }
 }
 

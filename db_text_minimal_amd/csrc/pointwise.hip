@@ -110,54 +110,89 @@ __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, cons
     shift[c] = fmaf(-run_mean[c], sc, beta[c]);
 }
 
-// out = act(y*sc+sh [+ res*rsc+rsh | + res])
-template <int AT>
+// out = act(y*sc+sh [+ res*rsc+rsh | + res]).  An item is QW channel quads moved by one 16-byte access (QW = 1: four fp32 channels; QW = 2,
+// 16-bit storage with C % 8 == 0: eight channels — round 5: the 8-byte accesses of the four-channel form ran the bf16 / fp16 passes at
+// 0.55-0.7 of the 16-byte rate); `total` counts items, C / (4 QW) items per pixel.
+template <int AT, int QW>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ y, const float* __restrict__ sc,
                                                        const float* __restrict__ sh, const void* __restrict__ res,
                                                        const float* __restrict__ rsc, const float* __restrict__ rsh,
-                                                       void* __restrict__ out, long total4, int C, int relu) {
-    const int c4n = C >> 2;
-    // the grid stride is a multiple of C/4 (host side), so a thread keeps its channel quad: per-channel coefficients are
+                                                       void* __restrict__ out, long total, int C, int relu) {
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
+    // the grid stride is a multiple of the items per pixel (host side), so a thread keeps its channels: per-channel coefficients are
     // loaded once, and no 64-bit modulo sits in the streaming loop
     const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
-    const int c = (int)(i0 % c4n) * 4;
-    const f32x4 s = *reinterpret_cast<const f32x4*>(sc + c);
-    const f32x4 h = *reinterpret_cast<const f32x4*>(sh + c);
-    f32x4 s2 = s, h2 = h;
-    if (res && rsc) {
-        s2 = *reinterpret_cast<const f32x4*>(rsc + c);
-        h2 = *reinterpret_cast<const f32x4*>(rsh + c);
+    const int c = (int)(i0 % cin) * 4 * QW;
+    f32x4 s[QW], h[QW], s2[QW], h2[QW];
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        s[q] = *reinterpret_cast<const f32x4*>(sc + c + 4 * q);
+        h[q] = *reinterpret_cast<const f32x4*>(sh + c + 4 * q);
+        s2[q] = s[q];
+        h2[q] = h[q];
+        if (res && rsc) {
+            s2[q] = *reinterpret_cast<const f32x4*>(rsc + c + 4 * q);
+            h2[q] = *reinterpret_cast<const f32x4*>(rsh + c + 4 * q);
+        }
     }
-    auto one = [&](f32x4 v, f32x4 r) {
-        f32x4 o;
+    auto ld = [&](const void* ptr, long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(ptr, i);
+        else dbn_ldq<AT>(ptr, i, v);
+    };
+    auto st = [&](long i, const f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) dbn_st4<AT>(out, i, v[0]);
+        else dbn_stq<AT>(out, i, v);
+    };
+    auto one = [&](long i, const f32x4 (&v)[QW], const f32x4 (&r)[QW]) {
+        f32x4 o[QW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = dbn_affine(v[e], s[e], h[e]);
-        if (res) {
-            if (rsc) {
+        for (int q = 0; q < QW; ++q) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += dbn_affine(r[e], s2[e], h2[e]);
-            } else {
-                o += r;
+            for (int e = 0; e < 4; ++e) o[q][e] = dbn_affine(v[q][e], s[q][e], h[q][e]);
+            if (res) {
+                if (rsc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[q][e] += dbn_affine(r[q][e], s2[q][e], h2[q][e]);
+                } else {
+                    o[q] += r[q];
+                }
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[q][e] = fmaxf(o[q][e], 0.f);
             }
         }
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-        }
-        return o;
+        st(i, o);
     };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     long i = i0;
-    for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // UNROLL (x2 with a residual) loads in flight per lane
-        f32x4 v[UNROLL], r[UNROLL];
+    for (; i + (UNROLL - 1) * stride < total; i += UNROLL * stride) {  // UNROLL (x2 with a residual) loads in flight per lane
+        f32x4 v[UNROLL][QW], r[UNROLL][QW];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) v[u] = dbn_ld4<AT>(y, i + u * stride);
+        for (int u = 0; u < UNROLL; ++u) ld(y, i + u * stride, v[u]);
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) r[u] = res ? dbn_ld4<AT>(res, i + u * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UNROLL; ++u) {
+            if (res) ld(res, i + u * stride, r[u]);
+            else {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) dbn_st4<AT>(out, i + u * stride, one(v[u], r[u]));
+                for (int q = 0; q < QW; ++q) r[u][q] = zero;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) one(i + u * stride, v[u], r[u]);
     }
-    for (; i < total4; i += stride) dbn_st4<AT>(out, i, one(dbn_ld4<AT>(y, i), res ? dbn_ld4<AT>(res, i) : f32x4{0.f, 0.f, 0.f, 0.f}));
+    for (; i < total; i += stride) {
+        f32x4 v[QW], r[QW];
+        ld(y, i, v);
+        if (res) ld(res, i, r);
+        else {
+#pragma unroll
+            for (int q = 0; q < QW; ++q) r[q] = zero;
+        }
+        one(i, v, r);
+    }
 }
 
 // backward reductions: g = dout * (zmask > 0);  sums of g and g*xhat
@@ -252,74 +287,110 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(const float* 
 // bias_part (optional, needs 256 % (C/4) == 0): per-block column sums of dy, [C][gridDim.x] — the gradient of the bias of the
 // conv that feeds this BatchNorm (analytically zero; the reference's value is the round-off of exactly this sum), so that no
 // separate pass re-reads dy for it.
-template <int AT>
+template <int AT, int QW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restrict__ y, const void* __restrict__ zmask,
                                                            const float* __restrict__ msc, const float* __restrict__ msh,
                                                            const void* __restrict__ dout, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,
                                                            void* __restrict__ dy, void* __restrict__ gout, int gout_acc,
-                                                           long total4, int C, float* __restrict__ bias_part) {
-    const int c4n = C >> 2;
+                                                           long total, int C, float* __restrict__ bias_part) {
+    // an item = QW channel quads moved by one 16-byte access (QW = 2: 16-bit storage, C % 8 == 0; see bn_apply_kernel)
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
     const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
-    const int c = (int)(i0 % c4n) * 4;  // constant per thread: the grid stride is a multiple of C/4 (host side)
-    f32x4 s_ = {0.f, 0.f, 0.f, 0.f}, h_ = s_;
-    if (msc) {
-        s_ = *reinterpret_cast<const f32x4*>(msc + c);
-        h_ = *reinterpret_cast<const f32x4*>(msh + c);
-    }
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
-    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
-    const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + c);
-    const f32x4 k2 = *reinterpret_cast<const f32x4*>(c2 + c);
-    const f32x4 gr = ga * rs;
-    const bool acc = gout && gout_acc;
+    const int c = (int)(i0 % cin) * 4 * QW;  // constant per thread: the grid stride is a multiple of the items per pixel (host side)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bsum = zero;
-    auto one = [&](long i, f32x4 g, f32x4 v, f32x4 z, f32x4 old) {
-        if (zmask) {
+    f32x4 s_[QW], h_[QW], mu[QW], rs[QW], k1[QW], k2[QW], gr[QW], bsum[QW];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
-        } else if (msc) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = dbn_affine(v[e], s_[e], h_[e]) > 0.f ? g[e] : 0.f;
+    for (int q = 0; q < QW; ++q) {
+        s_[q] = h_[q] = zero;
+        if (msc) {
+            s_[q] = *reinterpret_cast<const f32x4*>(msc + c + 4 * q);
+            h_[q] = *reinterpret_cast<const f32x4*>(msh + c + 4 * q);
         }
-        const f32x4 xh = (v - mu) * rs;
-        const f32x4 d = gr * (g - k1 - xh * k2);
-        dbn_st4<AT>(dy, i, d);
-        bsum += d;
-        if (gout) dbn_st4<AT>(gout, i, acc ? g + old : g);
+        mu[q] = *reinterpret_cast<const f32x4*>(mean + c + 4 * q);
+        rs[q] = *reinterpret_cast<const f32x4*>(rstd + c + 4 * q);
+        k1[q] = *reinterpret_cast<const f32x4*>(c1 + c + 4 * q);
+        k2[q] = *reinterpret_cast<const f32x4*>(c2 + c + 4 * q);
+        gr[q] = *reinterpret_cast<const f32x4*>(gamma + c + 4 * q) * rs[q];
+        bsum[q] = zero;
+    }
+    const bool acc = gout && gout_acc;
+    auto ld = [&](const void* ptr, long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(ptr, i);
+        else dbn_ldq<AT>(ptr, i, v);
+    };
+    auto st = [&](void* ptr, long i, const f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) dbn_st4<AT>(ptr, i, v[0]);
+        else dbn_stq<AT>(ptr, i, v);
+    };
+    auto one = [&](long i, f32x4 (&g)[QW], const f32x4 (&v)[QW], const f32x4 (&z)[QW], const f32x4 (&old)[QW]) {
+        f32x4 d[QW], go[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            if (zmask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[q][e] = z[q][e] > 0.f ? g[q][e] : 0.f;
+            } else if (msc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[q][e] = dbn_affine(v[q][e], s_[q][e], h_[q][e]) > 0.f ? g[q][e] : 0.f;
+            }
+            const f32x4 xh = (v[q] - mu[q]) * rs[q];
+            d[q] = gr[q] * (g[q] - k1[q] - xh * k2[q]);
+            bsum[q] += d[q];
+            go[q] = acc ? g[q] + old[q] : g[q];
+        }
+        st(dy, i, d);
+        if (gout) st(gout, i, go);
+    };
+    auto zeros = [&](f32x4 (&v)[QW]) {
+#pragma unroll
+        for (int q = 0; q < QW; ++q) v[q] = zero;
     };
     long i = i0;
-    for (; i + (UNROLL - 1) * stride < total4; i += UNROLL * stride) {  // 2..4 x UNROLL independent loads in flight per lane
-        f32x4 g[UNROLL], v[UNROLL], z[UNROLL], o[UNROLL];
+    for (; i + (UNROLL - 1) * stride < total; i += UNROLL * stride) {  // 2..4 x UNROLL independent loads in flight per lane
+        f32x4 g[UNROLL][QW], v[UNROLL][QW], z[UNROLL][QW], o[UNROLL][QW];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            g[u] = dbn_ld4<AT>(dout, i + u * stride);
-            v[u] = dbn_ld4<AT>(y, i + u * stride);
+            ld(dout, i + u * stride, g[u]);
+            ld(y, i + u * stride, v[u]);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            z[u] = zmask ? dbn_ld4<AT>(zmask, i + u * stride) : zero;
-            o[u] = acc ? dbn_ld4<AT>(gout, i + u * stride) : zero;
+            if (zmask) ld(zmask, i + u * stride, z[u]);
+            else zeros(z[u]);
+            if (acc) ld(gout, i + u * stride, o[u]);
+            else zeros(o[u]);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) one(i + u * stride, g[u], v[u], z[u], o[u]);
     }
-    for (; i < total4; i += stride)
-        one(i, dbn_ld4<AT>(dout, i), dbn_ld4<AT>(y, i), zmask ? dbn_ld4<AT>(zmask, i) : zero, acc ? dbn_ld4<AT>(gout, i) : zero);
-    if (bias_part) {  // threads t, t + C/4, t + 2C/4, ... of the block hold the same channel quad
-        __shared__ f32x4 red[256];
-        red[threadIdx.x] = bsum;
-        __syncthreads();
-        if ((int)threadIdx.x < c4n) {
-            f32x4 t = zero;
-            for (int k = threadIdx.x; k < 256; k += c4n) t += red[k];
-            const int cq = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;
+    for (; i < total; i += stride) {
+        f32x4 g[QW], v[QW], z[QW], o[QW];
+        ld(dout, i, g);
+        ld(y, i, v);
+        if (zmask) ld(zmask, i, z);
+        else zeros(z);
+        if (acc) ld(gout, i, o);
+        else zeros(o);
+        one(i, g, v, z, o);
+    }
+    if (bias_part) {  // threads t, t + cin, t + 2 cin, ... of the block hold the same channels
+        __shared__ f32x4 red[QW][256];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bias_part[(long)(cq + e) * gridDim.x + blockIdx.x] = t[e];
+        for (int q = 0; q < QW; ++q) red[q][threadIdx.x] = bsum[q];
+        __syncthreads();
+        if ((int)threadIdx.x < cin) {
+            const int cq = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % cin) * 4 * QW;
+#pragma unroll
+            for (int q = 0; q < QW; ++q) {
+                f32x4 t = zero;
+                for (int k = threadIdx.x; k < 256; k += cin) t += red[q][k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias_part[(long)(cq + 4 * q + e) * gridDim.x + blockIdx.x] = t[e];
+            }
         }
     }
 }
@@ -825,7 +896,17 @@ int dbn_bn_apply_t(int at, const void* y, const float* scale, const float* shift
     DBN_REQUIRE(y && scale && shift && out && M > 0 && C % 4 == 0);
     DBN_REQUIRE((res_scale == nullptr) == (res_shift == nullptr));
     const long total4 = M * (C / 4);
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bn_apply_kernel<AT>, dim3(bn_stream_grid(total4, C)), dim3(256), 0, (hipStream_t)stream, y,
+    if (at != 0 && C % 8 == 0) {  // 16-bit storage: eight channels per 16-byte access
+        const long total8 = M * (C / 8);
+        if (at == 1)
+            hipLaunchKernelGGL((bn_apply_kernel<1, 2>), dim3(bn_stream_grid(total8, C / 2)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
+                               res_scale, res_shift, out, total8, C, relu);
+        else
+            hipLaunchKernelGGL((bn_apply_kernel<2, 2>), dim3(bn_stream_grid(total8, C / 2)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
+                               res_scale, res_shift, out, total8, C, relu);
+        return dbn_status();
+    }
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL((bn_apply_kernel<AT, 1>), dim3(bn_stream_grid(total4, C)), dim3(256), 0, (hipStream_t)stream, y,
                                            scale, shift, res, res_scale, res_shift, out, total4, C, relu));
     return dbn_status();
 }
@@ -851,8 +932,9 @@ int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, 
     float* c1 = ws + (long)MAX_PART * 2 * C - 2 * C;  // tail of the scratch (nb <= MAX_PART-1 partial rows used)
     float* c2 = c1 + C;
     const int nbu = nb < MAX_PART ? nb : MAX_PART - 1;
-    const long total4 = (long)M * (C / 4);
-    const int grid = bn_stream_grid(total4, C);
+    const bool wide = at != 0 && C % 8 == 0 && (!dbias_conv || 256 % (C / 8) == 0);  // 16-bit storage: eight channels per 16-byte access
+    const long total4 = (long)M * (C / (wide ? 8 : 4));
+    const int grid = bn_stream_grid(total4, wide ? C / 2 : C);
     DBN_DISPATCH_AT(at, {
         if (sums && sums_parts < 0) {
             // already finalized by the producing kernel (dbn_bnb_final): sums = [2][C] = c1, c2; dgamma / dbeta are written
@@ -871,8 +953,14 @@ int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, 
                                grad_scale);
         }
         // the reduce partials at the front of ws have been consumed by the finalize kernel: the bias partials [C][grid] reuse them
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<AT>, dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
-                           save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
+        if constexpr (AT != 0) {
+            if (wide)
+                hipLaunchKernelGGL((bn_bwd_apply_kernel<AT, 2>), dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
+                                   save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
+        }
+        if (!wide)
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<AT, 1>), dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
+                               save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
     });
     if (dbias_conv)
         hipLaunchKernelGGL(fold_partials_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, ws, grid, C, dbias_conv, grad_scale);

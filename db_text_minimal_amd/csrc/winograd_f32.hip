@@ -41,14 +41,18 @@ constexpr int W_PPX = 180, W_PROW = 18;  // 10 x 18 patch pixels
 // its ceil(H/2) x ceil(W/2) tile grid — no ragged patches (a 20 x 20 map is 52 % of its 8 x 16 patches, but 100 / 128 of its tile
 // groups) — and the LDS patch is the band of pixel rows those tiles touch, full width (+ the one-pixel halo).
 constexpr int W_LIN_PPX = 448;  // most patch pixels of the LIN form (dbn_winograd_eligible checks the map against it)
-template <bool LIN>
+// PERSIST: the item loop of the persistent forms (round 5; measured neutral, see DESIGN: off by default).  CBS: channel blocks staged per
+// barrier (2: the patch form on Cs % 32 == 0 — half the barriers, twice the patch registers and LDS; the LIN band has no room for it).
+template <bool LIN, bool PERSIST, int CBS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void winograd_f32_kernel(const IgemmParams p) {
+    static_assert(CBS == 1 || (CBS == 2 && !LIN), "two blocks per barrier: patch form only");
     // LDS: loop = two patch buffers [4 chunks][patch pixels] f32x4 (23 KB; LIN: up to 57 KB); epilogue = the cross-wave exchange
     // [4 waves][2 dx][2 b][16][64] floats (64 KB) + the statistics scratch
     constexpr int PPX_MAX = LIN ? W_LIN_PPX : W_PPX;
     constexpr int P_PATCH = 4 * PPX_MAX;
     constexpr int X_FLOATS = 4 * 2 * 2 * 16 * 64;
-    static_assert(2 * P_PATCH <= X_FLOATS / 4, "the patch buffers live inside the exchange region");
+    constexpr int P_STAGE = CBS * P_PATCH;  // one stage = the patches of CBS consecutive channel blocks; two stages
+    static_assert(2 * P_STAGE <= X_FLOATS / 4, "the patch buffers live inside the exchange region");
     // + the statistics / sums scratch [<= 3][4][64] floats, a flag, 8 counts | the apply-on-load coefficients of <= 512 channels | the next item
     __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 4 + 2 * 128 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto resolve = [&](int idx) { return idx < xsize(xcd) ? xbase(xcd) + idx : -1; };
     auto pull = [&]() { return __hip_atomic_fetch_add(p.work + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     int item;
-    if (p.work) {
+    if (PERSIST && p.work) {
         if (tid == 0) *s_next = resolve(pull());
         __syncthreads();
         item = *s_next;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // 64 -> 64 launch still took 151 us against 85 us of matrix time, and neither pulled nor static persistence moved it (176 / 182 / 183 us).
     // The workgroup in the SECOND wave slot of its SIMDs therefore sleeps p.stagger_units x 1024 clocks once, at launch (about the
     // matrix time of one item): from then on one resident's epilogue / prologue runs beside the other's loop.
-    if (p.stagger_units > 0 && total > (int)gridDim.x) {
+    if (PERSIST && p.stagger_units > 0 && total > (int)gridDim.x) {
         int* const s_slot = s_next + 1;
         if (tid == 0) *s_slot = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u);  // HW_REG_HW_ID.WAVE_ID of wave 0
         __syncthreads();
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // item loop, stayed live across it and spilled (342 vector + 111 scalar registers in the first build).
         int tid_l = tid_wg;
         unsigned long long ka_l = kargs;
-        asm volatile("" : "+v"(tid_l), "+s"(ka_l));
+        if constexpr (PERSIST) asm volatile("" : "+v"(tid_l), "+s"(ka_l));
         const int tid = tid_l, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, lh = lane >> 5;
         const auto& p = *reinterpret_cast<KernArgs>(ka_l);
         const int a1 = wave == 0 ? 0 : (wave == 2 ? 2 : 1), a2 = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
@@ -178,15 +182,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             poff[j] = v ? (unsigned)(((pn * p.Hs + hs) * p.Ws + ws) * p.Cs) * 4u + (unsigned)chunk * 16u : OOB_OFFSET;
             pslot[j] = on ? chunk * ppx + pix : -1;
         }
+        // ONE register set whatever CBS: with two channel blocks per barrier the second block's patch is fetched once the first one's has
+        // gone to LDS, half a stage later (two sets had the compiler spill the patch registers inside the loop: 43 dwords)
         f32x4 pr[PL];
-        auto load_patch = [&](int cb) {
-            const unsigned add = (unsigned)(cb * 64);
+        auto load_patch = [&](int st, int u) {  // stage st = channel blocks CBS st .. CBS st + CBS - 1; u: block within the stage
+            const unsigned add = (unsigned)((st * CBS + u) * 64);
 #pragma unroll
             for (int j = 0; j < PL; ++j) pr[j] = buffer_load_f32x4(rsrc, poff[j] == OOB_OFFSET ? OOB_OFFSET : poff[j] + add);
         };
-        auto store_patch = [&](int buf, int cb) {
-            f32x4* const P = smem + buf * P_PATCH;
+        auto store_patch = [&](int buf, int st, int u) {
+            f32x4* const P = smem + buf * P_STAGE + u * P_PATCH;
             if (act) {  // (pixels outside the map are the conv's zero padding of the ACTIVATION: they stay zero)
+                const int cb = st * CBS + u;
                 const f32x4 asc = ACT[cb * 4 + (tid & 3)], ash = ACT[(p.Cs >> 2) + cb * 4 + (tid & 3)];
 #pragma unroll
                 for (int j = 0; j < PL; ++j)
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // (not zeroed: the first MFMA of every accumulator — channel block 0 — takes the constant 0 as its addend.  128 v_mov per wave
         // otherwise, and a vector instruction costs fp32-MFMA time on this chip whichever wave issues it: DESIGN 7.12)
         f32x16 acc[4][2];
-        if constexpr (!LIN) {
+        if constexpr (!LIN && PERSIST) {
             // (persistent loop: "not yet written" must not read as "whatever the previous item left" — the compiler then carries all 128
             // accumulator registers around the item loop, through the epilogue, and spills the epilogue's loads instead: an empty asm
             // DEFINES them here, at no instruction)
@@ -263,17 +270,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #if DBN_TRACE
         unsigned long long tr_bar = 0, tr_t = 0;
 #endif
-        load_patch(0);
+        load_patch(0, 0);
         issue_w(std::integral_constant<int, 0>{});
         issue_w(std::integral_constant<int, 1>{});
-        store_patch(0, 0);
+        store_patch(0, 0, 0);
+        if constexpr (CBS == 2) {
+            load_patch(0, 1);
+            store_patch(0, 0, 1);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         DBN_TRACE_MARK(1);
-        for (int cb = 0; cb < ncb; ++cb) {
-            const f32x4* const P = smem + (cb & 1) * P_PATCH;
-            load_patch(cb + 1);  // (past the last block: out-of-range offsets, zeros, never stored)
+        const int nst = ncb / CBS;  // stages (CBS == 2: the launcher checked that ncb is even)
+        for (int st = 0; st < nst; ++st) {
+            load_patch(st + 1, 0);  // (past the last block: out-of-range offsets, zeros, never stored)
+#pragma unroll
+            for (int u = 0; u < CBS; ++u) {
+            const int cb = st * CBS + u;
+            if (CBS == 2 && u == 1 && !DBN_WX_NOBAR) {
+                // the next stage's FIRST block goes to LDS already (its buffer was last read in stage st - 1, and every wave has passed the
+                // barrier that ended it), and the second block's fetch takes over the registers
+                if (st + 1 < nst) store_patch((st + 1) & 1, st + 1, 0);
+                load_patch(st + 1, 1);
+            }
+            const f32x4* const P = smem + (st & 1) * P_STAGE + u * P_PATCH;
             // Per point (i, j): V = (d[a1][b1] +- d[a1][b2]) + sa * (d[a2][b1] +- d[a2][b2]) — four LDS reads, twelve vector instructions per
             // chunk.  (Measured and not kept: forming all four points' V at the start of a block from the shared row combination — 16 reads
             // + 44 vector instructions per block instead of 32 + 96 — 3-8 % SLOWER: one long vector phase per block overlaps the other
@@ -331,12 +352,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 point(std::integral_constant<int, 2>{}, std::false_type{});
                 point(std::integral_constant<int, 3>{}, std::false_type{});
             }
-            if (cb + 1 < ncb && !DBN_WX_NOBAR) {
+            }  // (u)
+            if (st + 1 < nst && !DBN_WX_NOBAR) {
                 // the other buffer was last read in block cb - 1, and every wave has passed the barrier that ended it
 #if DBN_TRACE
                 tr_t = __builtin_amdgcn_s_memrealtime();
 #endif
-                store_patch((cb + 1) & 1, cb + 1);
+                store_patch((st + 1) & 1, st + 1, CBS - 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -353,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();  // every wave is done with the patches: the region becomes the exchange buffer
         // the pull for the NEXT item goes out here, so that its round trip runs under the epilogue (it is consumed at the item's end)
         int next_idx = 0;
-        if (p.work && tid == 0) next_idx = pull();
+        if (PERSIST && p.work && tid == 0) next_idx = pull();
 
 #if DBN_WX_NOEXCH  // (timing experiment, wrong results: no exchange, no statistics — what would an epilogue that stays in registers cost?)
         {
@@ -443,7 +465,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" : "=v"(oldv[b][r]), "=v"(yv[b][r]), "=v"(zv[b][r]), "=v"(y2v[b][r]));
+            for (int r = 0; r < 16; ++r)
+                if constexpr (PERSIST) asm volatile("" : "=v"(oldv[b][r]), "=v"(yv[b][r]), "=v"(zv[b][r]), "=v"(y2v[b][r]));
         if (p.accumulate) {  // (inference epilogue: the addend is a residual input, IgemmParams::res, instead of dst itself)
             const __amdgpu_buffer_rsrc_t rsrcA = p.res ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, dst_bytes, 0x00020000) : rsrcD;
 #pragma unroll
@@ -694,6 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
         DBN_TRACE_MARK(3);
 
+        if constexpr (!PERSIST) break;
         if (!p.work) {
             item_pos += gridDim.x;
             if (item_pos >= total) break;
@@ -707,7 +731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         item = *s_next;  // (rewritten at the end of the next item only: behind that item's barriers)
     }
-    if (p.work && tid == 0) {  // the last workgroup out leaves the counters at zero for the next launch on this stream
+    if (PERSIST && p.work && tid == 0) {  // the last workgroup out leaves the counters at zero for the next launch on this stream
         if (__hip_atomic_fetch_add(p.work + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
             for (int x = 0; x < 9; ++x) __hip_atomic_store(p.work + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -802,9 +826,14 @@ extern "C" int dbn_winograd_rows(int N, int H, int W) {
 // The work counters of the persistent form: nine ints per stream (launches on one stream are ordered, so they share them; launches on
 // different streams may overlap and must not), allocated and zeroed on the stream's first launch — before any graph capture, which the
 // engine only starts after eager warm-up steps — and left zero by every launch.
-static int g_wino_persistent = 1;
+static int g_wino_persistent = 0;  // (measured neutral on MI355X, round 5: off by default)
 extern "C" int dbn_set_winograd_persistent(int on) {  // test / A-B hook: 0 = one workgroup per item (round 4's form), 1 = pulled items, 2 = static schedule
     g_wino_persistent = on;
+    return DBN_OK;
+}
+static int g_wino_cbs = 1;
+extern "C" int dbn_set_winograd_blocks_per_barrier(int n) {  // test / A-B hook: 1 or 2 channel blocks per barrier (patch form, Cs % 32 == 0)
+    g_wino_cbs = n == 2 ? 2 : 1;
     return DBN_OK;
 }
 static int g_wino_stagger = 1000;
@@ -838,8 +867,14 @@ int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
     // the stagger of the persistent forms: g_wino_stagger permille of one item's matrix time (Cs / 16 blocks x 64 MFMAs x 64 clocks per wave)
     p.stagger_units = (grid < items && g_wino_stagger > 0) ? (int)((long)(p.Cs >> 4) * 4096 / 1024 * g_wino_stagger / 1000) : 0;
     p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;
-    if (lin) hipLaunchKernelGGL(winograd_f32_kernel<true>, dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(winograd_f32_kernel<false>, dim3(grid), dim3(256), 0, st, p);
+    const bool persist = grid < items;
+    const bool cb2 = !lin && g_wino_cbs == 2 && (p.Cs & 31) == 0;
+    if (lin && persist) hipLaunchKernelGGL((winograd_f32_kernel<true, true, 1>), dim3(grid), dim3(256), 0, st, p);
+    else if (lin) hipLaunchKernelGGL((winograd_f32_kernel<true, false, 1>), dim3(grid), dim3(256), 0, st, p);
+    else if (persist && cb2) hipLaunchKernelGGL((winograd_f32_kernel<false, true, 2>), dim3(grid), dim3(256), 0, st, p);
+    else if (persist) hipLaunchKernelGGL((winograd_f32_kernel<false, true, 1>), dim3(grid), dim3(256), 0, st, p);
+    else if (cb2) hipLaunchKernelGGL((winograd_f32_kernel<false, false, 2>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((winograd_f32_kernel<false, false, 1>), dim3(grid), dim3(256), 0, st, p);
     return dbn_status();
 }
 

@@ -376,6 +376,41 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 }
 
+// slabs -> gradient, round 4's form: grid (O, nib); 1024 threads = 16 points x 64 input channels of one output channel, each walking the
+// splits serially.  Still the launch for up to 64 splits (every layer but the 64 -> 64 ones: 14-22 us alone — the wide form below needs
+// 19-55 us there, its 72 KB of LDS and 200 registers per lane leave it one workgroup per CU)
+__global__ __launch_bounds__(1024) void winograd_wgrad_reduce_serial_kernel(const float* __restrict__ slab, int nsplit, int nsub, int nib, int I,
+                                                                     float* __restrict__ grad, float scale) {
+    __shared__ double sh[16][64];
+    __shared__ float st[576];
+    const int o = blockIdx.x, ib = blockIdx.y, sub = (o >> 6) * nib + ib;
+    const int pnt = threadIdx.x >> 6, il = threadIdx.x & 63;
+    const float* src = slab + ((long)sub * 16 + pnt) * 4096 + (o & 63) * 64 + il;
+    const long stride = (long)nsub * 16 * 4096;
+    double s = 0.0;
+    int z = 0;
+    for (; z + 3 < nsplit; z += 4)
+        s += ((double)src[z * stride] + (double)src[(z + 1) * stride]) + ((double)src[(z + 2) * stride] + (double)src[(z + 3) * stride]);
+    for (; z < nsplit; ++z) s += (double)src[z * stride];
+    sh[pnt][il] = s;
+    __syncthreads();
+    if (threadIdx.x < 576) {
+        const int c = threadIdx.x / 9, tap = threadIdx.x - c * 9, r = tap / 3, q = tap - r * 3;
+        // column r of G applied along i, column q along j
+        auto gcol = [](int k, double v0, double v1, double v2, double v3) {
+            return k == 0 ? v0 + 0.5 * (v1 + v2) : (k == 1 ? 0.5 * (v1 - v2) : 0.5 * (v1 + v2) + v3);
+        };
+        double t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = gcol(q, sh[4 * i + 0][c], sh[4 * i + 1][c], sh[4 * i + 2][c], sh[4 * i + 3][c]);
+        st[threadIdx.x] = (float)(gcol(r, t[0], t[1], t[2], t[3]) * (double)scale);
+    }
+    __syncthreads();
+    const int n = min(64, I - ib * 64) * 9;  // channels >= I are padding of the activation tensor
+    float* dst = grad + ((long)o * I + ib * 64) * 9;
+    for (int k = threadIdx.x; k < n; k += 1024) dst[k] = st[k];
+}
+
 // slabs -> gradient: fp64 sum over the splits in a fixed order, dg = G^T dU G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
 // Round 5 (the round-4 form — grid (O, nib), 1024 threads walking the splits serially with four 4-byte loads in flight — moved 67 MB in
 // 68 us = 1 TB/s and sat 0.67 ms per step alone on the chip): workgroups of 256 threads = OG output channels x 8 input-channel quads x
@@ -536,12 +571,11 @@ int dbn_winograd_wgrad_f32(int phases, const float* dy, const float* x, const fl
     }
     if (phases & 2) {
         const int nsub = p.nob * p.nib;
-        if (p.nsplit >= 32)
+        // 256 splits (the 64 -> 64 layers: one 64 x 64 block, every CU a split): the wide form (28 -> 20 us alone); fewer: round 4's
+        if (p.nsplit >= 128)
             hipLaunchKernelGGL(winograd_wgrad_reduce_kernel<32>, dim3(O, 2 * p.nib), dim3(256), 0, st, slab, p.nsplit, nsub, p.nib, I, grad, scale);
-        else if (p.nsplit >= 16)
-            hipLaunchKernelGGL(winograd_wgrad_reduce_kernel<16>, dim3(O / 2, 2 * p.nib), dim3(256), 0, st, slab, p.nsplit, nsub, p.nib, I, grad, scale);
         else
-            hipLaunchKernelGGL(winograd_wgrad_reduce_kernel<4>, dim3(O / 8, 2 * p.nib), dim3(256), 0, st, slab, p.nsplit, nsub, p.nib, I, grad, scale);
+            hipLaunchKernelGGL(winograd_wgrad_reduce_serial_kernel, dim3(O, p.nib), dim3(1024), 0, st, slab, p.nsplit, nsub, p.nib, I, grad, scale);
     }
     return dbn_status();
 }

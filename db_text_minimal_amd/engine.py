@@ -98,15 +98,22 @@ class KernelTimer:
             self.records.append(self._open)
             self._open = None
 
-    def summary(self):
-        """label -> dict(launches, ms, flops, bytes); call after a device synchronize."""
+    def summary(self, peak_tflops=None, hbm_gbs=None):
+        """label -> dict(launches, ms, flops, bytes); call after a device synchronize.
+        With both peaks given every launch is also priced against ITS roofline — max(FLOPs / matrix peak, algorithmic bytes / achievable HBM
+        rate): `roof_ms` is the sum of those bounds and `hbm_bound` the number of launches whose bound is the memory one (a 64 -> 64 3x3 layer
+        in bf16 has 288 FLOP/B against a ridge of ~400: it must not be reported against the 2.5 PFLOP/s peak)."""
         out = {}
         for label, flops, nbytes, e0, e1, _ in self.records:
-            d = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d = out.setdefault(label, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, roof_ms=0.0, hbm_bound=0))
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
             d['flops'] += flops
             d['bytes'] += nbytes
+            if peak_tflops and hbm_gbs and flops > 0:
+                t_m, t_h = flops / (peak_tflops * 1e9), nbytes / (hbm_gbs * 1e6)  # ms
+                d['roof_ms'] += max(t_m, t_h)
+                d['hbm_bound'] += int(t_h > t_m)
         return out
 
 
@@ -132,6 +139,8 @@ class Engine:
             self.L.dbn_set_patch_conv(2 if os.environ['DBN_PATCH_F32'] == '0' else 3)
         if 'DBN_WINO_PERSISTENT' in os.environ:  # A/B runs: 0 one workgroup per item, 1 persistent workgroups pulling items, 2 static schedule
             self.L.dbn_set_winograd_persistent(int(os.environ['DBN_WINO_PERSISTENT']))
+        if 'DBN_WINO_CBS' in os.environ:  # A/B runs: channel blocks per barrier of the Winograd patch form (1 | 2)
+            self.L.dbn_set_winograd_blocks_per_barrier(int(os.environ['DBN_WINO_CBS']))
         if 'DBN_WINO_STAGGER' in os.environ:  # A/B runs: permille of one item's matrix time (0 = off)
             self.L.dbn_set_winograd_stagger(int(os.environ['DBN_WINO_STAGGER']))
         if 'DBN_PHASE_PRIO' in os.environ:  # A/B runs
@@ -183,7 +192,7 @@ class Engine:
         # sharing the matrix pipe is zero-sum (measured: two conv streams take exactly 2x each); what the overlap hides is the few
         # HBM-bound kernels in between: 31.9 vs 32.05 ms/step, at the price of every launch of the two big 256->64 convs running
         # at half speed.  Off: the kernels run undisturbed (the dominant kernel's timed-region rate 76 -> 94 TFLOP/s).
-        self.overlap_head_branches = False
+        self.overlap_head_branches = os.environ.get('DBN_OVERLAP_HEAD', '0') == '1'
         self.side_priority = None  # HIP stream priority of the side stream (None: default)
         self._side = None
         self._side_used = False
@@ -744,7 +753,11 @@ class Engine:
             ks = self.L.dbn_igemm_splitk_plan_ns(N * Hd * Wd, Cd, R * R * Cs, Cs, self.ns) if self.splitk else 1
             cfg = self.L.dbn_igemm_kernel_config(at, self.ns, mode, N, Hs, Ws, Cs, Hd, Wd, Cd, R, R, stride, pad, 0, ks)
         blk = 'false' if (geom is not None and mode == 0 and geom[3] % 16 != 0) else 'true'
-        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, 0.0, tag)
+        nbytes = 0.0
+        if geom is not None:  # algorithmic traffic: source and destination once, in the storage type (weights are L2-resident)
+            N, Hs, Ws, Cs, Hd, Wd = geom[:6]
+            nbytes = float(N) * (Hs * Ws * Cs + Hd * Wd * Cd) * (4 if self.at == 0 else 2)
+        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, nbytes, tag)
 
     def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer, panel=None):
         """The data gradient of a 3x3 / stride-1 / pad-1 conv through the Winograd kernel (the rotated / transposed filters), with the

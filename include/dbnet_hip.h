@@ -264,6 +264,8 @@ int dbn_head_tail_bwd(const float* xb, const float* xt, const float* wb, const f
 int dbn_set_winograd_persistent(int on);
 /* ... and the one-time phase stagger between the two persistent workgroups of a CU, in permille of one item's matrix time (0: off) */
 int dbn_set_winograd_stagger(int permille);
+/* ... and the channel blocks the patch form stages per barrier: 1 (default) or 2 (Cs % 32 == 0 layers; A/B hook) */
+int dbn_set_winograd_blocks_per_barrier(int n);
 int dbn_winograd_eligible(int N, int H, int W, int Cs, int Cd);
 long dbn_winograd_panel_floats(int O, int Cs);
 /* dgrad = 0: panel of the forward conv of w [O][I][3][3] over a source with Cs >= I channels.  dgrad = 1: panel of the DATA GRADIENT

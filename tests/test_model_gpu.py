@@ -965,6 +965,8 @@ def test_apply_on_load_batchnorm_relu_is_bit_identical(size, train):
             outs.append((preds.clone(), losses.clone(), model.engine.flat_grad.clone(), model.engine.flat.clone()))
         else:
             model.eval()
+            model.engine.fold_eval_bn = False  # (round 5: the default eval path folds the BatchNorm into the weights and writes the
+            # activations from the conv epilogues; apply-on-load belongs to the unfolded conv -> coefficients -> bn_apply chain)
             with torch.no_grad():
                 outs.append((model(img).clone(), ))
         written = sorted(k for k in model.engine.bufs if k.endswith('/z1') or k == 'fpn/z')
@@ -998,3 +1000,55 @@ def test_pyramid_conv_on_a_winograd_level_0():
     for k in g0:
         scale = float(g0[k].abs().max())
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-2 * scale + 1e-7, k  # (+ 1e-7: biases in front of a BatchNorm have zero gradient — rounding noise of 1e-9)
+
+
+@pytest.mark.parametrize('math,arch,n,h,w', [('f32', 'resnet18', 2, 128, 128), ('f32', 'resnet18', 1, 96, 70), ('bf16', 'resnet18', 2, 128, 128),
+                                             ('fp16', 'resnet18', 2, 160, 128), ('f32', 'resnet50', 1, 96, 96), ('f32', 'deformable_resnet18', 1, 96, 96)])
+def test_eval_with_folded_batchnorm_equals_the_unfolded_chain(math, arch, n, h, w):
+    """Round 5: in eval mode every conv -> BatchNorm -> (+ residual) -> ReLU chain runs as ONE launch on weights with the running statistics
+    folded in (engine.fold_eval_bn; basic.py:32-36, resnet.py:70-91,135-159, segmentation_body.py:55-61 under model.eval()).  Same function
+    as the unfolded chain (conv -> coefficients -> bn_apply, engine.fold_eval_bn = False) up to the rounding of w * scale — fp32: 2e-5 on the
+    maps; 16-bit storage: the folded weights are rounded to the storage type (the unfolded chain rounds the raw weights and applies the
+    scale in fp32), bounded like two 16-bit runs of one net — and both within the usual bounds of the oracle.  Also after a train step
+    (the running statistics change through raw pointers: the folded tensors must follow)."""
+    seed = 21
+    img, gts = O.synthetic_batch(n, (h, w), seed=seed)
+    sd = O.new_state(seed, arch)
+    model = make_model(seed, arch)
+    model.engine.set_conv_math(math)
+    ref = O.forward(sd, img, training=False, update_stats=False)
+
+    def run(fold):
+        model.engine.fold_eval_bn = fold
+        model.eval()
+        with torch.no_grad():
+            return model(img.to(DEV)).clone()
+    a, b = run(True), run(False)
+    assert a.shape == (n, 2, h, w)
+
+    def close(tag, u, v):
+        # the eval maps of a net with procedurally filled running statistics are saturated sigmoids: rounding-level differences in the
+        # logits (w * scale is rounded once more in the folded form) move single pixels by 1e-4 (resnet18) ... 4e-3 (the unconditioned
+        # 53-layer nets, which amplify perturbations ~1e3x, DESIGN section 4); in 16-bit storage single pixels flip outright, as between any
+        # two 16-bit evaluations of one net — there the MEAN is what is bounded
+        d = (u - v).abs()
+        print('%s: max %.3e mean %.3e' % (tag, float(d.max()), float(d.mean())))
+        if math == 'f32':
+            assert float(d.max()) <= (1e-3 if arch == 'resnet18' else 1e-2) and float(d.mean()) <= (1e-5 if arch == 'resnet18' else 2e-4), tag
+        else:
+            assert float(d.mean()) <= 4e-3, tag
+    close('folded vs unfolded eval maps (%s, %s)' % (math, arch), a.cpu(), b.cpu())
+    assert torch.equal(run(True), a)  # (cached folded tensors: same bits)
+    # ... and the folded path against the oracle at the bounds the unfolded one is held to (fp32 resnet18: north_star; else DESIGN section 4)
+    if math == 'f32' and arch == 'resnet18':
+        report('folded eval maps vs oracle', a.cpu(), ref, MAP_ATOL, MAP_RTOL)
+    else:
+        d = (a.cpu() - ref).abs()
+        assert float(d.mean()) <= 4e-3 and (math != 'f32' or float(d.max()) <= 1e-2), (float(d.mean()), float(d.max()))
+    if math in ('f32', 'bf16'):  # a train step moves the running statistics and the weights: the folded tensors are re-made
+        model.train()
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        tr.step(img.to(DEV), gts.to(DEV))
+        a2, b2 = run(True), run(False)
+        close('folded vs unfolded after a train step', a2.cpu(), b2.cpu())
+        assert not torch.equal(a2, a)

@@ -1782,3 +1782,88 @@ def test_winograd_apply_on_load_equals_bn_apply_then_conv(N, C, Co, H, W):
         assert bool(torch.isfinite(t0).all()) and torch.equal(t0, t1)
     # and the activation really matters (relu(shift) != 0 at the padding would show here)
     assert float((z - y).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize('at', [0, 1, 2])
+@pytest.mark.parametrize('case', [(2, 64, 64, 3, 1, 1, 16, 32, True), (1, 64, 128, 3, 2, 1, 18, 14, False), (2, 64, 128, 1, 2, 0, 16, 16, False),
+                                  (1, 256, 64, 1, 1, 0, 12, 12, True), (2, 128, 128, 3, 1, 1, 8, 16, True)])
+def test_inference_epilogue_folded_bn_residual_relu(case, at):
+    """Round 5: dbn_fold_bn_eval + dbn_igemm_act_t / dbn_winograd_conv_act_f32 — relu(bn_eval(conv(x) + bias) [+ residual]) in ONE launch
+    (basic.py:32-36, resnet.py:70-91 under model.eval()) against F.conv2d -> F.batch_norm(training=False) -> add -> relu in fp64 on the
+    operands as stored.  fp32 (direct and Winograd kernel), bf16 and fp16 storage (output rounding 2^-9 / 2^-11 relative)."""
+    N, Ci, Co, k, s, p, H, W, with_res = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(2.0 / (Ci * k * k))**0.5)
+    b = rnd(Co, seed=3) * 0.1
+    gamma, beta = rnd(Co, seed=4) * 0.3 + 1, rnd(Co, seed=5) * 0.2
+    rm, rv = rnd(Co, seed=6) * 0.1, torch.rand(Co, generator=torch.Generator().manual_seed(7)) + 0.5
+    dt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[at]
+    xs = nhwc(x).to(dt)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd(N, Co, Ho, Wo, seed=8) if with_res else None
+    rs_ = nhwc(res).to(dt) if with_res else None
+    wd, bd = w.to(DEV), b.to(DEV)
+    gd, btd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)  # (kept alive: the call takes raw pointers)
+    wf, bf = torch.full_like(wd, float('nan')), torch.full((Co, ), float('nan'), device=DEV)
+    _lib.check(L().dbn_fold_bn_eval(wd.data_ptr(), Co, Ci * k * k, bd.data_ptr(), gd.data_ptr(), btd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+                                    1e-5, wf.data_ptr(), bf.data_ptr(), stream()), 'fold')
+    sc = gamma.double() / torch.sqrt(rv.double() + 1e-5)
+    report('folded weight', wf.cpu(), w.double() * sc.view(-1, 1, 1, 1), 1e-6, 1e-6)
+    report('folded bias', bf.cpu(), beta.double() + (b.double() - rm.double()) * sc, 1e-6, 1e-6)
+    # reference on the operands as stored
+    xr = nchw(xs.float()).double()
+    ref = F.batch_norm(F.conv2d(xr, w.double(), b.double(), s, p), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    if with_res:
+        ref = ref + nchw(rs_.float()).double()
+    ref = torch.relu(ref)
+    ns, kind = (0, 0) if at == 0 else (1, at)
+    n = L().dbn_igemm_panel_floats_t(kind, Co, Ci, k, k, 0, 1, Ci)
+    wpk = torch.empty(n, device=DEV)
+    _lib.check(L().dbn_pack_weights_t(kind, wf.data_ptr(), Co, Ci, k, k, 0, 1, Ci, wpk.data_ptr(), stream()), 'pack')
+    y = torch.full((N, Ho, Wo, Co), float('nan'), device=DEV, dtype=dt)
+    _lib.check(L().dbn_igemm_act_t(at, ns, xs.data_ptr(), wpk.data_ptr(), bf.data_ptr(), rs_.data_ptr() if with_res else None, 1, y.data_ptr(),
+                                   N, H, W, Ci, Ho, Wo, Co, k, k, s, p, 0, 0, stream()), 'igemm act')
+    scale = float(ref.abs().max())
+    # (16-bit: the folded weights are rounded to the storage type once more than the unfolded chain's: 2^-8 / 2^-10 of the output scale)
+    tol = {0: 1e-5, 1: 2.0**-7, 2: 2.0**-9}[at]
+    report('igemm act %s at %d' % (case, at), nchw(y.float()), ref, tol * scale, tol)
+    assert float(y.float().min()) >= 0.0
+    if at == 0 and k == 3 and s == 1 and L().dbn_winograd_eligible(N, H, W, Ci, Co):
+        up = torch.empty(L().dbn_winograd_panel_floats(Co, Ci), device=DEV)
+        _lib.check(L().dbn_winograd_pack(wf.data_ptr(), Co, Ci, Ci, 0, up.data_ptr(), stream()), 'winograd pack')
+        for persistent in (0, 1):
+            L().dbn_set_winograd_persistent(persistent)
+            yw = torch.full_like(y, float('nan'))
+            _lib.check(L().dbn_winograd_conv_act_f32(xs.data_ptr(), up.data_ptr(), bf.data_ptr(), rs_.data_ptr() if with_res else None, 1,
+                                                     yw.data_ptr(), N, H, W, Ci, Co, stream()), 'winograd act')
+            report('winograd act %s' % (case, ), nchw(yw), ref, 1e-5 * scale, 1e-5)
+        L().dbn_set_winograd_persistent(0)
+
+
+@pytest.mark.parametrize('N,Ci,Co,H,W', [(16, 64, 64, 96, 96), (8, 128, 128, 80, 80), (40, 256, 256, 40, 40)])
+def test_winograd_persistent_forms_are_bit_identical(N, Ci, Co, H, W):
+    """Round 5: the persistent forms of winograd_f32_kernel (workgroups that pull (patch, channel tile) items from per-XCD counters;
+    a static schedule) compute every item exactly as the one-workgroup-per-item form does: same bits, with the train-mode BatchNorm
+    statistics, on launches of more than 512 items (fewer: the launch is not persistent).  Repeated: the counters are left at zero."""
+    x = torch.randn(N, H, W, Ci, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=(2.0 / (Ci * 9))**0.5).to(DEV)
+    up = torch.empty(L().dbn_winograd_panel_floats(Co, Ci), device=DEV)
+    _lib.check(L().dbn_winograd_pack(w.data_ptr(), Co, Ci, Ci, 0, up.data_ptr(), stream()), 'winograd pack')
+    assert L().dbn_winograd_rows(N, H, W) * (Co // 64) > 512
+    outs = []
+    for mode in (0, 1, 2, 1):
+        L().dbn_set_winograd_persistent(mode)
+        gamma, beta = torch.ones(Co, device=DEV), torch.zeros(Co, device=DEV)
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        sc, sh, mu, rs = (torch.full((Co, ), float('nan'), device=DEV) for _ in range(4))
+        ws = torch.full((L().dbn_winograd_ws_floats(N, H, W, Co), ), float('nan'), device=DEV)
+        y = torch.full((N, H, W, Co), float('nan'), device=DEV)
+        _lib.check(L().dbn_winograd_conv_bn_f32(x.data_ptr(), up.data_ptr(), None, y.data_ptr(), N, H, W, Ci, Co, gamma.data_ptr(), beta.data_ptr(),
+                                                1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                                                rs.data_ptr(), ws.data_ptr(), stream()), 'winograd+bn')
+        torch.cuda.synchronize()
+        outs.append((y, sc, sh, mu, rs))
+    L().dbn_set_winograd_persistent(0)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)

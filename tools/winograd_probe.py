@@ -9,6 +9,8 @@ from gpu_util import L, rnd, DEV, pack, stream
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 if 'DBN_WINO_PERSISTENT' in os.environ:  # A/B: 0 = one workgroup per item (round 4's form)
     L().dbn_set_winograd_persistent(int(os.environ['DBN_WINO_PERSISTENT']))
+if 'DBN_WINO_CBS' in os.environ:
+    L().dbn_set_winograd_blocks_per_barrier(int(os.environ['DBN_WINO_CBS']))
 if 'DBN_WINO_STAGGER' in os.environ:
     L().dbn_set_winograd_stagger(int(os.environ['DBN_WINO_STAGGER']))
 
