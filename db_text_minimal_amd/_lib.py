@@ -142,6 +142,7 @@ SIGNATURES.update({
     'dbn_nearest_up_bwd_t': 'i' + SIGNATURES['dbn_nearest_up_bwd'],
     'dbn_nchw3_to_nhwc4_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
     'dbn_nchw3_to_nhwc4_packed_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
+    'dbn_nchw3_to_nhwc16_and_4_t': 'ipppiiip',
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })

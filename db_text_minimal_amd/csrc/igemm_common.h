@@ -70,6 +70,26 @@ struct IgemmParams {
     const float* bias;  // [Cd] or null
     void* dst;          // [N,Hdf,Wdf,Cd], activation type AT (split-K: fp32 slabs)
     int N, Hs, Ws, Cs, Cd, Hdf, Wdf, R, S, stride, pad, accumulate, ncls;
+    // ---- (kept at the FRONT of the block, in the kernel-argument lines a workgroup reads first: a workgroup of winograd_f32_kernel —
+    // two resident per CU — spent ~4 us between launch and its first load, much of it in dependent scalar-load round trips to the far
+    // end of this 1.2 KB argument block and in three integer divisions; round-5 trace)
+    // winograd_f32_kernel only: src is the INPUT of a BatchNorm + ReLU whose output the conv consumes; relu(fma(src, in_scale[c],
+    // in_shift[c])) is applied while the patch is staged (the activation tensor is never written; same arithmetic as bn_apply_kernel)
+    const float *in_scale, *in_shift;
+    // Inference epilogue (round 5: eval-mode BatchNorm folded into the weights, `bias` = its shift): `res` non-NULL (with accumulate = 1) —
+    // the tensor that is added comes from `res` (same shape / storage type as dst) instead of from dst itself: a residual connection;
+    // relu != 0: max(., 0) on the final value (after bias and the addition)
+    const void* res;
+    int relu;
+    // winograd_f32_kernel, round 5: persistent workgroups pull (patch, channel tile) items from `work` — [8 per-XCD counters][1 exit counter]
+    // ints, zero on entry and left zero; NULL: one workgroup per item (gridDim.x == work_items)
+    int work_items;
+    int* work;
+    // winograd_f32_kernel: the item -> (image, patch row, patch column, channel tile) divisions as host-made multipliers,
+    // x / d = (x * magic(d)) >> 40, magic(d) = ceil(2^40 / d) (41 bits; exact for x < 2^23, d <= 2^16): d = channel tiles, patches (LIN:
+    // tile groups) per image, patches per row
+    unsigned long long wino_m_ntn, wino_m_tpi, wino_m_tw;
+    int wino_tpi, wino_tw;
     int stat_rows;      // rows of the partials array (all M-tiles of the call; a call over many images runs as several launches)
     int stat_row0;      // first row this launch writes
     float* stats;       // optional BatchNorm partials [3][Cd][stat_rows] (pivot, sum, sum sq) + [stat_rows] counts
@@ -116,19 +136,7 @@ struct IgemmParams {
     const float* seg_wpk[4];
     unsigned seg_bytes[4];
     unsigned seg_plane_bytes[4];  // AT = 3
-    // winograd_f32_kernel only: src is the INPUT of a BatchNorm + ReLU whose output the conv consumes; relu(fma(src, in_scale[c],
-    // in_shift[c])) is applied while the patch is staged (the activation tensor is never written; same arithmetic as bn_apply_kernel)
-    const float *in_scale, *in_shift;
     int first_level;  // MODE 3, exact-fp32 loop only: levels [first_level, 4) (the finer ones are in dst already: accumulate = 1)
-    // winograd_f32_kernel, round 5: persistent workgroups pull (patch, channel tile) items from `work` — [8 per-XCD counters][1 exit counter]
-    // ints, zero on entry and left zero; NULL: one workgroup per item (gridDim.x == work_items)
-    int* work;
-    int work_items;
-    // Inference epilogue (round 5: eval-mode BatchNorm folded into the weights, `bias` = its shift): `res` non-NULL (with accumulate = 1) —
-    // the tensor that is added comes from `res` (same shape / storage type as dst) instead of from dst itself: a residual connection;
-    // relu != 0: max(., 0) on the final value (after bias and the addition)
-    const void* res;
-    int relu;
 };
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger

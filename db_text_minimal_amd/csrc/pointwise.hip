@@ -749,6 +749,25 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, void* __restr
     }
 }
 
+// 16-bit storage, training: the 16-channel-block form (the stem conv's source) AND the packed 4-channel form (the X operand of the stem's
+// weight gradient) in ONE pass over the image, with 16-byte stores (round 5: the two launches of the kernel above — three strided
+// 4-byte loads and four 8-byte stores per thread each — were 0.22 ms at the head of every bf16 step with nothing beside them)
+template <int AT>
+__global__ void nchw3_to_nhwc16_and_4_kernel(const float* __restrict__ x, void* __restrict__ out16, void* __restrict__ out4, int N, long HW) {
+    static_assert(AT != 0, "16-bit storage");
+    const long total = (long)N * HW;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, p = i - n * HW;
+        const float* b = x + n * 3 * HW + p;
+        const f32x4 v = {b[0], b[HW], b[2 * HW], 0.f};
+        const f32x4 lo[2] = {v, z}, hi[2] = {z, z};
+        dbn_stq<AT>(out16, 2 * i, lo);
+        dbn_stq<AT>(out16, 2 * i + 1, hi);
+        if (out4) dbn_st4<AT>(out4, i, v);
+    }
+}
+
 template <int AT>
 __global__ void axpy_kernel(const void* __restrict__ x, void* __restrict__ y, long total4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x)
@@ -1077,6 +1096,15 @@ int dbn_nchw3_to_nhwc4_packed_t(int at, const float* x, void* out, int N, int H,
     DBN_REQUIRE(x && out && N > 0);
     DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
                                            x, out, N, (long)H * W, 1));
+    return dbn_status();
+}
+// 16-bit storage: out16 [N,H,W,16] (channels 3.. zero) and — out4 non-NULL — the packed [N,H,W,4] form, in one launch
+int dbn_nchw3_to_nhwc16_and_4_t(int at, const float* x, void* out16, void* out4, int N, int H, int W, void* stream) {
+    DBN_REQUIRE(x && out16 && N > 0 && (at == 1 || at == 2));
+    if (at == 1)
+        hipLaunchKernelGGL(nchw3_to_nhwc16_and_4_kernel<1>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out16, out4, N, (long)H * W);
+    else
+        hipLaunchKernelGGL(nchw3_to_nhwc16_and_4_kernel<2>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, out16, out4, N, (long)H * W);
     return dbn_status();
 }
 int dbn_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, void* stream) { return dbn_nchw3_to_nhwc4_t(0, x, out, N, H, W, stream); }

@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int P_STAGE = CBS * P_PATCH;  // one stage = the patches of CBS consecutive channel blocks; two stages
     static_assert(2 * P_STAGE <= X_FLOATS / 4, "the patch buffers live inside the exchange region");
     // + the statistics / sums scratch [<= 3][4][64] floats, a flag, 8 counts | the apply-on-load coefficients of <= 512 channels | the next item
-    __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 4 + 2 * 128 + 1];
+#ifndef DBN_WINO_LDSPAD
+#define DBN_WINO_LDSPAD 0  // (timing experiment: extra LDS in 16-byte units — 1024 pushes a workgroup over half a CU's LDS: one resident workgroup per CU)
+#endif
+    __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 4 + 2 * 128 + 1 + DBN_WINO_LDSPAD];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int ntn = p.Cd >> 6;
@@ -137,15 +140,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const __amdgpu_buffer_rsrc_t rsrcW =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wpk), 0, (unsigned)((long)p.Cs * 16 * p.Cd * 4), 0x00020000);
         const int tile = item;
-        const int mt = tile / ntn, nt = tile - mt * ntn, n0 = nt * 64;
+        auto mdiv = [](int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); };  // x / d with the host's magic(d)
+        const int mt = mdiv(tile, p.wino_m_ntn), nt = tile - mt * ntn, n0 = nt * 64;
         // patch geometry: image pn; the patch's first pixel row / column in the image (hs0, ws0: the halo starts one pixel before the
         // first output pixel), its row pitch `prow` and pixel count `ppx` (= the LDS stride between the four 16-byte chunks of a block)
         int pn, ph0 = 0, pw0 = 0, hs0, ws0, prow, ppx, t0 = 0, TWl = 1, ntiles = 0;
         if constexpr (LIN) {
             TWl = (p.Wdf + 1) >> 1;
             ntiles = ((p.Hdf + 1) >> 1) * TWl;
-            const int groups = (ntiles + 31) >> 5;
-            pn = mt / groups;
+            const int groups = p.wino_tpi;  // (= (ntiles + 31) >> 5)
+            pn = mdiv(mt, p.wino_m_tpi);
             t0 = (mt - pn * groups) << 5;
             const int tr0 = t0 / TWl, tr1 = min(t0 + 31, ntiles - 1) / TWl;  // first / last tile row of this group
             hs0 = 2 * tr0 - 1;
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             prow = 2 * TWl + 2;
             ppx = (2 * (tr1 - tr0 + 1) + 2) * prow;
         } else {
-            const int tw = (p.Wdf + 15) >> 4, tpi = ((p.Hdf + 7) >> 3) * tw;  // (ragged right / bottom patches: pixels past the map are masked)
-            pn = mt / tpi;
-            const int t_ = mt - pn * tpi, ty_ = t_ / tw;
+            const int tw = p.wino_tw, tpi = p.wino_tpi;  // ((W + 15) >> 4 patches per row, ((H + 7) >> 3) * tw per image; ragged right / bottom patches: pixels past the map are masked)
+            pn = mdiv(mt, p.wino_m_tpi);
+            const int t_ = mt - pn * tpi, ty_ = mdiv(t_, p.wino_m_tw);
             ph0 = ty_ * 8;
             pw0 = (t_ - ty_ * tw) * 16;
             hs0 = ph0 - 1;
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 
         DBN_TRACE_MARK(0);
+#if DBN_TRACE
+        if (p.trace && threadIdx.x == 0)  // HW_REG_HW_ID (wave / SIMD / CU / SH / SE) | HW_REG_XCC_ID << 32: which CU this workgroup ran on
+            p.trace[(long)blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) << 32);
+#endif
 #if DBN_TRACE
         unsigned long long tr_bar = 0, tr_t = 0;
 #endif
@@ -864,6 +873,17 @@ int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st) {
     p.work = (g_wino_persistent == 1 && items > slots) ? wino_work_counters(st) : nullptr;  // (a single round: nothing to pull)
     if (p.work || (g_wino_persistent == 2 && items > slots)) grid = slots;
     p.work_items = items;
+    auto magic = [](int d) { return ((1ULL << 40) + (unsigned long long)d - 1) / (unsigned long long)d; };
+    {
+        const int tw = lin ? 1 : (p.Wdf + 15) / 16;
+        const int tpi = lin ? (((p.Hdf + 1) / 2) * ((p.Wdf + 1) / 2) + 31) / 32 : ((p.Hdf + 7) / 8) * tw;
+        if ((long)items >= (1L << 23) || tpi > 65536 || (p.Cd >> 6) > 65536) return DBN_ERR_ARG;  // (the multipliers' exact range)
+        p.wino_tw = tw;
+        p.wino_tpi = tpi;
+        p.wino_m_ntn = magic(p.Cd >> 6);
+        p.wino_m_tpi = magic(tpi);
+        p.wino_m_tw = magic(tw);
+    }
     // the stagger of the persistent forms: g_wino_stagger permille of one item's matrix time (Cs / 16 blocks x 64 MFMAs x 64 clocks per wave)
     p.stagger_units = (grid < items && g_wino_stagger > 0) ? (int)((long)(p.Cs >> 4) * 4096 / 1024 * g_wino_stagger / 1000) : 0;
     p.trace = (DBN_TRACE && dbn_g_trace && grid <= dbn_g_trace_blocks) ? dbn_g_trace : nullptr;

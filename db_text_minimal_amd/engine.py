@@ -1219,10 +1219,11 @@ class Engine:
         self.generation += 1
         bb = m.backbone
         x4 = self.buf('x4', N, H, W, 4 if self.at == 0 else 16)  # 16-bit storage: 16-channel blocks (channels 3.. are zero)
-        check(L.dbn_nchw3_to_nhwc4_t(self.at, x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
-        if train and self.at != 0:  # the stem's weight gradient wants (tap, channel) columns without the 13 zero channels per block
-            x4w = self.buf('x4w', N, H, W, 4)
-            check(L.dbn_nchw3_to_nhwc4_packed_t(self.at, x.data_ptr(), x4w.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4_packed')
+        if self.at == 0:
+            check(L.dbn_nchw3_to_nhwc4_t(self.at, x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
+        else:  # ... and, for the stem's weight gradient, (tap, channel) columns without the 13 zero channels per block: one pass writes both
+            x4w = self.buf('x4w', N, H, W, 4) if train else None
+            check(L.dbn_nchw3_to_nhwc16_and_4_t(self.at, x.data_ptr(), x4.data_ptr(), _p(x4w), N, H, W, st), 'nchw3_to_nhwc16_and_4')
         y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)

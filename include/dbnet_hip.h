@@ -514,6 +514,8 @@ int dbn_nearest_up_bwd_t(int at, const void* dbig, void* dsrc, int N, int Hs, in
                          int accumulate, void* stream);
 /* x [N,3,H,W] fp32 -> [N,H,W,4] fp32 (at = 0) or [N,H,W,16] in the 16-bit type (channels 3.. zero) */
 int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W, void* stream);
+/* ... 16-bit storage: the 16-channel form and (out4 non-NULL) the packed 4-channel form of dbn_nchw3_to_nhwc4_packed_t in ONE launch */
+int dbn_nchw3_to_nhwc16_and_4_t(int at, const float* x, void* out16, void* out4, int N, int H, int W, void* stream);
 /* the same into [N,H,W,4] of the storage type (16-bit: 4 channels, not a 16-channel block): X operand of the stem weight gradient */
 int dbn_nchw3_to_nhwc4_packed_t(int at, const float* x, void* out, int N, int H, int W, void* stream);
 /* head tail with typed 64-channel inputs / input gradients; the maps, dpreds and the ConvT parameter gradients are fp32 */

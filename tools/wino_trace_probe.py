@@ -31,3 +31,21 @@ for (N, H, Ci, Co, what) in ((16, 160, 64, 64, '64->64 @160'), (16, 160, 256, 64
     print('   prologue %s us\n   loop     %s us\n   of which store+barrier %s us\n   epilogue %s us' % (
         q(us(t[:, 1] - t[:, 0])), q(us(t[:, 2] - t[:, 1])), q(us(t[:, 5])), q(us(t[:, 3] - t[:, 2]))))
     print('   loop per block %.2f us; MFMA time of one block for one wave alone: %.2f us' % (us(t[:, 2] - t[:, 1]).mean() / (Ci // 16), 64 * 64 / 2400.0))
+    # Round 5: are the two residents of a CU in LOCKSTEP?  Group the workgroups by the CU they ran on (HW_ID: cu 11:8, sh 12, se 15:13;
+    # XCC_ID) and measure, per CU, how long 0 / 1 / 2 of its residents were inside their main loop.
+    hw = t[:, 7]
+    key = ((hw >> 32) << 8) | ((hw >> 8) & 0xFF)
+    t0_, t1_ = t[:, 0].min(), t[:, 3].max()
+    occ = np.zeros(3)
+    for k_ in np.unique(key):
+        sel = t[key == k_]
+        ev = sorted([(a, 1) for a in sel[:, 1]] + [(b, -1) for b in sel[:, 2]])
+        cur, last = 0, t0_
+        for tt, d in ev:
+            occ[min(cur, 2)] += tt - last
+            cur, last = cur + d, tt
+        occ[min(cur, 2)] += t1_ - last
+    occ /= occ.sum()
+    print('   %d CUs seen, %.1f workgroups per CU; share of the launch with 0 / 1 / 2 residents of a CU inside the main loop: %.3f / %.3f / %.3f'
+          % (len(np.unique(key)), len(t) / len(np.unique(key)), occ[0], occ[1], occ[2]))
+    print('   launch %.1f us (first entry to last exit)' % us(t1_ - t0_))
