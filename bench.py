@@ -358,7 +358,7 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'winograd_f32_kernel', 'winograd_wgrad_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'stem7x7_b16_kernel', 'convt2x2_b16_kernel', 'winograd_f32_kernel', 'winograd_wgrad_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
                                 'head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
     clock = ClockProbe(dev, args.steps)
@@ -392,8 +392,8 @@ def main():
     step_ev[args.steps].record()
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
-    eng.prof = None
+    eng.prof = None  # (the collector stays off until the alternative modes below have been timed as well: round 5 found it to be the
+    # whole of the "bimodal" bf16 figure — a generation-2 pass is ~95 ms, half of twenty 10 ms steps; tools/bimodal_probe.py)
     if cprof is not None and rank == 0:
         import pstats
         pstats.Stats(cprof, stream=sys.stderr).sort_stats('tottime').print_stats(14)
@@ -491,7 +491,7 @@ def main():
     # sources have changed since, or the kernel is not in it, the line says `traffic: null, traffic_stale: true` instead.
     from db_text_minimal_amd._lib import source_stamp
     roofline['traffic_stale'] = True
-    for tag in ('r04', 'r03'):
+    for tag in ('r05', 'r04', 'r03'):
         try:
             prof = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))
         except (OSError, ValueError):
@@ -566,6 +566,7 @@ def main():
             alt[mode] = {'images_per_s': round(world * args.batch * args.steps / (time.perf_counter() - t1), 2),
                          'dtype': MATH[mode][0], 'note': MATH[mode][1]}
         eng.set_conv_math(args.math)
+    gc.enable()
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt

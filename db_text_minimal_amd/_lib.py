@@ -143,10 +143,23 @@ SIGNATURES.update({
     'dbn_nchw3_to_nhwc4_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
     'dbn_nchw3_to_nhwc4_packed_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
     'dbn_nchw3_to_nhwc16_and_4_t': 'ipppiiip',
+    'dbn_convt16_rows': '',
+    'dbn_convt16_panel_bytes': '',
+    'dbn_convt16_eligible': 'iiiiii',
+    'dbn_convt16_pack': 'ippp',
+    'dbn_convt16_bn_t': 'ippppiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
+    'dbn_stem16_padded_h': 'i',
+    'dbn_stem16_padded_w': 'i',
+    'dbn_stem16_rows': '',
+    'dbn_stem16_panel_bytes': '',
+    'dbn_stem16_eligible': 'iiii',
+    'dbn_stem16_pack': 'ippp',
+    'dbn_nchw3_to_padded4_t': 'ipppiiip',
+    'dbn_stem16_conv_bn_t': 'ipppiii' + 'pp' + 'ff' + 'ppppppp' + 'p',
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

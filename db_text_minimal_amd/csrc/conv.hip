@@ -95,6 +95,13 @@ int launch_igemm(IgemmParams& p, int cfg, int mode, int ns, hipStream_t st, int 
 
 }  // namespace
 
+int dbn_launch_bn_finalize_tiles(const float* ws, int rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(C), dim3(rows >= 2048 ? 1024 : 256), 0, st, ws, rows, C, gamma, beta, eps, momentum,
+                       run_mean, run_var, scale, shift, save_mean, save_rstd);
+    return dbn_status();
+}
+
 extern "C" {
 
 int dbn_has_experiments(void) { return DBN_HAS_EXPERIMENTS; }

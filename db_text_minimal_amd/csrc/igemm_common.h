@@ -275,6 +275,9 @@ static inline int chunk_images(int N, long px_rows, long src_bytes_per_image, lo
 
 // launchers of the kernel translation units.  cfg: 1 = 128x128, 2 = 256x64, 3 = 128x64, 4 = 64x64; mode: kernel MODE 0..3
 int dbn_launch_convt_f32(IgemmParams& p, hipStream_t st);  // convt_f32.hip
+// conv.hip: folds [3][C][rows] (+ [rows] counts) tile statistics into the train-mode BatchNorm's coefficients and running statistics
+int dbn_launch_bn_finalize_tiles(const float* ws, int rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st);
 int dbn_launch_winograd_f32(IgemmParams& p, hipStream_t st);                                       // winograd_f32.hip
 int dbn_launch_winograd_pack(const float* w, int O, int I, int Cs, int dgrad, float* out, hipStream_t st);
 int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st);

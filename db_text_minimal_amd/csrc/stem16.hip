@@ -1,0 +1,238 @@
+// The stem convolution in 16-bit storage (bf16 training, fp16 / bf16 inference): Conv2d(3 -> 64, 7x7, stride 2, pad 3, no bias) of
+// /root/reference/src/modules/resnet.py:167-172,231-235 on a PACKED input — four channels per pixel (r, g, b, 0), 8 bytes — instead of
+// the 16-channel blocks the generic 16-bit loop needs (13 of 16 input channels zeros: K = 784 where 147 are real; round-4 review:
+// 0.32 ms of the bf16 step at 0.04 of the matrix peak, 2.3 ms of the 1280^2 fp16 forward, plus a 16-channel copy of the image).
+//
+// GEMM view: M = N * Ho * Wo output pixels, N = 64, K = 7 rows x 8 taps x 4 channels = 224 = 14 k-steps of v_mfma_f32_32x32x16
+// (the eighth tap and the fourth channel carry zero weights).  The input is a zero-BORDERED tensor xp [N][H + 6][Wp][4] (the image at
+// offset (3, 3); Wp >= W + 6 even), so the conv is a "valid" one and no load needs a bounds test: k-step (r, sq) of output pixel
+// (ho, wo) is the 32 contiguous bytes at xp[n][2 ho + r][2 wo + 4 sq ..+3], and lane (li, lh) of the MFMA — row li, k-half lh — takes
+// 16 of them straight from global memory into its A fragment (32 lanes x 16 bytes = 512 contiguous bytes per half-wave; neighbouring
+// rows overlap: L1 / L2 hits).  The whole weight panel (28 KB) lives in registers for the life of a wave, a wave walks 32-row blocks
+// with a grid stride, and the 32 x 64 result leaves through a wave-private LDS transpose as 16-byte row-major stores: no LDS panels,
+// no barrier.  Train mode: the BatchNorm statistics (pivot, sum, sum of squares per channel over the fp32 accumulators) are kept per
+// WAVE over all its blocks — one partial row per wave in bn_finalize_tiles_kernel's format.
+#include "igemm_common.h"
+
+namespace {
+
+struct Stem16Params {
+    const void* xp;    // [N][Hp][Wp][4] 16-bit, zero border
+    const void* wpk;   // [14 k-steps][2 k-halves][64 columns][8] 16-bit (dbn_stem16_pack)
+    void* y;           // [N][Ho][Wo][64] 16-bit
+    float* stats;      // optional: [3][64][rows] pivot / sum / sum sq + [rows] counts, rows = 4 * gridDim.x
+    int N, Ho, Wo, Hp, Wp;
+    int M;             // N * Ho * Wo (< 2^24)
+    unsigned x_bytes;
+};
+
+constexpr int ST_PITCH = 64 + 8;  // 16-bit elements per row of the wave's transpose buffer (+16 bytes: rotates the banks)
+
+template <int AT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem7x7_b16_kernel(const Stem16Params p) {
+    static_assert(AT == 1 || AT == 2, "16-bit storage");
+    __shared__ unsigned short smem[4 * 32 * ST_PITCH];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    // the weight panel: fragment of k-step t, column block b = 16 bytes at ((t * 2 + lh) * 64 + b * 32 + li) * 16
+    u32x4_ bw[14][2];
+    {
+        const u32x4_* W = reinterpret_cast<const u32x4_*>(p.wpk);
+#pragma unroll
+        for (int t = 0; t < 14; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bw[t][b] = W[(t * 2 + lh) * 64 + b * 32 + li];
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xp), 0, p.x_bytes, 0x00020000);
+    unsigned short* const T = smem + wave * 32 * ST_PITCH;
+    const int HWo = p.Ho * p.Wo;
+    const float r_hw = 1.0f / (float)HWo, r_w = 1.0f / (float)p.Wo;
+    const unsigned rowpitch = (unsigned)p.Wp * 8u;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+    bool have = false;
+    int cnt = 0;
+    // The A fragments of a block travel in two halves of seven k-steps: the second half is in flight under the first half's MFMAs, the NEXT
+    // block's first half under the second half's MFMAs and the whole epilogue (first build: all fourteen loads at the top of a block and
+    // nothing in flight while it multiplied, transposed and stored — 4.3 us per block, 860 us for the 1280^2 fp16 forward's 2.1 GB).
+    auto block_base = [&](int mb_) {
+        const int m = min(mb_ * 32 + li, p.M - 1);  // (rows past M repeat the last pixel: loaded, multiplied, never stored or counted)
+        int n, rem, ho, wo;
+        divmod24(m, HWo, r_hw, n, rem);
+        divmod24(rem, p.Wo, r_w, ho, wo);
+        return (unsigned)((n * p.Hp + 2 * ho) * p.Wp + 2 * wo) * 8u + (unsigned)lh * 16u;
+    };
+    auto load_half = [&](u32x4_ (&a)[7], unsigned base, int half) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int t = half * 7 + i;
+            a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(base + (unsigned)(t >> 1) * rowpitch + (unsigned)(t & 1) * 32u), 0, 0);
+        }
+    };
+    u32x4_ a0[7], a1[7];
+    if (gw * 32 < p.M) load_half(a0, block_base(gw), 0);
+    for (int mb = gw; mb * 32 < p.M; mb += nw) {
+        const int m0 = mb * 32;
+        load_half(a1, block_base(mb), 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        auto mma = [&](const u32x4_ (&a)[7], int half) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int t = half * 7 + i;
+                    if constexpr (AT == 2)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, bw[t][b]), acc[b], 0, 0, 0);
+                    else
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bw[t][b]), acc[b], 0, 0, 0);
+                }
+        };
+        mma(a0, 0);
+        if ((mb + nw) * 32 < p.M) load_half(a0, block_base(mb + nw), 0);  // (the next block's first half)
+        mma(a1, 1);
+        const int nrows = min(32, p.M - m0);
+        if (p.stats) {
+            if (!have) {  // the wave's pivot: row 0 of its first block (accumulator register 0 of the lh = 0 half)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) pv[b] = __shfl(acc[b][0], li, 64);
+                have = true;
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float d = row < nrows ? acc[b][r] - pv[b] : 0.f;
+                    s1[b] += d;
+                    s2[b] += d * d;
+                }
+            cnt += nrows;
+        }
+        // 32 x 64 tile -> the wave's transpose buffer in the storage type -> 16-byte row-major stores (a row = 128 contiguous bytes)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                dbn_st1<AT>(T, row * ST_PITCH + b * 32 + li, acc[b][r]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: LDS operations complete in order; the fence is for the compiler)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = lane + 64 * j, row = piece >> 3, c8 = piece & 7;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * ST_PITCH + c8 * 8);
+            if (row < nrows) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(p.y) + ((long)(m0 + row) * 64 + c8 * 8)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the buffer is rewritten by the next block)
+    }
+    if (p.stats) {
+        const int rows = nw;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float t1 = s1[b] + __shfl_xor(s1[b], 32, 64), t2 = s2[b] + __shfl_xor(s2[b], 32, 64);
+            if (lh == 0) {
+                const long c = b * 32 + li;
+                p.stats[(0L * 64 + c) * rows + gw] = pv[b];
+                p.stats[(1L * 64 + c) * rows + gw] = t1;
+                p.stats[(2L * 64 + c) * rows + gw] = t2;
+            }
+        }
+        if (lane == 0) p.stats[3L * 64 * rows + gw] = (float)cnt;
+    }
+}
+
+// w [64][3][7][7] fp32 -> [14][2][64][8] in the 16-bit type: k-step t = (r = t >> 1, sq = t & 1), k-half lh, element j: tap 4 sq + 2 lh + (j >> 2),
+// channel j & 3; the eighth tap and the fourth channel are zero
+__global__ void stem16_pack_kernel(const float* __restrict__ w, int f16, unsigned short* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 14 * 2 * 64 * 8) return;
+    const int j = idx & 7, col = (idx >> 3) & 63, lh = (idx >> 9) & 1, t = idx >> 10;
+    const int r = t >> 1, sq = t & 1, tap = 4 * sq + 2 * lh + (j >> 2), ch = j & 3;
+    const float v = (tap < 7 && ch < 3) ? w[((col * 3 + ch) * 7 + r) * 7 + tap] : 0.f;
+    if (f16) {
+        const _Float16 h = (_Float16)v;
+        out[idx] = __builtin_bit_cast(unsigned short, h);
+    } else {
+        out[idx] = (unsigned short)bf16_bits_rne(v);
+    }
+}
+
+// x [N,3,H,W] fp32 -> the interior of xp [N][Hp][Wp][4] (image at (3, 3); the border stays as the caller zeroed it) and, x4 non-NULL, the
+// packed [N][H][W][4] form (the X operand of the stem's weight gradient), one pass
+template <int AT>
+__global__ void nchw3_to_padded4_kernel(const float* __restrict__ x, void* __restrict__ xp, void* __restrict__ x4, int N, int H, int W, int Hp,
+                                        int Wp) {
+    const long HW = (long)H * W, total = (long)N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / HW, q = i - n * HW;
+        const int h = (int)(q / W), w_ = (int)(q - (long)h * W);
+        const float* b = x + n * 3 * HW + q;
+        const f32x4 v = {b[0], b[HW], b[2 * HW], 0.f};
+        dbn_st4<AT>(xp, (n * Hp + h + 3) * Wp + w_ + 3, v);
+        if (x4) dbn_st4<AT>(x4, i, v);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// geometry of the zero-bordered packed input of a [N,3,H,W] image: rows H + 6, row pitch in pixels (even, >= W + 7)
+int dbn_stem16_padded_w(int W) { return (W + 8) & ~1; }
+int dbn_stem16_padded_h(int H) { return H + 6; }
+// partial rows of BatchNorm statistics a call writes (= waves of the launch); ws: (3 * 64 + 1) * rows floats
+int dbn_stem16_rows(void) { return 4 * 512; }
+long dbn_stem16_panel_bytes(void) { return 14L * 2 * 64 * 8 * 2; }
+
+// kind: 1 bf16, 2 fp16
+int dbn_stem16_pack(int kind, const float* w_oihw, void* out, void* stream) {
+    DBN_REQUIRE(w_oihw && out && (kind == 1 || kind == 2));
+    hipLaunchKernelGGL(stem16_pack_kernel, dim3(56), dim3(256), 0, (hipStream_t)stream, w_oihw, kind == 2 ? 1 : 0, reinterpret_cast<unsigned short*>(out));
+    return dbn_status();
+}
+
+int dbn_nchw3_to_padded4_t(int at, const float* x, void* xp, void* x4, int N, int H, int W, void* stream) {
+    DBN_REQUIRE(x && xp && N > 0 && H > 0 && W > 0 && (at == 1 || at == 2));
+    const int Hp = dbn_stem16_padded_h(H), Wp = dbn_stem16_padded_w(W);
+    if (at == 1)
+        hipLaunchKernelGGL(nchw3_to_padded4_kernel<1>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, xp, x4, N, H, W, Hp, Wp);
+    else
+        hipLaunchKernelGGL(nchw3_to_padded4_kernel<2>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, x, xp, x4, N, H, W, Hp, Wp);
+    return dbn_status();
+}
+
+// 1: dbn_stem16_conv_bn_t takes the call (16-bit storage, index ranges)
+int dbn_stem16_eligible(int at, int N, int H, int W) {
+    if (!((at == 1 || at == 2) && N > 0 && H >= 7 && W >= 7)) return 0;
+    const long Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    return (long)N * Ho * Wo < (1L << 24) && (long)N * dbn_stem16_padded_h(H) * dbn_stem16_padded_w(W) * 8 < dbn_g_byte_limit &&
+           (long)N * Ho * Wo * 64 * 2 < (1L << 40);
+}
+
+// y [N][Ho][Wo][64] = conv7x7/2 (xp), Ho = (H - 1) / 2 + 1.  gamma non-NULL: + the train-mode BatchNorm that follows, as dbn_conv_bn_t
+// (scale / shift / saved mean / rstd, running statistics; ws: (3 * 64 + 1) * dbn_stem16_rows() floats).
+int dbn_stem16_conv_bn_t(int at, const void* xp, const void* wpk, void* y, int N, int H, int W, const float* gamma, const float* beta, float eps,
+                         float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                         float* ws, void* stream) {
+    DBN_REQUIRE(xp && wpk && y && dbn_stem16_eligible(at, N, H, W));
+    DBN_REQUIRE(!gamma || (beta && scale && shift && save_mean && save_rstd && ws));
+    Stem16Params p;
+    p.xp = xp; p.wpk = wpk; p.y = y; p.stats = gamma ? ws : nullptr;
+    p.N = N; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.Hp = dbn_stem16_padded_h(H); p.Wp = dbn_stem16_padded_w(W);
+    p.M = N * p.Ho * p.Wo;
+    p.x_bytes = (unsigned)((long)N * p.Hp * p.Wp * 8);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = 512;  // two workgroups per CU; rows = 4 * grid
+    if (at == 1) hipLaunchKernelGGL(stem7x7_b16_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(stem7x7_b16_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+    if (!gamma) return dbn_status();
+    dbn_launch_bn_finalize_tiles(ws, 4 * grid, 64, gamma, beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd, st);
+    return dbn_status();
+}
+
+}  // extern "C"

@@ -716,7 +716,50 @@ class Engine:
             self.prof.end()
         return y, sc, sh
 
+    # ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage through its own kernel (round 5, csrc/convt16.hip: the layer is
+    # HBM-bound and the generic parity-class launch ran it at 2.5x its memory time).  DBN_CONVT16=0: the generic launch.
+    convt16 = os.environ.get('DBN_CONVT16', '1') == '1'
+
+    def _convt16(self, name, x, ct, out_name, bn_name=None, bn=None):
+        """None when the layer does not take the 16-bit ConvT kernel; else (y, scale, shift) — scale / shift None without a BatchNorm."""
+        N, H, W, C = x.shape
+        L = self.L
+        if not (self.convt16 and self.at != 0 and ct.k == 2 and ct.stride == 2 and bool(L.dbn_convt16_eligible(self.at, N, H, W, C, ct.cout))
+                and ct.cin == C):
+            return None
+        w = ct.weight
+        key = (name, 'convt16', self.kind)
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        ent = self.packs.get(key)
+        if ent is None or ent[1] != stamp:
+            panel = ent[0] if ent is not None else torch.empty(L.dbn_convt16_panel_bytes(), device=w.device, dtype=torch.uint8)
+            check(L.dbn_convt16_pack(self.kind, w.data_ptr(), panel.data_ptr(), self.stream), 'convt16_pack')
+            self.packs[key] = (panel, stamp)
+        panel = self.packs[key][0]
+        y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
+        if self.prof:
+            self.prof.begin('convt2x2_b16_kernel<%d>' % self.at, 2.0 * N * H * W * C * ct.cout * 4, float(2 * (x.numel() + y.numel())), 'convT fwd ' + name)
+        sc = sh = None
+        if bn is not None:
+            sc, sh = self.fbuf(bn_name + '/scale', ct.cout), self.fbuf(bn_name + '/shift', ct.cout)
+            mu, rs = self.fbuf(bn_name + '/mean', ct.cout), self.fbuf(bn_name + '/rstd', ct.cout)
+            ws = self.scratch('_conv_bn_ws', (3 * 64 + 1) * L.dbn_convt16_rows())
+            check(L.dbn_convt16_bn_t(self.at, x.data_ptr(), panel.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, bn.weight.data_ptr(),
+                                     bn.bias.data_ptr(), bn.eps, bn.momentum, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                     sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), 'convt16+bn ' + name)
+            self.nbt_pending[bn_name] = self.nbt_pending.get(bn_name, 0) + 1
+        else:
+            check(L.dbn_convt16_bn_t(self.at, x.data_ptr(), panel.data_ptr(), _p(ct.bias), y.data_ptr(), N, H, W, None, None, 0.0, 0.0, None,
+                                     None, None, None, None, None, None, self.stream), 'convt16 ' + name)
+        if self.prof:
+            self.prof.end()
+        return y, sc, sh
+
     def convT_bn(self, name, x, ct, out_name, bn_name, bn, train):
+        if train and self.fuse_bn_stats:
+            got = self._convt16(name, x, ct, out_name, bn_name, bn)
+            if got is not None:
+                return got
         if not (train and self.fuse_bn_stats):
             y = self.convT_fwd(name, x, ct, out_name)
             sc, sh = self.bn_coef(bn_name, bn, y, train)
@@ -992,6 +1035,9 @@ class Engine:
             launch()
 
     def convT_fwd(self, name, x, ct, out_name):
+        got = self._convt16(name, x, ct, out_name)
+        if got is not None:
+            return got[0]
         N, H, W, C = x.shape
         wpk = self.pack(name, ct.weight, 1, 2)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
@@ -1218,13 +1264,19 @@ class Engine:
         L, st = self.L, self.stream
         self.generation += 1
         bb = m.backbone
-        x4 = self.buf('x4', N, H, W, 4 if self.at == 0 else 16)  # 16-bit storage: 16-channel blocks (channels 3.. are zero)
-        if self.at == 0:
+        stem16 = self._stem16_ok(bb.conv1, N, H, W)
+        if stem16:
+            y0, sc, sh = self._stem16_conv_bn(x, bb.conv1, bb.bn1, train)
+        x4 = None if stem16 else self.buf('x4', N, H, W, 4 if self.at == 0 else 16)  # 16-bit storage: 16-channel blocks (channels 3.. are zero)
+        if stem16:
+            pass
+        elif self.at == 0:
             check(L.dbn_nchw3_to_nhwc4_t(self.at, x.data_ptr(), x4.data_ptr(), N, H, W, st), 'nchw3_to_nhwc4')
         else:  # ... and, for the stem's weight gradient, (tap, channel) columns without the 13 zero channels per block: one pass writes both
             x4w = self.buf('x4w', N, H, W, 4) if train else None
             check(L.dbn_nchw3_to_nhwc16_and_4_t(self.at, x.data_ptr(), x4.data_ptr(), _p(x4w), N, H, W, st), 'nchw3_to_nhwc16_and_4')
-        y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
+        if not stem16:
+            y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
         H0, W0 = y0.shape[1], y0.shape[2]
         pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
         self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
@@ -1334,6 +1386,59 @@ class Engine:
             self.saved_out = head_out
             self.saved_shape = (N, H, W, Hh, Wh, resample)
         return out
+
+    # ---- the stem in 16-bit storage (round 5, csrc/stem16.hip): conv 7x7 / 2 on a PACKED, zero-bordered 4-channel image instead of 16-channel
+    # blocks with 13 zero channels (K = 224 instead of 784, no 16-channel copy of the input).  DBN_STEM16=0: the generic 16-bit loop.
+    stem16 = os.environ.get('DBN_STEM16', '1') == '1'
+
+    def _stem16_ok(self, conv, N, H, W):
+        return (self.stem16 and self.at != 0 and (conv.k, conv.stride, conv.padding, conv.cin, conv.cout) == (7, 2, 3, 3, 64) and conv.bias is None
+                and bool(self.L.dbn_stem16_eligible(self.at, N, H, W)))
+
+    def _stem16_conv_bn(self, x, conv, bn, train):
+        """x: the fp32 NCHW input.  Returns (y, scale, shift) like conv_bn; in training also leaves the packed [N,H,W,4] image in 'x4w'."""
+        L, st = self.L, self.stream
+        N, _, H, W = x.shape
+        Hp, Wp = L.dbn_stem16_padded_h(H), L.dbn_stem16_padded_w(W)
+        dt = ACT_DTYPES[self.at]
+        xp = self.bufs.get('x4p')
+        if xp is None or tuple(xp.shape) != (N, Hp, Wp, 4) or xp.dtype != dt or xp.device != self.flat.device:
+            xp = torch.zeros((N, Hp, Wp, 4), device=self.flat.device, dtype=dt)  # (the zero border is written once, here)
+            self.bufs['x4p'] = xp
+        x4w = self.buf('x4w', N, H, W, 4) if train else None
+        check(L.dbn_nchw3_to_padded4_t(self.at, x.data_ptr(), xp.data_ptr(), _p(x4w), N, H, W, st), 'nchw3_to_padded4')
+        w = conv.weight
+        key = ('backbone.conv1', 'stem16', self.kind)
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        ent = self.packs.get(key)
+        if ent is None or ent[1] != stamp:
+            panel = ent[0] if ent is not None else torch.empty(L.dbn_stem16_panel_bytes(), device=w.device, dtype=torch.uint8)
+            check(L.dbn_stem16_pack(self.kind, w.data_ptr(), panel.data_ptr(), st), 'stem16_pack')
+            self.packs[key] = (panel, stamp)
+        panel = self.packs[key][0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = self.buf('stem/y', N, Ho, Wo, 64)
+        name = 'backbone.bn1'
+        if self.prof:
+            self.prof.begin('stem7x7_b16_kernel<%d>' % self.at, 2.0 * N * Ho * Wo * 64 * 3 * 49, float(2 * (N * Hp * Wp * 4 + N * Ho * Wo * 64)),
+                            'fwd backbone.conv1')
+        if train and self.fuse_bn_stats:
+            sc, sh = self.fbuf(name + '/scale', 64), self.fbuf(name + '/shift', 64)
+            mu, rs = self.fbuf(name + '/mean', 64), self.fbuf(name + '/rstd', 64)
+            ws = self.scratch('_conv_bn_ws', (3 * 64 + 1) * L.dbn_stem16_rows())
+            check(L.dbn_stem16_conv_bn_t(self.at, xp.data_ptr(), panel.data_ptr(), y.data_ptr(), N, H, W, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                         bn.eps, bn.momentum, bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(),
+                                         sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), st), 'stem16 conv+bn')
+            self.nbt_pending[name] = self.nbt_pending.get(name, 0) + 1
+        else:
+            check(L.dbn_stem16_conv_bn_t(self.at, xp.data_ptr(), panel.data_ptr(), y.data_ptr(), N, H, W, None, None, 0.0, 0.0, None, None,
+                                         None, None, None, None, None, st), 'stem16 conv')
+            sc = sh = None
+        if self.prof:
+            self.prof.end()
+        if sc is None:
+            sc, sh = self.bn_coef(name, bn, y, train)
+        return y, sc, sh
 
     # ---- deformable conv2 (resnet.py:54-65,81-82,111-124,145-146): offsets conv -> bilinear im2col -> 1x1 GEMM
     def _offset_conv(self, name, oc):

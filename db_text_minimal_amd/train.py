@@ -127,6 +127,16 @@ class DBTrainer:
         self.use_graph = os.environ.get('DBN_STEP_GRAPH', '0') == '1'
         self.graph_warmup = 2
         self._graph = None
+        # The cyclic garbage collector and the step (round 5: the root cause of the "bimodal" 16-bit step of DESIGN section 9 row 3 /
+        # section 12.4 — tools/bimodal_probe.py).  A step enqueues ~300 launches in ~4 ms of host time and creates a few thousand short-lived
+        # Python objects; every few steps that trips a generation-2 collection, which walks the WHOLE heap of the process (torch, the
+        # model's module tree, the engine's tables: ~90-100 ms) while the GPU runs dry — one such stall inside twenty 10 ms bf16 steps
+        # is the difference between 1670 and 1280 images/s, two are 1100.  Nothing in a step creates reference cycles.  After the
+        # third step — every buffer, panel and table exists by then — the trainer collects once and FREEZES the heap (gc.freeze():
+        # existing objects leave the collector's generations for good), so later passes scan only what was created since: < 1 ms.
+        # DBN_GC_FREEZE=0 leaves the collector alone.
+        self.gc_freeze = os.environ.get('DBN_GC_FREEZE', '1') == '1'
+        self._steps = 0
 
     def sync_from_rank0(self):
         """Data-parallel replicas must start from identical state: rank 0's flat parameter buffer, its BatchNorm buffers and
@@ -223,6 +233,11 @@ class DBTrainer:
         model, eng = self.model, self.model.engine
         if not model.training:
             raise RuntimeError('DBTrainer.step requires model.train()')
+        self._steps += 1
+        if self.gc_freeze and self._steps == 4:
+            import gc
+            gc.collect()
+            gc.freeze()
         gts = gts.contiguous().float()
         if self._need_sync:
             self._warm_arena_then_sync(img, gts)

@@ -514,6 +514,34 @@ int dbn_nearest_up_bwd_t(int at, const void* dbig, void* dsrc, int N, int Hs, in
                          int accumulate, void* stream);
 /* x [N,3,H,W] fp32 -> [N,H,W,4] fp32 (at = 0) or [N,H,W,16] in the 16-bit type (channels 3.. zero) */
 int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W, void* stream);
+/* ---- The stem convolution in 16-bit storage on a PACKED input (round 5; csrc/stem16.hip): Conv2d(3 -> 64, 7x7, stride 2, pad 3, no bias) of
+ * modules/resnet.py:167-172,231-235.  The image is stored as xp [N][dbn_stem16_padded_h(H)][dbn_stem16_padded_w(W)][4] in the 16-bit type —
+ * (r, g, b, 0) per pixel at offset (3, 3) inside a ZERO border the caller provides once (dbn_nchw3_to_padded4_t rewrites the interior only;
+ * x4 non-NULL: also the packed [N][H][W][4] form, the X operand of the stem's weight gradient) — so the conv needs no bounds tests and
+ * K = 7 x 8 x 4 = 224 instead of the 7 x 7 x 16 = 784 of the 16-channel-block form.  wpk: dbn_stem16_panel_bytes() bytes from
+ * dbn_stem16_pack(kind 1 bf16 | 2 fp16, w [64][3][7][7] fp32).  y [N][(H-1)/2+1][(W-1)/2+1][64] in the 16-bit type.  gamma non-NULL: + the
+ * train-mode BatchNorm that follows, as dbn_conv_bn_t (ws: (3 * 64 + 1) * dbn_stem16_rows() floats). */
+int dbn_stem16_padded_h(int H);
+int dbn_stem16_padded_w(int W);
+int dbn_stem16_rows(void);
+long dbn_stem16_panel_bytes(void);
+int dbn_stem16_eligible(int at, int N, int H, int W);
+int dbn_stem16_pack(int kind, const float* w_oihw, void* out, void* stream);
+int dbn_nchw3_to_padded4_t(int at, const float* x, void* xp, void* x4, int N, int H, int W, void* stream);
+int dbn_stem16_conv_bn_t(int at, const void* xp, const void* wpk, void* y, int N, int H, int W, const float* gamma, const float* beta, float eps,
+                         float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                         float* ws, void* stream);
+/* ---- ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage (round 5; csrc/convt16.hip): the head's up-sampling layers,
+ * modules/segmentation_head.py:27-29,74-76.  x [N][H][W][64], y [N][2H][2W][64] in the 16-bit type; wpk: dbn_convt16_panel_bytes() bytes from
+ * dbn_convt16_pack(kind 1 bf16 | 2 fp16, w [64][64][2][2] fp32 — the module's own [Cin][Cout][kh][kw] layout); bias [64] fp32 or NULL.
+ * gamma non-NULL: + the train-mode BatchNorm that follows, as dbn_conv_bn_t (ws: (3 * 64 + 1) * dbn_convt16_rows() floats). */
+int dbn_convt16_rows(void);
+long dbn_convt16_panel_bytes(void);
+int dbn_convt16_eligible(int at, int N, int H, int W, int Cin, int Cout);
+int dbn_convt16_pack(int kind, const float* w_iohw, void* out, void* stream);
+int dbn_convt16_bn_t(int at, const void* x, const void* wpk, const float* bias, void* y, int N, int H, int W, const float* gamma, const float* beta,
+                     float eps, float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                     float* ws, void* stream);
 /* ... 16-bit storage: the 16-channel form and (out4 non-NULL) the packed 4-channel form of dbn_nchw3_to_nhwc4_packed_t in ONE launch */
 int dbn_nchw3_to_nhwc16_and_4_t(int at, const float* x, void* out16, void* out4, int N, int H, int W, void* stream);
 /* the same into [N,H,W,4] of the storage type (16-bit: 4 channels, not a 16-channel block): X operand of the stem weight gradient */

@@ -1867,3 +1867,95 @@ def test_winograd_persistent_forms_are_bit_identical(N, Ci, Co, H, W):
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('at', [1, 2])
+@pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 96, 70), (3, 33, 47), (2, 128, 160)])
+def test_stem_conv_on_packed_16bit_input(N, H, W, at):
+    """Round 5, csrc/stem16.hip: the stem Conv2d(3 -> 64, 7x7, stride 2, pad 3) of resnet.py:167-172,231-235 in 16-bit storage on the packed,
+    zero-bordered 4-channel image (dbn_nchw3_to_padded4_t + dbn_stem16_pack + dbn_stem16_conv_bn_t) against F.conv2d in fp64 on the
+    operands as stored (image and weights rounded to the storage type): what is left is fp32 accumulation and the output rounding
+    (2^-9 bf16 / 2^-11 fp16 relative); the train-mode BatchNorm statistics — taken from the fp32 accumulators — against F.batch_norm.
+    Odd sizes: Ho = (H - 1) / 2 + 1, partial last 32-row block."""
+    dt = {1: torch.bfloat16, 2: torch.float16}[at]
+    x = rnd(N, 3, H, W, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=(2.0 / 147)**0.5)
+    xd, wd = x.to(DEV), w.to(DEV)
+    Hp, Wp = L().dbn_stem16_padded_h(H), L().dbn_stem16_padded_w(W)
+    xp = torch.zeros(N, Hp, Wp, 4, device=DEV, dtype=dt)
+    x4 = torch.full((N, H, W, 4), float('nan'), device=DEV, dtype=dt)
+    _lib.check(L().dbn_nchw3_to_padded4_t(at, xd.data_ptr(), xp.data_ptr(), x4.data_ptr(), N, H, W, stream()), 'padded4')
+    xs = x.to(dt).float()  # the image as stored
+    assert torch.equal(x4[..., :3].float().cpu(), xs.permute(0, 2, 3, 1)) and float(x4[..., 3].abs().max()) == 0
+    assert torch.equal(xp[:, 3:H + 3, 3:W + 3, :3].float().cpu(), xs.permute(0, 2, 3, 1))
+    assert float(xp[:, :3].abs().max()) == 0 and float(xp[:, H + 3:].abs().max()) == 0 and float(xp[:, :, :3].abs().max()) == 0 and float(xp[:, :, W + 3:].abs().max()) == 0
+    panel = torch.empty(L().dbn_stem16_panel_bytes(), device=DEV, dtype=torch.uint8)
+    _lib.check(L().dbn_stem16_pack(at, wd.data_ptr(), panel.data_ptr(), stream()), 'stem16 pack')
+    assert L().dbn_stem16_eligible(at, N, H, W)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ref = F.conv2d(xs.double(), w.to(dt).double(), None, 2, 3)
+    assert ref.shape == (N, 64, Ho, Wo)
+    scale = float(ref.abs().max())
+    tol = {1: 2.0**-8, 2: 2.0**-10}[at]
+    y = torch.full((N, Ho, Wo, 64), float('nan'), device=DEV, dtype=dt)
+    _lib.check(L().dbn_stem16_conv_bn_t(at, xp.data_ptr(), panel.data_ptr(), y.data_ptr(), N, H, W, None, None, 0.0, 0.0, None, None, None, None,
+                                        None, None, None, stream()), 'stem16 conv')
+    report('stem16 conv at %d' % at, nchw(y.float()), ref, tol * scale, tol)
+    # with the train-mode BatchNorm statistics
+    gamma, beta = (rnd(64, seed=4) * 0.3 + 1).to(DEV), rnd(64, seed=5).to(DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    sc, sh, mu, rs = (torch.full((64, ), float('nan'), device=DEV) for _ in range(4))
+    ws = torch.full(((3 * 64 + 1) * L().dbn_stem16_rows(), ), float('nan'), device=DEV)
+    y2 = torch.full_like(y, float('nan'))
+    _lib.check(L().dbn_stem16_conv_bn_t(at, xp.data_ptr(), panel.data_ptr(), y2.data_ptr(), N, H, W, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
+                                        rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(),
+                                        stream()), 'stem16 conv+bn')
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+    report('stem16 BN mean', mu.cpu(), mean, 1e-5 * scale, 1e-5)
+    report('stem16 BN rstd', rs.cpu(), 1.0 / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+    report('stem16 BN scale', sc.cpu(), gamma.cpu().double() / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+    n = N * Ho * Wo
+    report('stem16 BN running var', rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), 1e-6, 1e-4)
+
+
+@pytest.mark.parametrize('at', [1, 2])
+@pytest.mark.parametrize('N,H,W,with_bias', [(2, 16, 16, True), (1, 24, 17, False), (3, 5, 7, True), (2, 40, 40, True)])
+def test_conv_transpose_2x2_16bit_kernel(N, H, W, with_bias, at):
+    """Round 5, csrc/convt16.hip: ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage (segmentation_head.py:27-29,74-76) with
+    its own kernel — weight panel in registers, A fragments straight from global memory, LDS-transposed 16-byte stores — against
+    F.conv_transpose2d in fp64 on the operands as stored, and its train-mode BatchNorm statistics against F.batch_norm; equal to the
+    generic parity-class launch up to the output rounding.  Odd sizes: partial last 32-pixel block."""
+    dt = {1: torch.bfloat16, 2: torch.float16}[at]
+    x = rnd(N, 64, H, W, seed=1)
+    w = rnd(64, 64, 2, 2, seed=2, scale=(2.0 / 64)**0.5)
+    b = rnd(64, seed=3) * 0.1 if with_bias else None
+    xs = nhwc(x).to(dt)
+    wd = w.to(DEV)
+    bd = b.to(DEV) if with_bias else None
+    panel = torch.empty(L().dbn_convt16_panel_bytes(), device=DEV, dtype=torch.uint8)
+    _lib.check(L().dbn_convt16_pack(at, wd.data_ptr(), panel.data_ptr(), stream()), 'convt16 pack')
+    assert L().dbn_convt16_eligible(at, N, H, W, 64, 64)
+    ref = F.conv_transpose2d(nchw(xs.float()).double(), w.to(dt).double(), b.double() if with_bias else None, 2)
+    scale = float(ref.abs().max())
+    tol = {1: 2.0**-8, 2: 2.0**-10}[at]
+    y = torch.full((N, 2 * H, 2 * W, 64), float('nan'), device=DEV, dtype=dt)
+    _lib.check(L().dbn_convt16_bn_t(at, xs.data_ptr(), panel.data_ptr(), bd.data_ptr() if with_bias else None, y.data_ptr(), N, H, W, None, None,
+                                    0.0, 0.0, None, None, None, None, None, None, None, stream()), 'convt16')
+    report('convt16 at %d' % at, nchw(y.float()), ref, tol * scale, tol)
+    gamma, beta = (rnd(64, seed=4) * 0.3 + 1).to(DEV), rnd(64, seed=5).to(DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    sc, sh, mu, rs = (torch.full((64, ), float('nan'), device=DEV) for _ in range(4))
+    ws = torch.full(((3 * 64 + 1) * L().dbn_convt16_rows(), ), float('nan'), device=DEV)
+    y2 = torch.full_like(y, float('nan'))
+    _lib.check(L().dbn_convt16_bn_t(at, xs.data_ptr(), panel.data_ptr(), bd.data_ptr() if with_bias else None, y2.data_ptr(), N, H, W,
+                                    gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                    mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'convt16+bn')
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
+    report('convt16 BN mean', mu.cpu(), mean, 1e-5 * scale, 1e-5)
+    report('convt16 BN rstd', rs.cpu(), 1.0 / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
+    n = N * 4 * H * W
+    report('convt16 BN running var', rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), 1e-6, 1e-4)

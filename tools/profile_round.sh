@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-A="--no-cpu-baseline --no-alt-modes"
+A="--no-cpu-baseline --no-alt-modes --no-parity"   # (the profiled passes skip the parity gate: its extra step would sit in the traces; the plain bench line below runs it)
 rocprofv3 --kernel-trace -d $O/trace -o r01 -- python3 $R/bench.py --steps 10 --warmup 3 $A > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A > $O/pmc_write.log 2>&1
@@ -31,8 +31,19 @@ rocprofv3 --kernel-trace -d $O/trace_x3 -o r01 -- python3 $R/bench.py --steps 10
 cd $R
 python3 tools/rocpd_stats.py $O/trace_x3/r01_results.db $O/kernel_stats_bf16x3.md > /dev/null
 grep '^{"metric"' $O/bench_bf16x3_under_rocprof.log > $O/bench_bf16x3_under_rocprof.json
-for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline
+python3 tools/step_breakdown.py $O/trace_bf16/r01_results.db 6 > $O/step_breakdown_bf16.txt 2>&1
+for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline and parity object
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-modes --math $m 2>/dev/null | grep '^{"metric"' > $O/bench_n1_$m.json
 done
+# round 5: the probes behind DESIGN section 13 (alone, HIP events) and the other BASELINE configurations
+python3 tools/winograd_probe.py 2>/dev/null | grep -v amdgpu > $O/winograd_probe.txt
+python3 tools/winograd_wgrad_probe.py 2>/dev/null | grep -v amdgpu > $O/winograd_wgrad_probe.txt
+if [ -f db_text_minimal_amd/libdbnet_hip_trace.so ]; then
+  DBN_LIB_PATH=$R/db_text_minimal_amd/libdbnet_hip_trace.so python3 tools/wino_trace_probe.py 2>/dev/null | grep -v amdgpu > $O/wino_trace.txt
+fi
+{ python3 tools/cfg_timing.py resnet50 8 800 f32 10; python3 tools/cfg_timing.py resnet50 8 800 bf16 10;
+  python3 tools/cfg_timing.py deformable_resnet50 8 800 f32 10; python3 tools/cfg_timing.py deformable_resnet50 8 800 bf16 10;
+  python3 tools/cfg_timing.py resnet18 32 1280 fp16 10 eval; DBN_FOLD_EVAL_BN=0 python3 tools/cfg_timing.py resnet18 32 1280 fp16 10 eval;
+  python3 tools/cfg_timing.py resnet18 16 640 f32 10 eval; DBN_FOLD_EVAL_BN=0 python3 tools/cfg_timing.py resnet18 16 640 f32 10 eval; } 2>/dev/null | grep -v amdgpu > $O/other_configs.txt
 rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3   # the DBs are large; the summaries above are what is kept
 ls -la $O
