@@ -669,14 +669,14 @@ static int pyramid_rows_one(int n, int H, int W) { return 64 * dbn_ceil_div((lon
 
 long dbn_pyramid_conv_ws_floats(int N, int H, int W, int Cd) { return (3L * Cd + 1) * N * pyramid_rows_one(1, H, W); }
 
-// first_level = 1 (exact fp32 only): dst already holds level 0's part of the sum (the plain 3x3 conv of s0, bias included — e.g. from
+// first_level = 1 (exact fp32, and — round 5 — 16-bit storage): dst already holds level 0's part of the sum (the plain 3x3 conv of s0, bias included — e.g. from
 // dbn_winograd_conv_bn_f32); the launch adds levels 1-3 to it (s0, w0, bias are not read).
 static int pyramid_run(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
                        const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,
                        int Cd, int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum,
                        float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws,
                        void* stream, int relu) {
-    DBN_REQUIRE(first_level == 0 || (first_level == 1 && at == 0 && ns == 0));
+    DBN_REQUIRE(first_level == 0 || (first_level == 1 && ((at == 0 && ns == 0) || ((at == 1 || at == 2) && ns == 1))));
     DBN_REQUIRE(!relu || !gamma);  // (the inference epilogue and the train-mode statistics exclude each other)
     if (first_level) { s0 = s1; w0 = w1; bias = nullptr; }
     DBN_REQUIRE(s0 && s1 && s2 && s3 && w0 && w1 && w2 && w3 && dst && (ns == 0 || ns == 1 || ns == 3));

@@ -902,7 +902,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         }
     }
     // wave-uniform walk over the units: tap (g_r, g_s) of channel block g_cb, k-tile g_kt of the weight panel
-    int g_left, g_kt, g_r, g_s, g_cb, g_level = 0;
+    int g_left, g_kt, g_r, g_s, g_cb, g_level = (MODE == 3 ? p.first_level : 0);  // (pyramid conv: levels [first_level, 4); round 5 also in the 16-bit loop)
     const unsigned bstep_bytes = (unsigned)(2 * NSX * p.Cd) * 16u;
     __amdgpu_buffer_rsrc_t rsrcB;
     auto level_dma = [&](int g) {  // MODE 3: source, tap geometry, weight panel of pyramid level g (see level_setup)
@@ -934,12 +934,12 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     int nstages;
     if (MODE == 3) {
         nstages = 0;
-        for (int g = 0; g < 4; ++g) {
+        for (int g = g_level; g < 4; ++g) {
             const int f = 1 << g, kk = f + 2;
             const int ph = ((q.oh0 & (f - 1)) + 1) & (f - 1), pw = ((q.ow0 & (f - 1)) + 1) & (f - 1);
             nstages += (taps_of_class(kk, ph, f) * taps_of_class(kk, pw, f) * (p.Cs >> 4) + DMA_SU - 1) / DMA_SU;
         }
-        level_dma(0);
+        level_dma(g_level);
     } else {
         const int rs = max(1, q.R * qS), cb = kt_begin / rs, tap = kt_begin - cb * rs;
         g_cb = 16 * cb;

@@ -1577,6 +1577,16 @@ class Engine:
             cur = self.conv_bn_act_eval(cname, cur, conv, name + ('/out' if last else '/z%d' % (i + 1)), bn, relu=True, res=res if last else None)
         return cur
 
+    # 16-bit storage: level 0 of the pyramid conv through the pixel-patch kernel.  1: in train mode only; 2: in inference too.  Measured
+    # (one box, interleaved): bf16 step 16 x 640^2 12.02 -> 11.5 ms; cfg5 fp16 inference 14.95 -> 15.7 ms — there the second pass over the
+    # 1.7 GB output (write, read, write) costs more than the faster level 0 saves — so inference keeps the one-launch form.
+    fpn_level0_patch = int(os.environ.get('DBN_FPN_LV0_PATCH', '1'))
+
+    def _fpn_level0_patch_ok(self, z0, Co, train=False):
+        N, H, W, Cg = z0.shape
+        return (self.fpn_level0_patch >= (1 if train else 2) and self.at != 0 and self.ns == 1 and Cg % 32 == 0 and H % 8 == 0 and W % 16 == 0
+                and Co % 128 == 0)
+
     def _fpn_conv_eval(self, name, conv, zs, out_name, bn):
         """Inference form of the FPN output conv + BatchNorm + ReLU (segmentation_body.py:55-61,75-76): the pyramid conv on the combined
         weights of the FOLDED filters, ReLU in its epilogue."""
@@ -1589,7 +1599,15 @@ class Engine:
         wpk = [self.pack('%s#f%d' % (fname, g), wds[g], 1, 1 << g, version=wver) for g in range(4)]
         lv0 = _VirtualConv(Cg, Co, 3, 1, 1, wds[0], vconv.bias)
         first = int(self.fpn_level0_winograd and wds[0].shape[0] == Cg and self._winograd_ok(zs[0], lv0))
-        if first:
+        if self._fpn_level0_patch_ok(zs[0], Co):  # 16-bit storage: level 0 through the pixel-patch kernel (see _fpn_conv_forward)
+            if self.prof:
+                self._prof_igemm(N * H * W, Co, 2.0 * N * H * W * Co * Cg * 9, 'fwd %s level 0' % name, 1, (N, H, W, Cg, H, W, 3, 1, 1))
+            check(self.L.dbn_igemm_act_t(self.at, self.ns, zs[0].data_ptr(), wpk[0].data_ptr(), vconv.bias.data_ptr(), None, 0, z.data_ptr(), N, H, W,
+                                         Cg, H, W, Co, 3, 3, 1, 1, 1, 0, self.stream), 'igemm fpn level 0')
+            if self.prof:
+                self.prof.end()
+            first = 1
+        elif first:
             up = self._winograd_panel(fname + '#lv0', wds[0], Cg, dgrad=1, version=wver)
             if self.prof:
                 self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * Co * Cg * 4, 0.0, 'fwd %s level 0' % name)
@@ -1801,7 +1819,18 @@ class Engine:
             # through the Winograd kernel (2.25x fewer matrix FLOPs) and the pyramid launch adds levels 1-3 onto it
             lv0 = _VirtualConv(Cg, Co, 3, 1, 1, wds[0], conv.bias)
             first = int(self.fpn_level0_winograd and not self._use_planes and wds[0].shape[0] == Cg and self._winograd_ok(zs[0], lv0))
-            if first:
+            # 16-bit storage (round 5): level 0 — 53 % of the pyramid's FLOPs — as a mode-1 3x3 / stride-1 launch on the level-0 panel, which
+            # takes the pixel-patch kernel (0.3-0.36 of the 16-bit matrix peak; the pyramid's generic loop: 0.2), levels 1-3 added onto it
+            first16 = self._fpn_level0_patch_ok(zs[0], Co, train)
+            if first16:
+                if self.prof:
+                    self._prof_igemm(N * H * W, Co, 2.0 * N * H * W * Co * Cg * 9, 'fwd %s level 0' % name, 1, (N, H, W, Cg, H, W, 3, 1, 1))
+                self._igemm('igemm fpn level 0', zs[0].data_ptr(), wpk[0].data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, Cg, H, W, Co, 3, 3, 1, 1, 1,
+                            0, 0)
+                if self.prof:
+                    self.prof.end()
+                first = 1
+            elif first:
                 # (wds[0][ci][co][u][v] = W[co][ci][2-u][2-v]: its data-gradient panel is the forward conv of W's first Cg input channels)
                 up = self._winograd_panel(name + '#lv0', wds[0], Cg, dgrad=1, version=wver)
                 if self.prof:

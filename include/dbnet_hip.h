@@ -414,7 +414,8 @@ int dbn_pyramid_conv_t(int at, const void* s0, const void* s1, const void* s2, c
                        const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs, int Cd,
                        int tile_hint, int ns, const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
                        float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd, float* ws, void* stream);
-/* first_level = 1 (at = 0, ns = 0 only): dst already holds level 0's part (the 3x3 conv of s0 with the bias — dbn_winograd_conv_bn_f32);
+/* first_level = 1 (at = 0 with ns = 0, or 16-bit storage with ns = 1): dst already holds level 0's part (the 3x3 conv of s0 with the bias —
+ * dbn_winograd_conv_bn_f32, or dbn_igemm_t in mode 1 with the level-0 panel, which takes the 16-bit pixel-patch kernel);
  * the launch adds levels 1-3 (s0, w0, bias unused).  first_level = 0: dbn_pyramid_conv_t. */
 int dbn_pyramid_conv_from_t(int first_level, int at, const void* s0, const void* s1, const void* s2, const void* s3, const float* w0,
                             const float* w1, const float* w2, const float* w3, const float* bias, void* dst, int N, int H, int W, int Cs,

@@ -1017,6 +1017,61 @@ def test_convolutions_on_16bit_storage(dtype, tile):
     report('split-K conv %s' % dtype, nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 256), (3, 40, 16, 32, 128)])
+@pytest.mark.parametrize('first', [0, 1])
+def test_pyramid_conv_on_16bit_storage_from_level_one(shape, dtype, first):
+    """The pyramid conv on bf16 / fp16 storage, whole (first_level = 0) and as levels 1-3 accumulated onto level 0's part, which a mode-1
+    3x3 launch on the level-0 panel wrote first (round 5: that launch takes the pixel-patch kernel).  Reference: the concat conv in fp64 on
+    the rounded operands (segmentation_body.py:75-76,82-87); first_level = 1 pays one more rounding of the level-0 part to the storage type.
+    Also the inference epilogue (ReLU) and the train-mode statistics of the accumulated form."""
+    N, H, W, Cg, Co = shape
+    kind = AT_OF[dtype]
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    rq = lambda t: t.to(dtype).double()
+    ps = [rnd(N, Cg, H >> g, W >> g, seed=20 + g) for g in range(4)]
+    w = rnd(Co, 4 * Cg, 3, 3, seed=3, scale=0.03)
+    bias = rnd(Co, seed=5)
+    wd_ = w.to(DEV)
+    wpk = []
+    for g in range(4):
+        k = (1 << g) + 2
+        wdg = torch.empty(Cg, Co, k, k, device=DEV)
+        _lib.check(L().dbn_fpn_combine_weights(wd_.data_ptr(), Co, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+        wpk.append(pack_t(wdg.cpu(), 1, 1 << g, kind))
+    cat = torch.cat([rq(ps[0])] + [F.interpolate(rq(ps[g]), size=(H, W)) for g in range(1, 4)], 1)
+    y_ref = F.conv2d(cat, w.double(), bias.double(), 1, 1)
+    xs = [nhwc(t).to(dtype) for t in ps]
+    bias_ = bias.to(DEV)
+    scale = float(y_ref.abs().max())
+    # (the combined filters are sums of up to 9 taps rounded ONCE to the storage type: allow that on top of the output rounding)
+    tol_a, tol_r = eps * scale * (1.5 if first == 0 else 2.5), 2 * eps
+    for relu in (0, 1):
+        y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+        if first:
+            igemm_t(xs[0], wpk[0], bias_, y, 3, 1, 1, 1)
+        _lib.check(L().dbn_pyramid_conv_act_t(first, kind, *[t.data_ptr() for t in xs], *[t.data_ptr() for t in wpk], bias_.data_ptr(), relu,
+                                              y.data_ptr(), N, H, W, Cg, Co, 1, stream()), 'pyramid_act')
+        report('pyramid16 first=%d relu=%d %s' % (first, relu, dtype), nchw(y.float()), y_ref.clamp_min(0) if relu else y_ref, tol_a, tol_r)
+    # train-mode statistics of the same sum
+    gamma, beta = rnd(Co, seed=6) * 0.3 + 1, rnd(Co, seed=7)
+    g_, b_ = gamma.to(DEV), beta.to(DEV)
+    rm_, rv_ = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+    ws = torch.empty(L().dbn_pyramid_conv_ws_floats(N, H, W, Co), device=DEV)
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+    if first:
+        igemm_t(xs[0], wpk[0], bias_, y, 3, 1, 1, 1)
+    _lib.check(L().dbn_pyramid_conv_from_t(first, kind, *[t.data_ptr() for t in xs], *[t.data_ptr() for t in wpk], bias_.data_ptr(), y.data_ptr(),
+                                           N, H, W, Cg, Co, 0, 1, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                           sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'pyramid_from')
+    report('pyramid16 train y first=%d' % first, nchw(y.float()), y_ref, tol_a, tol_r)
+    mean_ref = y_ref.mean((0, 2, 3))
+    var_ref = y_ref.var((0, 2, 3), unbiased=False)
+    report('pyramid16 batch mean', mu.cpu(), mean_ref, tol_a, tol_r)
+    report('pyramid16 batch rstd', rs.cpu(), (var_ref + 1e-5).rsqrt(), 0.0, 4 * eps)
+
+
 def test_stem_conv_on_16_channel_bf16_input():
     """The 16-bit path stores the model input with 16 channels (3 real): nchw3_to_nhwc4_t + the 7x7 stride-2 stem conv."""
     N, H, W = 2, 40, 48
