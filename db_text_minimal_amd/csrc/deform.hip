@@ -222,6 +222,208 @@ __global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict
     }
 }
 
+// ---- adjoint of the sampling as a GATHER (round 5): deterministic in plain fp32, no atomics, no fixed point ----------------------------
+// Round 3's tiled scatter above is exact but slow (configs[3] trace, round 5: 13.7 ms of the 72 ms fp32 step in deform_col2im_tiled_kernel
+// + 3.0 ms in its two absmax passes: 64-bit LDS atomics, one 4-byte load per lane).  The adjoint does not need a scatter:
+//   doffset[m][k]  = sum_c dcols[m][k][c] * d(bilinear)/d(y, x)      — a reduction over the channels of ONE sample: a team per (m, k)
+//   dx[n][y][x][c] = sum over the samples (m, k) one of whose four corners is (y, x) of  w_corner * dcols[m][k][c]
+// and WHICH samples can touch input pixel (y, x) is bounded by the largest learned offset: with E = ceil(max |offset|) (a device-side
+// maximum, one small pass over the offset map) only taps whose undeformed position (ho*stride - pad + r, wo*stride - pad + s) lies within
+// E of (y, x) can — (R + 2E)^2 output pixels at stride 1.  A 32-lane team owns an input pixel, in three nested stages: its lanes test 32
+// output pixels of that window at a time against the pixel's BOX (deform_bbox_kernel: the input rows / columns its nine samples touch —
+// one 16-byte load and four comparisons, so a large window, i.e. ONE large offset somewhere in the map, costs (R + 2E)^2 / 32 cheap rounds,
+// not 9x that many position tests); the taps of the pixels that pass are tested three pixels at a time, one lane per (pixel, tap) (offset
+// pair -> position -> is (y, x) one of the corners, with which weight — the same float expressions as sample_of / deform_im2col_kernel);
+// the hits are walked in (pixel, tap) order (ballot + shuffles: no memory), every lane adding w * dcols[m][k][its channel quads].  One fixed summation order per output element: bit-reproducible, and independent of the
+// grid.  Larger offsets only widen the window (E is read on the device: no host synchronisation, no fallback path).  A workgroup owns an
+// 8 x 8 tile of input pixels (team = one row, walking its 8 pixels), so the four corners' re-reads of a dcols row meet in L1 / L2.
+// Non-finite values: a NaN / Inf in dcols reaches exactly the dx / doffset elements its sample touches (as float atomics would);
+// a NaN offset makes its sample "outside" (contributes nothing) and does not widen the window.
+constexpr int GATHER_TILE = 8;
+
+template <int AT>
+__global__ __launch_bounds__(256) void deform_doffset_kernel(const void* __restrict__ dcols, const void* __restrict__ x,
+                                                             const void* __restrict__ offset, void* __restrict__ doffset, DeformDims d,
+                                                             long teams) {
+    const int lane = threadIdx.x & 31;
+    const int RS = d.R * d.S, c4n = d.C >> 2;
+    for (long t = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 5; t < teams; t += ((long)gridDim.x * blockDim.x) >> 5) {
+        const int m = (int)(t / RS), k = (int)(t - (long)m * RS);
+        int n, ho, wo;
+        const Sample sp = sample_of<AT>(d, offset, m, k, n, ho, wo);
+        float gy = 0.f, gx = 0.f;
+        if (sp.inside) {  // (team-uniform) an outside sample is the constant zero: zero gradients
+            const float hy = 1.f - sp.ly, hx = 1.f - sp.lx;
+            const long base = ((long)n * d.H + sp.y0) * d.W + sp.x0;
+            const long g4 = ((long)m * RS + k) * c4n;
+            for (int c4 = lane; c4 < c4n; c4 += 32) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 g = dbn_ld4<AT>(dcols, g4 + c4);
+                const f32x4 v0 = sp.ok[0] ? dbn_ld4<AT>(x, base * c4n + c4) : z;
+                const f32x4 v1 = sp.ok[1] ? dbn_ld4<AT>(x, (base + 1) * c4n + c4) : z;
+                const f32x4 v2 = sp.ok[2] ? dbn_ld4<AT>(x, (base + d.W) * c4n + c4) : z;
+                const f32x4 v3 = sp.ok[3] ? dbn_ld4<AT>(x, (base + d.W + 1) * c4n + c4) : z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gy += g[e] * (hx * (v2[e] - v0[e]) + sp.lx * (v3[e] - v1[e]));
+                    gx += g[e] * (hy * (v1[e] - v0[e]) + sp.ly * (v3[e] - v2[e]));
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {  // fixed shuffle tree inside the team
+                gy += __shfl_xor(gy, o, 64);
+                gx += __shfl_xor(gx, o, 64);
+            }
+        }
+        if (lane == 0) {
+            dbn_st1<AT>(doffset, (long)m * d.off_stride + 2 * k, gy);
+            dbn_st1<AT>(doffset, (long)m * d.off_stride + 2 * k + 1, gx);
+        }
+        if (k == 0)  // the padding channels of the offset map (its conv runs on 64): zero gradient
+            for (int ch = 2 * RS + lane; ch < d.off_stride; ch += 32) dbn_st1<AT>(doffset, (long)m * d.off_stride + ch, 0.f);
+    }
+}
+
+// Per output pixel m: the box of input pixels its R*S samples touch (rows ymin..ymax, columns xmin..xmax; empty: ymin > ymax), from the
+// same float expressions as sample_of — the gather below tests ONE box per output pixel before it looks at that pixel's taps.
+template <int AT>
+__global__ __launch_bounds__(256) void deform_bbox_kernel(const void* __restrict__ offset, int4* __restrict__ bbox, DeformDims d, int M) {
+    const int RS = d.R * d.S;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        int ymin = 1 << 30, ymax = -(1 << 30), xmin = 1 << 30, xmax = -(1 << 30);
+        for (int k = 0; k < RS; ++k) {
+            int n, ho, wo;
+            const Sample sp = sample_of<AT>(d, offset, m, k, n, ho, wo);
+            if (sp.inside) {
+                ymin = min(ymin, sp.y0);
+                ymax = max(ymax, sp.y0 + 1);
+                xmin = min(xmin, sp.x0);
+                xmax = max(xmax, sp.x0 + 1);
+            }
+        }
+        bbox[m] = int4{ymin, ymax, xmin, xmax};
+    }
+}
+
+// NQ: channel quads per lane (C <= 128 * NQ)
+template <int AT, int NQ>
+__global__ __launch_bounds__(256) void deform_dx_gather_kernel(const void* __restrict__ dcols, const void* __restrict__ offset,
+                                                               const int4* __restrict__ bbox, void* __restrict__ dx,
+                                                               const unsigned* __restrict__ maxbits, DeformDims d, int tiles_x, int tiles_y,
+                                                               int accumulate) {
+    const int lane = threadIdx.x & 31, team = threadIdx.x >> 5, half = (threadIdx.x >> 5) & 1, lbase = 32 * half;
+    const int RS = d.R * d.S, c4n = d.C >> 2;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int y = ty * GATHER_TILE + team;
+    // E = ceil(max |offset|): |base - pixel| <= E for every sample that can touch the pixel.  A non-finite maximum (a NaN / Inf offset: its
+    // sample is outside by the comparison rules, or infinitely far) must not widen the window: the finite offsets' bound is not known then, so
+    // the whole map is searched — correct, slow, and only in a step that has diverged anyway.
+    const unsigned mb = maxbits[0];
+    const float omax = __builtin_bit_cast(float, mb);
+    const int emax = max(d.H, d.W) + d.R;
+    const int E = (mb == DEFORM_NONFINITE || !(omax < (float)emax)) ? emax : (int)ceilf(omax);
+    if (y >= d.H) return;  // (team-uniform; no barrier below)
+    const int ay = y - E + d.pad - (d.R - 1), by = y + E + d.pad;
+    const int ho_lo = ay <= 0 ? 0 : (ay + d.stride - 1) / d.stride, ho_hi = min(d.Ho - 1, by / d.stride);
+    const int nho = ho_hi - ho_lo + 1;
+    const int PPR = 32 / RS;  // output pixels whose taps are tested side by side (three for 3 x 3)
+    for (int ix = 0; ix < GATHER_TILE; ++ix) {
+        const int x = tx * GATHER_TILE + ix;
+        if (x >= d.W) break;
+        const int ax = x - E + d.pad - (d.S - 1), bx = x + E + d.pad;
+        const int wo_lo = ax <= 0 ? 0 : (ax + d.stride - 1) / d.stride, wo_hi = min(d.Wo - 1, bx / d.stride);
+        const int nwo = wo_hi - wo_lo + 1;
+        const int npix = (nho > 0 && nwo > 0) ? nho * nwo : 0;
+        f32x4 acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < npix; i0 += 32) {
+            // stage 1: 32 output pixels of the window against their boxes
+            const int i = i0 + lane;
+            int m_l = 0;
+            bool pass = false;
+            if (i < npix) {
+                const int iho = i / nwo, iwo = i - iho * nwo;
+                m_l = (n * d.Ho + ho_lo + iho) * d.Wo + wo_lo + iwo;
+                const int4 bb = bbox[m_l];
+                pass = y >= bb.x && y <= bb.y && x >= bb.z && x <= bb.w;
+            }
+            unsigned pm = (unsigned)(__ballot(pass) >> lbase);
+            while (pm) {  // (team-uniform)
+                // stage 2: the taps of up to PPR passing pixels, one lane per (pixel, tap), in (pixel, tap) order
+                const int slot = lane / RS, k = lane - slot * RS;
+                int m_s = -1;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    if (u < PPR) {
+                        const bool have = pm != 0u;
+                        const int src = have ? __builtin_ctz(pm) : 0;
+                        pm &= pm - 1u;
+                        const int mm = __shfl(m_l, lbase + src, 64);
+                        if (have && slot == u) m_s = mm;
+                    }
+                }
+                float w = 0.f;
+                int mk = 0;
+                if (m_s >= 0 && slot < PPR) {
+                    const int rem = m_s - n * d.Ho * d.Wo;
+                    const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+                    const int r = k / d.S, s_ = k - r * d.S;
+                    const float py = (float)(ho * d.stride - d.pad + r) + dbn_ld1<AT>(offset, (long)m_s * d.off_stride + 2 * k);
+                    const float px = (float)(wo * d.stride - d.pad + s_) + dbn_ld1<AT>(offset, (long)m_s * d.off_stride + 2 * k + 1);
+                    if (py > -1.f && py < (float)d.H && px > -1.f && px < (float)d.W) {  // (sample_of's `inside`)
+                        const float fy = floorf(py), fx = floorf(px);
+                        const int y0 = (int)fy, x0 = (int)fx;
+                        const float ly = py - fy, lx = px - fx;
+                        const float wy = y == y0 ? 1.f - ly : (y == y0 + 1 ? ly : 0.f);
+                        const float wx = x == x0 ? 1.f - lx : (x == x0 + 1 ? lx : 0.f);
+                        w = wy * wx;  // (the corner weights of deform_im2col_kernel: (1 - ly | ly) * (1 - lx | lx))
+                        mk = m_s * RS + k;
+                    }
+                }
+                unsigned hits = (unsigned)(__ballot(w != 0.f) >> lbase);
+                while (hits) {  // stage 3 (team-uniform): the hits in lane order, four loads in flight
+                    int hm[4];
+                    float hw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool have = hits != 0u;
+                        const int src = have ? __builtin_ctz(hits) : 0;
+                        hits &= hits - 1u;
+                        const int mm = __shfl(mk, lbase + src, 64);
+                        const float ww = __shfl(w, lbase + src, 64);
+                        hm[u] = have ? mm : -1;
+                        hw[u] = have ? ww : 0.f;
+                    }
+                    f32x4 g[4][NQ];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const int c4 = lane + 32 * q;
+                            g[u][q] = (hm[u] >= 0 && c4 < c4n) ? dbn_ld4<AT>(dcols, (long)hm[u] * c4n + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (hm[u] >= 0) {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) acc[q] += hw[u] * g[u][q];
+                        }
+                }
+            }
+        }
+        const long o4 = (((long)n * d.H + y) * d.W + x) * c4n;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c4 = lane + 32 * q;
+            if (c4 < c4n) dbn_st4<AT>(dx, o4 + c4, accumulate ? acc[q] + dbn_ld4<AT>(dx, o4 + c4) : acc[q]);
+        }
+    }
+}
+
 // fp32 -> activation storage type (one rounding)
 template <int AT>
 __global__ void cast_f32_kernel(const float* __restrict__ src, void* __restrict__ dst, long n4) {
@@ -319,6 +521,51 @@ int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* of
 int dbn_deform_col2im(const float* dcols, const float* x, const float* offset, float* dx, float* doffset, int accumulate, void* ws, int N,
                       int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream) {
     return dbn_deform_col2im_t(0, dcols, x, offset, dx, doffset, accumulate, ws, N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride, stream);
+}
+
+// The same adjoint as a gather in plain fp32 (round 5; see deform_dx_gather_kernel): dx[N,H,W,C] = [dx +] sum over the samples that touch
+// each pixel, doffset[N*Ho*Wo][off_stride] (channels >= 2RS zero).  Deterministic (one fixed summation order, independent of the grid), no
+// atomics, equal to dbn_deform_col2im_t up to fp32 rounding of the sums.  ws: dbn_deform_col2im_gather_ws_bytes(N, Ho, Wo) bytes (the device-side
+// maximum of |offset| that bounds the search window + one box per output pixel).  C <= 512.
+long dbn_deform_col2im_gather_ws_bytes(int N, int Ho, int Wo) { return 16 + 16L * N * Ho * Wo; }
+int dbn_deform_col2im_gather_t(int at, const void* dcols, const void* x, const void* offset, void* dx, void* doffset, int accumulate,
+                               void* ws, int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride,
+                               void* stream) {
+    const DeformDims d{N, H, W, C, Ho, Wo, R, S, stride, pad, off_stride};
+    DBN_REQUIRE(dcols && x && offset && dx && doffset && ws && dims_ok(d) && off_stride % 4 == 0 && C <= 512 && R * S <= 32 && R * S >= 9);
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)N * Ho * Wo;
+    if (hipMemsetAsync(ws, 0, 16, st) != hipSuccess) return dbn_status();
+    unsigned* maxbits = reinterpret_cast<unsigned*>(ws);
+    int4* bbox = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + 16);
+    const int tiles_x = dbn_ceil_div(W, GATHER_TILE), tiles_y = dbn_ceil_div(H, GATHER_TILE);
+    DBN_DISPATCH_AT(at, {
+        hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(M * off_stride / 4, 256, 2048)), dim3(256), 0, st, offset, M * off_stride / 4, maxbits);
+        hipLaunchKernelGGL(deform_bbox_kernel<AT>, dim3(dbn_grid(M, 256, 4096)), dim3(256), 0, st, offset, bbox, d, (int)M);
+        hipLaunchKernelGGL(deform_doffset_kernel<AT>, dim3(dbn_grid(M * R * S * 32, 256, 1 << 16)), dim3(256), 0, st, dcols, x, offset, doffset,
+                           d, M * R * S);
+        if (C <= 128)
+            hipLaunchKernelGGL((deform_dx_gather_kernel<AT, 1>), dim3(N * tiles_y * tiles_x), dim3(256), 0, st, dcols, offset, bbox, dx, maxbits, d,
+                               tiles_x, tiles_y, accumulate);
+        else if (C <= 256)
+            hipLaunchKernelGGL((deform_dx_gather_kernel<AT, 2>), dim3(N * tiles_y * tiles_x), dim3(256), 0, st, dcols, offset, bbox, dx, maxbits, d,
+                               tiles_x, tiles_y, accumulate);
+        else
+            hipLaunchKernelGGL((deform_dx_gather_kernel<AT, 4>), dim3(N * tiles_y * tiles_x), dim3(256), 0, st, dcols, offset, bbox, dx, maxbits, d,
+                               tiles_x, tiles_y, accumulate);
+    });
+    return dbn_status();
+}
+
+// out_bits[0] = bit pattern of max |offset[i]| over n elements (n % 4 == 0) of the activation type `at`, 0x7FC00000 as soon as one element is
+// not finite: the number the caller reads back (one step late, no synchronisation in the step) to choose between the two adjoints — the
+// gather's search window grows with it.
+int dbn_deform_offset_absmax_t(int at, const void* offset, long n, unsigned* out_bits, void* stream) {
+    DBN_REQUIRE(offset && out_bits && n > 0 && n % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out_bits, 0, 4, st) != hipSuccess) return dbn_status();
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(n / 4, 256, 2048)), dim3(256), 0, st, offset, n / 4, out_bits));
+    return dbn_status();
 }
 
 // to_ohwi = 1: dst[O][T][C] = scale * src[O][C][T] (OIHW -> GEMM column order); 0: the inverse

@@ -485,6 +485,18 @@ int dbn_deform_im2col_t(int at, const void* x, const void* offset, void* cols, i
                         int stride, int pad, int off_stride, void* stream);
 int dbn_deform_col2im_t(int at, const void* dcols, const void* x, const void* offset, void* dx, void* doffset, int accumulate, void* ws,
                         int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride, void* stream);
+/* The same adjoint (the backward of torchvision.ops.DeformConv2d's sampling, resnet.py:61-65,119-124) as a GATHER in plain fp32 (round 5):
+ * a team per input pixel searches the taps whose undeformed position lies within ceil(max |offset|) of it (the maximum is taken on the
+ * device: no host synchronisation, larger offsets only widen the window) and adds their corner contributions in candidate order;
+ * doffset is a per-sample reduction over the channels.  One fixed summation order: bit-reproducible; equal to dbn_deform_col2im_t up to
+ * the fp32 rounding of the sums; non-finite dcols values reach exactly the elements their samples touch.  ws:
+ * dbn_deform_col2im_gather_ws_bytes(N, Ho, Wo) bytes, no initialisation needed.  C <= 512, off_stride % 4 == 0, 9 <= R * S <= 32. */
+long dbn_deform_col2im_gather_ws_bytes(int N, int Ho, int Wo);
+int dbn_deform_col2im_gather_t(int at, const void* dcols, const void* x, const void* offset, void* dx, void* doffset, int accumulate,
+                               void* ws, int N, int H, int W, int C, int Ho, int Wo, int R, int S, int stride, int pad, int off_stride,
+                               void* stream);
+/* out_bits[0] = bit pattern of max |offset| (0x7FC00000 if an element is not finite): what bounds the gather's window (n % 4 == 0) */
+int dbn_deform_offset_absmax_t(int at, const void* offset, long n, unsigned* out_bits, void* stream);
 int dbn_cast_f32(int at, const float* src, void* dst, long n, void* stream);
 
 int dbn_bn_train_stats_t(int at, const void* y, int M, int C, const float* gamma, const float* beta, float eps, float momentum,

@@ -769,6 +769,50 @@ def test_deformable_backbone_step_is_bit_reproducible(math):
 
 
 @pytest.mark.parametrize('math', ['f32', 'bf16'])
+def test_deformable_backbone_gather_adjoint_equals_the_fixed_point_scatter(math):
+    """Round 5's sampling adjoint (a per-pixel gather in plain fp32, engine.dcn_gather) against round 3's fixed-point scatter on the whole
+    DCN backbone (resnet.py:54-65,111-124) with non-zero learned offsets: the first step's gradients agree to the fp32 rounding of the sums
+    (bf16: to the one extra rounding of dx / doffset to storage), maps and losses likewise."""
+    seed = 13
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    sd = O.new_state(seed, 'deformable_resnet18')
+    g = torch.Generator().manual_seed(1)
+    for k in sd:
+        if 'conv2_offset' in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (0.05 if k.endswith('weight') else 0.7)
+    outs = []
+    for gather in (False, True):
+        model = make_model(seed, 'deformable_resnet18')
+        model.load_state_dict(sd)
+        model = model.train()
+        model.engine.set_conv_math(math)
+        model.engine.dcn_gather = gather
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+        preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+        torch.cuda.synchronize()
+        outs.append((model.engine.flat_grad.clone().double(), preds.clone().double(), losses.clone().double()))
+    (g0, p0, l0), (g1, p1, l1) = outs
+    assert torch.equal(p0, p1) and torch.equal(l0, l1)  # (the forward pass is the same code)
+    tol = 2e-2 if math == 'bf16' else 1e-4
+    rel = float((g0 - g1).norm() / g0.norm())
+    print('gather vs scatter, %s: relative gradient distance %.3e' % (math, rel))
+    assert rel <= tol, rel
+    # per parameter tensor (a small tensor must not hide behind the large ones)
+    views0 = model.engine.grad_views
+    worst = 0.0
+    for k, v in views0.items():
+        n = v.numel()
+        a = g0[v.storage_offset():v.storage_offset() + n] if v.storage_offset() + n <= g0.numel() else None
+        if a is None:
+            continue
+        b = g1[v.storage_offset():v.storage_offset() + n]
+        if float(a.norm()) > 0:
+            worst = max(worst, float((a - b).norm() / a.norm()))
+    print('worst per-tensor relative distance %.3e' % worst)
+    assert worst <= (10 * tol if math == 'bf16' else 20 * tol), worst
+
+
+@pytest.mark.parametrize('math', ['f32', 'bf16'])
 def test_graph_captured_step_is_bit_identical_to_the_eager_step(math):
     """DBTrainer.use_graph: forward + DBLoss + backward replayed as ONE hipGraph launch (two-stream fork / join captured with it),
     gradient exchange and Adam outside.  Five steps over changing batches — two eager warm-up steps, the capturing step, two

@@ -721,6 +721,98 @@ def test_deformable_conv(case, zero_offsets):
     report('deform conv dweight', g.cpu(), dw_ref, 2e-5 * float(dw_ref.abs().max()) + 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 9, 11, 1, 1.5), (1, 128, 12, 10, 2, 1.5), (2, 128, 17, 19, 1, 0.0), (1, 256, 13, 9, 1, 0.4), (1, 512, 8, 8, 2, 3.7),
+                                  (2, 64, 21, 6, 1, 6.0), (1, 192, 10, 10, 1, 0.9)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_deformable_col2im_as_a_gather(case, dtype):
+    """dbn_deform_col2im_gather_t (round 5): the adjoint of DeformConv2d's sampling (resnet.py:61-65,119-124) as a per-pixel gather in plain
+    fp32 — vs autograd of the restated op (oracle.deform_conv2d) on the operands as stored, vs round 3's fixed-point scatter
+    (dbn_deform_col2im_t: exact sums) at fp32 rounding of the sums, bit-identical from run to run, accumulate form, zero padding channels.
+    Offsets up to 6 pixels (window search bound taken on the device), stride 1 / 2, odd maps, C = 64 ... 512."""
+    from oracle import dbnet_oracle as O
+    N, C, H, W, stride, oscale = case
+    at = AT_OF[dtype]
+    rq = lambda t: t.to(dtype).float()
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = rq(rnd(N, C, H, W, seed=1)).requires_grad_(True)
+    off = rq(rnd(N, 18, Ho, Wo, seed=3) * oscale).requires_grad_(True)
+    dcols_ = rq(rnd(N, Ho, Wo, 9 * C, seed=4))
+    # cols = sampled columns [N, Ho, Wo, 9, C]: the 1x1 GEMM's input — the adjoint of the sampling is autograd of <cols, dcols>
+    eye = torch.zeros(9 * C, C, 3, 3)
+    for k in range(9):
+        eye[k * C + torch.arange(C), torch.arange(C), k // 3, k % 3] = 1.0
+    cols_ref = O.deform_conv2d(x.double(), off.double(), eye.double(), stride, 1)  # [N, 9C, Ho, Wo]
+    dx_ref, doff_ref = torch.autograd.grad(cols_ref, (x, off), dcols_.permute(0, 3, 1, 2).double())
+    OS = 64
+    xs = nhwc(x.detach()).to(dtype)
+    offs = torch.zeros(N, Ho, Wo, OS, device=DEV, dtype=dtype)
+    offs[..., :18] = nhwc(off.detach()).to(dtype)
+    dcols = dcols_.to(DEV).to(dtype)
+    dims = (N, H, W, C, Ho, Wo, 3, 3, stride, 1, OS)
+    ws = torch.empty(L().dbn_deform_col2im_gather_ws_bytes(N, Ho, Wo), device=DEV, dtype=torch.uint8).fill_(0xff)  # (needs no initialisation)
+    runs = []
+    for rep in range(3):
+        dx = torch.full((N, H, W, C), float('nan'), device=DEV, dtype=dtype)
+        doffs = torch.full((N, Ho, Wo, OS), float('nan'), device=DEV, dtype=dtype)
+        _lib.check(L().dbn_deform_col2im_gather_t(at, dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx.data_ptr(), doffs.data_ptr(), 0,
+                                                  ws.data_ptr(), *dims, stream()), 'deform_col2im_gather')
+        runs.append((dx.clone(), doffs.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:]), 'the gather is not bit-reproducible'
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-20  # (one rounding to the storage type | fp32 positions, weights and sums against fp64)
+    sdx, sdo = float(dx_ref.abs().max()), float(doff_ref.abs().max())
+    report('gather dx %s' % (case, ), nchw(dx.float()), dx_ref, eps * sdx, eps)
+    report('gather doffset %s' % (case, ), nchw(doffs[..., :18].float().contiguous()), doff_ref, eps * sdo * 4 + 1e-6, eps)
+    assert float(doffs[..., 18:].float().abs().max()) == 0.0
+    # round 3's scatter (exact fixed-point sums, one rounding): the same numbers up to the fp32 rounding of the gather's sums
+    ws3 = torch.empty(L().dbn_deform_col2im_ws_bytes(N, H, W, C, Ho, Wo, 3, 3), device=DEV, dtype=torch.uint8)
+    dx3 = torch.full((N, H, W, C), float('nan'), device=DEV, dtype=dtype)
+    do3 = torch.full((N, Ho, Wo, OS), float('nan'), device=DEV, dtype=dtype)
+    _lib.check(L().dbn_deform_col2im_t(at, dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx3.data_ptr(), do3.data_ptr(), 0, ws3.data_ptr(),
+                                       *dims, stream()), 'deform_col2im')
+    report('gather vs scatter dx', dx.float().cpu(), dx3.float().cpu(), 2 * eps * sdx, 2 * eps)
+    report('gather vs scatter doffset', doffs.float().cpu(), do3.float().cpu(), 8 * eps * sdo + 1e-6, 2 * eps)
+    base = rq(rnd(N, H, W, C, seed=9)).to(DEV).to(dtype)  # accumulate form: dx += ...
+    dx1 = base.clone()
+    _lib.check(L().dbn_deform_col2im_gather_t(at, dcols.data_ptr(), xs.data_ptr(), offs.data_ptr(), dx1.data_ptr(), doffs.data_ptr(), 1,
+                                              ws.data_ptr(), *dims, stream()), 'deform_col2im_gather acc')
+    report('gather dx (accumulate)', nchw(dx1.float()), dx_ref + nchw(base.float()).double(), eps * (sdx + 3), eps)
+
+
+def test_deformable_col2im_gather_non_finite_values_stay_local():
+    """A NaN in dcols reaches the dx / doffset elements its sample touches and nothing else; a NaN offset drops its sample (outside by the
+    comparison rules, as in the forward) and leaves every other element as it was."""
+    N, C, H, W = 1, 64, 12, 12
+    xs = nhwc(rnd(N, C, H, W, seed=1))
+    offs = torch.zeros(N, H, W, 64, device=DEV)
+    offs[..., :18] = (rnd(N, H, W, 18, seed=2) * 0.8).to(DEV)
+    dcols = rnd(N, H, W, 9 * C, seed=3).to(DEV)
+    dims = (N, H, W, C, H, W, 3, 3, 1, 1, 64)
+    ws = torch.zeros(L().dbn_deform_col2im_gather_ws_bytes(N, H, W), device=DEV, dtype=torch.uint8)
+
+    def run(dc, of):
+        dx = torch.full((N, H, W, C), float('nan'), device=DEV)
+        do = torch.full((N, H, W, 64), float('nan'), device=DEV)
+        _lib.check(L().dbn_deform_col2im_gather_t(0, dc.data_ptr(), xs.data_ptr(), of.data_ptr(), dx.data_ptr(), do.data_ptr(), 0, ws.data_ptr(),
+                                                  *dims, stream()), 'gather')
+        return dx.cpu(), do.cpu()
+
+    dx0, do0 = run(dcols, offs)
+    assert torch.isfinite(dx0).all() and torch.isfinite(do0).all()
+    d2 = dcols.clone()
+    d2[0, 5, 6, 4 * C + 7] = float('nan')  # sample (pixel (5, 6), tap 4), channel 7
+    dx, do = run(d2, offs)
+    bad = torch.isnan(dx)
+    assert 1 <= int(bad.sum()) <= 4 and bool(bad[0, 4:8, 5:9, 7].any()) and int(bad[..., 7].sum()) == int(bad.sum())
+    assert torch.equal(dx[~bad], dx0[~bad])
+    assert torch.isnan(do[0, 5, 6, 8:10]).all() and int(torch.isnan(do).sum()) == 2
+    o2 = offs.clone()
+    o2[0, 3, 3, 2] = float('nan')  # dy of tap 1 at pixel (3, 3)
+    dx, do = run(dcols, o2)
+    assert torch.isfinite(dx).all()
+    assert float((dx - dx0).abs().max()) > 0 and int(((dx - dx0).abs() > 0).sum()) <= 4 * C  # that sample's contributions are gone, nothing else moved
+    assert float(do[0, 3, 3, 2:4].abs().max()) == 0.0
+
+
 def test_deformable_col2im_non_finite_and_outliers():
     """The sampling adjoint accumulates in 64-bit fixed point (deterministic), which by itself would turn a NaN / Inf column gradient
     into finite garbage (to_fixed(NaN) = 0): a non-finite element of dcols must come out as NaN in ALL of dx and doffset, a

@@ -1,6 +1,6 @@
 """GPU: wall time per train step — or, with `eval` as the sixth argument, per inference forward (BASELINE configs[4]: fp16, 32 x 1280^2) —
 of a BASELINE config shape that is not the bench headline (parity cases).
-usage: python tools/cfg_timing.py <backbone> <batch> <size> <math> [steps] [eval]"""
+usage: [DBN_TIMING_LR=x] python tools/cfg_timing.py <backbone> <batch> <size> <math> [steps] [eval]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,7 +28,8 @@ if len(sys.argv) > 6 and sys.argv[6] == 'eval':
     sys.exit(0)
 m = DBTextModel(arch).cuda().train()
 m.engine.set_conv_math(math_)
-tr = DBTrainer(m, DBLoss(), FusedAdam(m))
+lr = float(os.environ.get('DBN_TIMING_LR', '0.005'))  # (the deformable nets: at the reference's 0.005 on random data the learned offsets reach tens of pixels within ten steps)
+tr = DBTrainer(m, DBLoss(), FusedAdam(m, lr=lr))
 img, gts = bench.synthetic(n, size, 42, torch.device('cuda'))
 for _ in range(3):
     p, l = tr.step(img, gts)
@@ -38,5 +39,8 @@ for _ in range(steps):
     p, l = tr.step(img, gts)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+offs = [float(t.float()[..., :18].abs().max()) for k, t in m.engine.bufs.items() if k.endswith('/offset')]
+if offs:
+    print('  (lr %g; learned offsets after the last step: max |offset| per deformable layer %s)' % (lr, ' '.join('%.1f' % v for v in offs)))
 print('%s bs%d %dx%d %s: %.2f ms/step, %.1f images/s, loss %.4f, peak mem %.1f GB' %
       (arch, n, size, size, math_, dt * 1e3, n / dt, float(l[4]), torch.cuda.max_memory_allocated() / 2**30))
