@@ -27,10 +27,10 @@
 #endif
 // timing experiments (wrong results by construction; tools/winograd_probe.py with DBN_LIB_PATH): 1 weight fragments of the first channel
 // block only, 2 no LDS reads / transform arithmetic in the loop, 3 no exchange / statistics in the epilogue, 5 no patch store / barrier
-// in the loop, 6 = 3 + 5, 7 = 2 + 3 + 5 (what is left: prologue, MFMAs, weight loads, plain stores)
-#define DBN_WX_NOXFORM (DBN_WINO_EXP == 2 || DBN_WINO_EXP == 7)
-#define DBN_WX_NOEXCH (DBN_WINO_EXP == 3 || DBN_WINO_EXP == 6 || DBN_WINO_EXP == 7)
-#define DBN_WX_NOBAR (DBN_WINO_EXP == 5 || DBN_WINO_EXP == 6 || DBN_WINO_EXP == 7)
+// in the loop, 6 = 3 + 5, 7 = 2 + 3 + 5 (what is left: prologue, MFMAs, weight loads, plain stores), 8 = 7 + 1 (... without the weight loads)
+#define DBN_WX_NOXFORM (DBN_WINO_EXP == 2 || DBN_WINO_EXP == 7 || DBN_WINO_EXP == 8)
+#define DBN_WX_NOEXCH (DBN_WINO_EXP == 3 || DBN_WINO_EXP == 6 || DBN_WINO_EXP == 7 || DBN_WINO_EXP == 8)
+#define DBN_WX_NOBAR (DBN_WINO_EXP == 5 || DBN_WINO_EXP == 6 || DBN_WINO_EXP == 7 || DBN_WINO_EXP == 8)
 
 namespace {
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             constexpr int st_ = decltype(SET)::value;
             const int g = min(w_next, w_last);
             ++w_next;
-#if DBN_WINO_EXP == 1  // (timing experiment, wrong results: the weight fragments of the first channel block only — no L2 weight traffic)
+#if DBN_WINO_EXP == 1 || DBN_WINO_EXP == 8  // (timing experiment, wrong results: the weight fragments of the first channel block only — no L2 weight traffic; 8 = 7 + this)
             if (w_next > 4) return;
 #endif
             const unsigned so = (unsigned)((g >> 2) * 16 + 4 * wave + (g & 3)) * point_bytes;
@@ -319,8 +319,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr bool plus = j == 1;
                 f32x4 v[2];
 #if DBN_WX_NOXFORM  // (timing experiment, wrong results: no LDS reads / transform arithmetic in the loop)
-                v[0] = pr[0];
-                v[1] = pr[1 % PL];
+                // (round 5: NOT the patch registers — `pr` is rewritten by load_patch at the top of every channel block, so MFMAs fed from it
+                // waited a global-load latency per block and builds 2 / 7 / 8 measured that wait, not the skeleton.  An opaque per-lane value.)
+                v[0] = f32x4{(float)lane, 1.f, 2.f, 3.f};
+                v[1] = f32x4{4.f, (float)li, 6.f, 7.f};
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]));
 #else
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
