@@ -370,6 +370,7 @@ def main():
     # depends on the allocation history (first process after a fresh checkout compiles its .pyc files and shifts it in).
     # Nothing in a step creates reference cycles; the collector runs again right after the region.
     import gc
+    trainer.gc_freeze = False  # (the trainer's own one-time collect + freeze comes at ITS fourth step: with --warmup < 4 that is a timed step)
     gc.collect()
     gc.disable()
     barrier()

@@ -235,11 +235,11 @@ __global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict
 // not 9x that many position tests); the taps of the pixels that pass are tested three pixels at a time, one lane per (pixel, tap) (offset
 // pair -> position -> is (y, x) one of the corners, with which weight — the same float expressions as sample_of / deform_im2col_kernel);
 // the hits are walked in (pixel, tap) order (ballot + shuffles: no memory), every lane adding w * dcols[m][k][its channel quads].  One fixed summation order per output element: bit-reproducible, and independent of the
-// grid.  Larger offsets only widen the window (E is read on the device: no host synchronisation, no fallback path).  A workgroup owns an
-// 8 x 8 tile of input pixels (team = one row, walking its 8 pixels), so the four corners' re-reads of a dcols row meet in L1 / L2.
+// grid.  Larger offsets only widen the window (E is read on the device: no host synchronisation, no fallback path).  A workgroup owns 8 rows x 2
+// columns of input pixels (team = one row), neighbouring workgroups follow in x, so the four corners' re-reads of a dcols row meet in L1 / L2.
 // Non-finite values: a NaN / Inf in dcols reaches exactly the dx / doffset elements its sample touches (as float atomics would);
 // a NaN offset makes its sample "outside" (contributes nothing) and does not widen the window.
-constexpr int GATHER_TILE = 8;
+constexpr int GATHER_TILE = 8, GATHER_TILE_X = 2;  // input rows (= teams) x columns (walked by each team) per workgroup
 
 template <int AT>
 __global__ __launch_bounds__(256) void deform_doffset_kernel(const void* __restrict__ dcols, const void* __restrict__ x,
@@ -305,15 +305,19 @@ __global__ __launch_bounds__(256) void deform_bbox_kernel(const void* __restrict
     }
 }
 
-// NQ: channel quads per lane (C <= 128 * NQ)
+// NQ: channel quads per lane (C <= 128 * NQ).  The kernel is a chain of dependent loads (box -> offsets -> dcols rows) per pixel, so what
+// it has to offer the memory system is parallelism: a team walks only GATHER_TILE_X pixels (10 000+ workgroups at 100^2), the boxes of three
+// window rounds are loaded together, the next tap group's offsets are loaded before the current group's hits are walked, and 8 (NQ <= 2) or 4
+// dcols rows are in flight per batch.
 template <int AT, int NQ>
 __global__ __launch_bounds__(256) void deform_dx_gather_kernel(const void* __restrict__ dcols, const void* __restrict__ offset,
                                                                const int4* __restrict__ bbox, void* __restrict__ dx,
                                                                const unsigned* __restrict__ maxbits, DeformDims d, int tiles_x, int tiles_y,
                                                                int accumulate) {
+    constexpr int HB = NQ <= 2 ? 8 : 4;  // dcols rows per batch
     const int lane = threadIdx.x & 31, team = threadIdx.x >> 5, half = (threadIdx.x >> 5) & 1, lbase = 32 * half;
     const int RS = d.R * d.S, c4n = d.C >> 2;
-    int bid = blockIdx.x;
+    int bid = dbn_xcd_remap(blockIdx.x, gridDim.x);  // (an XCD owns a contiguous run of tiles: the corner re-reads of a dcols row meet in ITS L2)
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y, n = bid / tiles_y;
@@ -330,8 +334,11 @@ __global__ __launch_bounds__(256) void deform_dx_gather_kernel(const void* __res
     const int ho_lo = ay <= 0 ? 0 : (ay + d.stride - 1) / d.stride, ho_hi = min(d.Ho - 1, by / d.stride);
     const int nho = ho_hi - ho_lo + 1;
     const int PPR = 32 / RS;  // output pixels whose taps are tested side by side (three for 3 x 3)
-    for (int ix = 0; ix < GATHER_TILE; ++ix) {
-        const int x = tx * GATHER_TILE + ix;
+    const int slot = lane / RS, k = lane - slot * RS;
+    const int r = k / d.S, s_ = k - r * d.S;
+    const int HWo = d.Ho * d.Wo;
+    for (int ix = 0; ix < GATHER_TILE_X; ++ix) {
+        const int x = tx * GATHER_TILE_X + ix;
         if (x >= d.W) break;
         const int ax = x - E + d.pad - (d.S - 1), bx = x + E + d.pad;
         const int wo_lo = ax <= 0 ? 0 : (ax + d.stride - 1) / d.stride, wo_hi = min(d.Wo - 1, bx / d.stride);
@@ -340,78 +347,108 @@ __global__ __launch_bounds__(256) void deform_dx_gather_kernel(const void* __res
         f32x4 acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int i0 = 0; i0 < npix; i0 += 32) {
-            // stage 1: 32 output pixels of the window against their boxes
-            const int i = i0 + lane;
-            int m_l = 0;
-            bool pass = false;
-            if (i < npix) {
-                const int iho = i / nwo, iwo = i - iho * nwo;
-                m_l = (n * d.Ho + ho_lo + iho) * d.Wo + wo_lo + iwo;
-                const int4 bb = bbox[m_l];
-                pass = y >= bb.x && y <= bb.y && x >= bb.z && x <= bb.w;
+        // one tap group: up to PPR passing pixels taken off the mask `pm` (their m from lane registers `m_l`), this lane's (pixel, tap)
+        // and its offset pair, loaded but not yet used
+        struct Group {
+            int m_s;
+            float oy, ox;
+        };
+        auto take_group = [&](unsigned& pm, int m_l) {
+            Group g;
+            g.m_s = -1;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (u < PPR) {
+                    const bool have = pm != 0u;
+                    const int src = have ? __builtin_ctz(pm) : 0;
+                    pm &= pm - 1u;
+                    const int mm = __shfl(m_l, lbase + src, 64);
+                    if (have && slot == u) g.m_s = mm;
+                }
             }
-            unsigned pm = (unsigned)(__ballot(pass) >> lbase);
-            while (pm) {  // (team-uniform)
-                // stage 2: the taps of up to PPR passing pixels, one lane per (pixel, tap), in (pixel, tap) order
-                const int slot = lane / RS, k = lane - slot * RS;
-                int m_s = -1;
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    if (u < PPR) {
-                        const bool have = pm != 0u;
-                        const int src = have ? __builtin_ctz(pm) : 0;
-                        pm &= pm - 1u;
-                        const int mm = __shfl(m_l, lbase + src, 64);
-                        if (have && slot == u) m_s = mm;
-                    }
+            g.oy = g.ox = 0.f;
+            if (g.m_s >= 0) {
+                g.oy = dbn_ld1<AT>(offset, (long)g.m_s * d.off_stride + 2 * k);
+                g.ox = dbn_ld1<AT>(offset, (long)g.m_s * d.off_stride + 2 * k + 1);
+            }
+            return g;
+        };
+        auto walk_group = [&](const Group& g) {
+            float w = 0.f;
+            int mk = 0;
+            if (g.m_s >= 0) {
+                const int rem = g.m_s - n * HWo;
+                const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
+                const float py = (float)(ho * d.stride - d.pad + r) + g.oy;
+                const float px = (float)(wo * d.stride - d.pad + s_) + g.ox;
+                if (py > -1.f && py < (float)d.H && px > -1.f && px < (float)d.W) {  // (sample_of's `inside`)
+                    const float fy = floorf(py), fx = floorf(px);
+                    const int y0 = (int)fy, x0 = (int)fx;
+                    const float ly = py - fy, lx = px - fx;
+                    const float wy = y == y0 ? 1.f - ly : (y == y0 + 1 ? ly : 0.f);
+                    const float wx = x == x0 ? 1.f - lx : (x == x0 + 1 ? lx : 0.f);
+                    w = wy * wx;  // (the corner weights of deform_im2col_kernel: (1 - ly | ly) * (1 - lx | lx))
+                    mk = g.m_s * RS + k;
                 }
-                float w = 0.f;
-                int mk = 0;
-                if (m_s >= 0 && slot < PPR) {
-                    const int rem = m_s - n * d.Ho * d.Wo;
-                    const int ho = rem / d.Wo, wo = rem - ho * d.Wo;
-                    const int r = k / d.S, s_ = k - r * d.S;
-                    const float py = (float)(ho * d.stride - d.pad + r) + dbn_ld1<AT>(offset, (long)m_s * d.off_stride + 2 * k);
-                    const float px = (float)(wo * d.stride - d.pad + s_) + dbn_ld1<AT>(offset, (long)m_s * d.off_stride + 2 * k + 1);
-                    if (py > -1.f && py < (float)d.H && px > -1.f && px < (float)d.W) {  // (sample_of's `inside`)
-                        const float fy = floorf(py), fx = floorf(px);
-                        const int y0 = (int)fy, x0 = (int)fx;
-                        const float ly = py - fy, lx = px - fx;
-                        const float wy = y == y0 ? 1.f - ly : (y == y0 + 1 ? ly : 0.f);
-                        const float wx = x == x0 ? 1.f - lx : (x == x0 + 1 ? lx : 0.f);
-                        w = wy * wx;  // (the corner weights of deform_im2col_kernel: (1 - ly | ly) * (1 - lx | lx))
-                        mk = m_s * RS + k;
-                    }
+            }
+            unsigned hits = (unsigned)(__ballot(w != 0.f) >> lbase);
+            while (hits) {  // (team-uniform) the hits in lane = (pixel, tap) order, HB rows in flight
+                int hm[HB];
+                float hw[HB];
+#pragma unroll
+                for (int u = 0; u < HB; ++u) {
+                    const bool have = hits != 0u;
+                    const int src = have ? __builtin_ctz(hits) : 0;
+                    hits &= hits - 1u;
+                    const int mm = __shfl(mk, lbase + src, 64);
+                    const float ww = __shfl(w, lbase + src, 64);
+                    hm[u] = have ? mm : -1;
+                    hw[u] = have ? ww : 0.f;
                 }
-                unsigned hits = (unsigned)(__ballot(w != 0.f) >> lbase);
-                while (hits) {  // stage 3 (team-uniform): the hits in lane order, four loads in flight
-                    int hm[4];
-                    float hw[4];
+                f32x4 gq[HB][NQ];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool have = hits != 0u;
-                        const int src = have ? __builtin_ctz(hits) : 0;
-                        hits &= hits - 1u;
-                        const int mm = __shfl(mk, lbase + src, 64);
-                        const float ww = __shfl(w, lbase + src, 64);
-                        hm[u] = have ? mm : -1;
-                        hw[u] = have ? ww : 0.f;
+                for (int u = 0; u < HB; ++u)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c4 = lane + 32 * q;
+                        gq[u][q] = (hm[u] >= 0 && c4 < c4n) ? dbn_ld4<AT>(dcols, (long)hm[u] * c4n + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    f32x4 g[4][NQ];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < HB; ++u)
+                    if (hm[u] >= 0) {
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const int c4 = lane + 32 * q;
-                            g[u][q] = (hm[u] >= 0 && c4 < c4n) ? dbn_ld4<AT>(dcols, (long)hm[u] * c4n + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
+                        for (int q = 0; q < NQ; ++q) acc[q] += hw[u] * gq[u][q];
+                    }
+            }
+        };
+        for (int i0 = 0; i0 < npix; i0 += 96) {
+            // stage 1: up to 96 output pixels of the window against their boxes, the three loads issued together
+            int m_l[3];
+            int4 bb[3];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (hm[u] >= 0) {
+            for (int t = 0; t < 3; ++t) {
+                const int i = i0 + 32 * t + lane;
+                const int iho = i / nwo, iwo = i - iho * nwo;
+                m_l[t] = i < npix ? (n * d.Ho + ho_lo + iho) * d.Wo + wo_lo + iwo : -1;
+                bb[t] = m_l[t] >= 0 ? bbox[m_l[t]] : int4{1, 0, 1, 0};
+            }
 #pragma unroll
-                            for (int q = 0; q < NQ; ++q) acc[q] += hw[u] * g[u][q];
-                        }
+            for (int t = 0; t < 3; ++t) {
+                if (i0 + 32 * t >= npix) break;  // (team-uniform)
+                const bool pass = m_l[t] >= 0 && y >= bb[t].x && y <= bb[t].y && x >= bb[t].z && x <= bb[t].w;
+                unsigned pm = (unsigned)(__ballot(pass) >> lbase);
+                if (!pm) continue;
+                // stage 2 + 3: the passing pixels' taps, PPR pixels per group; the next group's offsets are in flight while this one's hits are walked
+                Group cur = take_group(pm, m_l[t]);
+                while (true) {
+                    const bool more = pm != 0u;  // (team-uniform)
+                    Group nxt;
+                    nxt.m_s = -1;
+                    nxt.oy = nxt.ox = 0.f;
+                    if (more) nxt = take_group(pm, m_l[t]);
+                    walk_group(cur);
+                    if (!more) break;
+                    cur = nxt;
                 }
             }
         }
@@ -538,7 +575,7 @@ int dbn_deform_col2im_gather_t(int at, const void* dcols, const void* x, const v
     if (hipMemsetAsync(ws, 0, 16, st) != hipSuccess) return dbn_status();
     unsigned* maxbits = reinterpret_cast<unsigned*>(ws);
     int4* bbox = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + 16);
-    const int tiles_x = dbn_ceil_div(W, GATHER_TILE), tiles_y = dbn_ceil_div(H, GATHER_TILE);
+    const int tiles_x = dbn_ceil_div(W, GATHER_TILE_X), tiles_y = dbn_ceil_div(H, GATHER_TILE);
     DBN_DISPATCH_AT(at, {
         hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(M * off_stride / 4, 256, 2048)), dim3(256), 0, st, offset, M * off_stride / 4, maxbits);
         hipLaunchKernelGGL(deform_bbox_kernel<AT>, dim3(dbn_grid(M, 256, 4096)), dim3(256), 0, st, offset, bbox, d, (int)M);

@@ -1,7 +1,7 @@
 """GPU: the adjoint of the deformable sampling — round 3's fixed-point scatter (dbn_deform_col2im_t) against round 5's gather
 (dbn_deform_col2im_gather_t), alone, HIP events, on configs[3]'s three deformable stages (8 x 800^2: 100^2 x 128, 50^2 x 256, 25^2 x 512) for
 normally distributed offsets of growing size and for one outlier in an otherwise quiet map.
-usage: python tools/dcn_probe.py [bf16]"""
+usage: python tools/dcn_probe.py [f32|bf16] [H] [sigma]     (H, sigma: only that stage / offset size — for a rocprofv3 kernel trace)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,7 +26,11 @@ def timed(fn, reps=5):
     return a.elapsed_time(b) / reps * 1e3
 
 
+only_h = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only_s = sys.argv[3] if len(sys.argv) > 3 else ''
 for (N, C, H, stride) in ((8, 128, 100, 1), (8, 256, 50, 1), (8, 512, 25, 1), (8, 128, 200, 2)):
+    if only_h and H != only_h:
+        continue
     W = H
     Ho = Wo = (H + 2 - 3) // stride + 1
     g = torch.Generator().manual_seed(1)
@@ -38,6 +42,8 @@ for (N, C, H, stride) in ((8, 128, 100, 1), (8, 256, 50, 1), (8, 512, 25, 1), (8
     wsg = torch.empty(L.dbn_deform_col2im_gather_ws_bytes(N, Ho, Wo), device=dev, dtype=torch.uint8)
     dims = (N, H, W, C, Ho, Wo, 3, 3, stride, 1, 64)
     for label, scale, outlier in (('0', 0.0, 0), ('0.5', 0.5, 0), ('1', 1.0, 0), ('2', 2.0, 0), ('4', 4.0, 0), ('8', 8.0, 0), ('0.5 + one offset of 30', 0.5, 30)):
+        if only_s and label != only_s:
+            continue
         off = torch.zeros(N, Ho, Wo, 64)
         off[..., :18] = torch.randn(N, Ho, Wo, 18, generator=g) * scale
         if outlier:
