@@ -1619,10 +1619,11 @@ class Engine:
             cur = self.conv_bn_act_eval(cname, cur, conv, name + ('/out' if last else '/z%d' % (i + 1)), bn, relu=True, res=res if last else None)
         return cur
 
-    # 16-bit storage: level 0 of the pyramid conv through the pixel-patch kernel.  1: in train mode only; 2: in inference too.  Measured
-    # (one box, interleaved): bf16 step 16 x 640^2 12.02 -> 11.5 ms; cfg5 fp16 inference 14.95 -> 15.7 ms — there the second pass over the
-    # 1.7 GB output (write, read, write) costs more than the faster level 0 saves — so inference keeps the one-launch form.
-    fpn_level0_patch = int(os.environ.get('DBN_FPN_LV0_PATCH', '1'))
+    # 16-bit storage: level 0 of the pyramid conv through the pixel-patch kernel.  0: off (default); 1: in train mode; 2: in inference too.
+    # Measured: `tools/cfg_timing.py` (eager loop, host-paced) bf16 16 x 640^2 12.02 -> 11.5 ms, twice — but bench.py's step (resident inputs,
+    # collector off, GPU-paced), interleaved on one box: 1655 / 1654 images/s without it, 1643 / 1638 with it; cfg5 fp16 inference 14.95 ->
+    # 15.7 ms (the second pass over the 1.7 GB output — write, read, write — costs more than the faster level 0 saves).  Off.
+    fpn_level0_patch = int(os.environ.get('DBN_FPN_LV0_PATCH', '0'))
 
     def _fpn_level0_patch_ok(self, z0, Co, train=False):
         N, H, W, Cg = z0.shape
