@@ -108,10 +108,17 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // panel into registers, one stage ahead (as DIRECTB for fp32) — the ring carries the A panel only: half the DMA instructions and
     // their scalar bookkeeping, no fragment reads for B, a ring half the size.  bf16 step 1624 -> 1683 images/s (interleaved A/B on
     // one box; -DDBN_DIRECTB16=0 builds the ring with both panels)
-    constexpr bool DB16 = DBN_DIRECTB16 && AT != 0 && AT != 3 && MODE != 3 && !PATCH;
+#ifndef DBN_DIRECTB16_PYR
+#define DBN_DIRECTB16_PYR 1  // round 5: ... and the pyramid form (MODE 3) too: its ring is bound by the bytes it can keep in flight
+#endif
+    constexpr bool DB16 = DBN_DIRECTB16 && AT != 0 && AT != 3 && (MODE != 3 || DBN_DIRECTB16_PYR) && !PATCH;
     constexpr int DMA_UNIT = NP * 2 * BM + (DB16 ? 0 : NSX * 2 * BN);  // 16-byte slots of one unit
     constexpr int DMA_STAGE = DMA_SU * DMA_UNIT;
-    constexpr int DMA_NSTG = DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
+#ifndef DBN_PYR_NSTG
+#define DBN_PYR_NSTG 4  // ring depth of the register-fed pyramid form (A panel only: 8 KB per stage at 128 rows).  6 (48 KB, still three workgroups per CU) measured equal: cfg5 14.55 / 14.50 vs 14.56 / 14.59 ms, bf16 step 1660 / 1671 vs 1665 / 1664 images/s
+#endif
+    constexpr int DMA_NSTG = (DB16 && MODE == 3 && DMA_STAGE * 16 * DBN_PYR_NSTG <= 48 * 1024) ? DBN_PYR_NSTG :
+                             DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
     // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
     constexpr int P_PATCH = NSX * 4 * 180;
     constexpr int P_BUNIT = NSX * 2 * BN, P_BSTAGE = 2 * P_BUNIT;
@@ -920,8 +927,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         if (AT == 3) plane_bytes = p.seg_plane_bytes[g];
         long krows = 0;
         for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
-        rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_wpk[g] + krows * p.Cd * NSX / 2), 0, (unsigned)qKT * bstep_bytes,
-                                                  0x00020000);
+        if (!DB16)  // (DB16: the weight side has its own walker, level_b — it runs behind this one)
+            rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_wpk[g] + krows * p.Cd * NSX / 2), 0, (unsigned)qKT * bstep_bytes,
+                                                      0x00020000);
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             r_nb[i] = r_n[MODE == 3 ? i : 0] * gHs * gWs * p.Cs;
@@ -1001,13 +1009,33 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             for (int b = 0; b < NI; ++b) bvo[t][b] = (unsigned)((t * 2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
         f32x4 rbB[2][DMA_SU][NSX][NI];
         int bkt = kt_begin;  // weight k-tile of the next unit to fetch (clamped: units past the end multiply zeros of A)
-        const int bkt_max = max(kt_end - 1, kt_begin);
+        int bkt_max = max(kt_end - 1, kt_begin);
+        // MODE 3: the weight side walks the pyramid levels on its own (it runs DMA_NSTG - 2 stages behind the A side's level_dma): level g's
+        // panel starts at this class's row offset, has b_left k-tiles, and — like the A side — ends on a stage boundary (the odd unit past a
+        // level's end re-reads its last k-tile against zeros of A)
+        int b_level = MODE == 3 ? p.first_level : 0, b_left = 0;
+        auto level_b = [&](int g) {
+            const int f = 1 << g, kk = f + 2;
+            const int oh0g = q.oh0 & (f - 1), ow0g = q.ow0 & (f - 1);
+            const int ph = (oh0g + 1) & (f - 1), pw = (ow0g + 1) & (f - 1);
+            const int kt_g = (taps_of_class(kk, ph, f) * taps_of_class(kk, pw, f) * p.Cs) >> 4;
+            long krows = 0;
+            for (int d = 0; d < ph * f + pw; ++d) krows += taps_of_class(kk, d >> g, f) * taps_of_class(kk, d & (f - 1), f) * p.Cs;
+            rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg_wpk[g] + krows * p.Cd * NSX / 2), 0, (unsigned)kt_g * bstep_bytes,
+                                                      0x00020000);
+            b_left = kt_g;
+            bkt = 0;
+            bkt_max = max(kt_g - 1, 0);
+        };
+        if (MODE == 3) level_b(b_level);
         auto issue_bs = [&](auto SET) {
             constexpr int st__ = decltype(SET)::value;
+            if (MODE == 3 && b_left <= 0 && b_level < 3) level_b(++b_level);
 #pragma unroll
             for (int u = 0; u < DMA_SU; ++u) {
                 const unsigned so = (unsigned)min(bkt, bkt_max) * bstep_bytes;
                 ++bkt;
+                --b_left;
 #pragma unroll
                 for (int t = 0; t < NSX; ++t)
 #pragma unroll
@@ -1057,18 +1085,30 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             }
             slot = slot + 1 == DMA_NSTG ? 0 : slot + 1;
         };
-        static_assert(DMA_NSTG == 4, "the peeled iterations below spell the early counts out");
+        static_assert(DMA_NSTG == 4 || DMA_NSTG == 6, "the peeled iterations below spell the early counts out");
         using E0 = std::integral_constant<int, 0>;
         using E1 = std::integral_constant<int, 1>;
         using E2 = std::integral_constant<int, 2>;
         int st_ = 0;
         if (nstages > 0) body(S0{}, E0{});
         if (nstages > 1) body(S1{}, E1{});
-        for (st_ = 2; st_ + 2 <= nstages; st_ += 2) {
-            body(S0{}, E2{});
-            body(S1{}, E2{});
+        if constexpr (DMA_NSTG == 6) {  // (two more stages of the ramp: early = 2, 3; steady state early = DMA_NSTG - 2 = 4)
+            using E3 = std::integral_constant<int, 3>;
+            using E4 = std::integral_constant<int, 4>;
+            if (nstages > 2) body(S0{}, E2{});
+            if (nstages > 3) body(S1{}, E3{});
+            for (st_ = 4; st_ + 2 <= nstages; st_ += 2) {
+                body(S0{}, E4{});
+                body(S1{}, E4{});
+            }
+            if (st_ < nstages && nstages > 4) body(S0{}, E4{});
+        } else {
+            for (st_ = 2; st_ + 2 <= nstages; st_ += 2) {
+                body(S0{}, E2{});
+                body(S1{}, E2{});
+            }
+            if (st_ < nstages) body(S0{}, E2{});
         }
-        if (st_ < nstages) body(S0{}, E2{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
