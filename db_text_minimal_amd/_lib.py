@@ -131,6 +131,10 @@ SIGNATURES.update({
     'dbn_deform_col2im_gather_t': 'i' + SIGNATURES['dbn_deform_col2im'],
     'dbn_deform_col2im_gather_ws_bytes': 'iii',
     'dbn_deform_offset_absmax_t': 'iplpp',
+    'dbn_pw16_eligible': 'iiiiii',
+    'dbn_pw16_panel_bytes': '',
+    'dbn_pw16_pack': 'ipipp',
+    'dbn_pw16_act_t': 'ipppipiiiip',
     'dbn_cast_f32': 'ipplp',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,
@@ -162,7 +166,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_pw16_panel_bytes', 'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

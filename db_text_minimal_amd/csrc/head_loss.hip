@@ -42,44 +42,60 @@ __device__ __forceinline__ float group16_sum(float v) {
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v) { return dpp_f32<K | (K << 2) | (K << 4) | (K << 6)>(v); }
 
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f32<DPP_QUAD_XOR1>(v);
+    v += dpp_f32<DPP_QUAD_XOR2>(v);
+    v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);   // lane i <-> 7-i of its 8-lane half row
+    return v;
+}
+
 // xb/xt: [N,Hq,Wq,64] inputs of the last ConvT (already BN+ReLU'd);  wb/wt: [64][4]
 // (ConvTranspose2d weight [64,1,2,2]); out: [N,CH,2Hq,2Wq], CH=3 (train) or 2 (eval).
-template <int AT>
+// LPP lanes per pixel: 16 (a lane owns 4 channels: fp32 storage, one 16-byte load) or 8 (round 5, 16-bit storage: a lane owns 8 channels —
+// again one 16-byte load instead of an 8-byte one, which reaches 0.55-0.7 of its rate: 1.01 ms for 3.4 GB at cfg5)
+template <int AT, int LPP>
 __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restrict__ xb, const void* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ bias_b,
                                      const float* __restrict__ bias_t, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
                                      const float* __restrict__ sh_t, float* __restrict__ out, int N, int Hq, int Wq, int CH,
                                      float kstep, long per) {
-    const int q = threadIdx.x & 15;
-    // optional fused BatchNorm + ReLU of the inputs (xb/xt are then the pre-BN conv outputs): this lane's 4 channels
+    static_assert((LPP == 16) || (LPP == 8 && AT != 0), "eight lanes per pixel: 16-bit storage");
+    constexpr int NQ = 16 / LPP;  // channel quads per lane
+    const int q = threadIdx.x & (LPP - 1);
+    // optional fused BatchNorm + ReLU of the inputs (xb/xt are then the pre-BN conv outputs): this lane's channels
     const bool bn = sc_b != nullptr;
-    f32x4 scb = {1.f, 1.f, 1.f, 1.f}, shb = {0.f, 0.f, 0.f, 0.f}, sct = scb, sht = shb;
-    if (bn) {
-        scb = *reinterpret_cast<const f32x4*>(sc_b + 4 * q);
-        shb = *reinterpret_cast<const f32x4*>(sh_b + 4 * q);
-        sct = *reinterpret_cast<const f32x4*>(sc_t + 4 * q);
-        sht = *reinterpret_cast<const f32x4*>(sh_t + 4 * q);
+    f32x4 scb[NQ], shb[NQ], sct[NQ], sht[NQ];
+#pragma unroll
+    for (int h = 0; h < NQ; ++h) {
+        scb[h] = sct[h] = f32x4{1.f, 1.f, 1.f, 1.f};
+        shb[h] = sht[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bn) {
+            scb[h] = *reinterpret_cast<const f32x4*>(sc_b + 4 * (NQ * q + h));
+            shb[h] = *reinterpret_cast<const f32x4*>(sh_b + 4 * (NQ * q + h));
+            sct[h] = *reinterpret_cast<const f32x4*>(sc_t + 4 * (NQ * q + h));
+            sht[h] = *reinterpret_cast<const f32x4*>(sh_t + 4 * (NQ * q + h));
+        }
     }
     const long npx = (long)N * Hq * Wq;
-    // a block streams ONE contiguous run of `per` pixels (a multiple of 64), 16 pixels per trip, one per 16-lane group.  Measured at
+    // a block streams ONE contiguous run of `per` pixels (a multiple of 64), 256 / LPP pixels per trip, one per lane group.  Measured at
     // 16x320x320: 178 us with 128-pixel runs (12 800 blocks), 192-198 us with 4096-8192 blocks, 300 us with one trip per block;
     // the grid-stride sweep this replaces took 192-200 us
-    const long gstride = blockDim.x >> 4;
+    const long gstride = blockDim.x / LPP;
     const long r1 = min(npx, (blockIdx.x + 1) * per);
-    // weights of this lane's 4 channels: w[ci][ab]
-    f32x4 wbq[4], wtq[4];
+    // weights of this lane's channels: w[ci][ab]
+    f32x4 wbq[4 * NQ], wtq[4 * NQ];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        wbq[e] = *reinterpret_cast<const f32x4*>(wb + (4 * q + e) * 4);
-        wtq[e] = *reinterpret_cast<const f32x4*>(wt + (4 * q + e) * 4);
+    for (int e = 0; e < 4 * NQ; ++e) {
+        wbq[e] = *reinterpret_cast<const f32x4*>(wb + (4 * NQ * q + e) * 4);
+        wtq[e] = *reinterpret_cast<const f32x4*>(wt + (4 * NQ * q + e) * 4);
     }
     const float bb = bias_b[0], bt = bias_t[0];
     const int H = 2 * Hq, W = 2 * Wq;
     const long HW = (long)H * W;
     // (n, hq, wq) of the pixel: divided out once, then advanced by the stride with carries — a 64-bit division per pixel
     // (~100 VALU instructions, executed by the whole wave) had made this kernel instruction-bound at 4.3 TB/s
-    const long px0 = blockIdx.x * per + (threadIdx.x >> 4);
+    const long px0 = blockIdx.x * per + (threadIdx.x / LPP);
     const long HWq = (long)Hq * Wq;
     long n = px0 / HWq;
     int hq = (int)((px0 - n * HWq) / Wq), wq = (int)((px0 - n * HWq) - (long)hq * Wq);
@@ -92,24 +108,32 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
         if (hq >= Hq) { hq -= Hq; ++n; }
         n += g_n;
     };
-    auto finish = [&](f32x4 vb, f32x4 vt, long pn, int ph, int pw) {
+    auto load = [&](const void* x, long px, f32x4 (&v)[NQ]) {
+        if constexpr (NQ == 1) v[0] = dbn_ld4<AT>(x, px * 16 + q);
+        else dbn_ldq<AT>(x, px * 8 + q, v);
+    };
+    auto finish = [&](f32x4 (&vb)[NQ], f32x4 (&vt)[NQ], long pn, int ph, int pw) {
         if (bn) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vb[e] = dbn_affine_relu(vb[e], scb[e], shb[e]);
-                vt[e] = dbn_affine_relu(vt[e], sct[e], sht[e]);
-            }
+            for (int h = 0; h < NQ; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vb[h][e] = dbn_affine_relu(vb[h][e], scb[h][e], shb[h][e]);
+                    vt[h][e] = dbn_affine_relu(vt[h][e], sct[h][e], sht[h][e]);
+                }
         }
         f32x4 sb = {0.f, 0.f, 0.f, 0.f}, stt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            sb += vb[e] * wbq[e];
-            stt += vt[e] * wtq[e];
-        }
+        for (int h = 0; h < NQ; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sb += vb[h][e] * wbq[4 * h + e];
+                stt += vt[h][e] * wtq[4 * h + e];
+            }
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) {
-            sb[ab] = group16_sum(sb[ab]);
-            stt[ab] = group16_sum(stt[ab]);
+            sb[ab] = LPP == 16 ? group16_sum(sb[ab]) : group8_sum(sb[ab]);
+            stt[ab] = LPP == 16 ? group16_sum(stt[ab]) : group8_sum(stt[ab]);
         }
         if (q < 4) {
             const int ab = q;
@@ -126,11 +150,11 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
     // four pixels per trip, all eight loads issued before the first is used
     long px = px0;
     for (; px + 3 * gstride < r1; px += 4 * gstride) {
-        f32x4 vb[4], vt[4];
+        f32x4 vb[4][NQ], vt[4][NQ];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            vb[u] = dbn_ld4<AT>(xb, (px + u * gstride) * 16 + q);
-            vt[u] = dbn_ld4<AT>(xt, (px + u * gstride) * 16 + q);
+            load(xb, px + u * gstride, vb[u]);
+            load(xt, px + u * gstride, vt[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -138,7 +162,12 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
             advance();
         }
     }
-    for (; px < r1; px += gstride, advance()) finish(dbn_ld4<AT>(xb, px * 16 + q), dbn_ld4<AT>(xt, px * 16 + q), n, hq, wq);
+    for (; px < r1; px += gstride, advance()) {
+        f32x4 vb[NQ], vt[NQ];
+        load(xb, px, vb);
+        load(xt, px, vt);
+        finish(vb, vt, n, hq, wq);
+    }
 }
 
 // Backward.  For each quarter pixel: dl_b[ab], dl_t[ab] (grad wrt the two logits) from
@@ -777,9 +806,18 @@ int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb,
     DBN_REQUIRE((bn_scale_b && bn_shift_b && bn_scale_t && bn_shift_t) || (!bn_scale_b && !bn_shift_b && !bn_scale_t && !bn_shift_t));
     const long npx = (long)N * Hq * Wq;
     const long per = ((npx + 16383) / 16384 + 63) / 64 * 64;  // pixels per block
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(head_tail_fwd_kernel<AT>, dim3((unsigned)((npx + per - 1) / per)), dim3(256), 0,
-                                           (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b, bn_shift_b, bn_scale_t,
-                                           bn_shift_t, out, N, Hq, Wq, channels, kstep, per));
+    const dim3 grid((unsigned)((npx + per - 1) / per));
+    if (at == 1)
+        hipLaunchKernelGGL((head_tail_fwd_kernel<1, 8>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
+                           bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
+    else if (at == 2)
+        hipLaunchKernelGGL((head_tail_fwd_kernel<2, 8>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
+                           bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
+    else if (at == 0)
+        hipLaunchKernelGGL((head_tail_fwd_kernel<0, 16>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
+                           bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
+    else
+        return DBN_ERR_ARG;
     return dbn_status();
 }
 int dbn_head_tail_fwd(const float* xb, const float* xt, const float* wb, const float* wt, const float* bias_b,

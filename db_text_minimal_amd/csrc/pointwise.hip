@@ -416,44 +416,66 @@ __global__ void fold_partials_kernel(const float* __restrict__ part, int nb, int
 // One thread: the channel quad of TWO vertically adjacent outputs (rows 2k, 2k+1): their windows share input row 4k+1, so the 5
 // input rows are read once (15 loads for 2 outputs instead of 18).  Horizontal neighbours re-read through L1/L2 as before; it was
 // the vertical overlap that went back to HBM (FETCH_SIZE 1.54x the tensor with one output per thread, 1.25x the ideal now).
-template <int AT>
+// QW = 2 (16-bit storage, C % 8 == 0; round 5): eight channels per lane and access — the 8-byte accesses of the four-channel form reach
+// 0.55-0.7 of the 16-byte rate (cfg5: 621 us for 2.1 GB)
+template <int AT, int QW>
 __global__ void bnrelu_maxpool_fwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                           void* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
-    const int c4n = C >> 2;
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
     const int Hp = (Ho + 1) >> 1;
-    const long total = (long)N * Hp * Wo * c4n;
+    const long total = (long)N * Hp * Wo * cin;
+    auto ld = [&](long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(y, i);
+        else dbn_ldq<AT>(y, i, v);
+    };
+    auto st = [&](long i, const f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) dbn_st4<AT>(out, i, v[0]);
+        else dbn_stq<AT>(out, i, v);
+    };
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        long t = i / c4n;
+        const int ci = (int)(i % cin);
+        long t = i / cin;
         const int ow = (int)(t % Wo);
         t /= Wo;
         const int k = (int)(t % Hp);
         const int n = (int)(t / Hp);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + 4 * c4);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + 4 * c4);
-        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;  // relu output >= 0, so 0 is a neutral start (padding never wins)
+        f32x4 s[QW], h[QW], m0[QW], m1[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            s[q] = *reinterpret_cast<const f32x4*>(sc + 4 * (QW * ci + q));
+            h[q] = *reinterpret_cast<const f32x4*>(sh + 4 * (QW * ci + q));
+            m0[q] = m1[q] = f32x4{0.f, 0.f, 0.f, 0.f};  // relu output >= 0, so 0 is a neutral start (padding never wins)
+        }
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             const int ih = 4 * k - 1 + r;
             if ((unsigned)ih >= (unsigned)H) continue;
-            f32x4 rm = {0.f, 0.f, 0.f, 0.f};
+            f32x4 rm[QW];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int iw = ow * 2 - 1 + q;
+            for (int q = 0; q < QW; ++q) rm[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+                const int iw = ow * 2 - 1 + qq;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = dbn_ld4<AT>(y, (((long)n * H + ih) * W + iw) * c4n + c4);
+                f32x4 v[QW];
+                ld((((long)n * H + ih) * W + iw) * cin + ci, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rm[e] = fmaxf(rm[e], dbn_affine_relu(v[e], s[e], h[e]));
+                for (int q = 0; q < QW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rm[q][e] = fmaxf(rm[q][e], dbn_affine_relu(v[q][e], s[q][e], h[q][e]));
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (r <= 2) m0[e] = fmaxf(m0[e], rm[e]);
-                if (r >= 2) m1[e] = fmaxf(m1[e], rm[e]);
-            }
+            for (int q = 0; q < QW; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (r <= 2) m0[q][e] = fmaxf(m0[q][e], rm[q][e]);
+                    if (r >= 2) m1[q][e] = fmaxf(m1[q][e], rm[q][e]);
+                }
         }
-        const long o = (((long)n * Ho + 2 * k) * Wo + ow) * c4n + c4;
-        dbn_st4<AT>(out, o, m0);
-        if (2 * k + 1 < Ho) dbn_st4<AT>(out, o + (long)Wo * c4n, m1);
+        const long o = (((long)n * Ho + 2 * k) * Wo + ow) * cin + ci;
+        st(o, m0);
+        if (2 * k + 1 < Ho) st(o + (long)Wo * cin, m1);
     }
 }
 
@@ -1028,7 +1050,15 @@ int dbn_bnrelu_maxpool_fwd_t(int at, const void* y, const float* scale, const fl
                              void* stream) {
     DBN_REQUIRE(y && scale && shift && out && C % 4 == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_fwd_kernel<AT>, dim3(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 4))), dim3(256), 0,
+    if ((at == 1 || at == 2) && C % 8 == 0) {
+        const dim3 grid(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 8)));
+        if (at == 1)
+            hipLaunchKernelGGL((bnrelu_maxpool_fwd_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo);
+        else
+            hipLaunchKernelGGL((bnrelu_maxpool_fwd_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo);
+        return dbn_status();
+    }
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL((bnrelu_maxpool_fwd_kernel<AT, 1>), dim3(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 4))), dim3(256), 0,
                                            (hipStream_t)stream, y, scale, shift, out, N, H, W, C, Ho, Wo));
     return dbn_status();
 }

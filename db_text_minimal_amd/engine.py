@@ -719,6 +719,7 @@ class Engine:
 
     # ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage through its own kernel (round 5, csrc/convt16.hip: the layer is
     # HBM-bound and the generic parity-class launch ran it at 2.5x its memory time).  DBN_CONVT16=0: the generic launch.
+    pw16 = os.environ.get('DBN_PW16', '1') == '1'  # inference: pointwise convs 64 -> 64 | 256 on 16-bit storage through csrc/convt16.hip's kernel
     convt16 = os.environ.get('DBN_CONVT16', '1') == '1'
 
     def _convt16(self, name, x, ct, out_name, bn_name=None, bn=None):
@@ -1151,7 +1152,23 @@ class Engine:
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
         z = self.buf(out_name, N, Ho, Wo, conv.cout)
         assert res is None or (tuple(res.shape) == tuple(z.shape) and res.dtype == z.dtype), name
-        if self._winograd_ok(x, vconv):
+        if (self.pw16 and self.at != 0 and k == 1 and s == 1 and p == 0 and res is None and C == conv.cin
+                and bool(self.L.dbn_pw16_eligible(self.at, N, H, W, C, conv.cout))):
+            # 16-bit storage: a pointwise conv 64 -> 64 | 256 (the FPN lateral on c2) on the ConvT kernel's construction — whole panel in
+            # registers, A fragments straight from global memory, no ring (round 5)
+            key = (name, 'pw16', self.kind)
+            ent = self.packs.get(key)
+            stamp = (ver, self.param_epoch, vconv.weight.data_ptr())
+            if ent is None or ent[1] != stamp:
+                panel = ent[0] if ent is not None else torch.empty(self.L.dbn_pw16_panel_bytes(), device=x.device, dtype=torch.uint8)
+                check(self.L.dbn_pw16_pack(self.kind, vconv.weight.data_ptr(), conv.cout, panel.data_ptr(), self.stream), 'pw16_pack')
+                self.packs[key] = (panel, stamp)
+            panel = self.packs[key][0]
+            if self.prof:
+                self.prof.begin('convt2x2_b16_kernel<%d>' % self.at, 2.0 * N * H * W * conv.cout * C, float(2 * (x.numel() + z.numel())), 'fwd ' + name)
+            check(self.L.dbn_pw16_act_t(self.at, x.data_ptr(), panel.data_ptr(), vconv.bias.data_ptr(), int(relu), z.data_ptr(), N, H, W,
+                                        conv.cout, self.stream), 'pw16 ' + name)
+        elif self._winograd_ok(x, vconv):
             up = self._winograd_panel(name + '#fold', vconv.weight, C, version=ver)
             if self.prof:
                 self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 0.0, 'fwd ' + name)

@@ -555,6 +555,15 @@ int dbn_convt16_pack(int kind, const float* w_iohw, void* out, void* stream);
 int dbn_convt16_bn_t(int at, const void* x, const void* wpk, const float* bias, void* y, int N, int H, int W, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                      float* ws, void* stream);
+/* ... and the same kernel as a pointwise conv 64 -> 64 | 256 on 16-bit storage, inference form (round 5): y [N][H][W][Cout] =
+ * [relu](conv1x1(x [N][H][W][64]) + bias) — nn.Conv2d(64, Cout, 1) with the eval-mode BatchNorm folded into weight / bias (dbn_fold_bn_eval)
+ * and the ReLU of modules/basic.py:32-36; the FPN lateral reduce_conv_c2 of resnet18, modules/segmentation_body.py:46,68.  Panel:
+ * dbn_pw16_panel_bytes() bytes from the OIHW weight [Cout][64][1][1] (dbn_pw16_pack; kind 1 bf16, 2 fp16). */
+int dbn_pw16_eligible(int at, int N, int H, int W, int Cin, int Cout);
+long dbn_pw16_panel_bytes(void);
+int dbn_pw16_pack(int kind, const float* w_oihw, int Cout, void* out, void* stream);
+int dbn_pw16_act_t(int at, const void* x, const void* wpk, const float* bias, int relu, void* y, int N, int H, int W, int Cout, void* stream);
+
 /* ... 16-bit storage: the 16-channel form and (out4 non-NULL) the packed 4-channel form of dbn_nchw3_to_nhwc4_packed_t in ONE launch */
 int dbn_nchw3_to_nhwc16_and_4_t(int at, const float* x, void* out16, void* out4, int N, int H, int W, void* stream);
 /* the same into [N,H,W,4] of the storage type (16-bit: 4 channels, not a 16-channel block): X operand of the stem weight gradient */

@@ -1164,6 +1164,40 @@ def test_pyramid_conv_on_16bit_storage_from_level_one(shape, dtype, first):
     report('pyramid16 batch rstd', rs.cpu(), (var_ref + 1e-5).rsqrt(), 0.0, 4 * eps)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(2, 16, 24, True, True), (1, 7, 9, False, True), (3, 5, 13, True, False)])
+@pytest.mark.parametrize('Co', [64, 256])
+def test_pointwise_conv_from_64_channels_on_16bit_storage(case, dtype, Co):
+    """dbn_pw16_act_t (round 5): nn.Conv2d(64, 64 | 256, 1) + bias + ReLU on bf16 / fp16 storage — the FPN lateral on c2 in inference
+    (segmentation_body.py:46,68 with the eval-mode BatchNorm folded, basic.py:32-36) on csrc/convt16.hip's kernel.  Reference: fp64 on the
+    operands as stored; the only error left is the output rounding.  Ragged last block (N * H * W not a multiple of 32)."""
+    N, H, W, with_bias, relu = case
+    at = AT_OF[dtype]
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    rq = lambda t: t.to(dtype).double()
+    assert L().dbn_pw16_eligible(at, N, H, W, 64, Co) == 1 and L().dbn_pw16_eligible(at, N, H, W, 128, Co) == 0
+    assert L().dbn_pw16_eligible(at, N, H, W, 64, 128) == 0
+    x = rnd(N, 64, H, W, seed=1)
+    w = rnd(Co, 64, 1, 1, seed=2, scale=0.2)
+    b = rnd(Co, seed=3)
+    ref = F.conv2d(rq(x), rq(w), b.double() if with_bias else None)
+    if relu:
+        ref = ref.clamp_min(0)
+    panel = torch.empty(L().dbn_pw16_panel_bytes(), device=DEV, dtype=torch.uint8)
+    wd, bd = w.to(DEV), b.to(DEV)
+    _lib.check(L().dbn_pw16_pack(at, wd.data_ptr(), Co, panel.data_ptr(), stream()), 'pw16_pack')
+    xs = nhwc(x).to(dtype)
+    y = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+    _lib.check(L().dbn_pw16_act_t(at, xs.data_ptr(), panel.data_ptr(), bd.data_ptr() if with_bias else None, int(relu), y.data_ptr(), N, H, W,
+                                  Co, stream()), 'pw16')
+    report('pointwise 64->%d %s %s' % (Co, case, dtype), nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+    # the generic launch on the same operands: identical products, fp32 accumulation in a different order
+    y2 = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+    _lib.check(L().dbn_igemm_act_t(at, 1, xs.data_ptr(), pack_t(w, 0, 1, at, 64).data_ptr(), bd.data_ptr() if with_bias else None, None, int(relu),
+                                   y2.data_ptr(), N, H, W, 64, H, W, Co, 1, 1, 1, 0, 0, 0, stream()), 'igemm_act')
+    report('pointwise vs generic launch', y.float().cpu(), y2.float().cpu(), eps * float(ref.abs().max()), eps)
+
+
 def test_stem_conv_on_16_channel_bf16_input():
     """The 16-bit path stores the model input with 16 channels (3 real): nchw3_to_nhwc4_t + the 7x7 stride-2 stem conv."""
     N, H, W = 2, 40, 48
