@@ -490,44 +490,61 @@ __device__ __forceinline__ float round_to_storage(float v) {
 // bn_part (optional, needs 256 % (C/4) == 0 so that a thread keeps its channel quad): per-block partial sums of the two
 // reductions of the BatchNorm backward that consumes dz — sum(dz) and sum(dz * xhat) per channel, [2*C][gridDim.x] — so that
 // the stem's BatchNorm backward does not re-read y and dz (2 x 420 MB at bs16) to form them.
-template <int AT>
+template <int AT, int QW>
 __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
                                           const void* __restrict__ pooled, const void* __restrict__ dpool,
                                           void* __restrict__ dz, int N, int H, int W, int C, int Ho, int Wo,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ bn_part) {
-    // One thread: the channel quad of a 2x2 block of input pixels (rows 2a, 2a+1, columns 2b, 2b+1).  The four pixels lie in the
-    // windows (a..a+1) x (b..b+1) only, so 4 loads of the pooled maxima and 4 of their gradients serve all four (a thread per
-    // pixel read 9 + 9: FETCH_SIZE 1.43x the tensors).
-    const int c4n = C >> 2;
+    // One thread: QW channel quads (QW = 2: 16-bit storage, eight channels = one 16-byte access; round 5) of a 2x2 block of input pixels
+    // (rows 2a, 2a+1, columns 2b, 2b+1).  The four pixels lie in the windows (a..a+1) x (b..b+1) only, so 4 loads of the pooled maxima
+    // and 4 of their gradients serve all four (a thread per pixel read 9 + 9: FETCH_SIZE 1.43x the tensors).
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
     const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
-    const long total = (long)N * Hb * Wb * c4n;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, mu = s1, rs = s1;
-    const int cq0 = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % c4n) * 4;  // constant per thread (256 % (C/4) == 0, host side)
-    if (bn_part) {
-        mu = *reinterpret_cast<const f32x4*>(mean + cq0);
-        rs = *reinterpret_cast<const f32x4*>(rstd + cq0);
+    const long total = (long)N * Hb * Wb * cin;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1[QW], s2[QW], mu[QW], rs[QW];
+    const int cq0 = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % cin) * 4 * QW;  // constant per thread (256 % cin == 0, host side)
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+        s1[q] = s2[q] = mu[q] = rs[q] = zero;
+        if (bn_part) {
+            mu[q] = *reinterpret_cast<const f32x4*>(mean + cq0 + 4 * q);
+            rs[q] = *reinterpret_cast<const f32x4*>(rstd + cq0 + 4 * q);
+        }
     }
+    auto ld = [&](const void* ptr, long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(ptr, i);
+        else dbn_ldq<AT>(ptr, i, v);
+    };
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % c4n);
-        long t = i / c4n;
+        const int ci = (int)(i % cin);
+        long t = i / cin;
         const int b = (int)(t % Wb);
         t /= Wb;
         const int a = (int)(t % Hb);
         const int n = (int)(t / Hb);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + 4 * c4);
-        const f32x4 h = *reinterpret_cast<const f32x4*>(sh + 4 * c4);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s[QW], h[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            s[q] = *reinterpret_cast<const f32x4*>(sc + 4 * (QW * ci + q));
+            h[q] = *reinterpret_cast<const f32x4*>(sh + 4 * (QW * ci + q));
+        }
         // windows (a + u, b + w), u, w in {0, 1}
-        f32x4 pm[2][2], dp[2][2];
+        f32x4 pm[2][2][QW], dp[2][2][QW];
         bool wok[2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 wok[u][w] = a + u < Ho && b + w < Wo;
-                const long o = (((long)n * Ho + a + u) * Wo + b + w) * c4n + c4;
-                pm[u][w] = wok[u][w] ? dbn_ld4<AT>(pooled, o) : zero;
-                dp[u][w] = wok[u][w] ? dbn_ld4<AT>(dpool, o) : zero;
+                const long o = (((long)n * Ho + a + u) * Wo + b + w) * cin + ci;
+#pragma unroll
+                for (int q = 0; q < QW; ++q) pm[u][w][q] = dp[u][w][q] = zero;
+                if (wok[u][w]) {
+                    ld(pooled, o, pm[u][w]);
+                    ld(dpool, o, dp[u][w]);
+                }
             }
 #pragma unroll
         for (int dy_ = 0; dy_ < 2; ++dy_)
@@ -535,41 +552,53 @@ __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const floa
             for (int dx_ = 0; dx_ < 2; ++dx_) {
                 const int ih = 2 * a + dy_, iw = 2 * b + dx_;
                 if (ih >= H || iw >= W) continue;
-                const long pi = (((long)n * H + ih) * W + iw) * c4n + c4;
-                const f32x4 v = dbn_ld4<AT>(y, pi);
-                f32x4 z, g = zero;
+                const long pi = (((long)n * H + ih) * W + iw) * cin + ci;
+                f32x4 v[QW], g[QW];
+                ld(y, pi, v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) z[e] = round_to_storage<AT>(dbn_affine_relu(v[e], s[e], h[e]));
-                // pixel row 2a lies in window row a only, row 2a+1 in rows a and a+1 (same for columns)
+                for (int q = 0; q < QW; ++q) {
+                    f32x4 z;
+                    g[q] = zero;
 #pragma unroll
-                for (int u = 0; u <= dy_; ++u)
+                    for (int e = 0; e < 4; ++e) z[e] = round_to_storage<AT>(dbn_affine_relu(v[q][e], s[q][e], h[q][e]));
+                    // pixel row 2a lies in window row a only, row 2a+1 in rows a and a+1 (same for columns)
 #pragma unroll
-                    for (int w = 0; w <= dx_; ++w) {
-                        if (!wok[u][w]) continue;
+                    for (int u = 0; u <= dy_; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (z[e] > 0.f && z[e] == pm[u][w][e]) g[e] += dp[u][w][e];
-                    }
-                dbn_st4<AT>(dz, pi, g);
+                        for (int w = 0; w <= dx_; ++w) {
+                            if (!wok[u][w]) continue;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (z[e] > 0.f && z[e] == pm[u][w][q][e]) g[q][e] += dp[u][w][q][e];
+                        }
+                }
+                if constexpr (QW == 1) dbn_st4<AT>(dz, pi, g[0]);
+                else dbn_stq<AT>(dz, pi, g);
                 if (bn_part) {
-                    f32x4 gr = g;  // the BatchNorm backward reads the STORED gradient
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) gr[e] = round_to_storage<AT>(g[e]);
-                    s1 += gr;
-                    s2 += gr * ((v - mu) * rs);
+                    for (int q = 0; q < QW; ++q) {
+                        f32x4 gr = g[q];  // the BatchNorm backward reads the STORED gradient
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gr[e] = round_to_storage<AT>(g[q][e]);
+                        s1[q] += gr;
+                        s2[q] += gr * ((v[q] - mu[q]) * rs[q]);
+                    }
                 }
             }
     }
-    if (bn_part) {  // threads t, t + C/4, ... of the block hold the same channel quad
-        __shared__ f32x4 red[2][256];
-        red[0][threadIdx.x] = s1;
-        red[1][threadIdx.x] = s2;
+    if (bn_part) {  // threads t, t + cin, ... of the block hold the same channels
+        __shared__ f32x4 red[2][QW][256];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            red[0][q][threadIdx.x] = s1[q];
+            red[1][q][threadIdx.x] = s2[q];
+        }
         __syncthreads();
-        if ((int)threadIdx.x < 2 * c4n) {
-            const int which = threadIdx.x / c4n, t0 = threadIdx.x - which * c4n;
+        if ((int)threadIdx.x < 2 * cin * QW) {
+            const int which = threadIdx.x / (cin * QW), r_ = threadIdx.x - which * cin * QW, t0 = r_ / QW, q = r_ - t0 * QW;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            for (int k = t0; k < 256; k += c4n) t += red[which][k];
-            const int cq = (int)((blockIdx.x * (long)blockDim.x + t0) % c4n) * 4;
+            for (int k = t0; k < 256; k += cin) t += red[which][q][k];
+            const int cq = (int)((blockIdx.x * (long)blockDim.x + t0) % cin) * 4 * QW + 4 * q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) bn_part[((long)which * C + cq + e) * gridDim.x + blockIdx.x] = t[e];
         }
@@ -1077,7 +1106,19 @@ int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const fl
     DBN_REQUIRE((bn_part == nullptr) == (bn_mean == nullptr) && (bn_part == nullptr) == (bn_rstd == nullptr));
     DBN_REQUIRE(!bn_part || 256 % (C / 4) == 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(bnrelu_maxpool_bwd_kernel<AT>, dim3(dbn_maxpool_bwd_parts(N, H, W, C)), dim3(256), 0,
+    // (the grid — and with it the number of partial rows the caller sized bn_part for, dbn_maxpool_bwd_parts — is the same for both forms;
+    // the 16-byte form just walks half as many items)
+    if ((at == 1 || at == 2) && C % 8 == 0) {
+        const dim3 grid(dbn_maxpool_bwd_parts(N, H, W, C));
+        if (at == 1)
+            hipLaunchKernelGGL((bnrelu_maxpool_bwd_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W,
+                               C, Ho, Wo, bn_mean, bn_rstd, bn_part);
+        else
+            hipLaunchKernelGGL((bnrelu_maxpool_bwd_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W,
+                               C, Ho, Wo, bn_mean, bn_rstd, bn_part);
+        return dbn_status();
+    }
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL((bnrelu_maxpool_bwd_kernel<AT, 1>), dim3(dbn_maxpool_bwd_parts(N, H, W, C)), dim3(256), 0,
                                            (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W, C, Ho, Wo, bn_mean, bn_rstd,
                                            bn_part));
     return dbn_status();
