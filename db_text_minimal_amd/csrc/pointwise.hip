@@ -615,22 +615,37 @@ __device__ __forceinline__ int nearest_src(int d, int in, int out) {
 }
 
 // dst[n,h,w,coff+c] = src[n,nh,nw,c] (+ addend[n,h,w,c])
-template <int AT>
+template <int AT, int QW>
 __global__ void nearest_up_fwd_kernel(const void* __restrict__ src, const void* __restrict__ addend, void* __restrict__ dst,
                                       int N, int Hs, int Ws, int C, int H, int W, int Cdst, int coff) {
-    const int c4n = C >> 2;
-    const long total = (long)N * H * W * c4n;
+    // QW = 2 (16-bit storage, C, Cdst, coff multiples of 8; round 5): eight channels per 16-byte access
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
+    const long total = (long)N * H * W * cin;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        long t = i / c4n;
+        const int c = (int)(i % cin) * 4 * QW;
+        long t = i / cin;
         const int w = (int)(t % W);
         t /= W;
         const int h = (int)(t % H);
         const int n = (int)(t / H);
         const int sh_ = nearest_src(h, Hs, H), sw_ = nearest_src(w, Ws, W);
-        f32x4 v = dbn_ld4<AT>(src, ((((long)n * Hs + sh_) * Ws + sw_) * C + c) >> 2);
-        if (addend) v += dbn_ld4<AT>(addend, ((((long)n * H + h) * W + w) * C + c) >> 2);
-        dbn_st4<AT>(dst, ((((long)n * H + h) * W + w) * Cdst + coff + c) >> 2, v);
+        const long is = ((((long)n * Hs + sh_) * Ws + sw_) * C + c) / (4 * QW), ia = ((((long)n * H + h) * W + w) * C + c) / (4 * QW);
+        const long id = ((((long)n * H + h) * W + w) * Cdst + coff + c) / (4 * QW);
+        if constexpr (QW == 1) {
+            f32x4 v = dbn_ld4<AT>(src, is);
+            if (addend) v += dbn_ld4<AT>(addend, ia);
+            dbn_st4<AT>(dst, id, v);
+        } else {
+            f32x4 v[QW], a[QW];
+            dbn_ldq<AT>(src, is, v);
+            if (addend) {
+                dbn_ldq<AT>(addend, ia, a);
+#pragma unroll
+                for (int q = 0; q < QW; ++q) v[q] += a[q];
+            }
+            dbn_stq<AT>(dst, id, v);
+        }
     }
 }
 
@@ -1132,7 +1147,15 @@ int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst,
                          int coff, void* stream) {
     DBN_REQUIRE(src && dst && C % 4 == 0 && Cdst % 4 == 0 && coff % 4 == 0 && coff + C <= Cdst);
     DBN_REQUIRE(addend == nullptr || (Cdst == C && coff == 0));
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nearest_up_fwd_kernel<AT>, dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0,
+    if ((at == 1 || at == 2) && C % 8 == 0 && Cdst % 8 == 0 && coff % 8 == 0) {
+        const dim3 grid(dbn_grid((long)N * H * W * (C / 8)));
+        if (at == 1)
+            hipLaunchKernelGGL((nearest_up_fwd_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, src, addend, dst, N, Hs, Ws, C, H, W, Cdst, coff);
+        else
+            hipLaunchKernelGGL((nearest_up_fwd_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, src, addend, dst, N, Hs, Ws, C, H, W, Cdst, coff);
+        return dbn_status();
+    }
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL((nearest_up_fwd_kernel<AT, 1>), dim3(dbn_grid((long)N * H * W * (C / 4))), dim3(256), 0,
                                            (hipStream_t)stream, src, addend, dst, N, Hs, Ws, C, H, W, Cdst, coff));
     return dbn_status();
 }

@@ -43,7 +43,14 @@ if [ -f db_text_minimal_amd/libdbnet_hip_trace.so ]; then
 fi
 { python3 tools/cfg_timing.py resnet50 8 800 f32 10; python3 tools/cfg_timing.py resnet50 8 800 bf16 10;
   python3 tools/cfg_timing.py deformable_resnet50 8 800 f32 10; python3 tools/cfg_timing.py deformable_resnet50 8 800 bf16 10;
+  DBN_TIMING_LR=0.0002 python3 tools/cfg_timing.py deformable_resnet50 8 800 f32 10; DBN_TIMING_LR=0.0002 python3 tools/cfg_timing.py deformable_resnet50 8 800 bf16 10;
   python3 tools/cfg_timing.py resnet18 32 1280 fp16 10 eval; DBN_FOLD_EVAL_BN=0 python3 tools/cfg_timing.py resnet18 32 1280 fp16 10 eval;
   python3 tools/cfg_timing.py resnet18 16 640 f32 10 eval; DBN_FOLD_EVAL_BN=0 python3 tools/cfg_timing.py resnet18 16 640 f32 10 eval; } 2>/dev/null | grep -v amdgpu > $O/other_configs.txt
-rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3   # the DBs are large; the summaries above are what is kept
+cd /tmp   # the inference configuration (BASELINE configs[4]) kernel by kernel
+rocprofv3 --kernel-trace -d $O/trace_eval -o r01 -- python3 $R/tools/cfg_timing.py resnet18 32 1280 fp16 10 eval > $O/eval_fp16.log 2>&1
+cd $R
+python3 tools/rocpd_stats.py $O/trace_eval/r01_results.db $O/kernel_stats_eval_fp16.md > /dev/null
+python3 tools/dump_step.py $O/trace/r01_results.db 6 > $O/step_dump.txt 2>&1
+python3 tools/dump_step.py $O/trace_bf16/r01_results.db 6 > $O/step_dump_bf16.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3 $O/trace_eval   # the DBs are large; the summaries above are what is kept
 ls -la $O
