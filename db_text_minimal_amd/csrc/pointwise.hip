@@ -1123,7 +1123,10 @@ int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const fl
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     // (the grid — and with it the number of partial rows the caller sized bn_part for, dbn_maxpool_bwd_parts — is the same for both forms;
     // the 16-byte form just walks half as many items)
-    if ((at == 1 || at == 2) && C % 8 == 0) {
+#ifndef DBN_POOL_BWD_QW2
+#define DBN_POOL_BWD_QW2 0  // the 16-byte form of the BACKWARD measured slower (its 2 x 2 x 2 window arrays double: bf16 step 1663 / 1671 / 1662 / 1665 images/s with the four-channel form, 1636 / 1632 / 1639 / 1631 with this one, interleaved on one box): off
+#endif
+    if (DBN_POOL_BWD_QW2 && (at == 1 || at == 2) && C % 8 == 0) {
         const dim3 grid(dbn_maxpool_bwd_parts(N, H, W, C));
         if (at == 1)
             hipLaunchKernelGGL((bnrelu_maxpool_bwd_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, pooled, dpool, dz, N, H, W,

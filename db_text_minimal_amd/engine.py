@@ -1499,6 +1499,7 @@ class Engine:
         vconv, ver2 = self._cols_conv(name + '.conv2', conv)
         return self.conv_bn(name + '.conv2', cols, vconv, out_name, bn_name, bn, train, version=ver2)
 
+    flush_before_pool = os.environ.get('DBN_FLUSH_BEFORE_POOL', '1') == '1'
     dcn_gather = os.environ.get('DBN_DCN_GATHER', '1') == '1'  # the sampling adjoint as a gather (0: round 3's fixed-point scatter)
     dcn_gather_max_offset = float(os.environ.get('DBN_DCN_GATHER_MAX_OFFSET', '16'))  # ... while the previous step's max |offset| of the layer is below this
     _dcn_table = _dcn_host = _dcn_event = None
@@ -1827,7 +1828,8 @@ class Engine:
                     self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
         dz = self.buf('stem/dz', *y0.shape)
-        self._flush_wgrads()  # (late order: layer1's last weight gradient starts beside the max-pool backward, not behind it — round-5 trace: it had waited 218 us)
+        if self.flush_before_pool:
+            self._flush_wgrads()  # (late order: layer1's last weight gradient starts beside the max-pool backward, not behind it — round-5 trace: it had waited 218 us)
         # the max-pool backward also emits the partial sums of the stem BatchNorm's backward (it has y and dz in registers)
         nparts = L.dbn_maxpool_bwd_parts(N, y0.shape[1], y0.shape[2], 64)
         parts = self.scratch('_stem_bn_parts', 2 * 64 * nparts)
