@@ -135,6 +135,7 @@ SIGNATURES.update({
     'dbn_pw16_panel_bytes': '',
     'dbn_pw16_pack': 'ipipp',
     'dbn_pw16_act_t': 'ipppipiiiip',
+    'dbn_set_head_tail_wide': 'i',
     'dbn_cast_f32': 'ipplp',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
                                      const float* __restrict__ sh_t, float* __restrict__ out, int N, int Hq, int Wq, int CH,
                                      float kstep, long per) {
-    static_assert((LPP == 16) || (LPP == 8 && AT != 0), "eight lanes per pixel: 16-bit storage");
+    static_assert((LPP == 16) || (LPP == 8 && AT != 0), "eight lanes per pixel: 16-bit storage");  // (LPP = 16 serves every storage type)
     constexpr int NQ = 16 / LPP;  // channel quads per lane
     const int q = threadIdx.x & (LPP - 1);
     // optional fused BatchNorm + ReLU of the inputs (xb/xt are then the pre-BN conv outputs): this lane's channels
@@ -799,6 +799,12 @@ __global__ void pixel_confusion_kernel(const float* __restrict__ preds, long bat
 extern "C" {
 
 // xb/xt are stored in the activation type `at`; the maps `out` are always fp32 (what DBLoss and postprocess.py consume)
+static int g_head_tail_wide = 0;  // 0: by size (see dbn_head_tail_fwd_t); 1 / -1: always / never the eight-lane form on 16-bit storage (test hook)
+int dbn_set_head_tail_wide(int mode) {
+    const int old = g_head_tail_wide;
+    g_head_tail_wide = mode > 0 ? 1 : mode < 0 ? -1 : 0;
+    return old;
+}
 int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* bias_b,
                         const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
                         const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream) {
@@ -807,11 +813,20 @@ int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb,
     const long npx = (long)N * Hq * Wq;
     const long per = ((npx + 16383) / 16384 + 63) / 64 * 64;  // pixels per block
     const dim3 grid((unsigned)((npx + per - 1) / per));
-    if (at == 1)
+    // 16-bit storage: eight lanes x eight channels per pixel (16-byte loads) on LARGE maps only — measured: 32 x 640^2 quarter pixels (cfg5)
+    // 1015 -> 952 us, but 16 x 320^2 (the bf16 train step) 132 -> 155 us (twice the registers, short runs per block)
+    const bool wide = (at == 1 || at == 2) && (g_head_tail_wide > 0 || (g_head_tail_wide == 0 && npx >= (1L << 22)));
+    if (wide && at == 1)
         hipLaunchKernelGGL((head_tail_fwd_kernel<1, 8>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
                            bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
-    else if (at == 2)
+    else if (wide && at == 2)
         hipLaunchKernelGGL((head_tail_fwd_kernel<2, 8>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
+                           bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
+    else if (at == 1)
+        hipLaunchKernelGGL((head_tail_fwd_kernel<1, 16>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
+                           bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
+    else if (at == 2)
+        hipLaunchKernelGGL((head_tail_fwd_kernel<2, 16>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,
                            bn_shift_b, bn_scale_t, bn_shift_t, out, N, Hq, Wq, channels, kstep, per);
     else if (at == 0)
         hipLaunchKernelGGL((head_tail_fwd_kernel<0, 16>), grid, dim3(256), 0, (hipStream_t)stream, xb, xt, wb, wt, bias_b, bias_t, bn_scale_b,

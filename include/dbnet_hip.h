@@ -572,6 +572,9 @@ int dbn_nchw3_to_nhwc4_packed_t(int at, const float* x, void* out, int N, int H,
 int dbn_head_tail_fwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* bias_b,
                         const float* bias_t, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
                         const float* bn_shift_t, float* out, int N, int Hq, int Wq, int channels, float kstep, void* stream);
+/* test / A-B hook: the 16-bit forward's lane layout — 0 by size (eight lanes x eight channels per pixel from 2^22 quarter pixels), 1 always,
+ * -1 never; returns the previous setting */
+int dbn_set_head_tail_wide(int mode);
 int dbn_head_tail_bwd_t(int at, const void* xb, const void* xt, const float* wb, const float* wt, const float* preds,
                         const float* dpreds, const float* bn_scale_b, const float* bn_shift_b, const float* bn_scale_t,
                         const float* bn_shift_t, const float* bn_mean_b, const float* bn_rstd_b, const float* bn_mean_t,

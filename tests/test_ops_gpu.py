@@ -908,6 +908,47 @@ def test_head_tail_with_fused_batchnorm_relu():
     report('fused head bwd dwt', dwt.cpu().view(64, 1, 2, 2), grads[4], 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('ch', [2, 3])
+def test_head_tail_forward_lane_layouts_on_16bit_storage(dtype, ch):
+    """dbn_head_tail_fwd_t on bf16 / fp16 inputs (segmentation_head.py:27-29,35-45,74-79 with the BatchNorm + ReLU of the ConvT outputs applied
+    on load): the eight-lanes-per-pixel form that large maps take (round 5, 16-byte loads) against the sixteen-lane form and against fp64 on
+    the inputs as stored."""
+    N, Hq, Wq = 2, 11, 13
+    at = AT_OF[dtype]
+    rq = lambda t: t.to(dtype).double()
+    yb, yt = rnd(N, 64, Hq, Wq, seed=1), rnd(N, 64, Hq, Wq, seed=2)
+    sc = [rnd(64, seed=10 + i) * 0.3 + 1 for i in range(2)]
+    sh = [rnd(64, seed=20 + i) * 0.5 for i in range(2)]
+    zb = torch.relu(rq(yb) * sc[0].double().view(1, 64, 1, 1) + sh[0].double().view(1, 64, 1, 1))
+    zt = torch.relu(rq(yt) * sc[1].double().view(1, 64, 1, 1) + sh[1].double().view(1, 64, 1, 1))
+    wb, wt = rnd(64, 1, 2, 2, seed=3, scale=0.2), rnd(64, 1, 2, 2, seed=4, scale=0.2)
+    bb, bt = torch.tensor([0.1]), torch.tensor([-0.2])
+    P = torch.sigmoid(F.conv_transpose2d(zb, wb.double(), bb.double(), 2))
+    T = torch.sigmoid(F.conv_transpose2d(zt, wt.double(), bt.double(), 2))
+    ref = torch.cat([P, T] + ([torch.reciprocal(1 + torch.exp(-50 * (P - T)))] if ch == 3 else []), 1)
+    d = lambda t: t.contiguous().to(DEV)
+    ybs, yts = nhwc(yb).to(dtype), nhwc(yt).to(dtype)
+    args = [d(wb), d(wt), d(bb), d(bt), d(sc[0]), d(sh[0]), d(sc[1]), d(sh[1])]
+    outs = []
+    old = L().dbn_set_head_tail_wide(0)
+    try:
+        for mode in (-1, 1):
+            L().dbn_set_head_tail_wide(mode)
+            out = torch.full(ref.shape, float('nan'), device=DEV)
+            _lib.check(L().dbn_head_tail_fwd_t(at, ybs.data_ptr(), yts.data_ptr(), *[t.data_ptr() for t in args], out.data_ptr(), N, Hq, Wq, ch,
+                                               50.0, stream()), 'head fwd')
+            outs.append(out.cpu())
+    finally:
+        L().dbn_set_head_tail_wide(old)
+    # (the step function's slope of 50 amplifies the fp32 rounding of the two logits: the binary map gets the wider bound)
+    for i, name in enumerate(('sixteen lanes', 'eight lanes')):
+        report('head tail fwd %s %s P, T' % (name, dtype), outs[i][:, :2], ref[:, :2], 2e-6, 1e-5)
+        if ch == 3:
+            report('head tail fwd %s %s B' % (name, dtype), outs[i][:, 2:], ref[:, 2:], 1e-4, 1e-4)
+    report('eight lanes vs sixteen', outs[1][:, :2], outs[0][:, :2], 1e-6, 1e-6)
+
+
 @pytest.mark.parametrize('ns', [0, 3])
 def test_batched_weight_pack_equals_single_packs(ns):
     """dbn_pack_weights_batched (one launch, device job table) produces exactly the panels of the per-weight
