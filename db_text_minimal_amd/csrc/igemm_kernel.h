@@ -134,7 +134,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // taps) ahead — no weight ring, and the only barriers left are the two around a patch refill (one channel block = 18 units
     // between them).  Measured (interleaved A/B on one box): bf16x3 714 -> 732 images/s; the single-plane kernels (bf16 storage,
     // two patch buffers, ten barriers per block that also pace the ring) lose with it: 1644 -> 1620 — they keep the ring.
-    constexpr bool DBP = DBN_DIRECTBP && PATCH && NS == 3;
+#ifndef DBN_DBP_NS1
+#define DBN_DBP_NS1 0  // 1: the single-plane (bf16 / fp16) pixel-patch kernels too (A/B build; round 5 again: cfg5 14.22 / 14.20 vs 14.21 / 14.23 ms, bf16 step 1677 / 1677 vs 1662 / 1652 images/s: the ring stays)
+#endif
+    constexpr bool DBP = DBN_DIRECTBP && PATCH && (NS == 3 || (DBN_DBP_NS1 && NS == 1));
     constexpr int LOOP_SMEM = PATCH ? P_NBUF * P_PATCH + ((DBP || NS == 0) ? 0 : P_NSTG * P_BSTAGE) : AT != 0 ? DMA_NSTG * DMA_STAGE : 2 * STAGE;
     constexpr int EPI_SMEM = (EPI == 1 && DST_F32) ? BM * BN / (4 * (MI >= 2 ? 2 : 1)) : 0;
     // (16-bit destinations: the output tile is staged through LDS, BM rows of BN + 8 elements)
