@@ -309,6 +309,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // + 44 vector instructions per block instead of 32 + 96 — 3-8 % SLOWER: one long vector phase per block overlaps the other
             // resident wave's MFMAs worse than four short ones; issuing the next point's LDS reads ahead of the current point's MFMAs:
             // neutral, and its 32 registers are better spent on the weight fragments' prefetch distance.)
+#ifndef DBN_WINO_ROWCOMB
+#define DBN_WINO_ROWCOMB 1  // round 5: V through the shared row combinations r_c = d[a1][c] + sa * d[a2][c], formed lazily (see below)
+#endif
+            constexpr bool RC = DBN_WINO_ROWCOMB && !DBN_WX_NOXFORM && !LIN;  // (the LIN form has no registers for it: 51 spilled dwords)
+            // The wave's four points (i, 0..3) take the SAME two patch rows (a1, a2) and differ in the column pair only: with
+            //   r_c = d[a1][c] + sa * d[a2][c]   (c = 0..3),   V_0 = r_0 - r_2,  V_1 = r_1 + r_2,  V_2 = r_2 - r_1,  V_3 = r_1 - r_3
+            // a channel block needs 16 LDS reads and 64 vector instructions instead of 32 and 96.  Round 4 had tried this with all four V formed
+            // at the start of the block (one long vector phase: 3-8 % slower); here each r_c is formed in front of the first point that needs it
+            // (point 0: r_0, r_2 — 8 reads, 24 vector instructions as before; point 1: r_1 — 4 + 16; point 2: nothing to read, 8; point 3: r_3 —
+            // 4 + 16), so the phases only get shorter.  Rounding: fma(sa, d2, d1) then +-, where the old form took +- first: equally exact
+            // (sa = +-1), a different last bit.
+            f32x4 rc[RC ? 4 : 1][2];
+            auto form_r = [&](auto C) {
+                constexpr int c = RC ? decltype(C)::value : 0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f32x4 x1 = P[s2 * ppx2 + row1 + c], x2 = P[s2 * ppx2 + row2 + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rc[c][s2][e] = fmaf(sa, x2[e], x1[e]);  // (sa = +-1: exact)
+                }
+            };
             auto point = [&](auto J, auto FIRST) {
                 constexpr int j = decltype(J)::value;
                 constexpr bool first = decltype(FIRST)::value;  // channel block 0: the accumulators start here
@@ -325,13 +346,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 v[1] = f32x4{4.f, (float)li, 6.f, 7.f};
                 asm volatile("" : "+v"(v[0]), "+v"(v[1]));
 #else
+                if constexpr (RC) {
+                    if constexpr (j == 0) {
+                        form_r(std::integral_constant<int, 0>{});
+                        form_r(std::integral_constant<int, 2>{});
+                    } else if constexpr (j == 1) {
+                        form_r(std::integral_constant<int, 1>{});
+                    } else if constexpr (j == 3) {
+                        form_r(std::integral_constant<int, 3>{});
+                    }
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const f32x4 x11 = P[s2 * ppx2 + row1 + b1], x12 = P[s2 * ppx2 + row1 + b2];
-                    const f32x4 x21 = P[s2 * ppx2 + row2 + b1], x22 = P[s2 * ppx2 + row2 + b2];
-                    const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
+                    for (int s2 = 0; s2 < 2; ++s2) v[s2] = plus ? rc[RC ? b1 : 0][s2] + rc[RC ? b2 : 0][s2] : rc[RC ? b1 : 0][s2] - rc[RC ? b2 : 0][s2];
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const f32x4 x11 = P[s2 * ppx2 + row1 + b1], x12 = P[s2 * ppx2 + row1 + b2];
+                        const f32x4 x21 = P[s2 * ppx2 + row2 + b1], x22 = P[s2 * ppx2 + row2 + b2];
+                        const f32x4 t1 = plus ? x11 + x12 : x11 - x12, t2 = plus ? x21 + x22 : x21 - x22;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[s2][e] = fmaf(sa, t2[e], t1[e]);  // (sa = +-1: exact)
+                    }
                 }
 #endif
                 // (DBN_WINO_BATCH: the point's 24 vector instructions fenced into ONE batch in front of its 16 MFMAs — a vector instruction
