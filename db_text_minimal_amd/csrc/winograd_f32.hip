@@ -25,6 +25,12 @@
 #ifndef DBN_WINO_EXP
 #define DBN_WINO_EXP 0
 #endif
+#ifndef DBN_WINO_PAIR12
+#define DBN_WINO_PAIR12 0  // (measured neutral: 64->64 176.7 vs 176.0 us, 256->64 549 vs 550, step 728.7 / 729.0 vs 728.3 / 727.2 images/s interleaved: off) round 5: points 1 and 2 (both V_1 = r_1 + r_2 and V_2 = r_2 - r_1 come from the same two row combinations) as ONE phase: 32 MFMAs over FOUR accumulator chains instead of twice 16 over two (profiles/r03_mfma_peak_probe.txt: 0.93 -> 0.99 of the pipe)
+#endif
+#ifndef DBN_WINO_ROWCOMB
+#define DBN_WINO_ROWCOMB 1  // round 5: V through the shared row combinations r_c = d[a1][c] + sa * d[a2][c], formed lazily (see below)
+#endif
 // timing experiments (wrong results by construction; tools/winograd_probe.py with DBN_LIB_PATH): 1 weight fragments of the first channel
 // block only, 2 no LDS reads / transform arithmetic in the loop, 3 no exchange / statistics in the epilogue, 5 no patch store / barrier
 // in the loop, 6 = 3 + 5, 7 = 2 + 3 + 5 (what is left: prologue, MFMAs, weight loads, plain stores), 8 = 7 + 1 (... without the weight loads)
@@ -282,6 +288,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         load_patch(0, 0);
         issue_w(std::integral_constant<int, 0>{});
         issue_w(std::integral_constant<int, 1>{});
+        if constexpr (DBN_WINO_ROWCOMB && DBN_WINO_PAIR12 && !(DBN_WINO_EXP == 2 || DBN_WINO_EXP == 7 || DBN_WINO_EXP == 8) && !LIN)
+            issue_w(std::integral_constant<int, 2>{});  // (paired order: points 1 and 2 start together)
         store_patch(0, 0, 0);
         if constexpr (CBS == 2) {
             load_patch(0, 1);
@@ -309,10 +317,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // + 44 vector instructions per block instead of 32 + 96 — 3-8 % SLOWER: one long vector phase per block overlaps the other
             // resident wave's MFMAs worse than four short ones; issuing the next point's LDS reads ahead of the current point's MFMAs:
             // neutral, and its 32 registers are better spent on the weight fragments' prefetch distance.)
-#ifndef DBN_WINO_ROWCOMB
-#define DBN_WINO_ROWCOMB 1  // round 5: V through the shared row combinations r_c = d[a1][c] + sa * d[a2][c], formed lazily (see below)
-#endif
             constexpr bool RC = DBN_WINO_ROWCOMB && !DBN_WX_NOXFORM && !LIN;  // (the LIN form has no registers for it: 51 spilled dwords)
+            constexpr bool PAIRED = RC && DBN_WINO_PAIR12;
             // The wave's four points (i, 0..3) take the SAME two patch rows (a1, a2) and differ in the column pair only: with
             //   r_c = d[a1][c] + sa * d[a2][c]   (c = 0..3),   V_0 = r_0 - r_2,  V_1 = r_1 + r_2,  V_2 = r_2 - r_1,  V_3 = r_1 - r_3
             // a channel block needs 16 LDS reads and 64 vector instructions instead of 32 and 96.  Round 4 had tried this with all four V formed
@@ -333,7 +339,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             auto point = [&](auto J, auto FIRST) {
                 constexpr int j = decltype(J)::value;
                 constexpr bool first = decltype(FIRST)::value;  // channel block 0: the accumulators start here
-                issue_w(std::integral_constant<int, (j + 2) & 3>{});  // the weight fragments of the point after the next (set = point index)
+                if constexpr (!PAIRED) {
+                    issue_w(std::integral_constant<int, (j + 2) & 3>{});  // the weight fragments of the point after the next (set = point index)
+                } else if constexpr (j == 3) {  // (paired order, see pair12: sets 1 and 2 of the NEXT block, two phases ahead of its pair)
+                    issue_w(std::integral_constant<int, 1>{});
+                    issue_w(std::integral_constant<int, 2>{});
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 // B^T column j: 0: d0 - d2;  1: d1 + d2;  2: d2 - d1;  3: d1 - d3
                 constexpr int b1 = j == 0 ? 0 : (j == 2 ? 2 : 1), b2 = j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3));
@@ -387,7 +398,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             };
-            if (!LIN && cb == 0) {
+            auto pair12 = [&](auto FIRST) {
+                constexpr bool first = decltype(FIRST)::value;
+                // weight prefetch in the paired order (every set at least two point-times ahead of its use, none rewritten while in use):
+                // here point 3 of this block and point 0 of the next; point 3 then fetches sets 1 and 2 of the next block; the prologue 0, 1, 2
+                issue_w(std::integral_constant<int, 3>{});
+                issue_w(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                form_r(std::integral_constant<int, 1>{});
+                f32x4 v1[2], v2[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    v1[s2] = rc[RC ? 1 : 0][s2] + rc[RC ? 2 : 0][s2];
+                    v2[s2] = rc[RC ? 2 : 0][s2] - rc[RC ? 1 : 0][s2];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[s2][e], rw[1][s2][b][e], (first && s2 == 0 && e == 0) ? zero16 : acc[1][b], 0, 0, 0);
+                            acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[s2][e], rw[2][s2][b][e], (first && s2 == 0 && e == 0) ? zero16 : acc[2][b], 0, 0, 0);
+                        }
+            };
+            if constexpr (PAIRED) {
+                if (cb == 0) {
+                    point(std::integral_constant<int, 0>{}, std::true_type{});
+                    pair12(std::true_type{});
+                    point(std::integral_constant<int, 3>{}, std::true_type{});
+                } else {
+                    point(std::integral_constant<int, 0>{}, std::false_type{});
+                    pair12(std::false_type{});
+                    point(std::integral_constant<int, 3>{}, std::false_type{});
+                }
+            } else if (!LIN && cb == 0) {
                 point(std::integral_constant<int, 0>{}, std::true_type{});
                 point(std::integral_constant<int, 1>{}, std::true_type{});
                 point(std::integral_constant<int, 2>{}, std::true_type{});
