@@ -228,7 +228,7 @@ __global__ void deform_col2im_finish_kernel(const unsigned long long* __restrict
 //   doffset[m][k]  = sum_c dcols[m][k][c] * d(bilinear)/d(y, x)      — a reduction over the channels of ONE sample: a team per (m, k)
 //   dx[n][y][x][c] = sum over the samples (m, k) one of whose four corners is (y, x) of  w_corner * dcols[m][k][c]
 // and WHICH samples can touch input pixel (y, x) is bounded by the largest learned offset: with E = ceil(max |offset|) (a device-side
-// maximum, one small pass over the offset map) only taps whose undeformed position (ho*stride - pad + r, wo*stride - pad + s) lies within
+// maximum, taken by deform_bbox_kernel on its way) only taps whose undeformed position (ho*stride - pad + r, wo*stride - pad + s) lies within
 // E of (y, x) can — (R + 2E)^2 output pixels at stride 1.  A 32-lane team owns an input pixel, in three nested stages: its lanes test 32
 // output pixels of that window at a time against the pixel's BOX (deform_bbox_kernel: the input rows / columns its nine samples touch —
 // one 16-byte load and four comparisons, so a large window, i.e. ONE large offset somewhere in the map, costs (R + 2E)^2 / 32 cheap rounds,
@@ -287,13 +287,21 @@ __global__ __launch_bounds__(256) void deform_doffset_kernel(const void* __restr
 // Per output pixel m: the box of input pixels its R*S samples touch (rows ymin..ymax, columns xmin..xmax; empty: ymin > ymax), from the
 // same float expressions as sample_of — the gather below tests ONE box per output pixel before it looks at that pixel's taps.
 template <int AT>
-__global__ __launch_bounds__(256) void deform_bbox_kernel(const void* __restrict__ offset, int4* __restrict__ bbox, DeformDims d, int M) {
+__global__ __launch_bounds__(256) void deform_bbox_kernel(const void* __restrict__ offset, int4* __restrict__ bbox, DeformDims d, int M,
+                                                          unsigned* __restrict__ maxbits) {
+    // ... and, while every offset passes through a register anyway, max |offset| over the 2*R*S real channels (absmax_kernel's contract:
+    // the bit pattern, 0x7FC00000 as soon as one is not finite) — a separate pass over the 64-channel map cost 15-60 us per layer in the step
     const int RS = d.R * d.S;
+    float om = 0.f;
+    bool bad = false;
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
         int ymin = 1 << 30, ymax = -(1 << 30), xmin = 1 << 30, xmax = -(1 << 30);
         for (int k = 0; k < RS; ++k) {
             int n, ho, wo;
             const Sample sp = sample_of<AT>(d, offset, m, k, n, ho, wo);
+            const float oy = fabsf(dbn_ld1<AT>(offset, (long)m * d.off_stride + 2 * k)), ox = fabsf(dbn_ld1<AT>(offset, (long)m * d.off_stride + 2 * k + 1));
+            bad |= !(oy <= 3.0e38f) | !(ox <= 3.0e38f);  // (fmaxf drops a NaN)
+            om = fmaxf(om, fmaxf(oy, ox));
             if (sp.inside) {
                 ymin = min(ymin, sp.y0);
                 ymax = max(ymax, sp.y0 + 1);
@@ -303,6 +311,10 @@ __global__ __launch_bounds__(256) void deform_bbox_kernel(const void* __restrict
         }
         bbox[m] = int4{ymin, ymax, xmin, xmax};
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmaxf(om, __shfl_xor(om, o, 64));
+    const bool any_bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) atomicMax(maxbits, any_bad ? DEFORM_NONFINITE : __builtin_bit_cast(unsigned, om));  // non-negative floats order like their bit patterns
 }
 
 // NQ: channel quads per lane (C <= 128 * NQ).  The kernel is a chain of dependent loads (box -> offsets -> dcols rows) per pixel, so what
@@ -577,8 +589,7 @@ int dbn_deform_col2im_gather_t(int at, const void* dcols, const void* x, const v
     int4* bbox = reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + 16);
     const int tiles_x = dbn_ceil_div(W, GATHER_TILE_X), tiles_y = dbn_ceil_div(H, GATHER_TILE);
     DBN_DISPATCH_AT(at, {
-        hipLaunchKernelGGL(absmax_kernel<AT>, dim3(dbn_grid(M * off_stride / 4, 256, 2048)), dim3(256), 0, st, offset, M * off_stride / 4, maxbits);
-        hipLaunchKernelGGL(deform_bbox_kernel<AT>, dim3(dbn_grid(M, 256, 4096)), dim3(256), 0, st, offset, bbox, d, (int)M);
+        hipLaunchKernelGGL(deform_bbox_kernel<AT>, dim3(dbn_grid(M, 256, 2048)), dim3(256), 0, st, offset, bbox, d, (int)M, maxbits);
         hipLaunchKernelGGL(deform_doffset_kernel<AT>, dim3(dbn_grid(M * R * S * 32, 256, 1 << 16)), dim3(256), 0, st, dcols, x, offset, doffset,
                            d, M * R * S);
         if (C <= 128)
