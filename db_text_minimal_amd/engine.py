@@ -160,6 +160,7 @@ class Engine:
         self.views = {}
         self.grad_views = {}
         self._dcn_slots, self._dcn_E = {}, {}
+        self.dcn_forms = {'gather': 0, 'scatter': 0}
         self.grad_scale = 1.0
         self._live = None
         self.nbt_pending = {}
@@ -1548,6 +1549,7 @@ class Engine:
             self._dcn_table = torch.zeros(64, dtype=torch.int32, device=x.device)
             self._dcn_host = torch.zeros(64, dtype=torch.int32).pin_memory()
         gather = self.dcn_gather and C <= 512 and slot < 64 and self._dcn_E.get(name, 0.0) <= self.dcn_gather_max_offset
+        self.dcn_forms['gather' if gather else 'scatter'] += 1  # (observability: which adjoint the layers of this engine have taken so far)
         if gather:
             ws = self.scratch('_dcn_gather_ws', self.L.dbn_deform_col2im_gather_ws_bytes(N, Ho, Wo) // 4 + 1)
             check(self.L.dbn_deform_col2im_gather_t(self.at, dcols.data_ptr(), x.data_ptr(), off.data_ptr(), dx.data_ptr(), doff.data_ptr(),

@@ -812,6 +812,43 @@ def test_deformable_backbone_gather_adjoint_equals_the_fixed_point_scatter(math)
     assert worst <= (10 * tol if math == 'bf16' else 20 * tol), worst
 
 
+def test_deformable_adjoint_is_chosen_from_the_previous_steps_offsets():
+    """engine._dcn_read_back / _dcn_send_back: the sampling adjoint of a deformable layer is the gather while the PREVIOUS step's max |offset|
+    of that layer is at most engine.dcn_gather_max_offset, the fixed-point scatter beyond — decided without a synchronisation inside the
+    step, deterministically: two runs agree bit for bit, and the maxima read back equal the offsets the forward pass produced."""
+    seed = 13
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    sd = O.new_state(seed, 'deformable_resnet18')
+    g = torch.Generator().manual_seed(1)
+    names = [k for k in sd if 'conv2_offset' in k]
+    for k in names:  # half of the deformable layers get offsets of tens of pixels, the others stay below one
+        big = (names.index(k) // 2) % 2 == 0
+        sd[k] = torch.randn(sd[k].shape, generator=g) * (0.02 if k.endswith('weight') else (25.0 if big else 0.4))
+    runs = []
+    for _ in range(2):
+        model = make_model(seed, 'deformable_resnet18')
+        model.load_state_dict(sd)
+        model = model.train()
+        eng = model.engine
+        tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=1e-4))
+        tr.step(img.to(DEV), gts.to(DEV))
+        first = dict(eng.dcn_forms)
+        offs = {k[:-len('/offset')]: float(t.float()[..., :18].abs().max()) for k, t in eng.bufs.items() if k.endswith('/offset')}
+        preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+        torch.cuda.synchronize()
+        second = {k: eng.dcn_forms[k] - first[k] for k in first}
+        runs.append((eng.flat_grad.clone(), eng.flat.clone(), preds.clone(), first, second, dict(eng._dcn_E), offs))
+    _, _, _, first, second, seen, offs = runs[0]
+    nl = len(offs)
+    assert nl >= 4 and first == {'gather': nl, 'scatter': 0}, (first, nl)  # nothing is known in the first step: the gather
+    nbig = sum(1 for v in offs.values() if v > model.engine.dcn_gather_max_offset)
+    assert 0 < nbig < nl and second == {'gather': nl - nbig, 'scatter': nbig}, (second, nbig, offs)
+    for name, v in offs.items():  # what the second step read back is the first step's maximum, exactly
+        assert seen[name] == pytest.approx(v, rel=0, abs=0), (name, seen[name], v)
+    for a, b in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('math', ['f32', 'bf16'])
 def test_graph_captured_step_is_bit_identical_to_the_eager_step(math):
     """DBTrainer.use_graph: forward + DBLoss + backward replayed as ONE hipGraph launch (two-stream fork / join captured with it),
