@@ -136,6 +136,8 @@ SIGNATURES.update({
     'dbn_pw16_pack': 'ipipp',
     'dbn_pw16_act_t': 'ipppipiiiip',
     'dbn_set_head_tail_wide': 'i',
+    'dbn_stem16_pool_eligible': 'iiii',
+    'dbn_stem16_conv_bn_relu_pool_t': 'ipppppiiip',
     'dbn_cast_f32': 'ipplp',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,

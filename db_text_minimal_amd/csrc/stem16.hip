@@ -146,6 +146,137 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- inference: stem conv + BatchNorm (running statistics) + ReLU + MaxPool2d(3, 2, 1) in ONE kernel (round 5) -------------------------------
+// /root/reference/src/modules/resnet.py:231-235 in eval mode.  The two-kernel form writes the 64-channel conv output (1.7 GB at 32 x 1280^2
+// fp16) and reads it back for the pool: 0.67 + 0.49 ms of the 14 ms forward, most of it that round trip.  Here a wave owns a strip of 15
+// pooled columns of one image and walks DOWN a chunk of pooled rows: per pooled row it computes the two new conv rows 2py, 2py + 1 (32
+// conv columns 30 seg - 1 .. 30 seg + 30 each: one MFMA row block, 31 of them used), applies relu(acc * scale + shift) on the fp32
+// accumulators, takes the horizontal 3-maxima of the row through its transpose buffer, and combines them with the maxima of conv row 2py - 1
+// kept from the previous pooled row (a chunk's first row computes that one extra).  The post-ReLU values are >= +0, so 16-bit patterns order
+// like unsigned integers and the maxima are packed integer maxima; conv columns / rows outside the map enter as 0 (never the maximum, as
+// in bnrelu_maxpool_fwd_kernel).  Conv output, BatchNorm pass and pool input never touch memory.  Ho must be even.
+struct StemPoolParams {
+    const void* xp;   // [N][Hp][Wp][4] 16-bit, zero border
+    const void* wpk;  // dbn_stem16_pack
+    const float* sc;  // [64] eval-mode BatchNorm scale / shift
+    const float* sh;
+    void* out;        // [N][Hq][Wq][64] 16-bit
+    int N, Ho, Wo, Hp, Wp, Hq, Wq, nseg, nchunk, rpc, ntask;
+    unsigned x_bytes;
+};
+
+constexpr int SP_COLS = 15;  // pooled columns per strip (2 * 15 + 1 = 31 conv columns of the 32-row MFMA block)
+
+template <int AT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem7x7_pool_b16_kernel(const StemPoolParams p) {
+    static_assert(AT == 1 || AT == 2, "16-bit storage");
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
+    constexpr int WAVE_LDS = 32 * ST_PITCH + 2 * 128 * 8;  // transpose buffer + this wave's PREV and HA item vectors (16-bit elements)
+    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    u32x4_ bw[14][2];
+    {
+        const u32x4_* W = reinterpret_cast<const u32x4_*>(p.wpk);
+#pragma unroll
+        for (int t = 0; t < 14; ++t)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bw[t][b] = W[(t * 2 + lh) * 64 + b * 32 + li];
+    }
+    float scv[2], shv[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        scv[b] = p.sc[b * 32 + li];
+        shv[b] = p.sh[b * 32 + li];
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xp), 0, p.x_bytes, 0x00020000);
+    unsigned short* const T = smem + wave * WAVE_LDS;
+    u16x8_* const PREV = reinterpret_cast<u16x8_*>(T + 32 * ST_PITCH);
+    u16x8_* const HA = PREV + 128;
+    const unsigned rowpitch = (unsigned)p.Wp * 8u;
+    auto load_half = [&](u32x4_ (&a)[7], unsigned base, int half) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int t = half * 7 + i;
+            a[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(base + (unsigned)(t >> 1) * rowpitch + (unsigned)(t & 1) * 32u), 0, 0);
+        }
+    };
+    const u16x8_ zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int task = gw; task < p.ntask; task += nw) {
+        const int seg = task % p.nseg, t2 = task / p.nseg, chunk = t2 % p.nchunk, n = t2 / p.nchunk;
+        const int c0 = 2 * SP_COLS * seg - 1, py0 = chunk * p.rpc, py1 = min(p.Hq, py0 + p.rpc);
+        // this lane's A base of conv row r: pixel (r, c0 + li) — the column may be -1 or >= Wo: valid memory of a neighbouring row (or out of
+        // the buffer: zeros), finite values, masked below
+        auto base_of = [&](int r) { return (unsigned)(((n * p.Hp + 2 * r) * p.Wp + 2 * (c0 + li)) * 8) + (unsigned)lh * 16u; };
+        const int r_first = py0 == 0 ? 0 : 2 * py0 - 1, r_last = 2 * py1 - 1;
+        if (py0 == 0) {  // no conv row above the map: its maxima are 0
+            PREV[lane] = zero8;
+            PREV[lane + 64] = zero8;
+        }
+        u32x4_ a0[7], a1[7];
+        load_half(a0, base_of(r_first), 0);
+        for (int r = r_first; r <= r_last; ++r) {
+            load_half(a1, base_of(r), 1);
+            f32x16 acc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[b][q] = 0.f;
+            auto mma = [&](const u32x4_ (&a)[7], int half) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int t = half * 7 + i;
+                        if constexpr (AT == 2)
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, bw[t][b]), acc[b], 0, 0, 0);
+                        else
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bw[t][b]), acc[b], 0, 0, 0);
+                    }
+            };
+            mma(a0, 0);
+            if (r < r_last) load_half(a0, base_of(r + 1), 0);  // (the next row's first half)
+            mma(a1, 1);
+            // relu(bn(conv)) of the 32 x 64 tile -> the transpose buffer; columns outside the map are 0
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (q & 3) + 8 * (q >> 2) + 4 * lh;
+                    const float v = fmaf(acc[b][q], scv[b], shv[b]);
+                    const bool ok = (unsigned)(c0 + row) < (unsigned)p.Wo;
+                    dbn_st1<AT>(T, row * ST_PITCH + b * 32 + li, (ok && v > 0.f) ? v : 0.f);  // (never -0: the integer maxima below rely on it)
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = lane + 64 * it;  // (pooled column item >> 3 of the strip, channels 8 (item & 7) ..)
+                if (item >= SP_COLS * 8) continue;
+                const int pxl = item >> 3, c8 = item & 7;
+                const unsigned short* t0 = T + (2 * pxl) * ST_PITCH + c8 * 8;
+                u16x8_ hm = *reinterpret_cast<const u16x8_*>(t0);
+                hm = __builtin_elementwise_max(hm, *reinterpret_cast<const u16x8_*>(t0 + ST_PITCH));
+                hm = __builtin_elementwise_max(hm, *reinterpret_cast<const u16x8_*>(t0 + 2 * ST_PITCH));
+                if ((r & 1) == 0) {
+                    HA[item] = hm;  // conv row 2py: waits for row 2py + 1
+                } else {
+                    const int py = (r - 1) >> 1;  // conv row 2py + 1 closes pooled row py (and is row 2(py + 1) - 1 of the next)
+                    if (py >= py0) {
+                        const u16x8_ m = __builtin_elementwise_max(__builtin_elementwise_max(PREV[item], HA[item]), hm);
+                        const int px = SP_COLS * seg + pxl;
+                        if (px < p.Wq)
+                            *reinterpret_cast<u16x8_*>(reinterpret_cast<unsigned short*>(p.out) + (((long)n * p.Hq + py) * p.Wq + px) * 64 + c8 * 8) = m;
+                    }
+                    PREV[item] = hm;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the transpose buffer is rewritten by the next row)
+        }
+    }
+}
+
 // w [64][3][7][7] fp32 -> [14][2][64][8] in the 16-bit type: k-step t = (r = t >> 1, sq = t & 1), k-half lh, element j: tap 4 sq + 2 lh + (j >> 2),
 // channel j & 3; the eighth tap and the fourth channel are zero
 __global__ void stem16_pack_kernel(const float* __restrict__ w, int f16, unsigned short* __restrict__ out) {
@@ -232,6 +363,34 @@ int dbn_stem16_conv_bn_t(int at, const void* xp, const void* wpk, void* y, int N
     else hipLaunchKernelGGL(stem7x7_b16_kernel<2>, dim3(grid), dim3(256), 0, st, p);
     if (!gamma) return dbn_status();
     dbn_launch_bn_finalize_tiles(ws, 4 * grid, 64, gamma, beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd, st);
+    return dbn_status();
+}
+
+// ---- inference: conv + eval-mode BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one launch (see stem7x7_pool_b16_kernel)
+int dbn_stem16_pool_eligible(int at, int N, int H, int W) {
+    if (!dbn_stem16_eligible(at, N, H, W)) return 0;
+    const int Ho = (H - 1) / 2 + 1;
+    return Ho % 2 == 0 && Ho >= 2;
+}
+// out [N][Hq][Wq][64] = maxpool3x3/2 (relu(conv7x7/2 (xp) * scale + shift)), Hq = (Ho - 1) / 2 + 1; scale / shift: [64] (dbn_bn_eval_coef)
+int dbn_stem16_conv_bn_relu_pool_t(int at, const void* xp, const void* wpk, const float* scale, const float* shift, void* out, int N, int H, int W,
+                                   void* stream) {
+    DBN_REQUIRE(xp && wpk && scale && shift && out && dbn_stem16_pool_eligible(at, N, H, W));
+    StemPoolParams p;
+    p.xp = xp; p.wpk = wpk; p.sc = scale; p.sh = shift; p.out = out;
+    p.N = N; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.Hp = dbn_stem16_padded_h(H); p.Wp = dbn_stem16_padded_w(W);
+    p.Hq = (p.Ho - 1) / 2 + 1; p.Wq = (p.Wo - 1) / 2 + 1;
+    p.nseg = (p.Wq + SP_COLS - 1) / SP_COLS;
+    // pooled rows per task: long enough that the chunk's one extra conv row is small (<= 1 / 40), short enough for ~5+ tasks per wave
+    const int grid = 512, waves = 4 * grid;
+    int rpc = 20;
+    while (rpc > 4 && (long)N * p.nseg * ((p.Hq + rpc - 1) / rpc) < 5L * waves) rpc >>= 1;
+    p.rpc = rpc; p.nchunk = (p.Hq + rpc - 1) / rpc;
+    p.ntask = N * p.nseg * p.nchunk;
+    p.x_bytes = (unsigned)((long)N * p.Hp * p.Wp * 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (at == 1) hipLaunchKernelGGL(stem7x7_pool_b16_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(stem7x7_pool_b16_kernel<2>, dim3(grid), dim3(256), 0, st, p);
     return dbn_status();
 }
 

@@ -720,6 +720,7 @@ class Engine:
 
     # ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage through its own kernel (round 5, csrc/convt16.hip: the layer is
     # HBM-bound and the generic parity-class launch ran it at 2.5x its memory time).  DBN_CONVT16=0: the generic launch.
+    stem16_pool = os.environ.get('DBN_STEM16_POOL', '1') == '1'  # inference: the 16-bit stem kernel applies BatchNorm + ReLU and pools (one launch)
     pw16 = os.environ.get('DBN_PW16', '1') == '1'  # inference: pointwise convs 64 -> 64 | 256 on 16-bit storage through csrc/convt16.hip's kernel
     convt16 = os.environ.get('DBN_CONVT16', '1') == '1'
 
@@ -1296,13 +1297,16 @@ class Engine:
             check(L.dbn_nchw3_to_nhwc16_and_4_t(self.at, x.data_ptr(), x4.data_ptr(), _p(x4w), N, H, W, st), 'nchw3_to_nhwc16_and_4')
         if not stem16:
             y0, sc, sh = self.conv_bn('backbone.conv1', x4, bb.conv1, 'stem/y', 'backbone.bn1', bb.bn1, train)
-        H0, W0 = y0.shape[1], y0.shape[2]
-        pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
-        self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
-        check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
-              'maxpool fwd')
-        if self.prof:
-            self.prof.end()
+        if y0 is None:
+            pool = sc  # (the stem kernel pooled already: _stem16_conv_bn's inference form)
+        else:
+            H0, W0 = y0.shape[1], y0.shape[2]
+            pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
+            self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
+            check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
+                  'maxpool fwd')
+            if self.prof:
+                self.prof.end()
         self._join_repack()
         self._repack_fpn()
         fpn = m.segmentation_body
@@ -1415,7 +1419,8 @@ class Engine:
                 and bool(self.L.dbn_stem16_eligible(self.at, N, H, W)))
 
     def _stem16_conv_bn(self, x, conv, bn, train):
-        """x: the fp32 NCHW input.  Returns (y, scale, shift) like conv_bn; in training also leaves the packed [N,H,W,4] image in 'x4w'."""
+        """x: the fp32 NCHW input.  Returns (y, scale, shift) like conv_bn; in training also leaves the packed [N,H,W,4] image in 'x4w'.
+        Inference with the fused pool: (None, pooled, None)."""
         L, st = self.L, self.stream
         N, _, H, W = x.shape
         Hp, Wp = L.dbn_stem16_padded_h(H), L.dbn_stem16_padded_w(W)
@@ -1436,8 +1441,22 @@ class Engine:
             self.packs[key] = (panel, stamp)
         panel = self.packs[key][0]
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = self.buf('stem/y', N, Ho, Wo, 64)
         name = 'backbone.bn1'
+        if not train and self.stem16_pool and bool(L.dbn_stem16_pool_eligible(self.at, N, H, W)):
+            # inference (round 5): conv + BatchNorm + ReLU + MaxPool2d(3, 2, 1) in ONE launch — the 64-channel conv output never reaches memory
+            sc, sh = self.fbuf(name + '/scale', 64), self.fbuf(name + '/shift', 64)
+            check(L.dbn_bn_eval_coef(64, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps,
+                                     sc.data_ptr(), sh.data_ptr(), st), 'bn eval ' + name)
+            pool = self.buf('stem/pool', N, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64)
+            if self.prof:
+                self.prof.begin('stem7x7_pool_b16_kernel<%d>' % self.at, 2.0 * N * Ho * Wo * 64 * 3 * 49, float(2 * (N * Hp * Wp * 4 + pool.numel())),
+                                'fwd backbone.conv1 + bn1 + relu + maxpool')
+            check(L.dbn_stem16_conv_bn_relu_pool_t(self.at, xp.data_ptr(), panel.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H, W,
+                                                   st), 'stem16 conv+bn+relu+pool')
+            if self.prof:
+                self.prof.end()
+            return None, pool, None
+        y = self.buf('stem/y', N, Ho, Wo, 64)
         if self.prof:
             self.prof.begin('stem7x7_b16_kernel<%d>' % self.at, 2.0 * N * Ho * Wo * 64 * 3 * 49, float(2 * (N * Hp * Wp * 4 + N * Ho * Wo * 64)),
                             'fwd backbone.conv1')

@@ -544,6 +544,12 @@ int dbn_nchw3_to_padded4_t(int at, const float* x, void* xp, void* x4, int N, in
 int dbn_stem16_conv_bn_t(int at, const void* xp, const void* wpk, void* y, int N, int H, int W, const float* gamma, const float* beta, float eps,
                          float momentum, float* run_mean, float* run_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                          float* ws, void* stream);
+/* inference (round 5): out [N][Hq][Wq][64] = MaxPool2d(3, 2, 1)(relu(conv7x7/2 (xp) * scale + shift)) in ONE launch — the stem of
+ * modules/resnet.py:231-235 in eval mode; scale / shift: the eval-mode BatchNorm coefficients (dbn_bn_eval_coef).  The 64-channel conv
+ * output is never written.  Eligible: dbn_stem16_eligible and an even conv height Ho = (H - 1) / 2 + 1; Hq = (Ho - 1) / 2 + 1. */
+int dbn_stem16_pool_eligible(int at, int N, int H, int W);
+int dbn_stem16_conv_bn_relu_pool_t(int at, const void* xp, const void* wpk, const float* scale, const float* shift, void* out, int N, int H, int W,
+                                   void* stream);
 /* ---- ConvTranspose2d(64 -> 64, 2x2, stride 2) forward in 16-bit storage (round 5; csrc/convt16.hip): the head's up-sampling layers,
  * modules/segmentation_head.py:27-29,74-76.  x [N][H][W][64], y [N][2H][2W][64] in the 16-bit type; wpk: dbn_convt16_panel_bytes() bytes from
  * dbn_convt16_pack(kind 1 bf16 | 2 fp16, w [64][64][2][2] fp32 — the module's own [Cin][Cout][kh][kw] layout); bias [64] fp32 or NULL.

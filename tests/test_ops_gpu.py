@@ -2092,6 +2092,49 @@ def test_winograd_persistent_forms_are_bit_identical(N, Ci, Co, H, W):
 
 
 @pytest.mark.parametrize('at', [1, 2])
+@pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 100, 70), (3, 36, 47), (2, 132, 250), (1, 28, 600)])
+def test_stem_conv_bn_relu_maxpool_in_one_launch_on_16bit_storage(N, H, W, at):
+    """Round 5, csrc/stem16.hip stem7x7_pool_b16_kernel (inference): MaxPool2d(3, 2, 1)(relu(bn_eval(conv7x7/2(x)))) of resnet.py:231-235 in
+    ONE launch on the packed zero-bordered image — against F.max_pool2d(F.relu(F.conv2d(...) * scale + shift)) in fp64 on the operands as
+    stored, and against the two-kernel path (dbn_stem16_conv_bn_t + dbn_bnrelu_maxpool_fwd_t), which rounds the conv output to the storage
+    type before the BatchNorm.  Strips of 15 pooled columns (ragged last strip, several strips), several row chunks, odd widths."""
+    dt = {1: torch.bfloat16, 2: torch.float16}[at]
+    x = rnd(N, 3, H, W, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=(2.0 / 147)**0.5)
+    sc, sh = rnd(64, seed=3) * 0.4 + 1.0, rnd(64, seed=4) * 0.5
+    xd, wd, scd, shd = x.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV)
+    Hp, Wp = L().dbn_stem16_padded_h(H), L().dbn_stem16_padded_w(W)
+    xp = torch.zeros(N, Hp, Wp, 4, device=DEV, dtype=dt)
+    _lib.check(L().dbn_nchw3_to_padded4_t(at, xd.data_ptr(), xp.data_ptr(), None, N, H, W, stream()), 'padded4')
+    panel = torch.empty(L().dbn_stem16_panel_bytes(), device=DEV, dtype=torch.uint8)
+    _lib.check(L().dbn_stem16_pack(at, wd.data_ptr(), panel.data_ptr(), stream()), 'stem16 pack')
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert L().dbn_stem16_pool_eligible(at, N, H, W) == 1 and L().dbn_stem16_pool_eligible(at, N, H + 2, W) == 0  # (odd conv height: two launches)
+    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    conv = F.conv2d(x.to(dt).double(), w.to(dt).double(), None, 2, 3)
+    ref = F.max_pool2d(F.relu(conv * sc.double().view(1, 64, 1, 1) + sh.double().view(1, 64, 1, 1)), 3, 2, 1)
+    assert ref.shape == (N, 64, Hq, Wq)
+    out = torch.full((N, Hq, Wq, 64), float('nan'), device=DEV, dtype=dt)
+    _lib.check(L().dbn_stem16_conv_bn_relu_pool_t(at, xp.data_ptr(), panel.data_ptr(), scd.data_ptr(), shd.data_ptr(), out.data_ptr(), N, H, W,
+                                                  stream()), 'stem16 pool')
+    tol = {1: 2.0**-8, 2: 2.0**-10}[at]
+    scale = float(ref.abs().max())
+    report('stem conv+bn+relu+pool at %d' % at, nchw(out.float()), ref, tol * scale * 0.5 + 1e-6, tol)
+    # the two-kernel path: the same numbers up to the extra rounding of the conv output to the storage type
+    y = torch.empty((N, Ho, Wo, 64), device=DEV, dtype=dt)
+    _lib.check(L().dbn_stem16_conv_bn_t(at, xp.data_ptr(), panel.data_ptr(), y.data_ptr(), N, H, W, None, None, 0.0, 0.0, None, None, None, None,
+                                        None, None, None, stream()), 'stem16 conv')
+    out2 = torch.full_like(out, float('nan'))
+    _lib.check(L().dbn_bnrelu_maxpool_fwd_t(at, y.data_ptr(), scd.data_ptr(), shd.data_ptr(), out2.data_ptr(), N, Ho, Wo, 64, stream()), 'maxpool')
+    report('one launch vs conv + pool', out.float().cpu(), out2.float().cpu(), 3 * tol * scale, 2 * tol)
+    # bit-identical from run to run
+    out3 = torch.full_like(out, float('nan'))
+    _lib.check(L().dbn_stem16_conv_bn_relu_pool_t(at, xp.data_ptr(), panel.data_ptr(), scd.data_ptr(), shd.data_ptr(), out3.data_ptr(), N, H, W,
+                                                  stream()), 'stem16 pool')
+    assert torch.equal(out, out3)
+
+
+@pytest.mark.parametrize('at', [1, 2])
 @pytest.mark.parametrize('N,H,W', [(2, 64, 64), (1, 96, 70), (3, 33, 47), (2, 128, 160)])
 def test_stem_conv_on_packed_16bit_input(N, H, W, at):
     """Round 5, csrc/stem16.hip: the stem Conv2d(3 -> 64, 7x7, stride 2, pad 3) of resnet.py:167-172,231-235 in 16-bit storage on the packed,
