@@ -138,6 +138,8 @@ SIGNATURES.update({
     'dbn_set_head_tail_wide': 'i',
     'dbn_stem16_pool_eligible': 'iiii',
     'dbn_stem16_conv_bn_relu_pool_t': 'ipppppiiip',
+    'dbn_head16_eligible': 'iiii',
+    'dbn_head16_tail_eval_t': 'i' + 'p' * 15 + 'iii' + 'p',
     'dbn_cast_f32': 'ipplp',
     'dbn_pack_weights_t': 'ip' + 'i' * 7 + 'pp',
     'dbn_igemm_panel_floats_t': 'i' * 8,

@@ -154,6 +154,136 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PW == 1 ? 4
     }
 }
 
+// ---- inference: the DB head's tail in ONE launch (round 5) --------------------------------------------------------------------------------
+// /root/reference/src/modules/segmentation_head.py:27-29,35-45,74-79 in eval mode, per branch (binarize / thresh):
+//   ConvTranspose2d(64, 64, 2, 2) -> BatchNorm (running statistics) -> ReLU -> ConvTranspose2d(64, 1, 2, 2) -> Sigmoid
+// Kernel = stride = 2 twice: an input pixel of the quarter-resolution map owns a 4 x 4 block of the full-resolution output and nothing else
+// touches it, so the whole chain is local.  The three-kernel form wrote the two 64-channel half-resolution tensors (2 x 1.7 GB at 32 x 1280^2
+// fp16) and read them back in the head-tail kernel: 2 x 0.43 + 0.95 ms of the 14 ms forward.  Here a wave takes 32 input pixels; per
+// parity class of the first ConvT: 8 MFMAs (weights from a 32 KB LDS copy of the panel), relu((acc + bias) * scale + shift) on the fp32
+// accumulators, the 32 x 64 result through the wave's transpose buffer (16-bit) as the B operand of the SECOND ConvT — D^T[a'b'][pixel] =
+// W2^T[a'b'][co] x Z^T[co][pixel], 4 MFMAs whose A operand is the 64 x 4 weight padded to 32 rows — sigmoid, and after the four classes
+// every pixel's lane stores its 4 x 4 block as four 16-byte rows.  blockIdx.y = branch (output channel).
+struct Head16Params {
+    const void* x[2];      // [N][Hq][Wq][64] 16-bit: relu(bn(conv3x3)) of the binarize / thresh branch
+    const void* wpk[2];    // dbn_convt16_pack of the branch's first ConvT
+    const float* bias1[2]; // [64] or NULL
+    const float* sc[2];    // [64] eval-mode BatchNorm after the first ConvT
+    const float* sh[2];
+    const float* w2[2];    // [64][1][2][2] fp32: the second ConvT
+    const float* bias2[2]; // [1]
+    float* out;            // [N][2][4 Hq][4 Wq]
+    int N, Hq, Wq, M;
+    unsigned x_bytes;
+};
+
+template <int AT>
+__global__ __launch_bounds__(256) void head16_tail_eval_kernel(const Head16Params p) {
+    static_assert(AT == 1 || AT == 2, "16-bit storage");
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * 4 * 2 * 64 * 8 + 4 * 32 * CT_PITCH];
+    const int br = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    u32x4_* const PANEL = reinterpret_cast<u32x4_*>(smem);
+    {
+        const u32x4_* Wp = reinterpret_cast<const u32x4_*>(p.wpk[br]);
+        for (int i = threadIdx.x; i < 4 * 4 * 2 * 64; i += 256) PANEL[i] = Wp[i];
+    }
+    __syncthreads();
+    unsigned short* const T = smem + 4 * 4 * 2 * 64 * 8 + wave * 32 * CT_PITCH;
+    // the second ConvT's weight as the A operand of D^T = W2^T x Z^T: row li = output sub-pixel a'b' (4 real rows), k = channel
+    u32x4_ w2f[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        unsigned short h[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = li < 4 ? p.w2[br][(16 * t + 8 * lh + j) * 4 + li] : 0.f;
+            if constexpr (AT == 2) h[j] = __builtin_bit_cast(unsigned short, (_Float16)v);
+            else h[j] = (unsigned short)bf16_bits_rne(v);
+        }
+        w2f[t] = u32x4_{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16),
+                        (unsigned)h[6] | ((unsigned)h[7] << 16)};
+    }
+    float b1[2], scv[2], shv[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        b1[b] = p.bias1[br] ? p.bias1[br][b * 32 + li] : 0.f;
+        scv[b] = p.sc[br][b * 32 + li];
+        shv[b] = p.sh[br][b * 32 + li];
+    }
+    const float b2 = p.bias2[br][0];
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x[br]), 0, p.x_bytes, 0x00020000);
+    const int HW = p.Hq * p.Wq;
+    const float r_hw = 1.0f / (float)HW, r_w = 1.0f / (float)p.Wq;
+    const int H4 = 4 * p.Hq, W4 = 4 * p.Wq;
+    for (int mb = gw; mb * 32 < p.M; mb += nw) {
+        const int m0 = mb * 32, nrows = min(32, p.M - m0);
+        u32x4_ a[4];
+        {
+            const unsigned base = (unsigned)min(m0 + li, p.M - 1) * 128u + (unsigned)lh * 16u;  // (rows past M repeat the last pixel; never stored)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(base + (unsigned)t * 32u), 0, 0);
+        }
+        float o[16];  // (lanes of the lower half: this pixel's 4 x 4 block, [class c = 2a + b][a'b'])
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = b1[b];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const u32x4_ bw = PANEL[((c * 4 + t) * 2 + lh) * 64 + b * 32 + li];
+                    if constexpr (AT == 2)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[t]), __builtin_bit_cast(f16x8, bw), acc[b], 0, 0, 0);
+                    else
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t]), __builtin_bit_cast(bf16x8, bw), acc[b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    dbn_st1<AT>(T, row * CT_PITCH + b * 32 + li, dbn_affine_relu(acc[b][r], scv[b], shv[b]));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x16 acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u32x4_ zf = *reinterpret_cast<const u32x4_*>(T + li * CT_PITCH + 16 * t + 8 * lh);  // Z[pixel li][channels 16 t + 8 lh ..+7]
+                if constexpr (AT == 2)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w2f[t]), __builtin_bit_cast(f16x8, zf), acc2, 0, 0, 0);
+                else
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2f[t]), __builtin_bit_cast(bf16x8, zf), acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[c * 4 + r] = __builtin_amdgcn_rcpf(1.f + __expf(-(acc2[r] + b2)));  // (rows 0..3 of D^T live in the lower half)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the transpose buffer is rewritten by the next class)
+        }
+        if (lh == 0 && li < nrows) {
+            int n, rem, h, w_;
+            divmod24(m0 + li, HW, r_hw, n, rem);
+            divmod24(rem, p.Wq, r_w, h, w_);
+            float* const base = p.out + (((long)n * 2 + br) * H4 + 4 * h) * W4 + 4 * w_;
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {  // output row 4h + 2a + a': columns 4w + 2b + b' = class (a, b), sub-pixel (a', b')
+                const int a_ = yy >> 1, ap = yy & 1;
+                const f32x4 v = {o[(2 * a_ + 0) * 4 + 2 * ap + 0], o[(2 * a_ + 0) * 4 + 2 * ap + 1], o[(2 * a_ + 1) * 4 + 2 * ap + 0],
+                                 o[(2 * a_ + 1) * 4 + 2 * ap + 1]};
+                *reinterpret_cast<f32x4*>(base + (long)yy * W4) = v;
+            }
+        }
+    }
+}
+
 // W [ci 64][co 64][2][2] fp32 -> [class ab][k-step t][k-half lh][column co][8] in the 16-bit type: element j is input channel 16 t + 8 lh + j
 __global__ void convt16_pack_kernel(const float* __restrict__ w, int f16, unsigned short* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +378,31 @@ int dbn_pw16_act_t(int at, const void* x, const void* wpk, const float* bias, in
         if (at == 1) hipLaunchKernelGGL((convt2x2_b16_kernel<1, 1>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((convt2x2_b16_kernel<2, 1>), dim3(grid), dim3(256), 0, st, p);
     }
+    return dbn_status();
+}
+
+// ---- inference: both branches of the DB head's tail in one launch (see head16_tail_eval_kernel): out [N][2][4 Hq][4 Wq] fp32 =
+// sigmoid(ConvT2(relu(bn(ConvT1(x) + bias1))) + bias2) per branch; x_*: [N][Hq][Wq][64] in the activation type `at`; panel_*: dbn_convt16_pack of
+// the first ConvT; scale / shift: the eval-mode BatchNorm coefficients behind it; w2_*: the second ConvT's weight [64][1][2][2], bias2_* [1].
+int dbn_head16_eligible(int at, int N, int Hq, int Wq) {
+    return dbn_convt16_eligible(at, N, Hq, Wq, 64, 64) && (long)N * Hq * Wq * 32 < (1L << 31);
+}
+int dbn_head16_tail_eval_t(int at, const void* x_b, const void* x_t, const void* panel_b, const void* panel_t, const float* bias1_b,
+                           const float* bias1_t, const float* scale_b, const float* shift_b, const float* scale_t, const float* shift_t,
+                           const float* w2_b, const float* w2_t, const float* bias2_b, const float* bias2_t, float* out, int N, int Hq, int Wq,
+                           void* stream) {
+    DBN_REQUIRE(x_b && x_t && panel_b && panel_t && scale_b && shift_b && scale_t && shift_t && w2_b && w2_t && bias2_b && bias2_t && out);
+    DBN_REQUIRE(dbn_head16_eligible(at, N, Hq, Wq));
+    Head16Params p;
+    p.x[0] = x_b; p.x[1] = x_t; p.wpk[0] = panel_b; p.wpk[1] = panel_t; p.bias1[0] = bias1_b; p.bias1[1] = bias1_t;
+    p.sc[0] = scale_b; p.sc[1] = scale_t; p.sh[0] = shift_b; p.sh[1] = shift_t; p.w2[0] = w2_b; p.w2[1] = w2_t;
+    p.bias2[0] = bias2_b; p.bias2[1] = bias2_t; p.out = out;
+    p.N = N; p.Hq = Hq; p.Wq = Wq; p.M = N * Hq * Wq;
+    p.x_bytes = (unsigned)((long)p.M * 128);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(384, 2);  // three workgroups per CU (50 KB of LDS each), both branches side by side
+    if (at == 1) hipLaunchKernelGGL(head16_tail_eval_kernel<1>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(head16_tail_eval_kernel<2>, grid, dim3(256), 0, st, p);
     return dbn_status();
 }
 

@@ -724,6 +724,19 @@ class Engine:
     pw16 = os.environ.get('DBN_PW16', '1') == '1'  # inference: pointwise convs 64 -> 64 | 256 on 16-bit storage through csrc/convt16.hip's kernel
     convt16 = os.environ.get('DBN_CONVT16', '1') == '1'
 
+    def _convt16_panel(self, name, ct):
+        w = ct.weight
+        key = (name, 'convt16', self.kind)
+        stamp = (w._version, self.param_epoch, w.data_ptr())
+        ent = self.packs.get(key)
+        if ent is None or ent[1] != stamp:
+            panel = ent[0] if ent is not None else torch.empty(self.L.dbn_convt16_panel_bytes(), device=w.device, dtype=torch.uint8)
+            check(self.L.dbn_convt16_pack(self.kind, w.data_ptr(), panel.data_ptr(), self.stream), 'convt16_pack')
+            self.packs[key] = (panel, stamp)
+        return self.packs[key][0]
+
+    head16 = os.environ.get('DBN_HEAD16', '1') == '1'  # inference, 16-bit storage: ConvT -> BN -> ReLU -> ConvT -> sigmoid of both branches in ONE launch
+
     def _convt16(self, name, x, ct, out_name, bn_name=None, bn=None):
         """None when the layer does not take the 16-bit ConvT kernel; else (y, scale, shift) — scale / shift None without a BatchNorm."""
         N, H, W, C = x.shape
@@ -731,15 +744,7 @@ class Engine:
         if not (self.convt16 and self.at != 0 and ct.k == 2 and ct.stride == 2 and bool(L.dbn_convt16_eligible(self.at, N, H, W, C, ct.cout))
                 and ct.cin == C):
             return None
-        w = ct.weight
-        key = (name, 'convt16', self.kind)
-        stamp = (w._version, self.param_epoch, w.data_ptr())
-        ent = self.packs.get(key)
-        if ent is None or ent[1] != stamp:
-            panel = ent[0] if ent is not None else torch.empty(L.dbn_convt16_panel_bytes(), device=w.device, dtype=torch.uint8)
-            check(L.dbn_convt16_pack(self.kind, w.data_ptr(), panel.data_ptr(), self.stream), 'convt16_pack')
-            self.packs[key] = (panel, stamp)
-        panel = self.packs[key][0]
+        panel = self._convt16_panel(name, ct)
         y = self.buf(out_name, N, 2 * H, 2 * W, ct.cout)
         if self.prof:
             self.prof.begin('convt2x2_b16_kernel<%d>' % self.at, 2.0 * N * H * W * C * ct.cout * 4, float(2 * (x.numel() + y.numel())), 'convT fwd ' + name)
@@ -1367,6 +1372,10 @@ class Engine:
         else:
             f = self.bn_apply(fy, s_, h_, 'fpn/z')
         z1 = {}
+        fused_tail = (not train and self.head16 and self.convt16 and self.at != 0 and f.shape[3] == 256 and head.binarize[3].k == 2
+                      and head.binarize[3].cin == 64 and head.binarize[3].cout == 64
+                      and bool(L.dbn_head16_eligible(self.at, N, f.shape[1], f.shape[2])))
+
         def branch(br):
             seq = getattr(head, br)
             hp = 'segmentation_head.%s.' % br
@@ -1375,6 +1384,9 @@ class Engine:
             else:
                 ya, s_, h_ = self.conv_bn(hp + '0', f, seq[0], br + '/y0', hp + '1', seq[1], train, x_act=f_act)
                 za = self.bn_apply(ya, s_, h_, br + '/z0')
+            if fused_tail:
+                z1[br] = (za, None, None)  # (inference, 16-bit storage: the whole tail of the branch is one kernel below)
+                return
             yb, s_, h_ = self.convT_bn(hp + '3', za, seq[3], br + '/y1', hp + '4', seq[4], train)
             z1[br] = (yb, s_, h_)  # BN + ReLU of the two largest activations is applied inside the head-tail kernels
 
@@ -1390,6 +1402,30 @@ class Engine:
             branch('binarize')
         ch = 3 if train else 2
         (yb_, sb_, hb_), (yt_, st_, ht_) = z1['binarize'], z1['thresh']
+        if fused_tail:
+            Hq, Wq = yb_.shape[1], yb_.shape[2]
+            resample = (4 * Hq, 4 * Wq) != (H, W)
+            out = device_empty((N, 2, H, W), x.device)
+            head_out = self.fbuf('head/out', N, 2, 4 * Hq, 4 * Wq) if resample else out
+            coef = []
+            for br in ('binarize', 'thresh'):
+                seq, hp = getattr(head, br), 'segmentation_head.%s.' % br
+                bn = seq[4]
+                sc_, sh_ = self.fbuf(hp + '4/scale', 64), self.fbuf(hp + '4/shift', 64)
+                check(L.dbn_bn_eval_coef(64, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps,
+                                         sc_.data_ptr(), sh_.data_ptr(), st), 'bn eval ' + hp + '4')
+                coef.append((self._convt16_panel(hp + '3', seq[3]), seq[3].bias, sc_, sh_, seq[6]))
+            (pb, b1b, scb, shb, b6), (pt, b1t, sct, sht, t6) = coef
+            if self.prof:
+                self.prof.begin('head16_tail_eval_kernel<%d>' % self.at, 0.0, float(yb_.element_size()) * N * Hq * Wq * 128 + 4.0 * N * 16 * Hq * Wq * 2)
+            check(L.dbn_head16_tail_eval_t(self.at, yb_.data_ptr(), yt_.data_ptr(), pb.data_ptr(), pt.data_ptr(), _p(b1b), _p(b1t), scb.data_ptr(),
+                                           shb.data_ptr(), sct.data_ptr(), sht.data_ptr(), b6.weight.data_ptr(), t6.weight.data_ptr(),
+                                           b6.bias.data_ptr(), t6.bias.data_ptr(), head_out.data_ptr(), N, Hq, Wq, st), 'head16_tail_eval')
+            if self.prof:
+                self.prof.end()
+            if resample:
+                check(L.dbn_bilinear_fwd(head_out.data_ptr(), out.data_ptr(), N * 2, 4 * Hq, 4 * Wq, H, W, st), 'bilinear_fwd')
+            return out
         Hh, Wh = yb_.shape[1], yb_.shape[2]
         resample = (2 * Hh, 2 * Wh) != (H, W)  # only when H or W is not a multiple of 32 (models.py:43-46)
         out = device_empty((N, ch, H, W), x.device)

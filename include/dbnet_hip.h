@@ -569,6 +569,15 @@ int dbn_pw16_eligible(int at, int N, int H, int W, int Cin, int Cout);
 long dbn_pw16_panel_bytes(void);
 int dbn_pw16_pack(int kind, const float* w_oihw, int Cout, void* out, void* stream);
 int dbn_pw16_act_t(int at, const void* x, const void* wpk, const float* bias, int relu, void* y, int N, int H, int W, int Cout, void* stream);
+/* inference (round 5): the DB head's tail of BOTH branches in one launch — per branch ConvTranspose2d(64, 64, 2, 2) -> eval-mode BatchNorm ->
+ * ReLU -> ConvTranspose2d(64, 1, 2, 2) -> Sigmoid (modules/segmentation_head.py:27-29,35-45,74-79): out [N][2][4 Hq][4 Wq] fp32 (channel 0 the
+ * binarize branch, 1 the threshold branch); x_*: [N][Hq][Wq][64] in the activation type; panel_*: dbn_convt16_pack of the first ConvT;
+ * scale / shift: dbn_bn_eval_coef of the BatchNorm behind it; w2_*: the second ConvT's weight [64][1][2][2], bias2_*: [1]. */
+int dbn_head16_eligible(int at, int N, int Hq, int Wq);
+int dbn_head16_tail_eval_t(int at, const void* x_b, const void* x_t, const void* panel_b, const void* panel_t, const float* bias1_b,
+                           const float* bias1_t, const float* scale_b, const float* shift_b, const float* scale_t, const float* shift_t,
+                           const float* w2_b, const float* w2_t, const float* bias2_b, const float* bias2_t, float* out, int N, int Hq, int Wq,
+                           void* stream);
 
 /* ... 16-bit storage: the 16-channel form and (out4 non-NULL) the packed 4-channel form of dbn_nchw3_to_nhwc4_packed_t in ONE launch */
 int dbn_nchw3_to_nhwc16_and_4_t(int at, const float* x, void* out16, void* out4, int N, int H, int W, void* stream);

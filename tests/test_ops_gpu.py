@@ -909,6 +909,71 @@ def test_head_tail_with_fused_batchnorm_relu():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(2, 9, 7, True), (1, 16, 24, False), (3, 5, 13, True)])
+def test_db_head_tail_of_both_branches_in_one_launch_on_16bit_storage(case, dtype):
+    """dbn_head16_tail_eval_t (round 5, inference): per branch ConvTranspose2d(64, 64, 2, 2) -> eval-mode BatchNorm -> ReLU ->
+    ConvTranspose2d(64, 1, 2, 2) -> Sigmoid (segmentation_head.py:27-29,35-45,74-79), both branches, one launch, the two 64-channel
+    half-resolution tensors never written.  Reference: fp64 on the operands as stored (input, first weight and second weight rounded to the
+    storage type; the kernel also rounds the activations between the two ConvTs: that is the tolerance); and the three-kernel path
+    (dbn_convt16_bn_t twice + dbn_head_tail_fwd_t).  Ragged last 32-pixel block."""
+    N, Hq, Wq, with_bias = case
+    at = AT_OF[dtype]
+    eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+    rq = lambda t: t.to(dtype).double()
+    xs, w1, b1, sc, sh, w2, b2 = [], [], [], [], [], [], []
+    refs, logits = [], []
+    for i in range(2):
+        x = rnd(N, 64, Hq, Wq, seed=1 + i).abs()  # (post-ReLU activations)
+        xs.append(x)
+        w1.append(rnd(64, 64, 2, 2, seed=3 + i, scale=0.15))
+        b1.append(rnd(64, seed=5 + i) * 0.1)
+        sc.append(rnd(64, seed=7 + i) * 0.3 + 1)
+        sh.append(rnd(64, seed=9 + i) * 0.5)
+        w2.append(rnd(64, 1, 2, 2, seed=11 + i, scale=0.2))
+        b2.append(torch.tensor([0.1 - 0.3 * i]))
+        y = F.conv_transpose2d(rq(x), rq(w1[i]), b1[i].double() if with_bias else None, 2)
+        z = torch.relu(y * sc[i].double().view(1, 64, 1, 1) + sh[i].double().view(1, 64, 1, 1))
+        lg = F.conv_transpose2d(z, rq(w2[i]), b2[i].double(), 2)
+        logits.append(lg)
+        refs.append(torch.sigmoid(lg))
+    ref = torch.cat(refs, 1)
+    d = lambda t: t.contiguous().to(DEV)
+    xd = [nhwc(x).to(dtype) for x in xs]
+    panels = []
+    for i in range(2):
+        pnl = torch.empty(L().dbn_convt16_panel_bytes(), device=DEV, dtype=torch.uint8)
+        w1d = d(w1[i])
+        _lib.check(L().dbn_convt16_pack(at, w1d.data_ptr(), pnl.data_ptr(), stream()), 'convt16_pack')
+        panels.append(pnl)
+    b1d, scd, shd, w2d, b2d = [d(t) for t in b1], [d(t) for t in sc], [d(t) for t in sh], [d(t) for t in w2], [d(t) for t in b2]
+    assert L().dbn_head16_eligible(at, N, Hq, Wq) == 1
+    out = torch.full((N, 2, 4 * Hq, 4 * Wq), float('nan'), device=DEV)
+    bp = lambda i: b1d[i].data_ptr() if with_bias else None
+    _lib.check(L().dbn_head16_tail_eval_t(at, xd[0].data_ptr(), xd[1].data_ptr(), panels[0].data_ptr(), panels[1].data_ptr(), bp(0), bp(1),
+                                          scd[0].data_ptr(), shd[0].data_ptr(), scd[1].data_ptr(), shd[1].data_ptr(), w2d[0].data_ptr(),
+                                          w2d[1].data_ptr(), b2d[0].data_ptr(), b2d[1].data_ptr(), out.data_ptr(), N, Hq, Wq, stream()), 'head16')
+    lscale = max(float(l.abs().max()) for l in logits)
+    report('head tail in one launch %s %s' % (case, dtype), out.cpu(), ref, 0.25 * 3 * eps * (lscale + 1.0), 0.0)
+    # the three-kernel path on the same operands (rounds the first ConvT's output instead of the activation, and keeps the second weight in fp32)
+    ys = []
+    for i in range(2):
+        y1 = torch.empty((N, 2 * Hq, 2 * Wq, 64), device=DEV, dtype=dtype)
+        _lib.check(L().dbn_convt16_bn_t(at, xd[i].data_ptr(), panels[i].data_ptr(), bp(i), y1.data_ptr(), N, Hq, Wq, None, None, 0.0, 0.0, None,
+                                        None, None, None, None, None, None, stream()), 'convt16')
+        ys.append(y1)
+    out3 = torch.full_like(out, float('nan'))
+    _lib.check(L().dbn_head_tail_fwd_t(at, ys[0].data_ptr(), ys[1].data_ptr(), w2d[0].data_ptr(), w2d[1].data_ptr(), b2d[0].data_ptr(),
+                                       b2d[1].data_ptr(), scd[0].data_ptr(), shd[0].data_ptr(), scd[1].data_ptr(), shd[1].data_ptr(),
+                                       out3.data_ptr(), N, 2 * Hq, 2 * Wq, 2, 50.0, stream()), 'head_tail_fwd')
+    report('one launch vs three', out.cpu(), out3.cpu(), 0.25 * 5 * eps * (lscale + 1.0), 0.0)
+    out2 = torch.full_like(out, float('nan'))
+    _lib.check(L().dbn_head16_tail_eval_t(at, xd[0].data_ptr(), xd[1].data_ptr(), panels[0].data_ptr(), panels[1].data_ptr(), bp(0), bp(1),
+                                          scd[0].data_ptr(), shd[0].data_ptr(), scd[1].data_ptr(), shd[1].data_ptr(), w2d[0].data_ptr(),
+                                          w2d[1].data_ptr(), b2d[0].data_ptr(), b2d[1].data_ptr(), out2.data_ptr(), N, Hq, Wq, stream()), 'head16')
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('ch', [2, 3])
 def test_head_tail_forward_lane_layouts_on_16bit_storage(dtype, ch):
     """dbn_head_tail_fwd_t on bf16 / fp16 inputs (segmentation_head.py:27-29,35-45,74-79 with the BatchNorm + ReLU of the ConvT outputs applied
