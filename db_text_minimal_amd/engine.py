@@ -1687,12 +1687,24 @@ class Engine:
         if blk.downsample is not None and not self._fold_ok(x, blk.downsample[0], False):
             return None
         cur, res = x, x
+        beside = blk.downsample is not None and self.eval_downsample_beside and self.overlap_wgrad
         if blk.downsample is not None:
-            res = self.conv_bn_act_eval(name + '.downsample.0', x, blk.downsample[0], name + '/yd', blk.downsample[1], relu=False)
+            # the projection shortcut reads x like conv1 and is needed by the LAST conv only: on the second stream, beside conv1 (round 5: at
+            # cfg5 the three 1x1 / stride-2 launches — a K of 4-16 k-steps, two ring stages per workgroup — were 0.28 + 0.22 + 0.21 ms of the
+            # main stream)
+            if beside:
+                with self.side_stream():
+                    res = self.conv_bn_act_eval(name + '.downsample.0', x, blk.downsample[0], name + '/yd', blk.downsample[1], relu=False)
+            else:
+                res = self.conv_bn_act_eval(name + '.downsample.0', x, blk.downsample[0], name + '/yd', blk.downsample[1], relu=False)
         for i, (cname, conv, bn) in enumerate(convs):
             last = i == len(convs) - 1
+            if last and beside:
+                self.join_side()
             cur = self.conv_bn_act_eval(cname, cur, conv, name + ('/out' if last else '/z%d' % (i + 1)), bn, relu=True, res=res if last else None)
         return cur
+
+    eval_downsample_beside = os.environ.get('DBN_EVAL_DOWNSAMPLE_BESIDE', '1') == '1'
 
     # 16-bit storage: level 0 of the pyramid conv through the pixel-patch kernel.  0: off (default); 1: in train mode; 2: in inference too.
     # Measured: `tools/cfg_timing.py` (eager loop, host-paced) bf16 16 x 640^2 12.02 -> 11.5 ms, twice — but bench.py's step (resident inputs,
