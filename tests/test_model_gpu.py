@@ -1083,6 +1083,36 @@ def test_pyramid_conv_on_a_winograd_level_0():
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-2 * scale + 1e-7, k  # (+ 1e-7: biases in front of a BatchNorm have zero gradient — rounding noise of 1e-9)
 
 
+@pytest.mark.parametrize('math,n,h,w', [('bf16', 2, 128, 128), ('fp16', 2, 160, 128), ('fp16', 1, 96, 70), ('bf16', 1, 200, 136)])
+def test_inference_fusions_on_16bit_storage_equal_the_unfused_launches(math, n, h, w):
+    """Round 5, inference on 16-bit storage: the stem conv + BatchNorm + ReLU + max-pool in one launch (engine.stem16_pool), the head's ConvT ->
+    BatchNorm -> ReLU -> ConvT -> sigmoid of both branches in one launch (engine.head16), the pointwise kernel of the c2 lateral (engine.pw16)
+    and the projection shortcut on the second stream — against the same model with every one of them switched off: the same function up to
+    where the 16-bit roundings fall (mean difference of the maps bounded like two 16-bit evaluations of one net), both within the oracle's
+    bounds; sizes that are no multiples of 32 take the real resamples behind the fused head (models.py:43-46); run-to-run bit identity."""
+    seed = 23
+    img, _ = O.synthetic_batch(n, (h, w), seed=seed)
+    sd = O.new_state(seed)
+    model = make_model(seed)
+    model.engine.set_conv_math(math)
+    model.eval()
+    ref = O.forward(sd, img, training=False, update_stats=False)
+    eng = model.engine
+
+    def run(on):
+        eng.stem16_pool = eng.head16 = eng.pw16 = eng.eval_downsample_beside = on
+        with torch.no_grad():
+            return model(img.to(DEV)).clone()
+    a, b = run(True), run(False)
+    assert a.shape == (n, 2, h, w) and torch.isfinite(a).all()
+    d = (a - b).abs()
+    print('fused vs unfused (%s %dx%d): max %.3e mean %.3e' % (math, h, w, float(d.max()), float(d.mean())))
+    assert float(d.mean()) <= 4e-3
+    for t in (a, b):
+        assert float((t.cpu() - ref).abs().mean()) <= 4e-3
+    assert torch.equal(run(True), a)
+
+
 @pytest.mark.parametrize('math,arch,n,h,w', [('f32', 'resnet18', 2, 128, 128), ('f32', 'resnet18', 1, 96, 70), ('bf16', 'resnet18', 2, 128, 128),
                                              ('fp16', 'resnet18', 2, 160, 128), ('f32', 'resnet50', 1, 96, 96), ('f32', 'deformable_resnet18', 1, 96, 96)])
 def test_eval_with_folded_batchnorm_equals_the_unfolded_chain(math, arch, n, h, w):
