@@ -124,6 +124,11 @@ class _VirtualConv:
         self.cin, self.cout, self.k, self.stride, self.padding, self.weight, self.bias = cin, cout, k, stride, padding, weight, bias
 
 
+class ConvPlan(object):
+    """What one conv takes at one (geometry, input shape, conv math, mode) — see Engine.plan."""
+    __slots__ = ('winograd', 'winograd_wgrad', 'apply_on_load', 'fold', 'pw16')
+
+
 class _Shape:
     """A tensor's shape without the tensor (eligibility checks ahead of the launches)."""
 
@@ -160,6 +165,7 @@ class Engine:
         self.views = {}
         self.grad_views = {}
         self._dcn_slots, self._dcn_E = {}, {}
+        self._plans = {}
         self.dcn_forms = {'gather': 0, 'scatter': 0}
         self.grad_scale = 1.0
         self._live = None
@@ -600,10 +606,41 @@ class Engine:
     # arithmetic, 2.25x fewer matrix FLOPs; the result equals the direct convolution up to fp32 rounding (another summation order).
     winograd = os.environ.get('DBN_WINOGRAD', '1') == '1'
 
+    # ---- per-layer plan (round 5, review item 9): WHICH kernel family and fusion form a conv takes at one (geometry, input shape, conv math,
+    # mode) is decided in ONE place and cached; the call sites (_winograd_ok, lazy_act, wgrad, _fold_ok, conv_bn_act_eval) read it.  The key
+    # holds every engine switch a decision depends on, so A/B switches flipped at run time (tests do) take effect at once.
+    def plan(self, conv, shape, train=False, fp32_tensors=True):
+        N, H, W, C = shape
+        dcn = bool(getattr(conv, 'with_dcn', False))
+        key = (conv.cin, conv.cout, conv.k, conv.stride, conv.padding, dcn, N, H, W, C, bool(train), bool(fp32_tensors), self.at, self.ns,
+               self.winograd, self.winograd_wgrad, self.fold_eval_bn, self._use_planes, self.splitk, self.pw16, self.apply_on_load)
+        pl = self._plans.get(key)
+        if pl is None:
+            L = self.L
+            k, s_, p_ = conv.k, conv.stride, conv.padding
+            Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+            pl = ConvPlan()
+            exact = self.ns == 0 and self.at == 0 and fp32_tensors
+            s1 = (k, s_, p_) == (3, 1, 1)
+            # exact fp32, 3x3 / stride 1: Winograd F(2x2, 3x3) forward / data gradient (csrc/winograd_f32.hip) ...
+            pl.winograd = bool(self.winograd and exact and s1 and L.dbn_winograd_eligible(N, H, W, C, conv.cout))
+            # ... and weight gradient (csrc/winograd_wgrad_f32.hip)
+            pl.winograd_wgrad = bool(self.winograd_wgrad and exact and s1 and L.dbn_winograd_wgrad_eligible(N, H, W, conv.cout, C, conv.cin))
+            # relu(bn(.)) of this conv's INPUT applied while the patches are staged (the activation tensor is never written): the conv and —
+            # in training — its weight gradient must both be Winograd launches
+            pl.apply_on_load = bool(self.apply_on_load and not self._use_planes and not dcn and pl.winograd and (not train or pl.winograd_wgrad)
+                                    and not (not train and self.fold_eval_bn))
+            # inference: conv -> BatchNorm -> (+ residual) -> ReLU as ONE launch on weights with the running statistics folded in
+            pl.fold = bool(not train and self.fold_eval_bn and not self._use_planes and not dcn
+                           and not (self.splitk and L.dbn_igemm_splitk_plan_ns(N * Ho * Wo, conv.cout, k * k * C, C, self.ns) > 1))
+            # ... of a pointwise conv from 64 channels on 16-bit storage: the ConvT kernel's construction (csrc/convt16.hip)
+            pl.pw16 = bool(pl.fold and self.pw16 and self.at != 0 and (k, s_, p_) == (1, 1, 0) and C == conv.cin
+                           and L.dbn_pw16_eligible(self.at, N, H, W, C, conv.cout))
+            self._plans[key] = pl
+        return pl
+
     def _winograd_ok(self, x, conv):
-        N, H, W, C = x.shape
-        return (self.winograd and self.ns == 0 and self.at == 0 and x.dtype == torch.float32 and conv.k == 3 and conv.stride == 1 and
-                conv.padding == 1 and bool(self.L.dbn_winograd_eligible(N, H, W, C, conv.cout)))
+        return self.plan(conv, x.shape, fp32_tensors=x.dtype == torch.float32).winograd
 
     def _winograd_panel(self, name, w, cs, dgrad=0, version=None):
         """G g G^T of every filter (dgrad: of the rotated / transposed filters of the data gradient), re-made when the parameter
@@ -901,9 +938,9 @@ class Engine:
         flush_wgrad_reduces() (conv_wgrad, convT_bwd); False: a kernel of this pass reads gview next (FPN level scatter, DCN)."""
         N, Ho, Wo, _ = sm.shape
         _, H, W, Cb = big.shape
-        if (self.winograd_wgrad and self.at == 0 and self.ns == 0 and (k, stride, pad) == (3, 1, 1) and (Ho, Wo) == (H, W)
-                and sm.dtype == torch.float32 and big.dtype == torch.float32
-                and self.L.dbn_winograd_wgrad_eligible(N, H, W, O, Cb, I)):
+        if ((k, stride, pad) == (3, 1, 1) and (Ho, Wo) == (H, W)
+                and self.plan(_VirtualConv(I, O, k, stride, pad, None, None), big.shape, True,
+                              fp32_tensors=sm.dtype == torch.float32 and big.dtype == torch.float32).winograd_wgrad):
             # 3x3 / stride 1 in exact fp32: Winograd F(2x2,3x3) over the tiles (csrc/winograd_wgrad_f32.hip), 2.25x fewer matrix FLOPs
             slab = self.scratch('_wgrad_slab', self.L.dbn_winograd_wgrad_slab_floats(N, H, W, O, Cb))
             asc, ash = (big_act[0].data_ptr(), big_act[1].data_ptr()) if big_act is not None else (None, None)
@@ -1123,12 +1160,7 @@ class Engine:
     train_forwards = 0  # counts train-mode forwards: the running statistics change under them through raw pointers
 
     def _fold_ok(self, x, conv, train):
-        if train or not self.fold_eval_bn or self._use_planes or getattr(conv, 'with_dcn', False):
-            return False
-        N, H, W, C = x.shape
-        k, s, p = conv.k, conv.stride, conv.padding
-        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        return not (self.splitk and self.L.dbn_igemm_splitk_plan_ns(N * Ho * Wo, conv.cout, k * k * C, C, self.ns) > 1)
+        return self.plan(conv, x.shape, train).fold
 
     def _folded(self, name, conv, bn):
         """(virtual conv with the folded weight / bias, version stamp), re-made when a parameter or a running statistic changed."""
@@ -1159,8 +1191,7 @@ class Engine:
         assert C >= conv.cin and C % 4 == 0, (name, C, conv.cin)
         z = self.buf(out_name, N, Ho, Wo, conv.cout)
         assert res is None or (tuple(res.shape) == tuple(z.shape) and res.dtype == z.dtype), name
-        if (self.pw16 and self.at != 0 and k == 1 and s == 1 and p == 0 and res is None and C == conv.cin
-                and bool(self.L.dbn_pw16_eligible(self.at, N, H, W, C, conv.cout))):
+        if res is None and self.plan(conv, x.shape).pw16:
             # 16-bit storage: a pointwise conv 64 -> 64 | 256 (the FPN lateral on c2) on the ConvT kernel's construction — whole panel in
             # registers, A fragments straight from global memory, no ring (round 5)
             key = (name, 'pw16', self.kind)
@@ -1209,17 +1240,8 @@ class Engine:
     def lazy_act(self, y, convs, train):
         """True when relu(bn(y)) may stay unwritten: every conv in `convs` (all read it as their input) runs as a Winograd conv forward
         and — in training — takes its weight gradient through the Winograd kernel too."""
-        if not (self.apply_on_load and self.winograd and self.at == 0 and self.ns == 0 and not self._use_planes):
-            return False
-        if not train and self.fold_eval_bn:  # inference: the producer's epilogue writes the activation itself (conv_bn_act_eval)
-            return False
-        N, H, W, C = y.shape
-        for conv in convs:
-            if getattr(conv, 'with_dcn', False) or not self._winograd_ok(y, conv):
-                return False
-            if train and not (self.winograd_wgrad and self.L.dbn_winograd_wgrad_eligible(N, H, W, conv.cout, C, conv.cin)):
-                return False
-        return True
+        # (inference with folded BatchNorm: the producer's epilogue writes the activation itself, conv_bn_act_eval — the plan says no)
+        return all(self.plan(conv, y.shape, train, fp32_tensors=y.dtype == torch.float32).apply_on_load for conv in convs)
 
     bias_grad_in_bn = True  # bias gradients of convs that feed a BatchNorm are formed inside its backward apply pass
 
