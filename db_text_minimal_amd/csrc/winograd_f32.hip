@@ -299,6 +299,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         DBN_TRACE_MARK(1);
+#ifndef DBN_WINO_PRIO
+#define DBN_WINO_PRIO 0  // wave priority experiment: 1 = the main loop above the set-up / epilogue phases of the co-resident workgroup, 2 = below
+#endif
+        if (DBN_WINO_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+        if (DBN_WINO_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         const int nst = ncb / CBS;  // stages (CBS == 2: the launcher checked that ncb is even)
         for (int st = 0; st < nst; ++st) {
             load_patch(st + 1, 0);  // (past the last block: out-of-range offsets, zeros, never stored)
@@ -460,6 +465,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         DBN_TRACE_MARK(2);
+        if (DBN_WINO_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (DBN_WINO_PRIO == 2) __builtin_amdgcn_s_setprio(3);
 #if DBN_TRACE
         if (p.trace && threadIdx.x == 0) p.trace[(long)blockIdx.x * 8 + 5] = tr_bar;  // ticks spent from "MFMAs issued" to "past the barrier"
 #endif
