@@ -177,19 +177,21 @@ struct Head16Params {
     unsigned x_bytes;
 };
 
+constexpr int H16_WAVES = 8;  // waves per workgroup: they share one 32 KB LDS copy of the weight panel (two workgroups = 16 waves per CU: 69 KB each)
+
 template <int AT>
-__global__ __launch_bounds__(256) void head16_tail_eval_kernel(const Head16Params p) {
+__global__ __launch_bounds__(64 * H16_WAVES) void head16_tail_eval_kernel(const Head16Params p) {
     static_assert(AT == 1 || AT == 2, "16-bit storage");
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * 4 * 2 * 64 * 8 + 4 * 32 * CT_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short smem[4 * 4 * 2 * 64 * 8 + H16_WAVES * 32 * CT_PITCH];
     const int br = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int gw = blockIdx.x * H16_WAVES + wave, nw = gridDim.x * H16_WAVES;
     u32x4_* const PANEL = reinterpret_cast<u32x4_*>(smem);
     {
         const u32x4_* Wp = reinterpret_cast<const u32x4_*>(p.wpk[br]);
-        for (int i = threadIdx.x; i < 4 * 4 * 2 * 64; i += 256) PANEL[i] = Wp[i];
+        for (int i = threadIdx.x; i < 4 * 4 * 2 * 64; i += 64 * H16_WAVES) PANEL[i] = Wp[i];
     }
     __syncthreads();
     unsigned short* const T = smem + 4 * 4 * 2 * 64 * 8 + wave * 32 * CT_PITCH;
@@ -219,14 +221,19 @@ __global__ __launch_bounds__(256) void head16_tail_eval_kernel(const Head16Param
     const int HW = p.Hq * p.Wq;
     const float r_hw = 1.0f / (float)HW, r_w = 1.0f / (float)p.Wq;
     const int H4 = 4 * p.Hq, W4 = 4 * p.Wq;
+    // the A fragments of block mb + nw are fetched while block mb is computed (a wave's blocks are a chain of load -> 48 MFMAs -> stores
+    // otherwise, and three waves per SIMD do not cover the load: first build 0.69 ms at cfg5)
+    auto load_a = [&](u32x4_ (&a_)[4], int mb_) {
+        const unsigned base = (unsigned)min(mb_ * 32 + li, p.M - 1) * 128u + (unsigned)lh * 16u;  // (rows past M repeat the last pixel; never stored)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a_[t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(base + (unsigned)t * 32u), 0, 0);
+    };
+    u32x4_ a[4], an[4];
+    if (gw * 32 < p.M) load_a(a, gw);
     for (int mb = gw; mb * 32 < p.M; mb += nw) {
         const int m0 = mb * 32, nrows = min(32, p.M - m0);
-        u32x4_ a[4];
-        {
-            const unsigned base = (unsigned)min(m0 + li, p.M - 1) * 128u + (unsigned)lh * 16u;  // (rows past M repeat the last pixel; never stored)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(base + (unsigned)t * 32u), 0, 0);
-        }
+        const bool more = (mb + nw) * 32 < p.M;
+        if (more) load_a(an, mb + nw);
         float o[16];  // (lanes of the lower half: this pixel's 4 x 4 block, [class c = 2a + b][a'b'])
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -280,6 +287,10 @@ __global__ __launch_bounds__(256) void head16_tail_eval_kernel(const Head16Param
                                  o[(2 * a_ + 1) * 4 + 2 * ap + 1]};
                 *reinterpret_cast<f32x4*>(base + (long)yy * W4) = v;
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = an[t];
         }
     }
 }
@@ -400,9 +411,9 @@ int dbn_head16_tail_eval_t(int at, const void* x_b, const void* x_t, const void*
     p.N = N; p.Hq = Hq; p.Wq = Wq; p.M = N * Hq * Wq;
     p.x_bytes = (unsigned)((long)p.M * 128);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(384, 2);  // three workgroups per CU (50 KB of LDS each), both branches side by side
-    if (at == 1) hipLaunchKernelGGL(head16_tail_eval_kernel<1>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(head16_tail_eval_kernel<2>, grid, dim3(256), 0, st, p);
+    const dim3 grid(256, 2);  // two workgroups of eight waves per CU (69 KB of LDS each), both branches side by side
+    if (at == 1) hipLaunchKernelGGL(head16_tail_eval_kernel<1>, grid, dim3(64 * H16_WAVES), 0, st, p);
+    else hipLaunchKernelGGL(head16_tail_eval_kernel<2>, grid, dim3(64 * H16_WAVES), 0, st, p);
     return dbn_status();
 }
 
