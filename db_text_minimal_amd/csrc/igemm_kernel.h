@@ -790,6 +790,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     for (int s_ = 0; s_ < P_NSTG - 1; ++s_) issue_b(s_);
     store_patch(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DBN_TRACE_MARK(1);  // (TRACE builds: tools/trace_probe16.py)
     int slot = 0;
     for (int cb = 0; cb < ncb; ++cb) {
         const f32x4* const P = patch + (P_NBUF == 2 ? (cb & 1) : 0) * P_PATCH;
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    DBN_TRACE_MARK(2);
     }
     } else if constexpr (AT != 0) {
     // ---- stored 16-bit operands: LDS-DMA ring ------------------------------------------------------------------------------
