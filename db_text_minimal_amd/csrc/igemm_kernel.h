@@ -122,7 +122,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
     constexpr int P_PATCH = NSX * 4 * 180;
     constexpr int P_BUNIT = NSX * 2 * BN, P_BSTAGE = 2 * P_BUNIT;
-    constexpr int P_NSTG = NSX == 1 ? 4 : 3;
+#ifndef DBN_P_NSTG
+#define DBN_P_NSTG 4  // weight-ring depth of the single-plane pixel-patch kernels (A/B build; round 5: 6 / 8 stages — fewer workgroups per CU — are slower: cfg5 12.29 -> 12.52 / 12.56 ms, bf16 step 1704 -> 1687 / 1642 images/s)
+#endif
+    constexpr int P_NSTG = NSX == 1 ? DBN_P_NSTG : 3;
     // three planes: ONE patch buffer (refilled between two barriers at a channel-block boundary) keeps the workgroup at 70 KB
     // so that two fit a CU; with a second buffer it was alone on its CU (103 KB, one wave per SIMD: every LDS latency exposed)
     constexpr int P_NBUF = NSX == 1 ? 2 : 1;
