@@ -123,6 +123,13 @@ struct PackJob {
     int O, I, R, S, mode, Cs, Cd, f;
 };
 
+#ifndef DBN_PACK_GRID
+// workgroups per job (grid-stride inside; those past a job's size leave at once).  48 until late in round 5: the model's largest jobs
+// (512 x 512 x 9) then walked 24 groups of scattered loads per thread, the launch took 256 us in bf16 — on the second stream, but beside the
+// input conversion and the stem, which it slowed (the conversion alone: 29 us, in the step: 107).  bf16 step, one box, interleaved three times:
+// 48: 1731 / 1736 / 1735 images/s, 192: 1742 / 1745 / 1749, 512: 1754 / 1756 / 1755, 1024: 1755 / 1755 / 1757 (12: 1695); fp32 unchanged
+#define DBN_PACK_GRID 512
+#endif
 template <int BF16>
 __global__ void pack_many_kernel(const PackJob* __restrict__ jobs, int NS) {
     const PackJob j = jobs[blockIdx.y];
@@ -305,7 +312,7 @@ int dbn_pack_weights_t(int kind, const float* w_oihw, int O, int I, int R, int S
 // up to 4 : O, Cd = mode 0 ? O : I, f = (mode 1 and stride > 1) ? stride : 1).  ns = 0: fp32 panels, 1 / 3: split-bf16.
 int dbn_pack_weights_batched(const void* jobs, int n, int ns, void* stream) {  // ns: panel kind (0 fp32, 1 bf16, 3 bf16x3, 2 fp16)
     DBN_REQUIRE(jobs && n > 0 && (ns == 0 || ns == 1 || ns == 2 || ns == 3));
-    const dim3 grid(48, n);
+    const dim3 grid(DBN_PACK_GRID, n);
     if (ns == 0)
         hipLaunchKernelGGL(pack_many_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const PackJob*>(jobs), 0);
     else if (ns == 2)

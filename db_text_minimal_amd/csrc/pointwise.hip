@@ -798,9 +798,10 @@ __global__ void fpn_scatter_wgrad_kernel(const float* __restrict__ t0, const flo
 // 16-bit path fetches 8-channel pieces of 16-channel blocks)
 template <int AT>
 __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, void* __restrict__ out, int N, long HW, int packed) {
-    const long total = (long)N * HW;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long n = i / HW, p = i - n * HW;
+    // grid (pixel blocks, N): the image index comes from blockIdx.y (a flat index cost a 64-bit division per pixel)
+    const long n = blockIdx.y;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        const long i = n * HW + p;
         const float* b = x + n * 3 * HW + p;
         const f32x4 v = {b[0], b[HW], b[2 * HW], 0.f};
         if (AT == 0 || packed) {
@@ -1182,7 +1183,8 @@ int dbn_nearest_up_bwd(const float* dbig, float* dsrc, int N, int Hs, int Ws, in
 // x: [N,3,H,W] fp32.  out: [N,H,W,4] fp32 (at = 0) or [N,H,W,16] in the 16-bit storage type (channels 3.. zero).
 int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W, void* stream) {
     DBN_REQUIRE(x && out && N > 0);
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+    DBN_REQUIRE(N <= 65535);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)H * W), N), dim3(256), 0, (hipStream_t)stream,
                                            x, out, N, (long)H * W, 0));
     return dbn_status();
 }
@@ -1191,7 +1193,8 @@ int dbn_nchw3_to_nhwc4_t(int at, const float* x, void* out, int N, int H, int W,
 // largest weight gradient of the step, against 0.13 ms on this form)
 int dbn_nchw3_to_nhwc4_packed_t(int at, const float* x, void* out, int N, int H, int W, void* stream) {
     DBN_REQUIRE(x && out && N > 0);
-    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+    DBN_REQUIRE(N <= 65535);
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL(nchw3_to_nhwc4_kernel<AT>, dim3(dbn_grid((long)H * W), N), dim3(256), 0, (hipStream_t)stream,
                                            x, out, N, (long)H * W, 1));
     return dbn_status();
 }

@@ -7,38 +7,53 @@
 
 namespace {
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN, int Cb, int I,
-                                    int R, int S, float* __restrict__ grad, float scale, int natural) {
-    // one thread: 4 consecutive slab positions (one b128 load per split), 4 splits in flight; fixed summation order
+// (the stem: 64 x 196 gradient elements and hundreds of pixel splits — a thread that walked all the splits of its positions was a chain of
+// dependent loads, 51 us alone at the end of the step; now WRG thread groups share the splits of 16 position quads and are combined in group
+// order through LDS: fixed summation order, bit-reproducible)
+constexpr int WRG = 16;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int O, int J, int Jp, int BM, int BN,
+                                                           int Cb, int I, int R, int S, float* __restrict__ grad, float scale, int natural) {
+    // one thread: 4 consecutive slab positions (one b128 load per split) of the splits g, g + WRG, ...; 4 loads in flight
+    __shared__ double part[WRG][16][4];
     const long total = (long)O * Jp, count4 = total >> 2, total4 = wgrad_slab_stride(O, Jp) >> 2;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < count4; q += (long)gridDim.x * blockDim.x) {
-        const long idx = q << 2;
+    const int pos = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long q = blockIdx.x * 16L + pos;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (q < count4) {
         const f32x4* src = reinterpret_cast<const f32x4*>(slab) + q;
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        int z = 0;
-        for (; z + 4 <= splitk; z += 4) {
-            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + 1) * total4];
-            const f32x4 v2 = src[(long)(z + 2) * total4], v3 = src[(long)(z + 3) * total4];
+        int z = g;
+        for (; z + 3 * WRG < splitk; z += 4 * WRG) {
+            const f32x4 v0 = src[(long)z * total4], v1 = src[(long)(z + WRG) * total4];
+            const f32x4 v2 = src[(long)(z + 2 * WRG) * total4], v3 = src[(long)(z + 3 * WRG) * total4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] += ((double)v0[e] + (double)v1[e]) + ((double)v2[e] + (double)v3[e]);
         }
-        for (; z < splitk; ++z) {
+        for (; z < splitk; z += WRG) {
             const f32x4 v = src[(long)z * total4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
         }
-        const int prow = (int)(idx / Jp);
-        const int pcol0 = (int)(idx - (long)prow * Jp);
-        const int o = natural ? prow : (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int pcol = pcol0 + e;
-            const int j = natural ? pcol : (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
-            if (j >= J) continue;
-            const int tap = j / Cb, i = j - tap * Cb;
-            if (i >= I) continue;
-            grad[((long)o * I + i) * (R * S) + tap] = (float)(s[e] * scale);
-        }
+    for (int e = 0; e < 4; ++e) part[g][pos][e] = s[e];
+    __syncthreads();
+    if (g != 0 || q >= count4) return;
+#pragma unroll
+    for (int k = 1; k < WRG; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += part[k][pos][e];
+    const long idx = q << 2;
+    const int prow = (int)(idx / Jp);
+    const int pcol0 = (int)(idx - (long)prow * Jp);
+    const int o = natural ? prow : (prow / BM) * BM + tile_pos_to_index(prow % BM, BM);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int pcol = pcol0 + e;
+        const int j = natural ? pcol : (pcol / BN) * BN + tile_pos_to_index(pcol % BN, BN);
+        if (j >= J) continue;
+        const int tap = j / Cb, i = j - tap * Cb;
+        if (i >= I) continue;
+        grad[((long)o * I + i) * (R * S) + tap] = (float)(s[e] * scale);
     }
 }
 
@@ -368,7 +383,7 @@ static int wgrad_run(const void* sm_, const void* big_, float* slab, float* grad
         hipLaunchKernelGGL(wgrad_reduce64_kernel, dim3(O, Cb / 64), dim3(threads), smem, st, slab, splits_total, O, J, Jp, bm, bn, Cb, I,
                            R * S, G, grad_oihw, scale, natural ? 1 : 0);
     } else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dbn_grid((long)O * Jp / 4)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)O * Jp / 4 + 15) / 16)), dim3(256), 0, st, slab, splits_total, O, J, Jp, bm, bn,
                            Cb, I, R, S, grad_oihw, scale, natural ? 1 : 0);
     return dbn_status();
 }

@@ -64,9 +64,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define DBN_WINO_LDSPAD 0  // (timing experiment: extra LDS in 16-byte units — 1024 pushes a workgroup over half a CU's LDS: one resident workgroup per CU)
 #endif
     __shared__ f32x4 smem[X_FLOATS / 4 + (3 * 4 * 64) / 4 + 4 + 2 * 128 + 1 + DBN_WINO_LDSPAD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    const int ntn = p.Cd >> 6;
+    const int tid = threadIdx.x;
     // ---- PERSISTENT workgroups (round 5): the grid is at most two workgroups per CU; each pulls (patch, 64-channel tile) items from
     // per-XCD counters until none is left (dbn_xcd_remap's layout: XCD x owns a contiguous run of items, so the halo rows of neighbouring
     // patches and the weight panels of one channel tile stay in that XCD's L2).  What it
@@ -875,6 +873,12 @@ struct WinoPackJob {
     float* out;
     int O, I, Cs, dgrad;
 };
+#ifndef DBN_WPACK_GRID
+// workgroups per job: FEW on purpose — the launch runs on the second stream beside the fp32 stem conv and ends long before the first
+// Winograd conv needs a panel; wider grids finish sooner and slow the stem more (fp32 step, one box, interleaved three times: 16: 727 / 724 /
+// 724 images/s, 64: 723 / 720 / 721, 256: 720 / 720 / 720) — the opposite of pack_many_kernel in the 16-bit modes (pack.hip)
+#define DBN_WPACK_GRID 16
+#endif
 __global__ void winograd_pack_many_kernel(const WinoPackJob* __restrict__ jobs) {
     const WinoPackJob j = jobs[blockIdx.y];
     const long total = (long)j.Cs * j.O;
@@ -907,7 +911,7 @@ __global__ void winograd_pack_many_kernel(const WinoPackJob* __restrict__ jobs) 
 }  // namespace
 
 int dbn_launch_winograd_pack_many(const void* jobs, int n, hipStream_t st) {
-    hipLaunchKernelGGL(winograd_pack_many_kernel, dim3(16, n), dim3(256), 0, st, reinterpret_cast<const WinoPackJob*>(jobs));
+    hipLaunchKernelGGL(winograd_pack_many_kernel, dim3(DBN_WPACK_GRID, n), dim3(256), 0, st, reinterpret_cast<const WinoPackJob*>(jobs));
     return dbn_status();
 }
 
