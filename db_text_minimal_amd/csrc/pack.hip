@@ -280,6 +280,14 @@ long dbn_igemm_panel_floats_t(int kind, int O, int I, int R, int S, int mode, in
     return panel_floats_all(O, I, R, S, mode, stride, kind == 2 ? 1 : kind, cs);
 }
 
+// Workgroups per parity class of a stride-4 / -8 transposed conv's panels (the pyramid conv's derived panels: 16 / 64 classes of <= 65 536
+// elements, packed every step beside layer1 or — fp32 — in front of the pyramid conv).  FEWER is better here, measured late in round 5 on one
+// box, interleaved three times: 1024: bf16 1645-1651 images/s / fp32 715-716, 256: 1645-1648 / 717-718, 64 (until then): 1678-1684 / 724,
+// 32: 1687-1691 / 726, 16: 1689-1690 / 725.  (The cap of the other panels — the stem's, levels 0 and 1 — goes the other way: 64 or 16
+// instead of 1024 costs fp32 727 -> 717 / 716; those launches sit on the main stream's chain.)
+#ifndef DBN_PACKF_CAP
+#define DBN_PACKF_CAP 16
+#endif
 static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, int stride, int ns, float* out, void* stream, int cs = 0,
                     int f16 = 0) {
     DBN_REQUIRE(w_oihw && out && O > 0 && I > 0 && R > 0 && S > 0 && (mode == 0 || mode == 1));
@@ -293,7 +301,7 @@ static int pack_run(const float* w_oihw, int O, int I, int R, int S, int mode, i
     // panel offsets as in igemm_run)
     const int f = (mode == 1 && stride > 1) ? stride : 1;
     const long total = (long)(((dbn_ceil_div(R, f) * dbn_ceil_div(S, f) * Cs + 15) / 16) * 16) * Cd;  // largest class
-    const dim3 grid(dbn_grid(total, 256, f > 2 ? 64 : 1024), f * f);
+    const dim3 grid(dbn_grid(total, 256, f > 2 ? DBN_PACKF_CAP : 1024), f * f);
     if (ns == 0)
         hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, st, w_oihw, O, I, R, S, mode, Cs, Cd, f, out);
     else
