@@ -150,6 +150,9 @@ SIGNATURES.update({
     'dbn_bnrelu_maxpool_fwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_fwd'],
     'dbn_bnrelu_maxpool_bwd_t': 'i' + SIGNATURES['dbn_bnrelu_maxpool_bwd'][:-1] + 'pppp',
     'dbn_maxpool_bwd_parts': 'iiii',
+    'dbn_bnrelu_maxpool_fwd_arg_t': 'ipppppp' + 'iiii' + 'p',
+    'dbn_maxpool_bn_backward_ws_floats': 'iiii',
+    'dbn_maxpool_bn_backward_t': 'i' + 'p' * 10 + 'iiii' + 'f' + 'pp',
     'dbn_nearest_up_fwd_t': 'i' + SIGNATURES['dbn_nearest_up_fwd'],
     'dbn_nearest_up_bwd_t': 'i' + SIGNATURES['dbn_nearest_up_bwd'],
     'dbn_nchw3_to_nhwc4_t': 'i' + SIGNATURES['dbn_nchw3_to_nhwc4'],
@@ -171,7 +174,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_pw16_panel_bytes', 'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_maxpool_bn_backward_ws_floats', 'dbn_pw16_panel_bytes', 'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

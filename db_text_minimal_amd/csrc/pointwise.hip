@@ -605,6 +605,212 @@ __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const floa
     }
 }
 
+// ---- the same pair with a RECORDED argmax (late in round 5) ------------------------------------------------------------------------
+// Forward: besides the pooled maximum, the position of the window's FIRST maximum in scan order (rows, then columns: the rule of
+// /root/reference's nn.MaxPool2d, whose backward routes a window's gradient to that one position) as a code 3 r + q per element — 15 where the
+// pooled value is 0, i.e. where ReLU passes no gradient — and the PRE-BatchNorm value y at that position.  With them the stem's backward needs
+// no gradient tensor at the conv's resolution: the two channel sums of the BatchNorm backward come from the POOLED tensors (a window's gradient
+// lands on exactly one position, so sum(g) = sum(dpool [code != 15]) and sum(g xhat) = sum(dpool xhat(ypool))), and one pass over y then
+// writes dy = gamma rstd (g - c1 - xhat c2) directly.  (The kernels above give the gradient to EVERY position that ties with the maximum and
+// therefore cannot take their sums from the pooled side.)
+template <int AT, int QW>
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
+                                              void* __restrict__ out, unsigned* __restrict__ idx, void* __restrict__ ypool, int N, int H, int W,
+                                              int C, int Ho, int Wo) {
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
+    const int Hp = (Ho + 1) >> 1;
+    const long total = (long)N * Hp * Wo * cin;
+    auto ld = [&](long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(y, i);
+        else dbn_ldq<AT>(y, i, v);
+    };
+    auto st = [&](void* ptr, long i, const f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) dbn_st4<AT>(ptr, i, v[0]);
+        else dbn_stq<AT>(ptr, i, v);
+    };
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        long t = i / cin;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int k = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        f32x4 s[QW], h[QW], m0[QW], m1[QW], y0[QW], y1[QW];
+        unsigned c0[QW], c1[QW];  // four one-byte codes per quad
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            s[q] = *reinterpret_cast<const f32x4*>(sc + 4 * (QW * ci + q));
+            h[q] = *reinterpret_cast<const f32x4*>(sh + 4 * (QW * ci + q));
+            m0[q] = m1[q] = f32x4{-1.f, -1.f, -1.f, -1.f};  // below every ReLU output: the first valid position always takes the window
+            y0[q] = y1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            c0[q] = c1[q] = 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int ih = 4 * k - 1 + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            f32x4 rm[QW], ry[QW];
+            unsigned rq[QW];
+#pragma unroll
+            for (int q = 0; q < QW; ++q) {
+                rm[q] = f32x4{-1.f, -1.f, -1.f, -1.f};
+                ry[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rq[q] = 0u;
+            }
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+                const int iw = ow * 2 - 1 + qq;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                f32x4 v[QW];
+                ld((((long)n * H + ih) * W + iw) * cin + ci, v);
+#pragma unroll
+                for (int q = 0; q < QW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = dbn_affine_relu(v[q][e], s[q][e], h[q][e]);
+                        if (z > rm[q][e]) {  // strictly greater: the first maximum of the row keeps it
+                            rm[q][e] = z;
+                            ry[q][e] = v[q][e];
+                            rq[q] = (rq[q] & ~(0xFFu << (8 * e))) | ((unsigned)qq << (8 * e));
+                        }
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < QW; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned col = (rq[q] >> (8 * e)) & 0xFFu;
+                    if (r <= 2 && rm[q][e] > m0[q][e]) {
+                        m0[q][e] = rm[q][e];
+                        y0[q][e] = ry[q][e];
+                        c0[q] = (c0[q] & ~(0xFFu << (8 * e))) | ((3u * r + col) << (8 * e));
+                    }
+                    if (r >= 2 && rm[q][e] > m1[q][e]) {
+                        m1[q][e] = rm[q][e];
+                        y1[q][e] = ry[q][e];
+                        c1[q] = (c1[q] & ~(0xFFu << (8 * e))) | ((3u * (r - 2) + col) << (8 * e));
+                    }
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < QW; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!(m0[q][e] > 0.f)) c0[q] = (c0[q] & ~(0xFFu << (8 * e))) | (15u << (8 * e));
+                if (!(m1[q][e] > 0.f)) c1[q] = (c1[q] & ~(0xFFu << (8 * e))) | (15u << (8 * e));
+                m0[q][e] = fmaxf(m0[q][e], 0.f);
+                m1[q][e] = fmaxf(m1[q][e], 0.f);
+            }
+        const long o = (((long)n * Ho + 2 * k) * Wo + ow) * cin + ci;
+        st(out, o, m0);
+        st(ypool, o, y0);
+#pragma unroll
+        for (int q = 0; q < QW; ++q) idx[o * QW + q] = c0[q];
+        if (2 * k + 1 < Ho) {
+            const long o1 = o + (long)Wo * cin;
+            st(out, o1, m1);
+            st(ypool, o1, y1);
+#pragma unroll
+            for (int q = 0; q < QW; ++q) idx[o1 * QW + q] = c1[q];
+        }
+    }
+}
+
+// part[2 * C][gridDim.x]: per-block sums of g and g * xhat over the POOLED elements (g = dpool where the code is not 15); threads t, t + C/4, ...
+// of a block hold the same channel quad (256 % (C/4) == 0, host side)
+template <int AT>
+__global__ __launch_bounds__(256) void maxpool_bn_stats_kernel(const void* __restrict__ dpool, const unsigned* __restrict__ idx,
+                                                               const void* __restrict__ ypool, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ part, long total, int C) {
+    const int cin = C / 4;
+    const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % cin) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 dp = dbn_ld4<AT>(dpool, i), yp = dbn_ld4<AT>(ypool, i);
+        const unsigned code = idx[i];
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = ((code >> (8 * e)) & 0xFFu) != 15u ? dp[e] : 0.f;
+        s1 += g;
+        s2 += g * ((yp - mu) * rs);
+    }
+    __shared__ f32x4 red[2][256];
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * cin) {
+        const int which = threadIdx.x / cin, t0 = threadIdx.x - which * cin;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = t0; k < 256; k += cin) t += red[which][k];
+        const int cq = (int)((blockIdx.x * (long)blockDim.x + t0) % cin) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[((long)which * C + cq + e) * gridDim.x + blockIdx.x] = t[e];
+    }
+}
+
+// dy[n,ih,iw,c] = gamma rstd (g - c1 - xhat c2), g = the sum of dpool over the windows whose recorded first maximum is (ih, iw).
+// One thread: a channel quad of a 2 x 2 block of input pixels (rows 2a, 2a+1, columns 2b, 2b+1), which lies in the windows
+// (a..a+1) x (b..b+1) only; pixel (2a + dy, 2b + dx) is position (dy - 2u + 1, dx - 2w + 1) of window (a + u, b + w).
+template <int AT>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const void* __restrict__ y, const void* __restrict__ dpool,
+                                                                   const unsigned* __restrict__ idx, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                   void* __restrict__ dy, int N, int H, int W, int C, int Ho, int Wo) {
+    const int cin = C / 4;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const long total = (long)N * Hb * Wb * cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        long t = i / cin;
+        const int b = (int)(t % Wb);
+        t /= Wb;
+        const int a = (int)(t % Hb);
+        const int n = (int)(t / Hb);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * ci), rs = *reinterpret_cast<const f32x4*>(rstd + 4 * ci);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + 4 * ci), k2 = *reinterpret_cast<const f32x4*>(c2 + 4 * ci);
+        const f32x4 gr = *reinterpret_cast<const f32x4*>(gamma + 4 * ci) * rs;
+        f32x4 dp[2][2];
+        unsigned cd[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                dp[u][w] = f32x4{0.f, 0.f, 0.f, 0.f};
+                cd[u][w] = 0x0F0F0F0Fu;  // (no window there: no position matches)
+                if (a + u < Ho && b + w < Wo) {
+                    const long o = (((long)n * Ho + a + u) * Wo + b + w) * cin + ci;
+                    dp[u][w] = dbn_ld4<AT>(dpool, o);
+                    cd[u][w] = idx[o];
+                }
+            }
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                const int ih = 2 * a + dy_, iw = 2 * b + dx_;
+                if (ih >= H || iw >= W) continue;
+                const long pi = (((long)n * H + ih) * W + iw) * cin + ci;
+                const f32x4 v = dbn_ld4<AT>(y, pi);
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u <= dy_; ++u)
+#pragma unroll
+                    for (int w = 0; w <= dx_; ++w) {
+                        const unsigned code = 3u * (unsigned)(dy_ - 2 * u + 1) + (unsigned)(dx_ - 2 * w + 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (((cd[u][w] >> (8 * e)) & 0xFFu) == code) g[e] += dp[u][w][e];
+                    }
+                const f32x4 xh = (v - mu) * rs;
+                dbn_st4<AT>(dy, pi, gr * (g - k1 - xh * k2));
+            }
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // nearest upsample (F.interpolate(size=...) semantics: src = min(floor(dst*in/out), in-1))
 // ----------------------------------------------------------------------------------
@@ -1145,6 +1351,60 @@ int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const fl
 int dbn_bnrelu_maxpool_bwd(const float* y, const float* scale, const float* shift, const float* pooled, const float* dpool,
                            float* dz, int N, int H, int W, int C, void* stream) {
     return dbn_bnrelu_maxpool_bwd_t(0, y, scale, shift, pooled, dpool, dz, N, H, W, C, nullptr, nullptr, nullptr, stream);
+}
+
+// ---- MaxPool2d(3, 2, 1) over relu(bn(y)) with the recorded argmax, and the backward through pool, ReLU and the BatchNorm in one pass
+// (see bnrelu_maxpool_fwd_arg_kernel).  idx: N*Ho*Wo*C bytes; ypool: [N,Ho,Wo,C] in the storage type.
+int dbn_bnrelu_maxpool_fwd_arg_t(int at, const void* y, const float* scale, const float* shift, void* out, void* idx, void* ypool, int N, int H,
+                                 int W, int C, void* stream) {
+    DBN_REQUIRE(y && scale && shift && out && idx && ypool && C % 4 == 0 && N > 0 && H > 0 && W > 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    unsigned* ix = reinterpret_cast<unsigned*>(idx);
+    if ((at == 1 || at == 2) && C % 8 == 0) {
+        const dim3 grid(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 8)));
+        if (at == 1)
+            hipLaunchKernelGGL((bnrelu_maxpool_fwd_arg_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, ix, ypool, N, H, W, C, Ho, Wo);
+        else
+            hipLaunchKernelGGL((bnrelu_maxpool_fwd_arg_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, out, ix, ypool, N, H, W, C, Ho, Wo);
+        return dbn_status();
+    }
+    DBN_DISPATCH_AT(at, hipLaunchKernelGGL((bnrelu_maxpool_fwd_arg_kernel<AT, 1>), dim3(dbn_grid((long)N * ((Ho + 1) / 2) * Wo * (C / 4))), dim3(256), 0,
+                                           (hipStream_t)stream, y, scale, shift, out, ix, ypool, N, H, W, C, Ho, Wo));
+    return dbn_status();
+}
+static int maxpool_bn_parts(int N, int Ho, int Wo, int C) { return dbn_grid((long)N * Ho * Wo * (C / 4), 256, 2048); }
+// floats of scratch dbn_maxpool_bn_backward_t needs
+long dbn_maxpool_bn_backward_ws_floats(int N, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    return 2L * C * maxpool_bn_parts(N, Ho, Wo, C) + 2L * C;
+}
+// dy [N,H,W,C] = the gradient at the conv output y of  pool(relu(bn(y)))  given dpool [N,Ho,Wo,C] (train-mode BatchNorm: saved mean / rstd,
+// gamma; dgamma / dbeta are written, times grad_scale).  idx / ypool: as written by dbn_bnrelu_maxpool_fwd_arg_t for this y.
+int dbn_maxpool_bn_backward_t(int at, const void* y, const void* dpool, const void* idx, const void* ypool, const float* save_mean,
+                              const float* save_rstd, const float* gamma, void* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                              float grad_scale, float* ws, void* stream) {
+    DBN_REQUIRE(y && dpool && idx && ypool && save_mean && save_rstd && gamma && dy && dgamma && dbeta && ws);
+    DBN_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && 256 % (C / 4) == 0 && (long)N * H * W < (1L << 31));
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int parts = maxpool_bn_parts(N, Ho, Wo, C);
+    float* part = ws;
+    float* c1 = ws + 2L * C * parts;
+    float* c2 = c1 + C;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned* ix = reinterpret_cast<const unsigned*>(idx);
+    const long pooled4 = (long)N * Ho * Wo * (C / 4);
+    const int M = N * H * W;
+    const dim3 agrid(dbn_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4)));
+    DBN_DISPATCH_AT(at, {
+        hipLaunchKernelGGL(maxpool_bn_stats_kernel<AT>, dim3(parts), dim3(256), 0, st, dpool, ix, ypool, save_mean, save_rstd, part, pooled4, C);
+        if (parts >= 512)
+            hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C), dim3(256), 0, st, part, parts, M, C, dgamma, dbeta, c1, c2, grad_scale);
+        else
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, part, parts, M, C, dgamma, dbeta, c1, c2, grad_scale);
+        hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel<AT>, agrid, dim3(256), 0, st, y, dpool, ix, save_mean, save_rstd, gamma, c1, c2, dy, N, H, W, C, Ho,
+                           Wo);
+    });
+    return dbn_status();
 }
 
 int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,

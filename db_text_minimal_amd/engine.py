@@ -1329,9 +1329,19 @@ class Engine:
         else:
             H0, W0 = y0.shape[1], y0.shape[2]
             pool = self.buf('stem/pool', N, (H0 - 1) // 2 + 1, (W0 - 1) // 2 + 1, 64)  # MaxPool2d(3, 2, 1)
-            self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
-            check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
-                  'maxpool fwd')
+            if train and self.pool_argmax:
+                # (late in round 5) the forward records each window's first maximum and the pre-BatchNorm value there: the backward then
+                # needs no gradient tensor at the conv's resolution and no separate BatchNorm apply pass (backward(): _stem_pool_backward)
+                idx = self.buf('stem/pool_idx', *pool.shape, dtype=torch.uint8)
+                ypool = self.buf('stem/pool_y', *pool.shape)
+                self._prof_hbm('bnrelu_maxpool_fwd_arg_kernel', (y0.numel() + 2 * pool.numel()) * y0.element_size() + idx.numel())
+                check(L.dbn_bnrelu_maxpool_fwd_arg_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), idx.data_ptr(),
+                                                     ypool.data_ptr(), N, H0, W0, 64, st), 'maxpool fwd (argmax)')
+                self._pool_arg_generation = self.generation
+            else:
+                self._prof_hbm('bnrelu_maxpool_fwd_kernel', (y0.numel() + pool.numel()) * y0.element_size())
+                check(L.dbn_bnrelu_maxpool_fwd_t(self.at, y0.data_ptr(), sc.data_ptr(), sh.data_ptr(), pool.data_ptr(), N, H0, W0, 64, st),
+                      'maxpool fwd')
             if self.prof:
                 self.prof.end()
         self._join_repack()
@@ -1918,9 +1928,30 @@ class Engine:
                     self._side_waits_for_reductions()
                     self.grad_ready_hook('layer%d' % li)
         y0 = B['stem/y']
-        dz = self.buf('stem/dz', *y0.shape)
         if self.flush_before_pool:
             self._flush_wgrads()  # (late order: layer1's last weight gradient starts beside the max-pool backward, not behind it — round-5 trace: it had waited 218 us)
+        if self.pool_argmax and self._pool_arg_generation == self.generation:
+            # pool + ReLU + BatchNorm backward from the recorded argmax: sums over the pooled tensors, then ONE pass y -> dy
+            dy0 = self.buf('stem/dy', *y0.shape)
+            ws = self.scratch('_stem_pool_bn_ws', L.dbn_maxpool_bn_backward_ws_floats(N, y0.shape[1], y0.shape[2], 64))
+            es = y0.element_size()
+            self._prof_hbm('maxpool_bn_stats_kernel + maxpool_bn_bwd_apply_kernel',
+                           (2 * y0.numel() + 3 * dpool.numel()) * es + 2 * dpool.numel())  # dpool, ypool, idx | y, dpool, idx -> dy
+            check(L.dbn_maxpool_bn_backward_t(self.at, y0.data_ptr(), dpool.data_ptr(), B['stem/pool_idx'].data_ptr(), B['stem/pool_y'].data_ptr(),
+                                              B['backbone.bn1/mean'].data_ptr(), B['backbone.bn1/rstd'].data_ptr(),
+                                              self.views['backbone.bn1.weight'].data_ptr(), dy0.data_ptr(),
+                                              self.grad_views['backbone.bn1.weight'].data_ptr(), self.grad_views['backbone.bn1.bias'].data_ptr(),
+                                              N, y0.shape[1], y0.shape[2], 64, self.grad_scale, ws.data_ptr(), st), 'maxpool + bn backward')
+            if self.prof:
+                self.prof.end()
+            self.conv_wgrad('backbone.conv1', dy0, B['x4w' if self.at != 0 else 'x4'], bb.conv1)
+            self.flush_wgrad_reduces()
+            self.join_side()
+            self._dcn_send_back()
+            self.saved_generation = -1
+            self.backwards_since_clear += 1
+            return
+        dz = self.buf('stem/dz', *y0.shape)
         # the max-pool backward also emits the partial sums of the stem BatchNorm's backward (it has y and dz in registers)
         nparts = L.dbn_maxpool_bwd_parts(N, y0.shape[1], y0.shape[2], 64)
         parts = self.scratch('_stem_bn_parts', 2 * 64 * nparts)
@@ -1940,6 +1971,10 @@ class Engine:
         self.backwards_since_clear += 1  # FusedAdam.step refuses gradients that a second backward pass overwrote
 
     backwards_since_clear = 0
+    # the stem's max-pool with a recorded argmax (PyTorch's first-maximum rule; csrc/pointwise.hip: bnrelu_maxpool_fwd_arg_kernel).
+    # DBN_POOL_ARGMAX=0: round 4's pair (gradient to every position that ties with the maximum, a gradient tensor at the conv's resolution)
+    pool_argmax = os.environ.get('DBN_POOL_ARGMAX', '1') == '1'
+    _pool_arg_generation = -1
     fpn_structured = True  # FPN output conv per upsample level (forward and backward) instead of over the concat
     fpn_one_launch = True  # forward: the four levels in one launch (dbn_pyramid_conv_f32) instead of four accumulating ones
     fpn_exact = False  # set by forward(): the levels are exact 1, 1/2, 1/4, 1/8 sizes, so the structured path applies

@@ -521,6 +521,18 @@ int dbn_maxpool_bwd_parts(int N, int H, int W, int C);
 int dbn_bnrelu_maxpool_bwd_t(int at, const void* y, const float* scale, const float* shift, const void* pooled, const void* dpool,
                              void* dz, int N, int H, int W, int C, const float* bn_mean, const float* bn_rstd, float* bn_part,
                              void* stream);
+/* The stem's pool with a RECORDED argmax (replaces nn.MaxPool2d(3, 2, 1) over relu(bn1(conv1(x))) and its autograd,
+ * /root/reference/src/modules/resnet.py:167-172,231-235).  Forward: out as dbn_bnrelu_maxpool_fwd_t, plus idx [N,Ho,Wo,C] bytes — the position
+ * 3 r + q of the window's FIRST maximum in scan order (PyTorch's rule), 15 where the pooled value is 0 — and ypool [N,Ho,Wo,C] (storage type),
+ * the pre-BatchNorm value y at that position.  Backward: dy [N,H,W,C] = gradient at y given dpool, through pool, ReLU and the train-mode
+ * BatchNorm, in one pass over y (the BatchNorm's two channel sums come from the pooled tensors); dgamma / dbeta are written (x grad_scale).
+ * Needs 256 % (C/4) == 0; ws: dbn_maxpool_bn_backward_ws_floats(N,H,W,C) floats. */
+int dbn_bnrelu_maxpool_fwd_arg_t(int at, const void* y, const float* scale, const float* shift, void* out, void* idx, void* ypool, int N, int H,
+                                 int W, int C, void* stream);
+long dbn_maxpool_bn_backward_ws_floats(int N, int H, int W, int C);
+int dbn_maxpool_bn_backward_t(int at, const void* y, const void* dpool, const void* idx, const void* ypool, const float* save_mean,
+                              const float* save_rstd, const float* gamma, void* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                              float grad_scale, float* ws, void* stream);
 int dbn_nearest_up_fwd_t(int at, const void* src, const void* addend, void* dst, int N, int Hs, int Ws, int C, int H, int W, int Cdst,
                          int coff, void* stream);
 int dbn_nearest_up_bwd_t(int at, const void* dbig, void* dsrc, int N, int Hs, int Ws, int C, int H, int W, int Cbig, int coff,

@@ -1163,3 +1163,40 @@ def test_eval_with_folded_batchnorm_equals_the_unfolded_chain(math, arch, n, h, 
         a2, b2 = run(True), run(False)
         close('folded vs unfolded after a train step', a2.cpu(), b2.cpu())
         assert not torch.equal(a2, a)
+
+
+def test_stem_backward_from_the_recorded_argmax_against_the_two_pass_form():
+    """engine.pool_argmax (late in round 5): the stem's pool records its argmax in the forward pass and the backward goes from dpool to the
+    gradient at the conv output in one pass (dbn_maxpool_bn_backward_t) — against round 4's max-pool backward + BatchNorm backward pair.
+    fp32, a random image (no exact ties): the same gradients to rounding.  bf16: the pair gives a window's gradient to EVERY position that
+    ties with the maximum (frequent with 8 mantissa bits), the new form to the first one as nn.MaxPool2d does — so the two differ, and the
+    new form must not be farther from the fp32 gradients than the old one.  Forward results are the same code."""
+    seed = 21
+    img, gts = O.synthetic_batch(2, 96, seed=seed)
+    keys = ('backbone.conv1.weight', 'backbone.bn1.weight', 'backbone.bn1.bias')
+    res = {}
+    for math in ('f32', 'bf16'):
+        for arg in (False, True):
+            model = make_model(seed, 'resnet18').train()
+            model.engine.set_conv_math(math)
+            model.engine.pool_argmax = arg
+            tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+            preds, losses = tr.step(img.to(DEV), gts.to(DEV))
+            torch.cuda.synchronize()
+            eng = model.engine
+            stem = {k: eng.grad_views[k].clone().double() for k in keys}
+            res[(math, arg)] = (eng.flat_grad.clone().double(), preds.clone().double(), losses.clone().double(), stem)
+    for math in ('f32', 'bf16'):
+        assert torch.equal(res[(math, False)][1], res[(math, True)][1]) and torch.equal(res[(math, False)][2], res[(math, True)][2])
+    g0, g1 = res[('f32', False)][0], res[('f32', True)][0]
+    assert float((g0 - g1).norm() / g0.norm()) <= 1e-5
+    for k in keys:
+        a, b = res[('f32', False)][3][k], res[('f32', True)][3][k]
+        rel = float((a - b).norm() / a.norm())
+        print('f32 %s: two-pass vs recorded argmax %.3e' % (k, rel))
+        assert rel <= 1e-5, (k, rel)
+        ref = b
+        d_old = float((res[('bf16', False)][3][k] - ref).norm() / ref.norm())
+        d_new = float((res[('bf16', True)][3][k] - ref).norm() / ref.norm())
+        print('bf16 %s: distance to the fp32 gradient %.3e (every tie) / %.3e (first maximum)' % (k, d_old, d_new))
+        assert d_new <= 1.1 * d_old + 1e-3, (k, d_old, d_new)

@@ -2289,3 +2289,82 @@ def test_conv_transpose_2x2_16bit_kernel(N, H, W, with_bias, at):
     report('convt16 BN rstd', rs.cpu(), 1.0 / torch.sqrt(var + 1e-5), 1e-5, 1e-4)
     n = N * 4 * H * W
     report('convt16 BN running var', rv.cpu(), 0.9 + 0.1 * var * n / (n - 1), 1e-6, 1e-4)
+
+
+@pytest.mark.parametrize('at', [0, 1])
+@pytest.mark.parametrize('N,H,W,ties', [(2, 16, 16, False), (1, 17, 23, False), (3, 32, 48, True), (2, 9, 14, True)])
+def test_stem_pool_with_recorded_argmax_and_its_backward_through_the_batchnorm(N, H, W, ties, at):
+    """Late in round 5, csrc/pointwise.hip (dbn_bnrelu_maxpool_fwd_arg_t, dbn_maxpool_bn_backward_t): MaxPool2d(3, 2, 1) over
+    relu(bn1(y)) of resnet.py:231-235 with the window's FIRST maximum recorded, and the gradient at the conv output y through pool, ReLU and the
+    train-mode BatchNorm in one pass — against torch's autograd in fp64 (nn.MaxPool2d routes a window's gradient to its first maximum).
+    ties: y quantised to a few levels, so that most windows hold several equal maxima (and whole windows of zeros after the ReLU) —
+    the case in which round 4's kernel pair (a gradient to EVERY tying position) differs from the reference."""
+    C = 64
+    dt = {0: torch.float32, 1: torch.bfloat16}[at]
+    y = rnd(N, C, H, W, seed=1)
+    if ties:
+        y = torch.round(y * 2) / 2
+    y = y.to(dt).double()  # the operand as stored
+    gamma, beta = (rnd(C, seed=2) * 0.3 + 1).double(), (rnd(C, seed=3) * 0.3).double()
+    if ties:
+        gamma[::7] = -gamma[::7]  # negative scales: the maximum of z is not the maximum of y
+    yr = y.clone().requires_grad_(True)
+    mean = yr.mean((0, 2, 3), keepdim=True)
+    var = yr.var((0, 2, 3), unbiased=False, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    z = F.relu((yr - mean) * rstd * gamma.view(1, C, 1, 1) + beta.view(1, C, 1, 1))
+    pool_ref = F.max_pool2d(z, 3, 2, 1)
+    dp = rnd(*pool_ref.shape, seed=4).to(dt).double()
+    dy_ref, = torch.autograd.grad(pool_ref, yr, dp)
+    xh = ((y - mean) * rstd).detach()
+    # forward operands exactly as the engine hands them over: scale / shift (fp32), saved mean / rstd (fp32)
+    meanf, rstdf = mean.detach().view(C).float(), rstd.detach().view(C).float()
+    scale = (gamma.float() * rstdf)
+    shift = beta.float() - meanf * scale
+    Ho, Wo = pool_ref.shape[2:]
+    ys = nhwc(y.float()).to(dt)
+    scd, shd, meand, rstdd, gammad = scale.to(DEV), shift.to(DEV), meanf.to(DEV), rstdf.to(DEV), gamma.float().to(DEV)
+    pool = torch.full((N, Ho, Wo, C), float('nan'), device=DEV, dtype=dt)
+    ypool = torch.full((N, Ho, Wo, C), float('nan'), device=DEV, dtype=dt)
+    idx = torch.full((N, Ho, Wo, C), 77, device=DEV, dtype=torch.uint8)
+    _lib.check(L().dbn_bnrelu_maxpool_fwd_arg_t(at, ys.data_ptr(), scd.data_ptr(), shd.data_ptr(), pool.data_ptr(), idx.data_ptr(),
+                                                ypool.data_ptr(), N, H, W, C, stream()), 'pool fwd arg')
+    tol = {0: 1e-5, 1: 2.0**-7}[at]
+    report('pool fwd (argmax form)', nchw(pool.float()), pool_ref.detach(), tol, tol)
+    # the same pooled values as the kernel without the record
+    pool2 = torch.full_like(pool, float('nan'))
+    _lib.check(L().dbn_bnrelu_maxpool_fwd_t(at, ys.data_ptr(), scd.data_ptr(), shd.data_ptr(), pool2.data_ptr(), N, H, W, C, stream()),
+               'pool fwd')
+    assert torch.equal(pool, pool2)
+    codes = idx.cpu()
+    assert int(((codes > 8) & (codes != 15)).sum()) == 0
+    assert bool(((codes == 15) == (pool.float().cpu() == 0)).all())
+    # the recorded position holds the recorded y, and that y gives the pooled value
+    yc = y.float()
+    n_, oh, ow, c_ = torch.meshgrid(torch.arange(N), torch.arange(Ho), torch.arange(Wo), torch.arange(C), indexing='ij')
+    live = codes != 15
+    ih = (2 * oh - 1 + (codes // 3).long())[live]
+    iw = (2 * ow - 1 + (codes % 3).long())[live]
+    assert bool(((ih >= 0) & (ih < H) & (iw >= 0) & (iw < W)).all())
+    assert torch.equal(yc[n_[live], c_[live], ih, iw], ypool.float().cpu()[live])
+    # backward
+    dps = nhwc(dp.float()).to(dt)
+    dy = torch.full((N, H, W, C), float('nan'), device=DEV, dtype=dt)
+    dgamma, dbeta = torch.full((C, ), float('nan'), device=DEV), torch.full((C, ), float('nan'), device=DEV)
+    ws = torch.full((L().dbn_maxpool_bn_backward_ws_floats(N, H, W, C), ), float('nan'), device=DEV)
+    _lib.check(L().dbn_maxpool_bn_backward_t(at, ys.data_ptr(), dps.data_ptr(), idx.data_ptr(), ypool.data_ptr(), meand.data_ptr(),
+                                             rstdd.data_ptr(), gammad.data_ptr(), dy.data_ptr(), dgamma.data_ptr(),
+                                             dbeta.data_ptr(), N, H, W, C, 1.0, ws.data_ptr(), stream()), 'pool + bn bwd')
+    g_ref, = torch.autograd.grad(F.max_pool2d(z, 3, 2, 1), z, dp, retain_graph=True)
+    g_ref = (g_ref * (z > 0)).detach()
+    scale_g = float(dy_ref.abs().max())
+    btol = {0: 2e-5, 1: 2.0**-7}[at]
+    report('dy through pool, relu, bn', nchw(dy.float()), dy_ref, btol * scale_g, btol)
+    report('dgamma', dgamma.cpu(), (g_ref * xh).sum((0, 2, 3)), 1e-4 * float((g_ref * xh).sum((0, 2, 3)).abs().max()) + 1e-5, 1e-4)
+    report('dbeta', dbeta.cpu(), g_ref.sum((0, 2, 3)), 1e-4 * float(g_ref.sum((0, 2, 3)).abs().max()) + 1e-5, 1e-4)
+    # run-to-run bit identity
+    dy2 = torch.full_like(dy, float('nan'))
+    _lib.check(L().dbn_maxpool_bn_backward_t(at, ys.data_ptr(), dps.data_ptr(), idx.data_ptr(), ypool.data_ptr(), meand.data_ptr(),
+                                             rstdd.data_ptr(), gammad.data_ptr(), dy2.data_ptr(), dgamma.data_ptr(),
+                                             dbeta.data_ptr(), N, H, W, C, 1.0, ws.data_ptr(), stream()), 'pool + bn bwd')
+    assert torch.equal(dy, dy2)
