@@ -614,9 +614,13 @@ __global__ void bnrelu_maxpool_bwd_kernel(const void* __restrict__ y, const floa
 // writes dy = gamma rstd (g - c1 - xhat c2) directly.  (The kernels above give the gradient to EVERY position that ties with the maximum and
 // therefore cannot take their sums from the pooled side.)
 template <int AT, int QW>
-__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void* __restrict__ y, const float* __restrict__ sc, const float* __restrict__ sh,
-                                              void* __restrict__ out, unsigned* __restrict__ idx, void* __restrict__ ypool, int N, int H, int W,
-                                              int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void* __restrict__ y, const float* __restrict__ sc,
+                                                                     const float* __restrict__ sh, void* __restrict__ out,
+                                                                     unsigned* __restrict__ idx, void* __restrict__ ypool, int N, int H, int W,
+                                                                     int C, int Ho, int Wo) {
+    // One thread: the channel quad(s) of two vertically adjacent outputs (rows 2k, 2k+1), as bnrelu_maxpool_fwd_kernel: the 5 input rows are
+    // read once; row 2 belongs to both windows.  Each loaded value updates the window maxima directly, in scan order (strictly greater: the
+    // first maximum keeps the window).
     static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
     const int cin = C / (4 * QW);
     const int Hp = (Ho + 1) >> 1;
@@ -650,14 +654,6 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void*
         for (int r = 0; r < 5; ++r) {
             const int ih = 4 * k - 1 + r;
             if ((unsigned)ih >= (unsigned)H) continue;
-            f32x4 rm[QW], ry[QW];
-            unsigned rq[QW];
-#pragma unroll
-            for (int q = 0; q < QW; ++q) {
-                rm[q] = f32x4{-1.f, -1.f, -1.f, -1.f};
-                ry[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rq[q] = 0u;
-            }
 #pragma unroll
             for (int qq = 0; qq < 3; ++qq) {
                 const int iw = ow * 2 - 1 + qq;
@@ -669,29 +665,18 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float z = dbn_affine_relu(v[q][e], s[q][e], h[q][e]);
-                        if (z > rm[q][e]) {  // strictly greater: the first maximum of the row keeps it
-                            rm[q][e] = z;
-                            ry[q][e] = v[q][e];
-                            rq[q] = (rq[q] & ~(0xFFu << (8 * e))) | ((unsigned)qq << (8 * e));
+                        if (r <= 2 && z > m0[q][e]) {
+                            m0[q][e] = z;
+                            y0[q][e] = v[q][e];
+                            c0[q] = (c0[q] & ~(0xFFu << (8 * e))) | ((unsigned)(3 * r + qq) << (8 * e));
+                        }
+                        if (r >= 2 && z > m1[q][e]) {
+                            m1[q][e] = z;
+                            y1[q][e] = v[q][e];
+                            c1[q] = (c1[q] & ~(0xFFu << (8 * e))) | ((unsigned)(3 * (r - 2) + qq) << (8 * e));
                         }
                     }
             }
-#pragma unroll
-            for (int q = 0; q < QW; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned col = (rq[q] >> (8 * e)) & 0xFFu;
-                    if (r <= 2 && rm[q][e] > m0[q][e]) {
-                        m0[q][e] = rm[q][e];
-                        y0[q][e] = ry[q][e];
-                        c0[q] = (c0[q] & ~(0xFFu << (8 * e))) | ((3u * r + col) << (8 * e));
-                    }
-                    if (r >= 2 && rm[q][e] > m1[q][e]) {
-                        m1[q][e] = rm[q][e];
-                        y1[q][e] = ry[q][e];
-                        c1[q] = (c1[q] & ~(0xFFu << (8 * e))) | ((3u * (r - 2) + col) << (8 * e));
-                    }
-                }
         }
 #pragma unroll
         for (int q = 0; q < QW; ++q)
@@ -754,15 +739,21 @@ __global__ __launch_bounds__(256) void maxpool_bn_stats_kernel(const void* __res
 // dy[n,ih,iw,c] = gamma rstd (g - c1 - xhat c2), g = the sum of dpool over the windows whose recorded first maximum is (ih, iw).
 // One thread: a channel quad of a 2 x 2 block of input pixels (rows 2a, 2a+1, columns 2b, 2b+1), which lies in the windows
 // (a..a+1) x (b..b+1) only; pixel (2a + dy, 2b + dx) is position (dy - 2u + 1, dx - 2w + 1) of window (a + u, b + w).
-template <int AT>
+template <int AT, int QW>
 __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const void* __restrict__ y, const void* __restrict__ dpool,
                                                                    const unsigned* __restrict__ idx, const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
                                                                    void* __restrict__ dy, int N, int H, int W, int C, int Ho, int Wo) {
-    const int cin = C / 4;
+    // QW = 2 (16-bit storage, C % 8 == 0): eight channels per 16-byte access
+    static_assert(QW == 1 || (QW == 2 && AT != 0), "two quads per access: 16-bit storage");
+    const int cin = C / (4 * QW);
     const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
     const long total = (long)N * Hb * Wb * cin;
+    auto ld = [&](const void* ptr, long i, f32x4 (&v)[QW]) {
+        if constexpr (QW == 1) v[0] = dbn_ld4<AT>(ptr, i);
+        else dbn_ldq<AT>(ptr, i, v);
+    };
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int ci = (int)(i % cin);
         long t = i / cin;
@@ -770,21 +761,32 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const void* _
         t /= Wb;
         const int a = (int)(t % Hb);
         const int n = (int)(t / Hb);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + 4 * ci), rs = *reinterpret_cast<const f32x4*>(rstd + 4 * ci);
-        const f32x4 k1 = *reinterpret_cast<const f32x4*>(c1 + 4 * ci), k2 = *reinterpret_cast<const f32x4*>(c2 + 4 * ci);
-        const f32x4 gr = *reinterpret_cast<const f32x4*>(gamma + 4 * ci) * rs;
-        f32x4 dp[2][2];
-        unsigned cd[2][2];
+        f32x4 mu[QW], rs[QW], k1[QW], k2[QW], gr[QW];
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+            const int c = 4 * (QW * ci + q);
+            mu[q] = *reinterpret_cast<const f32x4*>(mean + c);
+            rs[q] = *reinterpret_cast<const f32x4*>(rstd + c);
+            k1[q] = *reinterpret_cast<const f32x4*>(c1 + c);
+            k2[q] = *reinterpret_cast<const f32x4*>(c2 + c);
+            gr[q] = *reinterpret_cast<const f32x4*>(gamma + c) * rs[q];
+        }
+        f32x4 dp[2][2][QW];
+        unsigned cd[2][2][QW];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                dp[u][w] = f32x4{0.f, 0.f, 0.f, 0.f};
-                cd[u][w] = 0x0F0F0F0Fu;  // (no window there: no position matches)
+#pragma unroll
+                for (int q = 0; q < QW; ++q) {
+                    dp[u][w][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    cd[u][w][q] = 0x0F0F0F0Fu;  // (no window there: no position matches)
+                }
                 if (a + u < Ho && b + w < Wo) {
                     const long o = (((long)n * Ho + a + u) * Wo + b + w) * cin + ci;
-                    dp[u][w] = dbn_ld4<AT>(dpool, o);
-                    cd[u][w] = idx[o];
+                    ld(dpool, o, dp[u][w]);
+#pragma unroll
+                    for (int q = 0; q < QW; ++q) cd[u][w][q] = idx[o * QW + q];
                 }
             }
 #pragma unroll
@@ -794,19 +796,25 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const void* _
                 const int ih = 2 * a + dy_, iw = 2 * b + dx_;
                 if (ih >= H || iw >= W) continue;
                 const long pi = (((long)n * H + ih) * W + iw) * cin + ci;
-                const f32x4 v = dbn_ld4<AT>(y, pi);
-                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+                f32x4 v[QW], d[QW];
+                ld(y, pi, v);
 #pragma unroll
-                for (int u = 0; u <= dy_; ++u)
+                for (int q = 0; q < QW; ++q) {
+                    f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int w = 0; w <= dx_; ++w) {
-                        const unsigned code = 3u * (unsigned)(dy_ - 2 * u + 1) + (unsigned)(dx_ - 2 * w + 1);
+                    for (int u = 0; u <= dy_; ++u)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (((cd[u][w] >> (8 * e)) & 0xFFu) == code) g[e] += dp[u][w][e];
-                    }
-                const f32x4 xh = (v - mu) * rs;
-                dbn_st4<AT>(dy, pi, gr * (g - k1 - xh * k2));
+                        for (int w = 0; w <= dx_; ++w) {
+                            const unsigned code = 3u * (unsigned)(dy_ - 2 * u + 1) + (unsigned)(dx_ - 2 * w + 1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (((cd[u][w][q] >> (8 * e)) & 0xFFu) == code) g[e] += dp[u][w][q][e];
+                        }
+                    const f32x4 xh = (v[q] - mu[q]) * rs[q];
+                    d[q] = gr[q] * (g - k1[q] - xh * k2[q]);
+                }
+                if constexpr (QW == 1) dbn_st4<AT>(dy, pi, d[0]);
+                else dbn_stq<AT>(dy, pi, d);
             }
     }
 }
@@ -1372,6 +1380,9 @@ int dbn_bnrelu_maxpool_fwd_arg_t(int at, const void* y, const float* scale, cons
                                            (hipStream_t)stream, y, scale, shift, out, ix, ypool, N, H, W, C, Ho, Wo));
     return dbn_status();
 }
+#ifndef DBN_POOL_APPLY_QW2
+#define DBN_POOL_APPLY_QW2 1  // 16-bit storage: the apply pass with 16-byte accesses (A/B switch)
+#endif
 static int maxpool_bn_parts(int N, int Ho, int Wo, int C) { return dbn_grid((long)N * Ho * Wo * (C / 4), 256, 2048); }
 // floats of scratch dbn_maxpool_bn_backward_t needs
 long dbn_maxpool_bn_backward_ws_floats(int N, int H, int W, int C) {
@@ -1401,8 +1412,18 @@ int dbn_maxpool_bn_backward_t(int at, const void* y, const void* dpool, const vo
             hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C), dim3(256), 0, st, part, parts, M, C, dgamma, dbeta, c1, c2, grad_scale);
         else
             hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dbn_ceil_div(C, 8)), dim3(256), 0, st, part, parts, M, C, dgamma, dbeta, c1, c2, grad_scale);
-        hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel<AT>, agrid, dim3(256), 0, st, y, dpool, ix, save_mean, save_rstd, gamma, c1, c2, dy, N, H, W, C, Ho,
-                           Wo);
+        bool wide = false;
+        if constexpr (AT != 0) {
+            if (DBN_POOL_APPLY_QW2 && C % 8 == 0) {
+                wide = true;
+                const dim3 wgrid(dbn_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8)));
+                hipLaunchKernelGGL((maxpool_bn_bwd_apply_kernel<AT, 2>), wgrid, dim3(256), 0, st, y, dpool, ix, save_mean, save_rstd, gamma, c1, c2, dy, N,
+                                   H, W, C, Ho, Wo);
+            }
+        }
+        if (!wide)
+            hipLaunchKernelGGL((maxpool_bn_bwd_apply_kernel<AT, 1>), agrid, dim3(256), 0, st, y, dpool, ix, save_mean, save_rstd, gamma, c1, c2, dy, N, H,
+                               W, C, Ho, Wo);
     });
     return dbn_status();
 }
