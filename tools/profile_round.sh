@@ -4,6 +4,16 @@
 # Writes gpurun_out/<tag>/: kernel_stats.md (rocprofv3 --kernel-trace of bench.py), step_breakdown.txt, pmc_traffic.json (two PMC
 # passes), bench_under_rocprof.json, bench_n1.json, kernel stats + bench lines for --math bf16 and bf16x3; copy the summaries into profiles/.
 set -u
+# fastest_step <db>: of the timed steps 5..9 the one with the shortest span (under the tracer a single step can be host-paced — the 16-bit
+# step is about as long as its own enqueue — and a dump of that one would show idle gaps that the un-profiled run does not have)
+fastest_step() {
+  local best=6 bestus=999999999
+  for k in 5 6 7 8 9; do
+    us=$(python3 tools/dump_step.py $1 $k 2>/dev/null | head -1 | sed -n 's/^step [0-9]*: \([0-9]*\)\..*/\1/p')
+    if [ -n "$us" ] && [ "$us" -lt "$bestus" ]; then bestus=$us; best=$k; fi
+  done
+  echo $best
+}
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -15,7 +25,8 @@ rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o r01 -- python3 $R/bench.py --steps
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A > $O/pmc_write.log 2>&1
 cd $R
 python3 tools/rocpd_stats.py $O/trace/r01_results.db $O/kernel_stats.md > /dev/null
-python3 tools/step_breakdown.py $O/trace/r01_results.db 6 > $O/step_breakdown.txt 2>&1
+K32=$(fastest_step $O/trace/r01_results.db)
+python3 tools/step_breakdown.py $O/trace/r01_results.db $K32 > $O/step_breakdown.txt 2>&1
 python3 tools/pmc_traffic.py $O/pmc_fetch/r01_results.db $O/pmc_write/r01_results.db $O/pmc_traffic.json > /dev/null
 grep '^{"metric"' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
 cp $O/pmc_traffic.json profiles/${TAG}_pmc_traffic.json   # bench.py reads the per-kernel traffic of the newest round from profiles/
@@ -31,7 +42,8 @@ rocprofv3 --kernel-trace -d $O/trace_x3 -o r01 -- python3 $R/bench.py --steps 10
 cd $R
 python3 tools/rocpd_stats.py $O/trace_x3/r01_results.db $O/kernel_stats_bf16x3.md > /dev/null
 grep '^{"metric"' $O/bench_bf16x3_under_rocprof.log > $O/bench_bf16x3_under_rocprof.json
-python3 tools/step_breakdown.py $O/trace_bf16/r01_results.db 6 > $O/step_breakdown_bf16.txt 2>&1
+K16=$(fastest_step $O/trace_bf16/r01_results.db)
+python3 tools/step_breakdown.py $O/trace_bf16/r01_results.db $K16 > $O/step_breakdown_bf16.txt 2>&1
 for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline and parity object
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-modes --math $m 2>/dev/null | grep '^{"metric"' > $O/bench_n1_$m.json
 done
@@ -50,7 +62,7 @@ cd /tmp   # the inference configuration (BASELINE configs[4]) kernel by kernel
 rocprofv3 --kernel-trace -d $O/trace_eval -o r01 -- python3 $R/tools/cfg_timing.py resnet18 32 1280 fp16 10 eval > $O/eval_fp16.log 2>&1
 cd $R
 python3 tools/rocpd_stats.py $O/trace_eval/r01_results.db $O/kernel_stats_eval_fp16.md > /dev/null
-python3 tools/dump_step.py $O/trace/r01_results.db 6 > $O/step_dump.txt 2>&1
-python3 tools/dump_step.py $O/trace_bf16/r01_results.db 6 > $O/step_dump_bf16.txt 2>&1
+python3 tools/dump_step.py $O/trace/r01_results.db $K32 > $O/step_dump.txt 2>&1
+python3 tools/dump_step.py $O/trace_bf16/r01_results.db $K16 > $O/step_dump_bf16.txt 2>&1
 rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3 $O/trace_eval   # the DBs are large; the summaries above are what is kept
 ls -la $O
