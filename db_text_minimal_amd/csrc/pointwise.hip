@@ -702,6 +702,9 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_arg_kernel(const void*
     }
 }
 
+#ifndef DBN_POOL_STATS_UNROLL
+#define DBN_POOL_STATS_UNROLL 1  // (fp32 729.1 -> 732.2 images/s over three interleaved pairs, bf16 unchanged; same summation order)
+#endif
 // part[2 * C][gridDim.x]: per-block sums of g and g * xhat over the POOLED elements (g = dpool where the code is not 15); threads t, t + C/4, ...
 // of a block hold the same channel quad (256 % (C/4) == 0, host side)
 template <int AT>
@@ -713,15 +716,31 @@ __global__ __launch_bounds__(256) void maxpool_bn_stats_kernel(const void* __res
     const int c = (int)(i0 % cin) * 4;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
-    for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
-        const f32x4 dp = dbn_ld4<AT>(dpool, i), yp = dbn_ld4<AT>(ypool, i);
-        const unsigned code = idx[i];
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto add = [&](const f32x4& dp, const f32x4& yp, unsigned code) {
         f32x4 g;
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = ((code >> (8 * e)) & 0xFFu) != 15u ? dp[e] : 0.f;
         s1 += g;
         s2 += g * ((yp - mu) * rs);
+    };
+    long i = i0;
+#if DBN_POOL_STATS_UNROLL
+    // four items (twelve loads) in flight per thread: beside the last weight-gradient kernel of the step this pass gets few wave slots
+    for (; i + 3 * stride < total; i += 4 * stride) {
+        f32x4 dp[4], yp[4];
+        unsigned code[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dp[k] = dbn_ld4<AT>(dpool, i + k * stride);
+            yp[k] = dbn_ld4<AT>(ypool, i + k * stride);
+            code[k] = idx[i + k * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) add(dp[k], yp[k], code[k]);
     }
+#endif
+    for (; i < total; i += stride) add(dbn_ld4<AT>(dpool, i), dbn_ld4<AT>(ypool, i), idx[i]);
     __shared__ f32x4 red[2][256];
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
