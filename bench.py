@@ -47,7 +47,8 @@ TRAIN_GFLOP_PER_IMAGE = 236.75  # fwd + dgrad + wgrad, no stem d
 # what the matrix pipe computes per conv math mode: dtype of the JSON line, wording of the workload, MFMA peak that bounds it
 # (bf16x3 evaluates six bf16 products per fp32 product: its roofline is the bf16 peak / 6)
 MATH = {
-    'f32': ('f32', 'fp32 (exact-fp32 MFMA)', PEAK_F32_MFMA_TFLOPS),
+    'f32': ('f32', 'fp32 (exact-fp32 MFMA products; 3x3/s1 convs and their data / weight gradients: Winograd F(2x2,3x3) in fp32)',
+            PEAK_F32_MFMA_TFLOPS),
     'bf16x3': ('bf16x3', 'fp32 tensors, conv products on the bf16 matrix pipe as an exact 3-way operand split (fp32-accurate)',
                PEAK_BF16_MFMA_TFLOPS / 6.0),
     'bf16': ('bf16', 'native bf16: activations, gradients and weight panels stored in bf16, bf16 MFMA, fp32 accumulate / BN statistics / '
@@ -75,10 +76,11 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(max_seconds=30.0, n16_budget_s=60.0):
-    """Oracle train step (fwd + DBLoss + backward + Adam) on the host cores: BASELINE configs[0]'s shape
-    (2x3x640x640; 1 warm-up + up to 3 timed steps, median) and ONE step at the benchmarked batch (16x3x640x640, no warm-up;
-    skipped when the N = 2 timing predicts more than `n16_budget_s`)."""
+def cpu_baseline(max_seconds=30.0, n16_budget_s=120.0):
+    """Oracle train step (fwd + DBLoss + backward + Adam) on the host cores (SURVEY.md §8d / BASELINE.md §4): BASELINE
+    configs[0]'s shape (2x3x640x640; 1 warm-up + up to 3 timed steps, median) and the benchmarked batch (16x3x640x640): 1 warm-up +
+    3 timed steps, median (fewer timed steps when the N = 2 timing predicts more than `n16_budget_s` for the four; none when one
+    step alone would exceed it)."""
     from oracle import dbnet_oracle as O
     threads = torch.get_num_threads()
     n, size = 2, 640
@@ -103,11 +105,25 @@ def cpu_baseline(max_seconds=30.0, n16_budget_s=60.0):
     predicted = 8.0 * med
     if predicted <= n16_budget_s:
         img16, gts16 = O.synthetic_batch(16, size, seed=42)
-        t0 = time.time()
-        O.train_step(sd, opt, img16, gts16)
-        t16 = time.time() - t0
+        t_all = time.time()
+        O.train_step(sd, opt, img16, gts16)  # warm-up (allocator, thread pool at this shape)
+        t16s = []
+        for _ in range(3):
+            t0 = time.time()
+            O.train_step(sd, opt, img16, gts16)
+            t16s.append(time.time() - t0)
+            if time.time() - t_all + t16s[-1] > n16_budget_s:
+                break
+        t16s.sort()
+        t16 = t16s[len(t16s) // 2]
         out['n16'] = {'value': round(16 / t16, 4), 'skipped': False, 'unit': 'images/s', 'seconds': round(t16, 2),
-                      'sample': 'one train step of the CPU oracle at 16x3x640x640 fp32 (the benchmarked batch), no warm-up'}
+                      'seconds_all': [round(t, 2) for t in t16s],
+                      'sample': '1 warm-up + %d timed train steps of the CPU oracle at 16x3x640x640 fp32 (the benchmarked batch), '
+                                'median' % len(t16s)}
+        # the line's baseline figure is the one on the benchmarked workload; BASELINE configs[0]'s shape stays beside it
+        out['n2'] = {'value': out['value'], 'unit': 'images/s', 'sample': out['sample']}
+        out['value'] = out['n16']['value']
+        out['sample'] = out['n16']['sample'] + '; torch CPU threads=%d' % threads
     else:
         out['n16'] = {'value': None, 'skipped': True,
                       'why': 'predicted %.0f s per step on this host (> %.0f s budget)' % (predicted, n16_budget_s)}
@@ -136,7 +152,9 @@ def parity_gate(dev, math):
     model = model.to(dev).train()
     model.engine.set_conv_math(math)
     img, gts = fx.synthetic_batch(n, size, seed=seed + 100)
-    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    # distributed=False: the gate is a rank-local computation — with N > 1 ranks the process group is up already, and a trainer
+    # that joined it would issue its start-up broadcasts and a gradient all-reduce that no other rank answers
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005), distributed=False)
     preds, losses = tr.step(img.to(dev), gts.to(dev))
     torch.cuda.synchronize()
     maps_err, maps_worst, l2_rel, maps_mean = 0.0, 0.0, 0.0, 0.0
@@ -157,11 +175,14 @@ def parity_gate(dev, math):
     # two 16-bit evaluations of one net, and in train mode at random-init weights the approximate-binary map differs by ~3e-2 on average
     # (the reference under autocast shows the same, DESIGN section 4: that mode's yardstick is tests/test_model_gpu.py's fp64-distance
     # test) — here the five losses are held to 2 % and the map distances are reported
-    ok = bool(maps_worst <= 1.0 and loss_worst <= 1.0) if exact else bool(maps_mean == maps_mean and float((lerr / lref.abs()).max()) <= 2e-2)
+    # AND gated on loose numeric bounds — mean map error 5e-2 (measured 3.0e-2), L2 norm of each map within 2e-2 (measured 5e-5) — so
+    # that ok = true means more than "finite": a wrong 16-bit map path moves both by far more
+    ok = (bool(maps_worst <= 1.0 and loss_worst <= 1.0) if exact else
+          bool(maps_mean <= 5e-2 and l2_rel <= 2e-2 and float((lerr / lref.abs()).max()) <= 2e-2))
     out = {'golden': 'cfg2_16x640 (the reference\'s train step at 16x3x640x640, tests/golden/make_golden.py --only-cfg2)',
            'maps_max_err': float('%.3e' % maps_err), 'maps_tol': '1e-3 abs + 1e-2 rel on 3 x 4096 strided samples (north_star)',
            'maps_worst_err_over_tol': round(maps_worst, 4), 'maps_mean_err': float('%.3e' % maps_mean), 'maps_l2_rel_err': float('%.3e' % l2_rel),
-           'loss_max_err': float('%.3e' % float(lerr.max())), 'loss_tol': '1e-5 abs + 1e-5 rel on the five losses' if exact else '2e-2 rel (16-bit storage; map distances reported, bounded by the fp64-distance test instead)',
+           'loss_max_err': float('%.3e' % float(lerr.max())), 'loss_tol': '1e-5 abs + 1e-5 rel on the five losses' if exact else '2e-2 rel; maps gated at mean err <= 5e-2 and L2-norm rel err <= 2e-2 (16-bit storage: single pixels flip through k = 50; the fp64-distance test is the yardstick)',
            'conv_math': math, 'ok': ok}
     del tr, model, preds, losses
     torch.cuda.empty_cache()
@@ -201,7 +222,7 @@ def self_launch(args):
     """--gpus N > 1 without a torch.distributed.run environment: start the N ranks as a FRESH child process (never an exec:
     this process may not have touched the GPU yet, and must not need to), forward rank 0's JSON line, return the child's code.
     The reference is single-device (src/train.py:96-98): the whole launcher is this build's."""
-    if args.backend == 'nccl':
+    if args.backend == 'nccl' and os.environ.get('DBN_DIST_ONE_DEVICE', '0') != '1':
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU
         if have < args.gpus:
             print('bench.py: --gpus %d but only %d GPU(s) visible' % (args.gpus, have), file=sys.stderr)
@@ -313,8 +334,9 @@ def main():
     ap.add_argument('--dry', action='store_true', help='launch / rendezvous / exchange plumbing only, no GPU work (CPU test of --gpus N)')
     ap.add_argument('--no-parity', action='store_true', help='skip the cfg2_16x640 parity gate that runs before the timed region')
     args = ap.parse_args()
-    if args.backend != 'nccl' and not args.dry:
-        raise SystemExit('--backend gloo is for --dry runs: the step itself has no CPU path')
+    if args.backend != 'nccl' and not args.dry and os.environ.get('DBN_DIST_ONE_DEVICE', '0') != '1':
+        raise SystemExit('--backend gloo is for --dry runs (the step itself has no CPU path) and for the one-GPU rehearsal of an '
+                         'N-rank run (DBN_DIST_ONE_DEVICE=1: every rank on device 0, device tensors through gloo; tests/test_dist2_gpu.py)')
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:  # nothing has touched the GPU yet
         raise SystemExit(self_launch(args))
@@ -325,7 +347,7 @@ def main():
     from db_text_minimal_amd.engine import KernelTimer
     from db_text_minimal_amd.train import init_distributed
 
-    rank, local, world = init_distributed()
+    rank, local, world = init_distributed(args.backend)
     if world != args.gpus:  # (--gpus N > 1 without WORLD_SIZE was self-launched above: a mismatch here is a wrong external launch)
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     dev = torch.device('cuda', local)
@@ -353,7 +375,8 @@ def main():
 
     def barrier():
         if dist.is_initialized():
-            dist.barrier(device_ids=[local])
+            torch.cuda.synchronize()  # (gloo's barrier knows nothing of the device queue)
+            dist.barrier(device_ids=[local]) if args.backend == 'nccl' else dist.barrier()
         torch.cuda.synchronize()
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch

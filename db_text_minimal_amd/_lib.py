@@ -70,6 +70,7 @@ SIGNATURES = {
     'dbn_db_loss_ws_bytes': '',
     'dbn_db_loss_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
     'dbn_db_loss_sum_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',
+    'dbn_db_loss_frac_fwd': 'pp' + 'iiii' + 'ffff' + 'i' + 'pppp',
     'dbn_db_loss_bwd': 'pppp' + 'ff' + 'iiii' + 'pp',
     'dbn_db_loss_ohem_ws_bytes': 'iii',
     'dbn_db_loss_ohem_fwd': 'pp' + 'iiii' + 'ffff' + 'pppp',

@@ -353,7 +353,7 @@ __global__ void fold_head_grads_kernel(const float* __restrict__ part, int nb, f
 // ----------------------------------------------------------------------------------
 // loss
 // ----------------------------------------------------------------------------------
-enum { S_POS = 0, S_NEG, S_BCE, S_L1, S_A, S_BGM, S_BM, NSUM };
+enum { S_POS = 0, S_NEG, S_BCE, S_L1, S_A, S_BGM, S_BM, S_NONBIN /* pixels whose gt or mask is not 0 / 1 */, NSUM };
 
 // loads/stores of V consecutive floats (V = 4: one 16-byte access when H*W % 4 == 0; V = 1: any size)
 template <int V>
@@ -382,7 +382,10 @@ struct DbLossFinal {
 
 // losses[5] = prob, thresh, binary, prob+beta*thresh, total;  coef[8] for the backward:
 //   0: c_bce = (sum_pos + n_neg)/(n_pos+n_neg+eps)/px   1: 1/(sum_A+eps)
-//   2: dice U   3: dice I   4: has_pos flag (n_pos + n_neg > 0 ... always 1; kept for clarity)
+//   2: dice U   3: dice I   4..6: per-pixel OHEM (ohem_finalize_kernel)
+//   7: number of pixels whose prob_gt or supervision_mask is neither 0 nor 1 — for those the closed form below is NOT the
+//      reference's value (losses.py:33-39 takes topk over loss * negative): the host side reads it and refuses such maps
+//      unless the caller asked for the literal form (dbn_db_loss_frac_fwd)
 __device__ __forceinline__ void db_loss_finish(const double (&s)[NSUM], const DbLossFinal& f) {
     // losses.py:25-28 — int() truncations
     const long n_pos = (long)(float)s[S_POS];
@@ -404,6 +407,7 @@ __device__ __forceinline__ void db_loss_finish(const double (&s)[NSUM], const Db
     losses[1] = thr;
     coef[0] = num_w / denom / (float)bce_div;
     coef[1] = 1.f / ((float)s[S_A] + f.eps);
+    coef[7] = (float)s[S_NONBIN];
     if (f.CH == 3) {
         const float U = (float)s[S_BM] + (float)s[S_POS] + f.eps;
         const float I = (float)s[S_BGM];
@@ -500,6 +504,7 @@ __global__ void db_loss_fwd_kernel(const float* __restrict__ preds, const float*
             s[S_A] += A[e];
             s[S_BGM] += B[e] * G[e] * M[e];
             s[S_BM] += B[e] * M[e];
+            s[S_NONBIN] += (G[e] * (1.f - G[e]) != 0.f || M[e] * (1.f - M[e]) != 0.f) ? 1.f : 0.f;
         }
         if (++cnt == 64) {  // flush the fp32 running sums into doubles regularly
 #pragma unroll
@@ -645,15 +650,17 @@ __global__ void ohem_prepare_kernel(const double* __restrict__ part, int nb, flo
     }
 }
 
-// v[i] = bce_i * negative_i; partial sums of bce_i * positive_i (double, [block])
+// v[i] = bce_i * negative_i; partial sums of bce_i * positive_i (double, [block]).
+// frac (the scalar-BCE reductions on non-binary maps, dbn_db_loss_frac_fwd): v[i] = negative_i alone — the scalar bce >= 0 scales
+// every element alike, so topk(bce * negative, k).sum() = bce * (sum of the k largest negative_i).
 __global__ void ohem_values_kernel(const float* __restrict__ preds, const float* __restrict__ gts, int N, long HW, int CH,
-                                   float* __restrict__ v, double* __restrict__ part) {
+                                   float* __restrict__ v, double* __restrict__ part, int frac) {
     const long total = (long)N * HW, NHW = total;
     double acc = 0.0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long n = i / HW, o = i - n * HW;
-        const float P = preds[n * CH * HW + o], G = gts[i], M = gts[NHW + i];
-        const float l = bce_px(P, G);
+        const float G = gts[i], M = gts[NHW + i];
+        const float l = frac ? 1.f : bce_px(preds[n * CH * HW + o], G);
         v[i] = fabsf(l * ((1.f - G) * M));  // +0 (never -0): the select orders values by their bit pattern
         acc += (double)(l * (G * M));
     }
@@ -734,10 +741,13 @@ __global__ void ohem_sum_kernel(const float* __restrict__ v, long total, const u
 // prob_loss of the per-pixel OHEM; overwrites losses[0], [3], [4] and coef[0], coef[4..6] left by the 'mean' finalize.
 __global__ void ohem_finalize_kernel(const double* __restrict__ part_sums, int nb_sums, const double* __restrict__ part_pos, int nb_pos,
                                      const double* __restrict__ part_sel, int nb_sel, const unsigned long long* __restrict__ st,
-                                     int CH, float alpha, float beta, float eps, float* __restrict__ losses, float* __restrict__ coef) {
+                                     int CH, float alpha, float beta, float eps, float* __restrict__ losses, float* __restrict__ coef,
+                                     int frac, double bce_div) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s_pos = 0.0, pos_loss = 0.0, sel = 0.0, cnt_gt = 0.0;
+    double s_pos = 0.0, pos_loss = 0.0, sel = 0.0, cnt_gt = 0.0, s_bce = 0.0;
     for (int b = 0; b < nb_sums; ++b) s_pos += part_sums[(long)b * NSUM + S_POS];
+    if (frac)
+        for (int b = 0; b < nb_sums; ++b) s_bce += part_sums[(long)b * NSUM + S_BCE];
     for (int b = 0; b < nb_pos; ++b) pos_loss += part_pos[b];
     for (int b = 0; b < nb_sel; ++b) {
         sel += part_sel[2 * b];
@@ -749,7 +759,21 @@ __global__ void ohem_finalize_kernel(const double* __restrict__ part_sums, int n
     const double cnt_eq = (double)st[4];
     const long n_pos = (long)(float)s_pos;
     const float denom = (float)((double)n_pos + k + (double)eps);
-    const float prob = (float)(pos_loss + sel + n_tie * (double)tau) / denom;
+    float prob = (float)(pos_loss + sel + n_tie * (double)tau) / denom;
+    if (frac) {
+        // losses.py:30-39 with a scalar bce: (bce * positive).sum() + topk(bce * negative, k).sum() = bce * (sum_pos + top-k sum);
+        // pos_loss holds sum_pos here (l = 1 in ohem_values_kernel).  The backward stays the scalar-BCE one: coef[0] only.
+        const float bce = (float)(s_bce / bce_div);
+        const float num_w = (float)(pos_loss + sel + n_tie * (double)tau);
+        prob = bce * num_w / denom;
+        const float thr_f = losses[1], pt_f = prob + beta * thr_f;
+        losses[0] = prob;
+        losses[3] = pt_f;
+        losses[4] = (CH == 3 ? alpha * losses[2] : 0.f) + pt_f;
+        coef[0] = num_w / denom / (float)bce_div;
+        coef[7] = 0.f;  // the maps were evaluated literally: nothing to refuse
+        return;
+    }
     const float thr = losses[1];
     const float pt = prob + beta * thr;
     losses[0] = prob;
@@ -900,14 +924,16 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     // 512-thread workgroups (eight waves per SIMD at 1024 workgroups: twice the loads in flight of the 256-thread form)
     const int nb = dbn_grid((long)N * HW / (vec ? 4 : 1), 512, 1024);
     char* base = (char*)ws;
-    DbLossFinal fin = {(long)N * HW, channels, alpha, beta, negative_ratio, eps, per_pixel == 2 ? 1 : 0, losses, coef,
+    // per_pixel: 0 'mean', 1 'none' (per-pixel OHEM), 2 'sum', 3 / 4 'mean' / 'sum' on non-binary maps (literal top-k of negative)
+    const int frac = per_pixel >= 3, bce_sum = (per_pixel == 2 || per_pixel == 4) ? 1 : 0;
+    DbLossFinal fin = {(long)N * HW, channels, alpha, beta, negative_ratio, eps, bce_sum, losses, coef,
                        (unsigned*)(base + DB_LOSS_PART_BYTES)};
     if (hipMemsetAsync(fin.counter, 0, sizeof(unsigned), st) != hipSuccess) return dbn_status();
     if (vec)
         hipLaunchKernelGGL(db_loss_fwd_kernel<4>, dim3(nb), dim3(512), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
     else
         hipLaunchKernelGGL(db_loss_fwd_kernel<1>, dim3(nb), dim3(512), 0, st, preds, gts, N, HW, channels, (double*)ws, fin);
-    if (per_pixel != 1) return dbn_status();
+    if (per_pixel != 1 && !frac) return dbn_status();
     double* part_pos = (double*)(base + OHEM_OFF_POS);
     double* part_sel = (double*)(base + OHEM_OFF_SEL);
     unsigned long long* state = (unsigned long long*)(base + OHEM_OFF_ST);
@@ -916,14 +942,14 @@ static int db_loss_fwd_run(const float* preds, const float* gts, int N, int H, i
     const long total = (long)N * HW;
     const int nbv = dbn_grid(total, 256, 1024);
     hipLaunchKernelGGL(ohem_prepare_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, nb, negative_ratio, state, hist);
-    hipLaunchKernelGGL(ohem_values_kernel, dim3(nbv), dim3(256), 0, st, preds, gts, N, HW, channels, v, part_pos);
+    hipLaunchKernelGGL(ohem_values_kernel, dim3(nbv), dim3(256), 0, st, preds, gts, N, HW, channels, v, part_pos, frac);
     for (int pass = 0; pass < 3; ++pass) {
         hipLaunchKernelGGL(ohem_hist_kernel, dim3(nbv), dim3(256), 0, st, v, total, state, pass, hist);
         hipLaunchKernelGGL(ohem_scan_kernel, dim3(1), dim3(64), 0, st, state, hist, pass);
     }
     hipLaunchKernelGGL(ohem_sum_kernel, dim3(nbv), dim3(256), 0, st, v, total, state, part_sel);
     hipLaunchKernelGGL(ohem_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, part_pos, nbv, part_sel, nbv, state,
-                       channels, alpha, beta, eps, losses, coef);
+                       channels, alpha, beta, eps, losses, coef, frac, bce_sum ? 1.0 : (double)((long)N * HW));
     return dbn_status();
 }
 
@@ -945,6 +971,15 @@ int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int 
 int dbn_db_loss_ohem_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                          float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream) {
     return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, 1, losses, coef, ws, stream);
+}
+
+// DBLoss(reduction='mean' | 'sum') on NON-BINARY prob_gt / supervision_mask maps, literally as losses.py:33-39 evaluates it:
+// bce * (sum(positive) + sum of the n_neg largest negative_i) / (n_pos + n_neg + eps), the top-k sum by the device radix select of
+// the per-pixel OHEM path.  (For binary maps it equals dbn_db_loss_fwd, which needs no select.)  `sum` != 0: reduction='sum'.
+// ws: dbn_db_loss_ohem_ws_bytes(N,H,W) bytes.  Backward: dbn_db_loss_bwd with the coef written here.
+int dbn_db_loss_frac_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                         float negative_ratio, float eps, int sum, float* losses, float* coef, void* ws, void* stream) {
+    return db_loss_fwd_run(preds, gts, N, H, W, channels, alpha, beta, negative_ratio, eps, sum ? 4 : 3, losses, coef, ws, stream);
 }
 
 static int db_loss_bwd_run(const float* preds, const float* gts, const float* coef, const float* grad_losses, const float* ohem_v,

@@ -99,12 +99,22 @@ class BucketedAllReduce:
 
 
 class DBTrainer:
-    def __init__(self, model, criterion, optimizer=None, process_group=None, lr=0.005):
+    def __init__(self, model, criterion, optimizer=None, process_group=None, lr=0.005, distributed=None, gc_freeze=None):
+        """`distributed`: None = data parallel exactly when a process group is initialised (the default group or
+        `process_group`); False = this trainer never touches a process group, whatever the process has initialised (a
+        rank-local side computation beside a data-parallel job: bench.py's parity gate — a trainer that joined the default
+        group there would pair its start-up broadcasts with the other ranks' gradient all-reduce).
+        `gc_freeze`: see freeze_heap(); None reads DBN_GC_FREEZE (default off: a process-wide side effect is the caller's
+        decision — fit() and bench.py take it explicitly)."""
         self.model = model
         self.criterion = criterion
         self.optimizer = optimizer if optimizer is not None else FusedAdam(model, lr=lr)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        have_group = dist.is_available() and dist.is_initialized()
+        self.distributed = have_group if distributed is None else bool(distributed)
+        if self.distributed and not have_group:
+            raise RuntimeError('DBTrainer(distributed=True) needs an initialised process group (train.init_distributed)')
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
         self._gone = None
         # The data-parallel exchange: ONE sum all-reduce of the flat gradient buffer after the backward pass — the step of
         # BASELINE's north_star (reference train.py:169-172 is the sequence being parallelised).  overlap_allreduce = True
@@ -115,7 +125,7 @@ class DBTrainer:
         # RCCL communicator — which should happen AFTER the activation arena exists (init_distributed: creating it first
         # cost 2.4 ms/step at bs16 640^2).  So the sync is deferred to the first step(), which knows the batch shape: it
         # takes one dry forward+backward to allocate every buffer, restores the BatchNorm buffers, then broadcasts.
-        self._need_sync = dist.is_available() and dist.is_initialized()  # (also with one forced rank: tests/dist_child.py)
+        self._need_sync = self.distributed  # (also with one forced rank: tests/dist_child.py)
         self.exchange_events = None  # set to [] to collect (issue, done) HIP event pairs around the exchange (bench.py)
         # hipGraph: forward + DBLoss + backward of the steady-state step as ONE graph launch (the arena is static, so the ~340
         # kernel launches of a step replay with their captured arguments; the two-stream fork / join is captured with them).
@@ -132,11 +142,32 @@ class DBTrainer:
         # Python objects; every few steps that trips a generation-2 collection, which walks the WHOLE heap of the process (torch, the
         # model's module tree, the engine's tables: ~90-100 ms) while the GPU runs dry — one such stall inside twenty 10 ms bf16 steps
         # is the difference between 1670 and 1280 images/s, two are 1100.  Nothing in a step creates reference cycles.  After the
-        # third step — every buffer, panel and table exists by then — the trainer collects once and FREEZES the heap (gc.freeze():
-        # existing objects leave the collector's generations for good), so later passes scan only what was created since: < 1 ms.
-        # DBN_GC_FREEZE=0 leaves the collector alone.
-        self.gc_freeze = os.environ.get('DBN_GC_FREEZE', '1') == '1'
+        # third step — every buffer, panel and table exists by then — freeze_heap() collects once and FREEZES the heap (gc.freeze():
+        # existing objects leave the collector's generations), so later passes scan only what was created since: < 1 ms.
+        # That is a PROCESS-WIDE side effect (the caller's data loaders and loggers are frozen with everything else), so it is
+        # opt-in: DBTrainer(gc_freeze=True) / DBN_GC_FREEZE=1 do it at the fourth step, fit() asks for it and undoes it on return
+        # (unfreeze_heap()), a caller with its own loop calls freeze_heap() when its set-up is complete.
+        self.gc_freeze = (os.environ.get('DBN_GC_FREEZE', '0') == '1') if gc_freeze is None else bool(gc_freeze)
+        self._froze = False
         self._steps = 0
+
+    def freeze_heap(self):
+        """gc.collect() + gc.freeze(): every object alive in this PROCESS now leaves the cyclic collector's generations, so the
+        generation-2 passes a step's few thousand temporaries trip every few steps stop walking torch, the module tree and
+        the engine's tables (~90 ms each with the GPU running dry: 9.5 vs 12.4 ms per bf16 step, tools/bimodal_probe.py).
+        Frozen objects are still freed by reference counting; cyclic garbage among them is not reclaimed until
+        unfreeze_heap().  Call it once the steady state is reached (after the first steps of a batch shape)."""
+        import gc
+        gc.collect()
+        gc.freeze()
+        self._froze = True
+
+    def unfreeze_heap(self):
+        """Undo freeze_heap(): the frozen objects return to the oldest generation (gc.unfreeze())."""
+        if self._froze:
+            import gc
+            gc.unfreeze()
+            self._froze = False
 
     def sync_from_rank0(self):
         """Data-parallel replicas must start from identical state: rank 0's flat parameter buffer, its BatchNorm buffers and
@@ -182,6 +213,9 @@ class DBTrainer:
 
     def param_checksum(self):
         """See replica_divergence(): ((sum, sum of squares) of this rank's parameters, spread over the ranks)."""
+        if not self.distributed:
+            f = self.model.engine.flat.double()
+            return [float(f.sum()), float((f * f).sum())], 0.0
         return replica_divergence(self.model.engine.flat, self.pg)
 
     def _loss(self, preds, gts):
@@ -193,11 +227,15 @@ class DBTrainer:
         st = torch.cuda.current_stream(dev).cuda_stream
         reduction = getattr(c, 'reduction', 'mean')
         per_pixel = reduction == 'none'
+        frac = bool(getattr(c, 'fractional_maps', False)) and not per_pixel  # literal top-k form of the scalar-BCE reductions
+        guard = getattr(c, '_guard', None)
+        if guard is not None:
+            guard.check()  # (a count that has landed from an earlier step; never waits)
         if self._gone is None or self._gone.device != dev:
             self._gone = torch.tensor([0., 0., 0., 0., 1.], device=dev)
             self._coef = torch.zeros(8, device=dev)
             self._ws = None
-        need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if per_pixel else L.dbn_db_loss_ws_bytes()) // 4 + 1
+        need = (L.dbn_db_loss_ohem_ws_bytes(N, H, W) if (per_pixel or frac) else L.dbn_db_loss_ws_bytes()) // 4 + 1
         if self._ws is None or self._ws.numel() < need:
             self._ws = engine_mod.device_empty(need, dev)
         losses = engine_mod.device_empty(5, dev)
@@ -205,8 +243,15 @@ class DBTrainer:
         eng = self.model.engine
         if eng.prof:  # reads the 3 maps and the 4 targets once
             eng.prof.begin('db_loss_fwd_kernel', 0.0, 4.0 * (preds.numel() + gts.numel()))
-        check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
-                  self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
+        if frac:
+            check(L.dbn_db_loss_frac_fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps,
+                                         1 if reduction == 'sum' else 0, losses.data_ptr(), self._coef.data_ptr(), self._ws.data_ptr(), st),
+                  'db_loss_frac_fwd')
+        else:
+            check(fwd(preds.data_ptr(), gts.data_ptr(), N, H, W, C, c.alpha, c.beta, float(c.negative_ratio), c.eps, losses.data_ptr(),
+                      self._coef.data_ptr(), self._ws.data_ptr(), st), 'db_loss_fwd')
+            if guard is not None and not per_pixel:
+                guard.watch(self._coef)
         if eng.prof:
             eng.prof.end()
             eng.prof.begin('db_loss_bwd_kernel', 0.0, 4.0 * (2 * preds.numel() + gts.numel()))  # + writes the 3 map gradients
@@ -235,20 +280,18 @@ class DBTrainer:
             raise RuntimeError('DBTrainer.step requires model.train()')
         self._steps += 1
         if self.gc_freeze and self._steps == 4:
-            import gc
-            gc.collect()
-            gc.freeze()
+            self.freeze_heap()
         gts = gts.contiguous().float()
         if self._need_sync:
             self._warm_arena_then_sync(img, gts)
-        distributed = dist.is_available() and dist.is_initialized()
+        distributed = self.distributed
         if self.use_graph and eng.prof is None and not (distributed and self.overlap_allreduce):
             self.optimizer.zero_grad()  # (before the backward pass, as on the eager path: the replay below counts as ONE pass)
             got = self._graph_step(img, gts, resident)
             if got is not None:
                 preds, losses = got
                 ev = self._exchange_event()
-                scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
+                scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg) if distributed else 1.0
                 self._exchange_event(ev)
                 self.optimizer.step(grad_scale=scale)
                 return preds, losses
@@ -270,7 +313,7 @@ class DBTrainer:
         else:
             eng.backward(dpreds)
             ev = self._exchange_event()
-            scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg)
+            scale = allreduce_flat_grads(eng.flat_grad, self.world, self.pg) if distributed else 1.0
             self._exchange_event(ev)
         self.optimizer.step(grad_scale=scale)
         return preds, losses
@@ -332,11 +375,18 @@ class DBTrainer:
         return e
 
 
-def init_distributed():
-    """One process per GPU, launched by torch.distributed.run; backend nccl == RCCL on ROCm."""
+def init_distributed(backend=None):
+    """One process per GPU, launched by torch.distributed.run; backend nccl == RCCL on ROCm (the default).
+    `backend='gloo'` (or DBN_DIST_BACKEND=gloo) moves the same device tensors through gloo instead — for exercising the
+    N > 1 control path (start-up broadcasts, gradient all-reduce, checksums) with several ranks on ONE GPU, which RCCL
+    refuses (tests/dist_child2.py); DBN_DIST_ONE_DEVICE=1 then maps every local rank to device 0.
+    Returns (rank, local device index, world)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('DBN_DIST_ONE_DEVICE', '0') == '1':
+        local = 0
+    backend = backend or os.environ.get('DBN_DIST_BACKEND', 'nccl')
     force = os.environ.get('DBN_FORCE_DIST', '0') == '1'  # exercise the RCCL path even with one rank
     if (world > 1 or force) and not dist.is_initialized():
         torch.cuda.set_device(local)
@@ -345,7 +395,7 @@ def init_distributed():
         # No device_id: the RCCL communicator is then created lazily by the first collective, i.e. after the model's arena
         # exists.  Creating it eagerly BEFORE the activations are allocated costs 2.4 ms/step (6 %) at bs16 640^2 on MI355X
         # (tools/dist_probe2.py: 37.6 vs 35.2 ms) — RCCL's buffers come first and the arena lands in a slower placement.
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 
@@ -412,8 +462,11 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
     AVERAGED OVER THE RANKS before they are compared, recorded or given to the scheduler, so every rank takes the same
     save / no-save decision (the checkpoint barrier is reached by all or none) and the same learning-rate schedule.
     `trainer`: a ready DBTrainer (default: built here); `pixel_metric=False` skips the device pixel metric."""
-    if trainer is None:
-        trainer = DBTrainer(model, criterion, optimizer, process_group=process_group)
+    own_trainer = trainer is None
+    if own_trainer:
+        # (the heap freeze of DBTrainer.freeze_heap is taken for the duration of this call and undone on return)
+        trainer = DBTrainer(model, criterion, optimizer, process_group=process_group,
+                            gc_freeze=os.environ.get('DBN_GC_FREEZE', '1') == '1')
     distributed = dist.is_available() and dist.is_initialized()
     is_writer = (not distributed) or dist.get_rank(process_group) == 0
     ctl_dev = _collective_device(model) if distributed else None
@@ -472,4 +525,6 @@ def fit(model, criterion, optimizer, train_loader, test_loader=None, epochs=1, s
         history.append(rec)
     if last_cp_path:
         save(last_cp_path)
+    if own_trainer:
+        trainer.unfreeze_heap()
     return history

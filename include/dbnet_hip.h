@@ -320,6 +320,14 @@ int dbn_db_loss_bwd(const float* preds, const float* gts, const float* coef, con
  * OHEM term is summed instead of averaged; everything else as dbn_db_loss_fwd (same ws; backward: dbn_db_loss_bwd). */
 int dbn_db_loss_sum_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
                         float negative_ratio, float eps, float* losses, float* coef, void* ws, void* stream);
+/* The two entry points above evaluate losses.py:33-39's `topk(loss * negative, n_neg).sum()` (loss a SCALAR in these reductions)
+ * in closed form, bce * n_neg — exact for binary prob_gt / supervision_mask maps (what data_loaders.py:112-134 produces) and
+ * only for those.  coef[7] receives the number of pixels whose gt or mask is neither 0 nor 1 (the host side refuses such maps,
+ * db_text_minimal_amd/losses.py).  dbn_db_loss_frac_fwd evaluates the expression literally for ANY maps:
+ * bce * (sum(positive) + sum of the n_neg largest negative_i) / (n_pos + n_neg + eps), top-k sum by the device radix select of
+ * the per-pixel path below.  sum != 0: reduction='sum'.  ws: dbn_db_loss_ohem_ws_bytes(N,H,W) bytes; backward: dbn_db_loss_bwd. */
+int dbn_db_loss_frac_fwd(const float* preds, const float* gts, int N, int H, int W, int channels, float alpha, float beta,
+                         float negative_ratio, float eps, int sum, float* losses, float* coef, void* ws, void* stream);
 
 /* DBLoss(reduction='none') — true per-pixel OHEM (losses.py:30-39 with a per-pixel BCE): the n_neg largest
  * negative losses are found by a 3-pass radix select on device (no sort, no host sync).  `ws` holds

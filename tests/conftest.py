@@ -11,6 +11,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 _RCCL_CHILD = {}
+_DIST2_CHILD = {}
+_BENCH2_CHILD = {}
 
 
 def pytest_configure(config):
@@ -25,14 +27,42 @@ def _free_port():
     return p
 
 
+def _start_child(store, nproc, script_args, env_extra, timeout, tag):
+    """Run `python -m torch.distributed.run --nproc-per-node nproc <script_args>` as a fresh process group TO COMPLETION before
+    the first test; fills `store` with proc / out / log / timed_out."""
+    out = os.path.join(tempfile.mkdtemp(prefix='dbn_%s_' % tag), 'verdict.json')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('DBN_FORCE_DIST', None)
+    env.update(env_extra)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port())] + [a.replace('{out}', out) for a in script_args]
+    log = open(out + '.log', 'w')
+    # its own process group, so that pytest_sessionfinish can end the launcher AND the workers it spawned
+    store.update(proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True),
+                 out=out, log=out + '.log')
+    # ... and it runs to completion BEFORE the first test: two processes time-slicing one GPU perturb more than timing — under
+    # that contention a few launches per thousand of otherwise bit-reproducible kernels return different bits (measured round 3:
+    # dbn_head_tail_bwd 20 of 600 calls beside a second process training in bf16, 0 of 600 alone or beside an f32 one; DESIGN §4), which is what made the bit-identity
+    # tests of this suite flaky while the child was still training.
+    try:
+        store['proc'].wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        # a child that is still training would run BESIDE the tests (exactly the co-tenancy described above): end its process
+        # group now and let the test report the timeout as a failure
+        _kill_child(store['proc'])
+        store['timed_out'] = True
+
+
 def pytest_collection_finish(session):
-    """The RCCL test (tests/test_rccl_gpu.py) needs a FRESH process that initialises the GPU itself under
-    torch.distributed.run.  A process that has already initialised the GPU must not exec another program on this pool, so
-    the child is started here — after collection (only when that test is among the selected items) and before any test of
-    this session has touched the GPU — and the test only collects its verdict."""
+    """The multi-process GPU tests (tests/test_rccl_gpu.py, tests/test_dist2_gpu.py) need FRESH processes that initialise the
+    GPU themselves under torch.distributed.run.  A process that has already initialised the GPU must not exec another program
+    on this pool, so the children are started here — after collection (only when their tests are among the selected items) and
+    before any test of this session has touched the GPU — one after the other, and the tests only collect the verdicts."""
     if session.config.option.collectonly:  # listing tests must not start a GPU training process
         return
-    if not any(item.fspath.basename == 'test_rccl_gpu.py' for item in session.items):
+    want_rccl = any(item.fspath.basename == 'test_rccl_gpu.py' for item in session.items)
+    want_dist2 = [item.name for item in session.items if item.fspath.basename == 'test_dist2_gpu.py']
+    if not (want_rccl or want_dist2):
         return
     try:
         import torch
@@ -41,28 +71,17 @@ def pytest_collection_finish(session):
     except Exception:
         return
     # the invariant this hook relies on, checked instead of assumed: importing the test modules (collection) made no GPU call
-    assert not torch.cuda.is_initialized(), ('a test module initialised the GPU at import time: the RCCL child must be started '
+    assert not torch.cuda.is_initialized(), ('a test module initialised the GPU at import time: the child processes must be started '
                                              'from a process that has not touched the GPU (tests/conftest.py)')
-    out = os.path.join(tempfile.mkdtemp(prefix='dbn_rccl_'), 'verdict.json')
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    env.pop('DBN_FORCE_DIST', None)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_child.py'), out]
-    log = open(out + '.log', 'w')
-    # its own process group, so that pytest_sessionfinish can end the launcher AND the worker it spawned
-    _RCCL_CHILD.update(proc=subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True),
-                       out=out, log=out + '.log')
-    # ... and it runs to completion BEFORE the first test: two processes time-slicing one GPU perturb more than timing — under
-    # that contention a few launches per thousand of otherwise bit-reproducible kernels return different bits (measured round 3:
-    # dbn_head_tail_bwd 20 of 600 calls beside a second process training in bf16, 0 of 600 alone or beside an f32 one), which is what made the bit-identity
-    # tests of this suite flaky while the child was still training.
-    try:
-        _RCCL_CHILD['proc'].wait(timeout=900)
-    except subprocess.TimeoutExpired:
-        # a child that is still training would run BESIDE the tests (exactly the co-tenancy described above): end its process
-        # group now and let the RCCL test report the timeout as a failure
-        _kill_child(_RCCL_CHILD['proc'])
-        _RCCL_CHILD['timed_out'] = True
+    if want_rccl:
+        _start_child(_RCCL_CHILD, 1, [os.path.join(ROOT, 'tests', 'dist_child.py'), '{out}'], {}, 900, 'rccl')
+    one_gpu = {'DBN_DIST_BACKEND': 'gloo', 'DBN_DIST_ONE_DEVICE': '1'}
+    if any('real_trainer' in n for n in want_dist2):
+        _start_child(_DIST2_CHILD, 2, [os.path.join(ROOT, 'tests', 'dist_child2.py'), '{out}'], one_gpu, 600, 'dist2')
+    if any('bench' in n for n in want_dist2):
+        # bench.py as the driver launches it for N = 2 (parity gate ON), both ranks on the one GPU over gloo
+        _start_child(_BENCH2_CHILD, 2, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--backend', 'gloo',
+                                        '--no-alt-modes', '--serial-steps', '1'], one_gpu, 600, 'bench2')
 
 
 def _kill_child(proc):
@@ -80,15 +99,25 @@ def _kill_child(proc):
 
 def pytest_sessionfinish(session, exitstatus):
     """Do not leave the child behind (-x, Ctrl-C, or a session that never reached the RCCL test)."""
-    proc = _RCCL_CHILD.get('proc')
-    if proc is None or proc.poll() is not None:
-        return
-    _kill_child(proc)
+    for store in (_RCCL_CHILD, _DIST2_CHILD, _BENCH2_CHILD):
+        proc = store.get('proc')
+        if proc is not None and proc.poll() is None:
+            _kill_child(proc)
 
 
 @pytest.fixture(scope='session')
 def rccl_child():
     return _RCCL_CHILD
+
+
+@pytest.fixture(scope='session')
+def dist2_child():
+    return _DIST2_CHILD
+
+
+@pytest.fixture(scope='session')
+def bench2_child():
+    return _BENCH2_CHILD
 
 
 @pytest.fixture(scope='session')

@@ -248,6 +248,22 @@ def case_loss_kats():
     run('reduction_none', preds3, gts, DBLoss(reduction='none'))
     # losses.py:30 hands any torch reduction string to F.binary_cross_entropy: 'sum' = the scalar BCE summed, not averaged
     run('reduction_sum', preds3, gts, DBLoss(reduction='sum'))
+    # NON-BINARY maps (round 6): losses.py:33-39 takes topk over loss * negative literally, which differs from the binary-map
+    # closed form bce * n_neg.  (i) a fractional supervision_mask, (ii) fractional prob_gt AND mask, (iii) few positives so that
+    # n_neg = int(ratio * n_pos) < sum(negative) and the top-k really selects, (iv) the same under reduction='sum'.
+    # (drawn after every older case: the older cases' random streams are unchanged)
+    gf = gts.clone()
+    gf[1] = torch.rand(n, s, s, generator=g)
+    run('fractional_mask', preds3, gf)
+    gf2 = gts.clone()
+    gf2[0] = torch.rand(n, s, s, generator=g) ** 3
+    gf2[1] = torch.rand(n, s, s, generator=g)
+    run('fractional_gt_and_mask', preds3, gf2)
+    gf3 = gts.clone()
+    gf3[0] = (torch.rand(n, s, s, generator=g) > 0.97).float()
+    gf3[1] = torch.rand(n, s, s, generator=g)
+    run('fractional_mask_topk_selects', preds3, gf3, DBLoss(negative_ratio=2))
+    run('fractional_mask_sum', preds3, gf3, DBLoss(reduction='sum', negative_ratio=2))
     np.savez_compressed(os.path.join(HERE, 'loss_kats.npz'), **out)
 
 

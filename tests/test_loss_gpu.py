@@ -12,7 +12,20 @@ from oracle import dbnet_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_none', 'reduction_sum']
+KATS = ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_none', 'reduction_sum',
+        'fractional_mask', 'fractional_gt_and_mask', 'fractional_mask_topk_selects', 'fractional_mask_sum']
+
+
+def _crit(tag, **extra):
+    if tag == 'alpha_beta':
+        return DBLoss(alpha=5.0, beta=2.0, negative_ratio=1, **extra)
+    if tag.startswith('reduction_'):
+        return DBLoss(reduction=tag[len('reduction_'):], **extra)
+    if tag.startswith('fractional_mask_'):
+        return DBLoss(negative_ratio=2, reduction='sum' if tag.endswith('_sum') else 'mean', fractional_maps=True)
+    if tag.startswith('fractional'):
+        return DBLoss(fractional_maps=True)
+    return DBLoss(**extra)
 
 
 @pytest.mark.parametrize('tag', KATS)
@@ -20,7 +33,7 @@ def test_loss_known_answers(golden_dir, tag):
     z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
     preds = torch.from_numpy(z[tag + '/preds']).to(DEV).requires_grad_(True)
     gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
-    crit = DBLoss(alpha=5.0, beta=2.0, negative_ratio=1) if tag == 'alpha_beta' else DBLoss(reduction=tag[len('reduction_'):]) if tag.startswith('reduction_') else DBLoss()
+    crit = _crit(tag)
     res = crit(preds, gts)
     res5 = res if isinstance(res, tuple) else (res, )
     got = torch.stack([r.detach() for r in res5]).cpu()
@@ -29,6 +42,73 @@ def test_loss_known_answers(golden_dir, tag):
     ref = torch.from_numpy(z[tag + '/dpreds'])
     scale = float(ref.abs().max())
     report('dpreds ' + tag, preds.grad.cpu(), ref, 1e-6 * max(scale, 1e-3), 1e-4)
+
+
+@pytest.mark.parametrize('tag', ['default', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta', 'reduction_sum', 'eval2ch'])
+def test_literal_topk_form_equals_the_closed_form_on_binary_maps(golden_dir, tag):
+    """DBLoss(fractional_maps=True) (dbn_db_loss_frac_fwd: radix select over `negative`) on the BINARY known-answer cases: the same
+    reference numbers as the closed form, and check_maps() has nothing to refuse."""
+    z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
+    preds = torch.from_numpy(z[tag + '/preds']).to(DEV).requires_grad_(True)
+    gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
+    crit = _crit(tag, fractional_maps=True)
+    res = crit(preds, gts)
+    res5 = res if isinstance(res, tuple) else (res, )
+    report('losses (literal form) ' + tag, torch.stack([r.detach() for r in res5]).cpu(), torch.from_numpy(z[tag + '/losses']).float(), 1e-5, 1e-5)
+    res5[-1].backward()
+    ref = torch.from_numpy(z[tag + '/dpreds'])
+    report('dpreds (literal form) ' + tag, preds.grad.cpu(), ref, 1e-6 * max(float(ref.abs().max()), 1e-3), 1e-4)
+    crit.check_maps()
+
+
+@pytest.mark.parametrize('tag', ['fractional_mask', 'fractional_gt_and_mask'])
+def test_closed_form_refuses_non_binary_maps(golden_dir, tag):
+    """The default DBLoss evaluates topk(loss * negative) in closed form, exact for binary prob_gt / supervision_mask only
+    (losses.py:33-39): a batch with fractional maps must not diverge silently — the kernel counts the offending pixels, the
+    count comes back through pinned memory, and the NEXT call (or check_maps()) raises.  Binary batches never raise."""
+    z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
+    preds = torch.from_numpy(z[tag + '/preds']).to(DEV)
+    gts = torch.from_numpy(z[tag + '/gts']).to(DEV)
+    crit = DBLoss()
+    got = crit(preds, gts)  # evaluated (closed form), flagged on the device
+    assert abs(float(got[0]) - float(z[tag + '/losses'][0])) > 1e-4  # ... and indeed not the reference's value
+    with pytest.raises(ValueError, match='fractional_maps=True'):
+        crit.check_maps()
+    crit(preds, gts)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='neither 0 nor 1'):
+        crit(preds, gts)  # the deferred form: the previous call's count has landed
+    ok = DBLoss()
+    gb = torch.from_numpy(z['default/gts']).to(DEV)
+    for _ in range(3):
+        ok(preds, gb)
+        torch.cuda.synchronize()
+    ok.check_maps()
+
+
+def test_trainer_refuses_non_binary_maps_and_takes_the_literal_form_on_request():
+    """DBTrainer.step goes to the loss kernels directly (train.py: _loss): same guard, same literal form."""
+    from db_text_minimal_amd import DBTextModel, DBTrainer, FusedAdam
+    img, gts = O.synthetic_batch(2, 64, seed=4)
+    gts[1] = torch.rand(2, 64, 64, generator=torch.Generator().manual_seed(2))  # a fractional supervision mask
+    sd = O.new_state(4)
+    model = DBTextModel()
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    tr = DBTrainer(model, DBLoss(), FusedAdam(model, lr=0.005))
+    tr.step(img.to(DEV), gts.to(DEV))
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match='fractional_maps=True'):
+        tr.step(img.to(DEV), gts.to(DEV))
+    model2 = DBTextModel()
+    model2.load_state_dict(sd)
+    model2 = model2.to(DEV).train()
+    tr2 = DBTrainer(model2, DBLoss(fractional_maps=True), FusedAdam(model2, lr=0.005))
+    preds, losses = tr2.step(img.to(DEV), gts.to(DEV))
+    torch.cuda.synchronize()
+    _, ref, grads = O.loss_and_grads(sd, img, gts)
+    report('trainer losses, fractional mask (literal form) vs oracle', losses.cpu().double(), torch.tensor([float(v) for v in ref]).double(), 1e-5, 1e-4)
+    tr2.step(img.to(DEV), gts.to(DEV))  # nothing to refuse
 
 
 def test_loss_individual_outputs_backward():

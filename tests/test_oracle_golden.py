@@ -138,7 +138,8 @@ def test_oracle_odd_size_matches_reference(golden_dir):
 
 
 @pytest.mark.parametrize('tag', ['default', 'eval2ch', 'no_positive', 'all_masked', 'neg_limited', 'saturated', 'alpha_beta',
-                                 'reduction_none', 'reduction_sum'])
+                                 'reduction_none', 'reduction_sum', 'fractional_mask', 'fractional_gt_and_mask',
+                                 'fractional_mask_topk_selects', 'fractional_mask_sum'])
 def test_oracle_loss_known_answers(golden_dir, tag):
     z = np.load(os.path.join(golden_dir, 'loss_kats.npz'))
     preds = torch.from_numpy(z[tag + '/preds']).requires_grad_(True)
@@ -148,12 +149,18 @@ def test_oracle_loss_known_answers(golden_dir, tag):
         kw = dict(alpha=5.0, beta=2.0, negative_ratio=1)
     if tag.startswith('reduction_'):
         kw = dict(reduction=tag[len('reduction_'):])
+    if tag.startswith('fractional_mask_'):
+        kw = dict(negative_ratio=2, reduction='sum' if tag.endswith('_sum') else 'mean')
     res = O.db_loss(preds, gts, **kw)
     res5 = res if isinstance(res, tuple) else (res, )
     assert np.allclose([float(v) for v in res5], z[tag + '/losses'], rtol=1e-6, atol=1e-7)
     res5[-1].backward()
     assert np.allclose(preds.grad.numpy(), z[tag + '/dpreds'], rtol=1e-5, atol=1e-9)
-    if tag not in ('reduction_none', ):
+    if tag.startswith('fractional'):
+        # non-binary maps: the closed form is NOT the reference's value (the product refuses such maps or takes the literal form)
+        cf = O.db_loss_closed_form(preds.detach(), gts, **kw)
+        assert abs(cf[0] - z[tag + '/losses'][0]) > 1e-3 * abs(z[tag + '/losses'][0]), (cf, z[tag + '/losses'])
+    elif tag not in ('reduction_none', ):
         # closed form evaluated by the HIP kernel == the literal reference formula (binary maps)
         cf = O.db_loss_closed_form(preds.detach(), gts, **kw)
         ref = z[tag + '/losses']
