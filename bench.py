@@ -189,6 +189,34 @@ def parity_gate(dev, math):
     return out
 
 
+def mfma_sustained(dev, math):
+    """What the matrix pipe of THIS box sustains on non-zero operands in the arithmetic of `math` (csrc/mfma_probe.hip: back-to-back MFMAs
+    from registers, 8 waves per CU, N(0, 0.05) operands): the chip clocks to its power budget, so the nominal peak of
+    MI355X_MICROARCH.md (a product of the 2.4 GHz maximum clock) is not reachable on random data — round 6 measured 1650 TFLOP/s fp16
+    against 2496 with all-zero operands.  Returned in the units of the line's `peak` (bf16x3: a sixth of the bf16 rate)."""
+    from db_text_minimal_amd import _lib
+    L = _lib.lib()
+    kind = 0 if math == 'f32' else 1
+    g = torch.Generator(device=dev).manual_seed(7)
+    ops = torch.randn(65536 // 4 if kind == 0 else 65536 // 2, device=dev, generator=g) * 0.05
+    if kind == 1:
+        ops = ops.to(torch.bfloat16)
+    out = torch.empty(524288, device=dev)
+    iters = 2000 if kind == 0 else 4000
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(3):  # (the clock settles over the first launches)
+        _lib.check(L.dbn_mfma_sustained(kind, ops.data_ptr(), out.data_ptr(), iters, st), 'mfma_sustained')
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    for i in range(3):
+        _lib.check(L.dbn_mfma_sustained(kind, ops.data_ptr(), out.data_ptr(), iters, st), 'mfma_sustained')
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(3))[1]
+    tf = L.dbn_mfma_sustained_flops(kind, iters) / (ms * 1e-3) / 1e12
+    return tf / 6.0 if math == 'bf16x3' else tf
+
+
 class ClockProbe:
     """Sustained shader clock during the timed region: dbn_clock_probe (one wave, s_memtime vs s_memrealtime over 200 us)
     launched on its own stream at the start of every timed step, beside the step's kernels."""
@@ -381,7 +409,7 @@ def main():
 
     # HIP events around the igemm launches of every TIMED_EVERY-th step of the timed region (an event pair per launch
     # fences the queue: bracketing all ~60 launches of all steps costs 2 % of the step time)
-    timer = KernelTimer(labels=('igemm_f32_kernel', 'stem7x7_b16_kernel', 'convt2x2_b16_kernel', 'winograd_f32_kernel', 'winograd_wgrad_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
+    timer = KernelTimer(labels=('igemm_f32_kernel', 'conv3x3_wres16_kernel', 'stem7x7_b16_kernel', 'convt2x2_b16_kernel', 'winograd_f32_kernel', 'winograd_wgrad_f32_kernel', 'convt2x2_f32_kernel', 'wgrad_f32_kernel', 'wgrad_tr_kernel', 'wgrad_patch_kernel',
                                 'head_tail_fwd_kernel', 'head_tail_bwd_kernel', 'db_loss_fwd_kernel', 'db_loss_bwd_kernel'))
     TIMED_EVERY = max(4, args.steps // 2)  # two instrumented steps of the K (at 12 ms/step in bf16 an instrumented step is ~30 % slower)
     clock = ClockProbe(dev, args.steps)
@@ -499,6 +527,13 @@ def main():
                 'note': ('measured in the timed region; the backward-pass launches of this kernel share the CUs with the concurrent '
                          'weight-gradient stream, so their durations (here and in the rocprofv3 trace of this command) include that '
                          'sharing; roofline_serial is the same kernel with the streams serialised')}
+    # the same fraction against what the matrix pipe sustains on this box (power-capped clock, non-zero operands): the nominal `peak` is the
+    # contract's yardstick, this one says how much of the attainable rate the kernel reaches
+    sustained = mfma_sustained(dev, args.math)
+    roofline.update(peak_sustained=round(sustained, 1), frac_of_sustained=round(achieved / sustained, 4),
+                    peak_sustained_how='dbn_mfma_sustained (csrc/mfma_probe.hip): back-to-back MFMAs of this arithmetic from registers, N(0, 0.05) '
+                                       'operands, 8 waves per CU, in this run on this GPU: the chip clocks to its power budget, the nominal peak '
+                                       'assumes 2.4 GHz')
     if d.get('hbm_bound', 0) > 0:  # (16-bit modes) some launches of the dominant symbol are HBM-bound at their own roofline
         roofline.update(hbm_bound_launches=d['hbm_bound'], frac_of_own_roofline=round(d['roof_ms'] / d['ms'], 4),
                         own_roofline='per launch max(FLOPs / %.0f TFLOP/s, algorithmic bytes / %.0f GB/s)' % (peak_mfma, HBM_ACHIEVABLE_GBS))

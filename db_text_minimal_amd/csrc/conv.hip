@@ -187,6 +187,20 @@ int dbn_set_stagger(int permille) {
     return old;
 }
 
+static bool patch_eligible_fwd(int mode, int at, int H, int W, int Cs);
+// the weight-resident 3x3 kernel of the 16-bit storage types (wres16.hip): 1 = takes every pixel-patch launch it is eligible for
+// (default), 0 = off (test / A-B hook: the pixel-patch kernel again)
+int dbn_g_wres16 = getenv("DBN_WRES16") ? atoi(getenv("DBN_WRES16")) != 0 : 1;  // (DBN_WRES16=0: A/B runs of whole programs)
+int dbn_set_wres16(int on) {
+    const int old = dbn_g_wres16;
+    dbn_g_wres16 = on != 0;
+    return old;
+}
+// Would a dbn_igemm_t / dbn_conv_bn_t / dbn_igemm_bnsums_t call with this geometry (3x3, stride 1, pad 1 implied) launch
+// conv3x3_wres16_kernel<at, Cs, Cd, mode, epi>?  bnb / y2: the call carries the BatchNorm-backward sums / their second BatchNorm.
+int dbn_wres16_would_run(int at, int mode, int N, int H, int W, int Cs, int Cd, int bnb, int y2) {
+    return patch_eligible_fwd(mode, at, H, W, Cs) && Cd % 64 == 0 && dbn_wres16_eligible(at, mode, N, H, W, Cs, Cd, bnb != 0, y2 != 0, false);
+}
 static int g_patch_enabled = 1;  // 0: never; 1: default; 2: the 16-bit matrix modes only (exact fp32 takes the gather loop); 3: exact fp32 on every eligible launch
 static const int g_patch_bn64 = dbn_env_int("DBN_PATCH_BN64", 1);
 int dbn_set_patch_conv(int on) {  // test / A-B hook: 0 routes the 3x3 stride-1 convolutions through the generic gather loop again
@@ -210,6 +224,9 @@ static bool patch_eligible(int kmode, int ns, int at, int cfg, int R, int S, int
     if (ns == 0) return (g_patch_enabled == 1 || g_patch_enabled == 3) && at == 0 && geom && (tile_hint == 3 || (tile_hint == 0 && g_patch_enabled == 3));
     return g_patch_enabled && ns > 0 && at != 3 && (cfg == 1 || cfg == 3) && geom;
 }
+static bool patch_eligible_fwd(int mode, int at, int H, int W, int Cs) {  // a 16-bit 3x3 / stride-1 / pad-1 call at the library's own tile choice
+    return patch_eligible(mode, 1, at, 3, 3, 3, 1, 1, H, W, H, W, Cs, 1, 0);
+}
 static int patch_cfg(int cfg, int ns = 1) { return (ns == 0 || (cfg == 1 && g_patch_bn64)) ? 3 : cfg; }
 
 // Tile configuration of a dbn_igemm / dbn_conv_bn call (`mode`, `stride` as the caller passes them).  The convolutions that can take
@@ -230,7 +247,11 @@ int dbn_igemm_kernel_config(int at, int ns, int kmode, int N, int Hs, int Ws, in
                             int pad, int tile_hint, int ksplit) {
     const int cfg = resolve_cfg(N * Hd * Wd, Cd, tile_hint, at, ns, kmode >= 2 ? 1 : kmode, R, S, kmode == 2 && stride == 1 ? 2 : stride, pad, Hs,
                                 Ws, Hd, Wd, Cs, ksplit);
-    if (Cd % 64 == 0 && patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit, tile_hint)) return patch_cfg(cfg, ns) + 16;
+    if (Cd % 64 == 0 && patch_eligible(kmode, ns, at, cfg, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, ksplit, tile_hint)) {
+        // + 64: a PLAIN call (no sums / statistics epilogue) launches conv3x3_wres16_kernel<at, Cs, Cd, mode, 0>
+        const int wres = (ns == 1 && patch_cfg(cfg, ns) == 3 && dbn_wres16_eligible(at, kmode, N, Hd, Wd, Cs, Cd, false, false, false)) ? 64 : 0;
+        return patch_cfg(cfg, ns) + 16 + wres;
+    }
     // + 32: the launch is convt2x2_f32_kernel<Cs> (a non-accumulating transposed 2x2 / stride-2 conv in exact fp32)
     if (kmode == 2 && convt_eligible(1, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, 0, ksplit)) return cfg + 32;
     return cfg;

@@ -287,3 +287,6 @@ int dbn_convt_f32_rows(int M);
 int dbn_launch_igemm_f32(IgemmParams& p, int cfg, int mode, hipStream_t st);                    // conv_f32.hip: exact fp32 (ns 0, at 0)
 int dbn_launch_igemm_x(IgemmParams& p, int cfg, int mode, int ns, int at, hipStream_t st);      // conv_x3.hip: fp32 tensors, bf16 math
 int dbn_launch_igemm_b16(IgemmParams& p, int cfg, int mode, int at, hipStream_t st);            // conv_b16.hip: bf16 / fp16 storage
+// wres16.hip: the weight-resident 3x3 / stride-1 kernel of the 16-bit storage types (takes the pixel-patch launches it is eligible for)
+bool dbn_wres16_eligible(int at, int mode, int N, int H, int W, int Cs, int Cd, bool bnb, bool y2, bool stats);
+int dbn_launch_wres16(IgemmParams& p, int mode, int at, hipStream_t st);

@@ -1935,6 +1935,11 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
                         (!p.bnb_y2 || (p.bnb_zmask && p.bnb_mean2 && p.bnb_rstd2 && p.bnb_part2));
     if constexpr (BM == 128 && WM == 2 && WN == 2 && (NS > 0 || BN == 64) && AT != 3) {  // (exact fp32: the 128 x 64 tile only)
         if (p.patch && mode < 2) {
+            if constexpr (NS == 1 && (AT == 1 || AT == 2)) {  // round 6: the weight-resident kernel (wres16.hip) where the panel fits the registers
+                if (gy == 1 && (!p.bnb_part || epi_ok) &&
+                    dbn_wres16_eligible(AT, mode, p.N, p.Hdf, p.Wdf, p.Cs, p.Cd, p.bnb_part != nullptr, p.bnb_y2 != nullptr, p.stats != nullptr))
+                    return dbn_launch_wres16(p, mode, AT, st);
+            }
             if constexpr (AT == 0 || AT == 1) {
                 if (p.bnb_part) {
                     if (!epi_ok) return DBN_ERR_ARG;

@@ -846,6 +846,11 @@ class Engine:
         if geom is not None:  # algorithmic traffic: source and destination once, in the storage type (weights are L2-resident)
             N, Hs, Ws, Cs, Hd, Wd = geom[:6]
             nbytes = float(N) * (Hs * Ws * Cs + Hd * Wd * Cd) * (4 if self.at == 0 else 2)
+        if geom is not None and mode < 2 and geom[6] == 3 and geom[7] == 1 and geom[8] == 1 and self.ns == 1 and \
+                self.L.dbn_wres16_would_run(at, mode, geom[0], geom[4], geom[5], geom[3], Cd, epi, 0):
+            # round 6: the weight-resident kernel (csrc/wres16.hip) — <at, Cs, Cd, mode>; the epilogue flavour is not part of the label
+            self.prof.begin('conv3x3_wres16_kernel<%d,%d,%d,%d>' % (at, geom[3], Cd, mode), flops, nbytes, tag)
+            return
         self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, nbytes, tag)
 
     def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer, panel=None):
@@ -1593,8 +1598,12 @@ class Engine:
     _dcn_table = _dcn_host = _dcn_event = None
 
     def _dcn_read_back(self):
-        """Start of a backward pass: the per-layer offset maxima the previous pass left behind (its copy has long finished)."""
-        if self._dcn_event is not None:
+        """Start of a backward pass: the per-layer offset maxima the previous pass left behind.  Deformable nets only (`_dcn_event` is None
+        otherwise).  The wait is on the PREVIOUS backward pass's copy: it bounds the host's run-ahead to one step on those nets — the price
+        of a deterministic choice of the adjoint's form (taking the value only "if it has already landed" would make the form, and with it
+        the low bits of the gradients, depend on host timing: test_deformable_backbone_step_is_bit_reproducible).  Never under stream
+        capture (an event wait inside a captured pass is illegal; a replayed graph keeps the forms it was captured with)."""
+        if self._dcn_event is not None and not torch.cuda.is_current_stream_capturing():
             self._dcn_event.synchronize()
             self._dcn_event = None
             vals = self._dcn_host.view(torch.float32)

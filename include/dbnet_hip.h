@@ -454,6 +454,18 @@ int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int 
 /* 0: route 3x3 / stride-1 convolutions of the 16-bit matrix modes through the generic gather loop instead of the pixel-patch
    form (A/B and test hook; returns the previous setting) */
 int dbn_set_patch_conv(int on);
+/* 1 (default): the 3x3 / stride-1 convolutions of the 16-bit storage types with 64 -> 64, 128 -> 128 or 256 -> 64 channels run in the
+ * weight-resident kernel (csrc/wres16.hip: the panel in registers, the activations streamed row by row); 0: the pixel-patch kernel
+ * again (test / A-B hook).  Returns the previous setting.  dbn_igemm_kernel_config reports such a launch with bit 64. */
+int dbn_set_wres16(int on);
+int dbn_wres16_would_run(int at, int mode, int N, int H, int W, int Cs, int Cd, int bnb, int y2); /* 1: such a call launches that kernel */
+
+/* ---- measurement infrastructure (bench.py: roofline.peak_sustained): what the matrix pipe sustains on this box with non-zero
+ * operands — the chip clocks to its power budget, far below the 2.4 GHz of the nominal peaks under back-to-back MFMAs (csrc/mfma_probe.hip).
+ * kind 0: v_mfma_f32_32x32x2_f32, 1: ..._32x32x16_bf16, 2: ..._32x32x16_f16.  operands: 65536 bytes of values of that type; out: 524288
+ * floats of scratch.  One launch (1024 workgroups x 8 waves, iters x 16 MFMAs per wave) of dbn_mfma_sustained_flops(kind, iters) FLOPs. */
+int dbn_mfma_sustained(int kind, const void* operands, float* out, int iters, void* stream);
+long dbn_mfma_sustained_flops(int kind, int iters);
 /* First-round stagger of the exact-fp32 implicit-GEMM launches (workgroups sharing a CU start out of phase so that their prologues /
  * epilogues overlap other workgroups' MFMA loops), in permille of the nominal delay; 0 = off.  Returns the previous setting. */
 int dbn_set_stagger(int permille);

@@ -1512,6 +1512,7 @@ def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
         return y, d
 
     try:
+        L().dbn_set_wres16(0)  # (round 6: the weight-resident kernel takes 128 -> 128 on 16-bit storage — another summation order; tests/test_wres16_gpu.py)
         assert L().dbn_set_patch_conv(3 if ns == 0 else 1) in (0, 1, 2, 3)  # (3: exact fp32 takes the patch kernel wherever it is eligible)
         if tile in (0, 3):  # (exact fp32 has the 128 x 64 patch kernel only; 128 x 128 stays on the gather loop)
             cfg = L().dbn_igemm_kernel_config(AT_OF[dtype], ns, 0, N, H, W, Ci, H, W, Co, 3, 3, 1, 1, tile, 1)
@@ -1521,6 +1522,7 @@ def test_pixel_patch_convolution_equals_the_gather_form(mode_name, Co, tile):
         y0, d0 = run()
     finally:
         L().dbn_set_patch_conv(1)
+        L().dbn_set_wres16(1)
     assert torch.isfinite(y1.float()).all() and torch.isfinite(d1.float()).all()
     assert torch.equal(y1, y0), 'forward: max |diff| %g' % float((y1.float() - y0.float()).abs().max())
     assert torch.equal(d1, d0), 'data gradient: max |diff| %g' % float((d1.float() - d0.float()).abs().max())
@@ -1541,6 +1543,7 @@ def test_pixel_patch_convolution_is_race_free_at_full_size(mode_name):
     ns, dtype = {'f32': (0, torch.float32), 'bf16x3': (3, torch.float32), 'bf16': (1, torch.bfloat16)}[mode_name]
     N, H, W = 16, 160, 160
     g = torch.Generator(device=DEV).manual_seed(3)
+    L().dbn_set_wres16(0)  # (this test is about the pixel-patch kernel; the weight-resident one has its own: tests/test_wres16_gpu.py)
     for (Ci, Co, tile, mode) in ((64, 256, 1, 1), (256, 64, 3, 0), (128, 128, 1, 1), (128, 128, 1, 0)):
         if ns == 0:
             tile = 3  # (the exact-fp32 patch kernel exists for the 128 x 64 tile)
@@ -1560,6 +1563,7 @@ def test_pixel_patch_convolution_is_race_free_at_full_size(mode_name):
             torch.cuda.synchronize()
             assert torch.equal(y, ref), '%s Ci %d Co %d tile %d mode %d run %d: %d elements differ' % (
                 mode_name, Ci, Co, tile, mode, run, int((y != ref).sum()))
+    L().dbn_set_wres16(1)
 
 
 def test_image_chunking_on_bf16_storage():
@@ -1708,7 +1712,8 @@ def test_pixel_patch_weight_gradient(case, mode_name):
 
 
 # N, Cin (of the forward conv = channels of dx), Cout, k, s, p, H, W, as_forward
-BNSUM_CASES = [(2, 64, 64, 3, 1, 1, 16, 12, False), (1, 256, 128, 3, 1, 1, 12, 12, False), (3, 128, 64, 1, 1, 0, 9, 7, False),
+BNSUM_CASES = [(2, 128, 128, 3, 1, 1, 16, 32, False), (1, 64, 256, 3, 1, 1, 8, 64, False), (2, 256, 64, 3, 1, 1, 8, 80, True),  # (the weight-resident kernel, csrc/wres16.hip)
+               (2, 64, 64, 3, 1, 1, 16, 12, False), (1, 256, 128, 3, 1, 1, 12, 12, False), (3, 128, 64, 1, 1, 0, 9, 7, False),
                (2, 64, 64, 2, 2, 0, 10, 12, True), (1, 64, 128, 3, 2, 1, 18, 14, True), (2, 64, 64, 3, 1, 1, 40, 24, False),
                (1, 64, 128, 3, 2, 1, 18, 14, False), (2, 128, 256, 3, 2, 1, 16, 16, False), (1, 64, 64, 3, 2, 1, 17, 13, False)]
 
