@@ -550,23 +550,27 @@ def main():
     # sources have changed since, or the kernel is not in it, the line says `traffic: null, traffic_stale: true` instead.
     from db_text_minimal_amd._lib import source_stamp
     roofline['traffic_stale'] = True
-    for tag in ('r05', 'r04', 'r03'):
+    suffix = '' if args.math == 'f32' else '_' + args.math  # (the PMC passes of a mode: profiles/rNN_pmc_traffic[_bf16].json)
+    for tag in ('r06', 'r05', 'r04', 'r03'):
         try:
-            prof = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic.json')))
+            prof = json.load(open(os.path.join(ROOT, 'profiles', tag + '_pmc_traffic' + suffix + '.json')))
         except (OSError, ValueError):
             continue
         ks = prof.get('kernels', {})
         tr = ks.get(dname)
         if tr is None:  # a label that covers several template instances of one kernel (winograd_f32_kernel<false> / <true>): launch-weighted mean
-            inst = [v for k, v in ks.items() if k.startswith(dname + '<')]
+            inst = [v for k, v in ks.items() if k.startswith(dname + '<') or k.startswith(dname.rstrip('>') + ',')]
             n = sum(v['launches_sampled'] for v in inst)
             if n:
                 tr = {'hbm_bytes_per_launch': int(sum(v['hbm_bytes_per_launch'] * v['launches_sampled'] for v in inst) / n)}
         if tr and prof.get('csrc_stamp') == source_stamp():
             roofline['traffic'] = tr['hbm_bytes_per_launch']
             roofline['traffic_stale'] = False
+            alg = d['bytes'] / d['launches'] if d.get('bytes') else None
+            if alg:
+                roofline['traffic_over_algorithmic'] = round(tr['hbm_bytes_per_launch'] / alg, 3)
             roofline['traffic_unit'] = ('bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC passes of this source tree: '
-                                        'profiles/%s_pmc_traffic.json, csrc stamp %s)' % (tag, prof['csrc_stamp']))
+                                        'profiles/%s_pmc_traffic%s.json, csrc stamp %s)' % (tag, suffix, prof['csrc_stamp']))
             break
 
     kernels = []

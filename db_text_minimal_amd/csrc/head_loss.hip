@@ -39,8 +39,23 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 // value of lane `k` (0..3) of this lane's quad
+#ifndef DBN_HT_NODPP
+#define DBN_HT_NODPP 0  // 1 (A/B build, tools/cotenancy_diff.py): the quad broadcasts of head_tail_bwd through ds_bpermute instead of DPP
+#endif
+#ifndef DBN_HT_CHECK
+#define DBN_HT_CHECK 0  // 1 (A/B build): head_tail_bwd_kernel re-loads its loop-invariant operands at the end and counts the lanes whose registers differ
+#endif
+#ifndef DBN_HT_WAVES
+#define DBN_HT_WAVES 0  // n > 0 (A/B build): head_tail_bwd_kernel compiled for n waves per SIMD (register budget 512 / n)
+#endif
 template <int K>
-__device__ __forceinline__ float quad_bcast(float v) { return dpp_f32<K | (K << 2) | (K << 4) | (K << 6)>(v); }
+__device__ __forceinline__ float quad_bcast(float v) {
+#if DBN_HT_NODPP
+    return __shfl(v, (int)((threadIdx.x & 63u & ~3u) | K), 64);
+#else
+    return dpp_f32<K | (K << 2) | (K << 4) | (K << 6)>(v);
+#endif
+}
 
 __device__ __forceinline__ float group8_sum(float v) {
     v += dpp_f32<DPP_QUAD_XOR1>(v);
@@ -173,8 +188,13 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const void* __restri
 // Backward.  For each quarter pixel: dl_b[ab], dl_t[ab] (grad wrt the two logits) from
 // dpreds and the saved maps; dxb = sum_ab dl_b[ab]*wb[ci][ab]; dwb[ci][ab] += xb[ci]*dl_b[ab].
 // part: [grid][2*(256+1)] block partials of (dwb[64*4], dbias_b, dwt[64*4], dbias_t).
+#if DBN_HT_WAVES
+#define DBN_HT_OCC __attribute__((amdgpu_waves_per_eu(DBN_HT_WAVES, DBN_HT_WAVES)))
+#else
+#define DBN_HT_OCC
+#endif
 template <int AT>
-__global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restrict__ xb, const void* __restrict__ xt, const float* __restrict__ wb,
+__global__ __launch_bounds__(256) DBN_HT_OCC void head_tail_bwd_kernel(const void* __restrict__ xb, const void* __restrict__ xt, const float* __restrict__ wb,
                                      const float* __restrict__ wt, const float* __restrict__ preds,
                                      const float* __restrict__ dpreds, const float* __restrict__ sc_b,
                                      const float* __restrict__ sh_b, const float* __restrict__ sc_t,
@@ -297,6 +317,36 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const void* __restri
             abt += lt[0] + lt[1] + lt[2] + lt[3];
         }
     }
+#if DBN_HT_CHECK
+    // A/B build (tools/cotenancy_diff.py): do the loop-invariant registers still hold what was loaded into them?  Counts, behind the partial
+    // rows of `part` ([770 x 2047] used of 2048 x 770): [0] lanes whose wbq differs from a fresh load, [1] wtq, [2] scale / shift, [3] mean / rstd,
+    // [4] lanes whose register copy differs in the LOW 16 bits only
+    {
+        float* dbg = part + (long)(2 * 257 + 4 * 64) * gridDim.x;
+        int bad_w = 0, bad_t = 0, low_only = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 a = *reinterpret_cast<const volatile f32x4*>(wb + (4 * q + e) * 4), b = *reinterpret_cast<const volatile f32x4*>(wt + (4 * q + e) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned ua = __builtin_bit_cast(unsigned, a[k]), ur = __builtin_bit_cast(unsigned, wbq[e][k]);
+                bad_w += ua != ur;
+                low_only += (ua != ur) && ((ua >> 16) == (ur >> 16));
+                bad_t += __builtin_bit_cast(unsigned, b[k]) != __builtin_bit_cast(unsigned, wtq[e][k]);
+            }
+        }
+        int bad_s = 0;
+        if (bn) {
+            const f32x4 a = *reinterpret_cast<const volatile f32x4*>(sc_b + 4 * q), b = *reinterpret_cast<const volatile f32x4*>(sh_b + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad_s += (__builtin_bit_cast(unsigned, a[k]) != __builtin_bit_cast(unsigned, scb[k])) + (__builtin_bit_cast(unsigned, b[k]) != __builtin_bit_cast(unsigned, shb[k]));
+        }
+        if (bad_w) atomicAdd(dbg + 0, 1.f);
+        if (bad_t) atomicAdd(dbg + 1, 1.f);
+        if (bad_s) atomicAdd(dbg + 2, 1.f);
+        if (low_only) atomicAdd(dbg + 4, 1.f);
+    }
+#endif
     // block reduction: groups with the same q hold the same channel slots
     constexpr int ROWS = 2 * 257 + 4 * 64;  // dwb 256, dbias_b, dwt 256, dbias_t, then the BN sums s1_b, s2_b, s1_t, s2_t [64] each
     __shared__ float red[16][ROWS];  // [grp][...]

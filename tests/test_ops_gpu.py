@@ -1799,7 +1799,14 @@ def test_data_gradient_with_batchnorm_backward_sums(case, tile, mask, accumulate
         torch.cuda.synchronize()
         assert int(cnt.abs().sum()) == 0, 'the finalize left a counter behind'
     torch.cuda.synchronize()
-    assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
+    # (round 6: a plain 3x3 / stride-1 call on bf16 storage may take the weight-resident kernel where the call with the sums epilogue stays on
+    # the pixel-patch kernel — 64 -> 64 and 128 -> 128, csrc/wres16.hip: two summation orders, equal to a rounding step of the storage type)
+    wres = lambda bnb: bool(at in (1, 2) and k == 3 and s == 1 and p == 1 and L().dbn_wres16_would_run(at, mode, N, Hd, Wd, srcs.shape[3], Cd, bnb, int(two)))
+    if wres(0) == wres(1):
+        assert torch.equal(dst, plain), 'the sums epilogue changed the convolution result'
+    else:
+        d_ = (dst.float() - plain.float()).abs()
+        assert bool((d_ <= 4e-5 * float(plain.float().abs().max()) + 2.0**-7 * 1.01 * plain.float().abs()).all()), float(d_.max())
     dz = nchw(dst.float()).double()
     m32 = torch.addcmul(msh.view(1, -1, 1, 1), y, msc.view(1, -1, 1, 1))
     m = z.double() if mask == 'tensor' else m32.double()

@@ -64,5 +64,26 @@ cd $R
 python3 tools/rocpd_stats.py $O/trace_eval/r01_results.db $O/kernel_stats_eval_fp16.md > /dev/null
 python3 tools/dump_step.py $O/trace/r01_results.db $K32 > $O/step_dump.txt 2>&1
 python3 tools/dump_step.py $O/trace_bf16/r01_results.db $K16 > $O/step_dump_bf16.txt 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3 $O/trace_eval   # the DBs are large; the summaries above are what is kept
+# round 6: counter evidence for the 16-bit modes and for the matrix pipe.  Every counter group is its own pass (--pmc only, no trace
+# domains beside it); FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950.
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch16 -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A --math bf16 > $O/pmc_fetch16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write16 -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A --math bf16 > $O/pmc_write16.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_eval -o r01 -- python3 $R/tools/cfg_timing.py resnet18 32 1280 fp16 3 eval > $O/pmc_fetch_eval.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_eval -o r01 -- python3 $R/tools/cfg_timing.py resnet18 32 1280 fp16 3 eval > $O/pmc_write_eval.log 2>&1
+# matrix-pipe busy cycles per kernel (SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over the SIMDs) against the kernel's own cycles (GRBM_GUI_ACTIVE)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_mfma -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A > $O/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_mfma16 -o r01 -- python3 $R/bench.py --steps 2 --warmup 1 $A --math bf16 > $O/pmc_mfma16.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/pmc_mfma_eval -o r01 -- python3 $R/tools/cfg_timing.py resnet18 32 1280 fp16 3 eval > $O/pmc_mfma_eval.log 2>&1
+cd $R
+python3 tools/pmc_traffic.py $O/pmc_fetch16/r01_results.db $O/pmc_write16/r01_results.db $O/pmc_traffic_bf16.json > /dev/null
+python3 tools/pmc_traffic.py $O/pmc_fetch_eval/r01_results.db $O/pmc_write_eval/r01_results.db $O/pmc_traffic_fp16.json > /dev/null
+cp $O/pmc_traffic_bf16.json profiles/${TAG}_pmc_traffic_bf16.json
+cp $O/pmc_traffic_fp16.json profiles/${TAG}_pmc_traffic_fp16.json
+python3 tools/pmc_mfma_busy.py $O/pmc_mfma/r01_results.db > $O/mfma_busy_f32.txt 2>&1
+python3 tools/pmc_mfma_busy.py $O/pmc_mfma16/r01_results.db > $O/mfma_busy_bf16.txt 2>&1
+python3 tools/pmc_mfma_busy.py $O/pmc_mfma_eval/r01_results.db > $O/mfma_busy_eval_fp16.txt 2>&1
+python3 tools/mfma_peak.py 2>/dev/null | grep -v amdgpu > $O/mfma_peak.txt
+python3 tools/wres_probe.py 2>/dev/null | grep -v amdgpu > $O/wres_probe.txt
+rm -rf $O/pmc_fetch $O/pmc_write $O/trace $O/trace_bf16 $O/trace_x3 $O/trace_eval $O/pmc_fetch16 $O/pmc_write16 $O/pmc_fetch_eval $O/pmc_write_eval $O/pmc_mfma $O/pmc_mfma16 $O/pmc_mfma_eval   # the DBs are large; the summaries above are what is kept
 ls -la $O
