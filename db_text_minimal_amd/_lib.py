@@ -103,6 +103,8 @@ SIGNATURES.update({
     'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',
     'dbn_set_wres16': 'i',
+    'dbn_conv_bn_set_final': 'pp',
+    'dbn_conv_bn_final_group_doubles': 'ii',
     'dbn_wres16_would_run': 'iiiiiiiii',
     'dbn_mfma_sustained': 'ippip',
     'dbn_mfma_sustained_flops': 'ii',
@@ -179,7 +181,7 @@ SIGNATURES.update({
     'dbn_head_tail_fwd_t': 'i' + SIGNATURES['dbn_head_tail_fwd'],
     'dbn_head_tail_bwd_t': 'i' + SIGNATURES['dbn_head_tail_bwd'],
 })
-LONG_RETURN = {'dbn_mfma_sustained_flops', 'dbn_maxpool_bn_backward_ws_floats', 'dbn_pw16_panel_bytes', 'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
+LONG_RETURN = {'dbn_mfma_sustained_flops', 'dbn_conv_bn_final_group_doubles', 'dbn_maxpool_bn_backward_ws_floats', 'dbn_pw16_panel_bytes', 'dbn_stem16_panel_bytes', 'dbn_convt16_panel_bytes', 'dbn_winograd_panel_floats', 'dbn_winograd_wgrad_slab_floats', 'dbn_winograd_ws_floats', 'dbn_igemm_splitk_slab_floats', 'dbn_deform_col2im_ws_bytes', 'dbn_deform_col2im_gather_ws_bytes', 'dbn_igemm_bn_final_counters', 'dbn_igemm_bn_final_group_floats', 'dbn_igemm_panel_floats_t', 'dbn_wgrad_slab_floats_hw', 'dbn_wgrad_slab_floats', 'dbn_igemm_panel_floats', 'dbn_igemm_bf16s_panel_floats', 'dbn_db_loss_ohem_ws_bytes', 'dbn_conv_bn_ws_floats', 'dbn_pyramid_conv_ws_floats'}
 _KIND = {'p': _P, 'i': _I, 'l': _L, 'f': _F}
 
 

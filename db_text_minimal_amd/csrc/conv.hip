@@ -273,6 +273,28 @@ static int igemm_dispatch(IgemmParams& p, int kmode, int ns, int tile_hint, hipS
 static inline int dst_esize(int at) { return (at == 0 || at == 3) ? 4 : 2; }
 static inline int src_planes(int at) { return at == 3 ? 3 : 1; }
 
+// optional in-kernel finalize of the train-mode BatchNorm statistics (IgemmParams::bnf_*; dbn_conv_bn_set_final)
+struct BnFin {
+    int* cnt;
+    double* grp;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *run_mean, *run_var, *scale, *shift, *mean, *rstd;
+};
+static thread_local int* g_bnf_cnt = nullptr;
+static thread_local double* g_bnf_grp = nullptr;
+// The NEXT dbn_conv_bn_t / dbn_winograd_conv_bn[_act]_f32 call of this thread folds its statistics rows itself (the workgroup that
+// completes the last group of 64 rows writes scale / shift / mean / rstd / running statistics): no bn_finalize_tiles_kernel launch behind
+// the conv.  counters: dbn_igemm_bn_final_counters(rows, Cd) ints, ZERO before the first use (the kernels leave them zero), one set per
+// call that may be in flight at a time; group: dbn_conv_bn_final_group_doubles(rows, Cd) doubles of scratch.  Consumed (or dropped, where
+// the launch has no such epilogue: the 2x2 ConvTranspose kernel) by that next call; NULL clears it.
+int dbn_conv_bn_set_final(int* counters, double* group) {
+    g_bnf_cnt = counters;
+    g_bnf_grp = counters ? group : nullptr;
+    return (counters && !group) ? DBN_ERR_ARG : DBN_OK;
+}
+long dbn_conv_bn_final_group_doubles(int rows, int Cd) { return 4L * Cd * ((rows + 63) / 64); }
+
 // optional BatchNorm-backward sums of a call (IgemmParams::bnb_*); y / zmask advance with dst over image chunks
 struct IgemmBnb {
     const void *y, *zmask;
@@ -288,8 +310,14 @@ struct IgemmBnb {
 static int igemm_run_one(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                          int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int cfg, int ns,
                          hipStream_t st, float* stats, int stat_rows, int stat_row0, int ksplit, float* slab, int* rows_out, int at,
-                         long plane_bytes, const IgemmBnb* bnb = nullptr, int tile_hint = -1, const void* res = nullptr, int relu = 0) {
+                         long plane_bytes, const IgemmBnb* bnb = nullptr, int tile_hint = -1, const void* res = nullptr, int relu = 0,
+                         const BnFin* bnf = nullptr) {
     IgemmParams p{};
+    if (bnf) {
+        p.bnf_cnt = bnf->cnt; p.bnf_grp = bnf->grp; p.bnf_gamma = bnf->gamma; p.bnf_beta = bnf->beta; p.bnf_eps = bnf->eps;
+        p.bnf_momentum = bnf->momentum; p.bnf_run_mean = bnf->run_mean; p.bnf_run_var = bnf->run_var; p.bnf_scale = bnf->scale;
+        p.bnf_shift = bnf->shift; p.bnf_mean = bnf->mean; p.bnf_rstd = bnf->rstd;
+    }
     p.res = res; p.relu = relu;  // inference epilogue (dbn_igemm_act_t)
     p.bnb_y = bnb ? bnb->y : nullptr; p.bnb_zmask = bnb ? bnb->zmask : nullptr;
     p.bnb_msc = bnb ? bnb->msc : nullptr; p.bnb_msh = bnb ? bnb->msh : nullptr;
@@ -381,7 +409,7 @@ static int bn_tile_rows_one(int n, int Hd, int Wd, int mode, int stride, int cfg
 static int igemm_run(const void* src, const float* wpk, const float* bias, void* dst, int N, int Hs, int Ws, int Cs, int Hd,
                      int Wd, int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                      void* stream, float* stats = nullptr, int ksplit = 1, float* slab = nullptr, int stat_rows_total = 0, int at = 0,
-                     const IgemmBnb* bnb = nullptr, const void* res = nullptr, int relu = 0) {
+                     const IgemmBnb* bnb = nullptr, const void* res = nullptr, int relu = 0, const BnFin* bnf = nullptr) {
     DBN_REQUIRE((!res && !relu) || (ksplit <= 1 && !stats && !bnb && !(mode == 1 && stride > 1)));  // inference epilogue: plain launches only
     DBN_REQUIRE(src && wpk && dst && (ns == 0 || ns == 1 || ns == 3));
     // 16-bit storage / pre-split planes: 8-channel pieces of 16-channel blocks
@@ -414,7 +442,7 @@ static int igemm_run(const void* src, const float* wpk, const float* bias, void*
                                      reinterpret_cast<char*>(dst) + (long)n0 * Hd * Wd * Cd * des, n, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride,
                                      pad, mode, accumulate, cfg, ns, st, stats, stat_rows_total, row0, ksplit, slab, &rows, at, plane_bytes,
                                      bnb ? &b : nullptr, tile_hint,
-                                     res ? reinterpret_cast<const char*>(res) + (long)n0 * Hd * Wd * Cd * des : nullptr, relu);
+                                     res ? reinterpret_cast<const char*>(res) + (long)n0 * Hd * Wd * Cd * des : nullptr, relu, bnf);
         if (rc) return rc;
         row0 += rows;
     }
@@ -521,10 +549,18 @@ int dbn_conv_bn_t(int at, const void* src, const float* wpk, const float* bias, 
     DBN_REQUIRE(gamma && beta && scale && shift && save_mean && save_rstd && ws);
     const int rows = bn_tile_rows(N, Hs, Ws, Cs, Hd, Wd, Cd, mode, stride, tile_hint, at, ns, R, S, pad, true, accumulate);
     DBN_REQUIRE(rows > 0);
+    // the in-kernel finalize, when the caller announced it (dbn_conv_bn_set_final) and the launch has that epilogue (every igemm_f32_kernel /
+    // conv3x3_wres16_kernel launch; not the 2x2 ConvTranspose kernel)
+    int* const fcnt = g_bnf_cnt;
+    double* const fgrp = g_bnf_grp;
+    g_bnf_cnt = nullptr;
+    g_bnf_grp = nullptr;
+    const bool fin = fcnt && !convt_eligible(mode, ns, at, tile_hint, R, S, stride, pad, Hs, Ws, Hd, Wd, Cs, Cd, accumulate, 1);
+    const BnFin f{fcnt, fgrp, gamma, beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd};
     // (16-bit storage: the statistics are those of the fp32 accumulators, i.e. of the values BEFORE they are rounded for storage)
     const int rc = igemm_run(src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode, accumulate, tile_hint, ns, stream, ws,
-                             1, nullptr, rows, at);
-    if (rc) return rc;
+                             1, nullptr, rows, at, nullptr, nullptr, 0, fin ? &f : nullptr);
+    if (rc || fin) return rc;
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();
@@ -575,8 +611,17 @@ int dbn_winograd_conv_bn_act_f32(const float* src, const float* in_scale, const 
     p.src_bytes = (unsigned)((long)N * H * W * Cs * 4);
     const int rows = dbn_winograd_rows(N, H, W);
     p.stats = gamma ? ws : nullptr; p.stat_rows = rows; p.stat_row0 = 0;
+    int* const fcnt = g_bnf_cnt;
+    double* const fgrp = g_bnf_grp;
+    g_bnf_cnt = nullptr;
+    g_bnf_grp = nullptr;
+    const bool fin = gamma && fcnt;
+    if (fin) {  // the statistics rows are folded by the kernel's own last workgroups (dbn_conv_bn_set_final)
+        p.bnf_cnt = fcnt; p.bnf_grp = fgrp; p.bnf_gamma = gamma; p.bnf_beta = beta; p.bnf_eps = eps; p.bnf_momentum = momentum;
+        p.bnf_run_mean = run_mean; p.bnf_run_var = run_var; p.bnf_scale = scale; p.bnf_shift = shift; p.bnf_mean = save_mean; p.bnf_rstd = save_rstd;
+    }
     const int rc = dbn_launch_winograd_f32(p, (hipStream_t)stream);
-    if (rc || !gamma) return rc;
+    if (rc || !gamma || fin) return rc;
     hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(Cd), dim3(rows >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, ws, rows, Cd, gamma,
                        beta, eps, momentum, run_mean, run_var, scale, shift, save_mean, save_rstd);
     return dbn_status();

@@ -116,6 +116,15 @@ struct IgemmParams {
     float* bnb_grp;
     float *bnb_c1c2[2], *bnb_dgamma[2], *bnb_dbeta[2];
     float bnb_gscale, bnb_invM;
+    // optional in-kernel finalize of the train-mode BatchNorm STATISTICS (`stats` rows; round 6, dbn_conv_bn_set_final): the workgroup that
+    // completes a group of 64 partial rows folds the group, the one that completes the last group folds the groups and writes what
+    // bn_finalize_tiles_kernel would (scale / shift / saved mean / rstd / running statistics) — no finalize launch behind the conv.
+    // bnf_cnt: [Cd / 64][1 + groups] ints, zero on entry and left zero; bnf_grp: [Cd][groups][4] doubles of scratch.
+    int* bnf_cnt;
+    double* bnf_grp;
+    const float *bnf_gamma, *bnf_beta;
+    float bnf_eps, bnf_momentum;
+    float *bnf_run_mean, *bnf_run_var, *bnf_scale, *bnf_shift, *bnf_mean, *bnf_rstd;
     unsigned src_bytes;
     unsigned plane_bytes;  // AT = 3: distance between the three bf16 planes of src (0 otherwise)
     // MODE 2 only: per class its number of tiles, first M-tile index, weight-panel offset (floats)
@@ -241,6 +250,151 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&af)[NS > 0 ? NS : 1][M
         for (int a = 0; a < MI; ++a)
 #pragma unroll
             for (int b = 0; b < NI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][a], bf[j][b], acc[a][b], 0, 0, 0);
+    }
+}
+
+// ---- in-kernel finalize of the BatchNorm statistics rows (IgemmParams::bnf_*).  Called by EVERY thread of a workgroup after it wrote its
+// partial row `trow` (the row's stores through dbn_stat_put: memory-side when the finalize is on).  BN: channels [n0, n0 + BN) of tile column
+// nt belong to this workgroup's rows; blockDim.x % BN == 0.  s_flag: one int of LDS; sd: 3 * blockDim.x doubles of LDS (dead panels).
+// Hand-over as igemm_kernel.h's bnb_finish: sc1 stores of the payload, s_waitcnt vmcnt(0), agent-scope integer counters, sc1 loads — no
+// device-scope fence.  The merge is bn_finalize_tiles_kernel's (every partial shifted to a common pivot, fp64), in two levels; the
+// order of every sum is fixed by (blockDim.x, BN, rows): bit-reproducible.
+// (the kernels hold their IgemmParams in different address spaces — a by-value copy of the fields the finalize needs travels instead)
+struct BnStatFinal {
+    float* stats;
+    int stat_rows, Cd;
+    int* bnf_cnt;
+    double* bnf_grp;
+    const float *bnf_gamma, *bnf_beta;
+    float bnf_eps, bnf_momentum;
+    float *bnf_run_mean, *bnf_run_var, *bnf_scale, *bnf_shift, *bnf_mean, *bnf_rstd;
+};
+#define DBN_BNF_ARGS(p)                                                                                                              \
+    BnStatFinal {                                                                                                                    \
+        (p).stats, (p).stat_rows, (p).Cd, (p).bnf_cnt, (p).bnf_grp, (p).bnf_gamma, (p).bnf_beta, (p).bnf_eps, (p).bnf_momentum,        \
+            (p).bnf_run_mean, (p).bnf_run_var, (p).bnf_scale, (p).bnf_shift, (p).bnf_mean, (p).bnf_rstd                                \
+    }
+__device__ __forceinline__ void dbn_stat_put(bool fin, float* ptr, float v) {
+    if (fin) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *ptr = v;
+}
+__device__ __forceinline__ void dbn_bn_stats_finish(const BnStatFinal p, int trow, int nt, int n0, int BN, int* s_flag, double* sd) {
+    if (!p.bnf_cnt) return;
+    constexpr int G = 64;
+    const int rows = p.stat_rows, NG = (rows + G - 1) / G, g = trow / G;
+    const int tid = threadIdx.x, NT = blockDim.x, parts = NT / BN;
+    const int cl = tid % BN, part = tid / BN;
+    const long c = n0 + cl;
+    int* const cnt = p.bnf_cnt + nt * (NG + 1);
+    auto xld = [](const float* q) { return (double)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto xldd = [](const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto xstd = [](double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto combine = [&](double& n, double& a1, double& a2) {  // the `parts` partial tuples of a channel (same pivot), in the order of the parts
+        __syncthreads();
+        sd[tid] = n;
+        sd[NT + tid] = a1;
+        sd[2 * NT + tid] = a2;
+        __syncthreads();
+        if (part == 0)
+            for (int q = 1; q < parts; ++q) {
+                n += sd[q * BN + cl];
+                a1 += sd[NT + q * BN + cl];
+                a2 += sd[2 * NT + q * BN + cl];
+            }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial-row stores have completed
+    __syncthreads();
+    DBN_RACE_JITTER();
+    if (tid == 0) {
+        const int gsize = min(G, rows - g * G);
+        const int last = __hip_atomic_fetch_add(cnt + 1 + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1;
+        if (last) __hip_atomic_store(cnt + 1 + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nobody touches it again in this call)
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    asm volatile("" ::: "memory");
+    {   // ---- this group's rows -> one tuple (pivot of its first row, count, sum, sum of squares about that pivot) per channel
+        const int r0 = g * G, r1 = min(rows, r0 + G);
+        const float* const pv = p.stats + (0L * p.Cd + c) * rows;
+        const float* const s1 = p.stats + (1L * p.Cd + c) * rows;
+        const float* const s2 = p.stats + (2L * p.Cd + c) * rows;
+        const float* const cn = p.stats + 3L * p.Cd * rows;
+        const double P0 = xld(pv + r0);
+        double n = 0.0, a1 = 0.0, a2 = 0.0;
+        int r = r0 + part;
+        for (; r + 3 * parts < r1; r += 4 * parts) {  // four rows in flight
+            double nq[4], dq[4], tq[4], uq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                nq[u] = xld(cn + r + u * parts);
+                dq[u] = xld(pv + r + u * parts);
+                tq[u] = xld(s1 + r + u * parts);
+                uq[u] = xld(s2 + r + u * parts);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d = dq[u] - P0;
+                n += nq[u];
+                a1 += tq[u] + nq[u] * d;
+                a2 += uq[u] + d * (2.0 * tq[u] + nq[u] * d);
+            }
+        }
+        for (; r < r1; r += parts) {
+            const double nq = xld(cn + r), d = xld(pv + r) - P0, tq = xld(s1 + r);
+            n += nq;
+            a1 += tq + nq * d;
+            a2 += xld(s2 + r) + d * (2.0 * tq + nq * d);
+        }
+        combine(n, a1, a2);
+        if (part == 0) {
+            double* const Gq = p.bnf_grp + ((long)c * NG + g) * 4;
+            xstd(Gq + 0, P0);
+            xstd(Gq + 1, n);
+            xstd(Gq + 2, a1);
+            xstd(Gq + 3, a2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DBN_RACE_JITTER();
+    if (tid == 0) {
+        const int last = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NG - 1;
+        if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    asm volatile("" ::: "memory");
+    {   // ---- the groups -> the BatchNorm's coefficients (bn_finalize_tiles_kernel's arithmetic)
+        const double* const Gc = p.bnf_grp + (long)c * NG * 4;
+        const double P0 = xldd(Gc);
+        double n = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int q = part; q < NG; q += parts) {
+            const double pq = xldd(Gc + 4 * q), nq = xldd(Gc + 4 * q + 1), tq = xldd(Gc + 4 * q + 2), uq = xldd(Gc + 4 * q + 3);
+            const double d = pq - P0;
+            n += nq;
+            a1 += tq + nq * d;
+            a2 += uq + d * (2.0 * tq + nq * d);
+        }
+        combine(n, a1, a2);
+        if (part == 0) {
+            const double m1 = a1 / n, mean = P0 + m1, m2 = a2 - a1 * m1;
+            double var = m2 / n;
+            if (var < 0.0) var = 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.bnf_eps));
+            const float meanf = (float)mean;
+            const float sc = p.bnf_gamma[c] * rstd;
+            p.bnf_scale[c] = sc;
+            p.bnf_shift[c] = fmaf(-meanf, sc, p.bnf_beta[c]);
+            p.bnf_mean[c] = meanf;
+            p.bnf_rstd[c] = rstd;
+            if (p.bnf_run_mean) {
+                const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+                p.bnf_run_mean[c] = (1.f - p.bnf_momentum) * p.bnf_run_mean[c] + p.bnf_momentum * meanf;
+                p.bnf_run_var[c] = (1.f - p.bnf_momentum) * p.bnf_run_var[c] + p.bnf_momentum * (float)unb;
+            }
+        }
     }
 }
 

@@ -147,7 +147,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     constexpr int OUT_SMEM = DST_F32 ? 0 : (BM * (BN + 8) * 2 + 15) / 16;
     constexpr int SMEM_A = LOOP_SMEM > EPI_SMEM ? LOOP_SMEM : EPI_SMEM;
     // (+ one slot: the in-kernel finalize of the BatchNorm sums keeps its flag in the last 16 bytes, behind every scratch region)
-    __shared__ f32x4 smem[(SMEM_A > OUT_SMEM ? SMEM_A : OUT_SMEM) + 1];
+    // (... and at least the 3 * NT doubles of the in-kernel statistics finalize, dbn_bn_stats_finish)
+    constexpr int FIN_SMEM = (3 * NT * 8 + 15) / 16;
+    constexpr int SMEM_B = SMEM_A > OUT_SMEM ? SMEM_A : OUT_SMEM;
+    __shared__ f32x4 smem[(SMEM_B > FIN_SMEM ? SMEM_B : FIN_SMEM) + 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1479,12 +1482,25 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 s2 += r2[w * BN + cl];
             }
             const long c = n0 + cl;
-            p.stats[(0L * p.Cd + c) * p.stat_rows + trow] = piv[cl];
-            p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
-            p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
+            dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (0L * p.Cd + c) * p.stat_rows + trow, piv[cl]);
+            dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (1L * p.Cd + c) * p.stat_rows + trow, s1);
+            dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (2L * p.Cd + c) * p.stat_rows + trow, s2);
         }
-        if (nt == 0 && tid == 0) p.stats[3L * p.Cd * p.stat_rows + trow] = (float)min(BM, qM - m0);
+        // (the count row: tile column 0 writes it; with the in-kernel finalize EVERY column does — the same value — because each column
+        // folds its own channels on its own counters and must not read a count that column 0's workgroup has yet to write)
+        if ((nt == 0 || p.bnf_cnt) && tid == 0) dbn_stat_put(p.bnf_cnt != nullptr, p.stats + 3L * p.Cd * p.stat_rows + trow, (float)min(BM, qM - m0));
     }
+    // optional in-kernel finalize of those rows (IgemmParams::bnf_cnt): the last workgroup of every 64 rows folds them, the last of those the
+    // groups.  Called at the END of the workgroup, behind its output stores (first build: right here — every workgroup then sat through
+    // an s_waitcnt vmcnt(0) and an atomic round trip before it stored its tile: 716 -> 700 images/s)
+    static_assert((long)sizeof(smem) >= 3L * NT * 8 + 16, "LDS scratch of the statistics finalize");
+    auto fin_stats = [&]() {
+        if (p.stats && p.bnf_cnt) {
+            __syncthreads();  // (the LDS staging of the output tile is dead)
+            dbn_bn_stats_finish(DBN_BNF_ARGS(p), p.stat_row0 + q_row_base + mt, nt, n0, BN, reinterpret_cast<int*>(smem) + (sizeof(smem) / 4 - 4),
+                                reinterpret_cast<double*>(smem));
+        }
+    };
 
     // ---- epilogue: D[row][col], col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // the bias values of this lane's NI columns are loaded once (inside the row loop the compiler re-loaded them for every
@@ -1825,6 +1841,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
                 tile_row(row, ok, doff);
                 if (ok) *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(dstv) + doff + n0 + piece * 8) = v;
             }
+            fin_stats();
             return;
         }
     }
@@ -1890,6 +1907,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and once more when this thread's output stores have completed
     DBN_TRACE_MARK(4);
 #endif
+    fin_stats();
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int AT = 0>

@@ -788,11 +788,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float s1 = (r1[tid] + r1[64 + tid]) + (r1[128 + tid] + r1[192 + tid]);
                 const float s2 = (r2[tid] + r2[64 + tid]) + (r2[128 + tid] + r2[192 + tid]);
                 const long c = n0 + tid;
-                p.stats[(0L * p.Cd + c) * p.stat_rows + trow] = piv[tid];
-                p.stats[(1L * p.Cd + c) * p.stat_rows + trow] = s1;
-                p.stats[(2L * p.Cd + c) * p.stat_rows + trow] = s2;
+                dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (0L * p.Cd + c) * p.stat_rows + trow, piv[tid]);
+                dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (1L * p.Cd + c) * p.stat_rows + trow, s1);
+                dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (2L * p.Cd + c) * p.stat_rows + trow, s2);
             }
-            if (nt == 0) {  // the number of real pixels of this tile group: every wave holds one (dy, dx) of each tile — lanes 0 and 32 its two halves
+            if (nt == 0 || p.bnf_cnt) {  // (with the in-kernel finalize every tile column writes the count — the same value: igemm_kernel.h)  // the number of real pixels of this tile group: every wave holds one (dy, dx) of each tile — lanes 0 and 32 its two halves
                 int* const cntp = reinterpret_cast<int*>(r2 + 4 * 64);
                 __syncthreads();
                 if (li == 0) cntp[wave * 2 + lh] = __builtin_popcount(vmask);
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (tid == 0) {
                     int c_ = 0;
                     for (int k = 0; k < 8; ++k) c_ += cntp[k];
-                    p.stats[3L * p.Cd * p.stat_rows + trow] = (float)c_;
+                    dbn_stat_put(p.bnf_cnt != nullptr, p.stats + 3L * p.Cd * p.stat_rows + trow, (float)c_);
                 }
             }
         }
@@ -813,6 +813,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #endif
         DBN_TRACE_MARK(3);
+        // optional in-kernel finalize of the statistics rows (IgemmParams::bnf_cnt, igemm_common.h), behind this item's output stores
+        if (p.stats && p.bnf_cnt) {
+            __syncthreads();
+            dbn_bn_stats_finish(DBN_BNF_ARGS(p), p.stat_row0 + mt, nt, n0, 64, reinterpret_cast<int*>(smem) + (sizeof(smem) / 4 - 4), reinterpret_cast<double*>(smem));
+            __syncthreads();
+        }
 
         if constexpr (!PERSIST) break;
         if (!p.work) {

@@ -526,17 +526,22 @@ void conv3x3_wres16_kernel(const IgemmParams p, const int T, const int nstrip) {
                 const float a = half_sum(s1[gq][e]), b = half_sum(s2[gq][e]);
                 if (li == 0) {
                     const long c = oc * 32 + 8 * (ks * GPW + gq) + 4 * lh + e;
-                    p.stats[(0L * CD + c) * p.stat_rows + trow] = pv[e];
-                    p.stats[(1L * CD + c) * p.stat_rows + trow] = a;
-                    p.stats[(2L * CD + c) * p.stat_rows + trow] = b;
+                    dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (0L * CD + c) * p.stat_rows + trow, pv[e]);
+                    dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (1L * CD + c) * p.stat_rows + trow, a);
+                    dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (2L * CD + c) * p.stat_rows + trow, b);
                 }
             }
         }
-        if (tid == 0) p.stats[3L * CD * p.stat_rows + trow] = (float)npx;
+        if (tid == 0) dbn_stat_put(p.bnf_cnt != nullptr, p.stats + 3L * CD * p.stat_rows + trow, (float)npx);
         // the rows a pixel-patch launch would have written beyond this launch's workgroups: empty
         for (int r = (int)blockIdx.x + nwg; r < p.launch_rows; r += nwg) {
-            for (int i = tid; i < 3 * CD; i += NT) p.stats[(long)i * p.stat_rows + p.stat_row0 + r] = 0.f;
-            if (tid == 0) p.stats[3L * CD * p.stat_rows + p.stat_row0 + r] = 0.f;
+            for (int i = tid; i < 3 * CD; i += NT) dbn_stat_put(p.bnf_cnt != nullptr, p.stats + (long)i * p.stat_rows + p.stat_row0 + r, 0.f);
+            if (tid == 0) dbn_stat_put(p.bnf_cnt != nullptr, p.stats + 3L * CD * p.stat_rows + p.stat_row0 + r, 0.f);
+        }
+        // optional in-kernel finalize (IgemmParams::bnf_cnt, igemm_common.h): one arrival per partial row, the empty ones included
+        for (int r = (int)blockIdx.x; r < p.launch_rows; r += nwg) {
+            __syncthreads();
+            dbn_bn_stats_finish(DBN_BNF_ARGS(p), p.stat_row0 + r, 0, 0, CD, reinterpret_cast<int*>(smem + G::SMEM - 1), reinterpret_cast<double*>(smem));
         }
     }
     if constexpr (EPI == 1) {

@@ -679,6 +679,7 @@ class Engine:
             sc, sh = self.fbuf(bn_name + '/scale', Co), self.fbuf(bn_name + '/shift', Co)
             mu, rs = self.fbuf(bn_name + '/mean', Co), self.fbuf(bn_name + '/rstd', Co)
             ws = self.scratch('_conv_bn_ws', self.L.dbn_winograd_ws_floats(N, H, W, Co))
+            self._announce_bn_final(bn_name, self.L.dbn_winograd_rows(N, H, W), Co)
             check(self.L.dbn_winograd_conv_bn_act_f32(x.data_ptr(), asc, ash, up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, Co,
                                                       bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
@@ -711,6 +712,23 @@ class Engine:
 
     splitk = True  # split the reduction of convs with few output tiles (dbn_igemm_splitk_plan)
     fuse_bn_stats = True  # accumulate train-mode BN statistics in the conv epilogue (no separate statistics pass)
+XX
+
+    def _announce_bn_final(self, bn_name, rows, C):
+        """Counters (zero once: the kernels leave them zero) and group scratch of this BatchNorm's in-kernel statistics finalize."""
+        if not self.bn_final_in_kernel or rows <= 0:
+            return
+        ncnt = self.L.dbn_igemm_bn_final_counters(rows, C)
+        cnt = self.bufs.get(bn_name + '/bnf_cnt')
+        if cnt is None or cnt.numel() != ncnt or cnt.device != self.flat.device:
+            cnt = torch.zeros(ncnt, device=self.flat.device, dtype=torch.int32)
+            self.bufs[bn_name + '/bnf_cnt'] = cnt
+        ng = self.L.dbn_conv_bn_final_group_doubles(rows, C)
+        grp = self.bufs.get(bn_name + '/bnf_grp')
+        if grp is None or grp.numel() != ng or grp.device != self.flat.device:
+            grp = torch.empty(ng, device=self.flat.device, dtype=torch.float64)
+            self.bufs[bn_name + '/bnf_grp'] = grp
+        check(self.L.dbn_conv_bn_set_final(cnt.data_ptr(), grp.data_ptr()), 'conv_bn_set_final')
 
     def _conv_bn_call(self, what, bn_name, bn, y, args, mode, stride, accumulate=0):
         """args: dbn_igemm_f32's arguments up to and including `mode` (without accumulate / tile_hint / stream)."""
@@ -720,6 +738,8 @@ class Engine:
         N, Hd, Wd = y.shape[0], y.shape[1], y.shape[2]
         ws = self.scratch('_conv_bn_ws', self.L.dbn_conv_bn_ws_floats(N, Hd, Wd, C, mode, stride))
         at, srcp = self._src(args[0], args[7])
+        # args = (src, wpk, bias, dst, N, Hs, Ws, Cs, Hd, Wd, Cd, R, S, stride, pad, mode)
+        self._announce_bn_final(bn_name, self.L.dbn_igemm_bn_rows(at, self.ns, *args[4:15], mode, 0), C)
         check(self.L.dbn_conv_bn_t(at, srcp, *args[1:], accumulate, 0, self.ns, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum,
                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                      mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), self.stream), what)

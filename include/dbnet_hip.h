@@ -104,6 +104,15 @@ int dbn_igemm_bnsums_t(int at, int ns, const void* src, const float* wpk, const 
  * Arguments: dbn_igemm_f32's, ns = 0 (fp32 MFMA) / 3 / 1 (split-bf16), then dbn_bn_train_stats' BN arguments.
  * With accumulate = 1 the statistics are those of the final (previous dst + this conv) values.  ws: dbn_conv_bn_ws_floats(N,Hd,Wd,Cd,mode,stride) floats. */
 long dbn_conv_bn_ws_floats(int N, int Hd, int Wd, int Cd, int mode, int stride);
+/* Round 6: the NEXT dbn_conv_bn_t / dbn_winograd_conv_bn[_act]_f32 call of the calling thread folds its statistics rows ITSELF — the
+ * workgroup that completes a group of 64 partial rows folds the group, the one that completes the last group folds the groups and writes
+ * scale / shift / saved mean / rstd / running statistics: no finalize launch behind the conv (32 launches of a ResNet18-FPN train step).
+ * counters: dbn_igemm_bn_final_counters(rows, Cd) ints with rows = dbn_igemm_bn_rows(...) / dbn_winograd_rows(...), ZERO before the first
+ * use (the kernels leave them zero) and not shared by calls that may be in flight together; group: dbn_conv_bn_final_group_doubles(rows, Cd)
+ * doubles of scratch.  Where the launch has no such epilogue (the 2x2 ConvTranspose kernel) the announcement is dropped and the finalize
+ * kernel runs as before.  Same results as the finalize kernel up to fp64 summation order.  NULL clears a pending announcement. */
+int dbn_conv_bn_set_final(int* counters, double* group);
+long dbn_conv_bn_final_group_doubles(int rows, int Cd);
 int dbn_conv_bn_f32(const float* src, const float* wpk, const float* bias, float* dst, int N, int Hs, int Ws, int Cs, int Hd, int Wd,
                     int Cd, int R, int S, int stride, int pad, int mode, int accumulate, int tile_hint, int ns,
                     const float* gamma, const float* beta, float eps, float momentum, float* run_mean, float* run_var,
