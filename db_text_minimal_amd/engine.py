@@ -712,7 +712,13 @@ class Engine:
 
     splitk = True  # split the reduction of convs with few output tiles (dbn_igemm_splitk_plan)
     fuse_bn_stats = True  # accumulate train-mode BN statistics in the conv epilogue (no separate statistics pass)
-XX
+    # round 6: ... and fold the per-tile rows in the conv's own last workgroups (dbn_conv_bn_set_final): no bn_finalize_tiles_kernel launch —
+    # 7 us of kernel + ~6 us of dependent-dispatch gap, 32 times a step — between a conv and whatever consumes its BatchNorm's coefficients.
+    # Built, tested (tests/test_bn_final_gpu.py), measured and OFF: 277 -> 245 launches per fp32 step, but 711.4 / 711.9 images/s against
+    # 726.8 / 723.7 with the finalize kernels (one box, interleaved): every workgroup of every conv pays the hand-over (its row stores drained,
+    # an atomic round trip, two barriers: ~2-3 us at the end of a 20-70 us lifetime, six rounds per launch) to save one ~13 us launch.
+    # DBN_BN_FINAL=1 turns it on.
+    bn_final_in_kernel = os.environ.get('DBN_BN_FINAL', '0') == '1'
 
     def _announce_bn_final(self, bn_name, rows, C):
         """Counters (zero once: the kernels leave them zero) and group scratch of this BatchNorm's in-kernel statistics finalize."""
