@@ -415,7 +415,7 @@ class Engine:
         return self.at, ptr
 
     fuse_bn_bwd_sums = True  # data gradients also reduce the two sums of the BatchNorm backward that consumes their output
-    bnb_finalize_in_kernel = True  # ... and fold them to the per-channel results themselves (last-arriver, fixed order)
+    bnb_finalize_in_kernel = os.environ.get('DBN_BNB_FINAL', '0') == '1'  # ... and fold them to the per-channel results themselves (last-arriver, fixed order).  OFF since round 6 (DBN_BNB_FINAL=1: on): the per-workgroup hand-over costs more than the finalize launches it removes — one box, interleaved: fp32 725.9 / 726.9 -> 729.8 / 730.9 images/s, bf16 1708.7 -> 1780.5 (the same finding as for the statistics rows, bn_final_in_kernel)
 
     def _bnb_eligible(self, args):
         """Can this igemm call (dbn_igemm_f32 argument list) carry the BatchNorm-backward sums of its consumer?"""
