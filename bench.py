@@ -628,6 +628,28 @@ def main():
             barrier()
             alt[mode] = {'images_per_s': round(world * args.batch * args.steps / (time.perf_counter() - t1), 2),
                          'dtype': MATH[mode][0], 'note': MATH[mode][1]}
+            if mode == 'bf16':
+                # BASELINE configs[2]'s matrix-pipe figure in THIS line (the driver records only the fp32 run): one instrumented step on a
+                # single stream, the MFMA kernel with the largest share, against the nominal and the sustained bf16 rate and its own
+                # per-launch roofline max(FLOPs / peak, bytes / 6.3 TB/s)
+                t_alt = KernelTimer()
+                eng.prof = t_alt
+                trainer.step(img, gts)
+                torch.cuda.synchronize()
+                eng.prof = None
+                sa = t_alt.summary(MATH[mode][2], HBM_ACHIEVABLE_GBS)
+                mf = [k for k in sa if sa[k]['flops'] > 0]
+                if mf:
+                    kd = max(mf, key=lambda k: sa[k]['ms'])
+                    a_ = sa[kd]['flops'] / (sa[kd]['ms'] * 1e-3) / 1e12
+                    sus = mfma_sustained(dev, mode)
+                    alt[mode]['roofline'] = {'bound': 'mfma', 'kernel': kd, 'achieved': round(a_, 1), 'peak': MATH[mode][2], 'unit': 'TFLOP/s',
+                                             'frac': round(a_ / MATH[mode][2], 4), 'peak_sustained': round(sus, 1),
+                                             'frac_of_sustained': round(a_ / sus, 4), 'launches': sa[kd]['launches'],
+                                             'ms_per_step': round(sa[kd]['ms'], 3),
+                                             'frac_of_own_roofline': round(sa[kd]['roof_ms'] / sa[kd]['ms'], 4) if sa[kd].get('roof_ms') else None,
+                                             'all_mfma_kernels_frac': round(sum(sa[k]['flops'] for k in mf) / (sum(sa[k]['ms'] for k in mf) * 1e-3) / 1e12 / MATH[mode][2], 4),
+                                             'how': 'one extra step, every launch bracketed by HIP events on a single stream'}
         eng.set_conv_math(args.math)
     gc.enable()
     if rank == 0:

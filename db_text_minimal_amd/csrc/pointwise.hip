@@ -1272,12 +1272,15 @@ int dbn_bn_backward_t(int at, const float* sums, int sums_parts, const void* y, 
                                grad_scale);
         }
         // the reduce partials at the front of ws have been consumed by the finalize kernel: the bias partials [C][grid] reuse them
+#ifndef DBN_DBG_SKIP_BN_BWD_APPLY
+#define DBN_DBG_SKIP_BN_BWD_APPLY 0  // 1 (timing-only A/B build, wrong results): the apply pass is not launched — the upper bound of what fusing it into its consumers could save
+#endif
         if constexpr (AT != 0) {
-            if (wide)
+            if (wide && !DBN_DBG_SKIP_BN_BWD_APPLY)
                 hipLaunchKernelGGL((bn_bwd_apply_kernel<AT, 2>), dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
                                    save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
         }
-        if (!wide)
+        if (!wide && !DBN_DBG_SKIP_BN_BWD_APPLY)
             hipLaunchKernelGGL((bn_bwd_apply_kernel<AT, 1>), dim3(grid), dim3(256), 0, st, y, zmask, mask_scale, mask_shift, dout, save_mean,
                                save_rstd, gamma, c1, c2, dy, gout, gout_accumulate, total4, C, dbias_conv ? ws : nullptr);
     });

@@ -44,9 +44,6 @@ python3 tools/rocpd_stats.py $O/trace_x3/r01_results.db $O/kernel_stats_bf16x3.m
 grep '^{"metric"' $O/bench_bf16x3_under_rocprof.log > $O/bench_bf16x3_under_rocprof.json
 K16=$(fastest_step $O/trace_bf16/r01_results.db)
 python3 tools/step_breakdown.py $O/trace_bf16/r01_results.db $K16 > $O/step_breakdown_bf16.txt 2>&1
-for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline and parity object
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-modes --math $m 2>/dev/null | grep '^{"metric"' > $O/bench_n1_$m.json
-done
 # round 5: the probes behind DESIGN section 13 (alone, HIP events) and the other BASELINE configurations
 python3 tools/winograd_probe.py 2>/dev/null | grep -v amdgpu > $O/winograd_probe.txt
 python3 tools/winograd_wgrad_probe.py 2>/dev/null | grep -v amdgpu > $O/winograd_wgrad_probe.txt
@@ -80,6 +77,10 @@ python3 tools/pmc_traffic.py $O/pmc_fetch16/r01_results.db $O/pmc_write16/r01_re
 python3 tools/pmc_traffic.py $O/pmc_fetch_eval/r01_results.db $O/pmc_write_eval/r01_results.db $O/pmc_traffic_fp16.json > /dev/null
 cp $O/pmc_traffic_bf16.json profiles/${TAG}_pmc_traffic_bf16.json
 cp $O/pmc_traffic_fp16.json profiles/${TAG}_pmc_traffic_fp16.json
+# (the plain lines of the alternative modes come AFTER the mode's traffic file exists: bench.py quotes it in roofline.traffic)
+for m in bf16 bf16x3; do   # the plain (un-profiled) lines of the two alternative modes, each with its own roofline and parity object
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-modes --math $m 2>/dev/null | grep '^{"metric"' > $O/bench_n1_$m.json
+done
 python3 tools/pmc_mfma_busy.py $O/pmc_mfma/r01_results.db > $O/mfma_busy_f32.txt 2>&1
 python3 tools/pmc_mfma_busy.py $O/pmc_mfma16/r01_results.db > $O/mfma_busy_bf16.txt 2>&1
 python3 tools/pmc_mfma_busy.py $O/pmc_mfma_eval/r01_results.db > $O/mfma_busy_eval_fp16.txt 2>&1
