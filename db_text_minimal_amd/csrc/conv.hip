@@ -189,11 +189,12 @@ int dbn_set_stagger(int permille) {
 
 static bool patch_eligible_fwd(int mode, int at, int H, int W, int Cs);
 // the weight-resident 3x3 kernel of the 16-bit storage types (wres16.hip): 1 = takes every pixel-patch launch it is eligible for
-// (default), 0 = off (test / A-B hook: the pixel-patch kernel again)
-int dbn_g_wres16 = getenv("DBN_WRES16") ? atoi(getenv("DBN_WRES16")) != 0 : 1;  // (DBN_WRES16=0: A/B runs of whole programs)
+// (default), 0 = off (test / A-B hook: the pixel-patch kernel again), 2 = also maps whose width is not a multiple of the 32-column strip
+// (correct but measured slower than the pixel-patch kernel there — dbn_wres16_eligible; the tests of the ragged last strip use it)
+int dbn_g_wres16 = getenv("DBN_WRES16") ? atoi(getenv("DBN_WRES16")) : 1;  // (DBN_WRES16=0: A/B runs of whole programs)
 int dbn_set_wres16(int on) {
     const int old = dbn_g_wres16;
-    dbn_g_wres16 = on != 0;
+    dbn_g_wres16 = on < 0 ? 0 : on > 2 ? 2 : on;
     return old;
 }
 // Would a dbn_igemm_t / dbn_conv_bn_t / dbn_igemm_bnsums_t call with this geometry (3x3, stride 1, pad 1 implied) launch

@@ -689,8 +689,8 @@ bool dbn_wres16_eligible(int at, int mode, int N, int H, int W, int Cs, int Cd, 
     // per-channel sums and four operand tensors spills 36 registers: pixel-patch kernel
     if (bnb && Cs == 128) return false;
     // maps whose width is not a multiple of the 32-column strip: measured slower than the pixel-patch kernel (128 -> 128 at 16 x 80^2:
-    // 38-40 vs 35-36 us — a third of the last strip's MFMAs are padding)
-    if (W % 32 != 0) return false;
+    // 38-40 vs 35-36 us — a third of the last strip's MFMAs are padding); dbn_set_wres16(2) lifts the rule (tests of the ragged strip)
+    if (W % 32 != 0 && dbn_g_wres16 != 2) return false;
     return (long)N * H * W * Cd * 2 < 0xF0000000L && (long)N * ((W + 31) / 32) * H < 0x7FFFFFFFL;
 }
 

@@ -465,7 +465,9 @@ int dbn_wgrad_kernel_config_hw(int at, int ns, int O, int Cb, int R, int S, int 
 int dbn_set_patch_conv(int on);
 /* 1 (default): the 3x3 / stride-1 convolutions of the 16-bit storage types with 64 -> 64, 128 -> 128 or 256 -> 64 channels run in the
  * weight-resident kernel (csrc/wres16.hip: the panel in registers, the activations streamed row by row); 0: the pixel-patch kernel
- * again (test / A-B hook).  Returns the previous setting.  dbn_igemm_kernel_config reports such a launch with bit 64. */
+ * again (test / A-B hook); 2: as 1, and also maps whose width is not a multiple of the kernel's 32-column strip (by default those stay
+ * on the pixel-patch kernel, which is faster there; the tests of the ragged last strip use 2).  Returns the previous setting.
+ * dbn_igemm_kernel_config reports such a launch with bit 64. */
 int dbn_set_wres16(int on);
 int dbn_wres16_would_run(int at, int mode, int N, int H, int W, int Cs, int Cd, int bnb, int y2); /* 1: such a call launches that kernel */
 

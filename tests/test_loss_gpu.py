@@ -138,7 +138,7 @@ def test_loss_full_size_properties():
     gts = torch.stack([(u[0] > 0.9).float(), (u[1] > 0.05).float(), 0.3 + 0.4 * u[2], (u[3] > 0.8).float()])
     crit = DBLoss()
     prob, thr, binl, pt, total = crit(preds, gts)
-    vals = [float(v) for v in (prob, thr, binl, pt, total)]
+    vals = [float(v.detach()) for v in (prob, thr, binl, pt, total)]
     assert all(np.isfinite(vals))
     assert abs(vals[3] - (vals[0] + 10 * vals[1])) < 1e-5 and abs(vals[4] - (vals[2] + vals[3])) < 1e-5
     assert 0 <= vals[2] <= 1  # the reference's `assert loss <= 1` (losses.py:65)

@@ -21,6 +21,15 @@ pytestmark = pytest.mark.gpu
 ULP = {torch.bfloat16: 2.0**-7, torch.float16: 2.0**-10}  # spacing of the storage type relative to the binade start
 
 
+@pytest.fixture
+def any_width(request):
+    """Maps whose width is not a multiple of 32 go to the pixel-patch kernel by default (faster there); dbn_set_wres16(2) sends them to
+    the weight-resident kernel all the same, so that its ragged last strip stays tested."""
+    L().dbn_set_wres16(2)
+    yield
+    L().dbn_set_wres16(1)
+
+
 def _is_wres(dtype, mode, N, H, W, Cs, Cd):
     return bool(L().dbn_igemm_kernel_config(AT_OF[dtype], 1, mode, N, H, W, Cs, H, W, Cd, 3, 3, 1, 1, 0, 1) & 64)
 
@@ -28,7 +37,7 @@ def _is_wres(dtype, mode, N, H, W, Cs, Cd):
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('Ci,Co', [(64, 64), (128, 128), (256, 64)])
 @pytest.mark.parametrize('N,H,W', [(2, 24, 64), (3, 16, 80), (1, 40, 160), (5, 8, 32)])
-def test_forward_and_data_gradient_vs_fp64_and_the_patch_kernel(dtype, Ci, Co, N, H, W):
+def test_forward_and_data_gradient_vs_fp64_and_the_patch_kernel(dtype, Ci, Co, N, H, W, any_width):
     """Forward (bias), data gradient (accumulate onto a base tensor) and the inference epilogue (bias + residual + ReLU): every strip
     layout (W = 32 k, a ragged last strip at W = 80), workgroup ranges that cross strips and images, the K-split exchange (Ci > 64)."""
     kind = 2 if dtype == torch.float16 else 1
@@ -58,11 +67,11 @@ def test_forward_and_data_gradient_vs_fp64_and_the_patch_kernel(dtype, Ci, Co, N
     y2, d2, a2 = run()
     assert torch.equal(y1, y2) and torch.equal(d1, d2) and torch.equal(a1, a2), 'not bit-reproducible run to run'
     try:
-        assert L().dbn_set_wres16(0) == 1
+        assert L().dbn_set_wres16(0) == 2
         assert not _is_wres(dtype, 0, N, H, W, Ci, Co)
         y0, d0, a0 = run()
     finally:
-        L().dbn_set_wres16(1)
+        L().dbn_set_wres16(2)
     wq = w.to(dtype).double()
     ref_y = F.conv2d(nchw(x.double()), wq, b.double().cpu(), 1, 1)
     xg = torch.zeros(N, Cd1, H, W, dtype=torch.float64, requires_grad=True)
@@ -80,7 +89,7 @@ def test_forward_and_data_gradient_vs_fp64_and_the_patch_kernel(dtype, Ci, Co, N
 
 @pytest.mark.parametrize('Ci,Co', [(64, 64), (128, 128), (256, 64)])
 @pytest.mark.parametrize('N,H,W,accumulate', [(2, 24, 64, 0), (3, 16, 80, 0), (4, 8, 96, 1)])
-def test_train_mode_batchnorm_statistics_epilogue(Ci, Co, N, H, W, accumulate):
+def test_train_mode_batchnorm_statistics_epilogue(Ci, Co, N, H, W, accumulate, any_width):
     """dbn_conv_bn_t on bf16 storage: the conv's epilogue accumulates the train-mode BatchNorm statistics of its output — one partial
     row per workgroup (pivot = its first pixel), the rows a pixel-patch launch would have written beyond that left empty — and the
     finalize kernel merges them: scale / shift / saved mean / rstd / running statistics against fp64 on the fp32 accumulators' values
@@ -111,7 +120,7 @@ def test_train_mode_batchnorm_statistics_epilogue(Ci, Co, N, H, W, accumulate):
         L().dbn_set_wres16(0)
         o = run()
     finally:
-        L().dbn_set_wres16(1)
+        L().dbn_set_wres16(2)
     ref = F.conv2d(nchw(x.double()), w.to(bf).double(), bias.double().cpu(), 1, 1) + (nchw(old.double()) if accumulate else 0)
     mean, var = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False)
     rstd = 1.0 / torch.sqrt(var + 1e-5)
