@@ -11,7 +11,7 @@ adam = [r for r in rows if 'adam_kernel' in r[0]]
 step = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 lo, hi = adam[step - 1][2], adam[step][2]
 ks = [r for r in rows if r[1] >= lo and r[2] <= hi]
-ism = lambda n: ('igemm_f32_kernel' in n) or ('winograd_f32_kernel' in n) or ('convt2x2_f32_kernel' in n) or ('wgrad_f32_kernel' in n) or ('wgrad_tr_kernel' in n) or ('wgrad_patch_kernel' in n)
+ism = lambda n: ('igemm_f32_kernel' in n) or ('winograd_f32_kernel' in n) or ('convt2x2_f32_kernel' in n) or ('wgrad_f32_kernel' in n) or ('wgrad_tr_kernel' in n) or ('wgrad_patch_kernel' in n) or ('conv3x3_wres16_kernel' in n) or ('convt2x2_b16_kernel' in n) or ('stem7x7_' in n) or ('head16_tail_eval_kernel' in n)
 mf = sorted([(r[1], r[2]) for r in ks if ism(r[0])])
 merged = []
 for s, e in mf:
