@@ -568,6 +568,7 @@ def main():
             roofline['traffic_stale'] = False
             alg = d['bytes'] / d['launches'] if d.get('bytes') else None
             if alg:
+                roofline['algorithmic_bytes_per_launch'] = int(alg)
                 roofline['traffic_over_algorithmic'] = round(tr['hbm_bytes_per_launch'] / alg, 3)
             roofline['traffic_unit'] = ('bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC passes of this source tree: '
                                         'profiles/%s_pmc_traffic%s.json, csrc stamp %s)' % (tag, suffix, prof['csrc_stamp']))

@@ -669,7 +669,8 @@ class Engine:
         if self.prof:
             # FLOPs the MFMA pipe EXECUTES: 16 products per 2 x 2 output tile and channel pair (the direct form's 36 are what
             # `step_tflops` counts): the roofline fraction of this kernel is matrix-pipe utilisation, not an effective rate
-            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 0.0, 'fwd ' + name)
+            # (algorithmic bytes: source + destination once — bench.py: roofline.traffic_over_algorithmic)
+            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * conv.cout * conv.cin * 4, 4.0 * N * H * W * (C + conv.cout), 'fwd ' + name)
         if bn is None:
             check(self.L.dbn_winograd_conv_bn_act_f32(x.data_ptr(), asc, ash, up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, C, conv.cout,
                                                       None, None, 0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
@@ -920,7 +921,10 @@ class Engine:
                     fin.c1c2_2, fin.dgamma_2, fin.dbeta_2 = (c1c2b.data_ptr(), G[second[0] + '.weight'].data_ptr(),
                                                              G[second[0] + '.bias'].data_ptr())
         if self.prof:  # (FLOPs the MFMA pipe executes: see _winograd_conv)
-            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * O * Cd * 4, 0.0, 'dgrad ' + name)
+            # algorithmic bytes: dy + dx once, + the operands of the fused BatchNorm-backward sums (y, a separate ReLU mask, a second BatchNorm's
+            # y) and the accumulated-onto dx, once each
+            extra = sum(a[k] is not None for k in ('y', 'zmask', 'y2')) + int(bool(accumulate))
+            self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * O * Cd * 4, 4.0 * N * H * W * (O + Cd * (1 + extra)), 'dgrad ' + name)
         check(L.dbn_winograd_dgrad_bnsums_f32(dy.data_ptr(), up.data_ptr(), dx.data_ptr(), N, H, W, O, Cd, int(accumulate), _p(a['y']),
                                               _p(a['zmask']), _p(a['msc']), _p(a['msh']), _p(a['mean']), _p(a['rstd']), _p(a['part']),
                                               _p(a['y2']), _p(a['mean2']), _p(a['rstd2']), _p(a['part2']),
@@ -2060,7 +2064,7 @@ class Engine:
                 # (wds[0][ci][co][u][v] = W[co][ci][2-u][2-v]: its data-gradient panel is the forward conv of W's first Cg input channels)
                 up = self._winograd_panel(name + '#lv0', wds[0], Cg, dgrad=1, version=wver)
                 if self.prof:
-                    self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * Co * Cg * 4, 0.0, 'fwd %s level 0' % name)
+                    self.prof.begin('winograd_f32_kernel', 2.0 * N * H * W * Co * Cg * 4, 4.0 * N * H * W * (Co + Cg), 'fwd %s level 0' % name)
                 check(self.L.dbn_winograd_conv_bn_f32(zs[0].data_ptr(), up.data_ptr(), _p(conv.bias), y.data_ptr(), N, H, W, Cg, Co, None, None,
                                                       0.0, 0.0, None, None, None, None, None, None, None, self.stream), 'winograd ' + name)
                 if self.prof:
