@@ -81,7 +81,7 @@ def test_reference_init_statistics():
     torch.manual_seed(0)
     m = DBTextModel()
     w = m.backbone.layer2[0].conv1.weight
-    assert abs(float(w.std()) - (2.0 / (9 * 128))**0.5) < 2e-3
+    assert abs(float(w.detach().std()) - (2.0 / (9 * 128))**0.5) < 2e-3
     assert float(m.backbone.bn1.weight.min()) == 1 and float(m.backbone.bn1.bias.abs().max()) == 0
     hw = m.segmentation_head.binarize[0].weight
     assert abs(float(hw.std()) - (2.0 / (256 * 9))**0.5) < 1e-3

@@ -170,7 +170,7 @@ def test_per_pixel_ohem_vs_oracle(n, size, ratio):
     pd = preds.to(DEV).requires_grad_(True)
     got = DBLoss(reduction='none', negative_ratio=ratio)(pd, gts.to(DEV))
     got[4].backward()
-    report('ohem losses', torch.stack([v.detach() for v in got]).cpu().double(), torch.tensor([float(v) for v in ref]).double(), 1e-6, 1e-5)
+    report('ohem losses', torch.stack([v.detach() for v in got]).cpu().double(), torch.tensor([float(v.detach()) for v in ref]).double(), 1e-6, 1e-5)
     report('ohem dpreds', pd.grad.cpu(), pc.grad, 1e-9, 1e-4)
 
 
