@@ -103,6 +103,8 @@ SIGNATURES.update({
     'dbn_wgrad_kernel_config_hw': 'i' * 12,
     'dbn_set_patch_conv': 'i',
     'dbn_set_wres16': 'i',
+    'dbn_set_pyramid_wide': 'i',
+    'dbn_pyramid_wide_would_run': 'iiiiii',
     'dbn_conv_bn_set_final': 'pp',
     'dbn_conv_bn_final_group_doubles': 'ii',
     'dbn_wres16_would_run': 'iiiiiiiii',

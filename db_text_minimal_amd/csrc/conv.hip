@@ -729,6 +729,18 @@ long dbn_igemm_splitk_slab_floats(int ksplit, int N, int Hd, int Wd, int Cd) { r
 int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 
 // ---- pyramid conv (MODE 3): conv3x3 over [s0 | up2(s1) | up4(s2) | up8(s3)] without the concatenation ----
+// the 128 x 256 tile of the 16-bit storage types (igemm_kernel.h launch_wide): 0 off, 1 the pyramid conv (Cd % 256 == 0, large maps), 2 also
+// plain forward / stride-1 data-gradient launches of the generic loop, 3 as 2 whatever the launch's size (tests)
+int dbn_g_wide_tile = getenv("DBN_PYR_WIDE") ? atoi(getenv("DBN_PYR_WIDE")) : 1;  // (A/B runs of whole programs)
+// Does a dbn_pyramid_conv_* call (16-bit storage, at = 1 | 2) with this geometry launch igemm_f32_kernel<128,256,2,2,3,1,at>?  (profiler labels)
+int dbn_pyramid_wide_would_run(int at, int N, int H, int W, int Cs, int Cd) {
+    return (at == 1 || at == 2) && dbn_wide_tile_geom_ok(3, N, H, W, Cs, Cd);
+}
+int dbn_set_pyramid_wide(int on) {  // test / A-B hook; returns the previous setting
+    const int old = dbn_g_wide_tile;
+    dbn_g_wide_tile = on < 0 ? 0 : on > 3 ? 3 : on;
+    return old;
+}
 static int pyramid_chunk(int N, int H, int W, int Cs, int Cd, int at = 0) {
     return chunk_images(N, (long)H * W, (long)H * W * Cs * dbn_esize(at), (long)H * W * Cd);
 }
@@ -785,7 +797,7 @@ static int pyramid_run(int first_level, int at, const void* s0, const void* s1, 
         p.ksplit = 1; p.kt_per = 0; p.patch = 0;
         p.relu = relu ? 1 : 0;
         p.src_bytes = p.seg_bytes[0];
-        const int rc = launch_igemm(p, 1, 3, ns, st, at);
+        const int rc = launch_igemm(p, 1, 3, ns, st, at);  // (16-bit storage, Cd % 256 == 0, large maps: the 128 x 256 tile — launch_wide)
         if (rc) return rc;
         row0 += p.launch_rows;
     }

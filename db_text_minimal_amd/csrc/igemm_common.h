@@ -442,5 +442,19 @@ int dbn_launch_igemm_f32(IgemmParams& p, int cfg, int mode, hipStream_t st);    
 int dbn_launch_igemm_x(IgemmParams& p, int cfg, int mode, int ns, int at, hipStream_t st);      // conv_x3.hip: fp32 tensors, bf16 math
 int dbn_launch_igemm_b16(IgemmParams& p, int cfg, int mode, int at, hipStream_t st);            // conv_b16.hip: bf16 / fp16 storage
 // wres16.hip: the weight-resident 3x3 / stride-1 kernel of the 16-bit storage types (takes the pixel-patch launches it is eligible for)
+
+// The 128 x 256 tile of the 16-bit storage types (igemm_kernel.h launch_wide; dbn_set_pyramid_wide): which launches take it, by geometry.
+// mode 3 = the pyramid conv (tiles of 128 8 x 8 blocks x 64 pixel classes), 0 / 1 = plain forward / stride-1 data gradient of the generic
+// loop.  Enough tiles for eight rounds of the 512 resident workgroups — below that the narrower tile's finer tail wins (bf16 training at
+// 16 x 640^2: 3200 wide tiles, 1774 against 1784 images/s; the 512 -> 512 convs of configs[4] at 40 x 40: 800 wide tiles, 11.15 against
+// 10.94 ms per forward); dbn_g_wide_tile: 0 off, 1 the pyramid form, 2 also the generic launches, 3 as 2 whatever the size (tests).
+extern "C" int dbn_g_wide_tile;
+static inline bool dbn_wide_tile_geom_ok(int mode, long N, int Hdf, int Wdf, int Cs, int Cd) {
+    if (Cd % 256 != 0 || (Cs & 15) != 0) return false;
+    const long min_tiles = dbn_g_wide_tile >= 3 ? 0 : 4096;
+    if (mode == 3) return dbn_g_wide_tile >= 1 && N * (Hdf >> 3) * (Wdf >> 3) / 2 * (Cd / 256) >= min_tiles;
+    if (mode == 0 || mode == 1) return dbn_g_wide_tile >= 2 && N * Hdf * Wdf / 128 * (Cd / 256) >= min_tiles;
+    return false;
+}
 bool dbn_wres16_eligible(int at, int mode, int N, int H, int W, int Cs, int Cd, bool bnb, bool y2, bool stats);
 int dbn_launch_wres16(IgemmParams& p, int mode, int at, hipStream_t st);

@@ -30,7 +30,7 @@ namespace {
 // exact-fp32 64 x 64 tiles without that epilogue: seven waves per SIMD as before round 4 (the buffer-store epilogue's row offsets peak
 // two registers above the 72 that seven waves allow)
 #define DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH, EPI, AT) \
-    __attribute__((amdgpu_waves_per_eu(((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : \
+    __attribute__((amdgpu_waves_per_eu(((MODE) == 3 && (BN) == 256) ? 2 : ((PATCH) && (NS) == 3 && (BN) == 64) ? 2 : ((EPI) == 1 && (NS) == 0 && (BM) * (BN) == 16384) ? 3 : \
                                        ((EPI) == 1 && (AT) == 1 && (PATCH) && (BN) == 64) ? 4 : \
                                        ((EPI) == 0 && (NS) == 0 && (AT) == 0 && (BM) * (BN) == 4096 && (MODE) < 2) ? 7 : 1, 8)))
 
@@ -117,7 +117,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #ifndef DBN_PYR_NSTG
 #define DBN_PYR_NSTG 4  // ring depth of the register-fed pyramid form (A panel only: 8 KB per stage at 128 rows).  6 (48 KB, still three workgroups per CU) measured equal: cfg5 14.55 / 14.50 vs 14.56 / 14.59 ms, bf16 step 1660 / 1671 vs 1665 / 1664 images/s
 #endif
-    constexpr int DMA_NSTG = (DB16 && MODE == 3 && DMA_STAGE * 16 * DBN_PYR_NSTG <= 48 * 1024) ? DBN_PYR_NSTG :
+#ifndef DBN_PYR_NSTG_WIDE
+#define DBN_PYR_NSTG_WIDE 4  // ... and of its 128 x 256 tile (round 6; two workgroups per CU, the ring inside the 64 KB epilogue region)
+#endif
+    constexpr int DMA_NSTG = (DB16 && MODE == 3 && BN == 256 && DMA_STAGE * 16 * DBN_PYR_NSTG_WIDE <= 64 * 1024) ? DBN_PYR_NSTG_WIDE :
+                             (DB16 && MODE == 3 && DMA_STAGE * 16 * DBN_PYR_NSTG <= 48 * 1024) ? DBN_PYR_NSTG :
                              DMA_STAGE * 16 * 4 <= 64 * 1024 ? 4 : DMA_STAGE * 16 * 3 <= 160 * 1024 ? 3 : 2;
     // PATCH: two patch buffers [plane][4 k/8 slices][10 x 18 pixels] + a ring of P_NSTG weight stages of two units
     constexpr int P_PATCH = NSX * 4 * 180;
@@ -2015,9 +2019,39 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
     return dbn_status();
 }
 
+// Round 6: the 16-bit storage types on a 128 x 256 tile — for the pyramid form ONE column tile for the FPN output conv's 256 channels, so
+// a workgroup's gathered A rows (the LDS-DMA ring's bytes) feed twice the MFMAs; 230 registers at two waves per SIMD
+// (DBN_IGEMM_OCC), two workgroups per CU instead of three.  Same row tiles (BM = 128) as configuration 1, so the BatchNorm partial rows and
+// every row count of the host side are unchanged; per output element the same products in the same order: bit-identical results.
+// dbn_g_wide_tile (conv.hip, dbn_set_pyramid_wide): 0 off, 1 the pyramid form, 2 also plain forward / stride-1 data-gradient launches,
+// 3 as 2 whatever the launch's size.
+template <int AT>
+int launch_wide(IgemmParams& p, int mode, hipStream_t st) {
+    static_assert(AT == 1 || AT == 2, "16-bit storage");
+    const int rows = mode == 3 ? 64 * dbn_ceil_div(p.N * (p.Hdf >> 3) * (p.Wdf >> 3), 128) : dbn_ceil_div(p.N * p.Hdf * p.Wdf, 128);
+    const int grid = rows * (p.Cd / 256);
+    if (p.stat_rows <= 0) p.stat_rows = rows;
+    p.launch_rows = rows;
+    if (grid == 0) return DBN_OK;
+    p.stagger_units = p.stagger_blocks = 0;
+    p.phase_prio = dbn_g_phase_prio;
+    p.trace = nullptr;
+    if (mode == 3) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 3, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    else if (mode == 0) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 0, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 1, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    return dbn_status();
+}
+static inline bool wide_tile_ok(const IgemmParams& p, int mode) {  // (the size rule: dbn_wide_tile_geom_ok, igemm_common.h)
+    if (p.bnb_part || p.patch || p.ksplit > 1) return false;
+    return dbn_wide_tile_geom_ok(mode, p.N, p.Hdf, p.Wdf, p.Cs, p.Cd);
+}
+
 // the four tile configurations of one (NS, AT) family
 template <int NS, int AT>
 int launch_igemm_cfg(IgemmParams& p, int cfg, int mode, hipStream_t st) {
+    if constexpr (NS == 1 && (AT == 1 || AT == 2)) {
+        if (cfg == 1 && wide_tile_ok(p, mode)) return launch_wide<AT>(p, mode, st);
+    }
     switch (cfg) {
         case 1: return launch_igemm_ns<128, 128, 2, 2, NS, AT>(p, mode, st);
         case 2: return launch_igemm_ns<256, 64, 4, 1, NS, AT>(p, mode, st);

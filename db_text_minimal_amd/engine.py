@@ -1818,7 +1818,8 @@ class Engine:
                 self.prof.end()
         if self.prof:
             flops = sum(2.0 * N * t.shape[1] * t.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, t in enumerate(zs) if g >= first)
-            self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0,true>' % (self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
+            bn_tile = 256 if self.L.dbn_pyramid_wide_would_run(self.at, N, H, W, Cg, Co) else 128  # (round 6: the 128 x 256 tile on large 16-bit launches)
+            self.prof.begin('igemm_f32_kernel<128,%d,2,2,3,%d,%d,false,0,true>' % (bn_tile, self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
         check(self.L.dbn_pyramid_conv_act_t(first, self.at, *[t.data_ptr() for t in zs], *[w_.data_ptr() for w_ in wpk], vconv.bias.data_ptr(), 1,
                                             z.data_ptr(), N, H, W, Cg, Co, self.ns, self.stream), 'pyramid_conv_act')
         if self.prof:
@@ -2071,7 +2072,8 @@ class Engine:
                     self.prof.end()
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs) if g >= first)
             if self.prof:
-                self.prof.begin('igemm_f32_kernel<128,128,2,2,3,%d,%d,false,0,true>' % (self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                bn_tile = 256 if (not self._use_planes and self.L.dbn_pyramid_wide_would_run(self.at, N, H, W, Cg, Co)) else 128
+                self.prof.begin('igemm_f32_kernel<128,%d,2,2,3,%d,%d,false,0,true>' % (bn_tile, self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co

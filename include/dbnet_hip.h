@@ -469,6 +469,13 @@ int dbn_set_patch_conv(int on);
  * on the pixel-patch kernel, which is faster there; the tests of the ragged last strip use 2).  Returns the previous setting.
  * dbn_igemm_kernel_config reports such a launch with bit 64. */
 int dbn_set_wres16(int on);
+/* The 128 x 256 tile of the 16-bit storage types (Cd % 256 == 0; one column tile for the FPN output conv's 256 channels: half the gathered
+ * activation bytes per output).  0: off (128 x 128); 1 (default): the pyramid conv on launches of >= 4096 such tiles (BASELINE configs[4]:
+ * 25 600); 2: also plain forward / stride-1 data-gradient launches of the generic loop; 3: as 2 whatever the size (tests).  Per output
+ * element the same products in the same order: bit-identical results.  Returns the previous setting (DBN_PYR_WIDE in the environment sets
+ * the initial one). */
+int dbn_set_pyramid_wide(int on);
+int dbn_pyramid_wide_would_run(int at, int N, int H, int W, int Cs, int Cd); /* 1: such a pyramid conv call launches the 128 x 256 tile */
 int dbn_wres16_would_run(int at, int mode, int N, int H, int W, int Cs, int Cd, int bnb, int y2); /* 1: such a call launches that kernel */
 
 /* ---- measurement infrastructure (bench.py: roofline.peak_sustained): what the matrix pipe sustains on this box with non-zero

@@ -1215,10 +1215,19 @@ def test_convolutions_on_16bit_storage(dtype, tile):
     report('split-K conv %s' % dtype, nchw(y.float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
 
 
+@pytest.fixture(params=[0, 3], ids=['tile128x128', 'tile128x256'])
+def pyramid_wide(request):
+    """Both tiles of the 16-bit pyramid conv (round 6: 128 x 256 where Cd % 256 == 0 — dbn_set_pyramid_wide, 3 = whatever the launch's size; other
+    Cd: the 128 x 128 tile either way)."""
+    old = L().dbn_set_pyramid_wide(request.param)
+    yield request.param
+    L().dbn_set_pyramid_wide(old)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(2, 16, 32, 64, 256), (3, 40, 16, 32, 128)])
 @pytest.mark.parametrize('first', [0, 1])
-def test_pyramid_conv_on_16bit_storage_from_level_one(shape, dtype, first):
+def test_pyramid_conv_on_16bit_storage_from_level_one(shape, dtype, first, pyramid_wide):
     """The pyramid conv on bf16 / fp16 storage, whole (first_level = 0) and as levels 1-3 accumulated onto level 0's part, which a mode-1
     3x3 launch on the level-0 panel wrote first (round 5: that launch takes the pixel-patch kernel).  Reference: the concat conv in fp64 on
     the rounded operands (segmentation_body.py:75-76,82-87); first_level = 1 pays one more rounding of the level-0 part to the storage type.
@@ -1268,6 +1277,85 @@ def test_pyramid_conv_on_16bit_storage_from_level_one(shape, dtype, first):
     var_ref = y_ref.var((0, 2, 3), unbiased=False)
     report('pyramid16 batch mean', mu.cpu(), mean_ref, tol_a, tol_r)
     report('pyramid16 batch rstd', rs.cpu(), (var_ref + 1e-5).rsqrt(), 0.0, 4 * eps)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', [(3, 12, 20, 64, 256, 3, 1, 1, 0), (3, 12, 20, 256, 256, 3, 1, 1, 1), (2, 16, 16, 128, 512, 1, 1, 0, 0), (2, 18, 22, 64, 256, 3, 2, 1, 0),
+                                  (8, 50, 50, 512, 512, 3, 1, 1, 0)])
+def test_generic_16bit_convs_on_the_wide_tile_agree_bit_for_bit(case, dtype):
+    """dbn_set_pyramid_wide(3): plain forward / stride-1 data-gradient launches of the generic 16-bit loop on the 128 x 256 tile against the
+    128 x 128 tile (0): equal bits (same products, same order), bias / accumulate included; the long 512 -> 512 case is the counted-wait race
+    screen of test_16bit_generic_loop_on_long_launches at this tile."""
+    N, H, W, Ci, Co, k, st_, pad, mode = case
+    kind = AT_OF[dtype]
+    x = nhwc(rnd(N, Ci, H, W, seed=31)).to(dtype)
+    Hd, Wd = ((H + 2 * pad - k) // st_ + 1, (W + 2 * pad - k) // st_ + 1) if mode == 0 else (H, W)
+    w = rnd(Co, Ci, k, k, seed=32, scale=(1.0 / (Ci * k * k))**0.5) if mode == 0 else rnd(Ci, Co, k, k, seed=32, scale=(1.0 / (Ci * k * k))**0.5)
+    wp = pack_t(w, mode, 1, kind, Ci if mode == 0 else 0)
+    b = rnd(Co, seed=33).to(DEV)
+    base = nhwc(rnd(N, Co, Hd, Wd, seed=34)).to(dtype)
+
+    def run(wide, accumulate):
+        old = L().dbn_set_pyramid_wide(wide)
+        try:
+            y = base.clone() if accumulate else torch.full((N, Hd, Wd, Co), float('nan'), device=DEV, dtype=dtype)
+            igemm_t(x, wp, None if accumulate else b, y, k, st_, pad, mode, accumulate=accumulate)
+            torch.cuda.synchronize()
+            return y
+        finally:
+            L().dbn_set_pyramid_wide(old)
+
+    for accumulate in (0, 1):
+        a, c, c2 = run(0, accumulate), run(3, accumulate), run(3, accumulate)
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(c, c2), 'wide tile: runs differ'
+        assert torch.equal(a, c), 'wide tile differs from the 128 x 128 tile (accumulate=%d)' % accumulate
+    if mode == 0:
+        ref = F.conv2d(nchw(x.double()), w.to(dtype).double(), b.double().cpu(), st_, pad)
+        eps = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-10
+        report('wide tile vs fp64', nchw(run(3, 0).float()), ref, eps * float(ref.abs().max()) * 0.5, eps)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(2, 16, 32, 64, 256), (5, 24, 40, 32, 512)])
+def test_pyramid_conv_tiles_agree_bit_for_bit(shape, dtype):
+    """The 128 x 256 tile of the 16-bit pyramid conv sums the same products in the same order as the 128 x 128 tile: equal outputs, equal
+    train-mode BatchNorm statistics (ragged last row tile: 5 x 3 x 5 = 75 blocks of 8 x 8; two column tiles at Co = 512)."""
+    N, H, W, Cg, Co = shape
+    kind = AT_OF[dtype]
+    xs = [nhwc(rnd(N, Cg, H >> g, W >> g, seed=40 + g)).to(dtype) for g in range(4)]
+    wd_ = rnd(Co, 4 * Cg, 3, 3, seed=9, scale=0.03).to(DEV)
+    wpk = []
+    for g in range(4):
+        k = (1 << g) + 2
+        wdg = torch.empty(Cg, Co, k, k, device=DEV)
+        _lib.check(L().dbn_fpn_combine_weights(wd_.data_ptr(), Co, 4 * Cg, g, Cg, wdg.data_ptr(), stream()), 'combine')
+        wpk.append(pack_t(wdg.cpu(), 1, 1 << g, kind))
+    bias_ = rnd(Co, seed=5).to(DEV)
+    g_, b_ = (rnd(Co, seed=6) * 0.3 + 1).to(DEV), rnd(Co, seed=7).to(DEV)
+
+    def run(wide):
+        old = L().dbn_set_pyramid_wide(wide)
+        try:
+            ya = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+            _lib.check(L().dbn_pyramid_conv_act_t(0, kind, *[t.data_ptr() for t in xs], *[t.data_ptr() for t in wpk], bias_.data_ptr(), 1,
+                                                  ya.data_ptr(), N, H, W, Cg, Co, 1, stream()), 'pyramid_act')
+            rm_, rv_ = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+            sc, sh, mu, rs = (torch.empty(Co, device=DEV) for _ in range(4))
+            ws = torch.empty(L().dbn_pyramid_conv_ws_floats(N, H, W, Co), device=DEV)
+            yt = torch.full((N, H, W, Co), float('nan'), device=DEV, dtype=dtype)
+            _lib.check(L().dbn_pyramid_conv_from_t(0, kind, *[t.data_ptr() for t in xs], *[t.data_ptr() for t in wpk], bias_.data_ptr(), yt.data_ptr(),
+                                                   N, H, W, Cg, Co, 0, 1, g_.data_ptr(), b_.data_ptr(), 1e-5, 0.1, rm_.data_ptr(), rv_.data_ptr(),
+                                                   sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), stream()), 'pyramid_from')
+            torch.cuda.synchronize()
+            return dict(act=ya, train=yt, scale=sc, shift=sh, mean=mu, rstd=rs, run_mean=rm_, run_var=rv_)
+        finally:
+            L().dbn_set_pyramid_wide(old)
+
+    a, b = run(0), run(3)
+    assert torch.isfinite(a['act'].float()).all() and torch.isfinite(a['train'].float()).all()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
