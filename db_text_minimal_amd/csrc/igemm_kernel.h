@@ -2025,8 +2025,13 @@ int launch_igemm_ns(IgemmParams& p, int mode, hipStream_t st) {
 // every row count of the host side are unchanged; per output element the same products in the same order: bit-identical results.
 // dbn_g_wide_tile (conv.hip, dbn_set_pyramid_wide): 0 off, 1 the pyramid form, 2 also plain forward / stride-1 data-gradient launches,
 // 3 as 2 whatever the launch's size.
+#ifndef DBN_WIDE_WM
+#define DBN_WIDE_WM 1  // wave layout of the wide tile: 1 x 4 waves of 128 x 64 — no two waves load the same weight fragments (the register-fed B side is
+                       // 28 GB per configs[4] launch with 2 x 2 waves of 64 x 128, half of it with 1 x 4): configs[4] 10.95 -> 10.74 ms per forward
+#endif
 template <int AT>
 int launch_wide(IgemmParams& p, int mode, hipStream_t st) {
+    constexpr int WM_ = DBN_WIDE_WM, WN_ = 4 / DBN_WIDE_WM;
     static_assert(AT == 1 || AT == 2, "16-bit storage");
     const int rows = mode == 3 ? 64 * dbn_ceil_div(p.N * (p.Hdf >> 3) * (p.Wdf >> 3), 128) : dbn_ceil_div(p.N * p.Hdf * p.Wdf, 128);
     const int grid = rows * (p.Cd / 256);
@@ -2036,9 +2041,9 @@ int launch_wide(IgemmParams& p, int mode, hipStream_t st) {
     p.stagger_units = p.stagger_blocks = 0;
     p.phase_prio = dbn_g_phase_prio;
     p.trace = nullptr;
-    if (mode == 3) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 3, 1, AT>), dim3(grid), dim3(256), 0, st, p);
-    else if (mode == 0) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 0, 1, AT>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_f32_kernel<128, 256, 2, 2, 1, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    if (mode == 3) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, WM_, WN_, 3, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    else if (mode == 0) hipLaunchKernelGGL((igemm_f32_kernel<128, 256, WM_, WN_, 0, 1, AT>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<128, 256, WM_, WN_, 1, 1, AT>), dim3(grid), dim3(256), 0, st, p);
     return dbn_status();
 }
 static inline bool wide_tile_ok(const IgemmParams& p, int mode) {  // (the size rule: dbn_wide_tile_geom_ok, igemm_common.h)
@@ -2046,6 +2051,10 @@ static inline bool wide_tile_ok(const IgemmParams& p, int mode) {  // (the size 
     return dbn_wide_tile_geom_ok(mode, p.N, p.Hdf, p.Wdf, p.Cs, p.Cd);
 }
 
+#ifndef DBN_CFG1_WM
+#define DBN_CFG1_WM 1  // the 128 x 128 tile of the 16-bit storage types as 1 x 4 waves of 128 x 32: no two waves load the same weight fragments from L2 (the
+                       // register-fed B side of the generic loop; 2 = the 2 x 2 layout of rounds 3-5).  configs[4] 10.77 -> 10.64 ms, bf16 step 1753 / 1765 -> 1768
+#endif
 // the four tile configurations of one (NS, AT) family
 template <int NS, int AT>
 int launch_igemm_cfg(IgemmParams& p, int cfg, int mode, hipStream_t st) {
@@ -2053,7 +2062,9 @@ int launch_igemm_cfg(IgemmParams& p, int cfg, int mode, hipStream_t st) {
         if (cfg == 1 && wide_tile_ok(p, mode)) return launch_wide<AT>(p, mode, st);
     }
     switch (cfg) {
-        case 1: return launch_igemm_ns<128, 128, 2, 2, NS, AT>(p, mode, st);
+        case 1:
+            if constexpr (NS == 1 && (AT == 1 || AT == 2) && DBN_CFG1_WM == 1) return launch_igemm_ns<128, 128, 1, 4, NS, AT>(p, mode, st);
+            else return launch_igemm_ns<128, 128, 2, 2, NS, AT>(p, mode, st);
         case 2: return launch_igemm_ns<256, 64, 4, 1, NS, AT>(p, mode, st);
         case 3: return launch_igemm_ns<128, 64, 2, 2, NS, AT>(p, mode, st);
         default: return launch_igemm_ns<64, 64, 2, 2, NS, AT>(p, mode, st);

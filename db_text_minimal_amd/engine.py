@@ -878,7 +878,10 @@ class Engine:
             # round 6: the weight-resident kernel (csrc/wres16.hip) — <at, Cs, Cd, mode>; the epilogue flavour is not part of the label
             self.prof.begin('conv3x3_wres16_kernel<%d,%d,%d,%d>' % (at, geom[3], Cd, mode), flops, nbytes, tag)
             return
-        self.prof.begin(IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk), flops, nbytes, tag)
+        label = IGEMM_TILE_NAMES[cfg & 15] % (mode, self.ns, at, 'true' if cfg & 16 else 'false', epi, blk)
+        if (cfg & 15) == 1 and at in (1, 2) and self.ns == 1:  # round 6: the 128 x 128 tile of the 16-bit storage types runs as 1 x 4 waves (csrc/igemm_kernel.h DBN_CFG1_WM)
+            label = label.replace('<128,128,2,2,', '<128,128,1,4,')
+        self.prof.begin(label, flops, nbytes, tag)
 
     def _winograd_dgrad(self, name, dy, conv, dx, accumulate, consumer, panel=None):
         """The data gradient of a 3x3 / stride-1 / pad-1 conv through the Winograd kernel (the rotated / transposed filters), with the
@@ -1819,7 +1822,8 @@ class Engine:
         if self.prof:
             flops = sum(2.0 * N * t.shape[1] * t.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, t in enumerate(zs) if g >= first)
             bn_tile = 256 if self.L.dbn_pyramid_wide_would_run(self.at, N, H, W, Cg, Co) else 128  # (round 6: the 128 x 256 tile on large 16-bit launches)
-            self.prof.begin('igemm_f32_kernel<128,%d,2,2,3,%d,%d,false,0,true>' % (bn_tile, self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
+            waves = '1,4' if (self.at in (1, 2) and self.ns == 1) else '2,2'  # (16-bit storage: 1 x 4 waves, see _prof_igemm)
+            self.prof.begin('igemm_f32_kernel<128,%d,%s,3,%d,%d,false,0,true>' % (bn_tile, waves, self.ns, self.at), flops, 0.0, 'fwd %s (pyramid)' % name)
         check(self.L.dbn_pyramid_conv_act_t(first, self.at, *[t.data_ptr() for t in zs], *[w_.data_ptr() for w_ in wpk], vconv.bias.data_ptr(), 1,
                                             z.data_ptr(), N, H, W, Cg, Co, self.ns, self.stream), 'pyramid_conv_act')
         if self.prof:
@@ -2073,7 +2077,8 @@ class Engine:
             flops = sum(2.0 * N * z.shape[1] * z.shape[2] * Cg * Co * ((1 << g) + 2)**2 for g, z in enumerate(zs) if g >= first)
             if self.prof:
                 bn_tile = 256 if (not self._use_planes and self.L.dbn_pyramid_wide_would_run(self.at, N, H, W, Cg, Co)) else 128
-                self.prof.begin('igemm_f32_kernel<128,%d,2,2,3,%d,%d,false,0,true>' % (bn_tile, self.ns, 3 if self._use_planes else self.at), flops, 0.0,
+                waves = '1,4' if (not self._use_planes and self.at in (1, 2) and self.ns == 1) else '2,2'
+                self.prof.begin('igemm_f32_kernel<128,%d,%s,3,%d,%d,false,0,true>' % (bn_tile, waves, self.ns, 3 if self._use_planes else self.at), flops, 0.0,
                                 'fwd %s (pyramid)' % name)
             if fused:
                 C = Co
