@@ -707,7 +707,10 @@ int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns) {
     const int KT = (K + 15) / 16;
     static const int max_tiles = dbn_env_int("DBN_SPLITK_MAX_TILES", 256);
     if (tiles > max_tiles) return 1;
-    long sk = 1024 / tiles;      // about four workgroups per CU
+#ifndef DBN_SPLITK_TARGET16
+#define DBN_SPLITK_TARGET16 256  // round 6: the 16-bit loop's stages are latency-bound (~1 us each whatever their size), so more splits per CU only add stages and slab
+#endif                           // traffic: pyramid level 2 / 3 data gradients 172 / 163 us at 5 / 10 splits, 143 / 142 us at 1 / 2 (tools/trace_probe_levels.py); bf16 step 1798 -> 1811
+    long sk = (ns == 1 ? DBN_SPLITK_TARGET16 : 1024) / tiles;      // exact fp32: about four workgroups per CU; one 16-bit plane: about one
     if (sk > KT / 32) sk = KT / 32;  // at least 32 k-tiles per split
     if (sk > 64) sk = 64;
     return sk < 2 ? 1 : (int)sk;
