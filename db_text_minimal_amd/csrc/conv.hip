@@ -710,7 +710,10 @@ int dbn_igemm_splitk_plan_ns(int M, int Cd, int K, int Cs, int ns) {
 #ifndef DBN_SPLITK_TARGET16
 #define DBN_SPLITK_TARGET16 256  // round 6: the 16-bit loop's stages are latency-bound (~1 us each whatever their size), so more splits per CU only add stages and slab
 #endif                           // traffic: pyramid level 2 / 3 data gradients 172 / 163 us at 5 / 10 splits, 143 / 142 us at 1 / 2 (tools/trace_probe_levels.py); bf16 step 1798 -> 1811
-    long sk = (ns == 1 ? DBN_SPLITK_TARGET16 : 1024) / tiles;      // exact fp32: about four workgroups per CU; one 16-bit plane: about one
+#ifndef DBN_SPLITK_TARGET32
+#define DBN_SPLITK_TARGET32 1024  // (512 / 2048 measured equal on the fp32 step: 731.6 / 734.0 and 732.6 / 730.4 against 731.8 / 732.7 images/s)
+#endif
+    long sk = (ns == 1 ? DBN_SPLITK_TARGET16 : DBN_SPLITK_TARGET32) / tiles;      // exact fp32: about four workgroups per CU; one 16-bit plane: about one
     if (sk > KT / 32) sk = KT / 32;  // at least 32 k-tiles per split
     if (sk > 64) sk = 64;
     return sk < 2 ? 1 : (int)sk;
