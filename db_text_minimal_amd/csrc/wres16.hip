@@ -46,7 +46,13 @@ struct WresGeom {
     static constexpr int SPP = CS / 8, PIX = SPP + 1, ROWPX = 34;  // 16-byte slots per pixel (+ 1 pad), pixels per input row
     static constexpr int ROW_SLOTS = ROWPX * PIX, ROW_DMA = (ROW_SLOTS + 63) / 64, ROW_PITCH = ROW_DMA * 64;
     static constexpr int DMA_PW = (ROW_DMA + NW - 1) / NW;  // DMA instructions per wave and row (the last round of a row may be short)
-    static constexpr int D = CS == 128 ? 8 : CS == 256 ? 5 : 6, PF = D - 3;  // ring depth; rows in flight ahead of the three a step reads
+#ifndef DBN_WRES_D64
+#define DBN_WRES_D64 6
+#endif
+#ifndef DBN_WRES_D128
+#define DBN_WRES_D128 8
+#endif
+    static constexpr int D = CS == 128 ? DBN_WRES_D128 : CS == 256 ? 5 : DBN_WRES_D64, PF = D - 3;  // ring depth; rows in flight ahead of the three a step reads
     static constexpr int GPW = 4 / KS;                       // accumulator register groups (4 channels x 32 pixels) a wave finishes
     static constexpr int RED = KS > 1 ? 2 * OC * 4 * (KS - 1) * 64 : 0;  // K-split exchange: two buffers of every wave's NON-own register groups
     static constexpr int NCONST = 6, CONST_SLOTS = NCONST * 8;  // per wave: bias, pivot, mean, mask scale, mask shift, mean2 (32 floats each)
