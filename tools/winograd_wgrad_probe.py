@@ -10,14 +10,25 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 
 
 def timed(fn):
+    """ms per launch, back to back with settled clocks (round 6: a launch timed alone after a synchronize, 5 warm-up launches before, read
+    10-25 % slow — the clocks ramp for tens of milliseconds; tools/wres_probe.py)."""
+    e0.record()
     for _ in range(5):
         fn()
+    e1.record()
+    torch.cuda.synchronize()
+    for _ in range(max(20, int(60.0 / max(e0.elapsed_time(e1) / 5, 1e-3)))):  # >= 60 ms of launches
+        fn()
     ts = []
-    for _ in range(15):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+    for _ in range(5):
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 10)
     ts.sort()
-    return ts[5]
+    return ts[2]
 
 
 for (N, H, Ci, Co, what) in ((16, 160, 64, 64, 'layer1 / smooth_p2'), (16, 160, 256, 64, 'head 256->64'), (16, 80, 128, 128, 'layer2'),
