@@ -738,6 +738,7 @@ int dbn_igemm_packed_floats(int K, int Cd) { return ((K + 15) / 16) * 16 * Cd; }
 // the 128 x 256 tile of the 16-bit storage types (igemm_kernel.h launch_wide): 0 off, 1 the pyramid conv (Cd % 256 == 0, large maps), 2 also
 // plain forward / stride-1 data-gradient launches of the generic loop, 3 as 2 whatever the launch's size (tests)
 int dbn_g_wide_tile = getenv("DBN_PYR_WIDE") ? atoi(getenv("DBN_PYR_WIDE")) : 1;  // (A/B runs of whole programs)
+int dbn_g_pyr_group = getenv("DBN_PYR_GROUP") ? atoi(getenv("DBN_PYR_GROUP")) : 0;  // tile order of the wide pyramid tile (igemm_kernel.h launch_wide)
 // Does a dbn_pyramid_conv_* call (16-bit storage, at = 1 | 2) with this geometry launch igemm_f32_kernel<128,256,2,2,3,1,at>?  (profiler labels)
 int dbn_pyramid_wide_would_run(int at, int N, int H, int W, int Cs, int Cd) {
     return (at == 1 || at == 2) && dbn_wide_tile_geom_ok(3, N, H, W, Cs, Cd);

@@ -146,6 +146,7 @@ struct IgemmParams {
     unsigned seg_bytes[4];
     unsigned seg_plane_bytes[4];  // AT = 3
     int first_level;  // MODE 3, exact-fp32 loop only: levels [first_level, 4) (the finer ones are in dst already: accumulate = 1)
+    int pyr_group;    // MODE 3 tile order: 0 = row tile major, the 64 pixel classes minor; G > 0 = blocks of G row tiles x 8 classes of one class row (launch_wide)
 };
 
 // permille of the nominal first-round stagger (0 = off): dbn_set_stagger
@@ -449,6 +450,7 @@ int dbn_launch_igemm_b16(IgemmParams& p, int cfg, int mode, int at, hipStream_t 
 // 16 x 640^2: 3200 wide tiles, 1774 against 1784 images/s; the 512 -> 512 convs of configs[4] at 40 x 40: 800 wide tiles, 11.15 against
 // 10.94 ms per forward); dbn_g_wide_tile: 0 off, 1 the pyramid form, 2 also the generic launches, 3 as 2 whatever the size (tests).
 extern "C" int dbn_g_wide_tile;
+extern "C" int dbn_g_pyr_group;  // conv.hip: row tiles per block of the wide pyramid tile's order (0 = class-minor order of rounds 3-5; DBN_PYR_GROUP)
 static inline bool dbn_wide_tile_geom_ok(int mode, long N, int Hdf, int Wdf, int Cs, int Cd) {
     if (Cd % 256 != 0 || (Cs & 15) != 0) return false;
     const long min_tiles = dbn_g_wide_tile >= 3 ? 0 : 4096;

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
     static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for the workgroup");
     // 16-bit storage (AT != 0): LDS-DMA ring (see the main loop): stages of DMA_SU units, unpadded images [plane][k/8][row]
     constexpr int DMA_SU = 2;
+#ifndef DBN_DBG16
+#define DBN_DBG16 0  // profile by deletion of the 16-bit ring loop (tools/flavour.sh <name> conv_b16.hip "-DDBN_DBG16=<bits>"; timing only, wrong results): 1 no per-instruction address arithmetic, 2 no weight-fragment loads, 4 no LDS fragment reads, 8 no A DMA
+#endif
 #ifndef DBN_DIRECTB16
 #define DBN_DIRECTB16 1
 #endif
@@ -191,8 +194,23 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         // tile order: m-tile major, pixel class minor — the 64 classes of one image region run together, so their
         // overlapping 3x3 neighbourhoods of the finest level are served by the L2 instead of 9 trips to HBM
         const int mtiles = (q.M + BM - 1) / BM, ntn_ = p.Cd / BN;
-        const int mt_ = tile / (64 * ntn_), rem_ = tile - mt_ * (64 * ntn_);
-        const int c = rem_ / ntn_;
+        int mt_ = tile / (64 * ntn_), rem_ = tile - mt_ * (64 * ntn_);
+        int c = rem_ / ntn_;
+        if (p.pyr_group > 0) {
+            // round 6 (the wide tile): G row tiles x the 8 classes of ONE class row run together — the workgroups resident on an XCD then
+            // share a few classes' weight panels (the level 1-3 panels are class-specific: 250 KB each, 16 MB for the 64 classes against
+            // 4 MB of L2; profile by deletion: the weight-fragment loads are a third of the launch) and still share the activation rows of
+            // the three horizontal taps.  Order inside a block of G x 64 x ntn tiles: class row, row tile, class column, column tile
+            const int G = p.pyr_group, per = G * 64 * ntn_;
+            const int blk = tile / per, t = tile - blk * per;
+            const int cr = t / (G * 8 * ntn_), t2 = t - cr * (G * 8 * ntn_);
+            const int g = t2 / (8 * ntn_), t3 = t2 - g * (8 * ntn_);
+            const int cc = t3 / ntn_;
+            mt_ = blk * G + g;
+            c = cr * 8 + cc;
+            rem_ = c * ntn_ + (t3 - cc * ntn_);
+            if (mt_ >= mtiles) return;  // (the last block is padded to G row tiles)
+        }
         tile = mt_ * ntn_ + (rem_ - c * ntn_);
         q.oh0 = c >> 3; q.ow0 = c & 7;
         q_row_base = c * mtiles;
@@ -1002,6 +1020,11 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
             const int tcb = fixed ? ucb[uc] : (uw ? ucb[DMA_SU - 1] : ucb[0]), tkt = fixed ? ukt[uc] : (uw ? ukt[DMA_SU - 1] : ukt[0]);
             auto* dst = (__attribute__((address_space(3))) void*)(smem + slot * DMA_STAGE + u * DMA_UNIT + i_lds[i]);
             if (isA) {
+                if constexpr ((DBN_DBG16 & 1) != 0) {  // profile by deletion (timing only): no tap / bounds / offset arithmetic per DMA instruction
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (int)(i_add[i] + (unsigned)r_nb[i] * 2u + (unsigned)u * 4096u), 0, 0, 0);
+                    continue;
+                }
+                if constexpr ((DBN_DBG16 & 8) != 0) continue;  // no A DMA at all
                 const int hs = MODE == 0 ? r_hb[i] + tr : r_hb[i] - tr;
                 const int ws = MODE == 0 ? r_wb[i] + ts : r_wb[i] - ts;
                 const bool v = v_u && (unsigned)hs < (unsigned)gHs && (unsigned)ws < (unsigned)gWs;
@@ -1022,7 +1045,7 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         for (int t = 0; t < NSX; ++t)
 #pragma unroll
             for (int b = 0; b < NI; ++b) bvo[t][b] = (unsigned)((t * 2 + lh) * p.Cd + n0 + wn * TN + b * 32 + li) * 16u;
-        f32x4 rbB[2][DMA_SU][NSX][NI];
+        f32x4 rbB[3][DMA_SU][NSX][NI];  // round 6: THREE sets — a stage's weight fragments are fetched two stages ahead (see the loop below)
         int bkt = kt_begin;  // weight k-tile of the next unit to fetch (clamped: units past the end multiply zeros of A)
         int bkt_max = max(kt_end - 1, kt_begin);
         // MODE 3: the weight side walks the pyramid levels on its own (it runs DMA_NSTG - 2 stages behind the A side's level_dma): level g's
@@ -1056,6 +1079,10 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                     for (int b = 0; b < NI; ++b) {
                         typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+                        if constexpr ((DBN_DBG16 & 2) != 0) {  // (deletion: no weight-fragment loads)
+                            rbB[st__][u][t][b] = f32x4{1.f, 2.f, 3.f, (float)so};
+                            continue;
+                        }
                         const u32x4_ v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bvo[t][b], (int)so, 0);
                         rbB[st__][u][t][b] = __builtin_bit_cast(f32x4, v_);
                     }
@@ -1063,26 +1090,33 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        // prologue: the first DMA_NSTG - 1 stages of A, then the first B set (no dummy register loads: the compiler deletes loads
-        // whose results are overwritten, and the counted waits below must match what is really in flight)
+        using S2 = std::integral_constant<int, 2>;
+        // prologue: the first DMA_NSTG - 1 stages of A, then the first TWO B sets (no dummy register loads: the compiler deletes loads
+        // whose results are overwritten, and the counted waits below must match what is really in flight).
+        // Round 6: the weight fragments of stage s are fetched at stage s - 2 (three register sets, the loop unrolled by three).  Profile
+        // by deletion (-DDBN_DBG16=2, configs[4]): without the fragment loads the pyramid launch is a third shorter — fetched ONE stage
+        // ahead (rounds 3-5) a set had one stage time, about a microsecond, to come back from L2, and every stage ended up waiting for it.
 #pragma unroll
         for (int s_ = 0; s_ < DMA_NSTG - 1; ++s_) issue_stage(s_);
         asm volatile("" ::: "memory");
         issue_bs(S0{});
+        issue_bs(S1{});
         asm volatile("" ::: "memory");
         int slot = 0;
-        // EARLY = min(stage index, DMA_NSTG - 2): younger than stage st_'s DMA are the (DMA_NSTG - 2) later A stages and the B sets
-        // issued since — one after the prologue, one more per iteration until the steady state of DMA_NSTG - 1
-        auto body = [&](auto PARITY, auto EARLY) {
-            constexpr int par = decltype(PARITY)::value, early = decltype(EARLY)::value;
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((DMA_NSTG - 2) * PW + NB * (1 + early)) : "memory");
+        // Issue order: A0 A1 A2 B0 B1 | stage 0: B2 A3 | stage 1: B3 A4 | ...  — the register loads of an iteration go out BEFORE its DMA
+        // instructions: vmcnt retires in order, so a B set fetched behind a stage of A made the stage that consumes the set wait for that
+        // (much younger) A stage as well — the ring's depth was one stage in effect.  Younger than stage s's A DMA (and so allowed to be
+        // outstanding when the stage starts) in the steady state: B_s, A_{s+1}, B_{s+1}, A_{s+2} = DMA_NSTG - 2 A stages and two B sets;
+        // the first stages have more behind them (the prologue's order), for which the same count is merely stricter than needed.
+        auto body = [&](auto SET, auto EARLY) {
+            constexpr int set = decltype(SET)::value;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(((DBN_DBG16 & 8) ? 0 : (DMA_NSTG - 2) * PW) + ((DBN_DBG16 & 2) ? 0 : NB * 2)) : "memory");
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_bs(std::integral_constant<int, (set + 2) % 3>{});
             asm volatile("" ::: "memory");
             const int fill = slot == 0 ? DMA_NSTG - 1 : slot - 1;
             issue_stage(fill);
-            // the counted wait assumes the register loads are YOUNGER than this iteration's DMA instructions (vmcnt retires in order)
-            asm volatile("" ::: "memory");
-            issue_bs(std::integral_constant<int, par ^ 1>{});
             asm volatile("" ::: "memory");
             const f32x4* Sg = smem + slot * DMA_STAGE;
 #pragma unroll
@@ -1092,37 +1126,29 @@ __global__ __launch_bounds__(WM* WN * 64) DBN_IGEMM_OCC(BM, BN, NS, MODE, PATCH,
 #pragma unroll
                 for (int t = 0; t < NSX; ++t) {
 #pragma unroll
-                    for (int a = 0; a < MI; ++a) af[t][a] = __builtin_bit_cast(bf16x8, As[(t * BM + wm * TM + a * 32 + li) * 2 + lh]);
+                    for (int a = 0; a < MI; ++a)
+                        af[t][a] = (DBN_DBG16 & 4) ? __builtin_bit_cast(bf16x8, rbB[set][u][t][a % NI]) : __builtin_bit_cast(bf16x8, As[(t * BM + wm * TM + a * 32 + li) * 2 + lh]);
 #pragma unroll
-                    for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, rbB[par][u][t][b]);
+                    for (int b = 0; b < NI; ++b) bf[t][b] = __builtin_bit_cast(bf16x8, rbB[set][u][t][b]);
                 }
                 mfma_split<NSX, MI, NI, AT == 2>(af, bf, acc);
             }
             slot = slot + 1 == DMA_NSTG ? 0 : slot + 1;
         };
-        static_assert(DMA_NSTG == 4 || DMA_NSTG == 6, "the peeled iterations below spell the early counts out");
+        static_assert(DMA_NSTG == 4, "the A-only ring of the register-fed form has four stages (six measured equal in round 5 and on the wide tile)");
         using E0 = std::integral_constant<int, 0>;
         using E1 = std::integral_constant<int, 1>;
-        using E2 = std::integral_constant<int, 2>;
         int st_ = 0;
         if (nstages > 0) body(S0{}, E0{});
         if (nstages > 1) body(S1{}, E1{});
-        if constexpr (DMA_NSTG == 6) {  // (two more stages of the ramp: early = 2, 3; steady state early = DMA_NSTG - 2 = 4)
-            using E3 = std::integral_constant<int, 3>;
-            using E4 = std::integral_constant<int, 4>;
-            if (nstages > 2) body(S0{}, E2{});
-            if (nstages > 3) body(S1{}, E3{});
-            for (st_ = 4; st_ + 2 <= nstages; st_ += 2) {
-                body(S0{}, E4{});
-                body(S1{}, E4{});
-            }
-            if (st_ < nstages && nstages > 4) body(S0{}, E4{});
-        } else {
-            for (st_ = 2; st_ + 2 <= nstages; st_ += 2) {
-                body(S0{}, E2{});
-                body(S1{}, E2{});
-            }
-            if (st_ < nstages) body(S0{}, E2{});
+        for (st_ = 2; st_ + 3 <= nstages; st_ += 3) {
+            body(S2{}, E1{});
+            body(S0{}, E1{});
+            body(S1{}, E1{});
+        }
+        if (st_ < nstages) {
+            body(S2{}, E1{});
+            if (st_ + 1 < nstages) body(S0{}, E1{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -2034,7 +2060,12 @@ int launch_wide(IgemmParams& p, int mode, hipStream_t st) {
     constexpr int WM_ = DBN_WIDE_WM, WN_ = 4 / DBN_WIDE_WM;
     static_assert(AT == 1 || AT == 2, "16-bit storage");
     const int rows = mode == 3 ? 64 * dbn_ceil_div(p.N * (p.Hdf >> 3) * (p.Wdf >> 3), 128) : dbn_ceil_div(p.N * p.Hdf * p.Wdf, 128);
-    const int grid = rows * (p.Cd / 256);
+    int grid = rows * (p.Cd / 256);
+    p.pyr_group = 0;
+    if (mode == 3 && dbn_g_pyr_group > 0) {  // (tile order of the pyramid form: see the kernel; the last block of row tiles is padded)
+        p.pyr_group = dbn_g_pyr_group;
+        grid = dbn_ceil_div(rows / 64, p.pyr_group) * p.pyr_group * 64 * (p.Cd / 256);
+    }
     if (p.stat_rows <= 0) p.stat_rows = rows;
     p.launch_rows = rows;
     if (grid == 0) return DBN_OK;
