@@ -25,9 +25,10 @@ for g in (1, 2, 3):
     _lib.check(L().dbn_pack_weights_t(at, w.data_ptr(), Cg, Co, k, k, 0, f, 0, wp.data_ptr(), st), 'pack')
     d = torch.empty(N, Hg, Hg, Cg, device=DEV, dtype=dt)
     plan = L().dbn_igemm_splitk_plan_ns(N * Hg * Hg, Cg, k * k * Co, Co, 1)
+    tile = int(os.environ.get('DBN_PROBE_TILE', '0'))  # tile hint of the launch (0 = the library's choice, 1 128x128, 2 256x64, 3 128x64, 4 64x64)
     for ks in ([int(a) for a in sys.argv[1:]] or [plan]):
         slab = torch.empty(L().dbn_igemm_splitk_slab_floats(ks, N, Hg, Hg, Cg), device=DEV) if ks > 1 else None
-        call = lambda: _lib.check(L().dbn_igemm_t(at, 1, dy.data_ptr(), wp.data_ptr(), None, d.data_ptr(), N, H, H, Co, Hg, Hg, Cg, k, k, f, 1, 0, 0, 0, ks,
+        call = lambda: _lib.check(L().dbn_igemm_t(at, 1, dy.data_ptr(), wp.data_ptr(), None, d.data_ptr(), N, H, H, Co, Hg, Hg, Cg, k, k, f, 1, 0, 0, tile, ks,
                                                  slab.data_ptr() if slab is not None else None, st), 'igemm_t')
         for _ in range(3):
             call()
@@ -40,7 +41,7 @@ for g in (1, 2, 3):
         torch.cuda.synchronize()
         us_ = e0.elapsed_time(e1) * 100
         flops = 2.0 * N * Hg * Hg * Cg * Co * k * k
-        cfg = L().dbn_igemm_kernel_config(at, 1, 0, N, H, H, Co, Hg, Hg, Cg, k, k, f, 1, 0, ks)
+        cfg = L().dbn_igemm_kernel_config(at, 1, 0, N, H, H, Co, Hg, Hg, Cg, k, k, f, 1, tile, ks)
         print('level %d (k %d, stride %d, M %d, K %d): planner ksplit %d, run with %d, tile cfg %d: %.1f us, %.0f TFLOP/s' %
               (g, k, f, N * Hg * Hg, k * k * Co, plan, ks, cfg & 15, us_, flops / us_ / 1e6))
         if traced:
